@@ -1,0 +1,57 @@
+"""
+TEST INFRASTRUCTURE.  Deterministic, closed-form weight / input fills shared by the golden generator
+(applied to the real reference's modules), the oracle tests and the GPU parity tests (applied to the product
+modules), so that large configurations need no weight files: every value is a function of its flat index
+and of the tensor's position in ``state_dict`` order.
+"""
+import math
+
+import torch
+
+
+def fill_tensor(t: torch.Tensor, j: int, amp: float, offset: float = 0.0) -> None:
+    i = torch.arange(t.numel(), dtype=torch.float64)
+    v = offset + amp * torch.sin(0.37 * i + 1.0 + 0.61 * j)
+    with torch.no_grad():
+        t.copy_(v.reshape(t.shape).to(t.dtype))
+
+
+def fill_state_dict(sd) -> None:
+    """In-place fill of a CNN ``state_dict`` (or a plain dict of tensors with the same keys)."""
+    for j, (k, t) in enumerate(sd.items()):
+        if k.endswith("num_batches_tracked") or k.endswith("running_mean") or k.endswith("running_var"):
+            continue
+        if k.endswith("_normalization.weight"):
+            fill_tensor(t, j, 0.2, 1.0)
+        elif k.endswith("_normalization.bias"):
+            fill_tensor(t, j, 0.1)
+        elif k.endswith("bias"):
+            fill_tensor(t, j, 0.05)
+        elif k.endswith("weight"):
+            fan_in = t[0].numel()
+            fill_tensor(t, j, 1.7 / math.sqrt(fan_in))
+        else:
+            raise KeyError(k)
+
+
+def det_input(shape, phase: float = 0.0, amp: float = 1.0, dtype=torch.float32) -> torch.Tensor:
+    n = 1
+    for s in shape:
+        n *= s
+    i = torch.arange(n, dtype=torch.float64)
+    return (amp * torch.sin(0.11 * i + phase) + 0.3 * amp * torch.cos(0.0137 * i * i + phase)).reshape(shape).to(dtype)
+
+
+def mnist_like(batch: int, seed: int = 42) -> torch.Tensor:
+    """MNIST-like synthetic batch [B,1,32,32]: ~19% ink, normalised, zero border of 2."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(batch, 1, 28, 28, generator=g)
+    m = torch.rand(batch, 1, 28, 28, generator=g)
+    x = torch.where(m < 0.81, torch.zeros_like(u), u)
+    x = (x - 0.1307) / 0.3081
+    return torch.nn.functional.pad(x, (2, 2, 2, 2))
+
+
+def normal(shape, seed: int, dtype=torch.float32) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=dtype)

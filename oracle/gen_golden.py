@@ -1,0 +1,365 @@
+"""
+TEST INFRASTRUCTURE -- golden-vector generator.  Runs ONLY in the build container (needs /root/reference).
+
+Imports the *real* reference through ``oracle/ref_import.py``, drives its hot-path classes/functions with
+deterministic closed-form inputs and weights (``oracle/detfill.py``) and records inputs + outputs as small
+``.npz`` fixtures under ``tests/golden/``.  Only numbers are written; no reference source or bytecode.
+
+    python oracle/gen_golden.py            # regenerates every fixture
+
+Fixtures:
+  convlayer.npz      ConvLayer fwd/bwd per distinct layer geometry, B=4, incl. BN running stats
+  attention.npz      QKVAttention fwd/bwd for every (T,H,C) of the MNIST and CIFAR configs, B=2
+  cnn_small.npz      CNN encoder+decoder (capacity 2) fwd + all parameter grads, residual add/None/cat
+  nelbo_mnist.npz    VAE.nelbo on the MNIST test config (B=6): losses, preds/latents slices, per-parameter
+                     grad checksums, parameter checksums after one Adam step
+  prior.npz          GaussianPrior.forward (z, loss) incl. cosine annealing
+  sinkhorn.npz       sinkhorn_log for several N, reg, thresholds, dtypes, incl. batched early exit
+  gaussian_ot.npz    GaussianModel.update/fit, mean_cov, w2_gaussian, compute_transport_operators,
+                     apply_transport, GaussianTransport.compute/transport
+  codebook.npz       CodebookModel.predict argmax indices + encodings
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import as R  # noqa: E402
+from detfill import fill_state_dict, det_input, mnist_like, normal  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(4)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, d):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **d)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB, {len(d)} arrays")
+
+
+# ------------------------------------------------------------------------------------------------ G1
+CONV_CASES = [
+    # name, cls, cin, cout, hw, kwargs
+    ("enc_first", "ConvLayer", 1, 8, 32, dict(down_sample=2, normalization="batchnorm", activation="relu")),
+    ("enc_same", "ConvLayer", 8, 8, 16, dict(normalization="batchnorm", activation="relu")),
+    ("enc_down", "ConvLayer", 8, 16, 16, dict(down_sample=2, normalization="batchnorm", activation="relu")),
+    ("enc_last", "ConvLayer", 16, 32, 2, dict(down_sample=2, normalization="batchnorm", activation="relu")),
+    ("same_1x1res", "ConvLayer", 12, 12, 1, dict(normalization="batchnorm", activation="relu")),
+    ("dec_up", "ConvLayer", 16, 8, 4, dict(up_sample=2, normalization="batchnorm", activation="relu")),
+    ("dec_first", "ConvLayer", 12, 6, 1, dict(up_sample=2, normalization="batchnorm", activation="relu")),
+    ("dec_last", "ConvLayer", 8, 1, 16, dict(up_sample=2, normalization="batchnorm", activation="relu")),
+    ("dec_11", "ConvLayer", 1, 1, 32, dict(normalization="batchnorm", activation="relu")),
+    ("rgb_in", "ConvLayer", 3, 16, 32, dict(down_sample=2, normalization="batchnorm", activation="relu")),
+    ("qkv", "Conv1x1", 8, 24, 16, dict(normalization="batchnorm")),
+    ("qkv1", "Conv1x1", 1, 3, 32, dict(normalization="batchnorm")),
+    ("proj", "Conv1x1", 8, 8, 16, dict()),
+    ("skip_down", "Conv1x1", 8, 16, 16, dict(down_sample=2, normalization="batchnorm")),
+    ("skip_up", "Conv1x1", 16, 8, 4, dict(up_sample=2, normalization="batchnorm")),
+    ("skip_up1", "Conv1x1", 8, 1, 16, dict(up_sample=2, normalization="batchnorm")),
+    ("nonorm_relu", "ConvLayer", 4, 8, 8, dict(activation="relu")),
+]
+
+
+def gen_convlayer():
+    cnn = R.ref("networks.cnn")
+    out = {}
+    for name, cls, cin, cout, hw, kw in CONV_CASES:
+        layer = getattr(cnn, cls)(cin, cout, **kw)
+        layer.train()
+        fill_state_dict(layer.state_dict())
+        x = det_input((4, cin, hw, hw), phase=0.3).requires_grad_(True)
+        y = layer(x)
+        g = det_input(tuple(y.shape), phase=1.1, amp=0.7)
+        y.backward(g)
+        out[f"{name}/x"] = npy(x)
+        out[f"{name}/gy"] = npy(g)
+        out[f"{name}/y"] = npy(y)
+        out[f"{name}/gx"] = npy(x.grad)
+        for k, p in layer.named_parameters():
+            out[f"{name}/param/{k}"] = npy(p)
+            out[f"{name}/grad/{k}"] = npy(p.grad)
+        for k, b in layer.named_buffers():
+            out[f"{name}/buf/{k}"] = npy(b)
+    save("convlayer.npz", out)
+
+
+# ------------------------------------------------------------------------------------------------ G2
+ATTN_CASES = [(256, 4, 2), (64, 4, 4), (16, 8, 4), (4, 8, 8), (1, 16, 16), (1024, 1, 1),
+              (256, 4, 4), (64, 8, 4), (16, 8, 8), (4, 16, 8), (1, 32, 16), (1024, 3, 1)]
+
+
+def gen_attention():
+    nu = R.ref("networks.nets_utils")
+    out = {}
+    for t, h, c in ATTN_CASES:
+        attn = nu.QKVAttention(h)
+        qkv = det_input((2, 3 * h * c, t), phase=0.7, amp=1.3).requires_grad_(True)
+        a = attn(qkv)
+        g = det_input(tuple(a.shape), phase=2.0)
+        a.backward(g)
+        key = f"T{t}_H{h}_C{c}"
+        out[f"{key}/qkv"] = npy(qkv)
+        out[f"{key}/out"] = npy(a)
+        out[f"{key}/gout"] = npy(g)
+        out[f"{key}/gqkv"] = npy(qkv.grad)
+    save("attention.npz", out)
+
+
+# ------------------------------------------------------------------------------------------------ G3
+def gen_cnn_small():
+    cnn = R.ref("networks.cnn")
+    out = {}
+    for residual in ("add", None, "cat"):
+        tag = str(residual)
+        cap = 4 if residual == "cat" else 2
+        enc = cnn.CNN(1, 16, 16, 1, capacity=cap, down_sample=True, residual=residual)
+        nets = [(enc, "enc", det_input((3, 1, 16, 16), 0.2))]
+        if residual != "cat":  # a 1-channel output cannot be split in two halves (cnn.py:308)
+            dec = cnn.CNN(8, 1, 1, 16, capacity=cap, up_sample=True, residual=residual)
+            nets.append((dec, "dec", det_input((3, 8, 1, 1), 0.9)))
+        for net, nm, xin in nets:
+            net.train()
+            fill_state_dict(net.state_dict())
+            x = xin.clone().requires_grad_(True)
+            y = net(x)
+            g = det_input(tuple(y.shape), 1.7, 0.5)
+            y.backward(g)
+            out[f"{tag}/{nm}/x"] = npy(x)
+            out[f"{tag}/{nm}/y"] = npy(y)
+            out[f"{tag}/{nm}/gy"] = npy(g)
+            out[f"{tag}/{nm}/gx"] = npy(x.grad)
+            out[f"{tag}/{nm}/heads"] = np.array([int(b.block[2].attention.n_heads) if hasattr(b.block[2], "attention")
+                                                  else 0 for b in net])
+            for k, p in net.named_parameters():
+                out[f"{tag}/{nm}/grad/{k}"] = npy(p.grad)
+            for k, b in net.named_buffers():
+                if not k.endswith("num_batches_tracked"):
+                    out[f"{tag}/{nm}/buf/{k}"] = npy(b)
+    save("cnn_small.npz", out)
+
+
+# ------------------------------------------------------------------------------------------------ G4
+class _FixedEps:
+    """Makes Normal.rsample draw a recorded eps (prior/gaussian.py:93 uses the global RNG)."""
+
+    def __init__(self, eps):
+        self.eps = eps
+
+    def __enter__(self):
+        import torch.distributions.normal as N
+        self._mod, self._orig = N, N._standard_normal
+        N._standard_normal = lambda shape, dtype, device: self.eps.to(dtype).reshape(shape)
+
+    def __exit__(self, *a):
+        self._mod._standard_normal = self._orig
+
+
+def _mnist_vae(residual="add", loss_coeff=0.1):
+    cnn, pg, vae = R.ref("networks.cnn"), R.ref("prior.gaussian"), R.ref("model.vae")
+    enc = cnn.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual=residual)
+    dec = cnn.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual=residual)
+    fill_state_dict(enc.state_dict())
+    fill_state_dict(dec.state_dict())
+    m = vae.VAE(metrics=R._MetricCollection(), encoder=enc, decoder=dec, prior=pg.GaussianPrior(loss_coeff=loss_coeff))
+    m.train()
+    return m
+
+
+def gen_nelbo():
+    out = {}
+    for residual in ("add", None):
+        tag = str(residual)
+        B = 6
+        m = _mnist_vae(residual)
+        x = mnist_like(B, seed=42)
+        eps = normal((B, 128, 1, 1), seed=43)
+        with _FixedEps(eps):
+            loss, logs, art = m.nelbo({"samples": x, "target": x, "kwargs": {}}, 0)
+        loss.backward()
+        out[f"{tag}/loss"] = npy(torch.stack([logs["train/loss/total"], logs["train/loss/recon"], logs["train/loss/prior"]]))
+        out[f"{tag}/preds"] = npy(art["preds"][:2])
+        out[f"{tag}/latents"] = npy(art["latents"])
+        names, gsum, gl2, psum = [], [], [], []
+        params = []
+        for pre, net in (("encoder.", m.encoder), ("decoder.", m.decoder)):
+            for k, p in net.named_parameters():
+                names.append(pre + k)
+                gsum.append(p.grad.double().sum().item())
+                gl2.append(p.grad.double().norm().item())
+                params.append(p)
+        out[f"{tag}/param_names"] = np.array(names)
+        out[f"{tag}/grad_sum"] = np.array(gsum)
+        out[f"{tag}/grad_l2"] = np.array(gl2)
+        # a few full gradients for exact comparisons
+        for k in ("encoder.0.block.0.weight", "encoder.4.block.2.qkv.weight", "decoder.4.block.2.qkv.weight",
+                  "decoder.0.skip.weight", "encoder.2.block.1._normalization.weight", "decoder.3.block.1.bias"):
+            if k in names:
+                out[f"{tag}/grad_full/{k}"] = npy(params[names.index(k)].grad)
+        opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
+        opt.step()
+        out[f"{tag}/param_sum_after_adam"] = np.array([p.double().sum().item() for p in params])
+        out[f"{tag}/param_l2_after_adam"] = np.array([p.double().norm().item() for p in params])
+        # BN running stats after the step (40 BN layers): checksum
+        rs = []
+        for pre, net in (("encoder.", m.encoder), ("decoder.", m.decoder)):
+            for k, b in net.named_buffers():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    rs.append(b.double().sum().item())
+        out[f"{tag}/running_stat_sums"] = np.array(rs)
+    save("nelbo_mnist.npz", out)
+
+
+# ------------------------------------------------------------------------------------------------ G5
+def gen_prior():
+    pg = R.ref("prior.gaussian")
+    out = {}
+    for tag, kw, step in (("plain", dict(loss_coeff=0.1), 0), ("anneal", dict(loss_coeff=0.5, annealing_steps=100), 30)):
+        prior = pg.GaussianPrior(**kw)
+        x = det_input((8, 256, 1, 1), 0.4, 0.8).requires_grad_(True)
+        eps = normal((8, 128, 1, 1), seed=7)
+        with _FixedEps(eps):
+            z, loss, art = prior(x, step=step)
+        gz = det_input(tuple(z.shape), 2.2)
+        gl = det_input(tuple(loss.shape), 0.1)
+        (z * gz).sum().add((loss * gl).sum()).backward()
+        out[f"{tag}/x"], out[f"{tag}/eps"], out[f"{tag}/z"], out[f"{tag}/loss"] = npy(x), npy(eps), npy(z), npy(loss)
+        out[f"{tag}/gz"], out[f"{tag}/gl"], out[f"{tag}/gx"] = npy(gz), npy(gl), npy(x.grad)
+        out[f"{tag}/cfg"] = np.array([kw.get("loss_coeff", 1.0), kw.get("annealing_steps", 0), step], dtype=np.float64)
+    save("prior.npz", out)
+
+
+# ------------------------------------------------------------------------------------------------ G6
+def gen_sinkhorn():
+    w2 = R.ref("ot.w2_utils")
+    out = {}
+
+    def problem(lead, n, m, dtype, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(*lead, n, 5, generator=g, dtype=torch.float64)
+        y = torch.randn(*lead, m, 5, generator=g, dtype=torch.float64) * 1.2 + 0.3
+        C = ((x.unsqueeze(-2) - y.unsqueeze(-3)) ** 2).sum(-1)
+        C = C / C.amax(dim=(-2, -1), keepdim=True)
+        a = torch.rand(*lead, n, generator=g, dtype=torch.float64) + 0.1
+        b = torch.rand(*lead, m, generator=g, dtype=torch.float64) + 0.1
+        a, b = a / a.sum(-1, keepdim=True), b / b.sum(-1, keepdim=True)
+        return a.to(dtype), b.to(dtype), C.to(dtype)
+
+    cases = [
+        ("n7_f64_reg05", (), 7, 7, torch.float64, 0.05, 50, 0.0),
+        ("n7x9_f32_reg05", (), 7, 9, torch.float32, 0.05, 50, 0.0),
+        ("n64_f32_reg05", (), 64, 64, torch.float32, 0.05, 50, 0.0),
+        ("n64_f64_reg05_thr", (), 64, 64, torch.float64, 0.05, 200, 1e-6),
+        ("n64_f64_reg1e-2", (), 64, 48, torch.float64, 1e-2, 100, 1e-8),
+        ("batch23_f64_thr", (2, 3), 16, 16, torch.float64, 0.05, 300, 1e-5),
+        ("batch23_f32", (2, 3), 33, 20, torch.float32, 0.1, 50, 0.0),
+        ("n1024_f32_reg05", (), 1024, 1024, torch.float32, 0.05, 50, 0.0),
+        ("n1024_f64_reg05", (), 1024, 1024, torch.float64, 0.05, 50, 0.0),
+    ]
+    for i, (name, lead, n, m, dt, reg, it, thr) in enumerate(cases):
+        a, b, C = problem(lead, n, m, dt, 100 + i)
+        pi = w2.sinkhorn_log(a, b, C, reg=reg, max_iter=it, threshold=thr)
+        out[f"{name}/cfg"] = np.array([reg, it, thr], dtype=np.float64)
+        if n <= 64:
+            out[f"{name}/a"], out[f"{name}/b"], out[f"{name}/C"], out[f"{name}/pi"] = npy(a), npy(b), npy(C), npy(pi)
+        else:
+            out[f"{name}/seed"] = np.array([100 + i, n, m])
+            out[f"{name}/row_sums"] = npy(pi.sum(-1))
+            out[f"{name}/col_sums"] = npy(pi.sum(-2))
+            out[f"{name}/pi_corner"] = npy(pi[..., :8, :8])
+        out[f"{name}/cost"] = npy((C * pi).sum(dim=(-2, -1)))
+    save("sinkhorn.npz", out)
+
+
+# ------------------------------------------------------------------------------------------------ G7
+def gen_gaussian_ot():
+    mu_ = R.ref("ot.matrix_utils")
+    w2 = R.ref("ot.w2_utils")
+    gm = R.ref("ot.distribution_models.gaussian_model")
+    gt = R.ref("ot.transport.gaussian_transport")
+    out = {}
+    for D, nb, B in ((8, 3, 64), (32, 2, 100), (128, 2, 256)):
+        tag = f"D{D}"
+        g = torch.Generator().manual_seed(500 + D)
+        A = torch.randn(D, D, generator=g) / math.sqrt(D)
+        src = [(torch.randn(B, D, generator=g) @ A * 1.5 + 0.5) for _ in range(nb)]
+        tgt = [(torch.randn(B, D, generator=g) * 0.8 - 0.2) for _ in range(nb)]
+        for decay in (None, 0.9):
+            dtag = f"{tag}/decay{decay}"
+            cfg = dict(update_decay=decay, dtype=torch.double)
+            op = gt.GaussianTransport(D, source_cfg=cfg, target_cfg=cfg,
+                                      transport_cfg=dict(diag=False, stochastic=False, pg_star=0.0, make_pd=True,
+                                                         verbose=False, dtype=torch.double))
+            op.reset()
+            op.source_model._n_obs.zero_()
+            for s, t in zip(src, tgt):
+                op.update(source_samples=s, target_samples=t)
+            sm = op.source_model
+            out[f"{dtag}/src_n"] = npy(sm._n_obs)
+            out[f"{dtag}/src_sum"] = npy(sm._running_sum)
+            out[f"{dtag}/src_sumcov"] = npy(sm._running_sum_cov)
+            w = op.compute()
+            out[f"{dtag}/w2"] = npy(w)
+            out[f"{dtag}/src_mean"] = npy(op.source_model.mean)
+            out[f"{dtag}/src_cov"] = npy(op.source_model.cov)
+            out[f"{dtag}/tgt_mean"] = npy(op.target_model.mean)
+            out[f"{dtag}/tgt_cov"] = npy(op.target_model.cov)
+            out[f"{dtag}/T"] = npy(op.transport_operator)
+            xin = src[0][:16]
+            out[f"{dtag}/transported"] = npy(op.transport(xin))
+        out[f"{tag}/src"] = npy(torch.stack(src))
+        out[f"{tag}/tgt"] = npy(torch.stack(tgt))
+        # plain functions
+        n, sx, sxx = float(B), src[0].double().sum(0), src[0].double().T @ src[0].double()
+        mean, cov = mu_.mean_cov(sx.clone(), sxx.clone(), torch.tensor(n, dtype=torch.double))
+        out[f"{tag}/meancov_mean"], out[f"{tag}/meancov_cov"] = npy(mean), npy(cov)
+        _, tcov = mu_.mean_cov(tgt[0].double().sum(0), tgt[0].double().T @ tgt[0].double(), torch.tensor(n, dtype=torch.double))
+        tmean = tgt[0].double().mean(0)
+        out[f"{tag}/w2_plain"] = npy(w2.w2_gaussian(mean, tmean, cov, tcov, make_pd=True))
+        out[f"{tag}/sqrtm_cov"] = npy(mu_.sqrtm(cov))
+        out[f"{tag}/invsqrtm_cov"] = npy(mu_.invsqrtm(cov + 1e-8 * torch.eye(D, dtype=torch.double)))
+    # batched leading dims + known-answer (tests/test_w2_utils.py:35-41)
+    g = torch.Generator().manual_seed(9)
+    m1, m2 = torch.randn(2, 3, 3, generator=g), torch.randn(2, 3, 3, generator=g)
+    c1 = torch.randn(2, 3, 3, 3, generator=g)
+    c1 = c1 @ c1.transpose(-1, -2) + 1e-5 * torch.eye(3)
+    c2 = torch.randn(2, 3, 3, 3, generator=g)
+    c2 = c2 @ c2.transpose(-1, -2) + 1e-5 * torch.eye(3)
+    out["batched/m1"], out["batched/m2"], out["batched/c1"], out["batched/c2"] = npy(m1), npy(m2), npy(c1), npy(c2)
+    out["batched/w2"] = npy(w2.w2_gaussian(m1, m2, c1, c2))
+    out["batched/w2_self"] = npy(w2.w2_gaussian(m1, m1, c1, c1))
+    save("gaussian_ot.npz", out)
+
+
+# ------------------------------------------------------------------------------------------------ G8
+def gen_codebook():
+    cb = R.ref("ot.distribution_models.codebook_model")
+    out = {}
+    for tag, lead, K, d, B in (("flat", (1,), 64, 16, 200), ("multi", (4,), 32, 8, 50)):
+        torch.manual_seed(3)
+        model = cb.CodebookModel(*lead, d, mixture_cfg=dict(n_components=K, training_mode="argmax", inference_mode="argmax"))
+        model.eval()
+        g = torch.Generator().manual_seed(77)
+        code = torch.randn(*lead, K, d, generator=g)
+        with torch.no_grad():
+            model.codebook.copy_(code)
+        x = torch.randn(*lead, B, d, generator=g) * 1.1
+        preds, _, dist = model.predict(x)
+        idx = dist.probs.argmax(-1)
+        out[f"{tag}/codebook"], out[f"{tag}/x"] = npy(code), npy(x)
+        out[f"{tag}/preds"], out[f"{tag}/indices"] = npy(preds), npy(idx)
+    save("codebook.npz", out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook"]
+    for w in which:
+        globals()["gen_" + w]()

@@ -1,0 +1,379 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A CPU restatement (plain PyTorch CPU ops, fp32/fp64) of the arithmetic on the hot path of
+theoad/ot-vae-lightning, written from the reference's behaviour, each function citing the
+reference file:line it follows (paths relative to /root/reference/).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+file.  The product (``ot_vae_lightning_amd``) never imports it and has no CPU fallback: it fails
+loudly when the HIP library is missing.
+
+Pinning: every function here is checked against golden vectors recorded from the *real* reference
+(imported in the build container by ``oracle/ref_import.py``; generator ``oracle/gen_golden.py``;
+vectors in ``tests/golden/``) by ``tests/test_oracle_vs_golden.py``.
+
+Everything is functional: network weights are passed as a flat ``dict`` keyed exactly like the
+reference's ``state_dict`` (e.g. ``0.block.1._normalization.running_mean``), so a product
+``state_dict`` can be fed straight in.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+STABILITY_CONST = 1e-8  # ot_vae_lightning/ot/matrix_utils.py:33
+BN_EPS = 1e-5           # nn.BatchNorm2d default, networks/cnn.py:122
+BN_MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------------
+# architecture inference  (networks/cnn.py:605-672, 416-455)
+# ------------------------------------------------------------------------------------------------
+def divisors(n: int) -> List[int]:
+    return [d for d in range(1, n + 1) if n % d == 0]
+
+
+def div_sqrt(n: int) -> int:
+    """Smallest divisor of n that is >= sqrt(n) (networks/cnn.py:660-672: searchsorted on divisors)."""
+    r = math.sqrt(n)
+    for d in divisors(n):
+        if d >= r:
+            return d
+    return n
+
+
+def block_scaling(max_res: int, min_res: int, max_scaling: int) -> List[int]:
+    """networks/cnn.py:605-621."""
+    log_ratio = int(math.log2(max_res // min_res))
+    log_scale = int(math.log2(max_scaling))
+    out: List[int] = []
+    while log_ratio > 0:
+        out.extend([2 ** log_scale] * (log_ratio // log_scale))
+        log_ratio %= log_scale
+        log_scale -= 1
+    return out
+
+
+def channel_list(in_f: int, out_f: int, in_res: int, out_res: int, scaling: int, capacity: int):
+    """networks/cnn.py:627-654."""
+    sfs = block_scaling(in_res, out_res, scaling)
+    feats = [max(min(2 ** i * capacity, out_f), in_f) for i in range(len(sfs))]
+    res = [in_res]
+    for sf in sfs:
+        res.append(res[-1] // sf)
+    feats[-1] = out_f
+    return [in_f] + feats, res
+
+
+def cnn_arch(in_features: int, out_features: int, in_resolution: int, out_resolution: int,
+             capacity: int = 8, max_attn_res: int = 16, down_sample: bool = False, up_sample: bool = False,
+             residual: Optional[str] = None, n_layers: int = 2) -> List[dict]:
+    """Per-ConvBlock description of ``CNN(...)`` (networks/cnn.py:416-455, 306-329)."""
+    assert bool(down_sample) != bool(up_sample)
+    if down_sample:
+        feats, res = channel_list(in_features, out_features, in_resolution, out_resolution, 2, capacity)
+        attn_res = res[1:]
+        in_res = res[:-1]
+    else:
+        feats, res = channel_list(out_features, in_features, out_resolution, in_resolution, 2, capacity)
+        feats, res = feats[::-1], res[::-1]
+        attn_res = res[:-1]
+        in_res = res[:-1]
+    blocks = []
+    for ic, oc, ar, ir in zip(feats[:-1], feats[1:], attn_res, in_res):
+        heads = div_sqrt(oc) if ar <= max_attn_res else 0
+        embed = oc // 2 if residual == "cat" else oc
+        if residual == "cat":
+            heads = div_sqrt(oc) if ar <= max_attn_res else 0  # heads computed from oc (cnn.py:445,449)
+        blocks.append(dict(cin=ic, cout=oc, embed=embed, heads=heads, down=bool(down_sample), up=bool(up_sample),
+                           residual=residual, n_layers=n_layers, in_res=ir))
+    return blocks
+
+
+# ------------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------------
+def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: bool, relu: bool,
+               norm: bool, ksize: int = 3, training: bool = True) -> Tensor:
+    """``ConvLayer.forward`` (networks/cnn.py:183-192): BN -> act -> nearest x2 up -> conv (stride-2 4x4 when
+    down-sampling, cnn.py:98-101).  ``p[prefix+'_normalization.running_*']`` are updated in place like
+    nn.BatchNorm2d does in training mode."""
+    out = x
+    if norm:
+        out = F.batch_norm(out, p[prefix + "_normalization.running_mean"], p[prefix + "_normalization.running_var"],
+                           p[prefix + "_normalization.weight"], p[prefix + "_normalization.bias"],
+                           training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
+    if relu:
+        out = F.relu(out)
+    if up:
+        out = F.interpolate(out, scale_factor=2.0, mode="nearest")
+    if down:
+        k = max(4, ksize)
+        stride, pad = 2, (k - 1) // 2
+    else:
+        k, stride, pad = ksize, 1, (1 if ksize == 3 else 0)
+    w = p[prefix + "weight"]
+    assert w.shape[-1] == k, (prefix, w.shape, k)
+    return F.conv2d(out, w, p.get(prefix + "bias"), stride=stride, padding=pad)
+
+
+def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:
+    """``QKVAttention.forward`` (networks/nets_utils.py:63-82).  qkv [N, 3*H*C, T] -> [N, H*C, T].
+    Both q and k are scaled by C**-0.5; softmax over keys in fp32; no mask / residual."""
+    n, width, t = qkv.shape
+    ch = width // (3 * n_heads)
+    q, k, v = qkv.chunk(3, dim=1)
+    scale = 1.0 / math.sqrt(ch)
+    q = (q * scale).view(n, n_heads, ch, t)
+    k = (k * scale).view(n, n_heads, ch, t)
+    w = torch.einsum("nhct,nhcs->nhts", q, k)
+    w = torch.softmax(w.float(), dim=-1).to(w.dtype)
+    a = torch.einsum("nhts,nhcs->nhct", w, v.reshape(n, n_heads, ch, t))
+    return a.reshape(n, -1, t)
+
+
+def attention_block(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, training: bool = True) -> Tensor:
+    """``AttentionBlock.forward`` (networks/cnn.py:235-240): proj_out(attn(qkv(BN(x)))), NOT residual."""
+    spatial = x.shape[2:]
+    qkv = conv_layer(x, p, prefix + "qkv.", down=False, up=False, relu=False, norm=True, ksize=1,
+                     training=training).flatten(2)
+    h = qkv_attention(qkv, heads).unflatten(2, spatial)
+    return conv_layer(h, p, prefix + "proj_out.", down=False, up=False, relu=False, norm=False, ksize=1,
+                      training=training)
+
+
+def conv_block(x: Tensor, p: Dict[str, Tensor], prefix: str, blk: dict, training: bool = True) -> Tensor:
+    """``ConvBlock.forward`` (networks/cnn.py:331-335)."""
+    out = conv_layer(x, p, prefix + "block.0.", down=blk["down"], up=blk["up"], relu=True, norm=True,
+                     training=training)
+    for j in range(1, blk["n_layers"]):
+        out = conv_layer(out, p, prefix + f"block.{j}.", down=False, up=False, relu=True, norm=True,
+                         training=training)
+    if blk["heads"] > 0:
+        out = attention_block(out, p, prefix + f"block.{blk['n_layers']}.", blk["heads"], training=training)
+    if blk["residual"] in ("add", "cat"):
+        sk = conv_layer(x, p, prefix + "skip.", down=blk["down"], up=blk["up"], relu=False, norm=True, ksize=1,
+                        training=training)
+        out = out + sk if blk["residual"] == "add" else torch.cat([out, sk], dim=1)
+    return out
+
+
+def cnn_forward(x: Tensor, p: Dict[str, Tensor], arch: Sequence[dict], prefix: str = "",
+                training: bool = True) -> Tensor:
+    """``CNN.forward`` (networks/cnn.py:457-458) = the ConvBlocks in sequence."""
+    for i, blk in enumerate(arch):
+        x = conv_block(x, p, f"{prefix}{i}.", blk, training=training)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# prior / loss  (prior/base.py:74-78, prior/gaussian.py:63-96, model/vae.py:158-189)
+# ------------------------------------------------------------------------------------------------
+def prior_annealing(step: int, annealing_steps: int) -> float:
+    """prior/base.py:75."""
+    if annealing_steps > step:
+        return 0.5 * math.cos(math.pi * (step / annealing_steps + 1)) + 0.5
+    return 1.0
+
+
+def gaussian_prior_encode(x: Tensor, eps: Tensor, loss_coeff: float = 1.0, step: int = 0,
+                          annealing_steps: int = 0) -> Tuple[Tensor, Tensor]:
+    """``GaussianPrior.encode`` + ``Prior.forward`` with the N(0,1) draw made explicit (``eps``).
+    mu, log_var = chunk(x, 2, dim=1); std = exp(log_var/2); z = mu + eps*std;
+    KL(q||N(0,I)) = sum 0.5*(mu^2 + log(1) - log(std^2) + std^2 - 1) over all non-batch dims."""
+    mu, log_var = torch.chunk(x, 2, dim=1)
+    std = (log_var / 2).exp()
+    z = mu + eps * std
+    var = std ** 2
+    dims = list(range(1, mu.dim()))
+    # same term order as closed_form_reverse_kl with p = N(0, 1): (mu-0)^2/1 + log(1) - log(var) + var/1 - 1
+    kl = torch.sum(0.5 * (mu ** 2 + 0.0 - var.log() + var - 1), dim=dims)
+    return z, kl * (loss_coeff * prior_annealing(step, annealing_steps))
+
+
+def vae_nelbo(x: Tensor, eps: Tensor, enc: Dict[str, Tensor], dec: Dict[str, Tensor], enc_arch, dec_arch,
+              loss_coeff: float = 1.0, step: int = 0, annealing_steps: int = 0, training: bool = True):
+    """``VAE.nelbo`` with expansion=1 (model/vae.py:165-189): loss = mse(decode(z), x) + mean_B(prior)/(C*H*W)."""
+    h = cnn_forward(x, enc, enc_arch, training=training)
+    z, prior = gaussian_prior_encode(h, eps, loss_coeff, step, annealing_steps)
+    preds = cnn_forward(z, dec, dec_arch, training=training)
+    prior_loss = prior.mean() / float(x[0].numel())
+    recon_loss = F.mse_loss(preds, x)
+    return dict(loss=recon_loss + prior_loss, recon=recon_loss, prior=prior_loss, preds=preds, latents=z,
+                enc_out=h)
+
+
+def adam_step(params: Sequence[Tensor], grads: Sequence[Tensor], exp_avg: Sequence[Tensor],
+              exp_avg_sq: Sequence[Tensor], step: int, lr: float = 1e-3, b1: float = 0.9, b2: float = 0.999,
+              eps: float = 1e-8) -> None:
+    """torch.optim.Adam as configured in model/vae.py:148-151 (no weight decay, no amsgrad); ``step`` is the
+    1-based step count *after* increment.  In place."""
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimal transport arithmetic
+# ------------------------------------------------------------------------------------------------
+def sinkhorn_log(a: Tensor, b: Tensor, C: Tensor, reg: float = 1e-5, max_iter: int = 1000,
+                 threshold: float = STABILITY_CONST, return_potentials: bool = False):
+    """``sinkhorn_log`` (ot/w2_utils.py:276-319).  a [*,N], b [*,M], C [*,N,M] -> pi [*,N,M].
+    Stops as soon as the *minimum over the batch* of the L1 change of (u, v) drops below threshold."""
+    u = torch.zeros_like(a)
+    v = torch.zeros_like(b)
+    log_a = torch.log(a + STABILITY_CONST)
+    log_b = torch.log(b + STABILITY_CONST)
+    Cr = -C / reg
+    n_done = 0
+    for _ in range(max_iter):
+        u0, v0 = u, v
+        v = log_b - torch.logsumexp(Cr + u.unsqueeze(-1), dim=-2)
+        u = log_a - torch.logsumexp(Cr + v.unsqueeze(-2), dim=-1)
+        n_done += 1
+        diff = (u - u0).abs().sum(-1) + (v - v0).abs().sum(-1)
+        if diff.min().item() < threshold:
+            break
+    pi = torch.exp(u.unsqueeze(-1) + v.unsqueeze(-2) + Cr)
+    if return_potentials:
+        return pi, u, v, n_done
+    return pi
+
+
+def sq_euclidean_cost(x: Tensor, y: Tensor) -> Tensor:
+    """C_ij = ||x_i - y_j||^2, the cost the Sinkhorn prior of BASELINE configs 3-4 composes with
+    ``sinkhorn_log`` (same expansion as ot/w2_utils.py:121-125)."""
+    return (x ** 2).sum(-1, keepdim=True) + (y ** 2).sum(-1).unsqueeze(-2) - 2 * (x @ y.transpose(-2, -1))
+
+
+def sinkhorn_ot_loss(z: Tensor, prior_samples: Tensor, reg: float = 0.05, max_iter: int = 50,
+                     threshold: float = 0.0, normalize_cost: bool = True) -> Tensor:
+    """Minibatch entropic OT cost sum(C * pi) with uniform marginals, cost optionally divided by its max
+    before the solve exactly like ``batch_ot_gmm`` does (ot/w2_utils.py:265-269)."""
+    C = sq_euclidean_cost(z, prior_samples)
+    n, m = C.shape[-2:]
+    a = torch.full(C.shape[:-1], 1.0 / n, dtype=C.dtype)
+    b = torch.full((*C.shape[:-2], m), 1.0 / m, dtype=C.dtype)
+    Cn = C / C.amax(dim=(-2, -1), keepdim=True) if normalize_cost else C
+    pi = sinkhorn_log(a, b, Cn, reg=reg, max_iter=max_iter, threshold=threshold)
+    return (C * pi).sum(dim=(-2, -1))
+
+
+def gaussian_stats(samples: Tensor, diag: bool = False):
+    """``GaussianModel._stats`` (ot/distribution_models/gaussian_model.py:144-151), fp64:
+    n = B, sum_x = sum_b x, sum_xxT = sum_b x x^T (or x^2 if diag)."""
+    s = samples.double()
+    n = torch.as_tensor(float(s.size(-2)), dtype=s.dtype)
+    sx = s.sum(-2)
+    sxx = (s ** 2).sum(-2) if diag else torch.einsum("...bi,...bj->...ij", s, s)
+    return n, sx, sxx
+
+
+def ema(avg: Tensor, new: Tensor, decay: Optional[float]) -> Tensor:
+    """utils/__init__.py:204-206."""
+    if decay is None:
+        return avg + new
+    return avg * decay + new * (1 - decay)
+
+
+def mean_cov(sum_x: Tensor, sum_xx: Tensor, n, diag: bool = False):
+    """``mean_cov`` (ot/matrix_utils.py:145-158)."""
+    n = torch.as_tensor(n, dtype=sum_x.dtype)
+    mean = sum_x / n[(...,) + (None,) * (sum_x.dim() - n.dim())]
+    cov = sum_xx / n[(...,) + (None,) * (sum_xx.dim() - n.dim())]
+    cov = cov - (mean ** 2 if diag else mean.unsqueeze(-1) @ mean.unsqueeze(-2))
+    return mean, cov
+
+
+def _eig_fn(m: Tensor, fn) -> Tensor:
+    """``_matrix_operator`` (ot/matrix_utils.py:37-46): V f(lambda) V^T from eigh(UPLO='L')."""
+    lam, vec = torch.linalg.eigh(m, UPLO="L")
+    return vec @ torch.diag_embed(fn(lam)) @ vec.transpose(-2, -1)
+
+
+def sqrtm(m: Tensor) -> Tensor:
+    return _eig_fn(m, torch.sqrt)
+
+
+def invsqrtm(m: Tensor) -> Tensor:
+    return _eig_fn(m, lambda x: 1.0 / torch.sqrt(x))
+
+
+def min_eig(m: Tensor) -> Tensor:
+    return torch.linalg.eigh(m)[0].min(dim=-1)[0]
+
+
+def make_psd(m: Tensor, strict: bool = False) -> Tensor:
+    """``make_psd`` (ot/matrix_utils.py:123-142): add |min(lambda_min, 0)| (+1e-8 if strict) to the diagonal."""
+    shift = min_eig(m).clamp(max=0).abs()
+    if strict:
+        shift = shift + STABILITY_CONST
+    eye = torch.eye(m.shape[-1], dtype=m.dtype)
+    return m + eye * shift[..., None, None]
+
+
+def symmetrize_triu(m: Tensor) -> Tensor:
+    """``Symmetric`` parametrisation (gaussian_model.py:220-226): upper triangle mirrored."""
+    return m.triu() + m.triu(1).transpose(-1, -2)
+
+
+def w2_gaussian(mean_s: Tensor, mean_t: Tensor, cov_s: Tensor, cov_t: Tensor, make_pd: bool = False) -> Tensor:
+    """``w2_gaussian`` (ot/w2_utils.py:40-80), fp64:
+    ||mu_s-mu_t||^2 + tr(S_s + S_t - 2 (S_t^1/2 S_s S_t^1/2)^1/2); with make_pd the two
+    covariances are shifted by make_psd(strict) only when one of the batch fails the eigenvalue test
+    (w2_utils.py:667-669).  The inner product matrix is validated as 'spsd', for which the reference's
+    substring test ``'pd' in 'spsd'`` is False, i.e. it is only checked for symmetry and never shifted."""
+    mean_s, mean_t, cov_s, cov_t = (t.double() for t in (mean_s, mean_t, cov_s, cov_t))
+    if make_pd:
+        if not bool((min_eig(cov_s) > 0).all()):
+            cov_s = make_psd(cov_s, strict=True)
+        if not bool((min_eig(cov_t) > 0).all()):
+            cov_t = make_psd(cov_t, strict=True)
+    rt = sqrtm(cov_t)
+    mix = rt @ cov_s @ rt
+    shift = ((mean_s - mean_t) ** 2).sum(-1)
+    tr = torch.diagonal(cov_s + cov_t - 2 * sqrtm(mix), dim1=-2, dim2=-1).sum(-1)
+    return shift + tr
+
+
+def transport_operator_full(cov_s: Tensor, cov_t: Tensor, pg_star: float = 0.0) -> Tensor:
+    """``_compute_transport_full_mat`` (ot/w2_utils.py:756-769), eq. 17:
+    T = (1-pg) S_s^-1/2 (S_s^1/2 S_t S_s^1/2)^1/2 S_s^-1/2 + pg I, with invsqrtm of S_s + 1e-8 I."""
+    cov_s, cov_t = cov_s.double(), cov_t.double()
+    eye = torch.eye(cov_s.shape[-1], dtype=cov_s.dtype).expand_as(cov_s)
+    rs = sqrtm(cov_s)
+    irs = invsqrtm(cov_s + STABILITY_CONST * eye)
+    return (1 - pg_star) * (irs @ sqrtm(rs @ cov_t @ rs) @ irs) + pg_star * eye
+
+
+def apply_transport(x: Tensor, mean_s: Tensor, mean_t: Tensor, T: Tensor) -> Tensor:
+    """``apply_transport`` without noise (ot/w2_utils.py:517-520), fp64: T (x - mu_s) + mu_t."""
+    x, mean_s, mean_t, T = (t.double() for t in (x, mean_s, mean_t, T))
+    return (T @ (x - mean_s).unsqueeze(-1)).squeeze(-1) + mean_t
+
+
+def gaussian_fit(n: Tensor, sum_x: Tensor, sum_xx: Tensor):
+    """``GaussianModel.fit`` tail (gaussian_model.py:123-126,204-226): mean_cov then the cov parametrisations
+    Symmetric -> MakePositiveDefinite(strict=True) as read back through ``model.cov``."""
+    mean, cov = mean_cov(sum_x, sum_xx, n)
+    return mean, make_psd(symmetrize_triu(cov), strict=True)
+
+
+def codebook_assign(x: Tensor, codebook: Tensor, temperature: float = 1.0, p: float = 2.0):
+    """``CodebookModel.energy`` + ``MixtureMixin.assign`` in 'argmax' mode + ``predict``
+    (ot/distribution_models/codebook_model.py:150-160, base.py:216-233).
+    x [*,B,d], codebook [*,K,d] -> (one-hot @ codebook [*,B,d], argmax indices [*,B] int64)."""
+    energy = 1.0 / (torch.cdist(x, codebook, p) + 1e-8)
+    weights = torch.softmax(energy / temperature, dim=-1)
+    idx = weights.argmax(-1)
+    onehot = F.one_hot(idx, energy.size(-1)).to(weights.dtype)
+    return onehot @ codebook, idx

@@ -1,0 +1,270 @@
+"""CPU: pins ``oracle/otvae_oracle.py`` against golden vectors recorded from the real reference
+(``oracle/gen_golden.py``).  fp32 network ops run the same ATen kernels in the same order, so the bound is
+tight (1e-6 relative); fp64 OT arithmetic 1e-10."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import otvae_oracle as O
+from conftest import group, load_golden, rel_err
+from detfill import fill_state_dict, mnist_like, normal
+
+torch.set_num_threads(4)
+TIGHT = 2e-6
+
+CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
+    "enc_first": (True, False, True, True, 3), "enc_same": (False, False, True, True, 3),
+    "enc_down": (True, False, True, True, 3), "enc_last": (True, False, True, True, 3),
+    "same_1x1res": (False, False, True, True, 3), "dec_up": (False, True, True, True, 3),
+    "dec_first": (False, True, True, True, 3), "dec_last": (False, True, True, True, 3),
+    "dec_11": (False, False, True, True, 3), "rgb_in": (True, False, True, True, 3),
+    "qkv": (False, False, False, True, 1), "qkv1": (False, False, False, True, 1),
+    "proj": (False, False, False, False, 1), "skip_down": (True, False, False, True, 1),
+    "skip_up": (False, True, False, True, 1), "skip_up1": (False, True, False, True, 1),
+    "nonorm_relu": (False, False, True, False, 3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONV_GEOM))
+def test_conv_layer(name):
+    g = group(load_golden("convlayer.npz"), name)
+    down, up, relu, norm, ks = CONV_GEOM[name]
+    p = {k[len("param/"):]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("param/")}
+    if norm:
+        c = g["x"].shape[1]
+        p["_normalization.running_mean"] = torch.zeros(c)
+        p["_normalization.running_var"] = torch.ones(c)
+    x = g["x"].clone().requires_grad_(True)
+    y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks)
+    y.backward(g["gy"])
+    assert rel_err(y, g["y"]) < TIGHT
+    assert rel_err(x.grad, g["gx"]) < TIGHT
+    for k, v in g.items():
+        if k.startswith("grad/"):
+            assert rel_err(p[k[5:]].grad, v) < TIGHT, k
+    if norm:
+        assert rel_err(p["_normalization.running_mean"], g["buf/_normalization.running_mean"]) < TIGHT
+        assert rel_err(p["_normalization.running_var"], g["buf/_normalization.running_var"]) < TIGHT
+
+
+def test_attention_all_shapes():
+    z = load_golden("attention.npz")
+    keys = sorted({k.split("/")[0] for k in z.files})
+    assert len(keys) == 12
+    for key in keys:
+        g = group(z, key)
+        h = int(key.split("_")[1][1:])
+        qkv = g["qkv"].clone().requires_grad_(True)
+        out = O.qkv_attention(qkv, h)
+        out.backward(g["gout"])
+        assert rel_err(out, g["out"]) < TIGHT, key
+        assert rel_err(qkv.grad, g["gqkv"]) < TIGHT, key
+
+
+def _arch_and_params(g, nm, arch):
+    shapes = {}
+    # rebuild the parameter dict from grad/ + buf/ key names; values come from the deterministic fill
+    keys = [k[5:] for k in g if k.startswith("grad/")] + [k[4:] for k in g if k.startswith("buf/")]
+    return keys
+
+
+def _build_params(arch):
+    """state_dict-ordered parameter dict of a CNN described by ``arch`` (zeros), then deterministic fill."""
+    p = {}
+
+    def conv(prefix, cin, cout, k, bias, norm):
+        p[prefix + "weight"] = torch.zeros(cout, cin, k, k)
+        if bias:
+            p[prefix + "bias"] = torch.zeros(cout)
+        if norm:
+            p[prefix + "_normalization.weight"] = torch.zeros(cin)
+            p[prefix + "_normalization.bias"] = torch.zeros(cin)
+            p[prefix + "_normalization.running_mean"] = torch.zeros(cin)
+            p[prefix + "_normalization.running_var"] = torch.ones(cin)
+            p[prefix + "_normalization.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    for i, b in enumerate(arch):
+        pre = f"{i}."
+        e = b["embed"]
+        conv(pre + "block.0.", b["cin"], e, 4 if b["down"] else 3, True, True)
+        for j in range(1, b["n_layers"]):
+            conv(pre + f"block.{j}.", e, e, 3, True, True)
+        if b["heads"] > 0:
+            a = pre + f"block.{b['n_layers']}."
+            conv(a + "qkv.", e, 3 * e, 1, False, True)
+            conv(a + "proj_out.", e, e, 1, False, False)
+        if b["residual"] in ("add", "cat"):
+            conv(pre + "skip.", b["cin"], e, 4 if b["down"] else 1, False, True)
+    fill_state_dict(p)
+    return p
+
+
+@pytest.mark.parametrize("residual", ["add", "None", "cat"])
+def test_cnn_small(residual):
+    z = load_golden("cnn_small.npz")
+    res = None if residual == "None" else residual
+    cap = 4 if res == "cat" else 2
+    nets = [("enc", O.cnn_arch(1, 16, 16, 1, capacity=cap, down_sample=True, residual=res))]
+    if res != "cat":
+        nets.append(("dec", O.cnn_arch(8, 1, 1, 16, capacity=cap, up_sample=True, residual=res)))
+    for nm, arch in nets:
+        g = group(z, f"{residual}/{nm}")
+        assert [b["heads"] for b in arch] == g["heads"].tolist()
+        p = _build_params(arch)
+        for k, v in p.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+        x = g["x"].clone().requires_grad_(True)
+        y = O.cnn_forward(x, p, arch)
+        y.backward(g["gy"])
+        assert rel_err(y, g["y"]) < TIGHT
+        assert rel_err(x.grad, g["gx"]) < 1e-5
+        n = 0
+        for k, v in g.items():
+            if k.startswith("grad/"):
+                assert rel_err(p[k[5:]].grad, v) < 2e-5, k
+                n += 1
+            if k.startswith("buf/"):
+                assert rel_err(p[k[4:]], v) < TIGHT, k
+        assert n == sum(1 for k, v in p.items() if v.requires_grad)
+
+
+@pytest.mark.parametrize("residual", ["add", "None"])
+def test_nelbo_mnist(residual):
+    g = group(load_golden("nelbo_mnist.npz"), residual)
+    res = None if residual == "None" else residual
+    ea = O.cnn_arch(1, 256, 32, 1, capacity=8, down_sample=True, residual=res)
+    da = O.cnn_arch(128, 1, 1, 32, capacity=8, up_sample=True, residual=res)
+    enc, dec = _build_params(ea), _build_params(da)
+    leaves = []
+    names = []
+    for pre, d in (("encoder.", enc), ("decoder.", dec)):
+        for k, v in d.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+                leaves.append(v)
+                names.append(pre + k)
+    assert names == [str(s) for s in g["param_names"]]
+    x, eps = mnist_like(6, 42), normal((6, 128, 1, 1), 43)
+    r = O.vae_nelbo(x, eps, enc, dec, ea, da, loss_coeff=0.1)
+    r["loss"].backward()
+    got = torch.stack([r["loss"], r["recon"], r["prior"]])
+    assert rel_err(got, g["loss"]) < TIGHT
+    assert rel_err(r["preds"][:2], g["preds"]) < 1e-5
+    assert rel_err(r["latents"], g["latents"]) < 1e-5
+    gs = torch.tensor([v.grad.double().sum().item() for v in leaves])
+    gl = torch.tensor([v.grad.double().norm().item() for v in leaves])
+    assert rel_err(gl, g["grad_l2"]) < 1e-4
+    assert (gs - g["grad_sum"]).abs().max() < 1e-4 * g["grad_l2"].max()
+    for k, v in g.items():
+        if k.startswith("grad_full/"):
+            assert rel_err(leaves[names.index(k[10:])].grad, v) < 1e-4, k
+    m = [torch.zeros_like(v) for v in leaves]
+    s = [torch.zeros_like(v) for v in leaves]
+    with torch.no_grad():
+        O.adam_step(leaves, [v.grad for v in leaves], m, s, step=1)
+    pl2 = torch.tensor([v.double().norm().item() for v in leaves])
+    assert rel_err(pl2, g["param_l2_after_adam"]) < 1e-6
+    rs = [v.double().sum().item() for d in (enc, dec) for k, v in d.items()
+          if k.endswith("running_mean") or k.endswith("running_var")]
+    assert rel_err(torch.tensor(rs), g["running_stat_sums"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["plain", "anneal"])
+def test_gaussian_prior(tag):
+    g = group(load_golden("prior.npz"), tag)
+    coeff, ann, step = g["cfg"].tolist()
+    x = g["x"].clone().requires_grad_(True)
+    z, loss = O.gaussian_prior_encode(x, g["eps"], coeff, int(step), int(ann))
+    ((z * g["gz"]).sum() + (loss * g["gl"]).sum()).backward()
+    assert rel_err(z, g["z"]) < TIGHT and rel_err(loss, g["loss"]) < TIGHT and rel_err(x.grad, g["gx"]) < TIGHT
+
+
+def _sinkhorn_problem(lead, n, m, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*lead, n, 5, generator=g, dtype=torch.float64)
+    y = torch.randn(*lead, m, 5, generator=g, dtype=torch.float64) * 1.2 + 0.3
+    C = ((x.unsqueeze(-2) - y.unsqueeze(-3)) ** 2).sum(-1)
+    C = C / C.amax(dim=(-2, -1), keepdim=True)
+    a = torch.rand(*lead, n, generator=g, dtype=torch.float64) + 0.1
+    b = torch.rand(*lead, m, generator=g, dtype=torch.float64) + 0.1
+    a, b = a / a.sum(-1, keepdim=True), b / b.sum(-1, keepdim=True)
+    return a.to(dtype), b.to(dtype), C.to(dtype)
+
+
+def test_sinkhorn_all_cases():
+    z = load_golden("sinkhorn.npz")
+    names = sorted({k.split("/")[0] for k in z.files})
+    assert len(names) == 9
+    for name in names:
+        g = group(z, name)
+        reg, it, thr = g["cfg"].tolist()
+        if "pi" in g:
+            a, b, C = g["a"], g["b"], g["C"]
+        else:
+            seed, n, m = g["seed"].tolist()
+            dt = torch.float32 if "f32" in name else torch.float64
+            a, b, C = _sinkhorn_problem((), n, m, dt, seed)
+        pi = O.sinkhorn_log(a, b, C, reg=reg, max_iter=int(it), threshold=thr)
+        tol = 1e-5 if pi.dtype == torch.float32 else 1e-10
+        if "pi" in g:
+            assert rel_err(pi, g["pi"]) < tol, name
+        else:
+            assert rel_err(pi.sum(-1), g["row_sums"]) < tol and rel_err(pi[:8, :8], g["pi_corner"]) < tol, name
+        assert rel_err((C * pi).sum(dim=(-2, -1)), g["cost"]) < tol, name
+
+
+@pytest.mark.parametrize("D", [8, 32, 128])
+def test_gaussian_ot(D):
+    z = load_golden("gaussian_ot.npz")
+    base = group(z, f"D{D}")
+    src, tgt = base["src"], base["tgt"]
+    for decay in (None, 0.9):
+        g = group(z, f"D{D}/decay{decay}")
+        st = {}
+        for nm, data in (("s", src), ("t", tgt)):
+            n = torch.zeros((), dtype=torch.float64)
+            sx = torch.zeros(D, dtype=torch.float64)
+            sxx = torch.zeros(D, D, dtype=torch.float64)
+            for batch in data:
+                bn, bsx, bsxx = O.gaussian_stats(batch)
+                n, sx, sxx = O.ema(n, bn, decay), O.ema(sx, bsx, decay), O.ema(sxx, bsxx, decay)
+            st[nm] = (n, sx, sxx)
+        assert rel_err(st["s"][0], g["src_n"]) < 1e-12
+        assert rel_err(st["s"][1], g["src_sum"]) < 1e-12 and rel_err(st["s"][2], g["src_sumcov"]) < 1e-12
+        ms, cs = O.gaussian_fit(*st["s"])
+        mt, ct = O.gaussian_fit(*st["t"])
+        assert rel_err(ms, g["src_mean"]) < 1e-12 and rel_err(cs, g["src_cov"]) < 1e-10
+        assert rel_err(mt, g["tgt_mean"]) < 1e-12 and rel_err(ct, g["tgt_cov"]) < 1e-10
+        w = O.w2_gaussian(ms, mt, cs, ct, make_pd=True)
+        assert rel_err(w, g["w2"]) < 1e-9
+        T = O.transport_operator_full(cs, ct)
+        assert rel_err(T, g["T"]) < 1e-8
+        out = O.apply_transport(src[0][:16], ms, mt, T).float()
+        assert rel_err(out, g["transported"]) < 1e-6
+    n, sx, sxx = O.gaussian_stats(src[0])
+    mean, cov = O.mean_cov(sx, sxx, n)
+    assert rel_err(mean, base["meancov_mean"]) < 1e-12 and rel_err(cov, base["meancov_cov"]) < 1e-12
+    assert rel_err(O.sqrtm(cov), base["sqrtm_cov"]) < 1e-9
+    tn, tsx, tsxx = O.gaussian_stats(tgt[0])
+    _, tcov = O.mean_cov(tsx, tsxx, tn)
+    assert rel_err(O.w2_gaussian(mean, tgt[0].double().mean(0), cov, tcov, make_pd=True), base["w2_plain"]) < 1e-9
+
+
+def test_w2_batched_and_self_zero():
+    g = group(load_golden("gaussian_ot.npz"), "batched")
+    w = O.w2_gaussian(g["m1"], g["m2"], g["c1"], g["c2"])
+    assert w.shape == (2, 3) and rel_err(w, g["w2"]) < 1e-9
+    w0 = O.w2_gaussian(g["m1"], g["m1"], g["c1"], g["c1"])
+    assert w0.abs().max() < 3e-8 * 3 + 1e-6  # reference's own known-answer (tests/test_w2_utils.py:35-41)
+    assert (w0 - g["w2_self"]).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["flat", "multi"])
+def test_codebook_indices_bit_exact(tag):
+    g = group(load_golden("codebook.npz"), tag)
+    preds, idx = O.codebook_assign(g["x"], g["codebook"])
+    assert torch.equal(idx, g["indices"])
+    assert torch.equal(preds, g["preds"])
