@@ -1,0 +1,176 @@
+/*
+ * otvae.h -- C ABI of libotvae_hip.so, the MI355X (gfx950) implementation of the training-step hot path of
+ * theoad/ot-vae-lightning.  Plain pointers and sizes only (no torch / HIP types): `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  All pointers are DEVICE pointers unless stated otherwise.
+ *
+ * Conventions
+ *   - Activations are fp32 NHWC ([N][H][W][C] contiguous).  Conv weights are HWIO ([KH][KW][Cin][Cout]); the
+ *     Python side keeps the reference's logical OIHW shape on a tensor whose strides give this memory order.
+ *   - Every function only enqueues work on `stream`: no allocation, no host synchronisation, no global state, so
+ *     all of them can be captured into a hipGraph.  Workspaces are supplied by the caller.
+ *   - Return value: OTVAE_OK or a negative OTVAE_E* code (bad shape/argument -> nothing was launched).
+ *   - There is no CPU implementation behind this ABI.
+ *
+ * Each entry point cites the reference code (paths under ot_vae_lightning/) whose arithmetic it replaces.
+ */
+#ifndef OTVAE_H
+#define OTVAE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTVAE_OK 0
+#define OTVAE_EINVAL (-1)       /* bad argument / shape */
+#define OTVAE_EUNSUPPORTED (-2) /* valid but not implemented for this size */
+#define OTVAE_ELAUNCH (-3)      /* hipLaunch / runtime error */
+
+int otvae_abi_version(void);           /* bumps when a signature changes */
+const char* otvae_last_error(void);    /* host string describing the last non-OK return of this thread */
+int otvae_device_info(int* n_cu, int* wave_size, char* arch, int arch_len); /* host query helper */
+
+/* Geometry of one ConvLayer (networks/cnn.py:48-154,183-192): input [N][Hs][Ws][Cs] --(nearest x`up`)-->
+ * conv KHxKW / stride / pad --> [N][Ho][Wo][Cn].  `up` is 1 or 2; up==2 requires stride==1. */
+typedef struct {
+    int32_t N, Hs, Ws, Cs;
+    int32_t up;
+    int32_t Ho, Wo, Cn;
+    int32_t KH, KW, stride, pad;
+} otvae_conv_geom;
+
+/* ---- BatchNorm2d, training mode (networks/cnn.py:122,184) ------------------------------------------------- */
+/* per-channel partial sums of x[M][C]: partial[P][2][C] (double), P = otvae_bn_stats_nparts(M, C). */
+int otvae_bn_stats_nparts(int64_t M, int C);
+int otvae_bn_stats(const float* x, int64_t M, int C, double* partial, void* stream);
+/* mean/invstd from the partials; for each of `n_bn` BatchNorm modules sharing this input (a ConvBlock's
+ * block[0] and skip normalise the same tensor) writes scale = gamma*invstd, shift = beta - mean*scale and updates
+ * running_mean/var (momentum, unbiased var) and num_batches_tracked.  Arrays of n_bn device pointers are HOST
+ * arrays. running pointers may be NULL (no update). */
+int otvae_bn_finalize(const double* partial, int P, int64_t M, int C, float eps, float momentum,
+                      float* mean, float* invstd, int n_bn,
+                      const float* const* gamma, const float* const* beta,
+                      float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
+                      float* const* scale, float* const* shift, void* stream);
+
+/* ---- ConvLayer.forward: y = conv(up(relu?(x*scale+shift))) + bias (+ residual) ---------------------------- */
+/* scale/shift NULL -> no normalisation; relu applies after the affine; bias/residual NULL -> absent.
+ * residual has y's shape (ConvBlock `out + skip(x)`, networks/cnn.py:334). wT is the HWIO weight. */
+int otvae_conv_fwd(const otvae_conv_geom* g, const float* x, const float* scale, const float* shift, int relu,
+                   const float* wT, const float* bias, const float* residual, float* y, void* stream);
+
+/* HWIO [T][Cs][Cn] -> [T][Cn][Cs] (the dgrad operand layout) */
+int otvae_weight_transpose(const float* wT, float* wD, int T, int Cs, int Cn, void* stream);
+
+/* ---- ConvLayer backward ------------------------------------------------------------------------------------ */
+/* Data gradient.  gv[N][Hs][Ws][Cs] = d loss / d (x*scale+shift) i.e. the gradient entering BatchNorm's output
+ * (after the nearest-upsample sum and the ReLU mask recomputed from x).  With mean/invstd != NULL also writes
+ * the per-block partial sums bn_partial[P][2][CsPad] of (gv, gv*xhat) that BatchNorm backward needs;
+ * P and CsPad from otvae_conv_bwd_data_ws. */
+int otvae_conv_bwd_data_ws(const otvae_conv_geom* g, int* P, int* CsPad);
+int otvae_conv_bwd_data(const otvae_conv_geom* g, const float* gy, const float* wD,
+                        const float* x, const float* scale, const float* shift, int relu,
+                        const float* mean, const float* invstd,
+                        float* gv, float* bn_partial, void* stream);
+/* BatchNorm backward for up to two branches that normalise the same x (block[0] and skip):
+ * finalize: reduces the partials, writes dgamma/dbeta of each branch and the coefficient vectors coef[(2+nb)][C]
+ * apply:    dx = sum_b coef[2+b][c]*gv_b - coef[0][c]*x - coef[1][c]   (elementwise, M*C elements) */
+int otvae_bn_bwd_finalize(int nb, const float* const* bn_partial, const int* P, int CsPad, int64_t M, int C,
+                          const float* mean, const float* invstd, const float* const* gamma,
+                          float* const* dgamma, float* const* dbeta, float* coef, void* stream);
+int otvae_bn_bwd_apply(int nb, const float* const* gv, const float* x, const float* coef, int64_t M, int C,
+                       float* dx, void* stream);
+
+/* Weight (+bias) gradient.  Workspace partial[P][K+hasb][Cn] floats with K = KH*KW*Cs; P from _ws.
+ * gw is written in HWIO order, gb[Cn] if has_bias. */
+int otvae_conv_bwd_weight_ws(const otvae_conv_geom* g, int has_bias, int* P);
+int otvae_conv_bwd_weight(const otvae_conv_geom* g, const float* x, const float* scale, const float* shift, int relu,
+                          const float* gy, int has_bias, float* partial, float* gw, float* gb, void* stream);
+
+/* ---- QKVAttention (networks/nets_utils.py:63-82) ---------------------------------------------------------- */
+/* qkv [N][T][3*H*C] (channel = which*H*C + h*C + c) -> out [N][T][H*C]; lse [N][H][T] saved for backward. */
+int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, void* stream);
+int otvae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* gout,
+                   int N, int T, int H, int C, float* gqkv, void* stream);
+
+/* ---- GaussianPrior (prior/gaussian.py:63-96) + Prior.forward scaling (prior/base.py:74-78) ---------------- */
+/* h [B][S][2D] (S = H*W positions, channels-last) ; eps,z [B][S][D]; loss[B] = coeff * KL(q||N(0,I)) */
+int otvae_gaussian_prior_fwd(const float* h, const float* eps, int B, int S, int D, float coeff,
+                             float* z, float* loss, void* stream);
+int otvae_gaussian_prior_bwd(const float* h, const float* eps, const float* gz, const float* gloss,
+                             int B, int S, int D, float coeff, float* gh, void* stream);
+
+/* ---- VAE.nelbo reduction (model/vae.py:158-176) ----------------------------------------------------------- */
+/* out[3] = {total, recon, prior}: recon = mean((pred-target)^2), prior = mean_B(prior_loss)/chw.
+ * ws: double[otvae_nelbo_ws()] scratch. */
+int otvae_nelbo_ws(void);
+int otvae_nelbo_fwd(const float* pred, const float* target, int64_t numel, const float* prior_loss, int B,
+                    float chw, double* ws, float* out, void* stream);
+/* gout[3] = upstream gradient of out: gpred = (gout[0]+gout[1]) * 2*(pred-target)/numel ;
+ * gprior[B] = (gout[0]+gout[2])/(B*chw).  gout NULL = {1,0,0}. */
+int otvae_nelbo_bwd(const float* pred, const float* target, int64_t numel, int B, float chw,
+                    const float* gout, float* gpred, float* gprior, void* stream);
+
+/* ---- Adam (model/vae.py:148-151; torch.optim.Adam defaults) over one flat buffer --------------------------- */
+/* hyper (device): float[4] = {lr, beta1, beta2, eps}; step (device int32) is the 1-based count of THIS update
+ * (incremented by otvae_step_begin). grad_scale multiplies g first (1/world_size for data-parallel means). */
+int otvae_step_begin(int32_t* step, void* stream);
+int otvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                    const int32_t* step, float grad_scale, void* stream);
+
+/* ---- sinkhorn_log (ot/w2_utils.py:276-319) ---------------------------------------------------------------- */
+/* a[nb][N], b[nb][M], C[nb][N][M] -> pi[nb][N][M] (may alias no input), u[nb][N], v[nb][M] potentials.
+ * dtype: 0 = fp32, 1 = fp64.  ws: bytes from otvae_sinkhorn_ws.  Stops all problems at the first iteration where
+ * min over the batch of (|du|_1+|dv|_1) < threshold, evaluated on the device (no host sync); threshold <= 0
+ * runs exactly max_iter iterations.  iters_done (device int32, may be NULL). */
+int64_t otvae_sinkhorn_ws(int dtype, int nb, int N, int M);
+int otvae_sinkhorn_log(int dtype, const void* a, const void* b, const void* C, int nb, int N, int M,
+                       double reg, int max_iter, double threshold, void* ws,
+                       void* pi, void* u, void* v, int32_t* iters_done, void* stream);
+/* cost[nb] = sum_ij C*pi (fp64 accumulate, fixed order), out dtype = dtype; ws: double[nb*64] */
+int otvae_ot_cost(int dtype, const void* C, const void* pi, int nb, int N, int M, double* ws, void* cost, void* stream);
+/* pairwise squared euclidean cost C[nb][N][M] = |x_i - y_j|^2, x[nb][N][D], y[nb][M][D] */
+int otvae_sqdist(int dtype, const void* x, const void* y, int nb, int N, int M, int D, void* C, void* stream);
+
+/* ---- GaussianModel statistics (ot/distribution_models/gaussian_model.py:99-108,144-157) ------------------- */
+/* samples [nb][B][D] (in_dtype 0=fp32,1=fp64) -> fp64 sum_x[nb][D], sum_xx[nb][D][D] (diag: [nb][D]),
+ * accumulated into the running buffers:  run = decay<0 ? run + new : run*decay + new*(1-decay)
+ * (utils/__init__.py:204-206); n_obs[nb] likewise with new = B.  With accumulate==0 the raw batch statistics are
+ * written instead (the all-reduce path reduces them before the EMA). */
+int64_t otvae_gauss_stats_ws(int nb, int B, int D, int diag); /* bytes */
+int otvae_gauss_stats(int in_dtype, const void* samples, int nb, int B, int D, int diag, int accumulate,
+                      double decay, double* ws, double* n_obs, double* sum_x, double* sum_xx, void* stream);
+/* mean_cov (ot/matrix_utils.py:145-158): mean = sum/n, cov = sum_xx/n - mean mean^T */
+int otvae_mean_cov(const double* n_obs, const double* sum_x, const double* sum_xx, int nb, int D, int diag,
+                   double* mean, double* cov, void* stream);
+
+/* ---- symmetric eigen-decomposition based matrix functions (ot/matrix_utils.py:37-109) --------------------- */
+/* A[nb][D][D] fp64 symmetric (lower triangle is read, like eigh(UPLO='L')).  fn: 0 = none (eigvals only),
+ * 1 = sqrtm, 2 = invsqrtm.  out[nb][D][D] = V f(lambda) V^T, eigvals[nb][D] ascending-unsorted.  D <= 128.
+ * ws: bytes from otvae_eigh_ws. */
+int64_t otvae_eigh_ws(int nb, int D);
+int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, void* stream);
+/* make_psd (ot/matrix_utils.py:123-142) without host sync: shift_b = (any_b lambda_min_b <= thr ? 1 : 0) *
+ * (|min(lambda_min_b,0)| + (strict ? 1e-8 : 0)), A_b += shift_b * I.  cond_any: 1 = apply only if some matrix of
+ * the batch fails the test (w2_utils.py:667-669), 0 = always (gaussian_model.py:204-214). */
+int otvae_make_psd(double* A, const double* eigvals, int nb, int D, int strict, int cond_any, void* stream);
+/* C[nb][m][n] = alpha * op(A) op(B) + beta*C, fp64, row-major; transX: 0 = N, 1 = T. bcast flags: operand has
+ * batch stride 0 */
+int otvae_gemm_f64(int transA, int transB, int nb, int m, int n, int k, double alpha, const double* A, int a_bcast,
+                   const double* B, int b_bcast, double beta, double* C, void* stream);
+/* w2_gaussian tail (ot/w2_utils.py:78-80): out[nb] = |ms-mt|^2 + tr(cs + ct - 2*sqrt_mix) */
+int otvae_w2_tail(const double* ms, const double* mt, const double* cs, const double* ct, const double* sqrt_mix,
+                  int nb, int D, double* out, void* stream);
+/* apply_transport (ot/w2_utils.py:517-520): y[nb][B][D] = T[nb] (x - ms) + mt ; x dtype 0/1, y same dtype */
+int otvae_apply_transport(int dtype, const void* x, const double* ms, const double* mt, const double* T,
+                          int nb, int B, int D, void* y, void* stream);
+
+/* ---- CodebookModel.energy/assign 'argmax'/predict (ot/distribution_models/codebook_model.py:150-160,
+ *      base.py:216-233): x[nb][B][d], codebook[nb][K][d] -> idx[nb][B] (int64), enc[nb][B][d] = codebook[idx] */
+int otvae_codebook_assign(const float* x, const float* codebook, int nb, int B, int K, int d, float temperature,
+                          int64_t* idx, float* enc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OTVAE_H */

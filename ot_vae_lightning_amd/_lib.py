@@ -1,0 +1,133 @@
+"""ctypes binding of ``libotvae_hip.so`` (C ABI in ``include/otvae.h``).
+
+The product path has no CPU implementation: if the library is missing or a call fails, an exception is raised.
+Bad shapes surface as ``ValueError`` like the reference's argument validation (e.g. ot/w2_utils.py:619-707).
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libotvae_hip.so")
+
+_lock = threading.Lock()
+_lib = None
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+pp = C.POINTER(C.c_void_p)  # host array of device pointers
+pi32 = C.POINTER(C.c_int)
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "Hs", "Ws", "Cs", "up", "Ho", "Wo", "Cn", "KH", "KW", "stride", "pad")]
+
+
+pg = C.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); mirrors include/otvae.h one to one (tests/test_abi.py checks both directions)
+SIGNATURES = {
+    "otvae_abi_version": (i32, []),
+    "otvae_last_error": (C.c_char_p, []),
+    "otvae_device_info": (i32, [pi32, pi32, C.c_char_p, i32]),
+    "otvae_bn_stats_nparts": (i32, [i64, i32]),
+    "otvae_bn_stats": (i32, [vp, i64, i32, vp, vp]),
+    "otvae_bn_finalize": (i32, [vp, i32, i64, i32, f32, f32, vp, vp, i32, pp, pp, pp, pp, pp, pp, pp, vp]),
+    "otvae_conv_fwd": (i32, [pg, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "otvae_weight_transpose": (i32, [vp, vp, i32, i32, i32, vp]),
+    "otvae_conv_bwd_data_ws": (i32, [pg, pi32, pi32]),
+    "otvae_conv_bwd_data": (i32, [pg, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "otvae_bn_bwd_finalize": (i32, [i32, pp, pi32, i32, i64, i32, vp, vp, pp, pp, pp, vp, vp]),
+    "otvae_bn_bwd_apply": (i32, [i32, pp, vp, vp, i64, i32, vp, vp]),
+    "otvae_conv_bwd_weight_ws": (i32, [pg, i32, pi32]),
+    "otvae_conv_bwd_weight": (i32, [pg, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
+    "otvae_attn_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
+    "otvae_attn_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "otvae_gaussian_prior_fwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),
+    "otvae_gaussian_prior_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
+    "otvae_nelbo_ws": (i32, []),
+    "otvae_nelbo_fwd": (i32, [vp, vp, i64, vp, i32, f32, vp, vp, vp]),
+    "otvae_nelbo_bwd": (i32, [vp, vp, i64, i32, f32, vp, vp, vp, vp]),
+    "otvae_step_begin": (i32, [vp, vp]),
+    "otvae_adam_step": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp]),
+    "otvae_sinkhorn_ws": (i64, [i32, i32, i32, i32]),
+    "otvae_sinkhorn_log": (i32, [i32, vp, vp, vp, i32, i32, i32, f64, i32, f64, vp, vp, vp, vp, vp, vp]),
+    "otvae_ot_cost": (i32, [i32, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "otvae_sqdist": (i32, [i32, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "otvae_gauss_stats_ws": (i64, [i32, i32, i32, i32]),
+    "otvae_gauss_stats": (i32, [i32, vp, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp]),
+    "otvae_mean_cov": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "otvae_eigh_ws": (i64, [i32, i32]),
+    "otvae_eigh_fn": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    "otvae_make_psd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "otvae_gemm_f64": (i32, [i32, i32, i32, i32, i32, i32, f64, vp, i32, vp, i32, f64, vp, vp]),
+    "otvae_w2_tail": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "otvae_apply_transport": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "otvae_codebook_assign": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Loads (once) and returns the ctypes library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -m ot_vae_lightning_amd.build` "
+                "(there is no CPU fallback for the MI355X path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().otvae_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    msg = f"{what} failed (code {rc}): {last_error()}"
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -2:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def ptr_array(tensors):
+    """Host array of device pointers for the `const float* const*` style arguments."""
+    arr = (C.c_void_p * max(1, len(tensors)))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(t: torch.Tensor, name: str = "tensor") -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the MI355X (got device {t.device}); "
+                           "ot_vae_lightning_amd has no CPU execution path")

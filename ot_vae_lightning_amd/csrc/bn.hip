@@ -1,0 +1,242 @@
+// BatchNorm2d (training mode) statistics, finalisation and backward for NHWC activations.
+// Replaces F.batch_norm(training=True) + its autograd backward as used by ConvLayer._normalization
+// (reference networks/cnn.py:122,184).  Sums are accumulated in fp64 and combined in a fixed order
+// (per-thread -> LDS tree -> per-block partial -> serial over <= 256 partials), so results are run-to-run identical.
+#include "common.h"
+
+#define BN_MAX_PARTS 256
+
+extern "C" int otvae_bn_stats_nparts(int64_t M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    const int rpb = C >= 256 ? 1 : 256 / C;  // rows handled per block iteration
+    int64_t want = (M + (int64_t)rpb * 16 - 1) / ((int64_t)rpb * 16);
+    if (want < 1) want = 1;
+    return (int)(want > BN_MAX_PARTS ? BN_MAX_PARTS : want);
+}
+
+// thread (rr, c): rows rr, rr+RPB*P ... of channel c (C <= 256), or loops channels (C > 256)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C, double* __restrict__ partial) {
+    __shared__ double sh[2][256];
+    const int P = gridDim.x;
+    if (C <= 256) {
+        const int rpb = 256 / C;
+        const int c = threadIdx.x % C, rr = threadIdx.x / C;
+        double s = 0.0, q = 0.0;
+        if (rr < rpb) {
+            for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)P * rpb) {
+                const float v = x[m * C + c];
+                s += (double)v;
+                q += (double)v * (double)v;
+            }
+        }
+        sh[0][threadIdx.x] = s;
+        sh[1][threadIdx.x] = q;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            double ts = 0.0, tq = 0.0;
+            for (int r = 0; r < rpb; ++r) {
+                ts += sh[0][r * C + threadIdx.x];
+                tq += sh[1][r * C + threadIdx.x];
+            }
+            partial[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = ts;
+            partial[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = tq;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            double s = 0.0, q = 0.0;
+            for (int64_t m = blockIdx.x; m < M; m += P) {
+                const float v = x[m * C + c];
+                s += (double)v;
+                q += (double)v * (double)v;
+            }
+            partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
+            partial[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+        }
+    }
+}
+
+extern "C" int otvae_bn_stats(const float* x, int64_t M, int C, double* partial, void* stream) {
+    OTVAE_REQUIRE(x && partial && M > 0 && C > 0, "otvae_bn_stats: bad argument");
+    const int P = otvae_bn_stats_nparts(M, C);
+    bn_stats_kernel<<<P, 256, 0, (hipStream_t)stream>>>(x, M, C, partial);
+    OTVAE_CHECK_LAUNCH("otvae_bn_stats");
+    return OTVAE_OK;
+}
+
+struct BnFin {
+    const float* gamma[2];
+    const float* beta[2];
+    float* rmean[2];
+    float* rvar[2];
+    int64_t* nbt[2];
+    float* scale[2];
+    float* shift[2];
+};
+
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int P, int64_t M, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, int n_bn, BnFin f) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int p = 0; p < P; ++p) {
+            s += partial[((size_t)p * 2 + 0) * C + c];
+            q += partial[((size_t)p * 2 + 1) * C + c];
+        }
+        const double mu = s / (double)M;
+        double var = q / (double)M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float fmu = (float)mu;
+        const float fis = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = fmu;
+        invstd[c] = fis;
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        for (int b = 0; b < n_bn; ++b) {
+            const float sc = f.gamma[b][c] * fis;
+            f.scale[b][c] = sc;
+            f.shift[b][c] = fmaf(-fmu, sc, f.beta[b][c]);
+            if (f.rmean[b]) f.rmean[b][c] = (1.f - momentum) * f.rmean[b][c] + momentum * fmu;
+            if (f.rvar[b]) f.rvar[b][c] = (1.f - momentum) * f.rvar[b][c] + momentum * (float)unbiased;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int b = 0; b < n_bn; ++b)
+            if (f.nbt[b]) *f.nbt[b] += 1;
+}
+
+extern "C" int otvae_bn_finalize(const double* partial, int P, int64_t M, int C, float eps, float momentum, float* mean,
+                                 float* invstd, int n_bn, const float* const* gamma, const float* const* beta,
+                                 float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
+                                 float* const* scale, float* const* shift, void* stream) {
+    OTVAE_REQUIRE(partial && mean && invstd && P > 0 && M > 0 && C > 0, "otvae_bn_finalize: bad argument");
+    OTVAE_REQUIRE(n_bn >= 0 && n_bn <= 2, "otvae_bn_finalize: n_bn must be 0..2");
+    BnFin f = {};
+    for (int b = 0; b < n_bn; ++b) {
+        OTVAE_REQUIRE(gamma[b] && beta[b] && scale[b] && shift[b], "otvae_bn_finalize: NULL gamma/beta/scale/shift");
+        f.gamma[b] = gamma[b];
+        f.beta[b] = beta[b];
+        f.rmean[b] = running_mean ? running_mean[b] : nullptr;
+        f.rvar[b] = running_var ? running_var[b] : nullptr;
+        f.nbt[b] = num_batches_tracked ? num_batches_tracked[b] : nullptr;
+        f.scale[b] = scale[b];
+        f.shift[b] = shift[b];
+    }
+    bn_finalize_kernel<<<cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(partial, P, M, C, eps, momentum, mean, invstd, n_bn, f);
+    OTVAE_CHECK_LAUNCH("otvae_bn_finalize");
+    return OTVAE_OK;
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------
+// For y = xhat*gamma + beta, xhat = (x-mean)*invstd, with g = dL/dy:
+//   dgamma = sum g*xhat, dbeta = sum g, dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)
+// With up to two branches b normalising the same x:
+//   dx = sum_b k_b*g_b - A*x - B,  k_b = gamma_b*invstd, A = invstd/M * sum_b k_b*dgamma_b,
+//   B = sum_b k_b*(dbeta_b/M) - A*mean
+struct BnBwdFin {
+    const float* partial[2];
+    int P[2];
+    const float* gamma[2];
+    float* dgamma[2];
+    float* dbeta[2];
+};
+
+__global__ void bn_bwd_finalize_kernel(int nb, BnBwdFin f, int CsPad, int64_t M, int C, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ coef) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const double is = (double)invstd[c], mu = (double)mean[c];
+        double A = 0.0, B = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int p = 0; p < f.P[b]; ++p) {
+                s1 += (double)f.partial[b][((size_t)p * 2 + 0) * CsPad + c];
+                s2 += (double)f.partial[b][((size_t)p * 2 + 1) * CsPad + c];
+            }
+            if (f.dbeta[b]) f.dbeta[b][c] = (float)s1;
+            if (f.dgamma[b]) f.dgamma[b][c] = (float)s2;
+            const double k = (double)f.gamma[b][c] * is;
+            coef[(size_t)(2 + b) * C + c] = (float)k;
+            A += k * s2;
+            B += k * s1;
+        }
+        A = A * is / (double)M;
+        B = B / (double)M - A * mu;
+        coef[c] = (float)A;
+        coef[(size_t)C + c] = (float)B;
+    }
+}
+
+extern "C" int otvae_bn_bwd_finalize(int nb, const float* const* bn_partial, const int* P, int CsPad, int64_t M, int C,
+                                     const float* mean, const float* invstd, const float* const* gamma, float* const* dgamma,
+                                     float* const* dbeta, float* coef, void* stream) {
+    OTVAE_REQUIRE(nb >= 1 && nb <= 2, "otvae_bn_bwd_finalize: nb must be 1 or 2");
+    OTVAE_REQUIRE(bn_partial && P && mean && invstd && gamma && coef && M > 0 && C > 0 && CsPad >= C,
+                  "otvae_bn_bwd_finalize: bad argument");
+    BnBwdFin f = {};
+    for (int b = 0; b < nb; ++b) {
+        OTVAE_REQUIRE(bn_partial[b] && gamma[b] && P[b] > 0, "otvae_bn_bwd_finalize: NULL branch %d", b);
+        f.partial[b] = bn_partial[b];
+        f.P[b] = P[b];
+        f.gamma[b] = gamma[b];
+        f.dgamma[b] = dgamma ? dgamma[b] : nullptr;
+        f.dbeta[b] = dbeta ? dbeta[b] : nullptr;
+    }
+    bn_bwd_finalize_kernel<<<cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(nb, f, CsPad, M, C, mean, invstd, coef);
+    OTVAE_CHECK_LAUNCH("otvae_bn_bwd_finalize");
+    return OTVAE_OK;
+}
+
+template <int NB, bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g0, const float* __restrict__ g1,
+                                                           const float* __restrict__ x, const float* __restrict__ coef,
+                                                           int64_t total, int C, float* __restrict__ dx) {
+    if constexpr (VEC) {
+        const int64_t n4 = total >> 2;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+            const int c = (int)((i << 2) % C);
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+            const float4 a = *reinterpret_cast<const float4*>(coef + c);
+            const float4 b = *reinterpret_cast<const float4*>(coef + C + c);
+            const float4 k0 = *reinterpret_cast<const float4*>(coef + 2 * (size_t)C + c);
+            const float4 gv0 = reinterpret_cast<const float4*>(g0)[i];
+            float4 r;
+            r.x = fmaf(k0.x, gv0.x, fmaf(-a.x, xv.x, -b.x));
+            r.y = fmaf(k0.y, gv0.y, fmaf(-a.y, xv.y, -b.y));
+            r.z = fmaf(k0.z, gv0.z, fmaf(-a.z, xv.z, -b.z));
+            r.w = fmaf(k0.w, gv0.w, fmaf(-a.w, xv.w, -b.w));
+            if constexpr (NB == 2) {
+                const float4 k1 = *reinterpret_cast<const float4*>(coef + 3 * (size_t)C + c);
+                const float4 gv1 = reinterpret_cast<const float4*>(g1)[i];
+                r.x = fmaf(k1.x, gv1.x, r.x);
+                r.y = fmaf(k1.y, gv1.y, r.y);
+                r.z = fmaf(k1.z, gv1.z, r.z);
+                r.w = fmaf(k1.w, gv1.w, r.w);
+            }
+            reinterpret_cast<float4*>(dx)[i] = r;
+        }
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int c = (int)(i % C);
+            float r = fmaf(coef[2 * (size_t)C + c], g0[i], fmaf(-coef[c], x[i], -coef[(size_t)C + c]));
+            if constexpr (NB == 2) r = fmaf(coef[3 * (size_t)C + c], g1[i], r);
+            dx[i] = r;
+        }
+    }
+}
+
+extern "C" int otvae_bn_bwd_apply(int nb, const float* const* gv, const float* x, const float* coef, int64_t M, int C,
+                                  float* dx, void* stream) {
+    OTVAE_REQUIRE(nb >= 1 && nb <= 2 && gv && gv[0] && x && coef && dx && M > 0 && C > 0, "otvae_bn_bwd_apply: bad argument");
+    OTVAE_REQUIRE(nb == 1 || gv[1], "otvae_bn_bwd_apply: second branch NULL");
+    const int64_t total = M * C;
+    const bool vec = (C % 4 == 0);
+    const int grid = imin(cdiv(vec ? total / 4 : total, 256), 4096);
+    hipStream_t st = (hipStream_t)stream;
+    const float* g1 = nb == 2 ? gv[1] : nullptr;
+    if (nb == 1) {
+        if (vec) bn_bwd_apply_kernel<1, true><<<grid, 256, 0, st>>>(gv[0], g1, x, coef, total, C, dx);
+        else bn_bwd_apply_kernel<1, false><<<grid, 256, 0, st>>>(gv[0], g1, x, coef, total, C, dx);
+    } else {
+        if (vec) bn_bwd_apply_kernel<2, true><<<grid, 256, 0, st>>>(gv[0], g1, x, coef, total, C, dx);
+        else bn_bwd_apply_kernel<2, false><<<grid, 256, 0, st>>>(gv[0], g1, x, coef, total, C, dx);
+    }
+    OTVAE_CHECK_LAUNCH("otvae_bn_bwd_apply");
+    return OTVAE_OK;
+}

@@ -1,0 +1,502 @@
+// fp64 Gaussian optimal-transport arithmetic:
+//   * streaming sufficient statistics (n, sum x, sum x x^T) of GaussianModel.update/_stats
+//     (reference ot/distribution_models/gaussian_model.py:99-108,144-157; utils/__init__.py:204-206)
+//   * mean_cov (ot/matrix_utils.py:145-158)
+//   * eigh-based matrix functions sqrtm / invsqrtm / min_eig / make_psd (ot/matrix_utils.py:37-142) through a
+//     parallel cyclic Jacobi eigensolver that keeps the matrix in LDS (one workgroup per matrix, D <= 128)
+//   * the small dense fp64 products, trace and affine map of w2_gaussian / compute_transport_operators /
+//     apply_transport (ot/w2_utils.py:40-80,756-769,517-520)
+//   * CodebookModel nearest-atom assignment (ot/distribution_models/codebook_model.py:150-160)
+// Everything is reduced in a fixed order (no atomics): results are run-to-run identical.
+#include "common.h"
+
+// ================================================================================================ statistics
+// Augmented sample x' = [x, 1] (dimension D+1): S' = sum_b x' x'^T holds sum x x^T, sum x (last column) and n.
+#define GS_TILE 16
+#define GS_KSPLIT_MAX 16
+
+static int gs_ksplit(int B) { return imax(1, imin(GS_KSPLIT_MAX, B / 64)); }
+
+extern "C" int64_t otvae_gauss_stats_ws(int nb, int B, int D, int diag) {
+    if (nb <= 0 || B <= 0 || D <= 0) return -1;
+    if (diag) return 8;
+    return (int64_t)nb * gs_ksplit(B) * (D + 1) * (D + 1) * (int64_t)sizeof(double);
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void gs_partial_kernel(const TIN* __restrict__ x, int B, int D, int ksplit,
+                                                         double* __restrict__ ws) {
+    __shared__ double xi[GS_TILE][GS_TILE + 1], xj[GS_TILE][GS_TILE + 1];
+    const int D1 = D + 1;
+    const int nt = (D1 + GS_TILE - 1) / GS_TILE;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    const int ks = blockIdx.y, b = blockIdx.z;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int rows_per = (B + ksplit - 1) / ksplit;
+    const int r0 = ks * rows_per, r1 = min(B, r0 + rows_per);
+    const TIN* xb = x + (size_t)b * B * D;
+    double acc = 0.0;
+    for (int r = r0; r < r1; r += GS_TILE) {
+        // stage 16 rows x 16 columns of each operand (column D is the constant 1)
+        const int row = r + ty;
+        const int ci = ti * GS_TILE + tx, cj = tj * GS_TILE + tx;
+        xi[ty][tx] = (row < r1 && ci < D1) ? (ci < D ? (double)xb[(size_t)row * D + ci] : 1.0) : 0.0;
+        xj[ty][tx] = (row < r1 && cj < D1) ? (cj < D ? (double)xb[(size_t)row * D + cj] : 1.0) : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GS_TILE; ++k) acc = fma(xi[k][ty], xj[k][tx], acc);
+        __syncthreads();
+    }
+    const int i = ti * GS_TILE + ty, j = tj * GS_TILE + tx;
+    if (i < D1 && j < D1) ws[(((size_t)b * ksplit + ks) * D1 + i) * D1 + j] = acc;
+}
+
+__global__ __launch_bounds__(256) void gs_final_kernel(const double* __restrict__ ws, int D, int ksplit, int accumulate,
+                                                       double decay, double* __restrict__ n_obs, double* __restrict__ sum_x,
+                                                       double* __restrict__ sum_xx) {
+    const int D1 = D + 1;
+    const int b = blockIdx.y;
+    const size_t total = (size_t)D1 * D1;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int i = e / D1, j = e - (size_t)i * D1;
+        double s = 0.0;
+        for (int k = 0; k < ksplit; ++k) s += ws[((size_t)b * ksplit + k) * total + e];
+        double* dst = nullptr;
+        if (i < D && j < D) dst = sum_xx + ((size_t)b * D + i) * D + j;
+        else if (i < D && j == D) dst = sum_x + (size_t)b * D + i;
+        else if (i == D && j == D) dst = n_obs + b;
+        if (dst) {
+            if (!accumulate) *dst = s;
+            else if (decay < 0.0) *dst = *dst + s;
+            else *dst = *dst * decay + s * (1.0 - decay);
+        }
+    }
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void gs_diag_kernel(const TIN* __restrict__ x, int B, int D, int accumulate, double decay,
+                                                      double* __restrict__ n_obs, double* __restrict__ sum_x,
+                                                      double* __restrict__ sum_xx) {
+    const int b = blockIdx.y;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d < D) {
+        const TIN* xb = x + (size_t)b * B * D;
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < B; ++r) {
+            const double v = (double)xb[(size_t)r * D + d];
+            s += v;
+            q += v * v;
+        }
+        double* ds = sum_x + (size_t)b * D + d;
+        double* dq = sum_xx + (size_t)b * D + d;
+        if (!accumulate) { *ds = s; *dq = q; }
+        else if (decay < 0.0) { *ds += s; *dq += q; }
+        else { *ds = *ds * decay + s * (1.0 - decay); *dq = *dq * decay + q * (1.0 - decay); }
+    }
+    if (d == 0) {
+        const double n = (double)B;
+        if (!accumulate) n_obs[b] = n;
+        else if (decay < 0.0) n_obs[b] += n;
+        else n_obs[b] = n_obs[b] * decay + n * (1.0 - decay);
+    }
+}
+
+extern "C" int otvae_gauss_stats(int in_dtype, const void* samples, int nb, int B, int D, int diag, int accumulate,
+                                 double decay, double* ws, double* n_obs, double* sum_x, double* sum_xx, void* stream) {
+    OTVAE_REQUIRE(samples && n_obs && sum_x && sum_xx && nb > 0 && B > 0 && D > 0, "otvae_gauss_stats: bad argument");
+    OTVAE_REQUIRE(in_dtype == 0 || in_dtype == 1, "otvae_gauss_stats: in_dtype must be 0 or 1");
+    hipStream_t st = (hipStream_t)stream;
+    if (diag) {
+        dim3 grid(cdiv(D, 256), nb);
+        if (in_dtype == 0) gs_diag_kernel<float><<<grid, 256, 0, st>>>((const float*)samples, B, D, accumulate, decay, n_obs, sum_x, sum_xx);
+        else gs_diag_kernel<double><<<grid, 256, 0, st>>>((const double*)samples, B, D, accumulate, decay, n_obs, sum_x, sum_xx);
+        OTVAE_CHECK_LAUNCH("otvae_gauss_stats(diag)");
+        return OTVAE_OK;
+    }
+    OTVAE_REQUIRE(ws, "otvae_gauss_stats: workspace missing");
+    const int ks = gs_ksplit(B);
+    const int nt = cdiv(D + 1, GS_TILE);
+    dim3 grid(nt * nt, ks, nb);
+    if (in_dtype == 0) gs_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)samples, B, D, ks, ws);
+    else gs_partial_kernel<double><<<grid, 256, 0, st>>>((const double*)samples, B, D, ks, ws);
+    OTVAE_CHECK_LAUNCH("otvae_gauss_stats(partial)");
+    gs_final_kernel<<<dim3(imin(cdiv((size_t)(D + 1) * (D + 1), 256), 256), nb), 256, 0, st>>>(ws, D, ks, accumulate, decay, n_obs,
+                                                                                           sum_x, sum_xx);
+    OTVAE_CHECK_LAUNCH("otvae_gauss_stats(final)");
+    return OTVAE_OK;
+}
+
+__global__ __launch_bounds__(256) void mean_cov_kernel(const double* __restrict__ n_obs, const double* __restrict__ sum_x,
+                                                       const double* __restrict__ sum_xx, int D, int diag,
+                                                       double* __restrict__ mean, double* __restrict__ cov) {
+    const int b = blockIdx.y;
+    const double n = n_obs[b];
+    const size_t total = diag ? (size_t)D : (size_t)D * D;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        if (diag) {
+            const double m = sum_x[(size_t)b * D + e] / n;
+            mean[(size_t)b * D + e] = m;
+            cov[(size_t)b * D + e] = sum_xx[(size_t)b * D + e] / n - m * m;
+        } else {
+            const int i = e / D, j = e - (size_t)i * D;
+            const double mi = sum_x[(size_t)b * D + i] / n, mj = sum_x[(size_t)b * D + j] / n;
+            cov[(size_t)b * D * D + e] = sum_xx[(size_t)b * D * D + e] / n - mi * mj;
+            if (j == 0) mean[(size_t)b * D + i] = mi;
+        }
+    }
+}
+
+extern "C" int otvae_mean_cov(const double* n_obs, const double* sum_x, const double* sum_xx, int nb, int D, int diag,
+                              double* mean, double* cov, void* stream) {
+    OTVAE_REQUIRE(n_obs && sum_x && sum_xx && mean && cov && nb > 0 && D > 0, "otvae_mean_cov: bad argument");
+    const size_t total = diag ? (size_t)D : (size_t)D * D;
+    mean_cov_kernel<<<dim3(imin(cdiv(total, 256), 256), nb), 256, 0, (hipStream_t)stream>>>(n_obs, sum_x, sum_xx, D, diag, mean, cov);
+    OTVAE_CHECK_LAUNCH("otvae_mean_cov");
+    return OTVAE_OK;
+}
+
+// ================================================================================================ eigensolver
+// Parallel cyclic Jacobi.  A (symmetrised from its lower triangle) lives in LDS with row stride D+1; the accumulated
+// rotations V^T live in the global workspace (rows = eigenvectors).  Each of the De-1 steps of a sweep rotates De/2
+// disjoint (p,q) pairs at once (round-robin tournament): rows phase | barrier | columns phase | barrier.
+#define EIGH_THREADS 512
+#define EIGH_MAX_D 128
+#define EIGH_MAX_SWEEPS 24
+
+extern "C" int64_t otvae_eigh_ws(int nb, int D) {
+    if (nb <= 0 || D <= 0) return -1;
+    return (int64_t)nb * D * D * (int64_t)sizeof(double);
+}
+
+__global__ __launch_bounds__(EIGH_THREADS) void eigh_kernel(const double* __restrict__ Ain, int D, int fn,
+                                                            double* __restrict__ out, double* __restrict__ eigvals,
+                                                            double* __restrict__ vt_ws) {
+    extern __shared__ __align__(16) double lds[];
+    const int LD = D + 1;
+    const int De = (D + 1) & ~1;  // even number of players; index D (if De > D) is a dummy
+    const int half = De / 2;
+    double* A = lds;                          // [D][LD]
+    double* cs = A + (size_t)D * LD;          // [half]
+    double* sn = cs + half;                   // [half]
+    int* pp = (int*)(sn + half);              // [half]
+    int* qq = pp + half;                      // [half]
+    double* red = (double*)(qq + half);       // [16]  (2*half ints keep 8-byte alignment)
+    const int tid = threadIdx.x;
+    const int nwave = EIGH_THREADS / 64;
+    const size_t boff = (size_t)blockIdx.x * D * D;
+    double* VT = vt_ws + boff;
+    const double* Ab = Ain + boff;
+
+    for (int e = tid; e < D * D; e += EIGH_THREADS) {
+        const int i = e / D, j = e - i * D;
+        A[i * LD + j] = (i >= j) ? Ab[(size_t)i * D + j] : Ab[(size_t)j * D + i];
+        VT[e] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    for (int sweep = 0; sweep < EIGH_MAX_SWEEPS; ++sweep) {
+        // convergence: off-diagonal mass vs total
+        double off = 0.0, tot = 0.0;
+        for (int e = tid; e < D * D; e += EIGH_THREADS) {
+            const int i = e / D, j = e - i * D;
+            const double v = A[i * LD + j];
+            tot += v * v;
+            if (i != j) off += v * v;
+        }
+        off = wave_sum(off);
+        tot = wave_sum(tot);
+        if ((tid & 63) == 0) {
+            red[tid >> 6] = off;
+            red[8 + (tid >> 6)] = tot;
+        }
+        __syncthreads();
+        double offs = 0.0, tots = 0.0;
+        for (int w = 0; w < nwave; ++w) {
+            offs += red[w];
+            tots += red[8 + w];
+        }
+        __syncthreads();
+        if (offs <= 1e-30 * tots || tots == 0.0) break;  // uniform
+
+        for (int step = 0; step < De - 1; ++step) {
+            // rotation parameters
+            if (tid < half) {
+                int p, q;
+                if (tid == 0) {
+                    p = De - 1;
+                    q = step % (De - 1);
+                } else {
+                    p = (step + tid) % (De - 1);
+                    q = (step - tid + (De - 1)) % (De - 1);
+                }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double c = 1.0, s = 0.0;
+                if (q < D) {
+                    const double apq = A[p * LD + q];
+                    if (apq != 0.0) {
+                        const double app = A[p * LD + p], aqq = A[q * LD + q];
+                        const double tau = (aqq - app) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        s = t * c;
+                    }
+                } else {
+                    q = -1;  // dummy pairing: nothing to do
+                }
+                cs[tid] = c;
+                sn[tid] = s;
+                pp[tid] = p;
+                qq[tid] = q;
+            }
+            __syncthreads();
+            // rows: A <- J^T A ; VT <- J^T VT
+            for (int e = tid; e < half * D; e += EIGH_THREADS) {
+                const int k = e / D, j = e - k * D;
+                const int p = pp[k], q = qq[k];
+                if (q < 0) continue;
+                const double c = cs[k], s = sn[k];
+                const double ap = A[p * LD + j], aq = A[q * LD + j];
+                A[p * LD + j] = c * ap - s * aq;
+                A[q * LD + j] = s * ap + c * aq;
+                const double vp = VT[(size_t)p * D + j], vq = VT[(size_t)q * D + j];
+                VT[(size_t)p * D + j] = c * vp - s * vq;
+                VT[(size_t)q * D + j] = s * vp + c * vq;
+            }
+            __syncthreads();
+            // columns: A <- A J
+            for (int e = tid; e < half * D; e += EIGH_THREADS) {
+                const int k = e / D, i = e - k * D;
+                const int p = pp[k], q = qq[k];
+                if (q < 0) continue;
+                const double c = cs[k], s = sn[k];
+                const double ap = A[i * LD + p], aq = A[i * LD + q];
+                A[i * LD + p] = c * ap - s * aq;
+                A[i * LD + q] = s * ap + c * aq;
+            }
+            __syncthreads();
+        }
+    }
+    // eigenvalues and f(lambda)
+    __syncthreads();
+    for (int k = tid; k < D; k += EIGH_THREADS) {
+        const double lam = A[k * LD + k];
+        eigvals[(size_t)blockIdx.x * D + k] = lam;
+    }
+    if (fn == 0 || out == nullptr) return;
+    // stash f(lambda) in A's pad column A[k][D]
+    for (int k = tid; k < D; k += EIGH_THREADS) {
+        const double lam = A[k * LD + k];
+        A[k * LD + D] = (fn == 1) ? sqrt(lam) : 1.0 / sqrt(lam);
+    }
+    __syncthreads();
+    double* ob = out + boff;
+    for (int e = tid; e < D * D; e += EIGH_THREADS) {
+        const int i = e / D, j = e - i * D;
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s = fma(A[k * LD + D] * VT[(size_t)k * D + i], VT[(size_t)k * D + j], s);
+        ob[e] = s;
+    }
+}
+
+static size_t eigh_lds_bytes(int D) {
+    const int De = (D + 1) & ~1, half = De / 2;
+    return ((size_t)D * (D + 1) + 2 * half + 16) * sizeof(double) + (2 * half + 2) * sizeof(int);
+}
+static size_t g_eigh_lds_set = 0;
+
+extern "C" int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, void* stream) {
+    OTVAE_REQUIRE(A && eigvals && ws && nb > 0 && D > 0, "otvae_eigh_fn: bad argument");
+    OTVAE_REQUIRE(fn >= 0 && fn <= 2, "otvae_eigh_fn: fn must be 0, 1 or 2");
+    OTVAE_REQUIRE(fn == 0 || out, "otvae_eigh_fn: out missing");
+    if (D > EIGH_MAX_D) {
+        otvae_set_error("otvae_eigh_fn: D = %d > %d is not implemented (matrix must fit LDS)", D, EIGH_MAX_D);
+        return OTVAE_EUNSUPPORTED;
+    }
+    const size_t lds = eigh_lds_bytes(D);
+    if (lds > 65536 && lds > g_eigh_lds_set) {
+        if (hipFuncSetAttribute((const void*)eigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            otvae_set_error("otvae_eigh_fn: cannot raise dynamic LDS limit");
+            return OTVAE_ELAUNCH;
+        }
+        g_eigh_lds_set = 160 * 1024;
+    }
+    eigh_kernel<<<nb, EIGH_THREADS, lds, (hipStream_t)stream>>>(A, D, fn, out, eigvals, (double*)ws);
+    OTVAE_CHECK_LAUNCH("otvae_eigh_fn");
+    return OTVAE_OK;
+}
+
+// make_psd: A_b += shift_b I, shift_b = |min(lmin_b, 0)| (+1e-8 if strict), optionally only if some matrix fails
+__global__ __launch_bounds__(256) void make_psd_kernel(double* __restrict__ A, const double* __restrict__ eigvals, int nb,
+                                                       int D, int strict, int cond_any) {
+    __shared__ int any_bad;
+    if (threadIdx.x == 0) any_bad = cond_any ? 0 : 1;
+    __syncthreads();
+    if (cond_any) {
+        int bad = 0;
+        for (int b = threadIdx.x; b < nb; b += 256) {
+            double mn = INFINITY;
+            for (int k = 0; k < D; ++k) mn = fmin(mn, eigvals[(size_t)b * D + k]);
+            if (strict ? !(mn > 0.0) : !(mn >= 0.0)) bad = 1;
+        }
+        if (bad) any_bad = 1;  // benign race: all writers store 1
+        __syncthreads();
+    }
+    if (!any_bad) return;
+    for (int b = 0; b < nb; ++b) {
+        double mn = INFINITY;
+        for (int k = 0; k < D; ++k) mn = fmin(mn, eigvals[(size_t)b * D + k]);
+        double shift = fabs(fmin(mn, 0.0));
+        if (strict) shift += 1e-8;
+        for (int i = threadIdx.x; i < D; i += 256) A[((size_t)b * D + i) * D + i] += shift;
+    }
+}
+
+extern "C" int otvae_make_psd(double* A, const double* eigvals, int nb, int D, int strict, int cond_any, void* stream) {
+    OTVAE_REQUIRE(A && eigvals && nb > 0 && D > 0, "otvae_make_psd: bad argument");
+    make_psd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(A, eigvals, nb, D, strict, cond_any);
+    OTVAE_CHECK_LAUNCH("otvae_make_psd");
+    return OTVAE_OK;
+}
+
+// ================================================================================================ dense helpers
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int transA, int transB, int m, int n, int k, double alpha,
+                                                       const double* __restrict__ A, size_t sA, const double* __restrict__ B,
+                                                       size_t sB, double beta, double* __restrict__ Cm) {
+    __shared__ double as[16][17], bs[16][17];
+    const int b = blockIdx.z;
+    const double* Ab = A + (size_t)b * sA;
+    const double* Bb = B + (size_t)b * sB;
+    double* Cb = Cm + (size_t)b * m * n;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < k; k0 += 16) {
+        const int ka = k0 + tx;  // A tile: rows i (ty), cols k (tx)
+        as[ty][tx] = (i < m && ka < k) ? (transA ? Ab[(size_t)ka * m + i] : Ab[(size_t)i * k + ka]) : 0.0;
+        const int kb = k0 + ty;  // B tile: rows k (ty), cols j (tx)
+        bs[ty][tx] = (kb < k && j < n) ? (transB ? Bb[(size_t)j * k + kb] : Bb[(size_t)kb * n + j]) : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = fma(as[ty][kk], bs[kk][tx], acc);
+        __syncthreads();
+    }
+    if (i < m && j < n) {
+        const size_t o = (size_t)i * n + j;
+        Cb[o] = alpha * acc + (beta != 0.0 ? beta * Cb[o] : 0.0);
+    }
+}
+
+extern "C" int otvae_gemm_f64(int transA, int transB, int nb, int m, int n, int k, double alpha, const double* A, int a_bcast,
+                              const double* B, int b_bcast, double beta, double* C, void* stream) {
+    OTVAE_REQUIRE(A && B && C && nb > 0 && m > 0 && n > 0 && k > 0, "otvae_gemm_f64: bad argument");
+    dim3 grid(cdiv(n, 16), cdiv(m, 16), nb);
+    gemm_f64_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(transA, transB, m, n, k, alpha, A, a_bcast ? 0 : (size_t)m * k, B,
+                                                          b_bcast ? 0 : (size_t)k * n, beta, C);
+    OTVAE_CHECK_LAUNCH("otvae_gemm_f64");
+    return OTVAE_OK;
+}
+
+__global__ __launch_bounds__(256) void w2_tail_kernel(const double* __restrict__ ms, const double* __restrict__ mt,
+                                                      const double* __restrict__ cs, const double* __restrict__ ct,
+                                                      const double* __restrict__ sq, int D, double* __restrict__ out) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const double d = ms[(size_t)b * D + i] - mt[(size_t)b * D + i];
+        const size_t dd = ((size_t)b * D + i) * D + i;
+        s += d * d + (cs[dd] + ct[dd] - 2.0 * sq[dd]);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int otvae_w2_tail(const double* ms, const double* mt, const double* cs, const double* ct, const double* sqrt_mix,
+                             int nb, int D, double* out, void* stream) {
+    OTVAE_REQUIRE(ms && mt && cs && ct && sqrt_mix && out && nb > 0 && D > 0, "otvae_w2_tail: bad argument");
+    w2_tail_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(ms, mt, cs, ct, sqrt_mix, D, out);
+    OTVAE_CHECK_LAUNCH("otvae_w2_tail");
+    return OTVAE_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void apply_transport_kernel(const T* __restrict__ x, const double* __restrict__ ms,
+                                                              const double* __restrict__ mt, const double* __restrict__ Tm,
+                                                              int B, int D, T* __restrict__ y) {
+    extern __shared__ double xc[];  // centred sample, D doubles
+    const int b = blockIdx.y, r = blockIdx.x;
+    const T* xr = x + ((size_t)b * B + r) * D;
+    for (int j = threadIdx.x; j < D; j += 256) xc[j] = (double)xr[j] - ms[(size_t)b * D + j];
+    __syncthreads();
+    const double* Tb = Tm + (size_t)b * D * D;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        double s = 0.0;
+        for (int j = 0; j < D; ++j) s = fma(Tb[(size_t)i * D + j], xc[j], s);
+        y[((size_t)b * B + r) * D + i] = (T)(s + mt[(size_t)b * D + i]);
+    }
+}
+
+extern "C" int otvae_apply_transport(int dtype, const void* x, const double* ms, const double* mt, const double* T, int nb,
+                                     int B, int D, void* y, void* stream) {
+    OTVAE_REQUIRE(x && ms && mt && T && y && nb > 0 && B > 0 && D > 0, "otvae_apply_transport: bad argument");
+    OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_apply_transport: dtype must be 0 or 1");
+    OTVAE_REQUIRE(D <= 4096, "otvae_apply_transport: D too large");
+    dim3 grid(B, nb);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        apply_transport_kernel<float><<<grid, 256, D * sizeof(double), st>>>((const float*)x, ms, mt, T, B, D, (float*)y);
+    else
+        apply_transport_kernel<double><<<grid, 256, D * sizeof(double), st>>>((const double*)x, ms, mt, T, B, D, (double*)y);
+    OTVAE_CHECK_LAUNCH("otvae_apply_transport");
+    return OTVAE_OK;
+}
+
+// ================================================================================================ codebook
+// idx = argmax_k 1/(|x - c_k|_2 + 1e-8) / temperature  (softmax is monotone, so the arg-max of the weights);
+// first index wins ties like torch.argmax.  One wave per sample, atoms strided over lanes.
+__global__ __launch_bounds__(256) void codebook_assign_kernel(const float* __restrict__ x, const float* __restrict__ cb, int B,
+                                                              int K, int d, float inv_temp, int64_t* __restrict__ idx,
+                                                              float* __restrict__ enc) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (r >= B) return;
+    const float* xr = x + ((size_t)b * B + r) * d;
+    const float* cbb = cb + (size_t)b * K * d;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+        float s = 0.f;
+        for (int j = 0; j < d; ++j) {
+            const float t = xr[j] - cbb[(size_t)k * d + j];
+            s = fmaf(t, t, s);
+        }
+        const float e = (1.f / (sqrtf(s) + 1e-8f)) * inv_temp;
+        if (e > best) {
+            best = e;
+            besti = k;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) {
+            best = ob;
+            besti = oi;
+        }
+    }
+    if (lane == 0) idx[(size_t)b * B + r] = besti;
+    for (int j = lane; j < d; j += 64) enc[((size_t)b * B + r) * d + j] = cbb[(size_t)besti * d + j];
+}
+
+extern "C" int otvae_codebook_assign(const float* x, const float* codebook, int nb, int B, int K, int d, float temperature,
+                                     int64_t* idx, float* enc, void* stream) {
+    OTVAE_REQUIRE(x && codebook && idx && enc && nb > 0 && B > 0 && K > 0 && d > 0, "otvae_codebook_assign: bad argument");
+    OTVAE_REQUIRE(temperature > 0.f, "otvae_codebook_assign: temperature must be positive");
+    codebook_assign_kernel<<<dim3(cdiv(B, 4), nb), 256, 0, (hipStream_t)stream>>>(x, codebook, B, K, d, 1.f / temperature, idx, enc);
+    OTVAE_CHECK_LAUNCH("otvae_codebook_assign");
+    return OTVAE_OK;
+}

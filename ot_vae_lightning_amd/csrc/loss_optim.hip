@@ -1,0 +1,204 @@
+// GaussianPrior re-parametrisation + closed-form KL (reference prior/gaussian.py:63-96, prior/base.py:74-78),
+// the nelbo reduction of VAE.nelbo (model/vae.py:158-176) and the Adam update configured by
+// VAE.configure_optimizers (model/vae.py:148-151), each fused into one pass over its data.
+#include "common.h"
+
+// ---- GaussianPrior ------------------------------------------------------------------------------------------
+// h [B][S][2D]: mu = h[..., :D], log_var = h[..., D:]; one workgroup per sample.
+__global__ __launch_bounds__(256) void gaussian_prior_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                                                 int S, int D, float coeff, float* __restrict__ z,
+                                                                 float* __restrict__ loss) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int n = S * D;
+    const float* hb = h + (size_t)b * S * 2 * D;
+    float kl = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int s = i / D, d = i - s * D;
+        const float mu = hb[(size_t)s * 2 * D + d];
+        const float lv = hb[(size_t)s * 2 * D + D + d];
+        const float sd = __expf(0.5f * lv);
+        const float var = sd * sd;
+        z[(size_t)b * n + i] = fmaf(eps[(size_t)b * n + i], sd, mu);
+        kl += 0.5f * (mu * mu - __logf(var) + var - 1.f);
+    }
+    kl = wave_sum(kl);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kl;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[b] = coeff * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void gaussian_prior_bwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                                                 const float* __restrict__ gz, const float* __restrict__ gloss,
+                                                                 int S, int D, float coeff, float* __restrict__ gh) {
+    const int b = blockIdx.x;
+    const int n = S * D;
+    const float* hb = h + (size_t)b * S * 2 * D;
+    float* gb = gh + (size_t)b * S * 2 * D;
+    const float gl = (gloss ? gloss[b] : 0.f) * coeff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int s = i / D, d = i - s * D;
+        const float mu = hb[(size_t)s * 2 * D + d];
+        const float lv = hb[(size_t)s * 2 * D + D + d];
+        const float sd = __expf(0.5f * lv);
+        const float g = gz ? gz[(size_t)b * n + i] : 0.f;
+        gb[(size_t)s * 2 * D + d] = fmaf(gl, mu, g);
+        // d z/d lv = eps*sd/2 ; d KL/d lv = (var - 1)/2
+        gb[(size_t)s * 2 * D + D + d] = 0.5f * (g * eps[(size_t)b * n + i] * sd + gl * (sd * sd - 1.f));
+    }
+}
+
+extern "C" int otvae_gaussian_prior_fwd(const float* h, const float* eps, int B, int S, int D, float coeff, float* z,
+                                        float* loss, void* stream) {
+    OTVAE_REQUIRE(h && eps && z && loss && B > 0 && S > 0 && D > 0, "otvae_gaussian_prior_fwd: bad argument");
+    gaussian_prior_fwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(h, eps, S, D, coeff, z, loss);
+    OTVAE_CHECK_LAUNCH("otvae_gaussian_prior_fwd");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_gaussian_prior_bwd(const float* h, const float* eps, const float* gz, const float* gloss, int B, int S,
+                                        int D, float coeff, float* gh, void* stream) {
+    OTVAE_REQUIRE(h && eps && gh && B > 0 && S > 0 && D > 0, "otvae_gaussian_prior_bwd: bad argument");
+    gaussian_prior_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(h, eps, gz, gloss, S, D, coeff, gh);
+    OTVAE_CHECK_LAUNCH("otvae_gaussian_prior_bwd");
+    return OTVAE_OK;
+}
+
+// ---- nelbo ---------------------------------------------------------------------------------------------------
+#define NELBO_PARTS 256
+extern "C" int otvae_nelbo_ws(void) { return NELBO_PARTS + 8; }
+
+__global__ __launch_bounds__(256) void nelbo_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                            int64_t numel, double* __restrict__ ws) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float d = pred[i] - target[i];
+        s += (double)(d * d);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void nelbo_final_kernel(const double* __restrict__ ws, int parts, int64_t numel,
+                                                          const float* __restrict__ prior_loss, int B, float chw,
+                                                          float* __restrict__ out) {
+    __shared__ double red[4];
+    __shared__ double pr[4];
+    double s = 0.0, p = 0.0;
+    for (int i = threadIdx.x; i < parts; i += 256) s += ws[i];
+    if (prior_loss)
+        for (int i = threadIdx.x; i < B; i += 256) p += (double)prior_loss[i];
+    s = wave_sum(s);
+    p = wave_sum(p);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s;
+        pr[threadIdx.x >> 6] = p;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float recon = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)numel);
+        const float prior = (float)(((pr[0] + pr[1]) + (pr[2] + pr[3])) / (double)B) / chw;
+        out[0] = recon + prior;
+        out[1] = recon;
+        out[2] = prior;
+    }
+}
+
+extern "C" int otvae_nelbo_fwd(const float* pred, const float* target, int64_t numel, const float* prior_loss, int B,
+                               float chw, double* ws, float* out, void* stream) {
+    OTVAE_REQUIRE(pred && target && ws && out && numel > 0 && B > 0 && chw > 0, "otvae_nelbo_fwd: bad argument");
+    const int parts = imin(NELBO_PARTS, cdiv(numel, 1024));
+    hipStream_t st = (hipStream_t)stream;
+    nelbo_partial_kernel<<<parts, 256, 0, st>>>(pred, target, numel, ws);
+    OTVAE_CHECK_LAUNCH("otvae_nelbo_fwd(partial)");
+    nelbo_final_kernel<<<1, 256, 0, st>>>(ws, parts, numel, prior_loss, B, chw, out);
+    OTVAE_CHECK_LAUNCH("otvae_nelbo_fwd(final)");
+    return OTVAE_OK;
+}
+
+__global__ __launch_bounds__(256) void nelbo_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        int64_t numel, int B, float chw, const float* __restrict__ gout,
+                                                        float* __restrict__ gpred, float* __restrict__ gprior) {
+    // out = {total = recon + prior, recon, prior}: d/d recon = g[0]+g[1], d/d prior = g[0]+g[2]
+    const float gr = gout ? gout[0] + gout[1] : 1.f;
+    const float gp = gout ? gout[0] + gout[2] : 1.f;
+    const float k = 2.f * gr / (float)numel;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256)
+        gpred[i] = k * (pred[i] - target[i]);
+    if (gprior && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < B; i += 256) gprior[i] = gp / ((float)B * chw);
+}
+
+extern "C" int otvae_nelbo_bwd(const float* pred, const float* target, int64_t numel, int B, float chw, const float* gout,
+                               float* gpred, float* gprior, void* stream) {
+    OTVAE_REQUIRE(pred && target && gpred && numel > 0 && B > 0, "otvae_nelbo_bwd: bad argument");
+    nelbo_bwd_kernel<<<imin(cdiv(numel, 256), 2048), 256, 0, (hipStream_t)stream>>>(pred, target, numel, B, chw, gout, gpred,
+                                                                                 gprior);
+    OTVAE_CHECK_LAUNCH("otvae_nelbo_bwd");
+    return OTVAE_OK;
+}
+
+// ---- Adam ----------------------------------------------------------------------------------------------------
+__global__ void step_begin_kernel(int32_t* step) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;
+}
+
+extern "C" int otvae_step_begin(int32_t* step, void* stream) {
+    OTVAE_REQUIRE(step, "otvae_step_begin: NULL step");
+    step_begin_kernel<<<1, 64, 0, (hipStream_t)stream>>>(step);
+    OTVAE_CHECK_LAUNCH("otvae_step_begin");
+    return OTVAE_OK;
+}
+
+// torch.optim.Adam (no weight decay / amsgrad): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, const float* __restrict__ hyper,
+                                                   const int32_t* __restrict__ step, float grad_scale) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+    const int t = *step;
+    const float bc1 = 1.f - powf(b1, (float)t);
+    const float bc2s = sqrtf(1.f - powf(b2, (float)t));
+    const float step_size = lr / bc1;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+#define ADAM1(f)                                            \
+    {                                                       \
+        const float gg = gv.f * grad_scale;                 \
+        mv.f = fmaf(b1, mv.f, (1.f - b1) * gg);             \
+        vv.f = fmaf(b2, vv.f, (1.f - b2) * gg * gg);        \
+        pv.f -= step_size * mv.f / (sqrtf(vv.f) / bc2s + eps); \
+    }
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // tail
+    for (int64_t i = (n4 << 2) + blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gg = g[i] * grad_scale;
+        const float mm = fmaf(b1, m[i], (1.f - b1) * gg);
+        const float vv = fmaf(b2, v[i], (1.f - b2) * gg * gg);
+        m[i] = mm;
+        v[i] = vv;
+        p[i] -= step_size * mm / (sqrtf(vv) / bc2s + eps);
+    }
+}
+
+extern "C" int otvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                               const int32_t* step, float grad_scale, void* stream) {
+    OTVAE_REQUIRE(p && g && m && v && hyper && step && n > 0, "otvae_adam_step: bad argument");
+    OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                  "otvae_adam_step: buffers must be 16-byte aligned");
+    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, step, grad_scale);
+    OTVAE_CHECK_LAUNCH("otvae_adam_step");
+    return OTVAE_OK;
+}
