@@ -1,0 +1,232 @@
+"""MI355X training engine for the VAE hot path: one training step = forward + backward + (gradient all-reduce) + Adam,
+replayed as a hipGraph.
+
+Design (DESIGN.md section "engine"):
+  * all trainable parameters live in ONE flat fp32 buffer (each ``nn.Parameter`` is a strided view into it, conv weights
+    in HWIO order); gradients, Adam moments and the dgrad-layout weight copies have flat buffers of their own;
+  * backward kernels write parameter gradients straight into the flat gradient buffer (``p._otvae_grad_view``), so a
+    step needs no gradient zeroing, no per-parameter accumulate kernels and exactly one Adam launch;
+  * data parallel = one process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI): every rank runs the
+    step on its shard of the batch with rank-local BatchNorm statistics (the reference does not sync BN, SURVEY.md
+    section 2.2), then ONE all-reduce(SUM) of the flat gradient buffer (6.6 MiB for the MNIST config) on a side stream,
+    and Adam consumes ``grad / world_size``;
+  * the whole step is captured once (``torch.cuda.CUDAGraph`` -> hipGraph) and replayed: no Python, no allocator and no
+    launch-latency gaps between the ~400 kernels of a step.  With more than one rank the graph is split around the
+    collective (graph A: forward+backward, eager RCCL all-reduce, graph B: Adam).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .. import _lib
+from .._lib import check, ptr, stream
+from ..networks.cnn import ConvLayer
+
+__all__ = ["HipTrainer", "flatten_parameters"]
+
+
+def _dense_view(flat: Tensor, off: int, like: Tensor) -> Tensor:
+    """A view of ``flat[off: off+numel]`` with ``like``'s shape and (dense, possibly permuted) strides."""
+    order = sorted(range(like.dim()), key=lambda d: (-like.stride(d), d))
+    phys_shape = [like.shape[d] for d in order]
+    inv = [order.index(d) for d in range(like.dim())]
+    v = flat[off: off + like.numel()].view(phys_shape)
+    return v.permute(inv) if like.dim() > 0 else v.view(())
+
+
+def flatten_parameters(params: List[torch.nn.Parameter], align: int = 4):
+    """Moves ``params`` into one flat buffer (keeping values, shapes and stride order).  Returns (flat, offsets)."""
+    device, dtype = params[0].device, params[0].dtype
+    offsets, total = [], 0
+    for p in params:
+        if p.dtype != dtype or p.device != device:
+            raise TypeError("all parameters must share dtype and device")
+        offsets.append(total)
+        total += (p.numel() + align - 1) // align * align
+    flat = torch.zeros(total, device=device, dtype=dtype)
+    with torch.no_grad():
+        for p, off in zip(params, offsets):
+            v = _dense_view(flat, off, p.data)
+            v.copy_(p.data)
+            p.data = v
+    return flat, offsets
+
+
+class HipTrainer:
+    """Runs ``model.nelbo`` training steps on the GPU.
+
+    trainer = HipTrainer(model, batch_shape=(1024, 1, 32, 32))
+    out = trainer.step(x)          # device tensor [total, recon, prior]; no host sync
+    """
+
+    def __init__(self, model, batch_shape, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 process_group=None, use_graph: bool = True, latent_stats=None):
+        self.lib = _lib.load()
+        self.model = model
+        self.params = list(model.optim_parameters())
+        if not self.params:
+            raise ValueError("model has no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("HipTrainer needs the model on the GPU (model.cuda()); there is no CPU path")
+        self.device = dev
+        self.pflat, self.offsets = flatten_parameters(self.params)
+        self.gflat = torch.zeros_like(self.pflat)
+        self.m = torch.zeros_like(self.pflat)
+        self.v = torch.zeros_like(self.pflat)
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps], device=dev, dtype=torch.float32)
+        self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
+        for p, off in zip(self.params, self.offsets):
+            p._otvae_grad_view = (lambda off=off, p=p: _dense_view(self.gflat, off, p.data))
+        # dgrad-layout ([T][Cout][Cin]) copies of every conv weight, refreshed at the start of each step
+        self.conv_weights = [mod.weight for mod in model.modules() if isinstance(mod, ConvLayer)]
+        wd_total = sum((w.numel() + 3) // 4 * 4 for w in self.conv_weights)
+        self.wdflat = torch.empty(wd_total, device=dev, dtype=torch.float32)
+        off = 0
+        for w in self.conv_weights:
+            w._otvae_wd = self.wdflat[off: off + w.numel()]
+            off += (w.numel() + 3) // 4 * 4
+        # distributed
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        # static I/O
+        self.x = torch.zeros(batch_shape, device=dev, dtype=torch.float32)
+        lat = (batch_shape[0], *model.latent_size)
+        self.eps = torch.zeros(lat, device=dev, dtype=torch.float32)
+        self.latent_stats = latent_stats  # optional TransportOperator fed with the step's latents (LatentTransport)
+        self.out: Optional[Tensor] = None
+        self.latents: Optional[Tensor] = None
+        self.use_graph = use_graph
+        self._graph_fb = None
+        self._graph_opt = None
+        self._captured = False
+        self.n_steps = 0
+
+    # -- pieces of a step ----------------------------------------------------------------------------------------
+    def _refresh_wd(self):
+        lib = self.lib
+        for w in self.conv_weights:
+            cn, cs, kh, kw = w.shape
+            check(lib.otvae_weight_transpose(ptr(w), ptr(w._otvae_wd), kh * kw, cs, cn, stream()),
+                  "otvae_weight_transpose")
+
+    def _forward_backward(self):
+        check(self.lib.otvae_step_begin(ptr(self.step_count), stream()), "otvae_step_begin")
+        self._refresh_wd()
+        for p in self.params:
+            p.grad = None
+        batch = {"samples": self.x, "target": self.x, "kwargs": {"eps": self.eps}}
+        loss, logs, art = self.model.nelbo(batch, 0)
+        loss.backward()
+        self._logs = logs
+        self.latents = art["latents"].detach()
+        if self.latent_stats is not None:
+            lat = self.latents.flatten(1)  # [B, D] with transport_dims = (1, 2, 3)
+            self.latent_stats.update(target_samples=lat)
+        return logs
+
+    def _adam(self):
+        check(self.lib.otvae_adam_step(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
+                                       ptr(self.hyper), ptr(self.step_count), 1.0 / self.world, stream()),
+              "otvae_adam_step")
+
+    def _allreduce(self):
+        if self.world > 1:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def _eager_step(self):
+        logs = self._forward_backward()
+        self._allreduce()
+        self._adam()
+        return logs
+
+    # -- graph capture -------------------------------------------------------------------------------------------
+    def _loss_vector(self, logs):
+        out3 = getattr(self.model, "_last_out3", None)  # the fused nelbo kernel's [total, recon, prior] vector
+        if out3 is not None:
+            return out3
+        return torch.stack([logs["train/loss/total"].detach(), logs["train/loss/recon"].detach(),
+                            logs["train/loss/prior"].detach()])
+
+    def capture(self, warmup: int = 2):
+        """Warm-up eagerly on a side stream (allocator + lazy kernel loading), then capture."""
+        if self._captured or not self.use_graph:
+            return
+        snap = (self.pflat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone())
+        bn_state = {k: v.clone() for k, v in self.model.state_dict().items() if "running_" in k or "num_batches" in k}
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._graph_fb = torch.cuda.CUDAGraph()
+        if self.world == 1:
+            with torch.cuda.graph(self._graph_fb):
+                logs = self._forward_backward()
+                self._adam()
+                self._out_static = self._loss_vector(logs)
+        else:
+            with torch.cuda.graph(self._graph_fb):
+                logs = self._forward_backward()
+                self._out_static = self._loss_vector(logs)
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt):
+                self._adam()
+        # the warm-up/capture must not count as training: restore parameters, moments, step and BN buffers
+        with torch.no_grad():
+            self.pflat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self.step_count.copy_(snap[3])
+            sd = self.model.state_dict()
+            for k, v in bn_state.items():
+                sd[k].copy_(v)
+            if self.latent_stats is not None:
+                self.latent_stats.reset()
+        torch.cuda.synchronize()
+        self._captured = True
+
+    # -- public --------------------------------------------------------------------------------------------------
+    def load_batch(self, x: Tensor, eps: Optional[Tensor] = None):
+        """Device-to-device copy of the next batch into the static input (and optional explicit eps)."""
+        self.x.copy_(x, non_blocking=True)
+        if eps is not None:
+            self.eps.copy_(eps.reshape(self.eps.shape), non_blocking=True)
+        else:
+            self.eps.normal_()
+
+    def step(self, x: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> Tensor:
+        """One optimisation step.  Returns a device tensor [total, recon, prior] (valid until the next step)."""
+        if x is not None:
+            self.load_batch(x, eps)
+        elif eps is None:
+            self.eps.normal_()
+        annealing = getattr(getattr(self.model, "prior", None), "annealing_steps", 0) > self.n_steps
+        if self.use_graph and not annealing:  # the annealing coefficient is a kernel argument: not replayable
+            if not self._captured:
+                self.capture()
+            self._graph_fb.replay()
+            if self.world > 1:
+                self._allreduce()
+                self._graph_opt.replay()
+            out = self._out_static
+        else:
+            logs = self._eager_step()
+            out = self._loss_vector(logs)
+        self.n_steps += 1
+        try:
+            self.model.global_step = self.n_steps
+        except AttributeError:  # Lightning owns global_step
+            pass
+        return out
+
+    def set_lr(self, lr: float):
+        self.hyper[0] = lr

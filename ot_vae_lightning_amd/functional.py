@@ -1,0 +1,418 @@
+"""Autograd-aware wrappers over the C ABI (``include/otvae.h``): the only place where tensors meet kernels.
+
+Layout contract: every 4-D activation handled here has the reference's logical shape ``[N, C, H, W]`` but
+channels-last (NHWC) memory; conv weights keep the logical ``[Cout, Cin, KH, KW]`` shape on HWIO memory.
+``as_nhwc`` / ``hwio_weight`` convert foreign tensors once at the boundary.
+
+Nothing here computes on the CPU: tensors must be on the GPU and the HIP library must be loadable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import ConvGeom, check, ptr, ptr_array, stream
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------------ layout helpers
+def is_nhwc(x: Tensor) -> bool:
+    """True if the memory of the logical [N,C,H,W] tensor is dense NHWC (size-1 dims may have any stride)."""
+    if x.dim() != 4:
+        return False
+    n, c, h, w = x.shape
+    want = (h * w * c, 1, w * c, c)
+    for size, st, ws in zip(x.shape, x.stride(), want):
+        if size != 1 and st != ws:
+            return False
+    return True
+
+
+def as_nhwc(x: Tensor) -> Tensor:
+    """Returns a tensor with the same logical shape/values whose memory is dense NHWC (no copy if it already is)."""
+    if is_nhwc(x):
+        return x
+    return x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def empty_nhwc(n: int, c: int, h: int, w: int, like: Tensor, dtype=None) -> Tensor:
+    return torch.empty((n, h, w, c), device=like.device, dtype=dtype or like.dtype).permute(0, 3, 1, 2)
+
+
+def is_hwio(w: Tensor) -> bool:
+    co, ci, kh, kw = w.shape
+    want = (1, co, kw * ci * co, ci * co)
+    return all(size == 1 or st == ws for size, st, ws in zip(w.shape, w.stride(), want))
+
+
+def hwio_weight(w: Tensor) -> Tensor:
+    """Logical OIHW tensor on HWIO memory (no copy if it already is)."""
+    if is_hwio(w):
+        return w
+    return w.permute(2, 3, 1, 0).contiguous().permute(3, 2, 0, 1)
+
+
+def new_hwio(co: int, ci: int, kh: int, kw: int, device=None, dtype=torch.float32) -> Tensor:
+    return torch.empty((kh, kw, ci, co), device=device, dtype=dtype).permute(3, 2, 0, 1)
+
+
+def _grad_buffer(param: Optional[Tensor], like: Tensor) -> Tensor:
+    """Where a parameter gradient is written: the trainer's flat-buffer slot if the parameter has one
+    (``param._otvae_grad_view()``), else a fresh tensor with the parameter's strides."""
+    if param is not None:
+        getter = getattr(param, "_otvae_grad_view", None)
+        if getter is not None:
+            return getter()
+    return torch.empty_strided(like.shape, like.stride(), device=like.device, dtype=like.dtype)
+
+
+def _geom(x: Tensor, weight: Tensor, stride: int, pad: int, up: int) -> Tuple[ConvGeom, int, int]:
+    n, cs, hs, ws = x.shape
+    cn, ci, kh, kw = weight.shape
+    if ci != cs:
+        raise ValueError(f"conv: input has {cs} channels but weight expects {ci}")
+    ho = (hs * up + 2 * pad - kh) // stride + 1
+    wo = (ws * up + 2 * pad - kw) // stride + 1
+    return ConvGeom(n, hs, ws, cs, up, ho, wo, cn, kh, kw, stride, pad), ho, wo
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm stats
+class BNBranch:
+    """What one ConvLayer contributes to a (possibly shared) BatchNorm statistics pass."""
+    __slots__ = ("gamma", "beta", "running_mean", "running_var", "num_batches_tracked")
+
+    def __init__(self, gamma, beta, running_mean=None, running_var=None, num_batches_tracked=None):
+        self.gamma, self.beta = gamma, beta
+        self.running_mean, self.running_var, self.num_batches_tracked = running_mean, running_var, num_batches_tracked
+
+
+@torch.no_grad()
+def bn_batch_stats(x: Tensor, branches: Sequence[BNBranch], update_running: bool = True):
+    """Training-mode statistics of x (NHWC) shared by all ``branches``: returns mean, invstd and one
+    (scale, shift) pair per branch; updates the running buffers like nn.BatchNorm2d (networks/cnn.py:122)."""
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    m = n * h * w
+    p = lib.otvae_bn_stats_nparts(m, c)
+    partial = torch.empty((p, 2, c), device=x.device, dtype=torch.float64)
+    check(lib.otvae_bn_stats(ptr(x), m, c, ptr(partial), stream()), "otvae_bn_stats")
+    mean = torch.empty(c, device=x.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    scales = [torch.empty_like(mean) for _ in branches]
+    shifts = [torch.empty_like(mean) for _ in branches]
+    nb = len(branches)
+    upd = update_running
+    check(lib.otvae_bn_finalize(
+        ptr(partial), p, m, c, BN_EPS, BN_MOMENTUM, ptr(mean), ptr(invstd), nb,
+        ptr_array([b.gamma for b in branches]), ptr_array([b.beta for b in branches]),
+        ptr_array([b.running_mean if upd else None for b in branches]),
+        ptr_array([b.running_var if upd else None for b in branches]),
+        ptr_array([b.num_batches_tracked if upd else None for b in branches]),
+        ptr_array(scales), ptr_array(shifts), stream()), "otvae_bn_finalize")
+    return mean, invstd, scales, shifts
+
+
+@torch.no_grad()
+def bn_eval_affine(branch: BNBranch):
+    """Inference-mode BatchNorm as a fixed affine (running statistics)."""
+    invstd = torch.rsqrt(branch.running_var + BN_EPS)
+    scale = branch.gamma * invstd
+    shift = branch.beta - branch.running_mean * scale
+    return branch.running_mean.clone(), invstd, scale, shift
+
+
+# ------------------------------------------------------------------------------------------------ fused ConvLayer(s)
+class ConvSpec:
+    """Static description of one ConvLayer branch (everything that is not a tensor)."""
+    __slots__ = ("stride", "pad", "up", "relu", "has_norm", "has_bias", "has_residual")
+
+    def __init__(self, stride, pad, up, relu, has_norm, has_bias, has_residual=False):
+        self.stride, self.pad, self.up, self.relu = stride, pad, up, relu
+        self.has_norm, self.has_bias, self.has_residual = has_norm, has_bias, has_residual
+
+
+class _ConvBNFn(torch.autograd.Function):
+    """1 or 2 ConvLayers reading the same input x (ConvBlock.block[0] and ConvBlock.skip normalise and convolve the
+    same tensor, networks/cnn.py:311-335).  Per branch the tensor inputs are (weight, bias, gamma, beta, residual),
+    missing ones passed as None."""
+
+    @staticmethod
+    def forward(ctx, x, specs, stats, params_ref, *tensors):
+        lib = _lib.load()
+        nbr = len(specs)
+        ctx.specs, ctx.stats, ctx.params_ref = specs, stats, params_ref
+        mean, invstd, scales, shifts, training = stats
+        outs = []
+        geoms = []
+        for b, sp in enumerate(specs):
+            w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
+            g, ho, wo = _geom(x, w, sp.stride, sp.pad, sp.up)
+            y = empty_nhwc(x.shape[0], w.shape[0], ho, wo, x)
+            check(lib.otvae_conv_fwd(C.byref(g), ptr(x), ptr(scales[b]) if sp.has_norm else None,
+                                     ptr(shifts[b]) if sp.has_norm else None, int(sp.relu), ptr(w), ptr(bias), ptr(res),
+                                     ptr(y), stream()), "otvae_conv_fwd")
+            outs.append(y)
+            geoms.append(g)
+        ctx.geoms = geoms
+        ctx.save_for_backward(x, *tensors)
+        return outs[0] if nbr == 1 else tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        lib = _lib.load()
+        specs, geoms = ctx.specs, ctx.geoms
+        mean, invstd, scales, shifts, training = ctx.stats
+        saved = ctx.saved_tensors
+        x, tensors = saved[0], saved[1:]
+        nbr = len(specs)
+        n, cs, hs, ws = x.shape
+        m_in = n * hs * ws
+        need_dx = ctx.needs_input_grad[0]
+        grads: List[Optional[Tensor]] = []
+        gvs, partials, ps = [], [], []
+        cspad = 0
+        per_branch = []
+        for b, sp in enumerate(specs):
+            w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
+            pw, pb, pgam, pbet = ctx.params_ref[b]
+            gy = gys[b]
+            if gy is None:
+                gy = torch.zeros_like(empty_nhwc(n, w.shape[0], geoms[b].Ho, geoms[b].Wo, x))
+            gy = as_nhwc(gy)
+            g = geoms[b]
+            # --- weight / bias gradient
+            p_w = C.c_int(0)
+            check(lib.otvae_conv_bwd_weight_ws(C.byref(g), int(sp.has_bias), C.byref(p_w)), "otvae_conv_bwd_weight_ws")
+            kk = g.KH * g.KW * g.Cs + (1 if sp.has_bias else 0)
+            wpart = torch.empty((p_w.value, kk, g.Cn), device=x.device, dtype=torch.float32)
+            gw = _grad_buffer(pw, w)
+            gb = _grad_buffer(pb, bias) if sp.has_bias else None
+            check(lib.otvae_conv_bwd_weight(C.byref(g), ptr(x), ptr(scales[b]) if sp.has_norm else None,
+                                            ptr(shifts[b]) if sp.has_norm else None, int(sp.relu), ptr(gy),
+                                            int(sp.has_bias), ptr(wpart), ptr(gw), ptr(gb), stream()),
+                  "otvae_conv_bwd_weight")
+            # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
+            gv = None
+            part = None
+            if need_dx or sp.has_norm:
+                wd = getattr(pw, "_otvae_wd", None) if pw is not None else None
+                if wd is None:
+                    wd = torch.empty(g.KH * g.KW * g.Cn * g.Cs, device=x.device, dtype=torch.float32)
+                    check(lib.otvae_weight_transpose(ptr(w), ptr(wd), g.KH * g.KW, g.Cs, g.Cn, stream()),
+                          "otvae_weight_transpose")
+                p_d, cp = C.c_int(0), C.c_int(0)
+                check(lib.otvae_conv_bwd_data_ws(C.byref(g), C.byref(p_d), C.byref(cp)), "otvae_conv_bwd_data_ws")
+                gv = empty_nhwc(n, cs, hs, ws, x)
+                if sp.has_norm:
+                    part = torch.empty((p_d.value, 2, cp.value), device=x.device, dtype=torch.float32)
+                    cspad = cp.value
+                check(lib.otvae_conv_bwd_data(C.byref(g), ptr(gy), ptr(wd), ptr(x),
+                                              ptr(scales[b]) if sp.has_norm else None,
+                                              ptr(shifts[b]) if sp.has_norm else None, int(sp.relu),
+                                              ptr(mean) if sp.has_norm else None, ptr(invstd) if sp.has_norm else None,
+                                              ptr(gv), ptr(part), stream()), "otvae_conv_bwd_data")
+                if sp.has_norm:
+                    ps.append(p_d.value)
+            per_branch.append((gw, gb, gv, part, gy if sp.has_residual else None))
+        # --- BatchNorm backward over the branches that have one
+        bn_idx = [b for b, sp in enumerate(specs) if sp.has_norm]
+        dgam = {b: None for b in range(nbr)}
+        dbet = {b: None for b in range(nbr)}
+        dx = None
+        if bn_idx:
+            nbn = len(bn_idx)
+            coef = torch.empty((2 + nbn, cs), device=x.device, dtype=torch.float32)
+            gam_t = [tensors[5 * b + 2] for b in bn_idx]
+            for b in bn_idx:
+                dgam[b] = _grad_buffer(ctx.params_ref[b][2], tensors[5 * b + 2])
+                dbet[b] = _grad_buffer(ctx.params_ref[b][3], tensors[5 * b + 3])
+            parr = (C.c_int * nbn)(*ps)
+            check(lib.otvae_bn_bwd_finalize(nbn, ptr_array([per_branch[b][3] for b in bn_idx]), parr, cspad, m_in, cs,
+                                            ptr(mean), ptr(invstd), ptr_array(gam_t),
+                                            ptr_array([dgam[b] for b in bn_idx]), ptr_array([dbet[b] for b in bn_idx]),
+                                            ptr(coef), stream()), "otvae_bn_bwd_finalize")
+            if need_dx:
+                if not training:
+                    coef[:2].zero_()  # eval mode: BatchNorm is a fixed affine, no batch-statistics terms
+                dx = empty_nhwc(n, cs, hs, ws, x)
+                check(lib.otvae_bn_bwd_apply(nbn, ptr_array([per_branch[b][2] for b in bn_idx]), ptr(x), ptr(coef),
+                                             m_in, cs, ptr(dx), stream()), "otvae_bn_bwd_apply")
+        if need_dx:
+            for b, sp in enumerate(specs):
+                if not sp.has_norm:
+                    dx = per_branch[b][2] if dx is None else dx + per_branch[b][2]
+        out: List[Optional[Tensor]] = [dx if need_dx else None, None, None, None]
+        for b in range(nbr):
+            gw, gb, gv, part, gres = per_branch[b]
+            out += [gw, gb, dgam[b], dbet[b], gres]
+        return tuple(out)
+
+
+def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
+    """Runs 1 or 2 ConvLayer branches on the same input.  Each branch dict has:
+    weight (OIHW/HWIO), bias|None, gamma|None, beta|None, running_mean/var/num_batches_tracked|None,
+    residual|None, stride, pad, up, relu.  Returns one tensor per branch (logical NCHW, NHWC memory)."""
+    _lib.require_cuda(x, "conv input")
+    x = as_nhwc(x)
+    if x.dtype != torch.float32:
+        raise TypeError("the MI355X conv path computes in fp32")
+    specs, tensors, params_ref, bns = [], [], [], []
+    for br in branches:
+        w = br["weight"]
+        has_norm = br.get("gamma") is not None
+        sp = ConvSpec(br["stride"], br["pad"], br["up"], bool(br["relu"]), has_norm, br.get("bias") is not None,
+                      br.get("residual") is not None)
+        specs.append(sp)
+        wt = w if is_hwio(w) else hwio_weight(w)
+        res = br.get("residual")
+        if res is not None:
+            res = as_nhwc(res)
+        tensors += [wt, br.get("bias"), br.get("gamma"), br.get("beta"), res]
+        params_ref.append((w if wt is w else None, br.get("bias"), br.get("gamma"), br.get("beta")))
+        if has_norm:
+            bns.append(BNBranch(br["gamma"], br["beta"], br.get("running_mean"), br.get("running_var"),
+                                br.get("num_batches_tracked")))
+    mean = invstd = None
+    scales: List[Optional[Tensor]] = [None] * len(specs)
+    shifts: List[Optional[Tensor]] = [None] * len(specs)
+    if bns:
+        if training:
+            mean, invstd, sc, sh = bn_batch_stats(x, bns)
+        else:
+            if len(bns) > 1:
+                # running statistics of the branches may differ (loaded checkpoints): no shared (mean, invstd)
+                return tuple(conv_layers(x, [br], training=False)[0] for br in branches)
+            mean, invstd, s0, h0 = bn_eval_affine(bns[0])
+            sc, sh = [s0], [h0]
+        it = iter(range(len(bns)))
+        for i, sp in enumerate(specs):
+            if sp.has_norm:
+                j = next(it)
+                scales[i], shifts[i] = sc[j], sh[j]
+    stats = (mean, invstd, scales, shifts, training)
+    out = _ConvBNFn.apply(x, tuple(specs), stats, tuple(params_ref), *tensors)
+    return out if isinstance(out, tuple) else (out,)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        lib = _lib.load()
+        n, width, h, w = qkv.shape
+        t = h * w
+        if width % (3 * heads) != 0:
+            raise ValueError(f"tensor width: {width} must be divisible by (3 * n_heads): {3 * heads}")
+        c = width // (3 * heads)
+        out = empty_nhwc(n, heads * c, h, w, qkv)
+        lse = torch.empty((n, heads, t), device=qkv.device, dtype=torch.float32)
+        check(lib.otvae_attn_fwd(ptr(qkv), n, t, heads, c, ptr(out), ptr(lse), stream()), "otvae_attn_fwd")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.dims = (n, t, heads, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        qkv, out, lse = ctx.saved_tensors
+        n, t, heads, c = ctx.dims
+        gout = as_nhwc(gout)
+        gqkv = torch.empty_strided(qkv.shape, qkv.stride(), device=qkv.device, dtype=qkv.dtype)
+        check(lib.otvae_attn_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(gout), n, t, heads, c, ptr(gqkv), stream()),
+              "otvae_attn_bwd")
+        return gqkv, None
+
+
+def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:
+    """qkv: logical [N, 3*H*C, H, W] (NHWC memory) or [N, 3*H*C, T] -> same rank, H*C channels
+    (reference networks/nets_utils.py:63-82)."""
+    _lib.require_cuda(qkv, "qkv")
+    if qkv.dim() == 3:
+        n, width, t = qkv.shape
+        q4 = as_nhwc(qkv.unsqueeze(-1))
+        return _AttentionFn.apply(q4, n_heads).squeeze(-1)
+    return _AttentionFn.apply(as_nhwc(qkv), n_heads)
+
+
+# ------------------------------------------------------------------------------------------------ prior / loss
+class _GaussianPriorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, eps, coeff):
+        lib = _lib.load()
+        b, c2, hh, ww = h.shape
+        d, s = c2 // 2, hh * ww
+        z = empty_nhwc(b, d, hh, ww, h)
+        loss = torch.empty(b, device=h.device, dtype=torch.float32)
+        check(lib.otvae_gaussian_prior_fwd(ptr(h), ptr(eps), b, s, d, float(coeff), ptr(z), ptr(loss), stream()),
+              "otvae_gaussian_prior_fwd")
+        ctx.save_for_backward(h, eps)
+        ctx.cfg = (b, s, d, float(coeff))
+        return z, loss
+
+    @staticmethod
+    def backward(ctx, gz, gloss):
+        lib = _lib.load()
+        h, eps = ctx.saved_tensors
+        b, s, d, coeff = ctx.cfg
+        gz = as_nhwc(gz) if gz is not None else None
+        gloss = gloss.contiguous() if gloss is not None else None
+        gh = torch.empty_strided(h.shape, h.stride(), device=h.device, dtype=h.dtype)
+        check(lib.otvae_gaussian_prior_bwd(ptr(h), ptr(eps), ptr(gz), ptr(gloss), b, s, d, coeff, ptr(gh), stream()),
+              "otvae_gaussian_prior_bwd")
+        return gh, None, None
+
+
+def gaussian_prior(h: Tensor, eps: Tensor, coeff: float) -> Tuple[Tensor, Tensor]:
+    """(z, coeff*KL[B]) for the re-parametrised diagonal Gaussian (reference prior/gaussian.py:63-96)."""
+    _lib.require_cuda(h, "prior input")
+    if h.dim() == 2:
+        z, loss = _GaussianPriorFn.apply(as_nhwc(h[:, :, None, None]), as_nhwc(eps[:, :, None, None]), coeff)
+        return z[:, :, 0, 0], loss
+    if h.dim() != 4:
+        raise ValueError("GaussianPrior on the MI355X path expects [B, 2D] or [B, 2D, H, W] with reparam_dim=1")
+    return _GaussianPriorFn.apply(as_nhwc(h), as_nhwc(eps), coeff)
+
+
+class _NelboFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, prior_loss, chw):
+        lib = _lib.load()
+        b = pred.shape[0]
+        numel = pred.numel()
+        ws = torch.empty(lib.otvae_nelbo_ws(), device=pred.device, dtype=torch.float64)
+        out = torch.empty(3, device=pred.device, dtype=torch.float32)
+        check(lib.otvae_nelbo_fwd(ptr(pred), ptr(target), numel, ptr(prior_loss), b, float(chw), ptr(ws), ptr(out),
+                                  stream()), "otvae_nelbo_fwd")
+        ctx.save_for_backward(pred, target)
+        ctx.cfg = (b, numel, float(chw), prior_loss is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        pred, target = ctx.saved_tensors
+        b, numel, chw, has_prior = ctx.cfg
+        gout = gout.contiguous()
+        gpred = torch.empty_strided(pred.shape, pred.stride(), device=pred.device, dtype=pred.dtype)
+        gprior = torch.empty(b, device=pred.device, dtype=torch.float32) if has_prior else None
+        check(lib.otvae_nelbo_bwd(ptr(pred), ptr(target), numel, b, chw, ptr(gout), ptr(gpred), ptr(gprior), stream()),
+              "otvae_nelbo_bwd")
+        return gpred, None, gprior, None
+
+
+def nelbo_loss(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor]) -> Tensor:
+    """[total, recon, prior] of VAE.nelbo (reference model/vae.py:158-176): recon = mse(pred, target),
+    prior = mean(prior_loss) / prod(target.shape[1:])."""
+    _lib.require_cuda(pred, "pred")
+    pred = as_nhwc(pred) if pred.dim() == 4 else pred.contiguous()
+    target = as_nhwc(target) if target.dim() == 4 else target.contiguous()
+    chw = 1
+    for s in target.shape[1:]:
+        chw *= s
+    return _NelboFn.apply(pred, target, prior_loss.contiguous() if prior_loss is not None else None, chw)

@@ -1,0 +1,2 @@
+from .cnn import *  # noqa: F401,F403
+from .nets_utils import *  # noqa: F401,F403

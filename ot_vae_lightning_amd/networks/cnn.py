@@ -1,0 +1,342 @@
+"""Modular CNN with the reference's plug-in API (``ConvLayer, Conv1x1, AttentionBlock, ConvBlock, CNN, AutoEncoder``;
+reference networks/cnn.py) whose arithmetic runs on the gfx950 kernels behind ``include/otvae.h``.
+
+Same class names, constructor signatures, ``state_dict`` keys and initialisation draws as the reference, so its
+checkpoints load and ``VAE(encoder=CNN(...), decoder=CNN(...), prior=...)`` is unchanged for the user.  What differs
+is execution: a ConvLayer is ONE fused kernel (BatchNorm-apply + ReLU + nearest up-sampling + convolution + bias
+[+ residual add]) fed by a statistics pass shared between a block's first layer and its skip branch, activations
+stay channels-last between layers, and attention never materialises the TxT matrix.
+
+Options the reference implements but no BASELINE configuration uses (group/instance norm, non-ReLU activations,
+equalised learning rate, FiLM embeddings, dropout, grouped/dilated convolutions) are rejected with
+``NotImplementedError`` rather than silently run on another path.
+"""
+import math
+import warnings
+from math import log2, sqrt
+from typing import List, Optional, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import functional as HF
+from .nets_utils import FilterSequential, QKVAttention
+
+__all__ = ["ConvLayer", "Conv1x1", "ConvBlock", "AttentionBlock", "CNN", "AutoEncoder"]
+
+
+def _is_none(s: Optional[str]) -> bool:
+    return s is None or "none" in s.lower() or "null" in s.lower()
+
+
+class ConvLayer(nn.Module):
+    """BatchNorm -> ReLU -> (nearest x2 up-sampling) -> convolution (4x4 stride 2 when down-sampling), pre-activation
+    order as in the reference (networks/cnn.py:183-192).  ``weight`` has the logical shape [out, in, kh, kw]."""
+
+    enable_warnings = False
+
+    def __init__(self, in_features: int, out_features: int,
+                 down_sample: Union[bool, int, nn.Module] = False, up_sample: Union[bool, int, nn.Module] = False,
+                 additional_embed: Optional[int] = None, normalization: Optional[str] = None,
+                 activation: Optional[str] = None, equalized_lr: Optional[float] = None, dropout: float = 0.,
+                 kernel_size=3, stride=1, padding=1, dilation=1, groups: int = 1, bias: bool = True) -> None:
+        super().__init__()
+        if isinstance(down_sample, nn.Module) or isinstance(up_sample, nn.Module):
+            raise NotImplementedError("module-valued down_sample/up_sample are not supported on the MI355X path")
+        if bool(additional_embed):
+            raise NotImplementedError("additional_embed (FiLM conditioning) is not supported on the MI355X path")
+        if equalized_lr:
+            raise NotImplementedError("equalized_lr is not supported on the MI355X path")
+        if dropout and dropout > 0:
+            raise NotImplementedError("dropout > 0 is not supported on the MI355X path")
+        kernel_size = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        stride = stride if isinstance(stride, int) else stride[0]
+        padding = padding if isinstance(padding, int) else padding[0]
+        dilation = dilation if isinstance(dilation, int) else dilation[0]
+        if bool(down_sample):  # reference cnn.py:98-101
+            kernel_size = max(2 * int(down_sample), kernel_size)
+            stride = 2 if isinstance(down_sample, bool) else int(down_sample)
+            padding = (kernel_size - 1) // 2
+        groups = groups if in_features % groups == 0 and out_features % groups == 0 else 1
+        if groups != 1 or dilation != 1:
+            raise NotImplementedError("grouped / dilated convolutions are not supported on the MI355X path")
+        if stride not in (1, 2):
+            raise NotImplementedError(f"stride {stride} is not supported on the MI355X path")
+        up = 1
+        if isinstance(up_sample, bool):
+            up = 2 if up_sample else 1
+        elif isinstance(up_sample, int) and up_sample > 0:
+            up = int(up_sample)
+        if up not in (1, 2):
+            raise NotImplementedError(f"up_sample factor {up} is not supported on the MI355X path")
+        self.in_channels, self.out_channels = in_features, out_features
+        self.kernel_size, self.stride, self.padding = (kernel_size, kernel_size), (stride, stride), (padding, padding)
+        self._up = up
+
+        # parameters: same creation order and the same RNG draws as nn.Conv2d.reset_parameters (reference: ConvLayer
+        # subclasses nn.Conv2d), written into HWIO memory
+        w0 = torch.empty(out_features, in_features, kernel_size, kernel_size)
+        nn.init.kaiming_uniform_(w0, a=math.sqrt(5))
+        self.weight = nn.Parameter(HF.new_hwio(out_features, in_features, kernel_size, kernel_size))
+        if bias:
+            fan_in = in_features * kernel_size * kernel_size
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        self._down_sample = nn.Identity()
+        self._up_sample = nn.Upsample(scale_factor=up) if up > 1 else nn.Identity()
+        self._dropout = nn.Identity()
+
+        if _is_none(normalization):
+            self._normalization = nn.Identity()
+        elif "batch" in normalization.lower():
+            self._normalization = nn.BatchNorm2d(in_features)  # parameter/buffer container; its forward is never called
+        elif "group" in normalization.lower() or "instance" in normalization.lower():
+            raise NotImplementedError(f"normalization={normalization} is not supported on the MI355X path")
+        else:
+            raise NotImplementedError(f"normalization={normalization} not supported")
+
+        if _is_none(activation):
+            self._activation = nn.Identity()
+        elif "leaky" in activation.lower() or "selu" in activation.lower() or "gelu" in activation.lower() \
+                or "silu" in activation.lower() or "swish" in activation.lower():
+            raise NotImplementedError(f"activation={activation} is not supported on the MI355X path")
+        elif "relu" in activation.lower():
+            self._activation = nn.ReLU()
+            nn.init.kaiming_uniform_(w0, mode="fan_out", nonlinearity="relu")
+        else:
+            raise NotImplementedError(f"activation={activation} not supported")
+        with torch.no_grad():
+            self.weight.copy_(w0)
+
+    # -- helpers ----------------------------------------------------------------------------------------------
+    @property
+    def _has_norm(self) -> bool:
+        return isinstance(self._normalization, nn.BatchNorm2d)
+
+    def branch(self, residual: Optional[Tensor] = None) -> dict:
+        bn = self._normalization if self._has_norm else None
+        return dict(weight=self.weight, bias=self.bias,
+                    gamma=bn.weight if bn is not None else None, beta=bn.bias if bn is not None else None,
+                    running_mean=bn.running_mean if bn is not None else None,
+                    running_var=bn.running_var if bn is not None else None,
+                    num_batches_tracked=bn.num_batches_tracked if bn is not None else None,
+                    residual=residual, stride=self.stride[0], pad=self.padding[0], up=self._up,
+                    relu=isinstance(self._activation, nn.ReLU))
+
+    def forward(self, x: Tensor, embed: Optional[Tensor] = None, *, residual: Optional[Tensor] = None) -> Tensor:
+        if embed is not None and self.enable_warnings:
+            warnings.warn("given conditional argument `embed` but the layer has no embedding projection")
+        return HF.conv_layers(x, [self.branch(residual)], training=self.training)[0]
+
+    def extra_repr(self) -> str:
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, up={self._up}, bias={self.bias is not None}")
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # nothing special: copy_() maps the checkpoint's OIHW values onto the HWIO memory
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class Conv1x1(ConvLayer):
+    """Bias-free, activation-free 1x1 ConvLayer (4x4 stride 2 when down-sampling), reference cnn.py:195-206."""
+
+    def __init__(self, in_features: int, out_features: int, **kwargs):
+        defaults = dict(down_sample=False, up_sample=False, additional_embed=None, normalization=None, activation=None,
+                        equalized_lr=False, dropout=0., stride=1, kernel_size=1, padding=0, dilation=1, groups=1,
+                        bias=False)
+        super().__init__(in_features, out_features, **{**defaults, **kwargs})
+
+
+class AttentionBlock(nn.Module):
+    """proj_out(attention(qkv(BN(x)))) -- not residual (reference cnn.py:212-240)."""
+
+    def __init__(self, channels: int, heads: int = 1, additional_embed: Optional[int] = None,
+                 normalization: Optional[str] = None, equalized_lr: Optional[float] = None, groups: int = 1):
+        super().__init__()
+        if channels % heads != 0:
+            raise ValueError(f"q,k,v channels: {channels} is not divisible by heads: {heads}")
+        self.qkv = Conv1x1(channels, channels * 3, additional_embed=additional_embed, normalization=normalization,
+                           equalized_lr=equalized_lr, groups=groups)
+        self.attention = QKVAttention(heads)
+        self.proj_out = Conv1x1(channels, channels, equalized_lr=equalized_lr, groups=groups)
+
+    def forward(self, x: Tensor, embed: Optional[Tensor] = None, *, residual: Optional[Tensor] = None) -> Tensor:
+        qkv = self.qkv(x)                                   # [N, 3*C, H, W] channels-last
+        h = HF.qkv_attention(qkv, self.attention.n_heads)   # [N, C, H, W]
+        return self.proj_out(h, residual=residual)
+
+
+class ConvBlock(nn.Module):
+    """[ConvLayer(down/up), ConvLayer x (n_layers-1), AttentionBlock|Identity] (+ skip), reference cnn.py:246-335."""
+
+    def __init__(self, in_features: int, out_features: int, n_attn_heads: int = 0, n_layers: int = 2,
+                 down_sample=False, up_sample=False, additional_embed: Optional[int] = None,
+                 normalization: Optional[str] = "batchnorm", activation: Optional[str] = "relu",
+                 residual: Optional[str] = None, equalized_lr: Optional[float] = None, dropout: float = 0.,
+                 kernel_size=3, stride=1, padding=1, dilation=1, groups: int = 1, bias: bool = True) -> None:
+        super().__init__()
+        self.out_features = out_features
+        embed_features = out_features // 2 if residual == "cat" else out_features
+        self.block = FilterSequential(
+            ConvLayer(in_features, embed_features, down_sample, up_sample, additional_embed, normalization, activation,
+                      equalized_lr, dropout, kernel_size, stride, padding, dilation, groups, bias),
+            *[ConvLayer(embed_features, embed_features, False, False, additional_embed, normalization, activation,
+                        equalized_lr, dropout, kernel_size, stride, padding, dilation, groups, bias)
+              for _ in range(n_layers - 1)],
+            AttentionBlock(embed_features, n_attn_heads, additional_embed, normalization, equalized_lr, groups)
+            if n_attn_heads > 0 else nn.Identity(),
+        )
+        self.residual = residual
+        self.skip = Conv1x1(in_features, embed_features, down_sample=down_sample, up_sample=up_sample,
+                            normalization=normalization, equalized_lr=equalized_lr, groups=groups) \
+            if residual in ["cat", "add"] else None
+
+    def forward(self, x: Tensor, embed: Optional[Tensor] = None) -> Tensor:
+        layers = [l for l in self.block if not isinstance(l, nn.Identity)]
+        first = layers[0]
+        sk = None
+        if self.skip is not None:
+            # block[0] and skip normalise the same tensor: one statistics pass, one fused backward
+            out, sk = HF.conv_layers(x, [first.branch(), self.skip.branch()], training=self.training)
+        else:
+            out = first(x)
+        fuse_add = self.residual == "add" and len(layers) > 1
+        for i, layer in enumerate(layers[1:], start=1):
+            last = i == len(layers) - 1
+            out = layer(out, residual=sk if (fuse_add and last) else None)
+        if self.residual == "add" and not fuse_add:
+            out = out + sk
+        elif self.residual == "cat":
+            out = torch.cat([out, sk], dim=1)
+        return out
+
+
+class CNN(FilterSequential):
+    """Stack of ConvBlocks whose widths/resolutions/heads are inferred exactly like the reference
+    (networks/cnn.py:341-458)."""
+
+    def __init__(self, in_features: int, out_features: int, in_resolution: Optional[int] = None,
+                 out_resolution: Optional[int] = None, intermediate_features: Optional[List[int]] = None,
+                 capacity: int = 8, max_attn_res: int = 16, n_layers: int = 2, residual: Optional[str] = None,
+                 down_sample=False, up_sample=False, additional_embed: Optional[int] = None,
+                 normalization: Optional[str] = "batchnorm", activation: Optional[str] = "relu",
+                 equalized_lr: Optional[float] = None, dropout: float = 0., kernel_size=3, stride=1, padding=1,
+                 dilation=1, groups: int = 1, bias: bool = True) -> None:
+        if bool(up_sample) and bool(down_sample):
+            raise ValueError("Both `up_sample` and `down_sample` are set.")
+        if intermediate_features is not None:
+            features = [in_features] + intermediate_features + [out_features]
+            attn_resolutions = [max_attn_res] * len(features)
+        else:
+            if not all([in_resolution is not None, out_resolution is not None, bool(up_sample) or bool(down_sample)]):
+                raise ValueError("`features` is None. Set `in_resolution`, `out_resolution` and"
+                                 " (`up_sample` or `down_sample`)  to infer number of blocks")
+            if bool(down_sample):
+                if in_resolution <= out_resolution:
+                    raise ValueError("`down_sample` set but `in_resolution` < `out_resolution`")
+                if isinstance(down_sample, bool):
+                    down_sample = 2
+                features, resolutions = get_channel_list(in_features, out_features, in_resolution, out_resolution,
+                                                         down_sample, capacity)
+                attn_resolutions = resolutions[1:]
+            else:
+                if out_resolution <= in_resolution:
+                    raise ValueError("`up_sample` set but `out_resolution` < `in_resolution`")
+                if isinstance(up_sample, bool):
+                    up_sample = 2
+                features, resolutions = get_channel_list(out_features, in_features, out_resolution, in_resolution,
+                                                         up_sample, capacity)
+                features, resolutions = features[::-1], resolutions[::-1]
+                attn_resolutions = resolutions[:-1]
+        heads = lambda ch, res: div_sqrt(ch) if res <= max_attn_res else 0  # noqa: E731
+        super().__init__(*[
+            ConvBlock(ic, oc, heads(oc, r), n_layers, down_sample, up_sample, additional_embed, normalization,
+                      activation, residual, equalized_lr, dropout, kernel_size, stride, padding, dilation, groups, bias)
+            for ic, oc, r in zip(features[:-1], features[1:], attn_resolutions)])
+        self.out_size = torch.Size([out_features, out_resolution, out_resolution])
+
+    def forward(self, x: Tensor, embed: Optional[Tensor] = None) -> Tensor:
+        return super().forward(x, embed=embed)
+
+
+class AutoEncoder(nn.Module):
+    """encoder CNN + mirrored decoder CNN with ``encode``/``decode``/``latent_size`` (reference cnn.py:463-600).
+    Class/time conditioning feeds FiLM embeddings, which the MI355X ConvLayer does not implement."""
+
+    def __init__(self, in_features: int, latent_features: int, in_resolution: Optional[int] = None,
+                 latent_resolution: Optional[int] = None, intermediate_features: Optional[List[int]] = None,
+                 capacity: int = 8, max_attn_res: int = 16, num_classes: Optional[int] = None,
+                 time_embed_dim: Optional[int] = None, double_encoded_features: bool = False, n_layers: int = 2,
+                 residual: Optional[str] = None, down_up_sample: Union[bool, int] = False,
+                 normalization: Optional[str] = "batchnorm", activation: Optional[str] = "relu",
+                 equalized_lr: Optional[float] = None, dropout: float = 0., kernel_size=3, stride=1, padding=1,
+                 dilation=1, groups: int = 1, bias: bool = True) -> None:
+        super().__init__()
+        if bool(num_classes) or bool(time_embed_dim):
+            raise NotImplementedError("class / time conditioned AutoEncoder is not supported on the MI355X path")
+        enc_out = latent_features * (1 + int(double_encoded_features))
+        self.latent_size = torch.Size([enc_out, latent_resolution, latent_resolution])
+        self.class_embed = None
+        self.time_embed = None
+        self.encoder = CNN(in_features, enc_out, in_resolution, latent_resolution, intermediate_features, capacity,
+                           max_attn_res, n_layers, residual, down_up_sample, False, None, normalization, activation,
+                           equalized_lr, dropout, kernel_size, stride, padding, dilation, groups, bias)
+        self.decoder = CNN(latent_features, in_features, latent_resolution, in_resolution,
+                           intermediate_features[::-1] if intermediate_features is not None else None, capacity,
+                           max_attn_res, n_layers, residual, False, down_up_sample, None, normalization, activation,
+                           equalized_lr, dropout, kernel_size, stride, padding, dilation, groups, bias)
+
+    def embed(self, labels: Optional[Tensor] = None, time: Optional[Tensor] = None):
+        if labels is not None:
+            warnings.warn("given conditional argument `labels` but `self.class_embed` is None.")
+        if time is not None:
+            warnings.warn("given conditional argument `time` but `self.time_embed` is None.")
+        return None
+
+    def encode(self, x: Tensor, labels: Optional[Tensor] = None, time: Optional[Tensor] = None) -> Tensor:
+        return self.encoder(x, self.embed(labels, time))
+
+    def decode(self, z: Tensor, labels: Optional[Tensor] = None, time: Optional[Tensor] = None) -> Tensor:
+        return self.decoder(z, self.embed(labels, time))
+
+    def forward(self, x: Tensor, labels: Optional[Tensor] = None, time: Optional[Tensor] = None) -> Tensor:
+        return self.decode(self.encode(x, labels, time), labels, time)
+
+
+# ---- architecture inference (reference cnn.py:605-672) -----------------------------------------------------------
+def get_block_scaling(max_resolution: int, min_resolution: int, max_scaling: int) -> List[int]:
+    """e.g. (64, 2, 4) -> [4, 4, 2]: greedy factorisation of the resolution ratio into powers of two <= max_scaling."""
+    remaining = int(log2(max_resolution // min_resolution))
+    exp = int(log2(max_scaling))
+    factors: List[int] = []
+    while remaining > 0:
+        factors += [2 ** exp] * (remaining // exp)
+        remaining %= exp
+        exp -= 1
+    return factors
+
+
+def get_channel_list(in_features: int, out_features: int, in_resolution: int, out_resolution: int,
+                     scaling_factor: int, capacity: int):
+    """Widths double from ``capacity`` (clamped to [in_features, out_features]); last width is ``out_features``."""
+    scalings = get_block_scaling(in_resolution, out_resolution, scaling_factor)
+    features = [max(min(capacity << i, out_features), in_features) for i in range(len(scalings))]
+    resolutions = [in_resolution]
+    for sf in scalings:
+        resolutions.append(resolutions[-1] // sf)
+    features[-1] = out_features
+    return [in_features] + features, resolutions
+
+
+def div_sqrt(n: int) -> int:
+    """The divisor of ``n`` the reference picks as head count: the smallest divisor >= sqrt(n)
+    (np.searchsorted over sympy.divisors, cnn.py:660-672)."""
+    assert isinstance(n, int) and n > 0, f"Error, n must be a positive integer. Given n={n}."
+    root = sqrt(n)
+    for d in range(1, n + 1):
+        if n % d == 0 and d >= root:
+            return d
+    return n

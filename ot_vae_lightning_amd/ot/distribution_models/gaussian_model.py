@@ -1,0 +1,168 @@
+"""``GaussianModel``: multivariate Gaussian fitted from streaming fp64 sufficient statistics
+(n, sum x, sum x x^T), reference ot/distribution_models/gaussian_model.py.  The statistics kernel accumulates the
+batch straight into the running buffers (or hands raw batch statistics to the all-reduce when running
+data-parallel); ``fit`` and the ``cov`` parametrisations (symmetrise, make strictly positive definite) run on the
+fp64 device kernels.  The autograd-trained variant (``update_with_autograd=True``) is outside the hot path."""
+from typing import Optional
+
+import torch
+import torch.distributions as D
+import torch.nn as nn
+import torch.nn.utils.parametrize as P
+from torch import Tensor
+
+from ... import _lib
+from ..._lib import check, ptr, stream
+from ..matrix_utils import eye_like, make_psd
+from ..w2_utils import W2Mixin
+from .base import DistributionModel
+
+__all__ = ["GaussianModel"]
+
+
+class GaussianModel(DistributionModel, W2Mixin):
+    Distribution = D.Distribution
+
+    def __init__(self, *size: int, w2_cfg={}, **kwargs):
+        DistributionModel.__init__(self, *size, **kwargs)
+        W2Mixin.__init__(self, **dict(w2_cfg))
+        if self.update_with_autograd:
+            raise NotImplementedError("update_with_autograd=True is outside the MI355X hot path")
+        self.batch_dim = -2
+        self.register_buffer("cov_init", torch.ones_like(self.vec_init) if self.diag else
+                             eye_like(self.mat_init).clone())
+        self.mean = nn.Parameter(self.vec_init.clone(), requires_grad=False)
+        self.cov = nn.Parameter(self.cov_init.clone(), requires_grad=False)
+        self.register_buffer("_running_sum", torch.zeros_like(self.mean.data))
+        self.register_buffer("_running_sum_cov", torch.zeros_like(self.cov.data))
+        self.register_buffer("_n_obs", torch.zeros(self.vec_shape[:-1], dtype=self.vec_init.dtype))
+        P.register_parametrization(self, "cov", Symmetric(diag=self.diag))
+        P.register_parametrization(self, "cov", MakePositiveDefinite(diag=self.diag, strict=True))
+
+    # -- state -------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def reset(self) -> None:
+        self.mean.copy_(self.vec_init)
+        self.cov = self.cov_init
+        self._running_sum.zero_()
+        self._running_sum_cov.zero_()
+        self._n_obs.zero_()
+
+    @property
+    def distribution(self):
+        return self.instantiate_normal(self.mean, scale=self.cov ** 0.5, covariance_matrix=self.cov)
+
+    @property
+    def variances(self) -> Tensor:
+        return self.cov
+
+    # -- statistics --------------------------------------------------------------------------------------------
+    def _batch_stats(self, samples: Tensor, accumulate: bool):
+        """Launches the statistics kernel.  accumulate=True: EMA/add straight into the running buffers (single
+        process); False: returns the raw (n, sum, sum_cov) of this batch."""
+        lib = _lib.load()
+        _lib.require_cuda(samples, "samples")
+        d = self.dim
+        lead = self.leading_shape
+        bsz = samples.shape[-2]
+        x = samples.detach()
+        if x.dtype not in (torch.float32, torch.float64):
+            x = x.float()
+        x = x.expand(*lead, bsz, d).reshape(-1, bsz, d).contiguous()
+        nb = x.shape[0]
+        if self._running_sum.dtype != torch.float64:
+            raise TypeError("GaussianModel on the MI355X path keeps its statistics in float64 (pass dtype=torch.double)")
+        ws = torch.empty(max(8, lib.otvae_gauss_stats_ws(nb, bsz, d, int(self.diag))), device=x.device, dtype=torch.uint8)
+        if accumulate:
+            n, sx, sxx = self._n_obs, self._running_sum, self._running_sum_cov
+        else:
+            n = torch.empty(nb, device=x.device, dtype=torch.float64)
+            sx = torch.empty((nb, d), device=x.device, dtype=torch.float64)
+            sxx = torch.empty((nb, d) if self.diag else (nb, d, d), device=x.device, dtype=torch.float64)
+        decay = -1.0 if self.decay is None else float(self.decay)
+        check(lib.otvae_gauss_stats(0 if x.dtype == torch.float32 else 1, ptr(x), nb, bsz, d, int(self.diag),
+                                    int(accumulate), decay, ptr(ws), ptr(n), ptr(sx), ptr(sxx), stream()),
+              "otvae_gauss_stats")
+        if accumulate:
+            return None
+        return n.reshape(lead), sx.reshape(*lead, d), sxx.reshape(*lead, *( (d,) if self.diag else (d, d)))
+
+    def _will_reduce(self) -> bool:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    @torch.no_grad()
+    def update(self, samples: Tensor) -> None:
+        self._validate_samples(samples)
+        if self.reduce_on_update and self._will_reduce():
+            n, sx, sxx = self._batch_stats(samples, accumulate=False)
+            n, sx, sxx = self.reduce(n), self.reduce(sx), self.reduce(sxx)
+            self._n_obs = self.ema_update(self._n_obs, n)
+            self._running_sum = self.ema_update(self._running_sum, sx)
+            self._running_sum_cov = self.ema_update(self._running_sum_cov, sxx)
+        else:
+            self._batch_stats(samples, accumulate=True)
+
+    @torch.no_grad()
+    def fit(self, samples: Optional[Tensor] = None) -> None:
+        if samples is not None:
+            self.update(samples)
+        self._n_obs = self.reduce(self._n_obs)
+        self._running_sum = self.reduce(self._running_sum)
+        self._running_sum_cov = self.reduce(self._running_sum_cov)
+        n = self._n_obs
+        if bool((n == 0).all()):
+            return
+        seen = n > 1e-8
+        if bool(seen.all()):
+            mean, cov = self.mean_cov(self._running_sum, self._running_sum_cov, n)
+            self.mean.copy_(mean.type_as(self.mean))
+            self.cov = cov.type_as(self.mean)
+        else:
+            mean, cov = self.mean_cov(self._running_sum[seen], self._running_sum_cov[seen], n[seen])
+            self.mean.data[seen] = mean.type_as(self.mean)
+            tmp = self.cov
+            tmp[seen] = cov.type_as(tmp)
+            self.cov = tmp
+
+    def predict(self, samples: Tensor) -> Tensor:
+        self._validate_samples(samples)
+        dist = self.instantiate_normal(self.mean.unsqueeze(-2), scale=self.cov.unsqueeze(-2) ** 0.5,
+                                       covariance_matrix=self.cov.unsqueeze(-3) if not self.diag else None)
+        return dist.log_prob(samples.type_as(self.mean))
+
+    def w2(self, other) -> Tensor:
+        return self.w2_gaussian(self.mean, other.mean, self.variances, self.get_var_normal(other))
+
+    def extra_repr(self) -> str:
+        return super().extra_repr() + W2Mixin.__repr__(self)
+
+
+class MakePositiveDefinite(nn.Module):
+    """cov parametrisation: always add |min(lambda_min,0)| + 1e-8 to the diagonal (reference gaussian_model.py:204-214)."""
+
+    def __init__(self, diag, strict):
+        super().__init__()
+        self.diag, self.strict = diag, strict
+
+    def forward(self, x):
+        if not x.is_cuda:  # parametrize evaluates forward at registration time, before the model is moved
+            return x
+        return make_psd(x, strict=self.strict, return_correction=False, diag=self.diag)
+
+    def right_inverse(self, x):
+        return x
+
+
+class Symmetric(nn.Module):
+    """cov parametrisation: mirror the upper triangle (reference gaussian_model.py:217-226)."""
+
+    def __init__(self, diag):
+        super().__init__()
+        self.diag = diag
+
+    def forward(self, X):
+        return X if self.diag else X.triu() + X.triu(1).transpose(-1, -2)
+
+    def right_inverse(self, X):
+        return X

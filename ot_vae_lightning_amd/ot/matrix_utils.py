@@ -1,0 +1,129 @@
+"""Matrix utilities with the reference's names and semantics (ot/matrix_utils.py): eigh-based ``sqrtm``/``invsqrtm``,
+``min_eig``/``is_pd``/``is_symmetric``/``is_spd``/``make_psd``, ``mean_cov``, ``eye_like``, ``STABILITY_CONST`` --
+computed in fp64 on the GPU by the LDS-resident Jacobi eigensolver and small fp64 kernels of ``gaussian_ot.hip``."""
+from typing import Tuple, Union
+
+import torch
+from torch import Tensor
+
+from .. import _lib
+from .._lib import check, ptr, stream
+
+__all__ = ["eye_like", "sqrtm", "invsqrtm", "is_spd", "is_pd", "is_symmetric", "min_eig", "make_psd", "mean_cov",
+           "STABILITY_CONST", "eigvals_and_fn", "matmul64"]
+
+STABILITY_CONST = 1e-8
+
+
+def _as_batch(m: Tensor) -> Tuple[Tensor, torch.Size]:
+    _lib.require_cuda(m, "matrix")
+    lead = m.shape[:-2]
+    d = m.shape[-1]
+    if m.shape[-2] != d:
+        raise ValueError(f"expected square matrices, got {tuple(m.shape)}")
+    return m.to(torch.float64).reshape(-1, d, d).contiguous(), lead
+
+
+def eigvals_and_fn(matrices: Tensor, fn: int):
+    """fn: 0 -> eigenvalues only, 1 -> sqrtm, 2 -> invsqrtm.  Returns (eigvals [*, D], f(M) [*, D, D] | None), fp64.
+    Reads the lower triangle like torch.linalg.eigh(UPLO='L') (reference matrix_utils.py:44)."""
+    lib = _lib.load()
+    a, lead = _as_batch(matrices)
+    nb, d = a.shape[0], a.shape[-1]
+    ws = torch.empty(lib.otvae_eigh_ws(nb, d), device=a.device, dtype=torch.uint8)
+    ev = torch.empty((nb, d), device=a.device, dtype=torch.float64)
+    out = torch.empty_like(a) if fn else None
+    check(lib.otvae_eigh_fn(ptr(a), nb, d, fn, ptr(out), ptr(ev), ptr(ws), stream()), "otvae_eigh_fn")
+    return ev.reshape(*lead, d), (out.reshape(*lead, d, d) if fn else None)
+
+
+def eye_like(matrices: Tensor) -> Tensor:
+    return torch.eye(matrices.shape[-2], matrices.shape[-1], device=matrices.device,
+                     dtype=matrices.dtype).expand_as(matrices)
+
+
+def sqrtm(matrices: Tensor) -> Tensor:
+    """V sqrt(lambda) V^T of a batch of SPSD matrices (NaN where an eigenvalue is negative, like the reference)."""
+    return eigvals_and_fn(matrices, 1)[1].to(matrices.dtype)
+
+
+def invsqrtm(matrices: Tensor) -> Tensor:
+    return eigvals_and_fn(matrices, 2)[1].to(matrices.dtype)
+
+
+def is_symmetric(matrices: Tensor) -> Tensor:
+    if matrices.size(-1) != matrices.size(-2):
+        return torch.zeros(matrices.shape[:-2], dtype=torch.bool, device=matrices.device)
+    return torch.sum((matrices - matrices.transpose(-2, -1)) ** 2, dim=(-1, -2)) < STABILITY_CONST
+
+
+def min_eig(matrices: Tensor) -> Tensor:
+    return eigvals_and_fn(matrices, 0)[0].min(dim=-1)[0].to(matrices.dtype)
+
+
+def is_pd(matrices: Tensor, strict=True) -> Tensor:
+    return min_eig(matrices) > 0 if strict else min_eig(matrices) >= 0
+
+
+def is_spd(matrices: Tensor, strict=True) -> Tensor:
+    return torch.logical_and(is_symmetric(matrices), is_pd(matrices, strict=strict)).bool()
+
+
+def make_psd(matrices: Tensor, strict: bool = False, return_correction: bool = False, diag: bool = False,
+             only_if_needed: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+    """Adds |min(lambda_min, 0)| (+1e-8 if ``strict``) to every diagonal (reference matrix_utils.py:123-142).
+    ``only_if_needed`` applies the shift only when some matrix of the batch fails the definiteness test, decided on
+    the device (the reference's ``_validate_args(make_pd=True)`` path, w2_utils.py:667-669, without the host sync)."""
+    if diag:
+        smallest = matrices.min(-1)[0]
+        corr = smallest.clamp(max=0).abs()
+        if strict:
+            corr = corr + STABILITY_CONST
+        res = matrices + corr[..., None]
+        return (res, corr) if return_correction else res
+    lib = _lib.load()
+    a, lead = _as_batch(matrices)
+    a = a.clone() if a.data_ptr() == matrices.data_ptr() else a
+    nb, d = a.shape[0], a.shape[-1]
+    ev, _ = eigvals_and_fn(a, 0)
+    check(lib.otvae_make_psd(ptr(a), ptr(ev), nb, d, int(strict), int(only_if_needed), stream()), "otvae_make_psd")
+    res = a.reshape(*lead, d, d).to(matrices.dtype)
+    if return_correction:
+        corr = ev.min(-1)[0].clamp(max=0).abs().reshape(lead)
+        if strict:
+            corr = corr + STABILITY_CONST
+        return res, corr.to(matrices.dtype)
+    return res
+
+
+def mean_cov(sum: Tensor, sum_corr: Tensor, num_obs: Union[Tensor, int, float], diag: bool = False):
+    """mean = sum/n, cov = sum_corr/n - mean mean^T (reference matrix_utils.py:145-158), fp64 on the device."""
+    lib = _lib.load()
+    _lib.require_cuda(sum, "sum")
+    d = sum.shape[-1]
+    lead = sum.shape[:-1]
+    sx = sum.to(torch.float64).reshape(-1, d).contiguous()
+    sxx = sum_corr.to(torch.float64).reshape(-1, d if diag else d * d).contiguous()
+    nb = sx.shape[0]
+    n = torch.as_tensor(num_obs, dtype=torch.float64, device=sum.device).expand(lead).reshape(-1).contiguous()
+    mean = torch.empty_like(sx)
+    cov = torch.empty_like(sxx)
+    check(lib.otvae_mean_cov(ptr(n), ptr(sx), ptr(sxx), nb, d, int(diag), ptr(mean), ptr(cov), stream()),
+          "otvae_mean_cov")
+    cov = cov.reshape(*lead, d) if diag else cov.reshape(*lead, d, d)
+    return mean.reshape(*lead, d).to(sum.dtype), cov.to(sum_corr.dtype)
+
+
+def matmul64(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False) -> Tensor:
+    """Batched fp64 product of [nb, m, k] x [nb, k, n] (operands may be 2-D = broadcast over the batch)."""
+    lib = _lib.load()
+    a_b, b_b = a.dim() == 2, b.dim() == 2
+    a3 = a.contiguous() if not a_b else a.contiguous().unsqueeze(0)
+    b3 = b.contiguous() if not b_b else b.contiguous().unsqueeze(0)
+    nb = max(a3.shape[0], b3.shape[0])
+    m, k = (a3.shape[2], a3.shape[1]) if trans_a else (a3.shape[1], a3.shape[2])
+    n = b3.shape[1] if trans_b else b3.shape[2]
+    out = torch.empty((nb, m, n), device=a.device, dtype=torch.float64)
+    check(lib.otvae_gemm_f64(int(trans_a), int(trans_b), nb, m, n, k, 1.0, ptr(a3), int(a3.shape[0] == 1 and nb > 1),
+                             ptr(b3), int(b3.shape[0] == 1 and nb > 1), 0.0, ptr(out), stream()), "otvae_gemm_f64")
+    return out

@@ -1,0 +1,2 @@
+from .base import *  # noqa: F401,F403
+from .gaussian_transport import *  # noqa: F401,F403

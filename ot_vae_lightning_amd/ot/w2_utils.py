@@ -1,0 +1,265 @@
+"""Wasserstein-2 utilities with the reference's names (ot/w2_utils.py) on the MI355X kernels:
+``sinkhorn_log`` (:276-319), ``w2_gaussian`` (:40-80), ``compute_transport_operators`` (:391-458, eq. 17),
+``apply_transport`` (:464-527), ``batch_w2_dissimilarity_gaussian_diag`` (:86-134), ``W2Mixin`` (:533-600).
+Out of scope for this path: GMM transport (``batch_ot_gmm``), barycenters, the stochastic
+(eq. 19) operators -- they raise ``NotImplementedError``."""
+import warnings
+from functools import partial
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.distributions as D
+from torch import Tensor
+
+from .. import _lib
+from .._lib import check, ptr, stream
+from .matrix_utils import *  # noqa: F401,F403
+from .matrix_utils import STABILITY_CONST, eigvals_and_fn, eye_like, is_symmetric, matmul64, mean_cov
+
+__all__ = ["w2_gaussian", "batch_w2_dissimilarity_gaussian_diag", "sinkhorn_log", "sinkhorn_log_potentials",
+           "sq_euclidean_cost", "ot_cost", "compute_transport_operators", "apply_transport", "W2Mixin"]
+
+_DT = {torch.float32: 0, torch.float64: 1}
+
+
+def _dt(t: Tensor) -> int:
+    if t.dtype not in _DT:
+        raise TypeError(f"expected float32 or float64, got {t.dtype}")
+    return _DT[t.dtype]
+
+
+# ------------------------------------------------------------------------------------------------ Sinkhorn
+def sinkhorn_log_potentials(a: Tensor, b: Tensor, C: Tensor, reg: float = 1e-5, max_iter: int = 1000,
+                            threshold: float = STABILITY_CONST):
+    """Returns (pi, u, v, iters_done[device int32]).  See ``sinkhorn_log``."""
+    lib = _lib.load()
+    _lib.require_cuda(C, "C")
+    if C.dim() < 2 or a.shape[-1] != C.shape[-2] or b.shape[-1] != C.shape[-1]:
+        raise ValueError(f"sinkhorn_log: a {tuple(a.shape)}, b {tuple(b.shape)} do not match C {tuple(C.shape)}")
+    lead = C.shape[:-2]
+    n, m = C.shape[-2:]
+    dt = _dt(C)
+    a2 = a.to(C.dtype).expand(*lead, n).reshape(-1, n).contiguous()
+    b2 = b.to(C.dtype).expand(*lead, m).reshape(-1, m).contiguous()
+    c3 = C.reshape(-1, n, m).contiguous()
+    nb = c3.shape[0]
+    ws = torch.empty(lib.otvae_sinkhorn_ws(dt, nb, n, m), device=C.device, dtype=torch.uint8)
+    pi = torch.empty_like(c3)
+    u = torch.empty_like(a2)
+    v = torch.empty_like(b2)
+    iters = torch.zeros(1, device=C.device, dtype=torch.int32)
+    check(lib.otvae_sinkhorn_log(dt, ptr(a2), ptr(b2), ptr(c3), nb, n, m, float(reg), int(max_iter), float(threshold),
+                                 ptr(ws), ptr(pi), ptr(u), ptr(v), ptr(iters), stream()), "otvae_sinkhorn_log")
+    return pi.reshape(*lead, n, m), u.reshape(*lead, n), v.reshape(*lead, m), iters
+
+
+def sinkhorn_log(a: Tensor, b: Tensor, C: Tensor, reg: float = 1e-5, max_iter: int = 1000,
+                 threshold: float = STABILITY_CONST) -> Tensor:
+    """Entropic OT plan by log-domain Sinkhorn iterations: a [*, N], b [*, M], C [*, N, M] -> pi [*, N, M].
+    Same arithmetic and stopping rule as the reference (stop every problem of the batch at the first iteration
+    where the smallest per-problem L1 change of (u, v) is below ``threshold``); the test runs on the device, so
+    unlike the reference there is no host synchronisation per iteration."""
+    return sinkhorn_log_potentials(a, b, C, reg, max_iter, threshold)[0]
+
+
+def sq_euclidean_cost(x: Tensor, y: Tensor) -> Tensor:
+    """C[*, i, j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j for x [*, N, D], y [*, M, D]."""
+    lib = _lib.load()
+    _lib.require_cuda(x, "x")
+    lead, n, d = x.shape[:-2], x.shape[-2], x.shape[-1]
+    m = y.shape[-2]
+    x3, y3 = x.reshape(-1, n, d).contiguous(), y.to(x.dtype).reshape(-1, m, d).contiguous()
+    out = torch.empty((x3.shape[0], n, m), device=x.device, dtype=x.dtype)
+    check(lib.otvae_sqdist(_dt(x), ptr(x3), ptr(y3), x3.shape[0], n, m, d, ptr(out), stream()), "otvae_sqdist")
+    return out.reshape(*lead, n, m)
+
+
+def ot_cost(C: Tensor, pi: Tensor) -> Tensor:
+    """sum_ij C_ij pi_ij over the last two dims (fp64 accumulation, fixed order)."""
+    lib = _lib.load()
+    lead, n, m = C.shape[:-2], C.shape[-2], C.shape[-1]
+    c3, p3 = C.reshape(-1, n, m).contiguous(), pi.to(C.dtype).reshape(-1, n, m).contiguous()
+    nb = c3.shape[0]
+    ws = torch.empty(nb * 64, device=C.device, dtype=torch.float64)
+    out = torch.empty(nb, device=C.device, dtype=C.dtype)
+    check(lib.otvae_ot_cost(_dt(C), ptr(c3), ptr(p3), nb, n, m, ptr(ws), ptr(out), stream()), "otvae_ot_cost")
+    return out.reshape(lead)
+
+
+# ------------------------------------------------------------------------------------------------ Gaussian W2
+def _check_vec_mat(mean_s, mean_t, cov_s, cov_t):
+    for name, t in (("mean_source", mean_s), ("mean_target", mean_t), ("cov_source", cov_s), ("cov_target", cov_t)):
+        if not isinstance(t, Tensor):
+            raise ValueError(f"`{name}` is expected to be a torch.Tensor, got `{type(t)}` instead.")
+    if mean_s.dim() < 1 or mean_t.dim() < 1:
+        raise ValueError("means should be 1-dim vectors (+ optional leading batch dimensions)")
+    if cov_s.dim() < 2 or cov_t.dim() < 2:
+        raise ValueError("covariances should be 2-dim matrices (+ optional leading batch dimensions)")
+    dims = {mean_s.size(-1), mean_t.size(-1), cov_s.size(-1), cov_s.size(-2), cov_t.size(-1), cov_t.size(-2)}
+    if len(dims) != 1:
+        raise ValueError(f"All the inputs dimensionalities should match, got {sorted(dims)}")
+
+
+def _require_spd(cov: Tensor, name: str, make_pd: bool, strict: bool, verbose: bool) -> Tensor:
+    """The 'spd'/'spsd' argument validation of the reference (w2_utils.py:661-679)."""
+    if not bool(is_symmetric(cov).all()):
+        raise ValueError(f"`{name}` should be symmetric.")
+    if make_pd:
+        return make_psd(cov, strict=strict, only_if_needed=True)  # noqa: F405
+    ev, _ = eigvals_and_fn(cov, 0)
+    lo = ev.min(-1)[0]
+    if not bool(((lo > 0) if strict else (lo >= 0)).all()):
+        raise ValueError(f"`{name}` should be symmetric and positive {'' if strict else 'semi '}definite. "
+                         "Use `make_pd=True` to automatically add a small value to the matrix diagonals.")
+    return cov
+
+
+def w2_gaussian(mean_source: Tensor, mean_target: Tensor, cov_source: Tensor, cov_target: Tensor,
+                make_pd: bool = False, verbose: bool = False, dtype=torch.double) -> Tensor:
+    """Squared Gelbrich distance |ms-mt|^2 + tr(Cs + Ct - 2 (Ct^1/2 Cs Ct^1/2)^1/2), fp64, batched over leading dims."""
+    lib = _lib.load()
+    _check_vec_mat(mean_source, mean_target, cov_source, cov_target)
+    lead = torch.broadcast_shapes(mean_source.shape[:-1], mean_target.shape[:-1], cov_source.shape[:-2],
+                                  cov_target.shape[:-2])
+    d = mean_source.shape[-1]
+    ms = mean_source.double().expand(*lead, d).reshape(-1, d).contiguous()
+    mt = mean_target.double().expand(*lead, d).reshape(-1, d).contiguous()
+    cs = _require_spd(cov_source.double().expand(*lead, d, d).reshape(-1, d, d).contiguous(), "cov_source", make_pd,
+                      True, verbose)
+    ct = _require_spd(cov_target.double().expand(*lead, d, d).reshape(-1, d, d).contiguous(), "cov_target", make_pd,
+                      True, verbose)
+    rt = eigvals_and_fn(ct, 1)[1]
+    mix = matmul64(matmul64(rt, cs), rt)
+    if not bool(is_symmetric(mix).all()):
+        raise ValueError("`cov_target_sqrt @ cov_source @ cov_target_sqrt` should be symmetric.")
+    sq = eigvals_and_fn(mix, 1)[1]
+    nb = ms.shape[0]
+    out = torch.empty(nb, device=ms.device, dtype=torch.float64)
+    check(lib.otvae_w2_tail(ptr(ms), ptr(mt), ptr(cs.contiguous()), ptr(ct.contiguous()), ptr(sq), nb, d, ptr(out),
+                            stream()), "otvae_w2_tail")
+    return out.reshape(lead)
+
+
+def batch_w2_dissimilarity_gaussian_diag(mean_source: Tensor, mean_target: Tensor, var_source: Tensor,
+                                         var_target: Tensor, dtype=torch.double) -> Tensor:
+    """D[*, i, j] = W2^2(N(ms_i, diag vs_i), N(mt_j, diag vt_j)) = |ms_i - mt_j|^2 + |sqrt vs_i - sqrt vt_j|^2."""
+    if (var_source < 0).any() or (var_target < 0).any():
+        raise ValueError("variances are expected to have positive entries.")
+    return sq_euclidean_cost(mean_source.to(dtype), mean_target.to(dtype)) + \
+        sq_euclidean_cost(var_source.to(dtype).sqrt(), var_target.to(dtype).sqrt())
+
+
+def compute_transport_operators(cov_source: Tensor, cov_target: Tensor, stochastic: bool, diag: bool,
+                                pg_star: float = 0, make_pd: bool = False, verbose: bool = False,
+                                dtype=torch.double) -> Tuple[Tensor, Tensor]:
+    """Eq. 17 of Freirich et al.: T = (1-pg) Cs^-1/2 (Cs^1/2 Ct Cs^1/2)^1/2 Cs^-1/2 + pg I  (and Cw = 0)."""
+    if stochastic:
+        raise NotImplementedError("stochastic transport operators (eq. 19) are outside the MI355X hot path")
+    if diag:
+        cs, ct = cov_source.to(dtype), cov_target.to(dtype)
+        if (cs < 0).any() or (ct < 0).any():
+            raise ValueError("variances are expected to have positive entries.")
+        T = (1 - pg_star) * torch.sqrt(ct / cs + STABILITY_CONST) + pg_star
+        return T, torch.zeros_like(T)
+    d = cov_source.shape[-1]
+    lead = torch.broadcast_shapes(cov_source.shape[:-2], cov_target.shape[:-2])
+    cs = _require_spd(cov_source.double().expand(*lead, d, d).reshape(-1, d, d).contiguous(), "cov_source", make_pd,
+                      True, verbose)
+    ct = cov_target.double().expand(*lead, d, d).reshape(-1, d, d).contiguous()
+    if not bool(is_symmetric(ct).all()):
+        raise ValueError("`cov_target` should be symmetric.")
+    rs = eigvals_and_fn(cs, 1)[1]
+    irs = eigvals_and_fn(cs + STABILITY_CONST * eye_like(cs), 2)[1]
+    inner = eigvals_and_fn(matmul64(matmul64(rs, ct), rs), 1)[1]
+    T = (1 - pg_star) * matmul64(matmul64(irs, inner), irs) + pg_star * eye_like(cs)
+    T = T.reshape(*lead, d, d).to(dtype)
+    return T, torch.zeros_like(T)
+
+
+def apply_transport(input: Tensor, mean_source: Tensor, mean_target: Tensor, T: Tensor, Cw: Optional[Tensor] = None,
+                    diag: bool = False, make_pd: bool = False, verbose: bool = False, dtype=torch.double) -> Tensor:
+    """T (x - mean_source) + mean_target, computed in fp64; returns ``dtype``.  input [*, B, D] against
+    [*, D]/[*, D, D] operators (already unsqueezed by the caller like the reference) or matching shapes."""
+    if Cw is not None and bool((Cw != 0).any()):
+        raise NotImplementedError("stochastic transport (non-zero Cw) is outside the MI355X hot path")
+    if diag:
+        return (T.to(dtype) * (input.to(dtype) - mean_source.to(dtype)) + mean_target.to(dtype))
+    lib = _lib.load()
+    _lib.require_cuda(input, "input")
+    d = input.shape[-1]
+    if T.shape[-1] != d or T.shape[-2] != d:
+        raise ValueError("All the inputs dimensionalities should match")
+    # normalise to x [nb, B, D], operators [nb, ...]
+    x = input
+    Tm, ms, mt = T, mean_source, mean_target
+    if Tm.dim() == x.dim() + 1 and Tm.shape[-3] == 1:  # operators carry an explicit singleton batch dim
+        Tm, ms, mt = Tm.squeeze(-3), ms.squeeze(-2), mt.squeeze(-2)
+    if x.dim() == Tm.dim() - 1:  # one vector per operator: [*, D]
+        x = x.unsqueeze(-2)
+        squeeze = True
+    else:
+        squeeze = False
+    lead = x.shape[:-2]
+    bsz = x.shape[-2]
+    x3 = x.reshape(-1, bsz, d)
+    x3 = (x3 if x3.dtype in _DT else x3.double()).contiguous()
+    nb = x3.shape[0]
+    Tm = Tm.double().expand(*lead, d, d).reshape(nb, d, d).contiguous()
+    ms = ms.double().expand(*lead, d).reshape(nb, d).contiguous()
+    mt = mt.double().expand(*lead, d).reshape(nb, d).contiguous()
+    y = torch.empty_like(x3)
+    check(lib.otvae_apply_transport(_dt(x3), ptr(x3), ptr(ms), ptr(mt), ptr(Tm), nb, bsz, d, ptr(y), stream()),
+          "otvae_apply_transport")
+    y = y.reshape(*lead, bsz, d)
+    if squeeze:
+        y = y.squeeze(-2)
+    return y.to(dtype)
+
+
+class W2Mixin(object):
+    """Binds the w2 configuration (diag / stochastic / pg_star / make_pd / verbose / dtype) like the reference
+    (ot/w2_utils.py:533-600)."""
+
+    def __init__(self, **kwargs):
+        self._orig_kwargs = dict(kwargs)
+        self.stochastic = kwargs.pop("stochastic", False)
+        self.diag = kwargs.pop("diag", False)
+        self.pg_star = kwargs.pop("pg_star", 0.)
+        self.make_pd = kwargs.pop("make_pd", False)
+        self.verbose = kwargs.pop("verbose", False)
+        self.dtype = kwargs.pop("dtype", torch.double)
+        self.mean_cov = partial(mean_cov, diag=self.diag)
+        self.batch_w2_dissimilarity_gaussian_diag = partial(batch_w2_dissimilarity_gaussian_diag, dtype=self.dtype)
+        self.compute_transport_operators = partial(compute_transport_operators, diag=self.diag,
+                                                   stochastic=self.stochastic, pg_star=self.pg_star,
+                                                   make_pd=self.make_pd, verbose=self.verbose, dtype=self.dtype)
+
+    def get_var_normal(self, distribution: Union[D.Normal, D.MultivariateNormal]):
+        return distribution.variance if self.diag else distribution.covariance_matrix
+
+    def instantiate_normal(self, *args, **kwargs):
+        if self.diag:
+            for k in ("covariance_matrix", "precision_matrix", "scale_tril"):
+                kwargs.pop(k, None)
+            return D.Independent(D.Normal(*args, **kwargs), 1)
+        kwargs.pop("scale", None)
+        return D.MultivariateNormal(*args, **kwargs)
+
+    def w2_gaussian(self, mean_source: Tensor, mean_target: Tensor, cov_source: Tensor, cov_target: Tensor) -> Tensor:
+        return w2_gaussian(mean_source, mean_target,
+                           torch.diag_embed(cov_source) if self.diag else cov_source,
+                           torch.diag_embed(cov_target) if self.diag else cov_target,
+                           make_pd=self.make_pd, verbose=self.verbose, dtype=self.dtype)
+
+    def apply_transport(self, inputs: Tensor, mean_source: Tensor, mean_target: Tensor, T: Tensor, Cw: Tensor,
+                        batch_dim: Optional[int] = None) -> Tensor:
+        return apply_transport(
+            inputs,
+            mean_source.unsqueeze(batch_dim) if batch_dim is not None else mean_source,
+            mean_target.unsqueeze(batch_dim) if batch_dim is not None else mean_target,
+            T.unsqueeze(batch_dim - bool(not self.diag)) if batch_dim is not None else T,
+            Cw.unsqueeze(batch_dim - bool(not self.diag)) if (batch_dim is not None and Cw is not None) else Cw,
+            diag=self.diag, make_pd=self.make_pd, verbose=self.verbose, dtype=self.dtype)
+
+    def __repr__(self):
+        return ", ".join(f"{k}={v}" for k, v in self._orig_kwargs.items())

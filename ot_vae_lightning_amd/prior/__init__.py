@@ -1,0 +1,3 @@
+from .base import *  # noqa: F401,F403
+from .gaussian import *  # noqa: F401,F403
+from .sinkhorn import *  # noqa: F401,F403

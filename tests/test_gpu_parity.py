@@ -1,0 +1,418 @@
+"""GPU parity tests (run with ``-m gpu`` on the MI355X box).  Every case drives the product path (Python API ->
+ctypes -> C ABI -> HIP kernels) and compares with
+  * the golden vectors recorded from the real reference (``tests/golden``), and
+  * the CPU oracle (``oracle/otvae_oracle.py``) on the same seeded inputs at larger sizes.
+Bounds: fp32 network / Sinkhorn results 1e-4 relative (max-norm, the tolerance BASELINE.json's north_star states);
+fp64 OT arithmetic 1e-8; indices bit-exact.  A full report of every measured error is appended to
+``gpurun_out/parity_report.txt``.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, group, load_golden, rel_err
+from detfill import det_input, fill_state_dict, mnist_like, normal
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-4
+REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.txt")
+
+
+class Report:
+    def __init__(self, title):
+        self.title, self.rows, self.failed = title, [], []
+
+    def check(self, name, got, want, tol=TOL32, exact=False):
+        if exact:
+            ok = torch.equal(got.cpu(), want.cpu())
+            err = 0.0 if ok else float("inf")
+        else:
+            err = rel_err(got, want)
+            ok = err < tol and math.isfinite(err)
+        self.rows.append((name, err, tol, ok))
+        if not ok:
+            self.failed.append((name, err, tol))
+
+    def finish(self):
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(f"== {self.title}\n")
+            for name, err, tol, ok in self.rows:
+                f.write(f"{'ok  ' if ok else 'FAIL'} {name:70s} err={err:.3e} tol={tol:.1e}\n")
+        assert not self.failed, f"{self.title}: {len(self.failed)} mismatches, first: {self.failed[:6]}"
+
+
+@pytest.fixture(scope="module")
+def A():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import ot_vae_lightning_amd as pkg
+    from ot_vae_lightning_amd import _lib
+    _lib.load()
+    return pkg
+
+
+def cuda(t):
+    return t.cuda() if isinstance(t, torch.Tensor) else t
+
+
+# ------------------------------------------------------------------------------------------------ ABI / device
+def test_library_and_device(A):
+    import ctypes as C
+    from ot_vae_lightning_amd import _lib
+    lib = _lib.load()
+    ncu, wave = C.c_int(0), C.c_int(0)
+    arch = C.create_string_buffer(64)
+    assert lib.otvae_device_info(C.byref(ncu), C.byref(wave), arch, 64) == 0
+    assert wave.value == 64
+    assert b"gfx950" in arch.value, arch.value
+    # a bad geometry is refused with ValueError, nothing launched
+    from ot_vae_lightning_amd import functional as HF
+    x = torch.zeros(2, 3, 8, 8, device="cuda")
+    w = torch.zeros(4, 5, 3, 3, device="cuda")
+    with pytest.raises(ValueError):
+        HF.conv_layers(x, [dict(weight=w, bias=None, stride=1, pad=1, up=1, relu=False)])
+    with pytest.raises(RuntimeError):
+        HF.conv_layers(torch.zeros(2, 3, 8, 8), [dict(weight=w.cpu(), bias=None, stride=1, pad=1, up=1, relu=False)])
+
+
+# ------------------------------------------------------------------------------------------------ G1 ConvLayer
+from test_oracle_vs_golden import CONV_GEOM  # noqa: E402
+
+CONV_CTOR = {
+    "enc_first": ("ConvLayer", dict(down_sample=2, normalization="batchnorm", activation="relu")),
+    "enc_same": ("ConvLayer", dict(normalization="batchnorm", activation="relu")),
+    "enc_down": ("ConvLayer", dict(down_sample=2, normalization="batchnorm", activation="relu")),
+    "enc_last": ("ConvLayer", dict(down_sample=2, normalization="batchnorm", activation="relu")),
+    "same_1x1res": ("ConvLayer", dict(normalization="batchnorm", activation="relu")),
+    "dec_up": ("ConvLayer", dict(up_sample=2, normalization="batchnorm", activation="relu")),
+    "dec_first": ("ConvLayer", dict(up_sample=2, normalization="batchnorm", activation="relu")),
+    "dec_last": ("ConvLayer", dict(up_sample=2, normalization="batchnorm", activation="relu")),
+    "dec_11": ("ConvLayer", dict(normalization="batchnorm", activation="relu")),
+    "rgb_in": ("ConvLayer", dict(down_sample=2, normalization="batchnorm", activation="relu")),
+    "qkv": ("Conv1x1", dict(normalization="batchnorm")),
+    "qkv1": ("Conv1x1", dict(normalization="batchnorm")),
+    "proj": ("Conv1x1", dict()),
+    "skip_down": ("Conv1x1", dict(down_sample=2, normalization="batchnorm")),
+    "skip_up": ("Conv1x1", dict(up_sample=2, normalization="batchnorm")),
+    "skip_up1": ("Conv1x1", dict(up_sample=2, normalization="batchnorm")),
+    "nonorm_relu": ("ConvLayer", dict(activation="relu")),
+}
+
+
+def test_conv_layer_vs_reference_golden(A):
+    z = load_golden("convlayer.npz")
+    rep = Report("ConvLayer fwd/bwd vs reference golden (B=4)")
+    for name in sorted(CONV_CTOR):
+        g = group(z, name)
+        cls, kw = CONV_CTOR[name]
+        cin, cout = g["x"].shape[1], g["y"].shape[1]
+        layer = getattr(A, cls)(cin, cout, **kw)
+        layer.load_state_dict({k[6:]: v for k, v in g.items() if k.startswith("param/")}, strict=False)
+        layer = layer.cuda().train()
+        x = g["x"].cuda().requires_grad_(True)
+        y = layer(x)
+        y.backward(g["gy"].cuda())
+        rep.check(f"{name}/y", y, g["y"])
+        rep.check(f"{name}/gx", x.grad, g["gx"])
+        for k, p in layer.named_parameters():
+            rep.check(f"{name}/grad/{k}", p.grad, g[f"grad/{k}"])
+        for k, b in layer.named_buffers():
+            if k.endswith("num_batches_tracked"):
+                rep.check(f"{name}/buf/{k}", b, g[f"buf/{k}"], exact=True)
+            else:
+                rep.check(f"{name}/buf/{k}", b, g[f"buf/{k}"])
+    rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G2 attention
+def test_attention_vs_reference_golden(A):
+    z = load_golden("attention.npz")
+    rep = Report("QKVAttention fwd/bwd vs reference golden (B=2)")
+    for key in sorted({k.split("/")[0] for k in z.files}):
+        g = group(z, key)
+        heads = int(key.split("_")[1][1:])
+        attn = A.QKVAttention(heads)
+        qkv = g["qkv"].cuda().requires_grad_(True)
+        out = attn(qkv)
+        out.backward(g["gout"].cuda())
+        rep.check(f"{key}/out", out, g["out"])
+        rep.check(f"{key}/gqkv", qkv.grad, g["gqkv"])
+    rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G3 small CNN
+@pytest.mark.parametrize("residual", ["add", "None", "cat"])
+def test_cnn_small_vs_reference_golden(A, residual):
+    z = load_golden("cnn_small.npz")
+    res = None if residual == "None" else residual
+    cap = 4 if res == "cat" else 2
+    rep = Report(f"CNN capacity {cap} residual={residual} vs reference golden")
+    nets = [("enc", lambda: A.CNN(1, 16, 16, 1, capacity=cap, down_sample=True, residual=res))]
+    if res != "cat":
+        nets.append(("dec", lambda: A.CNN(8, 1, 1, 16, capacity=cap, up_sample=True, residual=res)))
+    for nm, make in nets:
+        g = group(z, f"{residual}/{nm}")
+        net = make()
+        fill_state_dict(net.state_dict())
+        net = net.cuda().train()
+        x = g["x"].cuda().requires_grad_(True)
+        y = net(x)
+        y.backward(g["gy"].cuda())
+        rep.check(f"{nm}/y", y, g["y"])
+        rep.check(f"{nm}/gx", x.grad, g["gx"], tol=2e-4)
+        for k, p in net.named_parameters():
+            rep.check(f"{nm}/grad/{k}", p.grad, g[f"grad/{k}"], tol=3e-4)
+        for k, b in net.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                rep.check(f"{nm}/buf/{k}", b, g[f"buf/{k}"])
+    rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G4 nelbo
+def _mnist_vae(A, residual, loss_coeff=0.1):
+    enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual=residual)
+    dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual=residual)
+    fill_state_dict(enc.state_dict())
+    fill_state_dict(dec.state_dict())
+    return A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=loss_coeff)).cuda().train()
+
+
+@pytest.mark.parametrize("residual", ["add", "None"])
+def test_nelbo_and_adam_vs_reference_golden(A, residual):
+    g = group(load_golden("nelbo_mnist.npz"), residual)
+    res = None if residual == "None" else residual
+    rep = Report(f"VAE.nelbo + Adam (MNIST cfg, B=6, residual={residual}) vs reference golden")
+    model = _mnist_vae(A, res)
+    assert model.latent_size == torch.Size((128, 1, 1))
+    x, eps = mnist_like(6, 42).cuda(), normal((6, 128, 1, 1), 43).cuda()
+    trainer = A.HipTrainer(model, batch_shape=(6, 1, 32, 32), use_graph=False)
+    out = trainer.step(x, eps)
+    torch.cuda.synchronize()
+    rep.check("loss[total,recon,prior]", out, g["loss"])
+    logs = trainer._logs
+    names, params = [], []
+    for pre, net in (("encoder.", model.encoder), ("decoder.", model.decoder)):
+        for k, p in net.named_parameters():
+            names.append(pre + k)
+            params.append(p)
+    assert names == [str(s) for s in g["param_names"]]
+    gl2 = torch.tensor([p.grad.double().norm().item() for p in params])
+    rep.check("grad_l2 (all parameters)", gl2, g["grad_l2"], tol=3e-4)
+    gsum = torch.tensor([p.grad.double().sum().item() for p in params])
+    rep.check("grad_sum (all parameters, scaled by max l2)", gsum / g["grad_l2"].max(), g["grad_sum"] / g["grad_l2"].max(),
+              tol=3e-4)
+    for k, v in g.items():
+        if k.startswith("grad_full/"):
+            rep.check(k, params[names.index(k[10:])].grad, v, tol=3e-4)
+    pl2 = torch.tensor([p.double().norm().item() for p in params])
+    rep.check("param_l2 after one Adam step", pl2, g["param_l2_after_adam"], tol=1e-5)
+    rs = [b.double().sum().item() for net in (model.encoder, model.decoder) for k, b in net.named_buffers()
+          if k.endswith("running_mean") or k.endswith("running_var")]
+    rep.check("BatchNorm running stats (40 layers)", torch.tensor(rs), g["running_stat_sums"])
+    # forward artifacts
+    model2 = _mnist_vae(A, res)
+    loss, logs, art = model2.nelbo({"samples": x, "target": x, "kwargs": {"eps": eps}}, 0)
+    rep.check("preds[:2]", art["preds"][:2], g["preds"])
+    rep.check("latents", art["latents"], g["latents"])
+    rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G5 prior
+@pytest.mark.parametrize("tag", ["plain", "anneal"])
+def test_gaussian_prior_vs_reference_golden(A, tag):
+    g = group(load_golden("prior.npz"), tag)
+    coeff, ann, step = g["cfg"].tolist()
+    rep = Report(f"GaussianPrior.forward ({tag}) vs reference golden")
+    prior = A.GaussianPrior(loss_coeff=coeff, annealing_steps=int(ann))
+    x = g["x"].cuda().requires_grad_(True)
+    z, loss, art = prior(x, step=int(step), eps=g["eps"].cuda())
+    ((z * g["gz"].cuda()).sum() + (loss * g["gl"].cuda()).sum()).backward()
+    rep.check("z", z, g["z"])
+    rep.check("loss", loss, g["loss"])
+    rep.check("gx", x.grad, g["gx"])
+    assert prior.out_size(torch.Size((256, 1, 1))) == torch.Size((128, 1, 1))
+    assert rel_err(art["distribution"].mean, g["x"][:, :128]) == 0
+    rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G6 sinkhorn
+from test_oracle_vs_golden import _sinkhorn_problem  # noqa: E402
+
+
+def test_sinkhorn_vs_reference_golden(A):
+    z = load_golden("sinkhorn.npz")
+    rep = Report("sinkhorn_log vs reference golden")
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        g = group(z, name)
+        reg, it, thr = g["cfg"].tolist()
+        if "pi" in g:
+            a, b, C = g["a"], g["b"], g["C"]
+        else:
+            seed, n, m = g["seed"].tolist()
+            a, b, C = _sinkhorn_problem((), n, m, torch.float32 if "f32" in name else torch.float64, seed)
+        pi = A.sinkhorn_log(a.cuda(), b.cuda(), C.cuda(), reg=reg, max_iter=int(it), threshold=thr)
+        tol = TOL32 if pi.dtype == torch.float32 else 1e-8
+        if "pi" in g:
+            rep.check(f"{name}/pi", pi, g["pi"], tol)
+        else:
+            rep.check(f"{name}/row_sums", pi.sum(-1), g["row_sums"], tol)
+            rep.check(f"{name}/col_sums", pi.sum(-2), g["col_sums"], tol)
+            rep.check(f"{name}/pi_corner", pi[:8, :8], g["pi_corner"], tol)
+        rep.check(f"{name}/cost", A.ot_cost(C.cuda(), pi), g["cost"], tol)
+    rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G7 Gaussian OT
+@pytest.mark.parametrize("D", [8, 32, 128])
+def test_gaussian_transport_vs_reference_golden(A, D):
+    z = load_golden("gaussian_ot.npz")
+    base = group(z, f"D{D}")
+    rep = Report(f"GaussianModel/GaussianTransport D={D} vs reference golden")
+    src, tgt = base["src"].cuda(), base["tgt"].cuda()
+    for decay in (None, 0.9):
+        g = group(z, f"D{D}/decay{decay}")
+        cfg = dict(update_decay=decay, dtype=torch.double)
+        op = A.GaussianTransport(D, source_cfg=cfg, target_cfg=cfg,
+                                 transport_cfg=dict(diag=False, stochastic=False, pg_star=0.0, make_pd=True,
+                                                    verbose=False, dtype=torch.double)).cuda()
+        op.reset()
+        for s, t in zip(src, tgt):
+            op.update(source_samples=s, target_samples=t)
+        sm = op.source_model
+        rep.check(f"decay{decay}/n_obs", sm._n_obs, g["src_n"], 1e-12)
+        rep.check(f"decay{decay}/running_sum", sm._running_sum, g["src_sum"], 1e-12)
+        rep.check(f"decay{decay}/running_sum_cov", sm._running_sum_cov, g["src_sumcov"], 1e-12)
+        w = op.compute()
+        rep.check(f"decay{decay}/w2", w, g["w2"], 1e-8)
+        rep.check(f"decay{decay}/src_mean", op.source_model.mean, g["src_mean"], 1e-12)
+        rep.check(f"decay{decay}/src_cov", op.source_model.cov, g["src_cov"], 1e-10)
+        rep.check(f"decay{decay}/tgt_cov", op.target_model.cov, g["tgt_cov"], 1e-10)
+        rep.check(f"decay{decay}/T", op.transport_operator, g["T"], 1e-7)
+        rep.check(f"decay{decay}/transported", op.transport(src[0][:16]), g["transported"], 1e-5)
+    n = float(src[0].shape[0])
+    sx, sxx = src[0].double().sum(0), src[0].double().T @ src[0].double()
+    mean, cov = A.mean_cov(sx, sxx, n)
+    rep.check("mean_cov/mean", mean, base["meancov_mean"], 1e-12)
+    rep.check("mean_cov/cov", cov, base["meancov_cov"], 1e-12)
+    rep.check("sqrtm(cov)", A.sqrtm(cov), base["sqrtm_cov"], 1e-8)
+    rep.check("invsqrtm(cov + 1e-8 I)", A.invsqrtm(cov + 1e-8 * torch.eye(D, device="cuda", dtype=torch.double)),
+              base["invsqrtm_cov"], 1e-6)
+    tmean = tgt[0].double().mean(0)
+    _, tcov = A.mean_cov(tgt[0].double().sum(0), tgt[0].double().T @ tgt[0].double(), n)
+    rep.check("w2_gaussian(plain)", A.w2_gaussian(mean, tmean, cov, tcov, make_pd=True), base["w2_plain"], 1e-8)
+    rep.finish()
+
+
+def test_w2_known_answers(A):
+    """The reference's own known-answer tests (tests/test_w2_utils.py:35-41, 179-195)."""
+    g = group(load_golden("gaussian_ot.npz"), "batched")
+    rep = Report("w2_gaussian batched + self distance")
+    m1, m2, c1, c2 = (g[k].cuda() for k in ("m1", "m2", "c1", "c2"))
+    w = A.w2_gaussian(m1, m2, c1, c2)
+    assert w.shape == (2, 3)
+    rep.check("w2 batched [2,3]", w, g["w2"], 1e-8)
+    w0 = A.w2_gaussian(m1, m1, c1, c1)
+    assert w0.abs().max().item() < 1e-6
+    with pytest.raises(ValueError):
+        A.w2_gaussian(m1, m2, c1 - 5 * torch.eye(3, device="cuda"), c2, make_pd=False)
+    rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G8 codebook
+@pytest.mark.parametrize("tag", ["flat", "multi"])
+def test_codebook_indices_bit_exact(A, tag):
+    g = group(load_golden("codebook.npz"), tag)
+    enc, idx = A.codebook_assign(g["x"].cuda(), g["codebook"].cuda())
+    assert torch.equal(idx.cpu(), g["indices"]), "latent indices must be bit-exact"
+    assert torch.equal(enc.cpu(), g["preds"])
+
+
+# ------------------------------------------------------------------------------------------------ vs oracle, larger
+def test_training_step_vs_oracle_batch256_and_graph(A):
+    """MNIST config at batch 256: GPU step (eager and hipGraph replay) vs the CPU oracle on the same seeded batch."""
+    import otvae_oracle as O
+    from test_oracle_vs_golden import _build_params
+    rep = Report("training step B=256 vs CPU oracle; graph replay vs eager")
+    B = 256
+    x, eps = mnist_like(B, 7), normal((B, 128, 1, 1), 8)
+    ea = O.cnn_arch(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+    da = O.cnn_arch(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    enc, dec = _build_params(ea), _build_params(da)
+    leaves = []
+    for d in (enc, dec):
+        for k, v in d.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+                leaves.append(v)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    r = O.vae_nelbo(x, eps, enc, dec, ea, da, loss_coeff=0.1)
+    r["loss"].backward()
+    want_loss = torch.stack([r["loss"], r["recon"], r["prior"]]).detach()
+    want_gl2 = torch.tensor([v.grad.double().norm().item() for v in leaves])
+
+    model = _mnist_vae(A, "add")
+    tr = A.HipTrainer(model, batch_shape=(B, 1, 32, 32), use_graph=False)
+    out = tr.step(x.cuda(), eps.cuda()).clone()
+    params = [p for net in (model.encoder, model.decoder) for p in net.parameters()]
+    rep.check("loss", out, want_loss)
+    rep.check("grad_l2", torch.tensor([p.grad.double().norm().item() for p in params]), want_gl2, tol=3e-4)
+    rep.check("preds", tr._logs["train/loss/recon"], r["recon"].detach())
+    p_eager = tr.pflat.clone()
+
+    model_g = _mnist_vae(A, "add")
+    trg = A.HipTrainer(model_g, batch_shape=(B, 1, 32, 32), use_graph=True)
+    outg = trg.step(x.cuda(), eps.cuda()).clone()
+    torch.cuda.synchronize()
+    rep.check("graph vs eager: loss", outg, out, tol=1e-6)
+    rep.check("graph vs eager: parameters after Adam", trg.pflat, p_eager, tol=1e-6)
+    for k, b in model_g.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == 1, (k, int(b))
+    # a few more replays: loss must go down on a fixed batch
+    first = float(outg[0])
+    for _ in range(30):
+        last = trg.step(x.cuda(), eps.cuda())
+    assert float(last[0]) < first, (first, float(last[0]))
+    rep.finish()
+
+
+def test_sinkhorn_full_size_properties_and_oracle(A):
+    """Config 3 size (1024x1024, eps=0.05, 50 iterations): marginal property + agreement with the CPU oracle."""
+    import otvae_oracle as O
+    rep = Report("sinkhorn 1024x1024 fp32: properties and oracle")
+    z, p = normal((1024, 128), 11), normal((1024, 128), 12)
+    C = A.sq_euclidean_cost(z.cuda(), p.cuda())
+    rep.check("sq_euclidean_cost vs oracle", C, O.sq_euclidean_cost(z, p))
+    a = torch.full((1024,), 1 / 1024)
+    Cn = C / C.max()
+    pi, u, v, iters = A.sinkhorn_log_potentials(a.cuda(), a.cuda(), Cn, reg=0.05, max_iter=50, threshold=0.0)
+    assert int(iters) == 50
+    want = O.sinkhorn_log(a, a, Cn.cpu(), reg=0.05, max_iter=50, threshold=0.0)
+    rep.check("pi vs oracle", pi, want)
+    # after the u-update the row marginals are exact up to the +1e-8 inside the log
+    rep.check("row marginals == a", pi.sum(-1), a, tol=2e-4)
+    rep.check("OT cost vs oracle", A.ot_cost(C, pi), (C.cpu() * want).sum())
+    rep.finish()
+
+
+def test_empirical_cov_streaming_matches_full(A):
+    """Reference tests/test_empirical_cov.py: streaming (n, sum, sum xxT) equals the full-batch mean/cov and their
+    W2 distance is ~0 (D=128, 1e4 samples, batches of 100)."""
+    D, N = 128, 10000
+    g = torch.Generator().manual_seed(1)
+    m = torch.randn(D, D, generator=g, dtype=torch.float64)
+    zs = (torch.randn(N, D, generator=g, dtype=torch.float64) @ m.T + torch.randn(D, generator=g, dtype=torch.float64)).cuda()
+    model = A.GaussianModel(D, dtype=torch.double).cuda()
+    model.reset()
+    for b in range(N // 100):
+        model.update(zs[b * 100:(b + 1) * 100])
+    mean, cov = A.mean_cov(model._running_sum, model._running_sum_cov, model._n_obs)
+    mean_all = zs.mean(0)
+    cov_all = (zs - mean_all).T @ (zs - mean_all) / N
+    assert (mean - mean_all).norm() / mean_all.norm() < 1e-8
+    assert (cov - cov_all).norm() / cov_all.norm() < 1e-8
+    assert A.w2_gaussian(mean_all, mean, cov_all, cov, make_pd=True).abs().item() < 1e-4
