@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- training images/sec of the MNIST-32 CNN-VAE + GaussianPrior step on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = forward + backward + (RCCL all-reduce of the flat gradient buffer when N > 1) + Adam over one resident
+synthetic batch of 1024 images per GPU (weak scaling), replayed as a hipGraph, plus the latent statistics update
+(GaussianModel.update, the streaming fp64 covariance the Gaussian-W2 path consumes).  Inputs are already in HBM when
+the timed region starts.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      dominant kernel of the step, timed live with HIP events on the stream it runs on
+  cpu_baseline  the CPU oracle (oracle/otvae_oracle.py, a port pinned to the reference by golden vectors) timed on the
+                host cores of this box on a bounded sample of the same step (rank 0, N == 1 only)
+  parity        relative error of the GPU step's losses vs that oracle on identical inputs (fp32, tolerance 1e-4)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 1024
+# algorithmic traffic of one fused training step, MNIST test config (residual="add"), fp32
+ALG_BYTES_PER_IMAGE_FWD_BWD = 1.72e6
+ALG_FLOP_PER_IMAGE_FWD_BWD = 59e6
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+
+
+def build_model(A, seed=0):
+    torch.manual_seed(seed)
+    enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+    dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    return A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1))
+
+
+def cpu_baseline(A, batch=250, steps=3, warmup=1):
+    """The oracle on the host cores: same step definition (fwd + bwd + Adam), bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import otvae_oracle as O
+    from detfill import mnist_like, normal
+    torch.set_num_threads(os.cpu_count() or 1)
+    model = build_model(A)
+    ea = O.cnn_arch(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+    da = O.cnn_arch(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    enc = {k: v.detach().clone().contiguous() for k, v in model.encoder.state_dict().items()}
+    dec = {k: v.detach().clone().contiguous() for k, v in model.decoder.state_dict().items()}
+    leaves = [v.requires_grad_(True) for d in (enc, dec) for k, v in d.items()
+              if v.is_floating_point() and "running" not in k]
+    m = [torch.zeros_like(v) for v in leaves]
+    s = [torch.zeros_like(v) for v in leaves]
+    x, eps = mnist_like(batch, 42), normal((batch, 128, 1, 1), 43)
+    t0 = None
+    for it in range(warmup + steps):
+        if it == warmup:
+            t0 = time.perf_counter()
+        for v in leaves:
+            v.grad = None
+        r = O.vae_nelbo(x, eps, enc, dec, ea, da, loss_coeff=0.1)
+        r["loss"].backward()
+        with torch.no_grad():
+            O.adam_step(leaves, [v.grad for v in leaves], m, s, step=it + 1)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps (fwd+bwd+Adam) at batch {batch} after {warmup} warm-up, fp32, torch "
+                      f"{torch.__version__} CPU ops, oracle/otvae_oracle.py"}
+
+
+def parity_check(A, batch=64):
+    """GPU step vs oracle on identical weights / batch / eps: relative error of [total, recon, prior(KL)] and of the
+    Sinkhorn OT loss (256x256, eps 0.05, 50 iterations)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import otvae_oracle as O
+    from detfill import mnist_like, normal
+    model = build_model(A)
+    ea = O.cnn_arch(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+    da = O.cnn_arch(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    enc = {k: v.detach().clone().contiguous() for k, v in model.encoder.state_dict().items()}
+    dec = {k: v.detach().clone().contiguous() for k, v in model.decoder.state_dict().items()}
+    x, eps = mnist_like(batch, 5), normal((batch, 128, 1, 1), 6)
+    with torch.no_grad():
+        r = O.vae_nelbo(x, eps, enc, dec, ea, da, loss_coeff=0.1)
+    want = torch.stack([r["loss"], r["recon"], r["prior"]])
+    model = model.cuda().train()
+    with torch.no_grad():
+        loss, logs, art = model.nelbo({"samples": x.cuda(), "target": x.cuda(), "kwargs": {"eps": eps.cuda()}}, 0)
+    got = model._last_out3.cpu()
+    rel = ((got - want).abs() / want.abs()).tolist()
+    rec = ((art["preds"].cpu() - r["preds"]).abs().max() / r["preds"].abs().max()).item()
+    z, p = normal((256, 128), 11), normal((256, 128), 12)
+    ot_cpu = O.sinkhorn_ot_loss(z, p, reg=0.05, max_iter=50, threshold=0.0).item()
+    C = A.sq_euclidean_cost(z.cuda(), p.cuda())
+    a = torch.full((256,), 1 / 256, device="cuda")
+    pi = A.sinkhorn_log(a, a, C / C.max(), reg=0.05, max_iter=50, threshold=0.0)
+    ot_gpu = A.ot_cost(C, pi).item()
+    return {"loss_rel_err": max(rel), "reconstruction_rel_err": rec, "ot_loss_rel_err": abs(ot_gpu - ot_cpu) / abs(ot_cpu),
+            "tolerance": 1e-4, "batch": batch}
+
+
+def time_dominant_kernel(A, trainer, iters=30):
+    """Average duration of the dominant kernel of the step (profiles/: attention backward of the decoder's last
+    block, T=1024 tokens, 1 head, 1 channel), launched back to back on the current stream between two HIP events."""
+    from ot_vae_lightning_amd import functional as HF
+    n = PER_GPU_BATCH
+    qkv = torch.randn(n, 3, 32, 32, device="cuda")
+    qkv = HF.as_nhwc(qkv).requires_grad_(True)
+    out = HF.qkv_attention(qkv, 1)
+    g = torch.randn_like(out)
+    fn = out.grad_fn
+    for _ in range(3):
+        fn(g)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn(g)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    # algorithmic work of this launch: reads qkv (3 floats/token), out, lse, gout, writes gqkv -> 9 floats per token;
+    # arithmetic: T*T pair evaluations per image, each recomputed twice (dQ pass, dK/dV pass)
+    tokens = n * 1024
+    alg_bytes = tokens * 9 * 4
+    pair_evals = 2 * n * 1024 * 1024
+    return {"kernel": "attn_bwd_kernel<1> (T=1024,H=1,C=1)", "ms": ms, "alg_bytes": alg_bytes, "pair_evals": pair_evals}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ot_vae_lightning_amd import build as otbuild
+    if rank == 0 and not os.path.exists(otbuild.LIB):
+        otbuild.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    import ot_vae_lightning_amd as A
+    from ot_vae_lightning_amd.utils.synthetic import mnist_like
+
+    B = PER_GPU_BATCH
+    model = build_model(A).cuda().train()
+    if world > 1:  # identical replicas: broadcast rank 0's initial weights
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+    latent_model = A.GaussianTransport(128, source_cfg=dict(dtype=torch.double, reduce_on_update=False),
+                                       target_cfg=dict(dtype=torch.double, reduce_on_update=False),
+                                       transport_cfg=dict(make_pd=True)).cuda()
+    trainer = A.HipTrainer(model, batch_shape=(B, 1, 32, 32), use_graph=not args.no_graph, latent_stats=latent_model)
+    # resident synthetic data: 4 different MNIST-like batches per rank, rotated
+    pool = [mnist_like(B, seed=1000 + 17 * rank + i).cuda() for i in range(4)]
+    torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = trainer.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = [float(v) for v in out.tolist()]
+
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        dom = time_dominant_kernel(A, trainer)
+        achieved = dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9
+        line = {
+            "metric": "training images/sec (whole node) + OT-loss rel-err vs CPU ref",
+            "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MNIST-32 CNN VAE (capacity 8, latent 128x1x1, residual=add) + GaussianPrior("
+                                   "loss_coeff=0.1): fwd+bwd+Adam + latent Gaussian statistics update, hipGraph replay",
+                       "per_gpu_batch": B, "global_batch": world * B,
+                       "parallelism": f"dp{world}" if world > 1 else "single GPU"},
+            "final_loss": final_loss,
+            "step_roofline": {"alg_gbytes_per_s": round(ips * ALG_BYTES_PER_IMAGE_FWD_BWD / 1e9 / world, 2),
+                              "frac_of_hbm_peak": round(ips / world * ALG_BYTES_PER_IMAGE_FWD_BWD / 1e9 / HBM_PEAK_GBS, 5),
+                              "alg_tflops": round(ips / world * ALG_FLOP_PER_IMAGE_FWD_BWD / 1e12, 3),
+                              "frac_of_fp32_peak": round(ips / world * ALG_FLOP_PER_IMAGE_FWD_BWD / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)},
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_launch_ms": round(dom["ms"], 4),
+                         "note": "exp/VALU-bound kernel: %.1f G pair-evaluations/s" % (dom["pair_evals"] / dom["ms"] / 1e6)},
+        }
+        if world == 1:
+            try:
+                line["parity"] = parity_check(A)
+            except Exception as e:  # noqa: BLE001
+                line["parity"] = {"error": repr(e)}
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(A)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

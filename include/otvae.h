@@ -65,17 +65,17 @@ int otvae_weight_transpose(const float* wT, float* wD, int T, int Cs, int Cn, vo
 /* ---- ConvLayer backward ------------------------------------------------------------------------------------ */
 /* Data gradient.  gv[N][Hs][Ws][Cs] = d loss / d (x*scale+shift) i.e. the gradient entering BatchNorm's output
  * (after the nearest-upsample sum and the ReLU mask recomputed from x).  With mean/invstd != NULL also writes
- * the per-block partial sums bn_partial[P][2][CsPad] of (gv, gv*xhat) that BatchNorm backward needs;
+ * the per-block fp64 partial sums bn_partial[P][2][CsPad] of (gv, gv*xhat) that BatchNorm backward needs;
  * P and CsPad from otvae_conv_bwd_data_ws. */
 int otvae_conv_bwd_data_ws(const otvae_conv_geom* g, int* P, int* CsPad);
 int otvae_conv_bwd_data(const otvae_conv_geom* g, const float* gy, const float* wD,
                         const float* x, const float* scale, const float* shift, int relu,
                         const float* mean, const float* invstd,
-                        float* gv, float* bn_partial, void* stream);
+                        float* gv, double* bn_partial, void* stream);
 /* BatchNorm backward for up to two branches that normalise the same x (block[0] and skip):
  * finalize: reduces the partials, writes dgamma/dbeta of each branch and the coefficient vectors coef[(2+nb)][C]
  * apply:    dx = sum_b coef[2+b][c]*gv_b - coef[0][c]*x - coef[1][c]   (elementwise, M*C elements) */
-int otvae_bn_bwd_finalize(int nb, const float* const* bn_partial, const int* P, int CsPad, int64_t M, int C,
+int otvae_bn_bwd_finalize(int nb, const double* const* bn_partial, const int* P, int CsPad, int64_t M, int C,
                           const float* mean, const float* invstd, const float* const* gamma,
                           float* const* dgamma, float* const* dbeta, float* coef, void* stream);
 int otvae_bn_bwd_apply(int nb, const float* const* gv, const float* x, const float* coef, int64_t M, int C,

@@ -131,7 +131,7 @@ extern "C" int otvae_bn_finalize(const double* partial, int P, int64_t M, int C,
 //   dx = sum_b k_b*g_b - A*x - B,  k_b = gamma_b*invstd, A = invstd/M * sum_b k_b*dgamma_b,
 //   B = sum_b k_b*(dbeta_b/M) - A*mean
 struct BnBwdFin {
-    const float* partial[2];
+    const double* partial[2];
     int P[2];
     const float* gamma[2];
     float* dgamma[2];
@@ -146,8 +146,8 @@ __global__ void bn_bwd_finalize_kernel(int nb, BnBwdFin f, int CsPad, int64_t M,
         for (int b = 0; b < nb; ++b) {
             double s1 = 0.0, s2 = 0.0;
             for (int p = 0; p < f.P[b]; ++p) {
-                s1 += (double)f.partial[b][((size_t)p * 2 + 0) * CsPad + c];
-                s2 += (double)f.partial[b][((size_t)p * 2 + 1) * CsPad + c];
+                s1 += f.partial[b][((size_t)p * 2 + 0) * CsPad + c];
+                s2 += f.partial[b][((size_t)p * 2 + 1) * CsPad + c];
             }
             if (f.dbeta[b]) f.dbeta[b][c] = (float)s1;
             if (f.dgamma[b]) f.dgamma[b][c] = (float)s2;
@@ -163,7 +163,7 @@ __global__ void bn_bwd_finalize_kernel(int nb, BnBwdFin f, int CsPad, int64_t M,
     }
 }
 
-extern "C" int otvae_bn_bwd_finalize(int nb, const float* const* bn_partial, const int* P, int CsPad, int64_t M, int C,
+extern "C" int otvae_bn_bwd_finalize(int nb, const double* const* bn_partial, const int* P, int CsPad, int64_t M, int C,
                                      const float* mean, const float* invstd, const float* const* gamma, float* const* dgamma,
                                      float* const* dbeta, float* coef, void* stream) {
     OTVAE_REQUIRE(nb >= 1 && nb <= 2, "otvae_bn_bwd_finalize: nb must be 1 or 2");

@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
                                                          const float* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int relu,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                         float* __restrict__ gv, float* __restrict__ partial, int CsPad) {
-    __shared__ float red[4][2][16 * NT];
+                                                         float* __restrict__ gv, double* __restrict__ partial, int CsPad) {
+    __shared__ double red[4][2][16 * NT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int cls = blockIdx.z;
@@ -246,9 +246,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
     const int kh0 = (g.stride == 2) ? ((py + g.pad) & 1) : 0;
     const int kw0 = (g.stride == 2) ? ((px + g.pad) & 1) : 0;
 
-    float s1[NT], s2[NT];
+    // BatchNorm-backward sums in fp64: sum(gv*xhat) cancels heavily and the reference accumulates in double too
+    double s1[NT], s2[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.0;
 
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const unsigned row = tile * 64 + wave * 16 + r16;
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
                     }
                     gv[o] = val;
                     if (mean) {
-                        s1[j] += val;
-                        s2[j] += val * ((xv - mu) * is);
+                        s1[j] += (double)val;
+                        s2[j] += (double)val * (double)((xv - mu) * is);
                     }
                 }
             } else {
@@ -336,8 +337,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
                         }
                         gv[o] = val;
                         if (mean) {
-                            s1[j] += val;
-                            s2[j] += val * ((xv - mu) * is);
+                            s1[j] += (double)val;
+                            s2[j] += (double)val * (double)((xv - mu) * is);
                         }
                     }
                 }
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
         // fixed-order reduction: 4 lane groups of a wave (shuffle), then the 4 waves (LDS), one partial per block
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            float a = s1[j], b = s2[j];
+            double a = s1[j], b = s2[j];
             a += __shfl_xor(a, 16, 64);
             a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 16, 64);
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
         __syncthreads();
         if (threadIdx.x < 2 * 16 * NT) {
             const int which = threadIdx.x / (16 * NT), cc = threadIdx.x % (16 * NT);
-            const float t = (red[0][which][cc] + red[1][which][cc]) + (red[2][which][cc] + red[3][which][cc]);
+            const double t = (red[0][which][cc] + red[1][which][cc]) + (red[2][which][cc] + red[3][which][cc]);
             const unsigned p = blockIdx.z * gridDim.x + blockIdx.x;
             partial[((size_t)p * 2 + which) * CsPad + c0col + cc] = t;
         }
@@ -395,7 +396,7 @@ extern "C" int otvae_conv_bwd_data_ws(const otvae_conv_geom* gg, int* P, int* Cs
 template <bool SMALLC>
 static void launch_dgrad(int NT, dim3 grid, hipStream_t st, Geom g, const float* gy, const float* wD, const float* x,
                          const float* scale, const float* shift, int relu, const float* mean, const float* invstd, float* gv,
-                         float* partial, int CsPad) {
+                         double* partial, int CsPad) {
 #define OTVAE_DG(N_) \
     conv_dgrad_kernel<N_, SMALLC><<<grid, 256, 0, st>>>(g, gy, wD, x, scale, shift, relu, mean, invstd, gv, partial, CsPad)
     switch (NT) {
@@ -409,7 +410,7 @@ static void launch_dgrad(int NT, dim3 grid, hipStream_t st, Geom g, const float*
 
 extern "C" int otvae_conv_bwd_data(const otvae_conv_geom* gg, const float* gy, const float* wD, const float* x,
                                    const float* scale, const float* shift, int relu, const float* mean, const float* invstd,
-                                   float* gv, float* bn_partial, void* stream) {
+                                   float* gv, double* bn_partial, void* stream) {
     int rc = check_geom(gg, "otvae_conv_bwd_data");
     if (rc) return rc;
     OTVAE_REQUIRE(gy && wD && gv, "otvae_conv_bwd_data: NULL tensor");

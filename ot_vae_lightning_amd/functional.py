@@ -210,7 +210,7 @@ class _ConvBNFn(torch.autograd.Function):
                 check(lib.otvae_conv_bwd_data_ws(C.byref(g), C.byref(p_d), C.byref(cp)), "otvae_conv_bwd_data_ws")
                 gv = empty_nhwc(n, cs, hs, ws, x)
                 if sp.has_norm:
-                    part = torch.empty((p_d.value, 2, cp.value), device=x.device, dtype=torch.float32)
+                    part = torch.empty((p_d.value, 2, cp.value), device=x.device, dtype=torch.float64)
                     cspad = cp.value
                 check(lib.otvae_conv_bwd_data(C.byref(g), ptr(gy), ptr(wd), ptr(x),
                                               ptr(scales[b]) if sp.has_norm else None,
