@@ -73,28 +73,36 @@ struct BnFin {
     float* shift[2];
 };
 
-__global__ void bn_finalize_kernel(const double* __restrict__ partial, int P, int64_t M, int C, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ invstd, int n_bn, BnFin f) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+// one wave per channel: lanes stride over the <= 256 partials, fixed-order shuffle tree
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int P, int64_t M, int C, float eps,
+                                                          float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                                          int n_bn, BnFin f) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c < C) {
         double s = 0.0, q = 0.0;
-        for (int p = 0; p < P; ++p) {
+        for (int p = lane; p < P; p += 64) {
             s += partial[((size_t)p * 2 + 0) * C + c];
             q += partial[((size_t)p * 2 + 1) * C + c];
         }
-        const double mu = s / (double)M;
-        double var = q / (double)M - mu * mu;
-        if (var < 0.0) var = 0.0;
-        const float fmu = (float)mu;
-        const float fis = (float)(1.0 / sqrt(var + (double)eps));
-        mean[c] = fmu;
-        invstd[c] = fis;
-        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-        for (int b = 0; b < n_bn; ++b) {
-            const float sc = f.gamma[b][c] * fis;
-            f.scale[b][c] = sc;
-            f.shift[b][c] = fmaf(-fmu, sc, f.beta[b][c]);
-            if (f.rmean[b]) f.rmean[b][c] = (1.f - momentum) * f.rmean[b][c] + momentum * fmu;
-            if (f.rvar[b]) f.rvar[b][c] = (1.f - momentum) * f.rvar[b][c] + momentum * (float)unbiased;
+        s = wave_sum(s);
+        q = wave_sum(q);
+        if (lane == 0) {
+            const double mu = s / (double)M;
+            double var = q / (double)M - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float fmu = (float)mu;
+            const float fis = (float)(1.0 / sqrt(var + (double)eps));
+            mean[c] = fmu;
+            invstd[c] = fis;
+            const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+            for (int b = 0; b < n_bn; ++b) {
+                const float sc = f.gamma[b][c] * fis;
+                f.scale[b][c] = sc;
+                f.shift[b][c] = fmaf(-fmu, sc, f.beta[b][c]);
+                if (f.rmean[b]) f.rmean[b][c] = (1.f - momentum) * f.rmean[b][c] + momentum * fmu;
+                if (f.rvar[b]) f.rvar[b][c] = (1.f - momentum) * f.rvar[b][c] + momentum * (float)unbiased;
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -119,7 +127,7 @@ extern "C" int otvae_bn_finalize(const double* partial, int P, int64_t M, int C,
         f.scale[b] = scale[b];
         f.shift[b] = shift[b];
     }
-    bn_finalize_kernel<<<cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(partial, P, M, C, eps, momentum, mean, invstd, n_bn, f);
+    bn_finalize_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partial, P, M, C, eps, momentum, mean, invstd, n_bn, f);
     OTVAE_CHECK_LAUNCH("otvae_bn_finalize");
     return OTVAE_OK;
 }
@@ -138,24 +146,32 @@ struct BnBwdFin {
     float* dbeta[2];
 };
 
-__global__ void bn_bwd_finalize_kernel(int nb, BnBwdFin f, int CsPad, int64_t M, int C, const float* __restrict__ mean,
-                                       const float* __restrict__ invstd, float* __restrict__ coef) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        const double is = (double)invstd[c], mu = (double)mean[c];
-        double A = 0.0, B = 0.0;
-        for (int b = 0; b < nb; ++b) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int p = 0; p < f.P[b]; ++p) {
-                s1 += f.partial[b][((size_t)p * 2 + 0) * CsPad + c];
-                s2 += f.partial[b][((size_t)p * 2 + 1) * CsPad + c];
-            }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int nb, BnBwdFin f, int CsPad, int64_t M, int C,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              float* __restrict__ coef) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const double is = (double)invstd[c], mu = (double)mean[c];
+    double A = 0.0, B = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int p = lane; p < f.P[b]; p += 64) {
+            s1 += f.partial[b][((size_t)p * 2 + 0) * CsPad + c];
+            s2 += f.partial[b][((size_t)p * 2 + 1) * CsPad + c];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const double k = (double)f.gamma[b][c] * is;
+        if (lane == 0) {
             if (f.dbeta[b]) f.dbeta[b][c] = (float)s1;
             if (f.dgamma[b]) f.dgamma[b][c] = (float)s2;
-            const double k = (double)f.gamma[b][c] * is;
             coef[(size_t)(2 + b) * C + c] = (float)k;
-            A += k * s2;
-            B += k * s1;
         }
+        A += k * s2;
+        B += k * s1;
+    }
+    if (lane == 0) {
         A = A * is / (double)M;
         B = B / (double)M - A * mu;
         coef[c] = (float)A;
@@ -178,7 +194,7 @@ extern "C" int otvae_bn_bwd_finalize(int nb, const double* const* bn_partial, co
         f.dgamma[b] = dgamma ? dgamma[b] : nullptr;
         f.dbeta[b] = dbeta ? dbeta[b] : nullptr;
     }
-    bn_bwd_finalize_kernel<<<cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(nb, f, CsPad, M, C, mean, invstd, coef);
+    bn_bwd_finalize_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(nb, f, CsPad, M, C, mean, invstd, coef);
     OTVAE_CHECK_LAUNCH("otvae_bn_bwd_finalize");
     return OTVAE_OK;
 }

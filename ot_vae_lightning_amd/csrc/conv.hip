@@ -1,17 +1,21 @@
-// ConvLayer forward / data-gradient / weight-gradient as implicit GEMMs on the fp32 MFMA (v_mfma_f32_16x16x4_f32).
+// ConvLayer forward / data-gradient / weight-gradient as LDS-staged implicit GEMMs on the fp32 MFMA
+// (v_mfma_f32_16x16x4_f32), CDNA4 / gfx950.
 //
 // Replaces the ATen sequence  batch_norm -> relu -> upsample_nearest2d -> conv2d (+bias, +residual add)  issued by
 // ConvLayer.forward (reference networks/cnn.py:183-192) and its autograd backward, for the layer geometries the
 // CNN builder produces (3x3 s1 p1, 4x4 s2 p1, 1x1, optional nearest x2 up-sampling before the conv).
 //
-// GEMM view (M = pixels, K = taps*channels, N = output channels), all operands gathered straight from NHWC global
-// memory, normalisation/activation/up-sampling/zero-padding applied on the operand load:
-//   fwd   Y[m][n]  = sum_k act(X)[gather(m,k)] * W[k][n]                  rows = output pixels
-//   dgrad dU[q][c] = sum_(t,n) GY[gather(q,t)][n] * Wd[(t,n)][c]          rows = input positions (grouped so that
-//                    the 4 nearest-upsample children of a pixel, resp. one stride-parity class, share a wave)
-//   wgrad dW[k][n] = sum_m act(X)[gather(m,k)] * GY[m][n]                 rows = k, reduction over pixels
-// Tile per wave: 16 rows x (16*NT) columns, K advanced 4 at a time.  A wave's MFMA operands are one fp32 per lane:
-// A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15]; D[r] = D[(lane>>4)*4 + r][lane&15].
+// GEMM view, NHWC activations, HWIO weights:
+//   fwd   Y[m][n]  = sum_k A[m][k] W[k][n]        A[m][k] = act(x)[pixel(m) + tap(k)][chan(k)]   rows = output pixels
+//   dgrad dU[q][c] = sum_k G[q][k] Wd[k][c]       G[q][k] = gy[pixel(q) - tap(k)][chan(k)]       rows = input positions
+//   wgrad dW[k][n] = sum_m A[m][k] gy[m][n]       rows = k (taps*channels, + one bias row), reduction over pixels
+// A workgroup (4 waves) owns a 64-row x (16*NT)-column tile.  Per K-chunk of 32 the 256 threads gather the A tile
+// (normalisation, ReLU, nearest up-sampling and zero padding applied on the way) and the weight tile into LDS with
+// all loads of the chunk in flight at once, double-buffered against the MFMAs of the previous chunk; each wave then
+// feeds v_mfma_f32_16x16x4_f32 from LDS (A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15],
+// D[r] = D[(lane>>4)*4 + r][lane&15]).  LDS leading dimensions (KC+2 / BN+16) make both operand reads conflict-free.
+// Taps that cannot touch the image for any row of the layer (e.g. 8 of the 9 taps of a 3x3 conv on a 1x1 map) are
+// dropped from K at kernel start.
 #include "common.h"
 
 struct Geom {
@@ -36,126 +40,357 @@ static int check_geom(const otvae_conv_geom* g, const char* who) {
                   g->Ho, g->Wo, ho, wo);
     OTVAE_REQUIRE((int64_t)g->N * Hu * Wu * imax(g->Cs, g->Cn) < (int64_t)1 << 31, "%s: tensor too large for 32-bit indexing",
                   who);
+    OTVAE_REQUIRE(g->Cs <= 2048 && g->Cn <= 2048, "%s: more than 2048 channels unsupported", who);
     if (g->stride == 2) OTVAE_REQUIRE(g->Hs % 2 == 0 && g->Ws % 2 == 0, "%s: stride 2 needs even input size", who);
     return OTVAE_OK;
-}
-
-__device__ __forceinline__ float act_load(const float* __restrict__ x, unsigned idx, int c, const float* __restrict__ scale,
-                                          const float* __restrict__ shift, int relu) {
-    float a = x[idx];
-    if (scale) a = fmaf(a, scale[c], shift[c]);
-    if (relu) a = fmaxf(a, 0.f);
-    return a;
-}
-
-// ------------------------------------------------------------------------------------------------ forward
-template <int NT, bool SMALLC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, int relu,
-                                                       const float* __restrict__ wT, const float* __restrict__ bias,
-                                                       const float* __restrict__ res, float* __restrict__ y) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
-    const unsigned ntiles = (M + 63) / 64;
-    const int n0 = blockIdx.y * (16 * NT);
-    const int Hu = g.Hs * g.up, Wu = g.Ws * g.up;
-    const int ush = g.up - 1;  // up in {1,2} -> shift 0/1
-    const int T = g.KH * g.KW;
-
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const unsigned m = tile * 64 + wave * 16 + r16;
-        const bool mv = m < M;
-        int ox = 0, oy = 0, n = 0;
-        if (mv) {
-            ox = m % g.Wo;
-            unsigned t = m / g.Wo;
-            oy = t % g.Ho;
-            n = t / g.Ho;
-        }
-        f32x4 acc[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        if constexpr (!SMALLC) {
-            for (int kh = 0; kh < g.KH; ++kh) {
-                const int iy = oy * g.stride + kh - g.pad;
-                for (int kw = 0; kw < g.KW; ++kw) {
-                    const int ix = ox * g.stride + kw - g.pad;
-                    const bool inb = mv && iy >= 0 && iy < Hu && ix >= 0 && ix < Wu;
-                    const unsigned base = (((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * g.Cs;
-                    const float* wrow = wT + (size_t)(kh * g.KW + kw) * g.Cs * g.Cn;
-                    for (int c0 = 0; c0 < g.Cs; c0 += 4) {
-                        const int c = c0 + kq;
-                        float a = 0.f;
-                        if (inb) a = act_load(x, base + c, c, scale, shift, relu);
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            const int col = n0 + j * 16 + r16;
-                            const float b = col < g.Cn ? wrow[(size_t)c * g.Cn + col] : 0.f;
-                            acc[j] = mfma16(a, b, acc[j]);
-                        }
-                    }
-                }
-            }
-        } else {
-            const int K = T * g.Cs;
-            for (int k0 = 0; k0 < K; k0 += 4) {
-                const int k = k0 + kq;
-                const bool kv = k < K;
-                const int t = kv ? k / g.Cs : 0;
-                const int c = kv ? k - t * g.Cs : 0;
-                const int kh = t / g.KW, kw = t - kh * g.KW;
-                const int iy = oy * g.stride + kh - g.pad, ix = ox * g.stride + kw - g.pad;
-                const bool inb = kv && mv && iy >= 0 && iy < Hu && ix >= 0 && ix < Wu;
-                float a = 0.f;
-                if (inb) {
-                    const unsigned idx = (((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * g.Cs + c;
-                    a = act_load(x, idx, c, scale, shift, relu);
-                }
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int col = n0 + j * 16 + r16;
-                    const float b = (kv && col < g.Cn) ? wT[(size_t)k * g.Cn + col] : 0.f;
-                    acc[j] = mfma16(a, b, acc[j]);
-                }
-            }
-        }
-        // epilogue: rows kq*4+r of this wave's 16-pixel tile, column r16 of each n-tile
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + j * 16 + r16;
-            if (col < g.Cn) {
-                const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned pm = tile * 64 + wave * 16 + kq * 4 + r;
-                    if (pm < M) {
-                        const size_t o = (size_t)pm * g.Cn + col;
-                        float v = acc[j][r] + bv;
-                        if (res) v += res[o];
-                        y[o] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <bool SMALLC>
-static void launch_fwd(int NT, dim3 grid, hipStream_t st, Geom g, const float* x, const float* scale, const float* shift,
-                       int relu, const float* wT, const float* bias, const float* res, float* y) {
-    switch (NT) {
-        case 1: conv_fwd_kernel<1, SMALLC><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y); break;
-        case 2: conv_fwd_kernel<2, SMALLC><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y); break;
-        case 3: conv_fwd_kernel<3, SMALLC><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y); break;
-        default: conv_fwd_kernel<4, SMALLC><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y); break;
-    }
 }
 
 static inline int pick_nt(int ncols) {
     int nnt = cdiv(ncols, 16);
     return nnt >= 4 ? 4 : nnt;
+}
+
+#define MAX_TAPS 49
+#define KC 32  // K-chunk staged per pipeline step
+#define TM 64  // rows per workgroup tile
+#define PAD_MARK 0x7fc00001  // NaN payload marking "padding / out of range": becomes an exact 0 AFTER the activation
+#define ONE_MARK 0x7fc00002  // bias row of the weight gradient: exact 1
+
+// exact floor(k / d) for 0 <= k < 2^17, 1 <= d <= 2^11 with one multiply: (k+0.5)/d is at least 0.5/d away from an
+// integer while the float product is off by < 2^-23 * k/d, so truncation cannot cross an integer boundary.
+__device__ __forceinline__ int fast_div(int k, float inv_d) { return (int)(((float)k + 0.5f) * inv_d); }
+
+// ------------------------------------------------------------------------------------------------ fwd + dgrad
+// MODE 0 (FWD):   S = x  [N][Hs][Ws][Cs], CK = Cs, NC = Cn, Bmat = HWIO weight [T][Cs][Cn]
+// MODE 1 (DGRAD): S = gy [N][Ho][Wo][Cn], CK = Cn, NC = Cs, Bmat = wD [T][Cn][Cs]
+// Rows of DGRAD are grouped so that a lane's 4 accumulator registers are the 4 nearest-upsample children of one source
+// pixel (up == 2), or 4 positions of ONE stride-parity class (stride == 2, class = blockIdx.z).
+__device__ __forceinline__ void dgrad_row_to_pos(const Geom& g, unsigned row, int py, int px, int& n, int& iy, int& ix) {
+    if (g.up == 2) {
+        const unsigned parent = row >> 2, child = row & 3;
+        const int sx = parent % g.Ws;
+        const unsigned t = parent / g.Ws;
+        const int sy = t % g.Hs;
+        n = t / g.Hs;
+        iy = 2 * sy + (child >> 1);
+        ix = 2 * sx + (child & 1);
+    } else if (g.stride == 2) {
+        const int W2 = g.Ws >> 1, H2 = g.Hs >> 1;
+        const int jx = row % W2;
+        const unsigned t = row / W2;
+        const int jy = t % H2;
+        n = t / H2;
+        iy = 2 * jy + py;
+        ix = 2 * jx + px;
+    } else {
+        ix = row % g.Ws;
+        const unsigned t = row / g.Ws;
+        iy = t % g.Hs;
+        n = t / g.Hs;
+    }
+}
+
+template <int MODE, int NT>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __restrict__ S, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int relu,
+                                                        const float* __restrict__ Bmat,
+                                                        // FWD epilogue
+                                                        const float* __restrict__ bias, const float* __restrict__ res,
+                                                        float* __restrict__ y,
+                                                        // DGRAD epilogue
+                                                        const float* __restrict__ xin, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ gv,
+                                                        double* __restrict__ partial, int CsPad) {
+    constexpr int BN = 16 * NT;
+    constexpr int LDA = KC + 2;
+    constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 0);
+    constexpr int NB_ELEMS = KC * BN / 256;  // weight-tile elements staged per thread per chunk
+    __shared__ float As[2][TM * LDA];
+    __shared__ float Bs[2][KC * LDB];
+    __shared__ int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_w[MAX_TAPS];
+    __shared__ int s_ntaps;
+    __shared__ int row_n[TM], row_y[TM], row_x[TM];
+    __shared__ double red[(MODE == 1) ? 4 * 2 * BN : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int cls = blockIdx.z, py = cls >> 1, px = cls & 1;
+    const int Hu = g.Hs * g.up, Wu = g.Ws * g.up;
+    const int CK = MODE == 0 ? g.Cs : g.Cn;
+    const int NC = MODE == 0 ? g.Cn : g.Cs;
+    const int n0 = blockIdx.y * BN;
+    // source geometry seen by the gather: a tap is in range iff 0 <= t < lim, source coordinate = t >> sh
+    const int lim_y = MODE == 0 ? Hu : g.Ho * g.stride, lim_x = MODE == 0 ? Wu : g.Wo * g.stride;
+    const int sh = MODE == 0 ? g.up - 1 : g.stride - 1;
+    const int srcH = MODE == 0 ? g.Hs : g.Ho, srcW = MODE == 0 ? g.Ws : g.Wo;
+    const unsigned rows = MODE == 0 ? (unsigned)g.N * g.Ho * g.Wo
+                                    : (g.stride == 2 ? (unsigned)g.N * (g.Hs >> 1) * (g.Ws >> 1) : (unsigned)g.N * Hu * Wu);
+    const unsigned ntiles = (rows + TM - 1) / TM;
+
+    // ---- valid tap list (uniform over the launch, resp. over the parity class)
+    if (tid == 0) {
+        int nt = 0;
+        for (int kh = 0; kh < g.KH; ++kh)
+            for (int kw = 0; kw < g.KW; ++kw) {
+                bool ok;
+                int dy, dx;
+                if (MODE == 0) {
+                    // row anchor = (oy*stride, ox*stride); tap offset = kh - pad
+                    dy = kh - g.pad;
+                    dx = kw - g.pad;
+                    ok = (dy + (g.Ho - 1) * g.stride >= 0) && (dy < Hu) && (dx + (g.Wo - 1) * g.stride >= 0) && (dx < Wu);
+                } else {
+                    // row anchor = (iy, ix); t = iy + pad - kh must be a multiple of stride inside [0, Ho*stride)
+                    dy = g.pad - kh;
+                    dx = g.pad - kw;
+                    ok = true;
+                    if (g.stride == 2) ok = (((py + dy) & 1) == 0) && (((px + dx) & 1) == 0);
+                    ok = ok && (Hu - 1 + dy >= 0) && (dy < lim_y) && (Wu - 1 + dx >= 0) && (dx < lim_x);
+                }
+                if (ok) {
+                    tap_dy[nt] = dy;
+                    tap_dx[nt] = dx;
+                    tap_w[nt] = kh * g.KW + kw;
+                    ++nt;
+                }
+            }
+        s_ntaps = nt;
+    }
+    __syncthreads();
+    const int ntaps = s_ntaps;
+    const int K = ntaps * CK;
+    const int nch = (K + KC - 1) / KC;
+    const float inv_ck = 1.0f / (float)CK;
+
+    // staging role for the A tile: one k per thread, rows a_r0 + 8 i
+    const int a_kl = tid & 31, a_r0 = tid >> 5;
+
+    double s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.0;
+
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();  // readers of row_* / LDS buffers of the previous tile are done
+        if (tid < TM) {
+            const unsigned row = tile * TM + tid;
+            int n = -1, ry = 0, rx = 0;
+            if (row < rows) {
+                if (MODE == 0) {
+                    const int ox = row % g.Wo;
+                    const unsigned t = row / g.Wo;
+                    const int oy = t % g.Ho;
+                    n = t / g.Ho;
+                    ry = oy * g.stride;
+                    rx = ox * g.stride;
+                } else {
+                    int iy, ix;
+                    dgrad_row_to_pos(g, row, py, px, n, iy, ix);
+                    ry = iy;
+                    rx = ix;
+                }
+            }
+            row_n[tid] = n;
+            row_y[tid] = ry;
+            row_x[tid] = rx;
+        }
+        __syncthreads();
+
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        float areg[8], breg[NB_ELEMS];
+        float a_sc = 1.f, a_sh = 0.f;
+
+        auto stage_load = [&](int ch) {
+            // ---- A
+            const int k = ch * KC + a_kl;
+            const bool kv = k < K;
+            const int tl = kv ? fast_div(k, inv_ck) : 0;
+            const int c = k - tl * CK;
+            const int dy = tap_dy[tl], dx = tap_dx[tl];
+            if (MODE == 0 && scale != nullptr && kv) {
+                a_sc = scale[c];
+                a_sh = shift[c];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = a_r0 + 8 * i;
+                const int n = row_n[r];
+                const int ty = row_y[r] + dy, tx = row_x[r] + dx;
+                float v = __int_as_float(PAD_MARK);
+                if (kv && n >= 0 && ty >= 0 && ty < lim_y && tx >= 0 && tx < lim_x) {
+                    const unsigned pix = ((unsigned)n * srcH + (ty >> sh)) * srcW + (tx >> sh);
+                    v = S[(size_t)pix * CK + c];
+                }
+                areg[i] = v;
+            }
+            // ---- weights
+#pragma unroll
+            for (int j = 0; j < NB_ELEMS; ++j) {
+                const int e = tid + 256 * j;
+                const int kb = e / BN, col = e - kb * BN;
+                const int kk = ch * KC + kb;
+                float v = 0.f;
+                if (kk < K && n0 + col < NC) {
+                    const int t2 = fast_div(kk, inv_ck);
+                    const int c2 = kk - t2 * CK;
+                    v = Bmat[((size_t)tap_w[t2] * CK + c2) * NC + n0 + col];
+                }
+                breg[j] = v;
+            }
+        };
+        auto stage_store = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = areg[i];
+                if (__float_as_int(v) == PAD_MARK) {
+                    v = 0.f;
+                } else if (MODE == 0) {
+                    if (scale != nullptr) v = fmaf(v, a_sc, a_sh);
+                    if (relu) v = fmaxf(v, 0.f);
+                }
+                As[buf][(a_r0 + 8 * i) * LDA + a_kl] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NB_ELEMS; ++j) {
+                const int e = tid + 256 * j;
+                const int kb = e / BN, col = e - kb * BN;
+                Bs[buf][kb * LDB + col] = breg[j];
+            }
+        };
+
+        if (nch > 0) {
+            stage_load(0);
+            stage_store(0);
+        }
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            const int buf = ch & 1;
+            if (ch + 1 < nch) stage_load(ch + 1);  // global loads of the next chunk fly under this chunk's MFMAs
+            const float* Ab = &As[buf][(wave * 16 + r16) * LDA + kq];
+            const float* Bb = &Bs[buf][kq * LDB + r16];
+#pragma unroll
+            for (int ks = 0; ks < KC / 4; ++ks) {
+                const float a = Ab[ks * 4];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = mfma16(a, Bb[ks * 4 * LDB + j * 16], acc[j]);
+            }
+            if (ch + 1 < nch) stage_store(buf ^ 1);
+            __syncthreads();
+        }
+
+        // ---- epilogue
+        const unsigned row0 = tile * TM + wave * 16 + kq * 4;
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + j * 16 + r16;
+                if (col < g.Cn) {
+                    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned pm = row0 + r;
+                        if (pm < rows) {
+                            const size_t o = (size_t)pm * g.Cn + col;
+                            float v = acc[j][r] + bv;
+                            if (res) v += res[o];
+                            y[o] = v;
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + j * 16 + r16;
+                if (col >= g.Cs) continue;
+                const float sc = scale ? scale[col] : 1.f, shf = scale ? shift[col] : 0.f;
+                const float mu = mean ? mean[col] : 0.f, is = mean ? invstd[col] : 0.f;
+                if (g.up == 2) {
+                    if (row0 < rows) {
+                        const unsigned parent = row0 >> 2;
+                        float val = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+                        const size_t o = (size_t)parent * g.Cs + col;
+                        float xv = 0.f;
+                        if (relu || mean) xv = xin[o];
+                        if (relu) {
+                            const float v = scale ? fmaf(xv, sc, shf) : xv;
+                            val = v > 0.f ? val : 0.f;
+                        }
+                        gv[o] = val;
+                        if (mean) {
+                            s1[j] += (double)val;
+                            s2[j] += (double)val * (double)((xv - mu) * is);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned rr = row0 + r;
+                        if (rr < rows) {
+                            int pn, piy, pix;
+                            dgrad_row_to_pos(g, rr, py, px, pn, piy, pix);
+                            const size_t o = ((size_t)((unsigned)pn * g.Hs + piy) * g.Ws + pix) * g.Cs + col;
+                            float val = acc[j][r];
+                            float xv = 0.f;
+                            if (relu || mean) xv = xin[o];
+                            if (relu) {
+                                const float v = scale ? fmaf(xv, sc, shf) : xv;
+                                val = v > 0.f ? val : 0.f;
+                            }
+                            gv[o] = val;
+                            if (mean) {
+                                s1[j] += (double)val;
+                                s2[j] += (double)val * (double)((xv - mu) * is);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (MODE == 1 && mean) {
+        // fixed-order reduction of the BatchNorm-backward sums: lane groups (shuffle), waves (LDS), one partial per block
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            double a = s1[j], b = s2[j];
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64);
+            b += __shfl_xor(b, 32, 64);
+            if (kq == 0) {
+                red[(wave * 2 + 0) * BN + j * 16 + r16] = a;
+                red[(wave * 2 + 1) * BN + j * 16 + r16] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, cc = tid % BN;
+            const double t = (red[(0 * 2 + which) * BN + cc] + red[(1 * 2 + which) * BN + cc]) +
+                             (red[(2 * 2 + which) * BN + cc] + red[(3 * 2 + which) * BN + cc]);
+            const unsigned p = blockIdx.z * gridDim.x + blockIdx.x;
+            partial[((size_t)p * 2 + which) * CsPad + n0 + cc] = t;
+        }
+    }
+}
+
+template <int MODE>
+static void launch_gemm(int NT, dim3 grid, hipStream_t st, Geom g, const float* S, const float* scale, const float* shift,
+                        int relu, const float* Bmat, const float* bias, const float* res, float* y, const float* xin,
+                        const float* mean, const float* invstd, float* gv, double* partial, int CsPad) {
+#define OTVAE_CG(N_)                                                                                                     \
+    conv_gemm_kernel<MODE, N_><<<grid, 256, 0, st>>>(g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, \
+                                                     partial, CsPad)
+    switch (NT) {
+        case 1: OTVAE_CG(1); break;
+        case 2: OTVAE_CG(2); break;
+        case 3: OTVAE_CG(3); break;
+        default: OTVAE_CG(4); break;
+    }
+#undef OTVAE_CG
 }
 
 extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const float* scale, const float* shift, int relu,
@@ -167,12 +402,9 @@ extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const f
     Geom g = to_geom(gg);
     const int NT = pick_nt(g.Cn);
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
-    dim3 grid(imin(cdiv(M, 64), 16384), cdiv(cdiv(g.Cn, 16), NT));
-    hipStream_t st = (hipStream_t)stream;
-    if (g.Cs % 4 == 0)
-        launch_fwd<false>(NT, grid, st, g, x, scale, shift, relu, wT, bias, residual, y);
-    else
-        launch_fwd<true>(NT, grid, st, g, x, scale, shift, relu, wT, bias, residual, y);
+    dim3 grid(imin(cdiv(M, TM), 8192), cdiv(cdiv(g.Cn, 16), NT), 1);
+    launch_gemm<0>(NT, grid, (hipStream_t)stream, g, x, scale, shift, relu, wT, bias, residual, y, nullptr, nullptr, nullptr,
+                   nullptr, nullptr, 0);
     OTVAE_CHECK_LAUNCH("otvae_conv_fwd");
     return OTVAE_OK;
 }
@@ -199,184 +431,14 @@ extern "C" int otvae_weight_transpose(const float* wT, float* wD, int T, int Cs,
 }
 
 // ------------------------------------------------------------------------------------------------ data gradient
-// Rows enumerate positions of the conv input (after up-sampling) so that a lane's 4 accumulator registers are
-//   up == 2     : the 4 nearest-upsample children of one source pixel (summed in the epilogue)
-//   stride == 2 : 4 consecutive positions of ONE parity class (blockIdx.z), whose valid taps are uniform
-//   otherwise   : 4 consecutive positions.
-__device__ __forceinline__ void dgrad_row_to_pos(const Geom& g, unsigned row, int py, int px, int& n, int& iy, int& ix) {
-    if (g.up == 2) {
-        const unsigned parent = row >> 2, child = row & 3;
-        const int sx = parent % g.Ws;
-        const unsigned t = parent / g.Ws;
-        const int sy = t % g.Hs;
-        n = t / g.Hs;
-        iy = 2 * sy + (child >> 1);
-        ix = 2 * sx + (child & 1);
-    } else if (g.stride == 2) {
-        const int W2 = g.Ws >> 1, H2 = g.Hs >> 1;
-        const int jx = row % W2;
-        const unsigned t = row / W2;
-        const int jy = t % H2;
-        n = t / H2;
-        iy = 2 * jy + py;
-        ix = 2 * jx + px;
-    } else {
-        ix = row % g.Ws;
-        const unsigned t = row / g.Ws;
-        iy = t % g.Hs;
-        n = t / g.Hs;
-    }
-}
-
-template <int NT, bool SMALLC>
-__global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __restrict__ gy, const float* __restrict__ wD,
-                                                         const float* __restrict__ x, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, int relu,
-                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                         float* __restrict__ gv, double* __restrict__ partial, int CsPad) {
-    __shared__ double red[4][2][16 * NT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int cls = blockIdx.z;
-    const int py = cls >> 1, px = cls & 1;  // parity class (stride 2 only)
-    const int Hu = g.Hs * g.up, Wu = g.Ws * g.up;
-    const unsigned rows = (g.stride == 2) ? (unsigned)g.N * (g.Hs >> 1) * (g.Ws >> 1) : (unsigned)g.N * Hu * Wu;
-    const unsigned ntiles = (rows + 63) / 64;
-    const int c0col = blockIdx.y * (16 * NT);
-    const int kh0 = (g.stride == 2) ? ((py + g.pad) & 1) : 0;
-    const int kw0 = (g.stride == 2) ? ((px + g.pad) & 1) : 0;
-
-    // BatchNorm-backward sums in fp64: sum(gv*xhat) cancels heavily and the reference accumulates in double too
-    double s1[NT], s2[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.0;
-
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const unsigned row = tile * 64 + wave * 16 + r16;
-        const bool rv = row < rows;
-        int n = 0, iy = 0, ix = 0;
-        if (rv) dgrad_row_to_pos(g, row, py, px, n, iy, ix);
-        f32x4 acc[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        for (int kh = kh0; kh < g.KH; kh += g.stride) {
-            const int ty = iy + g.pad - kh;
-            const int oy = ty / g.stride;  // exact for valid taps
-            for (int kw = kw0; kw < g.KW; kw += g.stride) {
-                const int tx = ix + g.pad - kw;
-                const int ox = tx / g.stride;
-                const bool inb = rv && ty >= 0 && tx >= 0 && oy < g.Ho && ox < g.Wo;
-                const unsigned base = (((unsigned)n * g.Ho + oy) * g.Wo + ox) * g.Cn;
-                const float* wtap = wD + (size_t)(kh * g.KW + kw) * g.Cn * g.Cs;
-                if constexpr (!SMALLC) {
-                    for (int n0 = 0; n0 < g.Cn; n0 += 4) {
-                        const int co = n0 + kq;
-                        const float a = inb ? gy[base + co] : 0.f;
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            const int col = c0col + j * 16 + r16;
-                            const float b = col < g.Cs ? wtap[(size_t)co * g.Cs + col] : 0.f;
-                            acc[j] = mfma16(a, b, acc[j]);
-                        }
-                    }
-                } else {
-                    for (int n0 = 0; n0 < g.Cn; n0 += 4) {
-                        const int co = n0 + kq;
-                        const bool cv = co < g.Cn;
-                        const float a = (inb && cv) ? gy[base + co] : 0.f;
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            const int col = c0col + j * 16 + r16;
-                            const float b = (cv && col < g.Cs) ? wtap[(size_t)co * g.Cs + col] : 0.f;
-                            acc[j] = mfma16(a, b, acc[j]);
-                        }
-                    }
-                }
-            }
-        }
-        // epilogue
-        const unsigned row0 = tile * 64 + wave * 16 + kq * 4;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = c0col + j * 16 + r16;
-            if (col >= g.Cs) continue;
-            const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
-            const float mu = mean ? mean[col] : 0.f, is = mean ? invstd[col] : 0.f;
-            if (g.up == 2) {
-                const unsigned parent = row0 >> 2;
-                if (row0 < rows) {
-                    float val = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
-                    const size_t o = (size_t)parent * g.Cs + col;
-                    float xv = 0.f;
-                    if (relu || mean) xv = x[o];
-                    if (relu) {
-                        const float v = scale ? fmaf(xv, sc, sh) : xv;
-                        val = v > 0.f ? val : 0.f;
-                    }
-                    gv[o] = val;
-                    if (mean) {
-                        s1[j] += (double)val;
-                        s2[j] += (double)val * (double)((xv - mu) * is);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned rr = row0 + r;
-                    if (rr < rows) {
-                        int pn, piy, pix;
-                        dgrad_row_to_pos(g, rr, py, px, pn, piy, pix);
-                        const size_t o = ((size_t)((unsigned)pn * g.Hs + piy) * g.Ws + pix) * g.Cs + col;
-                        float val = acc[j][r];
-                        float xv = 0.f;
-                        if (relu || mean) xv = x[o];
-                        if (relu) {
-                            const float v = scale ? fmaf(xv, sc, sh) : xv;
-                            val = v > 0.f ? val : 0.f;
-                        }
-                        gv[o] = val;
-                        if (mean) {
-                            s1[j] += (double)val;
-                            s2[j] += (double)val * (double)((xv - mu) * is);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (mean) {
-        // fixed-order reduction: 4 lane groups of a wave (shuffle), then the 4 waves (LDS), one partial per block
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            double a = s1[j], b = s2[j];
-            a += __shfl_xor(a, 16, 64);
-            a += __shfl_xor(a, 32, 64);
-            b += __shfl_xor(b, 16, 64);
-            b += __shfl_xor(b, 32, 64);
-            if (kq == 0) {
-                red[wave][0][j * 16 + r16] = a;
-                red[wave][1][j * 16 + r16] = b;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 * 16 * NT) {
-            const int which = threadIdx.x / (16 * NT), cc = threadIdx.x % (16 * NT);
-            const double t = (red[0][which][cc] + red[1][which][cc]) + (red[2][which][cc] + red[3][which][cc]);
-            const unsigned p = blockIdx.z * gridDim.x + blockIdx.x;
-            partial[((size_t)p * 2 + which) * CsPad + c0col + cc] = t;
-        }
-    }
-}
-
 static void dgrad_grid(const Geom& g, int& NT, dim3& grid, int& CsPad) {
     NT = pick_nt(g.Cs);
     const int Hu = g.Hs * g.up, Wu = g.Ws * g.up;
     const unsigned rows = (g.stride == 2) ? (unsigned)g.N * (g.Hs >> 1) * (g.Ws >> 1) : (unsigned)g.N * Hu * Wu;
     const int ny = cdiv(cdiv(g.Cs, 16), NT);
     const int nz = g.stride == 2 ? 4 : 1;
-    // bounded number of blocks (each writes one BatchNorm partial): <= 512 over x*z
-    grid = dim3(imax(1, imin(cdiv(rows, 64), 512 / nz)), ny, nz);
+    // bounded number of blocks (each writes one BatchNorm partial): <= 1024 over x*z
+    grid = dim3(imax(1, imin(cdiv(rows, TM), 1024 / nz)), ny, nz);
     CsPad = ny * 16 * NT;
 }
 
@@ -393,21 +455,6 @@ extern "C" int otvae_conv_bwd_data_ws(const otvae_conv_geom* gg, int* P, int* Cs
     return OTVAE_OK;
 }
 
-template <bool SMALLC>
-static void launch_dgrad(int NT, dim3 grid, hipStream_t st, Geom g, const float* gy, const float* wD, const float* x,
-                         const float* scale, const float* shift, int relu, const float* mean, const float* invstd, float* gv,
-                         double* partial, int CsPad) {
-#define OTVAE_DG(N_) \
-    conv_dgrad_kernel<N_, SMALLC><<<grid, 256, 0, st>>>(g, gy, wD, x, scale, shift, relu, mean, invstd, gv, partial, CsPad)
-    switch (NT) {
-        case 1: OTVAE_DG(1); break;
-        case 2: OTVAE_DG(2); break;
-        case 3: OTVAE_DG(3); break;
-        default: OTVAE_DG(4); break;
-    }
-#undef OTVAE_DG
-}
-
 extern "C" int otvae_conv_bwd_data(const otvae_conv_geom* gg, const float* gy, const float* wD, const float* x,
                                    const float* scale, const float* shift, int relu, const float* mean, const float* invstd,
                                    float* gv, double* bn_partial, void* stream) {
@@ -422,122 +469,170 @@ extern "C" int otvae_conv_bwd_data(const otvae_conv_geom* gg, const float* gy, c
     int NT, CsPad;
     dim3 grid;
     dgrad_grid(g, NT, grid, CsPad);
-    hipStream_t st = (hipStream_t)stream;
-    if (g.Cn % 4 == 0)
-        launch_dgrad<false>(NT, grid, st, g, gy, wD, x, scale, shift, relu, mean, invstd, gv, bn_partial, CsPad);
-    else
-        launch_dgrad<true>(NT, grid, st, g, gy, wD, x, scale, shift, relu, mean, invstd, gv, bn_partial, CsPad);
+    launch_gemm<1>(NT, grid, (hipStream_t)stream, g, gy, scale, shift, relu, wD, nullptr, nullptr, nullptr, x, mean, invstd, gv,
+                   bn_partial, CsPad);
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_data");
     return OTVAE_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
-// Job = (pixel chunk pc, k-tile group, n-tile group) per WAVE.  A wave keeps KT x NT accumulator tiles
-// (KT = 8/NT) and walks its pixel chunk 4 pixels per MFMA.  Row K (after the last tap*channel row) is the bias row:
-// its A operand is 1 for valid pixels, so dBias falls out of the same MFMA stream.
+// Block = 64 k-rows x (16*NT) n-cols, reduction over one pixel chunk in sub-chunks of 32 pixels staged in LDS
+// (At[pixel][k], Gt[pixel][n], double-buffered).  Row K (after the last tap*channel row) is the bias row: A = 1.
+#define PC 32
 template <int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int relu,
-                                                         const float* __restrict__ gy, float* __restrict__ partial, int P,
-                                                         int Kp /* K + has_bias */, int has_bias, unsigned chunk, int nkg,
-                                                         int nng) {
-    constexpr int KT = 8 / NT;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                         const float* __restrict__ gy, float* __restrict__ partial, int Kp,
+                                                         int has_bias, unsigned chunk) {
+    constexpr int BN = 16 * NT;
+    constexpr int LDA = 64 + 16;
+    constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 0);
+    constexpr int NB_ELEMS = PC * BN / 256;
+    __shared__ float At[2][PC * LDA];
+    __shared__ float Gt[2][PC * LDB];
+    __shared__ int s_live[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const unsigned job = blockIdx.x * 4 + wave;
-    const unsigned njobs = (unsigned)P * nkg * nng;
-    if (job >= njobs) return;  // wave-uniform
-    const int kgi = job % nkg;
-    const int ngi = (job / nkg) % nng;
-    const unsigned pc = job / (nkg * nng);
+    const int kb = blockIdx.x, n0 = blockIdx.y * BN;
+    const unsigned pc = blockIdx.z;
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
     const unsigned mbeg = pc * chunk, mend = min(M, mbeg + chunk);
     const int K = g.KH * g.KW * g.Cs;
     const int Hu = g.Hs * g.up, Wu = g.Ws * g.up;
     const int ush = g.up - 1;
-    const int n0 = ngi * 16 * NT;
-    const int nkt = (Kp + 15) / 16;
 
-    // per-lane description of its row k in each owned k-tile
-    int kdy[KT], kdx[KT], kc[KT];
-    int kkind[KT];  // 0 = invalid/padding, 1 = tap row, 2 = bias row
-    bool tile_on[KT];
-#pragma unroll
-    for (int i = 0; i < KT; ++i) {
-        const int kt = kgi * KT + i;
-        const int k = kt * 16 + r16;
-        kkind[i] = 0;
-        kdy[i] = kdx[i] = kc[i] = 0;
-        if (kt < nkt && k < K) {
-            const int t = k / g.Cs;
-            kc[i] = k - t * g.Cs;
-            const int kh = t / g.KW;
-            kdy[i] = kh - g.pad;
-            kdx[i] = (t - kh * g.KW) - g.pad;
-            // a tap that never touches the image for any output pixel contributes nothing: switch the row off
-            const bool ytouch = (kdy[i] + (g.Ho - 1) * g.stride >= 0) && (kdy[i] < Hu);
-            const bool xtouch = (kdx[i] + (g.Wo - 1) * g.stride >= 0) && (kdx[i] < Wu);
-            kkind[i] = (ytouch && xtouch) ? 1 : 0;
-        } else if (kt < nkt && has_bias && k == K) {
-            kkind[i] = 2;
+    // ---- this thread's k row, fixed for the whole block: staging role = (k-local = tid & 63, pixels (tid >> 6) + 4 i)
+    const int a_kl = tid & 63, a_p0 = tid >> 6;
+    const int k = kb * 64 + a_kl;
+    int kind = 0, kdy = 0, kdx = 0, kc = 0;  // kind: 0 dead, 1 tap row, 2 bias row
+    float a_sc = 1.f, a_sh = 0.f;
+    if (k < K) {
+        const int t = k / g.Cs;
+        kc = k - t * g.Cs;
+        const int kh = t / g.KW;
+        kdy = kh - g.pad;
+        kdx = (t - kh * g.KW) - g.pad;
+        const bool ytouch = (kdy + (g.Ho - 1) * g.stride >= 0) && (kdy < Hu);
+        const bool xtouch = (kdx + (g.Wo - 1) * g.stride >= 0) && (kdx < Wu);
+        kind = (ytouch && xtouch) ? 1 : 0;
+        if (kind && scale) {
+            a_sc = scale[kc];
+            a_sh = shift[kc];
         }
-        tile_on[i] = __ballot(kkind[i] != 0) != 0ull;  // wave-uniform
+    } else if (has_bias && k == K) {
+        kind = 2;
     }
+    // which 16-row MFMA tiles hold a live row?  (every staging wave sees all 64 k-rows in its lanes)
+    {
+        const unsigned long long bal = __ballot(kind != 0);
+        if (tid < 4) s_live[tid] = ((bal >> (16 * tid)) & 0xffffull) ? 1 : 0;
+        __syncthreads();
+    }
+    const bool live = s_live[wave] != 0;
+    const bool any_live = (s_live[0] | s_live[1] | s_live[2] | s_live[3]) != 0;
 
-    f32x4 acc[KT][NT];
+    f32x4 acc[NT];
 #pragma unroll
-    for (int i = 0; i < KT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (unsigned m4 = mbeg; m4 < mend; m4 += 4) {
-        const unsigned m = m4 + kq;
-        const bool mv = m < mend;
-        int ox = 0, oy = 0, n = 0;
-        if (mv) {
-            ox = m % g.Wo;
-            unsigned t = m / g.Wo;
-            oy = t % g.Ho;
-            n = t / g.Ho;
-        }
-        float b[NT];
+    const unsigned span = mend > mbeg ? mend - mbeg : 0;
+    const int nsub = any_live ? (int)((span + PC - 1) / PC) : 0;
+    float areg[8], greg[NB_ELEMS];
+
+    auto stage_load = [&](int sub) {
+        const unsigned mb = mbeg + (unsigned)sub * PC;
+        // A: pixels mb + a_p0 + 4 i: decode the first, then step by 4 pixels
+        unsigned m = mb + a_p0;
+        int ox = m % g.Wo;
+        unsigned t = m / g.Wo;
+        int oy = t % g.Ho;
+        int n = t / g.Ho;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + j * 16 + r16;
-            b[j] = (mv && col < g.Cn) ? gy[(size_t)m * g.Cn + col] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < KT; ++i) {
-            if (!tile_on[i]) continue;
-            float a = 0.f;
-            if (kkind[i] == 1) {
-                const int iy = oy * g.stride + kdy[i], ix = ox * g.stride + kdx[i];
-                if (mv && iy >= 0 && iy < Hu && ix >= 0 && ix < Wu) {
-                    const unsigned idx = (((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * g.Cs + kc[i];
-                    a = act_load(x, idx, kc[i], scale, shift, relu);
+        for (int i = 0; i < 8; ++i) {
+            float v = __int_as_float(PAD_MARK);
+            if (m < mend) {
+                if (kind == 1) {
+                    const int iy = oy * g.stride + kdy, ix = ox * g.stride + kdx;
+                    if (iy >= 0 && iy < Hu && ix >= 0 && ix < Wu)
+                        v = x[((size_t)((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * g.Cs + kc];
+                } else if (kind == 2) {
+                    v = __int_as_float(ONE_MARK);
                 }
-            } else if (kkind[i] == 2) {
-                a = mv ? 1.f : 0.f;
             }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(a, b[j], acc[i][j]);
+            areg[i] = v;
+            m += 4;
+            ox += 4;
+            while (ox >= g.Wo) {
+                ox -= g.Wo;
+                if (++oy >= g.Ho) {
+                    oy = 0;
+                    ++n;
+                }
+            }
         }
+#pragma unroll
+        for (int j = 0; j < NB_ELEMS; ++j) {
+            const int e = tid + 256 * j;
+            const int p = e / BN, col = e - p * BN;
+            const unsigned mm = mb + p;
+            greg[j] = (mm < mend && n0 + col < g.Cn) ? gy[(size_t)mm * g.Cn + n0 + col] : 0.f;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = areg[i];
+            const int bits = __float_as_int(v);
+            if (bits == PAD_MARK) {
+                v = 0.f;
+            } else if (bits == ONE_MARK) {
+                v = 1.f;
+            } else {
+                if (scale) v = fmaf(v, a_sc, a_sh);
+                if (relu) v = fmaxf(v, 0.f);
+            }
+            At[buf][(a_p0 + 4 * i) * LDA + a_kl] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NB_ELEMS; ++j) {
+            const int e = tid + 256 * j;
+            const int p = e / BN, col = e - p * BN;
+            Gt[buf][p * LDB + col] = greg[j];
+        }
+    };
+
+    if (nsub > 0) {
+        stage_load(0);
+        stage_store(0);
     }
-    // store partial[pc][k][n]
+    __syncthreads();
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int buf = sub & 1;
+        if (sub + 1 < nsub) stage_load(sub + 1);
+        if (live) {
+            const float* Ab = &At[buf][kq * LDA + wave * 16 + r16];
+            const float* Gb = &Gt[buf][kq * LDB + r16];
+#pragma unroll
+            for (int ps = 0; ps < PC / 4; ++ps) {
+                const float a = Ab[ps * 4 * LDA];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = mfma16(a, Gb[ps * 4 * LDB + j * 16], acc[j]);
+            }
+        }
+        if (sub + 1 < nsub) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+    // partial[pc][k][n]
     float* out = partial + (size_t)pc * Kp * g.Cn;
 #pragma unroll
-    for (int i = 0; i < KT; ++i) {
-        const int kt = kgi * KT + i;
-        if (kt >= nkt) continue;
+    for (int j = 0; j < NT; ++j) {
+        const int col = n0 + j * 16 + r16;
+        if (col >= g.Cn) continue;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + j * 16 + r16;
-            if (col >= g.Cn) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = kt * 16 + kq * 4 + r;
-                if (k < Kp) out[(size_t)k * g.Cn + col] = acc[i][j][r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int kk = kb * 64 + wave * 16 + kq * 4 + r;
+            if (kk < Kp) out[(size_t)kk * g.Cn + col] = acc[j][r];
         }
     }
 }
@@ -567,21 +662,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-static void wgrad_plan(const Geom& g, int has_bias, int& NT, int& P, unsigned& chunk, int& nkg, int& nng, int& Kp) {
+static void wgrad_plan(const Geom& g, int has_bias, int& NT, int& P, unsigned& chunk, int& nkb, int& nnb, int& Kp) {
     NT = pick_nt(g.Cn);
-    if (NT == 3) NT = 4;  // KT = 8/NT must be integral
-    const int KT = 8 / NT;
     Kp = g.KH * g.KW * g.Cs + (has_bias ? 1 : 0);
-    const int nkt = cdiv(Kp, 16);
-    nkg = cdiv(nkt, KT);
-    nng = cdiv(cdiv(g.Cn, 16), NT);
+    nkb = cdiv(Kp, 64);
+    nnb = cdiv(cdiv(g.Cn, 16), NT);
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
-    // enough wave-jobs to fill the chip (256 CUs x 4 SIMDs x ~2), pixel chunks of >= 64 pixels, workspace <= 16 MiB
-    int want = cdiv(2048, nkg * nng);
-    int maxp_pix = imax(1, (int)(M / 64));
+    // enough workgroups to fill the chip (256 CUs x ~3), pixel chunks of >= 128 pixels, workspace <= 16 MiB, P <= 256
+    int want = cdiv(768, nkb * nnb);
+    int maxp_pix = imax(1, (int)(M / 128));
     int maxp_ws = imax(1, (int)((4u << 20) / ((unsigned)Kp * g.Cn)));
-    P = imax(1, imin(imin(want, maxp_pix), imin(maxp_ws, 512)));
-    chunk = ((M + P - 1) / P + 3) & ~3u;
+    P = imax(1, imin(imin(want, maxp_pix), imin(maxp_ws, 256)));
+    chunk = ((M + P - 1) / P + PC - 1) / PC * PC;
     P = cdiv(M, chunk);
 }
 
@@ -589,9 +681,9 @@ extern "C" int otvae_conv_bwd_weight_ws(const otvae_conv_geom* gg, int has_bias,
     int rc = check_geom(gg, "otvae_conv_bwd_weight_ws");
     if (rc) return rc;
     Geom g = to_geom(gg);
-    int NT, p, nkg, nng, Kp;
+    int NT, p, nkb, nnb, Kp;
     unsigned chunk;
-    wgrad_plan(g, has_bias, NT, p, chunk, nkg, nng, Kp);
+    wgrad_plan(g, has_bias, NT, p, chunk, nkb, nnb, Kp);
     if (P) *P = p;
     return OTVAE_OK;
 }
@@ -605,16 +697,16 @@ extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, 
     OTVAE_REQUIRE(!has_bias || gb, "otvae_conv_bwd_weight: gb missing");
     OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_conv_bwd_weight: scale/shift must come together");
     Geom g = to_geom(gg);
-    int NT, P, nkg, nng, Kp;
+    int NT, P, nkb, nnb, Kp;
     unsigned chunk;
-    wgrad_plan(g, has_bias, NT, P, chunk, nkg, nng, Kp);
-    const unsigned njobs = (unsigned)P * nkg * nng;
+    wgrad_plan(g, has_bias, NT, P, chunk, nkb, nnb, Kp);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(cdiv(njobs, 4));
+    dim3 grid(nkb, nnb, P);
     switch (NT) {
-        case 1: conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, P, Kp, has_bias, chunk, nkg, nng); break;
-        case 2: conv_wgrad_kernel<2><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, P, Kp, has_bias, chunk, nkg, nng); break;
-        default: conv_wgrad_kernel<4><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, P, Kp, has_bias, chunk, nkg, nng); break;
+        case 1: conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk); break;
+        case 2: conv_wgrad_kernel<2><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk); break;
+        case 3: conv_wgrad_kernel<3><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk); break;
+        default: conv_wgrad_kernel<4><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk); break;
     }
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight");
     const size_t total = (size_t)Kp * g.Cn;
