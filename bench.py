@@ -36,6 +36,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 
 
+def host_threads() -> int:
+    """Cores this process may really use (the GPU box gives a 16-core share of a much larger host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 quota
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, 16))
+
+
 def build_model(A, seed=0):
     torch.manual_seed(seed)
     enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
@@ -48,7 +63,7 @@ def cpu_baseline(A, batch=250, steps=3, warmup=1):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import otvae_oracle as O
     from detfill import mnist_like, normal
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     model = build_model(A)
     ea = O.cnn_arch(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
     da = O.cnn_arch(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")

@@ -637,11 +637,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
     }
 }
 
-// out[e] = sum_p partial[p][e] in a fixed order: 4 interleaved p-lanes per element, then p-lane 0..3.
+// out[e] = sum_p partial[p][e] in a fixed order.
+//   few partials : 4 interleaved p-lanes per element, then p-lane 0..3 through LDS
+//   many partials: one wave per element, lanes stride over p, shuffle tree
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int P, int K, int Kp, int Cn,
                                                            float* __restrict__ gw, float* __restrict__ gb) {
     __shared__ float red[4][64];
     const size_t total = (size_t)Kp * Cn;
+    if (P >= 32) {
+        const int lane = threadIdx.x & 63;
+        for (size_t e = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (size_t)gridDim.x * 4) {
+            float s = 0.f;
+            for (int p = lane; p < P; p += 64) s += partial[(size_t)p * total + e];
+            s = wave_sum(s);
+            if (lane == 0) {
+                const int k = e / Cn;
+                if (k < K)
+                    gw[e] = s;
+                else if (gb)
+                    gb[e - (size_t)K * Cn] = s;
+            }
+        }
+        return;
+    }
     const int el = threadIdx.x & 63, pg = threadIdx.x >> 6;
     for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
         const size_t e = e0 + el;
@@ -668,11 +686,13 @@ static void wgrad_plan(const Geom& g, int has_bias, int& NT, int& P, unsigned& c
     nkb = cdiv(Kp, 64);
     nnb = cdiv(cdiv(g.Cn, 16), NT);
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
-    // enough workgroups to fill the chip (256 CUs x ~3), pixel chunks of >= 128 pixels, workspace <= 16 MiB, P <= 256
-    int want = cdiv(768, nkb * nnb);
+    // enough workgroups to fill the chip several times over (256 CUs x ~3 resident x 4 rounds: the kernel is latency-
+    // bound per 32-pixel step, short chains + many resident blocks hide it), pixel chunks of >= 128 pixels,
+    // workspace <= 16 MiB, P <= 2048
+    int want = cdiv(3072, nkb * nnb);
     int maxp_pix = imax(1, (int)(M / 128));
     int maxp_ws = imax(1, (int)((4u << 20) / ((unsigned)Kp * g.Cn)));
-    P = imax(1, imin(imin(want, maxp_pix), imin(maxp_ws, 256)));
+    P = imax(1, imin(imin(want, maxp_pix), imin(maxp_ws, 2048)));
     chunk = ((M + P - 1) / P + PC - 1) / PC * PC;
     P = cdiv(M, chunk);
 }
@@ -710,7 +730,7 @@ extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, 
     }
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight");
     const size_t total = (size_t)Kp * g.Cn;
-    wgrad_reduce_kernel<<<imin(cdiv(total, 64), 2048), 256, 0, st>>>(partial, P, Kp - (has_bias ? 1 : 0), Kp, g.Cn, gw, gb);
+    wgrad_reduce_kernel<<<imin(cdiv(total, P >= 32 ? 4 : 64), 2048), 256, 0, st>>>(partial, P, Kp - (has_bias ? 1 : 0), Kp, g.Cn, gw, gb);
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(reduce)");
     return OTVAE_OK;
 }
