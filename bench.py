@@ -180,9 +180,7 @@ def main():
 
     B = PER_GPU_BATCH
     model = build_model(A).cuda().train()
-    if world > 1:  # identical replicas: broadcast rank 0's initial weights
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src=0)
+    A.broadcast_module(model, src=0)  # identical replicas (no-op for one rank)
     latent_model = A.GaussianTransport(128, source_cfg=dict(dtype=torch.double, reduce_on_update=False),
                                        target_cfg=dict(dtype=torch.double, reduce_on_update=False),
                                        transport_cfg=dict(make_pd=True)).cuda()

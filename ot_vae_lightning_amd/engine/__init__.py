@@ -1,1 +1,2 @@
 from .trainer import *  # noqa: F401,F403
+from .dp import *  # noqa: F401,F403

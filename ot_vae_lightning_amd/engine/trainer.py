@@ -26,6 +26,7 @@ from torch import Tensor
 from .. import _lib
 from .._lib import check, ptr, stream
 from ..networks.cnn import ConvLayer
+from .dp import FlatGradReducer
 
 __all__ = ["HipTrainer", "flatten_parameters"]
 
@@ -93,8 +94,8 @@ class HipTrainer:
             off += (w.numel() + 3) // 4 * 4
         # distributed
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.reducer = FlatGradReducer(self.gflat, process_group)
+        self.world = self.reducer.world
         # static I/O
         self.x = torch.zeros(batch_shape, device=dev, dtype=torch.float32)
         lat = (batch_shape[0], *model.latent_size)
@@ -133,15 +134,11 @@ class HipTrainer:
 
     def _adam(self):
         check(self.lib.otvae_adam_step(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
-                                       ptr(self.hyper), ptr(self.step_count), 1.0 / self.world, stream()),
+                                       ptr(self.hyper), ptr(self.step_count), self.reducer.grad_scale, stream()),
               "otvae_adam_step")
 
     def _allreduce(self):
-        if self.world > 1:
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.reducer.allreduce()
 
     def _eager_step(self):
         logs = self._forward_backward()

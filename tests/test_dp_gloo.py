@@ -1,0 +1,119 @@
+"""CPU, world_size 2 over gloo: the data-parallel exchange step of the training engine.
+
+What DDP does in the reference (stock Lightning DDP, BatchNorm NOT synchronised): every rank computes gradients on its
+shard with rank-local batch statistics, gradients are averaged over ranks.  The DP oracle is therefore: run the CPU
+oracle on each shard, average.  The test drives the product's flat-buffer layout (``flatten_parameters`` /
+``_dense_view``), ``FlatGradReducer`` and ``broadcast_module`` with gloo, and the additive (n, sum x, sum xx^T)
+statistics reduction of GaussianModel through the injected DDP callables.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import otvae_oracle as O
+        import ot_vae_lightning_amd as A
+        from ot_vae_lightning_amd.engine.trainer import _dense_view, flatten_parameters
+        from ot_vae_lightning_amd import utils
+        from detfill import mnist_like, normal
+
+        # -- replicas: rank 1 starts from different weights, broadcast makes them identical
+        torch.manual_seed(100 + rank)
+        enc = A.CNN(1, 16, 16, 1, capacity=2, down_sample=True, residual="add")
+        dec = A.CNN(8, 1, 1, 16, capacity=2, up_sample=True, residual="add")
+        model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1))
+        A.broadcast_module(model, src=0)
+        w = model.encoder[0].block[0].weight
+        ref = [torch.empty_like(w.contiguous()) for _ in range(world)]
+        dist.all_gather(ref, w.detach().contiguous())
+        assert torch.equal(ref[0], ref[1]), "broadcast_module did not produce identical replicas"
+
+        # -- flat layout keeps values, shapes and HWIO stride order
+        params = list(model.optim_parameters())
+        before = [p.detach().clone() for p in params]
+        strides = [p.stride() for p in params]
+        pflat, offs = flatten_parameters(params)
+        for p, b, st in zip(params, before, strides):
+            assert torch.equal(p.detach(), b) and p.shape == b.shape
+            assert all(s1 == s2 for s1, s2, n in zip(p.stride(), st, p.shape) if n > 1)
+            assert p.data_ptr() >= pflat.data_ptr() and p.data_ptr() < pflat.data_ptr() + pflat.numel() * 4
+        gflat = torch.zeros_like(pflat)
+
+        # -- shard gradients by the oracle, written through the flat gradient views
+        B = 8
+        x, eps = mnist_like(B * world, 3)[:, :, 8:24, 8:24].contiguous(), normal((B * world, 8, 1, 1), 4)
+        ea = O.cnn_arch(1, 16, 16, 1, capacity=2, down_sample=True, residual="add")
+        da = O.cnn_arch(8, 1, 1, 16, capacity=2, up_sample=True, residual="add")
+
+        def shard_grads(r):
+            pe = {k: v.detach().clone().contiguous() for k, v in model.encoder.state_dict().items()}
+            pd = {k: v.detach().clone().contiguous() for k, v in model.decoder.state_dict().items()}
+            leaves = [v.requires_grad_(True) for d in (pe, pd) for k, v in d.items()
+                      if v.is_floating_point() and "running" not in k]
+            out = O.vae_nelbo(x[r * B:(r + 1) * B], eps[r * B:(r + 1) * B], pe, pd, ea, da, loss_coeff=0.1)
+            out["loss"].backward()
+            return [v.grad for v in leaves]
+
+        mine = shard_grads(rank)
+        for p, off, gr in zip(params, offs, mine):
+            _dense_view(gflat, off, p.data).copy_(gr)
+        red = A.FlatGradReducer(gflat)
+        assert red.world == world and abs(red.grad_scale - 0.5) < 1e-12
+        red.allreduce()
+        want = [(a + b) / world for a, b in zip(shard_grads(0), shard_grads(1))]
+        for p, off, wgrad in zip(params, offs, want):
+            got = _dense_view(gflat, off, p.data) * red.grad_scale
+            assert torch.allclose(got, wgrad, rtol=1e-6, atol=1e-8)
+
+        # -- additive Gaussian statistics: sum over ranks of (n, sum x, sum xxT) == statistics of the union
+        z = normal((world * 32, 6), 9, dtype=torch.float64)
+        n, sx, sxx = O.gaussian_stats(z[rank * 32:(rank + 1) * 32])
+        n, sx, sxx = utils.ddp_reduce_sum(n), utils.ddp_reduce_sum(sx), utils.ddp_reduce_sum(sxx)
+        n_all, sx_all, sxx_all = O.gaussian_stats(z)
+        assert torch.allclose(n, n_all) and torch.allclose(sx, sx_all) and torch.allclose(sxx, sxx_all)
+        parts = utils.ddp_gather_all(z[rank * 32:(rank + 1) * 32])
+        assert torch.equal(torch.cat(parts), z)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_data_parallel_exchange_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"

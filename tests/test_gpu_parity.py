@@ -223,7 +223,7 @@ def test_nelbo_and_adam_vs_reference_golden(A, residual):
     # front of a BatchNorm) that is a function of rounding noise, in the reference too -> compare the others
     pl2 = torch.tensor([p.double().norm().item() for p in params])
     sig = g["grad_l2"] > 1e-3 * g["grad_l2"].max()
-    assert int(sig.sum()) > 60
+    assert int(sig.sum()) > 40
     rep.check("param_l2 after one Adam step (parameters with a non-zero gradient)", pl2[sig], g["param_l2_after_adam"][sig],
               tol=1e-5)
     rs = [b.double().sum().item() for net in (model.encoder, model.decoder) for k, b in net.named_buffers()
