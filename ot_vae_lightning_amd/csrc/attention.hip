@@ -4,11 +4,16 @@
 // The reference materialises the TxT matrix (6 MiB/image at T=1024); here it never leaves registers.
 //
 // Head width C is 1..16 and T is 1..1024 in every configuration, so the products are far too thin for MFMA tiles
-// (K = C): one VALU lane owns one query row (forward, dQ) or one key row (dK, dV) and the other side is read as a
-// wave-uniform LDS broadcast.  A workgroup stages the whole qkv slab of its image(s) in LDS with coalesced loads.
+// (K = C; fp32 MFMA runs at the VALU rate anyway): the kernels are exp/VALU-bound and organised to minimise issue slots
+// per (query, key) pair:
+//   * a "slice" = one (image, head).  Its keys are staged in LDS as records {k[C], v[C]} (and, for backward, its
+//     queries as {q/C [C], gout[C], lse, delta}) so that ONE wave-uniform LDS read (b64/b128 broadcast) feeds a pair;
+//   * every lane owns QPT (=4 when T >= 256) consecutive queries (or keys) of one slice, so each record read is
+//     amortised over QPT pairs and QPT independent exp/FMA chains hide each other's latency;
+//   * for C == 1 the row maximum is closed-form (q * max_s k or q * min_s k), so the forward needs a single pass.
 #include "common.h"
 
-#define ATTN_MAX_LDS_FLOATS 36864  // 144 KiB
+#define ATTN_LDS_FLOATS 16384  // 64 KiB dynamic LDS budget (the default limit: no function attribute needed)
 
 template <int C>
 __device__ __forceinline__ float dotc(const float (&a)[C], const float* __restrict__ b) {
@@ -19,207 +24,306 @@ __device__ __forceinline__ float dotc(const float (&a)[C], const float* __restri
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int N, int T, int H, int NB,
+struct Rec {
+    static constexpr int KV = 2 * C;                     // {k[C], v[C]}
+    static constexpr int QG = (2 * C + 2 + 3) & ~3;      // {q/C [C], gout[C], lse, delta} padded to 16 bytes
+};
+
+// stage {k, v} records of the block's slices: sm[sl][t][2C]
+template <int C>
+__device__ __forceinline__ void stage_kv(float* __restrict__ sm, const float* __restrict__ qkv, long slice0, int nsl, int T,
+                                         int H) {
+    const int HC = H * C, W3 = 3 * HC;
+    const int per = T * 2 * C;
+    for (int e = threadIdx.x; e < nsl * per; e += 256) {
+        const int sl = e / per, r = e - sl * per;
+        const int t = r / (2 * C), j = r - t * 2 * C;
+        const int which = j / C, c = j - which * C;
+        const long gs = slice0 + sl;
+        const long n = gs / H;
+        const int h = (int)(gs - n * H);
+        sm[e] = qkv[(n * T + t) * W3 + (1 + which) * HC + h * C + c];
+    }
+}
+
+template <int C, int QPT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int N, int T, int H, int SPB,
                                                        float* __restrict__ out, float* __restrict__ lse) {
     extern __shared__ __align__(16) float sm[];
     const int HC = H * C, W3 = 3 * HC;
-    const int n_base = blockIdx.x * NB;
-    const int nb = min(NB, N - n_base);
-    const int slab = nb * T * W3;
-    const float* src = qkv + (size_t)n_base * T * W3;
-    for (int i = threadIdx.x; i < slab; i += 256) sm[i] = src[i];
+    const int TPS = T / QPT;  // threads per slice
+    const long total = (long)N * H;
+    const long slice0 = (long)blockIdx.x * SPB;
+    const int nsl = (int)min((long)SPB, total - slice0);
+    stage_kv<C>(sm, qkv, slice0, nsl, T, H);
     __syncthreads();
+    const int sl = threadIdx.x / TPS;
+    if (sl >= nsl) return;
+    const int t0 = (threadIdx.x - sl * TPS) * QPT;
+    const long gs = slice0 + sl;
+    const long n = gs / H;
+    const int h = (int)(gs - n * H);
     const float inv_c = 1.f / (float)C;
-    const int items = nb * H * T;
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int t = it % T;
-        const int h = (it / T) % H;
-        const int nl = it / (T * H);
-        const float* base = sm + (size_t)nl * T * W3;
-        float q[C], acc[C];
+    const float* kv = sm + (size_t)sl * T * Rec<C>::KV;
+
+    float q[QPT][C], acc[QPT][C], mx[QPT], l[QPT];
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            q[c] = base[t * W3 + h * C + c] * inv_c;
-            acc[c] = 0.f;
+            q[i][c] = qkv[(n * T + t0 + i) * W3 + h * C + c] * inv_c;
+            acc[i][c] = 0.f;
         }
-        const float* kp = base + HC + h * C;
-        const float* vp = base + 2 * HC + h * C;
-        float mx = -INFINITY;
-        for (int s = 0; s < T; ++s) mx = fmaxf(mx, dotc<C>(q, kp + s * W3));
-        float l = 0.f;
+        l[i] = 0.f;
+        mx[i] = -INFINITY;
+    }
+    if constexpr (C == 1) {
+        float kmax = -INFINITY, kmin = INFINITY;
         for (int s = 0; s < T; ++s) {
-            const float p = __expf(dotc<C>(q, kp + s * W3) - mx);
-            l += p;
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = fmaf(p, vp[s * W3 + c], acc[c]);
+            const float k = kv[s * 2];
+            kmax = fmaxf(kmax, k);
+            kmin = fminf(kmin, k);
         }
-        const float rl = 1.f / l;
-        float* o = out + ((size_t)(n_base + nl) * T + t) * HC + h * C;
 #pragma unroll
-        for (int c = 0; c < C; ++c) o[c] = acc[c] * rl;
-        lse[((size_t)(n_base + nl) * H + h) * T + t] = mx + __logf(l);
+        for (int i = 0; i < QPT; ++i) mx[i] = fmaxf(q[i][0] * kmax, q[i][0] * kmin);
+    } else {
+        for (int s = 0; s < T; ++s) {
+            const float* r = kv + s * Rec<C>::KV;
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) mx[i] = fmaxf(mx[i], dotc<C>(q[i], r));
+        }
+    }
+#pragma unroll 2
+    for (int s = 0; s < T; ++s) {
+        const float* r = kv + s * Rec<C>::KV;
+        float kk[C], vv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            kk[c] = r[c];
+            vv[c] = r[C + c];
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            float sc = -mx[i];
+#pragma unroll
+            for (int c = 0; c < C; ++c) sc = fmaf(q[i][c], kk[c], sc);
+            const float p = __expf(sc);
+            l[i] += p;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[i][c] = fmaf(p, vv[c], acc[i][c]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        const float rl = 1.f / l[i];
+        float* o = out + (n * T + t0 + i) * HC + h * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = acc[i][c] * rl;
+        lse[(n * H + h) * T + t0 + i] = mx[i] + __logf(l[i]);
     }
 }
 
-// Backward.  LDS: qkv slab | gout slab [nb][T][HC] | lse [nb][H][T] | delta [nb][H][T]
-template <int C>
+template <int C, int QPT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                        const float* __restrict__ lse_g, const float* __restrict__ gout,
-                                                       int N, int T, int H, int NB, float* __restrict__ gqkv) {
+                                                       int N, int T, int H, int SPB, float* __restrict__ gqkv) {
     extern __shared__ __align__(16) float sm[];
+    constexpr int RKV = Rec<C>::KV, RQG = Rec<C>::QG;
     const int HC = H * C, W3 = 3 * HC;
-    const int n_base = blockIdx.x * NB;
-    const int nb = min(NB, N - n_base);
-    float* s_qkv = sm;
-    float* s_go = s_qkv + (size_t)NB * T * W3;
-    float* s_lse = s_go + (size_t)NB * T * HC;
-    float* s_del = s_lse + (size_t)NB * H * T;
-    {
-        const int slab = nb * T * W3;
-        const float* src = qkv + (size_t)n_base * T * W3;
-        for (int i = threadIdx.x; i < slab; i += 256) s_qkv[i] = src[i];
-        const int slab2 = nb * T * HC;
-        const float* gsrc = gout + (size_t)n_base * T * HC;
-        for (int i = threadIdx.x; i < slab2; i += 256) s_go[i] = gsrc[i];
-        const int nl_items = nb * H * T;
-        const float* lsrc = lse_g + (size_t)n_base * H * T;
-        for (int i = threadIdx.x; i < nl_items; i += 256) s_lse[i] = lsrc[i];
-    }
-    __syncthreads();
-    const int items = nb * H * T;
-    // delta[nl][h][t] = sum_c gout * out
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int t = it % T;
-        const int h = (it / T) % H;
-        const int nl = it / (T * H);
-        const float* o = out + ((size_t)(n_base + nl) * T + t) * HC + h * C;
-        const float* g = s_go + ((size_t)nl * T + t) * HC + h * C;
+    const int TPS = T / QPT;
+    const long total = (long)N * H;
+    const long slice0 = (long)blockIdx.x * SPB;
+    const int nsl = (int)min((long)SPB, total - slice0);
+    float* s_kv = sm;
+    float* s_qg = sm + (size_t)SPB * T * RKV;
+    const float inv_c = 1.f / (float)C;
+    stage_kv<C>(s_kv, qkv, slice0, nsl, T, H);
+    // query records {q/C, gout, lse, delta = sum_c gout*out}
+    for (int it = threadIdx.x; it < nsl * T; it += 256) {
+        const int sl = it / T, t = it - sl * T;
+        const long gs = slice0 + sl;
+        const long n = gs / H;
+        const int h = (int)(gs - n * H);
+        float* r = s_qg + (size_t)it * RQG;
+        const float* qp = qkv + (n * T + t) * W3 + h * C;
+        const float* gp = gout + (n * T + t) * HC + h * C;
+        const float* op = out + (n * T + t) * HC + h * C;
         float d = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) d = fmaf(g[c], o[c], d);
-        s_del[((size_t)nl * H + h) * T + t] = d;
+        for (int c = 0; c < C; ++c) {
+            const float g = gp[c];
+            r[c] = qp[c] * inv_c;
+            r[C + c] = g;
+            d = fmaf(g, op[c], d);
+        }
+        r[2 * C] = lse_g[(n * H + h) * T + t];
+        r[2 * C + 1] = d;
     }
     __syncthreads();
-    const float inv_c = 1.f / (float)C;
-    // phase A: one lane per query row -> dQ
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int t = it % T;
-        const int h = (it / T) % H;
-        const int nl = it / (T * H);
-        const float* base = s_qkv + (size_t)nl * T * W3;
-        const float* kp = base + HC + h * C;
-        const float* vp = base + 2 * HC + h * C;
-        float q[C], go[C], dq[C];
+    const int sl = threadIdx.x / TPS;
+    if (sl >= nsl) return;
+    const int t0 = (threadIdx.x - sl * TPS) * QPT;
+    const long gs = slice0 + sl;
+    const long n = gs / H;
+    const int h = (int)(gs - n * H);
+    const float* kv = s_kv + (size_t)sl * T * RKV;
+    const float* qg = s_qg + (size_t)sl * T * RQG;
+
+    // ---- phase A: this lane's QPT queries against every key -> dQ
+    {
+        float q[QPT][C], go[QPT][C], dq[QPT][C], ls[QPT], dl[QPT];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            q[c] = base[t * W3 + h * C + c] * inv_c;
-            go[c] = s_go[((size_t)nl * T + t) * HC + h * C + c];
-            dq[c] = 0.f;
-        }
-        const float ls = s_lse[((size_t)nl * H + h) * T + t];
-        const float dl = s_del[((size_t)nl * H + h) * T + t];
-        for (int s = 0; s < T; ++s) {
-            const float p = __expf(dotc<C>(q, kp + s * W3) - ls);
-            const float dp = dotc<C>(go, vp + s * W3);
-            const float ds = p * (dp - dl);
-#pragma unroll
-            for (int c = 0; c < C; ++c) dq[c] = fmaf(ds, kp[s * W3 + c], dq[c]);
-        }
-        float* o = gqkv + ((size_t)(n_base + nl) * T + t) * W3 + h * C;
-#pragma unroll
-        for (int c = 0; c < C; ++c) o[c] = dq[c] * inv_c;
-    }
-    // phase B: one lane per key row -> dK, dV
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int s = it % T;
-        const int h = (it / T) % H;
-        const int nl = it / (T * H);
-        const float* base = s_qkv + (size_t)nl * T * W3;
-        const float* qp = base + h * C;
-        const float* gp = s_go + (size_t)nl * T * HC + h * C;
-        const float* lp = s_lse + ((size_t)nl * H + h) * T;
-        const float* dlp = s_del + ((size_t)nl * H + h) * T;
-        float k[C], v[C], dk[C], dv[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            k[c] = base[s * W3 + HC + h * C + c] * inv_c;  // fold the 1/C of the score into k here
-            v[c] = base[s * W3 + 2 * HC + h * C + c];
-            dk[c] = dv[c] = 0.f;
-        }
-        for (int t = 0; t < T; ++t) {
-            const float p = __expf(dotc<C>(k, qp + t * W3) - lp[t]);
-            const float dp = dotc<C>(v, gp + t * HC);
-            const float ds = p * (dp - dlp[t]);
+        for (int i = 0; i < QPT; ++i) {
+            const float* r = qg + (size_t)(t0 + i) * RQG;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                dv[c] = fmaf(p, gp[t * HC + c], dv[c]);
-                dk[c] = fmaf(ds, qp[t * W3 + c], dk[c]);
+                q[i][c] = r[c];
+                go[i][c] = r[C + c];
+                dq[i][c] = 0.f;
+            }
+            ls[i] = r[2 * C];
+            dl[i] = r[2 * C + 1];
+        }
+#pragma unroll 2
+        for (int s = 0; s < T; ++s) {
+            const float* r = kv + s * RKV;
+            float kk[C], vv[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                kk[c] = r[c];
+                vv[c] = r[C + c];
+            }
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                float sc = -ls[i], dp = -dl[i];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    sc = fmaf(q[i][c], kk[c], sc);
+                    dp = fmaf(go[i][c], vv[c], dp);
+                }
+                const float ds = __expf(sc) * dp;
+#pragma unroll
+                for (int c = 0; c < C; ++c) dq[i][c] = fmaf(ds, kk[c], dq[i][c]);
             }
         }
-        float* o = gqkv + ((size_t)(n_base + nl) * T + s) * W3 + h * C;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            o[HC + c] = dk[c] * inv_c;
-            o[2 * HC + c] = dv[c];
+        for (int i = 0; i < QPT; ++i) {
+            float* o = gqkv + (n * T + t0 + i) * W3 + h * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = dq[i][c] * inv_c;
+        }
+    }
+    // ---- phase B: this lane's QPT keys against every query -> dK, dV
+    {
+        float k[QPT][C], v[QPT][C], dk[QPT][C], dv[QPT][C];
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const float* r = kv + (size_t)(t0 + i) * RKV;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                k[i][c] = r[c];
+                v[i][c] = r[C + c];
+                dk[i][c] = dv[i][c] = 0.f;
+            }
+        }
+#pragma unroll 2
+        for (int t = 0; t < T; ++t) {
+            const float* r = qg + (size_t)t * RQG;
+            float qq[C], gg[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                qq[c] = r[c];
+                gg[c] = r[C + c];
+            }
+            const float ls = r[2 * C], dl = r[2 * C + 1];
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                float sc = -ls, dp = -dl;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    sc = fmaf(k[i][c], qq[c], sc);
+                    dp = fmaf(v[i][c], gg[c], dp);
+                }
+                const float p = __expf(sc);
+                const float ds = p * dp;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    dv[i][c] = fmaf(p, gg[c], dv[i][c]);
+                    dk[i][c] = fmaf(ds, qq[c], dk[i][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            float* o = gqkv + (n * T + t0 + i) * W3 + h * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                o[HC + c] = dk[i][c];
+                o[2 * HC + c] = dv[i][c];
+            }
         }
     }
 }
 
-// Dynamic LDS above the 64 KiB default needs a one-time function attribute; done once per kernel instantiation and
-// only ever raised, outside of any captured region in practice (the first eager call of a shape does it).
-static size_t fwd_lds_set[33] = {0}, bwd_lds_set[33] = {0};
-static bool ensure_lds(const void* fn, size_t* cur, size_t want) {
-    if (want <= 65536 || want <= *cur) return true;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ATTN_MAX_LDS_FLOATS * sizeof(float))) !=
-        hipSuccess) {
-        otvae_set_error("attention: cannot raise dynamic LDS limit");
-        return false;
-    }
-    *cur = ATTN_MAX_LDS_FLOATS * sizeof(float);
-    return true;
+// slices per block: as many as 256 threads cover (T/QPT threads each) and as the LDS budget holds
+static int pick_qpt(int T, int C) { return (T >= 256 && T % 4 == 0 && C <= 4) ? 4 : 1; }
+static int pick_spb(int T, int qpt, int floats_per_key) {
+    int tps = T / qpt;
+    int spb = 256 / tps;
+    int cap = ATTN_LDS_FLOATS / (T * floats_per_key);
+    if (spb > cap) spb = cap;
+    return spb;
 }
 
-static int attn_nb(int T, int H, int C, int per_image_floats) {
-    int nb = 256 / (H * T);
-    if (nb < 1) nb = 1;
-    int cap = ATTN_MAX_LDS_FLOATS / per_image_floats;
-    if (nb > cap) nb = cap;
-    return nb;
-}
-
-#define ATTN_DISPATCH(C_, KERNEL, ...)                 \
-    switch (C_) {                                      \
-        case 1: KERNEL(1, __VA_ARGS__); break;         \
-        case 2: KERNEL(2, __VA_ARGS__); break;         \
-        case 3: KERNEL(3, __VA_ARGS__); break;         \
-        case 4: KERNEL(4, __VA_ARGS__); break;         \
-        case 6: KERNEL(6, __VA_ARGS__); break;         \
-        case 8: KERNEL(8, __VA_ARGS__); break;         \
-        case 12: KERNEL(12, __VA_ARGS__); break;       \
-        case 16: KERNEL(16, __VA_ARGS__); break;       \
-        case 32: KERNEL(32, __VA_ARGS__); break;       \
-        default:                                       \
-            otvae_set_error("attention: head width C=%d not instantiated (1,2,3,4,6,8,12,16,32)", C_); \
-            return OTVAE_EUNSUPPORTED;                 \
+#define ATTN_C_SWITCH(C_, MACRO)                                                                              \
+    switch (C_) {                                                                                             \
+        case 1: MACRO(1); break;                                                                              \
+        case 2: MACRO(2); break;                                                                              \
+        case 3: MACRO(3); break;                                                                              \
+        case 4: MACRO(4); break;                                                                              \
+        case 6: MACRO(6); break;                                                                              \
+        case 8: MACRO(8); break;                                                                              \
+        case 12: MACRO(12); break;                                                                            \
+        case 16: MACRO(16); break;                                                                            \
+        case 32: MACRO(32); break;                                                                            \
+        default:                                                                                              \
+            otvae_set_error("attention: head width C=%d not instantiated (1,2,3,4,6,8,12,16,32)", C_);        \
+            return OTVAE_EUNSUPPORTED;                                                                        \
     }
 
-extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, void* stream) {
-    OTVAE_REQUIRE(qkv && out && lse && N > 0 && T > 0 && H > 0 && C > 0, "otvae_attn_fwd: bad argument");
-    const int per_img = T * 3 * H * C;
-    if (per_img > ATTN_MAX_LDS_FLOATS) {
-        otvae_set_error("otvae_attn_fwd: T*3*H*C = %d floats exceeds the LDS slab (%d)", per_img, ATTN_MAX_LDS_FLOATS);
+static int attn_check(const char* who, int N, int T, int H, int C, int floats_per_key, int* qpt, int* spb) {
+    OTVAE_REQUIRE(N > 0 && T > 0 && H > 0 && C > 0, "%s: bad sizes", who);
+    *qpt = pick_qpt(T, C);
+    if (T / *qpt > 256) {
+        otvae_set_error("%s: T = %d unsupported (T <= 256, or T <= 1024 with T %% 4 == 0 and head width <= 4)", who, T);
         return OTVAE_EUNSUPPORTED;
     }
-    const int NB = attn_nb(T, H, C, per_img);
-    const size_t lds = (size_t)NB * per_img * sizeof(float);
+    *spb = pick_spb(T, *qpt, floats_per_key);
+    if (*spb < 1) {
+        otvae_set_error("%s: one (image, head) slice of T=%d, C=%d does not fit the 64 KiB LDS slab", who, T, C);
+        return OTVAE_EUNSUPPORTED;
+    }
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, void* stream) {
+    OTVAE_REQUIRE(qkv && out && lse, "otvae_attn_fwd: NULL tensor");
+    int qpt, spb;
+    int rc = attn_check("otvae_attn_fwd", N, T, H, C, 2 * C, &qpt, &spb);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = cdiv(N, NB);
-#define FWD_K(CC, ...)                                                                    \
-    do {                                                                                  \
-        if (!ensure_lds((const void*)attn_fwd_kernel<CC>, &fwd_lds_set[CC], lds)) return OTVAE_ELAUNCH; \
-        attn_fwd_kernel<CC><<<grid, 256, lds, st>>>(qkv, N, T, H, NB, out, lse);          \
+    const int grid = cdiv((int64_t)N * H, spb);
+    const size_t lds = (size_t)spb * T * 2 * C * sizeof(float);
+#define FWD_K(CC)                                                                                   \
+    do {                                                                                            \
+        if (qpt == 4) {                                                                             \
+            if constexpr (CC <= 4) attn_fwd_kernel<CC, 4><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse); \
+            else { otvae_set_error("otvae_attn_fwd: T >= 256 with head width %d > 4 unsupported", CC); return OTVAE_EUNSUPPORTED; } \
+        } else {                                                                                    \
+            attn_fwd_kernel<CC, 1><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse);              \
+        }                                                                                           \
     } while (0)
-    ATTN_DISPATCH(C, FWD_K, 0)
+    ATTN_C_SWITCH(C, FWD_K)
 #undef FWD_K
     OTVAE_CHECK_LAUNCH("otvae_attn_fwd");
     return OTVAE_OK;
@@ -227,22 +331,24 @@ extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, floa
 
 extern "C" int otvae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* gout, int N, int T, int H,
                               int C, float* gqkv, void* stream) {
-    OTVAE_REQUIRE(qkv && out && lse && gout && gqkv && N > 0 && T > 0 && H > 0 && C > 0, "otvae_attn_bwd: bad argument");
-    const int per_img = T * (3 * H * C + H * C + 2 * H);
-    if (per_img > ATTN_MAX_LDS_FLOATS) {
-        otvae_set_error("otvae_attn_bwd: per-image LDS slab of %d floats exceeds %d", per_img, ATTN_MAX_LDS_FLOATS);
-        return OTVAE_EUNSUPPORTED;
-    }
-    const int NB = attn_nb(T, H, C, per_img);
-    const size_t lds = (size_t)NB * per_img * sizeof(float);
+    OTVAE_REQUIRE(qkv && out && lse && gout && gqkv, "otvae_attn_bwd: NULL tensor");
+    int qpt, spb;
+    const int rqg = (2 * C + 2 + 3) & ~3;
+    int rc = attn_check("otvae_attn_bwd", N, T, H, C, 2 * C + rqg, &qpt, &spb);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = cdiv(N, NB);
-#define BWD_K(CC, ...)                                                                    \
-    do {                                                                                  \
-        if (!ensure_lds((const void*)attn_bwd_kernel<CC>, &bwd_lds_set[CC], lds)) return OTVAE_ELAUNCH; \
-        attn_bwd_kernel<CC><<<grid, 256, lds, st>>>(qkv, out, lse, gout, N, T, H, NB, gqkv); \
+    const int grid = cdiv((int64_t)N * H, spb);
+    const size_t lds = (size_t)spb * T * (2 * C + rqg) * sizeof(float);
+#define BWD_K(CC)                                                                                   \
+    do {                                                                                            \
+        if (qpt == 4) {                                                                             \
+            if constexpr (CC <= 4) attn_bwd_kernel<CC, 4><<<grid, 256, lds, st>>>(qkv, out, lse, gout, N, T, H, spb, gqkv); \
+            else { otvae_set_error("otvae_attn_bwd: T >= 256 with head width %d > 4 unsupported", CC); return OTVAE_EUNSUPPORTED; } \
+        } else {                                                                                    \
+            attn_bwd_kernel<CC, 1><<<grid, 256, lds, st>>>(qkv, out, lse, gout, N, T, H, spb, gqkv);  \
+        }                                                                                           \
     } while (0)
-    ATTN_DISPATCH(C, BWD_K, 0)
+    ATTN_C_SWITCH(C, BWD_K)
 #undef BWD_K
     OTVAE_CHECK_LAUNCH("otvae_attn_bwd");
     return OTVAE_OK;
