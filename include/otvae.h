@@ -61,6 +61,10 @@ int otvae_conv_fwd(const otvae_conv_geom* g, const float* x, const float* scale,
 
 /* HWIO [T][Cs][Cn] -> [T][Cn][Cs] (the dgrad operand layout) */
 int otvae_weight_transpose(const float* wT, float* wD, int T, int Cs, int Cn, void* stream);
+/* the same for every conv weight of a model in one launch: device table[n_layers][5] of int64
+ * {src element offset (from src_base), dst element offset (from dst_base), T, Cs, Cn}; max_elems = largest T*Cs*Cn */
+int otvae_weight_transpose_batched(const float* src_base, float* dst_base, const int64_t* table, int n_layers,
+                                   int64_t max_elems, void* stream);
 
 /* ---- ConvLayer backward ------------------------------------------------------------------------------------ */
 /* Data gradient.  gv[N][Hs][Ws][Cs] = d loss / d (x*scale+shift) i.e. the gradient entering BatchNorm's output

@@ -36,6 +36,7 @@ SIGNATURES = {
     "otvae_bn_finalize": (i32, [vp, i32, i64, i32, f32, f32, vp, vp, i32, pp, pp, pp, pp, pp, pp, pp, vp]),
     "otvae_conv_fwd": (i32, [pg, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "otvae_weight_transpose": (i32, [vp, vp, i32, i32, i32, vp]),
+    "otvae_weight_transpose_batched": (i32, [vp, vp, vp, i32, i64, vp]),
     "otvae_conv_bwd_data_ws": (i32, [pg, pi32, pi32]),
     "otvae_conv_bwd_data": (i32, [pg, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "otvae_bn_bwd_finalize": (i32, [i32, pp, pi32, i32, i64, i32, vp, vp, pp, pp, pp, vp, vp]),

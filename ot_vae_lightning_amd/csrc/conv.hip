@@ -90,7 +90,7 @@ __device__ __forceinline__ void dgrad_row_to_pos(const Geom& g, unsigned row, in
     }
 }
 
-template <int MODE, int NT>
+template <int MODE, int NT, bool VEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __restrict__ S, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int relu,
                                                         const float* __restrict__ Bmat,
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
     constexpr int LDA = KC + 2;
     constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 0);
     constexpr int NB_ELEMS = KC * BN / 256;  // weight-tile elements staged per thread per chunk
-    __shared__ float As[2][TM * LDA];
-    __shared__ float Bs[2][KC * LDB];
+    __shared__ __align__(16) float As[2][TM * LDA];
+    __shared__ __align__(16) float Bs[2][KC * LDB];
     __shared__ int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_w[MAX_TAPS];
     __shared__ int s_ntaps;
     __shared__ int row_n[TM], row_y[TM], row_x[TM];
@@ -199,10 +199,63 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        // Staged operands travel through registers between the global load (issued one chunk ahead) and the LDS store.
+        // VEC: channel counts are multiples of 4 -> float4 gathers along the channel (k) dimension, 4x fewer address
+        // computations and memory instructions; otherwise one scalar per slot.
+        constexpr int NBV = (8 * BN + 255) / 256;  // float4 weight slots per thread (VEC)
         float areg[8], breg[NB_ELEMS];
+        float4 areg4[2], breg4[NBV];
+        float4 a_sc4 = make_float4(1.f, 1.f, 1.f, 1.f), a_sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int a_ok = 0;
         float a_sc = 1.f, a_sh = 0.f;
+        // VEC role: k4 = tid & 7 (4 consecutive k), rows (tid >> 3) + 32 i
+        const int v_k4 = tid & 7, v_r0 = tid >> 3;
+        int vr_n[2], vr_y[2], vr_x[2];
+        if constexpr (VEC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                vr_n[i] = row_n[v_r0 + 32 * i];
+                vr_y[i] = row_y[v_r0 + 32 * i];
+                vr_x[i] = row_x[v_r0 + 32 * i];
+            }
+        }
 
         auto stage_load = [&](int ch) {
+            if constexpr (VEC) {
+                const int k = ch * KC + v_k4 * 4;
+                const bool kv = k < K;
+                const int tl = kv ? fast_div(k, inv_ck) : 0;
+                const int c = k - tl * CK;
+                const int dy = tap_dy[tl], dx = tap_dx[tl];
+                if (MODE == 0 && scale != nullptr && kv) {
+                    a_sc4 = *reinterpret_cast<const float4*>(scale + c);
+                    a_sh4 = *reinterpret_cast<const float4*>(shift + c);
+                }
+                a_ok = 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ty = vr_y[i] + dy, tx = vr_x[i] + dx;
+                    areg4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kv && vr_n[i] >= 0 && (unsigned)ty < (unsigned)lim_y && (unsigned)tx < (unsigned)lim_x) {
+                        const unsigned pix = ((unsigned)vr_n[i] * srcH + (ty >> sh)) * srcW + (tx >> sh);
+                        areg4[i] = *reinterpret_cast<const float4*>(S + (size_t)pix * CK + c);
+                        a_ok |= 1 << i;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NBV; ++j) {
+                    const int e = tid + 256 * j;
+                    const int kb = e / (BN / 4), c4 = e - kb * (BN / 4);
+                    const int kk = ch * KC + kb;
+                    breg4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < 8 * BN && kk < K && n0 + c4 * 4 < NC) {
+                        const int t2 = fast_div(kk, inv_ck);
+                        const int c2 = kk - t2 * CK;
+                        breg4[j] = *reinterpret_cast<const float4*>(Bmat + ((size_t)tap_w[t2] * CK + c2) * NC + n0 + c4 * 4);
+                    }
+                }
+                return;
+            }
             // ---- A
             const int k = ch * KC + a_kl;
             const bool kv = k < K;
@@ -241,6 +294,40 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
             }
         };
         auto stage_store = [&](int buf) {
+            if constexpr (VEC) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float4 v = areg4[i];
+                    if ((a_ok >> i) & 1) {
+                        if (MODE == 0) {
+                            if (scale != nullptr) {
+                                v.x = fmaf(v.x, a_sc4.x, a_sh4.x);
+                                v.y = fmaf(v.y, a_sc4.y, a_sh4.y);
+                                v.z = fmaf(v.z, a_sc4.z, a_sh4.z);
+                                v.w = fmaf(v.w, a_sc4.w, a_sh4.w);
+                            }
+                            if (relu) {
+                                v.x = fmaxf(v.x, 0.f);
+                                v.y = fmaxf(v.y, 0.f);
+                                v.z = fmaxf(v.z, 0.f);
+                                v.w = fmaxf(v.w, 0.f);
+                            }
+                        }
+                    }
+                    float* dst = &As[buf][(v_r0 + 32 * i) * LDA + v_k4 * 4];  // 8-byte aligned (LDA even)
+                    *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+                    *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+                }
+#pragma unroll
+                for (int j = 0; j < NBV; ++j) {
+                    const int e = tid + 256 * j;
+                    if (e < 8 * BN) {
+                        const int kb = e / (BN / 4), c4 = e - kb * (BN / 4);
+                        *reinterpret_cast<float4*>(&Bs[buf][kb * LDB + c4 * 4]) = breg4[j];  // LDB % 4 == 0
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float v = areg[i];
@@ -377,13 +464,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
     }
 }
 
-template <int MODE>
-static void launch_gemm(int NT, dim3 grid, hipStream_t st, Geom g, const float* S, const float* scale, const float* shift,
-                        int relu, const float* Bmat, const float* bias, const float* res, float* y, const float* xin,
-                        const float* mean, const float* invstd, float* gv, double* partial, int CsPad) {
-#define OTVAE_CG(N_)                                                                                                     \
-    conv_gemm_kernel<MODE, N_><<<grid, 256, 0, st>>>(g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, \
-                                                     partial, CsPad)
+template <int MODE, bool VEC>
+static void launch_gemm_v(int NT, dim3 grid, hipStream_t st, Geom g, const float* S, const float* scale, const float* shift,
+                          int relu, const float* Bmat, const float* bias, const float* res, float* y, const float* xin,
+                          const float* mean, const float* invstd, float* gv, double* partial, int CsPad) {
+#define OTVAE_CG(N_)                                                                                                      \
+    conv_gemm_kernel<MODE, N_, VEC><<<grid, 256, 0, st>>>(g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, \
+                                                          gv, partial, CsPad)
     switch (NT) {
         case 1: OTVAE_CG(1); break;
         case 2: OTVAE_CG(2); break;
@@ -391,6 +478,20 @@ static void launch_gemm(int NT, dim3 grid, hipStream_t st, Geom g, const float* 
         default: OTVAE_CG(4); break;
     }
 #undef OTVAE_CG
+}
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int MODE>
+static void launch_gemm(int NT, dim3 grid, hipStream_t st, Geom g, const float* S, const float* scale, const float* shift,
+                        int relu, const float* Bmat, const float* bias, const float* res, float* y, const float* xin,
+                        const float* mean, const float* invstd, float* gv, double* partial, int CsPad) {
+    const bool vec = (g.Cs % 4 == 0) && (g.Cn % 4 == 0) && aligned16(S) && aligned16(Bmat) &&
+                     (scale == nullptr || (aligned16(scale) && aligned16(shift)));
+    if (vec)
+        launch_gemm_v<MODE, true>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
+    else
+        launch_gemm_v<MODE, false>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
 }
 
 extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const float* scale, const float* shift, int relu,
@@ -427,6 +528,33 @@ extern "C" int otvae_weight_transpose(const float* wT, float* wD, int T, int Cs,
     const size_t total = (size_t)T * Cs * Cn;
     weight_transpose_kernel<<<imin(cdiv(total, 256), 2048), 256, 0, (hipStream_t)stream>>>(wT, wD, T, Cs, Cn);
     OTVAE_CHECK_LAUNCH("otvae_weight_transpose");
+    return OTVAE_OK;
+}
+
+// all conv weights of a model in ONE launch: table[l] = {src offset, dst offset, T, Cs, Cn} (element offsets into the
+// flat parameter buffer / the flat dgrad-layout buffer), blockIdx.y = layer
+__global__ void weight_transpose_batched_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                                const int64_t* __restrict__ table) {
+    const int64_t* d = table + (size_t)blockIdx.y * 5;
+    const float* wT = src_base + d[0];
+    float* wD = dst_base + d[1];
+    const int T = (int)d[2], Cs = (int)d[3], Cn = (int)d[4];
+    const size_t total = (size_t)T * Cs * Cn;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % Cs;
+        const size_t r = i / Cs;
+        const int n = r % Cn;
+        const int t = r / Cn;
+        wD[i] = wT[((size_t)t * Cs + c) * Cn + n];
+    }
+}
+
+extern "C" int otvae_weight_transpose_batched(const float* src_base, float* dst_base, const int64_t* table, int n_layers,
+                                              int64_t max_elems, void* stream) {
+    OTVAE_REQUIRE(src_base && dst_base && table && n_layers > 0 && max_elems > 0, "otvae_weight_transpose_batched: bad argument");
+    dim3 grid(imin(cdiv(max_elems, 256), 256), n_layers);
+    weight_transpose_batched_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src_base, dst_base, table);
+    OTVAE_CHECK_LAUNCH("otvae_weight_transpose_batched");
     return OTVAE_OK;
 }
 
@@ -479,7 +607,7 @@ extern "C" int otvae_conv_bwd_data(const otvae_conv_geom* gg, const float* gy, c
 // Block = 64 k-rows x (16*NT) n-cols, reduction over one pixel chunk in sub-chunks of 32 pixels staged in LDS
 // (At[pixel][k], Gt[pixel][n], double-buffered).  Row K (after the last tap*channel row) is the bias row: A = 1.
 #define PC 32
-template <int NT>
+template <int NT, bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int relu,
                                                          const float* __restrict__ gy, float* __restrict__ partial, int Kp,
@@ -488,8 +616,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
     constexpr int LDA = 64 + 16;
     constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 0);
     constexpr int NB_ELEMS = PC * BN / 256;
-    __shared__ float At[2][PC * LDA];
-    __shared__ float Gt[2][PC * LDB];
+    __shared__ __align__(16) float At[2][PC * LDA];
+    __shared__ __align__(16) float Gt[2][PC * LDB];
     __shared__ int s_live[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -523,10 +651,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
     } else if (has_bias && k == K) {
         kind = 2;
     }
+    // VEC role (channel counts multiples of 4): k4 = tid & 15 (4 consecutive k of ONE tap), pixels (tid >> 4) + 16 i
+    const int v_k4 = tid & 15, v_p0 = tid >> 4;
+    int vkind = 0, vdy = 0, vdx = 0, vc = 0;
+    float4 v_sc4 = make_float4(1.f, 1.f, 1.f, 1.f), v_sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (VEC) {
+        const int k0 = kb * 64 + v_k4 * 4;
+        if (k0 < K) {
+            const int t = k0 / g.Cs;
+            vc = k0 - t * g.Cs;
+            const int kh = t / g.KW;
+            vdy = kh - g.pad;
+            vdx = (t - kh * g.KW) - g.pad;
+            const bool ytouch = (vdy + (g.Ho - 1) * g.stride >= 0) && (vdy < Hu);
+            const bool xtouch = (vdx + (g.Wo - 1) * g.stride >= 0) && (vdx < Wu);
+            vkind = (ytouch && xtouch) ? 1 : 0;
+            if (vkind && scale) {
+                v_sc4 = *reinterpret_cast<const float4*>(scale + vc);
+                v_sh4 = *reinterpret_cast<const float4*>(shift + vc);
+            }
+        } else if (has_bias && k0 == K) {
+            vkind = 2;  // K % 4 == 0: the bias row opens a group {1, 0, 0, 0}
+        }
+    }
     // which 16-row MFMA tiles hold a live row?  (every staging wave sees all 64 k-rows in its lanes)
     {
-        const unsigned long long bal = __ballot(kind != 0);
-        if (tid < 4) s_live[tid] = ((bal >> (16 * tid)) & 0xffffull) ? 1 : 0;
+        if constexpr (VEC) {
+            const unsigned long long bal = __ballot(vkind != 0);  // lane l <-> k4 = l & 15
+            if (tid < 4) s_live[tid] = ((bal >> (4 * tid)) & 0xfull) ? 1 : 0;
+        } else {
+            const unsigned long long bal = __ballot(kind != 0);
+            if (tid < 4) s_live[tid] = ((bal >> (16 * tid)) & 0xffffull) ? 1 : 0;
+        }
         __syncthreads();
     }
     const bool live = s_live[wave] != 0;
@@ -538,10 +694,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
 
     const unsigned span = mend > mbeg ? mend - mbeg : 0;
     const int nsub = any_live ? (int)((span + PC - 1) / PC) : 0;
+    constexpr int NGV = (8 * BN + 255) / 256;
     float areg[8], greg[NB_ELEMS];
+    float4 areg4[2], greg4[NGV];
+    int a_ok = 0;
 
     auto stage_load = [&](int sub) {
         const unsigned mb = mbeg + (unsigned)sub * PC;
+        if constexpr (VEC) {
+            unsigned m = mb + v_p0;
+            int ox = m % g.Wo;
+            unsigned t = m / g.Wo;
+            int oy = t % g.Ho;
+            int n = t / g.Ho;
+            a_ok = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                areg4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < mend) {
+                    if (vkind == 1) {
+                        const int iy = oy * g.stride + vdy, ix = ox * g.stride + vdx;
+                        if ((unsigned)iy < (unsigned)Hu && (unsigned)ix < (unsigned)Wu) {
+                            areg4[i] = *reinterpret_cast<const float4*>(
+                                x + ((size_t)((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * g.Cs + vc);
+                            a_ok |= 1 << i;
+                        }
+                    } else if (vkind == 2) {
+                        areg4[i].x = 1.f;
+                    }
+                }
+                m += 16;
+                ox += 16;
+                while (ox >= g.Wo) {
+                    ox -= g.Wo;
+                    if (++oy >= g.Ho) {
+                        oy = 0;
+                        ++n;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NGV; ++j) {
+                const int e = tid + 256 * j;
+                const int p = e / (BN / 4), c4 = e - p * (BN / 4);
+                const unsigned mm = mb + p;
+                greg4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < 8 * BN && mm < mend && n0 + c4 * 4 < g.Cn)
+                    greg4[j] = *reinterpret_cast<const float4*>(gy + (size_t)mm * g.Cn + n0 + c4 * 4);
+            }
+            return;
+        }
         // A: pixels mb + a_p0 + 4 i: decode the first, then step by 4 pixels
         unsigned m = mb + a_p0;
         int ox = m % g.Wo;
@@ -580,6 +782,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
         }
     };
     auto stage_store = [&](int buf) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float4 v = areg4[i];
+                if ((a_ok >> i) & 1) {
+                    if (scale) {
+                        v.x = fmaf(v.x, v_sc4.x, v_sh4.x);
+                        v.y = fmaf(v.y, v_sc4.y, v_sh4.y);
+                        v.z = fmaf(v.z, v_sc4.z, v_sh4.z);
+                        v.w = fmaf(v.w, v_sc4.w, v_sh4.w);
+                    }
+                    if (relu) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+                *reinterpret_cast<float4*>(&At[buf][(v_p0 + 16 * i) * LDA + v_k4 * 4]) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NGV; ++j) {
+                const int e = tid + 256 * j;
+                if (e < 8 * BN) {
+                    const int p = e / (BN / 4), c4 = e - p * (BN / 4);
+                    *reinterpret_cast<float4*>(&Gt[buf][p * LDB + c4 * 4]) = greg4[j];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float v = areg[i];
@@ -722,12 +954,26 @@ extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, 
     wgrad_plan(g, has_bias, NT, P, chunk, nkb, nnb, Kp);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(nkb, nnb, P);
-    switch (NT) {
-        case 1: conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk); break;
-        case 2: conv_wgrad_kernel<2><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk); break;
-        case 3: conv_wgrad_kernel<3><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk); break;
-        default: conv_wgrad_kernel<4><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk); break;
+    const bool vec = (g.Cs % 4 == 0) && (g.Cn % 4 == 0) && aligned16(x) && aligned16(gy) &&
+                     (scale == nullptr || (aligned16(scale) && aligned16(shift)));
+#define OTVAE_WG(N_, V_) \
+    conv_wgrad_kernel<N_, V_><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk)
+    if (vec) {
+        switch (NT) {
+            case 1: OTVAE_WG(1, true); break;
+            case 2: OTVAE_WG(2, true); break;
+            case 3: OTVAE_WG(3, true); break;
+            default: OTVAE_WG(4, true); break;
+        }
+    } else {
+        switch (NT) {
+            case 1: OTVAE_WG(1, false); break;
+            case 2: OTVAE_WG(2, false); break;
+            case 3: OTVAE_WG(3, false); break;
+            default: OTVAE_WG(4, false); break;
+        }
     }
+#undef OTVAE_WG
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight");
     const size_t total = (size_t)Kp * g.Cn;
     wgrad_reduce_kernel<<<imin(cdiv(total, P >= 32 ? 4 : 64), 2048), 256, 0, st>>>(partial, P, Kp - (has_bias ? 1 : 0), Kp, g.Cn, gw, gb);

@@ -84,14 +84,22 @@ class HipTrainer:
         self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
         for p, off in zip(self.params, self.offsets):
             p._otvae_grad_view = (lambda off=off, p=p: _dense_view(self.gflat, off, p.data))
-        # dgrad-layout ([T][Cout][Cin]) copies of every conv weight, refreshed at the start of each step
+        # dgrad-layout ([T][Cout][Cin]) copies of every conv weight, refreshed by ONE launch at the start of each step
         self.conv_weights = [mod.weight for mod in model.modules() if isinstance(mod, ConvLayer)]
+        flat_ids = {id(p): off for p, off in zip(self.params, self.offsets)}
         wd_total = sum((w.numel() + 3) // 4 * 4 for w in self.conv_weights)
-        self.wdflat = torch.empty(wd_total, device=dev, dtype=torch.float32)
-        off = 0
+        self.wdflat = torch.empty(max(4, wd_total), device=dev, dtype=torch.float32)
+        off, table, self._wd_loose = 0, [], []
         for w in self.conv_weights:
             w._otvae_wd = self.wdflat[off: off + w.numel()]
+            cn, cs, kh, kw = w.shape
+            if id(w) in flat_ids:
+                table.append([flat_ids[id(w)], off, kh * kw, cs, cn])
+            else:  # a frozen conv weight is not in the flat buffer: transposed on its own
+                self._wd_loose.append(w)
             off += (w.numel() + 3) // 4 * 4
+        self._wd_table = torch.tensor(table, device=dev, dtype=torch.int64) if table else None
+        self._wd_max = max((t[2] * t[3] * t[4] for t in table), default=0)
         # distributed
         self.group = process_group
         self.reducer = FlatGradReducer(self.gflat, process_group)
@@ -112,7 +120,11 @@ class HipTrainer:
     # -- pieces of a step ----------------------------------------------------------------------------------------
     def _refresh_wd(self):
         lib = self.lib
-        for w in self.conv_weights:
+        if self._wd_table is not None:
+            check(lib.otvae_weight_transpose_batched(ptr(self.pflat), ptr(self.wdflat), ptr(self._wd_table),
+                                                     self._wd_table.shape[0], self._wd_max, stream()),
+                  "otvae_weight_transpose_batched")
+        for w in self._wd_loose:
             cn, cs, kh, kw = w.shape
             check(lib.otvae_weight_transpose(ptr(w), ptr(w._otvae_wd), kh * kw, cs, cn, stream()),
                   "otvae_weight_transpose")
