@@ -17,10 +17,7 @@
 // Taps that cannot touch the image for any row of the layer (e.g. 8 of the 9 taps of a 3x3 conv on a 1x1 map) are
 // dropped from K at kernel start.
 #include "common.h"
-
-struct Geom {
-    int N, Hs, Ws, Cs, up, Ho, Wo, Cn, KH, KW, stride, pad;
-};
+#include "conv_small.h"  // struct Geom + the direct VALU kernels used when both channel counts are tiny
 
 static inline Geom to_geom(const otvae_conv_geom* g) {
     Geom r = {g->N, g->Hs, g->Ws, g->Cs, g->up, g->Ho, g->Wo, g->Cn, g->KH, g->KW, g->stride, g->pad};
@@ -501,6 +498,11 @@ extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const f
     OTVAE_REQUIRE(x && wT && y, "otvae_conv_fwd: NULL tensor");
     OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_conv_fwd: scale and shift must be given together");
     Geom g = to_geom(gg);
+    if (conv_small_ok(g)) {
+        conv_small_fwd(g, x, scale, shift, relu, wT, bias, residual, y, (hipStream_t)stream);
+        OTVAE_CHECK_LAUNCH("otvae_conv_fwd(small)");
+        return OTVAE_OK;
+    }
     const int NT = pick_nt(g.Cn);
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
     dim3 grid(imin(cdiv(M, TM), 8192), cdiv(cdiv(g.Cn, 16), NT), 1);
@@ -597,6 +599,12 @@ extern "C" int otvae_conv_bwd_data(const otvae_conv_geom* gg, const float* gy, c
     int NT, CsPad;
     dim3 grid;
     dgrad_grid(g, NT, grid, CsPad);
+    if (conv_small_ok(g)) {  // same number of BatchNorm partials (grid.x * grid.z) as the workspace query promised
+        conv_small_dgrad(g, grid.x * grid.z, gy, wD, x, scale, shift, relu, mean, invstd, gv, bn_partial, CsPad,
+                         (hipStream_t)stream);
+        OTVAE_CHECK_LAUNCH("otvae_conv_bwd_data(small)");
+        return OTVAE_OK;
+    }
     launch_gemm<1>(NT, grid, (hipStream_t)stream, g, gy, scale, shift, relu, wD, nullptr, nullptr, nullptr, x, mean, invstd, gv,
                    bn_partial, CsPad);
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_data");
@@ -917,6 +925,10 @@ static void wgrad_plan(const Geom& g, int has_bias, int& NT, int& P, unsigned& c
     Kp = g.KH * g.KW * g.Cs + (has_bias ? 1 : 0);
     nkb = cdiv(Kp, 64);
     nnb = cdiv(cdiv(g.Cn, 16), NT);
+    if (conv_small_wgrad_ok(g)) {
+        conv_small_wgrad_plan(g, P, chunk);
+        return;
+    }
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
     // enough workgroups to fill the chip several times over (256 CUs x ~3 resident x 4 rounds: the kernel is latency-
     // bound per 32-pixel step, short chains + many resident blocks hide it), pixel chunks of >= 128 pixels,
@@ -953,6 +965,15 @@ extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, 
     unsigned chunk;
     wgrad_plan(g, has_bias, NT, P, chunk, nkb, nnb, Kp);
     hipStream_t st = (hipStream_t)stream;
+    const size_t total = (size_t)Kp * g.Cn;
+    if (conv_small_wgrad_ok(g)) {
+        conv_small_wgrad(g, x, scale, shift, relu, gy, has_bias, partial, st);
+        OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(small)");
+        wgrad_reduce_kernel<<<imin(cdiv(total, P >= 32 ? 4 : 64), 2048), 256, 0, st>>>(partial, P, Kp - (has_bias ? 1 : 0), Kp,
+                                                                                     g.Cn, gw, gb);
+        OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(reduce)");
+        return OTVAE_OK;
+    }
     dim3 grid(nkb, nnb, P);
     const bool vec = (g.Cs % 4 == 0) && (g.Cn % 4 == 0) && aligned16(x) && aligned16(gy) &&
                      (scale == nullptr || (aligned16(scale) && aligned16(shift)));
@@ -975,7 +996,6 @@ extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, 
     }
 #undef OTVAE_WG
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight");
-    const size_t total = (size_t)Kp * g.Cn;
     wgrad_reduce_kernel<<<imin(cdiv(total, P >= 32 ? 4 : 64), 2048), 256, 0, st>>>(partial, P, Kp - (has_bias ? 1 : 0), Kp, g.Cn, gw, gb);
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(reduce)");
     return OTVAE_OK;
