@@ -46,8 +46,9 @@ int otvae_bn_stats(const float* x, int64_t M, int C, double* partial, void* stre
 /* mean/invstd from the partials; for each of `n_bn` BatchNorm modules sharing this input (a ConvBlock's
  * block[0] and skip normalise the same tensor) writes scale = gamma*invstd, shift = beta - mean*scale and updates
  * running_mean/var (momentum, unbiased var) and num_batches_tracked.  Arrays of n_bn device pointers are HOST
- * arrays. running pointers may be NULL (no update). */
-int otvae_bn_finalize(const double* partial, int P, int64_t M, int C, float eps, float momentum,
+ * arrays. running pointers may be NULL (no update).  `ld` = row stride of the partials (C for otvae_bn_stats, CnPad when
+ * they come from the producing conv's epilogue, see otvae_conv_fwd). */
+int otvae_bn_finalize(const double* partial, int P, int ld, int64_t M, int C, float eps, float momentum,
                       float* mean, float* invstd, int n_bn,
                       const float* const* gamma, const float* const* beta,
                       float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
@@ -56,8 +57,12 @@ int otvae_bn_finalize(const double* partial, int P, int64_t M, int C, float eps,
 /* ---- ConvLayer.forward: y = conv(up(relu?(x*scale+shift))) + bias (+ residual) ---------------------------- */
 /* scale/shift NULL -> no normalisation; relu applies after the affine; bias/residual NULL -> absent.
  * residual has y's shape (ConvBlock `out + skip(x)`, networks/cnn.py:334). wT is the HWIO weight. */
+/* stat_partial (nullable): fp64 [P][2][CnPad] per-block partial sums (sum y, sum y^2) per output channel, written by
+ * the epilogue so that the NEXT layer's BatchNorm needs no separate pass over y; P, CnPad from _stats_ws. */
+int otvae_conv_fwd_stats_ws(const otvae_conv_geom* g, int* P, int* CnPad);
 int otvae_conv_fwd(const otvae_conv_geom* g, const float* x, const float* scale, const float* shift, int relu,
-                   const float* wT, const float* bias, const float* residual, float* y, void* stream);
+                   const float* wT, const float* bias, const float* residual, float* y, double* stat_partial,
+                   void* stream);
 
 /* HWIO [T][Cs][Cn] -> [T][Cn][Cs] (the dgrad operand layout) */
 int otvae_weight_transpose(const float* wT, float* wD, int T, int Cs, int Cn, void* stream);

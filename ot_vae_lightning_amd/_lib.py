@@ -33,8 +33,9 @@ SIGNATURES = {
     "otvae_device_info": (i32, [pi32, pi32, C.c_char_p, i32]),
     "otvae_bn_stats_nparts": (i32, [i64, i32]),
     "otvae_bn_stats": (i32, [vp, i64, i32, vp, vp]),
-    "otvae_bn_finalize": (i32, [vp, i32, i64, i32, f32, f32, vp, vp, i32, pp, pp, pp, pp, pp, pp, pp, vp]),
-    "otvae_conv_fwd": (i32, [pg, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "otvae_bn_finalize": (i32, [vp, i32, i32, i64, i32, f32, f32, vp, vp, i32, pp, pp, pp, pp, pp, pp, pp, vp]),
+    "otvae_conv_fwd_stats_ws": (i32, [pg, pi32, pi32]),
+    "otvae_conv_fwd": (i32, [pg, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "otvae_weight_transpose": (i32, [vp, vp, i32, i32, i32, vp]),
     "otvae_weight_transpose_batched": (i32, [vp, vp, vp, i32, i64, vp]),
     "otvae_conv_bwd_data_ws": (i32, [pg, pi32, pi32]),

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             for (int i = 0; i < QPT; ++i) mx[i] = fmaxf(mx[i], dotc<C>(q[i], r));
         }
     }
-#pragma unroll 2
+#pragma unroll 4
     for (int s = 0; s < T; ++s) {
         const float* r = kv + s * Rec<C>::KV;
         float kk[C], vv[C];
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             ls[i] = r[2 * C];
             dl[i] = r[2 * C + 1];
         }
-#pragma unroll 2
+#pragma unroll 4
         for (int s = 0; s < T; ++s) {
             const float* r = kv + s * RKV;
             float kk[C], vv[C];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 dk[i][c] = dv[i][c] = 0.f;
             }
         }
-#pragma unroll 2
+#pragma unroll 4
         for (int t = 0; t < T; ++t) {
             const float* r = qg + (size_t)t * RQG;
             float qq[C], gg[C];

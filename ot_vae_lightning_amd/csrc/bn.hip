@@ -74,16 +74,16 @@ struct BnFin {
 };
 
 // one wave per channel: lanes stride over the <= 256 partials, fixed-order shuffle tree
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int P, int64_t M, int C, float eps,
-                                                          float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int P, int ld, int64_t M, int C,
+                                                          float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                           int n_bn, BnFin f) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c < C) {
         double s = 0.0, q = 0.0;
         for (int p = lane; p < P; p += 64) {
-            s += partial[((size_t)p * 2 + 0) * C + c];
-            q += partial[((size_t)p * 2 + 1) * C + c];
+            s += partial[((size_t)p * 2 + 0) * ld + c];
+            q += partial[((size_t)p * 2 + 1) * ld + c];
         }
         s = wave_sum(s);
         q = wave_sum(q);
@@ -110,11 +110,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
             if (f.nbt[b]) *f.nbt[b] += 1;
 }
 
-extern "C" int otvae_bn_finalize(const double* partial, int P, int64_t M, int C, float eps, float momentum, float* mean,
+extern "C" int otvae_bn_finalize(const double* partial, int P, int ld, int64_t M, int C, float eps, float momentum, float* mean,
                                  float* invstd, int n_bn, const float* const* gamma, const float* const* beta,
                                  float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
                                  float* const* scale, float* const* shift, void* stream) {
-    OTVAE_REQUIRE(partial && mean && invstd && P > 0 && M > 0 && C > 0, "otvae_bn_finalize: bad argument");
+    OTVAE_REQUIRE(partial && mean && invstd && P > 0 && M > 0 && C > 0 && ld >= C, "otvae_bn_finalize: bad argument");
     OTVAE_REQUIRE(n_bn >= 0 && n_bn <= 2, "otvae_bn_finalize: n_bn must be 0..2");
     BnFin f = {};
     for (int b = 0; b < n_bn; ++b) {
@@ -127,7 +127,7 @@ extern "C" int otvae_bn_finalize(const double* partial, int P, int64_t M, int C,
         f.scale[b] = scale[b];
         f.shift[b] = shift[b];
     }
-    bn_finalize_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partial, P, M, C, eps, momentum, mean, invstd, n_bn, f);
+    bn_finalize_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partial, P, ld, M, C, eps, momentum, mean, invstd, n_bn, f);
     OTVAE_CHECK_LAUNCH("otvae_bn_finalize");
     return OTVAE_OK;
 }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
     __shared__ int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_w[MAX_TAPS];
     __shared__ int s_ntaps;
     __shared__ int row_n[TM], row_y[TM], row_x[TM];
-    __shared__ double red[(MODE == 1) ? 4 * 2 * BN : 1];
+    __shared__ double red[4 * 2 * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
                             float v = acc[j][r] + bv;
                             if (res) v += res[o];
                             y[o] = v;
+                            if (partial) {  // per-channel sums of the OUTPUT: the next layer's BatchNorm statistics
+                                s1[j] += (double)v;
+                                s2[j] += (double)v * (double)v;
+                            }
                         }
                     }
                 }
@@ -435,8 +439,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
         }
     }
 
-    if (MODE == 1 && mean) {
-        // fixed-order reduction of the BatchNorm-backward sums: lane groups (shuffle), waves (LDS), one partial per block
+    if ((MODE == 1 && mean) || (MODE == 0 && partial)) {
+        // fixed-order reduction of the per-channel sums (BatchNorm-backward sums, resp. output statistics): lane groups (shuffle), waves (LDS), one partial per block
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -491,23 +495,46 @@ static void launch_gemm(int NT, dim3 grid, hipStream_t st, Geom g, const float* 
         launch_gemm_v<MODE, false>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
 }
 
+static void fwd_grid(const Geom& g, int& NT, dim3& grid, int& CnPad) {
+    NT = pick_nt(g.Cn);
+    const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
+    const int ny = cdiv(cdiv(g.Cn, 16), NT);
+    grid = dim3(imin(cdiv(M, TM), 2048), ny, 1);  // <= 2048 blocks: each may write one statistics partial
+    CnPad = ny * 16 * NT;
+}
+
+extern "C" int otvae_conv_fwd_stats_ws(const otvae_conv_geom* gg, int* P, int* CnPad) {
+    int rc = check_geom(gg, "otvae_conv_fwd_stats_ws");
+    if (rc) return rc;
+    Geom g = to_geom(gg);
+    int NT, cp;
+    dim3 grid;
+    fwd_grid(g, NT, grid, cp);
+    if (conv_small_ok(g)) grid.x = imin(grid.x, 1024);
+    if (P) *P = grid.x;
+    if (CnPad) *CnPad = cp;
+    return OTVAE_OK;
+}
+
 extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const float* scale, const float* shift, int relu,
-                              const float* wT, const float* bias, const float* residual, float* y, void* stream) {
+                              const float* wT, const float* bias, const float* residual, float* y, double* stat_partial,
+                              void* stream) {
     int rc = check_geom(gg, "otvae_conv_fwd");
     if (rc) return rc;
     OTVAE_REQUIRE(x && wT && y, "otvae_conv_fwd: NULL tensor");
     OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_conv_fwd: scale and shift must be given together");
     Geom g = to_geom(gg);
+    int NT, CnPad;
+    dim3 grid;
+    fwd_grid(g, NT, grid, CnPad);
     if (conv_small_ok(g)) {
-        conv_small_fwd(g, x, scale, shift, relu, wT, bias, residual, y, (hipStream_t)stream);
+        conv_small_fwd(g, imin(grid.x, 1024), x, scale, shift, relu, wT, bias, residual, y, stat_partial, CnPad,
+                       (hipStream_t)stream);
         OTVAE_CHECK_LAUNCH("otvae_conv_fwd(small)");
         return OTVAE_OK;
     }
-    const int NT = pick_nt(g.Cn);
-    const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
-    dim3 grid(imin(cdiv(M, TM), 8192), cdiv(cdiv(g.Cn, 16), NT), 1);
     launch_gemm<0>(NT, grid, (hipStream_t)stream, g, x, scale, shift, relu, wT, bias, residual, y, nullptr, nullptr, nullptr,
-                   nullptr, nullptr, 0);
+                   nullptr, stat_partial, CnPad);
     OTVAE_CHECK_LAUNCH("otvae_conv_fwd");
     return OTVAE_OK;
 }

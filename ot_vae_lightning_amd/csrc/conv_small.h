@@ -10,8 +10,9 @@ typedef Geom SmallGeom;
 bool conv_small_ok(const SmallGeom& g);
 bool conv_small_wgrad_ok(const SmallGeom& g);
 void conv_small_wgrad_plan(const SmallGeom& g, int& P, unsigned& chunk);
-int conv_small_fwd(const SmallGeom& g, const float* x, const float* scale, const float* shift, int relu, const float* wT,
-                   const float* bias, const float* res, float* y, hipStream_t st);
+int conv_small_fwd(const SmallGeom& g, int nblocks, const float* x, const float* scale, const float* shift, int relu,
+                   const float* wT, const float* bias, const float* res, float* y, double* partial, int CnPad,
+                   hipStream_t st);
 int conv_small_dgrad(const SmallGeom& g, int nblocks, const float* gy, const float* wD, const float* x, const float* scale,
                      const float* shift, int relu, const float* mean, const float* invstd, float* gv, double* partial,
                      int CsPad, hipStream_t st);

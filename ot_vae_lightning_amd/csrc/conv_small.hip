@@ -29,8 +29,9 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const 
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int relu, const float* __restrict__ wT,
                                                              const float* __restrict__ bias, const float* __restrict__ res,
-                                                             float* __restrict__ y) {
+                                                             float* __restrict__ y, double* __restrict__ partial, int CnPad) {
     __shared__ float w_s[SMALL_MAXW];
+    __shared__ double redf[4][2][SMALL_MAXC];
     __shared__ float sc_s[SMALL_MAXC], sh_s[SMALL_MAXC], b_s[SMALL_MAXC];
     const int T = g.KH * g.KW;
     for (int i = threadIdx.x; i < T * g.Cs * g.Cn; i += 256) w_s[i] = wT[i];
@@ -44,6 +45,9 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const 
     const bool affine = scale != nullptr;
     const int Hu = g.Hs * g.up, Wu = g.Ws * g.up, ush = g.up - 1;
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
+    double s1[SMALL_MAXC], s2[SMALL_MAXC];
+#pragma unroll
+    for (int j = 0; j < SMALL_MAXC; ++j) s1[j] = s2[j] = 0.0;
     for (unsigned m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
         const int ox = m % g.Wo;
         const unsigned t0 = m / g.Wo;
@@ -72,14 +76,38 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const 
         const float* rp = res ? res + (size_t)m * g.Cn : nullptr;
 #pragma unroll
         for (int j = 0; j < SMALL_MAXC; ++j)
-            if (j < g.Cn) yp[j] = acc[j] + (rp ? rp[j] : 0.f);
+            if (j < g.Cn) {
+                const float v = acc[j] + (rp ? rp[j] : 0.f);
+                yp[j] = v;
+                if (partial) {
+                    s1[j] += (double)v;
+                    s2[j] += (double)v * (double)v;
+                }
+            }
+    }
+    if (partial) {  // per-channel sums of the output = the next layer's BatchNorm statistics
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < SMALL_MAXC; ++j) {
+            const double a = wave_sum(s1[j]), b = wave_sum(s2[j]);
+            if (lane == 0) {
+                redf[wave][0][j] = a;
+                redf[wave][1][j] = b;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * SMALL_MAXC) {
+            const int which = threadIdx.x / SMALL_MAXC, c = threadIdx.x % SMALL_MAXC;
+            partial[((size_t)blockIdx.x * 2 + which) * CnPad + c] =
+                (redf[0][which][c] + redf[1][which][c]) + (redf[2][which][c] + redf[3][which][c]);
+        }
     }
 }
 
-int conv_small_fwd(const SmallGeom& g, const float* x, const float* scale, const float* shift, int relu, const float* wT,
-                   const float* bias, const float* res, float* y, hipStream_t st) {
-    const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
-    conv_small_fwd_kernel<<<imin(cdiv(M, 256), 4096), 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y);
+int conv_small_fwd(const SmallGeom& g, int nblocks, const float* x, const float* scale, const float* shift, int relu,
+                   const float* wT, const float* bias, const float* res, float* y, double* partial, int CnPad,
+                   hipStream_t st) {
+    conv_small_fwd_kernel<<<nblocks, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y, partial, CnPad);
     return 0;
 }
 

@@ -95,13 +95,20 @@ class BNBranch:
 @torch.no_grad()
 def bn_batch_stats(x: Tensor, branches: Sequence[BNBranch], update_running: bool = True):
     """Training-mode statistics of x (NHWC) shared by all ``branches``: returns mean, invstd and one
-    (scale, shift) pair per branch; updates the running buffers like nn.BatchNorm2d (networks/cnn.py:122)."""
+    (scale, shift) pair per branch; updates the running buffers like nn.BatchNorm2d (networks/cnn.py:122).
+    If x was produced by one of our conv kernels, its per-channel partial sums were already written by that kernel's
+    epilogue (``x._otvae_stats``) and no pass over x is needed."""
     lib = _lib.load()
     n, c, h, w = x.shape
     m = n * h * w
-    p = lib.otvae_bn_stats_nparts(m, c)
-    partial = torch.empty((p, 2, c), device=x.device, dtype=torch.float64)
-    check(lib.otvae_bn_stats(ptr(x), m, c, ptr(partial), stream()), "otvae_bn_stats")
+    pre = getattr(x, "_otvae_stats", None)
+    if pre is not None:
+        partial, p, ld = pre
+    else:
+        p = lib.otvae_bn_stats_nparts(m, c)
+        ld = c
+        partial = torch.empty((p, 2, c), device=x.device, dtype=torch.float64)
+        check(lib.otvae_bn_stats(ptr(x), m, c, ptr(partial), stream()), "otvae_bn_stats")
     mean = torch.empty(c, device=x.device, dtype=torch.float32)
     invstd = torch.empty_like(mean)
     scales = [torch.empty_like(mean) for _ in branches]
@@ -109,7 +116,7 @@ def bn_batch_stats(x: Tensor, branches: Sequence[BNBranch], update_running: bool
     nb = len(branches)
     upd = update_running
     check(lib.otvae_bn_finalize(
-        ptr(partial), p, m, c, BN_EPS, BN_MOMENTUM, ptr(mean), ptr(invstd), nb,
+        ptr(partial), p, ld, m, c, BN_EPS, BN_MOMENTUM, ptr(mean), ptr(invstd), nb,
         ptr_array([b.gamma for b in branches]), ptr_array([b.beta for b in branches]),
         ptr_array([b.running_mean if upd else None for b in branches]),
         ptr_array([b.running_var if upd else None for b in branches]),
@@ -130,11 +137,12 @@ def bn_eval_affine(branch: BNBranch):
 # ------------------------------------------------------------------------------------------------ fused ConvLayer(s)
 class ConvSpec:
     """Static description of one ConvLayer branch (everything that is not a tensor)."""
-    __slots__ = ("stride", "pad", "up", "relu", "has_norm", "has_bias", "has_residual")
+    __slots__ = ("stride", "pad", "up", "relu", "has_norm", "has_bias", "has_residual", "out_stats")
 
-    def __init__(self, stride, pad, up, relu, has_norm, has_bias, has_residual=False):
+    def __init__(self, stride, pad, up, relu, has_norm, has_bias, has_residual=False, out_stats=False):
         self.stride, self.pad, self.up, self.relu = stride, pad, up, relu
         self.has_norm, self.has_bias, self.has_residual = has_norm, has_bias, has_residual
+        self.out_stats = out_stats  # also emit per-channel partial sums of the output (next layer's BatchNorm)
 
 
 class _ConvBNFn(torch.autograd.Function):
@@ -143,23 +151,33 @@ class _ConvBNFn(torch.autograd.Function):
     missing ones passed as None."""
 
     @staticmethod
-    def forward(ctx, x, specs, stats, params_ref, *tensors):
+    def forward(ctx, x, specs, stats, params_ref, stats_out, *tensors):
         lib = _lib.load()
         nbr = len(specs)
         ctx.specs, ctx.stats, ctx.params_ref = specs, stats, params_ref
         mean, invstd, scales, shifts, training = stats
         outs = []
         geoms = []
+        ctx.out_stats = []
         for b, sp in enumerate(specs):
             w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
             g, ho, wo = _geom(x, w, sp.stride, sp.pad, sp.up)
             y = empty_nhwc(x.shape[0], w.shape[0], ho, wo, x)
+            part, st = None, None
+            if sp.out_stats:
+                p_s, ld = C.c_int(0), C.c_int(0)
+                check(lib.otvae_conv_fwd_stats_ws(C.byref(g), C.byref(p_s), C.byref(ld)), "otvae_conv_fwd_stats_ws")
+                part = torch.empty((p_s.value, 2, ld.value), device=x.device, dtype=torch.float64)
+                st = (part, p_s.value, ld.value)
             check(lib.otvae_conv_fwd(C.byref(g), ptr(x), ptr(scales[b]) if sp.has_norm else None,
                                      ptr(shifts[b]) if sp.has_norm else None, int(sp.relu), ptr(w), ptr(bias), ptr(res),
-                                     ptr(y), stream()), "otvae_conv_fwd")
+                                     ptr(y), ptr(part), stream()), "otvae_conv_fwd")
             outs.append(y)
             geoms.append(g)
+            ctx.out_stats.append(st)
         ctx.geoms = geoms
+        stats_out.extend(ctx.out_stats)
+        ctx.out_stats = None
         ctx.save_for_backward(x, *tensors)
         return outs[0] if nbr == 1 else tuple(outs)
 
@@ -247,7 +265,7 @@ class _ConvBNFn(torch.autograd.Function):
             for b, sp in enumerate(specs):
                 if not sp.has_norm:
                     dx = per_branch[b][2] if dx is None else dx + per_branch[b][2]
-        out: List[Optional[Tensor]] = [dx if need_dx else None, None, None, None]
+        out: List[Optional[Tensor]] = [dx if need_dx else None, None, None, None, None]
         for b in range(nbr):
             gw, gb, gv, part, gres = per_branch[b]
             out += [gw, gb, dgam[b], dbet[b], gres]
@@ -267,7 +285,7 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
         w = br["weight"]
         has_norm = br.get("gamma") is not None
         sp = ConvSpec(br["stride"], br["pad"], br["up"], bool(br["relu"]), has_norm, br.get("bias") is not None,
-                      br.get("residual") is not None)
+                      br.get("residual") is not None, bool(br.get("out_stats", False)) and training)
         specs.append(sp)
         wt = w if is_hwio(w) else hwio_weight(w)
         res = br.get("residual")
@@ -296,8 +314,13 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
                 j = next(it)
                 scales[i], shifts[i] = sc[j], sh[j]
     stats = (mean, invstd, scales, shifts, training)
-    out = _ConvBNFn.apply(x, tuple(specs), stats, tuple(params_ref), *tensors)
-    return out if isinstance(out, tuple) else (out,)
+    stats_out: List[Optional[tuple]] = []
+    out = _ConvBNFn.apply(x, tuple(specs), stats, tuple(params_ref), stats_out, *tensors)
+    out = out if isinstance(out, tuple) else (out,)
+    for y, st in zip(out, stats_out):
+        if st is not None:
+            y._otvae_stats = st  # consumed by bn_batch_stats of the next layer (same tensor object, unmodified)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ attention

@@ -116,7 +116,7 @@ class ConvLayer(nn.Module):
     def _has_norm(self) -> bool:
         return isinstance(self._normalization, nn.BatchNorm2d)
 
-    def branch(self, residual: Optional[Tensor] = None) -> dict:
+    def branch(self, residual: Optional[Tensor] = None, out_stats: bool = True) -> dict:
         bn = self._normalization if self._has_norm else None
         return dict(weight=self.weight, bias=self.bias,
                     gamma=bn.weight if bn is not None else None, beta=bn.bias if bn is not None else None,
@@ -124,12 +124,15 @@ class ConvLayer(nn.Module):
                     running_var=bn.running_var if bn is not None else None,
                     num_batches_tracked=bn.num_batches_tracked if bn is not None else None,
                     residual=residual, stride=self.stride[0], pad=self.padding[0], up=self._up,
-                    relu=isinstance(self._activation, nn.ReLU))
+                    relu=isinstance(self._activation, nn.ReLU), out_stats=out_stats)
 
-    def forward(self, x: Tensor, embed: Optional[Tensor] = None, *, residual: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Tensor, embed: Optional[Tensor] = None, *, residual: Optional[Tensor] = None,
+                out_stats: bool = True) -> Tensor:
+        """``out_stats``: let the kernel's epilogue also emit the per-channel sums of its output, which the next layer's
+        BatchNorm picks up instead of re-reading the tensor (wasted only if the consumer has no BatchNorm)."""
         if embed is not None and self.enable_warnings:
             warnings.warn("given conditional argument `embed` but the layer has no embedding projection")
-        return HF.conv_layers(x, [self.branch(residual)], training=self.training)[0]
+        return HF.conv_layers(x, [self.branch(residual, out_stats)], training=self.training)[0]
 
     def extra_repr(self) -> str:
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
@@ -164,7 +167,7 @@ class AttentionBlock(nn.Module):
         self.proj_out = Conv1x1(channels, channels, equalized_lr=equalized_lr, groups=groups)
 
     def forward(self, x: Tensor, embed: Optional[Tensor] = None, *, residual: Optional[Tensor] = None) -> Tensor:
-        qkv = self.qkv(x)                                   # [N, 3*C, H, W] channels-last
+        qkv = self.qkv(x, out_stats=False)                  # [N, 3*C, H, W] channels-last; feeds attention, no BN
         h = HF.qkv_attention(qkv, self.attention.n_heads)   # [N, C, H, W]
         return self.proj_out(h, residual=residual)
 
@@ -200,7 +203,8 @@ class ConvBlock(nn.Module):
         sk = None
         if self.skip is not None:
             # block[0] and skip normalise the same tensor: one statistics pass, one fused backward
-            out, sk = HF.conv_layers(x, [first.branch(), self.skip.branch()], training=self.training)
+            # (the skip output is only ever added to the block output: nobody normalises it -> no statistics)
+            out, sk = HF.conv_layers(x, [first.branch(), self.skip.branch(out_stats=False)], training=self.training)
         else:
             out = first(x)
         fuse_add = self.residual == "add" and len(layers) > 1

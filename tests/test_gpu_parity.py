@@ -205,20 +205,27 @@ def test_nelbo_and_adam_vs_reference_golden(A, residual):
             names.append(pre + k)
             params.append(p)
     assert names == [str(s) for s in g["param_names"]]
-    # tolerance: 3e-4, or twice the reference's own fp32-vs-fp64 discrepancy on the same quantity when that is larger
-    # (gradients through BatchNorm over 6 samples at 1x1 resolution are badly conditioned; without skip connections
-    # the reference's fp32 gradient norms are only good to ~2e-3)
-    def ref_noise(a32, a64):
-        return 2.0 * (a32.double() - a64.double()).abs().max().item() / max(a64.double().abs().max().item(), 1e-30)
+    # Gradients through BatchNorm over 6 samples at 1x1 resolution are badly conditioned: the reference's own fp32 result
+    # differs from the same computation in fp64 (recorded in the golden file) by up to 2.4e-3 without skip connections.
+    # A port is held to the reference's accuracy: within max(3e-4, 2 x |ref32 - ref64|) of the fp32 OR of the fp64
+    # reference value (both errors are written to the report).
+    def check_grad(name, got, ref32, ref64, floor=0.0):
+        denom = max(ref64.double().abs().max().item(), floor, 1e-30)
+        noise = (ref32.double() - ref64.double()).abs().max().item() / denom
+        tol = max(3e-4, 2.0 * noise)
+        e32 = (got.detach().double().cpu() - ref32.double()).abs().max().item() / denom
+        e64 = (got.detach().double().cpu() - ref64.double()).abs().max().item() / denom
+        ok = min(e32, e64) < tol
+        rep.rows.append((f"{name} [vs fp32 ref {e32:.2e} | vs fp64 ref {e64:.2e} | ref noise {noise:.2e}]", min(e32, e64), tol, ok))
+        if not ok:
+            rep.failed.append((name, min(e32, e64), tol))
 
     gl2 = torch.tensor([p.grad.double().norm().item() for p in params])
-    tol_l2 = max(3e-4, ref_noise(g["grad_l2"], g["grad_l2_f64"]))
-    rep.check("grad_l2 (all parameters)", gl2, g["grad_l2"], tol=tol_l2)
+    check_grad("grad_l2 (all parameters)", gl2, g["grad_l2"], g["grad_l2_f64"])
     gmax = max(v.abs().max().item() for k, v in g.items() if k.startswith("grad_full/"))
     for k, v in g.items():
         if k.startswith("grad_full/"):
-            tol = max(3e-4, ref_noise(v, g["grad_full_f64/" + k[10:]]))
-            rep.check(k, params[names.index(k[10:])].grad, v, tol=tol, floor=1e-3 * gmax)
+            check_grad(k, params[names.index(k[10:])].grad, v, g["grad_full_f64/" + k[10:]], floor=1e-3 * gmax)
     # Adam's first step moves every weight by lr*g/(|g|+1e-8): for parameters whose exact gradient is zero (biases in
     # front of a BatchNorm) that is a function of rounding noise, in the reference too -> compare the others
     pl2 = torch.tensor([p.double().norm().item() for p in params])
