@@ -46,7 +46,9 @@ class VAE(VisionModule):
         self._expand = functools.partial(utils.replicate_batch, n=expansion)
         self._reduce_mean = functools.partial(utils.mean_replicated_batch, n=expansion)
         self._reduce_std = functools.partial(utils.std_replicated_batch, n=expansion)
-        self._filter = lambda callee: FilterKwargs(callee, arg_keys=["labels", "eps"])
+        # forward a keyword only to the plug-ins whose signature declares it (reference: FilterKwargs on 'labels',
+        # model/vae.py:50-51,209; generalised to every keyword so that priors can take e.g. `eps` / `prior_samples`)
+        self._filter = lambda callee, keys=("labels", "eps"): FilterKwargs(callee, arg_keys=list(keys))
 
     # -- reference API -------------------------------------------------------------------------------------------
     def batch_preprocess(self, batch) -> Batch:
@@ -84,7 +86,7 @@ class VAE(VisionModule):
         samples, target, kwargs = batch["samples"], batch["target"], batch["kwargs"]
         batch_size = samples.size(0)
         latents, prior_loss, prior_artifacts = self.encode(samples, expand=True, return_prior_artifacts=True, **kwargs)
-        reconstructions = self.decode(latents, expand_kwargs=True, **{k: v for k, v in kwargs.items() if k != "eps"})
+        reconstructions = self.decode(latents, expand_kwargs=True, **kwargs)
         reconstructions_mean = self._reduce_mean(reconstructions)
         out3 = HF.nelbo_loss(reconstructions_mean, target, prior_loss)   # [total, recon, prior/(C*H*W)]
         self._last_out3 = out3.detach()
@@ -101,15 +103,14 @@ class VAE(VisionModule):
 
     @VisionModule.preprocess
     def encode(self, samples: Tensor, return_prior_artifacts: bool = False, expand: bool = False, **kwargs):
-        enc_kwargs = {k: v for k, v in kwargs.items() if k != "eps"}
-        with self._filter(self._encode_func) as encode:
-            encodings = encode(samples, **enc_kwargs)
+        with self._filter(self._encode_func, kwargs.keys()) as encode:
+            encodings = encode(samples, **kwargs)
         if expand:
             encodings, kwargs = self._expand(encodings), self._expand(kwargs)
         if self.prior is None:
             results = encodings, torch.zeros(encodings.size(0), device=encodings.device, dtype=encodings.dtype), {}
         else:
-            with self._filter(self.prior) as prior:
+            with self._filter(self.prior, kwargs.keys()) as prior:
                 results = prior(encodings, **kwargs, step=self.global_step)
         return results if return_prior_artifacts else results[0]
 
@@ -117,13 +118,13 @@ class VAE(VisionModule):
     def decode(self, latents: Tensor, expand_kwargs: bool = False, **kwargs) -> Tensor:
         if expand_kwargs:
             kwargs = self._expand(kwargs)
-        with self._filter(self._decode_func) as decode:
+        with self._filter(self._decode_func, kwargs.keys()) as decode:
             return decode(latents, **kwargs)
 
     @VisionModule.postprocess
     def sample(self, batch_size: int, **kwargs) -> Tensor:
         if self.prior is not None:
-            with self._filter(self.prior.sample) as sample:
+            with self._filter(self.prior.sample, kwargs.keys()) as sample:
                 latents = sample((batch_size, *self.latent_size), device=self.device, **kwargs)
         else:
             latents = torch.randn((batch_size, *self.latent_size), device=self.device)

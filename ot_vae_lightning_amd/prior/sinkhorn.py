@@ -51,6 +51,9 @@ class SinkhornPrior(Prior):
     def sample(self, shape, device) -> Tensor:
         return torch.randn(*shape, device=device)
 
+    def forward(self, x: Tensor, step: int, prior_samples: Optional[Tensor] = None) -> Prior.EncodingResults:
+        return super().forward(x, step, prior_samples=prior_samples)
+
     def encode(self, x: Tensor, prior_samples: Optional[Tensor] = None) -> Prior.EncodingResults:
         z = x
         zf = z.flatten(1)

@@ -1,0 +1,208 @@
+"""GPU parity for the remaining BASELINE configurations and API surface (run with ``-m gpu``):
+  * configs[0] (README shape: residual=None, batch 250) and configs[3] (CIFAR-10 3x32x32, capacity 16, latent 256):
+    one training step vs the CPU oracle on identical weights / batch / eps;
+  * configs[2]: the minibatch Sinkhorn OT prior (eps 0.05, 50 iterations) inside VAE.nelbo, loss and gradients;
+  * inference mode (BatchNorm running statistics), ``VAE.forward/encode/decode/sample`` shapes as asserted by the
+    reference's tests/test_mnist_cnn_vae.py:217-226, ``AutoEncoder``, ``load_state_dict`` round trip;
+  * error behaviour the reference's validators have (ValueError on bad shapes, NotImplementedError on options outside
+    the hot path).
+"""
+import os
+
+import pytest
+import torch
+
+import otvae_oracle as O
+from conftest import rel_err
+from detfill import mnist_like, normal
+from test_gpu_parity import Report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    assert torch.cuda.is_available()
+    import ot_vae_lightning_amd as pkg
+    return pkg
+
+
+def _oracle_step(model, enc_kw, dec_kw, x, eps, loss_coeff):
+    ea, da = O.cnn_arch(**enc_kw), O.cnn_arch(**dec_kw)
+    pe = {k: v.detach().cpu().clone().contiguous() for k, v in model.encoder.state_dict().items()}
+    pd = {k: v.detach().cpu().clone().contiguous() for k, v in model.decoder.state_dict().items()}
+    leaves = [v.requires_grad_(True) for d in (pe, pd) for k, v in d.items() if v.is_floating_point() and "running" not in k]
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    r = O.vae_nelbo(x, eps, pe, pd, ea, da, loss_coeff=loss_coeff)
+    r["loss"].backward()
+    return r, leaves, pe, pd
+
+
+@pytest.mark.parametrize("cfg", ["readme_mnist_b250", "cifar_b32"])
+def test_training_step_other_configs_vs_oracle(A, cfg):
+    rep = Report(f"training step {cfg} vs CPU oracle")
+    torch.manual_seed(1)
+    if cfg == "readme_mnist_b250":
+        B, cin, lat, cap, res = 250, 1, 128, 8, None
+        x = mnist_like(B, 21)
+    else:
+        B, cin, lat, cap, res = 32, 3, 256, 16, "add"
+        x = normal((B, 3, 32, 32), 22)
+    enc_kw = dict(in_features=cin, out_features=2 * lat, in_resolution=32, out_resolution=1, capacity=cap,
+                  down_sample=True, residual=res)
+    dec_kw = dict(in_features=lat, out_features=cin, in_resolution=1, out_resolution=32, capacity=cap, up_sample=True,
+                  residual=res)
+    enc = A.CNN(cin, 2 * lat, 32, 1, capacity=cap, down_sample=True, residual=res)
+    dec = A.CNN(lat, cin, 1, 32, capacity=cap, up_sample=True, residual=res)
+    model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1))
+    eps = normal((B, lat, 1, 1), 23)
+    r, leaves, pe, pd = _oracle_step(model, enc_kw, dec_kw, x, eps, 0.1)
+    model = model.cuda().train()
+    tr = A.HipTrainer(model, batch_shape=tuple(x.shape), use_graph=False)
+    out = tr.step(x.cuda(), eps.cuda())
+    rep.check("loss[total,recon,prior]", out, torch.stack([r["loss"], r["recon"], r["prior"]]).detach())
+    params = [p for net in (model.encoder, model.decoder) for p in net.parameters()]
+    gl2 = torch.tensor([p.grad.double().norm().item() for p in params])
+    rep.check("grad_l2 (all parameters)", gl2, torch.tensor([v.grad.double().norm().item() for v in leaves]), tol=5e-4)
+    # BatchNorm running statistics after the step
+    rs_gpu = torch.tensor([b.double().sum().item() for net in (model.encoder, model.decoder)
+                           for k, b in net.named_buffers() if "running_" in k])
+    rs_cpu = torch.tensor([v.double().sum().item() for d in (pe, pd) for k, v in d.items() if "running_" in k])
+    rep.check("BatchNorm running statistics", rs_gpu, rs_cpu)
+    with torch.no_grad():
+        loss, logs, art = model.nelbo({"samples": x.cuda(), "target": x.cuda(), "kwargs": {"eps": eps.cuda()}}, 0)
+    assert art["preds"].shape == x.shape and art["latents"].shape == (B, lat, 1, 1)
+    rep.finish()
+
+
+def test_sinkhorn_prior_in_vae_step_vs_oracle(A):
+    """configs[2]: deterministic encoder + entropic OT (eps 0.05, 50 iterations) between latents and N(0, I) draws."""
+    rep = Report("VAE + SinkhornPrior (eps=0.05, 50 it) vs CPU oracle")
+    B = 128
+    torch.manual_seed(3)
+    enc = A.CNN(1, 128, 32, 1, capacity=8, down_sample=True, residual="add")
+    dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    prior = A.SinkhornPrior(reg=0.05, max_iter=50, threshold=0.0, loss_coeff=1.0)
+    model = A.VAE(encoder=enc, decoder=dec, prior=prior)
+    x, ps = mnist_like(B, 31), normal((B, 128), 32)
+    # oracle
+    ea = O.cnn_arch(1, 128, 32, 1, capacity=8, down_sample=True, residual="add")
+    da = O.cnn_arch(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    pe = {k: v.detach().clone().contiguous() for k, v in model.encoder.state_dict().items()}
+    pd = {k: v.detach().clone().contiguous() for k, v in model.decoder.state_dict().items()}
+    leaves = [v.requires_grad_(True) for d in (pe, pd) for k, v in d.items() if v.is_floating_point() and "running" not in k]
+    h = O.cnn_forward(x, pe, ea)
+    z = h
+    ot = O.sinkhorn_ot_loss(z.flatten(1), ps, reg=0.05, max_iter=50, threshold=0.0)
+    preds = O.cnn_forward(z, pd, da)
+    recon = torch.nn.functional.mse_loss(preds, x)
+    # envelope gradient: the plan is treated as a constant (SinkhornPrior's documented semantics)
+    C = O.sq_euclidean_cost(z.flatten(1), ps)
+    with torch.no_grad():
+        a = torch.full((B,), 1.0 / B)
+        pi = O.sinkhorn_log(a, a, C / C.max(), reg=0.05, max_iter=50, threshold=0.0)
+    loss = recon + (C * pi).sum() / x[0].numel()
+    loss.backward()
+    # product
+    model = model.cuda().train()
+    lossg, logs, art = model.nelbo({"samples": x.cuda(), "target": x.cuda(), "kwargs": {"prior_samples": ps.cuda()}}, 0)
+    lossg.backward()
+    rep.check("OT cost", logs["train/loss/prior"] * x[0].numel(), ot.detach())
+    rep.check("total loss", lossg, loss.detach())
+    params = [p for net in (model.encoder, model.decoder) for p in net.parameters()]
+    rep.check("grad_l2 (all parameters)", torch.tensor([p.grad.double().norm().item() for p in params]),
+              torch.tensor([v.grad.double().norm().item() for v in leaves]), tol=5e-4)
+    rep.finish()
+
+
+def test_inference_mode_and_api_shapes(A):
+    """Shapes asserted by the reference's inference test (tests/test_mnist_cnn_vae.py:217-226) + eval-mode parity."""
+    rep = Report("inference (BatchNorm running statistics) vs CPU oracle; API shapes")
+    torch.manual_seed(5)
+    enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+    dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1))
+    assert model.latent_size == torch.Size((128, 1, 1))
+    # give the running statistics non-trivial values
+    with torch.no_grad():
+        for k, b in model.state_dict().items():
+            if k.endswith("running_mean"):
+                b.copy_(0.1 * torch.sin(torch.arange(b.numel(), dtype=torch.float32)))
+            if k.endswith("running_var"):
+                b.copy_(1.0 + 0.3 * torch.cos(torch.arange(b.numel(), dtype=torch.float32)))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = mnist_like(10, 41)
+    ea = O.cnn_arch(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+    da = O.cnn_arch(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    pe = {k[len("encoder."):]: v.contiguous() for k, v in sd.items() if k.startswith("encoder.")}
+    pd = {k[len("decoder."):]: v.contiguous() for k, v in sd.items() if k.startswith("decoder.")}
+    with torch.no_grad():
+        h = O.cnn_forward(x, pe, ea, training=False)
+        rec = O.cnn_forward(h[:, :128], pd, da, training=False)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        hg = model.encoder(x.cuda())
+        recg = model.decoder(hg[:, :128].contiguous())
+        rep.check("encoder output (eval)", hg, h)
+        rep.check("decoder output (eval)", recg, rec)
+        lat = model.encode(x.cuda())
+        assert lat.shape == (10, 128, 1, 1)
+        assert model.decode(lat).shape == (10, 1, 32, 32)
+        assert model(x.cuda()).shape == (10, 1, 32, 32)
+        assert model.sample(5).shape == (5, 1, 32, 32)
+    for k, b in model.state_dict().items():  # eval mode must not touch the running statistics
+        if "running_" in k or "num_batches" in k:
+            assert torch.equal(b.cpu(), sd[k]), k
+    # state_dict round trip into a fresh model (values land on HWIO memory)
+    torch.manual_seed(6)
+    m2 = A.VAE(encoder=A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add"),
+               decoder=A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add"),
+               prior=A.GaussianPrior(loss_coeff=0.1))
+    m2.load_state_dict(model.state_dict())
+    m2 = m2.cuda().eval()
+    with torch.no_grad():
+        rep.check("load_state_dict round trip", m2.encoder(x.cuda()), hg, tol=1e-7)
+    # eval-mode backward (fixed affine BatchNorm) vs oracle
+    xg = x.cuda().requires_grad_(True)
+    hg2 = model.encoder(xg)
+    hg2.sum().backward()
+    xc = x.clone().requires_grad_(True)
+    pe2 = {k: v.clone() for k, v in pe.items()}
+    O.cnn_forward(xc, pe2, ea, training=False).sum().backward()
+    rep.check("d encoder / d input (eval)", xg.grad, xc.grad, tol=3e-4)
+    rep.finish()
+
+
+def test_autoencoder_plugin(A):
+    ae = A.AutoEncoder(1, 8, 16, 1, capacity=2, double_encoded_features=True, residual="add", down_up_sample=True)
+    assert ae.latent_size == torch.Size((16, 1, 1))
+    model = A.VAE(autoencoder=ae, prior=A.GaussianPrior(loss_coeff=0.5)).cuda().train()
+    x = normal((4, 1, 16, 16), 9).cuda()
+    loss, logs, art = model.nelbo({"samples": x, "target": x, "kwargs": {}}, 0)
+    loss.backward()
+    assert art["preds"].shape == x.shape and art["latents"].shape == (4, 8, 1, 1)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in ae.parameters())
+    assert set(logs) == {"train/loss/total", "train/loss/recon", "train/loss/prior"}
+
+
+def test_error_behaviour(A):
+    with pytest.raises(NotImplementedError):
+        A.ConvLayer(4, 4, normalization="groupnorm")
+    with pytest.raises(NotImplementedError):
+        A.ConvLayer(4, 4, activation="gelu")
+    with pytest.raises(NotImplementedError):
+        A.ConvLayer(4, 4, normalization="whatever")
+    with pytest.raises(ValueError):
+        A.CNN(1, 8, 32, 32, down_sample=True)          # in_resolution <= out_resolution
+    with pytest.raises(ValueError):
+        A.CNN(1, 8, up_sample=True, down_sample=True, in_resolution=4, out_resolution=8)
+    with pytest.raises(ValueError):
+        A.AttentionBlock(6, heads=4)
+    with pytest.raises(ValueError):
+        A.VAE(prior=None)
+    a = torch.ones(4, device="cuda") / 4
+    with pytest.raises(ValueError):
+        A.sinkhorn_log(a, a, torch.rand(3, 4, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        A.w2_gaussian(torch.zeros(200, device="cuda"), torch.zeros(200, device="cuda"),
+                      torch.eye(200, device="cuda"), torch.eye(200, device="cuda"))   # D > 128 this round
