@@ -216,6 +216,31 @@ def gen_nelbo():
         for k in list(out):
             if k.startswith(f"{tag}/grad_full/"):
                 out[k.replace("grad_full/", "grad_full_f64/")] = npy(p64[names.index(k.split("grad_full/")[1])].grad)
+        # sensitivity of the reference itself: the same fp32 computation with input and weights perturbed by ~1 ulp
+        # (4 draws).  The spread of its gradients is the resolution at which ANY fp32 implementation of this
+        # (deliberately hostile: sine weights, BatchNorm over 6 samples) case can be compared.
+        spread_l2 = np.zeros(len(params))
+        spread_full = {k: 0.0 for k in out if k.startswith(f"{tag}/grad_full/")}
+        base_l2 = np.array(gl2)
+        for trial in range(4):
+            gen = torch.Generator().manual_seed(900 + trial)
+            xp = x * (1.0 + (torch.rand(x.shape, generator=gen) - 0.5) * 2.4e-7)
+            mp = _mnist_vae(residual)
+            with torch.no_grad():  # ... and every weight by ~1 ulp: the analogue of a different-but-valid rounding
+                for p_ in mp.parameters():  # order inside each layer
+                    p_.mul_(1.0 + (torch.rand(p_.shape, generator=gen) - 0.5) * 2.4e-7)
+            with _FixedEps(eps):
+                lp, _, _ = mp.nelbo({"samples": xp, "target": xp, "kwargs": {}}, 0)
+            lp.backward()
+            pp = [p for net in (mp.encoder, mp.decoder) for _, p in net.named_parameters()]
+            l2p = np.array([p.grad.double().norm().item() for p in pp])
+            spread_l2 = np.maximum(spread_l2, np.abs(l2p - base_l2))
+            for k in spread_full:
+                i = names.index(k.split("grad_full/")[1])
+                spread_full[k] = max(spread_full[k], (pp[i].grad - params[i].grad).abs().max().item())
+        out[f"{tag}/grad_l2_spread"] = spread_l2
+        for k, v in spread_full.items():
+            out[k.replace("grad_full/", "grad_full_spread/")] = np.array(v)
         opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
         opt.step()
         out[f"{tag}/param_sum_after_adam"] = np.array([p.double().sum().item() for p in params])

@@ -205,29 +205,29 @@ def test_nelbo_and_adam_vs_reference_golden(A, residual):
             names.append(pre + k)
             params.append(p)
     assert names == [str(s) for s in g["param_names"]]
-    # Gradients through BatchNorm over 6 samples at 1x1 resolution are badly conditioned: the reference's own fp32 result
-    # differs from the same computation in fp64 (recorded in the golden file) by up to 2.4e-3 without skip connections.
-    # A port is held to the reference's accuracy class: within max(3e-4, 5 x |ref32 - ref64|) of the fp32 OR of the fp64
-    # reference value (both errors are written to the report; tools/diag_nelbo.py prints the per-parameter picture:
-    # 1e-6 forward rounding differences are amplified ~1000x by this deliberately hostile case -- closed-form sine
-    # weights, |dL/dW| up to 9e3 -- while the well-conditioned batch-256 default-init step below holds 3e-4).
-    def check_grad(name, got, ref32, ref64, floor=0.0):
-        denom = max(ref64.double().abs().max().item(), floor, 1e-30)
+    # Gradients through BatchNorm over 6 samples at 1x1 resolution with closed-form sine weights (|dL/dW| up to 9e3) are
+    # a deliberately hostile, badly conditioned case.  The golden file records how much the REFERENCE's own fp32 gradients
+    # move (a) when the same computation runs in fp64 and (b) when the input is perturbed by one ulp (4 draws); a port is
+    # held to that resolution: |ours - ref32| <= max(3e-4 * scale, 5 * fp64 discrepancy, 3 * one-ulp spread).
+    # (tools/diag_nelbo.py prints the per-parameter picture; the well-conditioned batch-256 step below holds 3e-4.)
+    def check_grad(name, got, ref32, ref64, spread, floor=0.0):
+        denom = max(ref32.double().abs().max().item(), floor, 1e-30)
         noise = (ref32.double() - ref64.double()).abs().max().item() / denom
-        tol = max(3e-4, 5.0 * noise)
+        spr = float(torch.as_tensor(spread).double().abs().max().item()) / denom
+        tol = max(3e-4, 5.0 * noise, 3.0 * spr)
         e32 = (got.detach().double().cpu() - ref32.double()).abs().max().item() / denom
-        e64 = (got.detach().double().cpu() - ref64.double()).abs().max().item() / denom
-        ok = min(e32, e64) < tol
-        rep.rows.append((f"{name} [vs fp32 ref {e32:.2e} | vs fp64 ref {e64:.2e} | ref noise {noise:.2e}]", min(e32, e64), tol, ok))
+        ok = e32 < tol
+        rep.rows.append((f"{name} [fp64 discrepancy {noise:.2e} | 1-ulp spread {spr:.2e}]", e32, tol, ok))
         if not ok:
-            rep.failed.append((name, min(e32, e64), tol))
+            rep.failed.append((name, e32, tol))
 
     gl2 = torch.tensor([p.grad.double().norm().item() for p in params])
-    check_grad("grad_l2 (all parameters)", gl2, g["grad_l2"], g["grad_l2_f64"])
+    check_grad("grad_l2 (all parameters)", gl2, g["grad_l2"], g["grad_l2_f64"], g["grad_l2_spread"])
     gmax = max(v.abs().max().item() for k, v in g.items() if k.startswith("grad_full/"))
     for k, v in g.items():
         if k.startswith("grad_full/"):
-            check_grad(k, params[names.index(k[10:])].grad, v, g["grad_full_f64/" + k[10:]], floor=1e-3 * gmax)
+            check_grad(k, params[names.index(k[10:])].grad, v, g["grad_full_f64/" + k[10:]],
+                       g["grad_full_spread/" + k[10:]], floor=1e-3 * gmax)
     # Adam's first step moves every weight by lr*g/(|g|+1e-8): for parameters whose exact gradient is zero (biases in
     # front of a BatchNorm) that is a function of rounding noise, in the reference too -> compare the others
     pl2 = torch.tensor([p.double().norm().item() for p in params])
