@@ -13,6 +13,9 @@
 //   * for C == 1 the row maximum is closed-form (q * max_s k or q * min_s k), so the forward needs a single pass.
 #include "common.h"
 
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
 #define ATTN_LDS_FLOATS 16384  // 64 KiB dynamic LDS budget (the default limit: no function attribute needed)
 
 template <int C>
@@ -63,7 +66,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const long gs = slice0 + sl;
     const long n = gs / H;
     const int h = (int)(gs - n * H);
-    const float inv_c = 1.f / (float)C;
+    // scores are kept in the log2 domain (q pre-multiplied by log2(e)/C) so that exp is a bare v_exp_f32
+    const float inv_c = LOG2E / (float)C;
     const float* kv = sm + (size_t)sl * T * Rec<C>::KV;
 
     float q[QPT][C], acc[QPT][C], mx[QPT], l[QPT];
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             float sc = -mx[i];
 #pragma unroll
             for (int c = 0; c < C; ++c) sc = fmaf(q[i][c], kk[c], sc);
-            const float p = __expf(sc);
+            const float p = EXP2(sc);
             l[i] += p;
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[i][c] = fmaf(p, vv[c], acc[i][c]);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         float* o = out + (n * T + t0 + i) * HC + h * C;
 #pragma unroll
         for (int c = 0; c < C; ++c) o[c] = acc[i][c] * rl;
-        lse[(n * H + h) * T + t0 + i] = mx[i] + __logf(l[i]);
+        lse[(n * H + h) * T + t0 + i] = mx[i] * LN2 + __logf(l[i]);  // natural-log LSE
     }
 }
 
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             r[C + c] = g;
             d = fmaf(g, op[c], d);
         }
-        r[2 * C] = lse_g[(n * H + h) * T + t];
+        r[2 * C] = lse_g[(n * H + h) * T + t] * LOG2E;  // log2-domain LSE
         r[2 * C + 1] = d;
     }
     __syncthreads();
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             const float* r = qg + (size_t)(t0 + i) * RQG;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                q[i][c] = r[c];
+                q[i][c] = r[c] * LOG2E;
                 go[i][c] = r[C + c];
                 dq[i][c] = 0.f;
             }
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                     sc = fmaf(q[i][c], kk[c], sc);
                     dp = fmaf(go[i][c], vv[c], dp);
                 }
-                const float ds = __expf(sc) * dp;
+                const float ds = EXP2(sc) * dp;
 #pragma unroll
                 for (int c = 0; c < C; ++c) dq[i][c] = fmaf(ds, kk[c], dq[i][c]);
             }
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             const float* r = kv + (size_t)(t0 + i) * RKV;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                k[i][c] = r[c];
+                k[i][c] = r[c] * LOG2E;
                 v[i][c] = r[C + c];
                 dk[i][c] = dv[i][c] = 0.f;
             }
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                     sc = fmaf(k[i][c], qq[c], sc);
                     dp = fmaf(v[i][c], gg[c], dp);
                 }
-                const float p = __expf(sc);
+                const float p = EXP2(sc);
                 const float ds = p * dp;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {

@@ -1,0 +1,68 @@
+"""Turns the rocprofv3 outputs merged into gpurun_out/ into the small, tracked summaries under profiles/.
+
+    python tools/summarize_profiles.py <kernel-stats dir> <tag>         # e.g. gpurun_out/prof8 r01_final
+    python tools/summarize_profiles.py --pmc gpurun_out <tag>           # pmc_fetch / pmc_write / pmc_mfma passes
+
+HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
+the bytes of wide coalesced reads, so reads = 2 * FETCH_SIZE KiB; the two counters need separate passes (TCC slots).
+"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_stats(src, tag, steps_in_run=27):
+    f = sorted(glob.glob(os.path.join(src, "*", "*_kernel_stats.csv")))[-1]
+    rows = list(csv.DictReader(open(f)))
+    out = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
+    with open(out, "w") as w:
+        w.write("kernel,calls_per_step,avg_us,ms_per_step,percent\n")
+        tot = sum(int(r["TotalDurationNs"]) for r in rows)
+        for r in rows:
+            w.write('"%s",%.1f,%.2f,%.4f,%.2f\n' % (r["Name"].split("(")[0], int(r["Calls"]) / steps_in_run,
+                                                   float(r["AverageNs"]) / 1e3,
+                                                   int(r["TotalDurationNs"]) / 1e6 / steps_in_run,
+                                                   100.0 * int(r["TotalDurationNs"]) / tot))
+    print("wrote", out, "total kernel ms/step %.3f" % (tot / 1e6 / steps_in_run))
+
+
+def pmc(src, tag):
+    def load(d, counter):
+        f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))[0]
+        a = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        for x in csv.DictReader(open(f)):
+            if x["Counter_Name"] == counter:
+                k = x["Kernel_Name"].split("(")[0]
+                a[k][0] += 1
+                a[k][1] += float(x["Counter_Value"])
+                a[k][2] += (int(x["End_Timestamp"]) - int(x["Start_Timestamp"]))
+        return a
+    F, W = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
+    MF, GA = load("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), load("pmc_mfma", "GRBM_GUI_ACTIVE")
+    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.csv")
+    with open(out, "w") as w:
+        w.write("kernel,launches,FETCH_SIZE_KiB_per_launch,read_MB_per_launch(2x_gfx950_correction),WRITE_SIZE_KiB_per_launch,"
+                "hbm_MB_per_launch,SQ_VALU_MFMA_BUSY_CYCLES_per_launch,GRBM_GUI_ACTIVE_per_launch,"
+                "mfma_busy_frac(=busy/(gui_active/8*1024 SIMDs))\n")
+        for k in sorted(F, key=lambda k: -F[k][1]):
+            n, fs, _ = F[k]
+            ws = W.get(k, [1, 0.0, 0])
+            mf, ga = MF.get(k, [1, 0.0, 0]), GA.get(k, [1, 0.0, 0])
+            fetch = fs / n
+            write = ws[1] / max(ws[0], 1)
+            mfb, gui = mf[1] / max(mf[0], 1), ga[1] / max(ga[0], 1)
+            frac = mfb / (gui / 8 * 1024) if gui else 0.0
+            w.write('"%s",%d,%.1f,%.3f,%.1f,%.3f,%.0f,%.0f,%.4f\n' % (k, n, fetch, 2 * fetch / 1024, write,
+                                                                     (2 * fetch + write) / 1024, mfb, gui, frac))
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--pmc":
+        pmc(sys.argv[2], sys.argv[3])
+    else:
+        kernel_stats(sys.argv[1], sys.argv[2])
