@@ -148,7 +148,11 @@ def time_dominant_kernel(A, trainer, iters=30):
     tokens = n * 1024
     alg_bytes = tokens * 9 * 4
     pair_evals = 2 * n * 1024 * 1024
-    return {"kernel": "attn_bwd_kernel<1> (T=1024,H=1,C=1)", "ms": ms, "alg_bytes": alg_bytes, "pair_evals": pair_evals}
+    # HBM traffic of this launch from the PMC passes (profiles/r01_pmc_per_kernel.csv: FETCH_SIZE 12376 KiB -> x2 gfx950
+    # correction, WRITE_SIZE 12288 KiB, separate --pmc runs as MI355X_MICROARCH.md prescribes) = 36.17 MB: the kernel
+    # moves its algorithmic bytes exactly once; what bounds it is v_exp_f32 / VALU issue, not HBM.
+    return {"kernel": "attn_bwd_kernel<1,4> (T=1024,H=1,C=1)", "ms": ms, "alg_bytes": alg_bytes, "pair_evals": pair_evals,
+            "pmc_traffic_bytes": (2 * 12376.0 + 12288.0) * 1024}
 
 
 def main():
@@ -228,9 +232,11 @@ def main():
                               "alg_tflops": round(ips / world * ALG_FLOP_PER_IMAGE_FWD_BWD / 1e12, 3),
                               "frac_of_fp32_peak": round(ips / world * ALG_FLOP_PER_IMAGE_FWD_BWD / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "avg_launch_ms": round(dom["ms"], 4),
-                         "note": "exp/VALU-bound kernel: %.1f G pair-evaluations/s" % (dom["pair_evals"] / dom["ms"] / 1e6)},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": dom["pmc_traffic_bytes"], "avg_launch_ms": round(dom["ms"], 4),
+                         "note": "dominant kernel of the step is exp/VALU-issue bound, not HBM/MFMA bound: "
+                                 "%.2f T (query,key) pair evaluations/s (each: 1 v_exp_f32 + ~5 VALU); its HBM traffic "
+                                 "equals its algorithmic bytes" % (dom["pair_evals"] / dom["ms"] / 1e9)},
         }
         if world == 1:
             try:

@@ -219,6 +219,9 @@ def gen_nelbo():
         # sensitivity of the reference itself: the same fp32 computation with input and weights perturbed by ~1 ulp
         # (4 draws).  The spread of its gradients is the resolution at which ANY fp32 implementation of this
         # (deliberately hostile: sine weights, BatchNorm over 6 samples) case can be compared.
+        spread_fwd = {"loss": 0.0, "preds": 0.0, "latents": 0.0}
+        base_fwd = {"loss": torch.tensor(out[f"{tag}/loss"]), "preds": torch.tensor(out[f"{tag}/preds"]),
+                    "latents": torch.tensor(out[f"{tag}/latents"])}
         spread_l2 = np.zeros(len(params))
         spread_full = {k: 0.0 for k in out if k.startswith(f"{tag}/grad_full/")}
         base_l2 = np.array(gl2)
@@ -230,14 +233,20 @@ def gen_nelbo():
                 for p_ in mp.parameters():  # order inside each layer
                     p_.mul_(1.0 + (torch.rand(p_.shape, generator=gen) - 0.5) * 2.4e-7)
             with _FixedEps(eps):
-                lp, _, _ = mp.nelbo({"samples": xp, "target": xp, "kwargs": {}}, 0)
+                lp, logp, artp = mp.nelbo({"samples": xp, "target": xp, "kwargs": {}}, 0)
             lp.backward()
+            cur = {"loss": torch.stack([logp["train/loss/total"], logp["train/loss/recon"], logp["train/loss/prior"]]).detach(),
+                   "preds": artp["preds"][:2].detach(), "latents": artp["latents"].detach()}
+            for kf in spread_fwd:
+                spread_fwd[kf] = max(spread_fwd[kf], (cur[kf] - base_fwd[kf]).abs().max().item())
             pp = [p for net in (mp.encoder, mp.decoder) for _, p in net.named_parameters()]
             l2p = np.array([p.grad.double().norm().item() for p in pp])
             spread_l2 = np.maximum(spread_l2, np.abs(l2p - base_l2))
             for k in spread_full:
                 i = names.index(k.split("grad_full/")[1])
                 spread_full[k] = max(spread_full[k], (pp[i].grad - params[i].grad).abs().max().item())
+        for kf, vf in spread_fwd.items():
+            out[f"{tag}/{kf}_spread"] = np.array(vf)
         out[f"{tag}/grad_l2_spread"] = spread_l2
         for k, v in spread_full.items():
             out[k.replace("grad_full/", "grad_full_spread/")] = np.array(v)

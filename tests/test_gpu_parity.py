@@ -197,7 +197,11 @@ def test_nelbo_and_adam_vs_reference_golden(A, residual):
     trainer = A.HipTrainer(model, batch_shape=(6, 1, 32, 32), use_graph=False)
     out = trainer.step(x, eps)
     torch.cuda.synchronize()
-    rep.check("loss[total,recon,prior]", out, g["loss"])
+    # forward quantities: 1e-4, or 3x the reference's own 1-ulp sensitivity where that is larger (hostile case, see below)
+    def fwd_tol(key):
+        return max(TOL32, 3.0 * float(g[key + "_spread"]) / max(g[key].abs().max().item(), 1e-30))
+
+    rep.check("loss[total,recon,prior]", out, g["loss"], tol=fwd_tol("loss"))
     logs = trainer._logs
     names, params = [], []
     for pre, net in (("encoder.", model.encoder), ("decoder.", model.decoder)):
@@ -243,8 +247,8 @@ def test_nelbo_and_adam_vs_reference_golden(A, residual):
     # forward artifacts
     model2 = _mnist_vae(A, res)
     loss, logs, art = model2.nelbo({"samples": x, "target": x, "kwargs": {"eps": eps}}, 0)
-    rep.check("preds[:2]", art["preds"][:2], g["preds"])
-    rep.check("latents", art["latents"], g["latents"])
+    rep.check("preds[:2]", art["preds"][:2], g["preds"], tol=fwd_tol("preds"))
+    rep.check("latents", art["latents"], g["latents"], tol=fwd_tol("latents"))
     rep.finish()
 
 
