@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
     __syncthreads();
     const unsigned P = (unsigned)g.N * g.Hs * g.Ws;
     const int nchild = g.up * g.up;
+    const int smask = g.stride - 1, sshift = g.stride - 1;
     double s1[SMALL_MAXC], s2[SMALL_MAXC];
 #pragma unroll
     for (int c = 0; c < SMALL_MAXC; ++c) s1[c] = s2[c] = 0.0;
@@ -141,13 +142,13 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
             const int iy = sy * g.up + (ch >> 1), ix = sx * g.up + (ch & 1);
             for (int kh = 0; kh < g.KH; ++kh) {
                 const int ty = iy + g.pad - kh;
-                if (ty < 0 || (ty % g.stride) != 0) continue;
-                const int oy = ty / g.stride;
+                if (ty < 0 || (ty & smask) != 0) continue;  // stride is 1 or 2
+                const int oy = ty >> sshift;
                 if (oy >= g.Ho) continue;
                 for (int kw = 0; kw < g.KW; ++kw) {
                     const int tx = ix + g.pad - kw;
-                    if (tx < 0 || (tx % g.stride) != 0) continue;
-                    const int ox = tx / g.stride;
+                    if (tx < 0 || (tx & smask) != 0) continue;
+                    const int ox = tx >> sshift;
                     if (ox >= g.Wo) continue;
                     const float* gp = gy + ((size_t)((unsigned)n * g.Ho + oy) * g.Wo + ox) * g.Cn;
                     const float* wp = w_s + (kh * g.KW + kw) * g.Cn * g.Cs;

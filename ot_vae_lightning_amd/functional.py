@@ -9,6 +9,7 @@ Nothing here computes on the CPU: tensors must be on the GPU and the HIP library
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -134,6 +135,59 @@ def bn_eval_affine(branch: BNBranch):
     return branch.running_mean.clone(), invstd, scale, shift
 
 
+# ------------------------------------------------------------------------------------------------ side stream
+class _SideStream:
+    """Fork/join helper for work that is off the critical path of backward (weight gradients).
+
+    ``with _SideStream(device) as side:`` makes the side stream wait for everything queued so far on the current
+    stream and switches to it; tensors passed to ``side.keep`` stay referenced until the join so that the caching
+    allocator cannot hand their memory to a later kernel of the main stream.  The join (main stream waits for the side
+    stream) is queued once per backward pass as an autograd-engine callback, i.e. before ``backward()`` returns and,
+    under hipGraph capture, before the capture ends (the side stream forks from and rejoins the capturing stream).
+    Set ``OTVAE_NO_SIDE_STREAM=1`` to run everything on one stream."""
+    _state = {}
+    enabled = os.environ.get("OTVAE_NO_SIDE_STREAM", "0") != "1"
+
+    def __init__(self, device):
+        self.device = device
+        st = _SideStream._state.get(device)
+        if st is None:
+            st = {"stream": torch.cuda.Stream(device=device), "keep": [], "pending": False}
+            _SideStream._state[device] = st
+        self.st = st
+        self.ctx = None
+
+    def keep(self, *tensors):
+        if _SideStream.enabled:
+            self.st["keep"].extend(t for t in tensors if t is not None)
+
+    def __enter__(self):
+        if not _SideStream.enabled:
+            return self
+        side = self.st["stream"]
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        if not self.st["pending"]:
+            self.st["pending"] = True
+            torch.autograd.Variable._execution_engine.queue_callback(lambda dev=self.device: _SideStream.join(dev))
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+    @staticmethod
+    def join(device):
+        st = _SideStream._state.get(device)
+        if st is None or not st["pending"]:
+            return
+        torch.cuda.current_stream(device).wait_stream(st["stream"])
+        st["keep"].clear()
+        st["pending"] = False
+
+
 # ------------------------------------------------------------------------------------------------ fused ConvLayer(s)
 class ConvSpec:
     """Static description of one ConvLayer branch (everything that is not a tensor)."""
@@ -211,10 +265,15 @@ class _ConvBNFn(torch.autograd.Function):
             wpart = torch.empty((p_w.value, kk, g.Cn), device=x.device, dtype=torch.float32)
             gw = _grad_buffer(pw, w)
             gb = _grad_buffer(pb, bias) if sp.has_bias else None
-            check(lib.otvae_conv_bwd_weight(C.byref(g), ptr(x), ptr(scales[b]) if sp.has_norm else None,
-                                            ptr(shifts[b]) if sp.has_norm else None, int(sp.relu), ptr(gy),
-                                            int(sp.has_bias), ptr(wpart), ptr(gw), ptr(gb), stream()),
-                  "otvae_conv_bwd_weight")
+            # The weight gradient is a leaf of the backward graph (only the optimizer reads it), while the data gradient
+            # below is on the critical path: run it on a side HIP stream so the two overlap (every launch here is a
+            # few dozen workgroups, far from filling 256 CUs).  Joined at the end of the backward pass.
+            with _SideStream(x.device) as side:
+                side.keep(x, gy, wpart, gw, gb, scales[b], shifts[b])
+                check(lib.otvae_conv_bwd_weight(C.byref(g), ptr(x), ptr(scales[b]) if sp.has_norm else None,
+                                                ptr(shifts[b]) if sp.has_norm else None, int(sp.relu), ptr(gy),
+                                                int(sp.has_bias), ptr(wpart), ptr(gw), ptr(gb), stream()),
+                      "otvae_conv_bwd_weight")
             # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
             gv = None
             part = None
