@@ -40,7 +40,7 @@ typedef struct {
 } otvae_conv_geom;
 
 /* ---- BatchNorm2d, training mode (networks/cnn.py:122,184) ------------------------------------------------- */
-/* per-channel partial sums of x[M][C]: partial[P][2][C] (double), P = otvae_bn_stats_nparts(M, C). */
+/* per-channel partial sums of x[M][C]: partial[2][C][P] (double, P fastest), P = otvae_bn_stats_nparts(M, C). */
 int otvae_bn_stats_nparts(int64_t M, int C);
 int otvae_bn_stats(const float* x, int64_t M, int C, double* partial, void* stream);
 /* mean/invstd from the partials; for each of `n_bn` BatchNorm modules sharing this input (a ConvBlock's
@@ -57,7 +57,7 @@ int otvae_bn_finalize(const double* partial, int P, int ld, int64_t M, int C, fl
 /* ---- ConvLayer.forward: y = conv(up(relu?(x*scale+shift))) + bias (+ residual) ---------------------------- */
 /* scale/shift NULL -> no normalisation; relu applies after the affine; bias/residual NULL -> absent.
  * residual has y's shape (ConvBlock `out + skip(x)`, networks/cnn.py:334). wT is the HWIO weight. */
-/* stat_partial (nullable): fp64 [P][2][CnPad] per-block partial sums (sum y, sum y^2) per output channel, written by
+/* stat_partial (nullable): fp64 [2][CnPad][P] per-block partial sums (sum y, sum y^2) per output channel, written by
  * the epilogue so that the NEXT layer's BatchNorm needs no separate pass over y; P, CnPad from _stats_ws. */
 int otvae_conv_fwd_stats_ws(const otvae_conv_geom* g, int* P, int* CnPad);
 int otvae_conv_fwd(const otvae_conv_geom* g, const float* x, const float* scale, const float* shift, int relu,
@@ -74,7 +74,7 @@ int otvae_weight_transpose_batched(const float* src_base, float* dst_base, const
 /* ---- ConvLayer backward ------------------------------------------------------------------------------------ */
 /* Data gradient.  gv[N][Hs][Ws][Cs] = d loss / d (x*scale+shift) i.e. the gradient entering BatchNorm's output
  * (after the nearest-upsample sum and the ReLU mask recomputed from x).  With mean/invstd != NULL also writes
- * the per-block fp64 partial sums bn_partial[P][2][CsPad] of (gv, gv*xhat) that BatchNorm backward needs;
+ * the per-block fp64 partial sums bn_partial[2][CsPad][P] of (gv, gv*xhat) that BatchNorm backward needs;
  * P and CsPad from otvae_conv_bwd_data_ws. */
 int otvae_conv_bwd_data_ws(const otvae_conv_geom* g, int* P, int* CsPad);
 int otvae_conv_bwd_data(const otvae_conv_geom* g, const float* gy, const float* wD,
@@ -94,7 +94,12 @@ int otvae_bn_bwd_apply(int nb, const float* const* gv, const float* x, const flo
  * gw is written in HWIO order, gb[Cn] if has_bias. */
 int otvae_conv_bwd_weight_ws(const otvae_conv_geom* g, int has_bias, int* P);
 int otvae_conv_bwd_weight(const otvae_conv_geom* g, const float* x, const float* scale, const float* shift, int relu,
-                          const float* gy, int has_bias, float* partial, float* gw, float* gb, void* stream);
+                          const float* gy, int has_bias, float* partial, float* gw, float* gb, int defer_reduce,
+                          void* stream);
+/* With defer_reduce != 0 only the partials are written; the caller later reduces any number of layers in one launch
+ * (host arrays of n entries; K = KH*KW*Cs, Kp = K + has_bias, P from otvae_conv_bwd_weight_ws): */
+int otvae_wgrad_reduce_batched(int n, const float* const* partial, const int* P, const int* K, const int* Kp,
+                               const int* Cn, float* const* gw, float* const* gb, void* stream);
 
 /* ---- QKVAttention (networks/nets_utils.py:63-82) ---------------------------------------------------------- */
 /* qkv [N][T][3*H*C] (channel = which*H*C + h*C + c) -> out [N][T][H*C]; lse [N][H][T] saved for backward. */

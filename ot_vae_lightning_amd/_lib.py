@@ -43,7 +43,8 @@ SIGNATURES = {
     "otvae_bn_bwd_finalize": (i32, [i32, pp, pi32, i32, i64, i32, vp, vp, pp, pp, pp, vp, vp]),
     "otvae_bn_bwd_apply": (i32, [i32, pp, vp, vp, i64, i32, vp, vp]),
     "otvae_conv_bwd_weight_ws": (i32, [pg, i32, pi32]),
-    "otvae_conv_bwd_weight": (i32, [pg, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
+    "otvae_conv_bwd_weight": (i32, [pg, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
+    "otvae_wgrad_reduce_batched": (i32, [i32, pp, pi32, pi32, pi32, pi32, pp, pp, vp]),
     "otvae_attn_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvae_attn_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "otvae_gaussian_prior_fwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),

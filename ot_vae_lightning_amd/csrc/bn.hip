@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
                 ts += sh[0][r * C + threadIdx.x];
                 tq += sh[1][r * C + threadIdx.x];
             }
-            partial[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = ts;
-            partial[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = tq;
+            partial[((size_t)0 * C + threadIdx.x) * P + blockIdx.x] = ts;
+            partial[((size_t)1 * C + threadIdx.x) * P + blockIdx.x] = tq;
         }
     } else {
         for (int c = threadIdx.x; c < C; c += 256) {
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
                 s += (double)v;
                 q += (double)v * (double)v;
             }
-            partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
-            partial[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+            partial[((size_t)0 * C + c) * P + blockIdx.x] = s;
+            partial[((size_t)1 * C + c) * P + blockIdx.x] = q;
         }
     }
 }
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     if (c < C) {
         double s = 0.0, q = 0.0;
         for (int p = lane; p < P; p += 64) {
-            s += partial[((size_t)p * 2 + 0) * ld + c];
-            q += partial[((size_t)p * 2 + 1) * ld + c];
+            s += partial[((size_t)0 * ld + c) * P + p];  // [2][ld][P]: lanes read consecutive p
+            q += partial[((size_t)1 * ld + c) * P + p];
         }
         s = wave_sum(s);
         q = wave_sum(q);
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int nb, BnBwdFin f
     for (int b = 0; b < nb; ++b) {
         double s1 = 0.0, s2 = 0.0;
         for (int p = lane; p < f.P[b]; p += 64) {
-            s1 += f.partial[b][((size_t)p * 2 + 0) * CsPad + c];
-            s2 += f.partial[b][((size_t)p * 2 + 1) * CsPad + c];
+            s1 += f.partial[b][((size_t)0 * CsPad + c) * f.P[b] + p];
+            s2 += f.partial[b][((size_t)1 * CsPad + c) * f.P[b] + p];
         }
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);

@@ -460,7 +460,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
             const double t = (red[(0 * 2 + which) * BN + cc] + red[(1 * 2 + which) * BN + cc]) +
                              (red[(2 * 2 + which) * BN + cc] + red[(3 * 2 + which) * BN + cc]);
             const unsigned p = blockIdx.z * gridDim.x + blockIdx.x;
-            partial[((size_t)p * 2 + which) * CsPad + n0 + cc] = t;
+            const unsigned Ptot = gridDim.x * gridDim.z;
+            partial[((size_t)which * CsPad + n0 + cc) * Ptot + p] = t;  // [2][CsPad][P]
         }
     }
 }
@@ -981,7 +982,7 @@ extern "C" int otvae_conv_bwd_weight_ws(const otvae_conv_geom* gg, int has_bias,
 
 extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, const float* scale, const float* shift,
                                      int relu, const float* gy, int has_bias, float* partial, float* gw, float* gb,
-                                     void* stream) {
+                                     int defer_reduce, void* stream) {
     int rc = check_geom(gg, "otvae_conv_bwd_weight");
     if (rc) return rc;
     OTVAE_REQUIRE(x && gy && partial && gw, "otvae_conv_bwd_weight: NULL tensor");
@@ -996,6 +997,7 @@ extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, 
     if (conv_small_wgrad_ok(g)) {
         conv_small_wgrad(g, x, scale, shift, relu, gy, has_bias, partial, st);
         OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(small)");
+        if (defer_reduce) return OTVAE_OK;
         wgrad_reduce_kernel<<<imin(cdiv(total, P >= 32 ? 4 : 64), 2048), 256, 0, st>>>(partial, P, Kp - (has_bias ? 1 : 0), Kp,
                                                                                      g.Cn, gw, gb);
         OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(reduce)");
@@ -1023,7 +1025,79 @@ extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, 
     }
 #undef OTVAE_WG
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight");
+    if (defer_reduce) return OTVAE_OK;
     wgrad_reduce_kernel<<<imin(cdiv(total, P >= 32 ? 4 : 64), 2048), 256, 0, st>>>(partial, P, Kp - (has_bias ? 1 : 0), Kp, g.Cn, gw, gb);
     OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(reduce)");
+    return OTVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batched reduce
+// The partial -> gradient reductions of up to 32 layers in ONE launch (blockIdx.y = layer): the ~50 per-layer
+// reductions of a backward pass are each a few microseconds of dependent-load latency; batching them removes their
+// launch gaps and lets them share the chip.  Same fixed summation order as wgrad_reduce_kernel.
+#define WRB_MAX 32
+struct WrbDesc {
+    const float* partial[WRB_MAX];
+    float* gw[WRB_MAX];
+    float* gb[WRB_MAX];
+    int P[WRB_MAX], K[WRB_MAX], Kp[WRB_MAX], Cn[WRB_MAX];
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
+    const int l = blockIdx.y;
+    const float* __restrict__ partial = d.partial[l];
+    float* __restrict__ gw = d.gw[l];
+    float* __restrict__ gb = d.gb[l];
+    const int P = d.P[l], K = d.K[l], Cn = d.Cn[l];
+    const size_t total = (size_t)d.Kp[l] * Cn;
+    const int lane = threadIdx.x & 63;
+    if (P >= 16) {  // one wave per element
+        for (size_t e = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (size_t)gridDim.x * 4) {
+            float s = 0.f;
+            for (int p = lane; p < P; p += 64) s += partial[(size_t)p * total + e];
+            s = wave_sum(s);
+            if (lane == 0) {
+                const int k = e / Cn;
+                if (k < K) gw[e] = s;
+                else if (gb) gb[e - (size_t)K * Cn] = s;
+            }
+        }
+    } else {  // one lane per element, serial over the few partials
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+            float s = 0.f;
+            for (int p = 0; p < P; ++p) s += partial[(size_t)p * total + e];
+            const int k = e / Cn;
+            if (k < K) gw[e] = s;
+            else if (gb) gb[e - (size_t)K * Cn] = s;
+        }
+    }
+}
+
+extern "C" int otvae_wgrad_reduce_batched(int n, const float* const* partial, const int* P, const int* K, const int* Kp,
+                                          const int* Cn, float* const* gw, float* const* gb, void* stream) {
+    OTVAE_REQUIRE(n > 0 && partial && P && K && Kp && Cn && gw && gb, "otvae_wgrad_reduce_batched: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += WRB_MAX) {
+        WrbDesc d = {};
+        const int m = imin(WRB_MAX, n - base);
+        size_t maxwork = 1;
+        for (int i = 0; i < m; ++i) {
+            const int j = base + i;
+            OTVAE_REQUIRE(partial[j] && gw[j] && P[j] > 0 && Kp[j] >= K[j] && Cn[j] > 0, "otvae_wgrad_reduce_batched: entry %d", j);
+            d.partial[i] = partial[j];
+            d.gw[i] = gw[j];
+            d.gb[i] = gb[j];
+            d.P[i] = P[j];
+            d.K[i] = K[j];
+            d.Kp[i] = Kp[j];
+            d.Cn[i] = Cn[j];
+            const size_t total = (size_t)Kp[j] * Cn[j];
+            const size_t work = P[j] >= 16 ? cdiv(total, 4) : cdiv(total, 256);
+            if (work > maxwork) maxwork = work;
+        }
+        dim3 grid(imin((int)maxwork, 512), m);
+        wgrad_reduce_batched_kernel<<<grid, 256, 0, st>>>(d);
+        OTVAE_CHECK_LAUNCH("otvae_wgrad_reduce_batched");
+    }
     return OTVAE_OK;
 }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const 
         __syncthreads();
         if (threadIdx.x < 2 * SMALL_MAXC) {
             const int which = threadIdx.x / SMALL_MAXC, c = threadIdx.x % SMALL_MAXC;
-            partial[((size_t)blockIdx.x * 2 + which) * CnPad + c] =
+            partial[((size_t)which * CnPad + c) * gridDim.x + blockIdx.x] =
                 (redf[0][which][c] + redf[1][which][c]) + (redf[2][which][c] + redf[3][which][c]);
         }
     }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
         if (threadIdx.x < 2 * SMALL_MAXC) {
             const int which = threadIdx.x / SMALL_MAXC, c = threadIdx.x % SMALL_MAXC;
             const double t = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
-            partial[((size_t)blockIdx.x * 2 + which) * CsPad + c] = t;
+            partial[((size_t)which * CsPad + c) * gridDim.x + blockIdx.x] = t;
         }
         // columns [SMALL_MAXC, CsPad) of the partial rows are never read (finalize only touches c < Cs)
     }

@@ -137,8 +137,8 @@ class HipTrainer:
         batch = {"samples": self.x, "target": self.x, "kwargs": {"eps": self.eps}}
         loss, logs, art = self.model.nelbo(batch, 0)
         loss.backward()
-        from ..functional import _SideStream
-        _SideStream.join(self.device)  # weight-gradient stream (normally already joined by the engine callback)
+        from ..functional import _PendingReduce
+        _PendingReduce.flush(self.device)  # normally already done by the autograd-engine callback at the end of backward
         self._logs = logs
         self.latents = art["latents"].detach()
         if self.latent_stats is not None:

@@ -144,9 +144,10 @@ class _SideStream:
     allocator cannot hand their memory to a later kernel of the main stream.  The join (main stream waits for the side
     stream) is queued once per backward pass as an autograd-engine callback, i.e. before ``backward()`` returns and,
     under hipGraph capture, before the capture ends (the side stream forks from and rejoins the capturing stream).
-    Set ``OTVAE_NO_SIDE_STREAM=1`` to run everything on one stream."""
+    Measured on MI355X (round 1): the ~50 fork/join edges per step cost more than the overlap wins inside a captured
+    step (5.51 vs 5.01 ms), so it is OFF by default; ``OTVAE_SIDE_STREAM=1`` enables it."""
     _state = {}
-    enabled = os.environ.get("OTVAE_NO_SIDE_STREAM", "0") != "1"
+    enabled = os.environ.get("OTVAE_SIDE_STREAM", "0") == "1"
 
     def __init__(self, device):
         self.device = device
@@ -186,6 +187,33 @@ class _SideStream:
         torch.cuda.current_stream(device).wait_stream(st["stream"])
         st["keep"].clear()
         st["pending"] = False
+
+
+class _PendingReduce:
+    """Weight-gradient partials of the current backward pass, reduced together by ``flush`` (queued as an
+    autograd-engine callback, so gradients are complete when ``backward()`` returns)."""
+    _state = {}
+
+    @staticmethod
+    def add(device, partial, p, k, kp, cn, gw, gb):
+        st = _PendingReduce._state.setdefault(device, [])
+        if not st:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda dev=device: _PendingReduce.flush(dev))
+        st.append((partial, p, k, kp, cn, gw, gb))
+
+    @staticmethod
+    def flush(device):
+        st = _PendingReduce._state.get(device)
+        if not st:
+            return
+        _SideStream.join(device)
+        lib = _lib.load()
+        n = len(st)
+        ia = lambda i: (C.c_int * n)(*[e[i] for e in st])  # noqa: E731
+        check(lib.otvae_wgrad_reduce_batched(n, ptr_array([e[0] for e in st]), ia(1), ia(2), ia(3), ia(4),
+                                             ptr_array([e[5] for e in st]), ptr_array([e[6] for e in st]), stream()),
+              "otvae_wgrad_reduce_batched")
+        st.clear()
 
 
 # ------------------------------------------------------------------------------------------------ fused ConvLayer(s)
@@ -272,8 +300,10 @@ class _ConvBNFn(torch.autograd.Function):
                 side.keep(x, gy, wpart, gw, gb, scales[b], shifts[b])
                 check(lib.otvae_conv_bwd_weight(C.byref(g), ptr(x), ptr(scales[b]) if sp.has_norm else None,
                                                 ptr(shifts[b]) if sp.has_norm else None, int(sp.relu), ptr(gy),
-                                                int(sp.has_bias), ptr(wpart), ptr(gw), ptr(gb), stream()),
+                                                int(sp.has_bias), ptr(wpart), ptr(gw), ptr(gb), 1, stream()),
                       "otvae_conv_bwd_weight")
+            # the partial -> gradient reduction is deferred: all layers of this backward pass reduce in one launch
+            _PendingReduce.add(x.device, wpart, p_w.value, kk - (1 if sp.has_bias else 0), kk, g.Cn, gw, gb)
             # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
             gv = None
             part = None
