@@ -190,8 +190,9 @@ class _SideStream:
 
 
 class _PendingReduce:
-    """Weight-gradient partials of the current backward pass, reduced together by ``flush`` (queued as an
-    autograd-engine callback, so gradients are complete when ``backward()`` returns)."""
+    """Weight-gradient partials of the current backward pass whose destination is a trainer-owned flat gradient
+    buffer, reduced together by ``flush`` (queued as an autograd-engine callback and called by the trainer before the
+    optimizer).  Destinations are kept as raw addresses: holding the tensors would make autograd clone them."""
     _state = {}
 
     @staticmethod
@@ -210,8 +211,14 @@ class _PendingReduce:
         lib = _lib.load()
         n = len(st)
         ia = lambda i: (C.c_int * n)(*[e[i] for e in st])  # noqa: E731
+        def raw(vals):  # host array of raw device addresses (gradient slots live in the trainer's flat buffer)
+            arr = (C.c_void_p * n)()
+            for i, v in enumerate(vals):
+                arr[i] = v
+            return arr
+
         check(lib.otvae_wgrad_reduce_batched(n, ptr_array([e[0] for e in st]), ia(1), ia(2), ia(3), ia(4),
-                                             ptr_array([e[5] for e in st]), ptr_array([e[6] for e in st]), stream()),
+                                             raw([e[5] for e in st]), raw([e[6] for e in st]), stream()),
               "otvae_wgrad_reduce_batched")
         st.clear()
 
@@ -296,14 +303,21 @@ class _ConvBNFn(torch.autograd.Function):
             # The weight gradient is a leaf of the backward graph (only the optimizer reads it), while the data gradient
             # below is on the critical path: run it on a side HIP stream so the two overlap (every launch here is a
             # few dozen workgroups, far from filling 256 CUs).  Joined at the end of the backward pass.
+            # When the gradient lands in a trainer-owned flat buffer (persistent memory, read by the optimizer and not
+            # through autograd's accumulation), the partial -> gradient reduction is deferred so that all layers of the
+            # backward pass reduce in ONE launch.  Otherwise it runs right away: autograd may clone / accumulate the
+            # returned tensor before a deferred kernel would have filled it.
+            defer = (pw is not None and getattr(pw, "_otvae_grad_view", None) is not None and
+                     (not sp.has_bias or getattr(pb, "_otvae_grad_view", None) is not None))
             with _SideStream(x.device) as side:
                 side.keep(x, gy, wpart, gw, gb, scales[b], shifts[b])
                 check(lib.otvae_conv_bwd_weight(C.byref(g), ptr(x), ptr(scales[b]) if sp.has_norm else None,
                                                 ptr(shifts[b]) if sp.has_norm else None, int(sp.relu), ptr(gy),
-                                                int(sp.has_bias), ptr(wpart), ptr(gw), ptr(gb), 1, stream()),
+                                                int(sp.has_bias), ptr(wpart), ptr(gw), ptr(gb), int(defer), stream()),
                       "otvae_conv_bwd_weight")
-            # the partial -> gradient reduction is deferred: all layers of this backward pass reduce in one launch
-            _PendingReduce.add(x.device, wpart, p_w.value, kk - (1 if sp.has_bias else 0), kk, g.Cn, gw, gb)
+            if defer:
+                _PendingReduce.add(x.device, wpart, p_w.value, kk - (1 if sp.has_bias else 0), kk, g.Cn,
+                                   gw.data_ptr(), gb.data_ptr() if gb is not None else None)
             # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
             gv = None
             part = None
