@@ -1,6 +1,7 @@
 """Turns the rocprofv3 outputs merged into gpurun_out/ into the small, tracked summaries under profiles/.
 
     python tools/summarize_profiles.py <kernel-stats dir> <tag>         # e.g. gpurun_out/prof8 r01_final
+    python tools/summarize_profiles.py --replay <kernel-trace dir> <tag> # replayed (timed) steps only
     python tools/summarize_profiles.py --pmc gpurun_out <tag>           # pmc_fetch / pmc_write / pmc_mfma passes
 
 HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
@@ -16,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_stats(src, tag, steps_in_run=27):
-    f = sorted(glob.glob(os.path.join(src, "*", "*_kernel_stats.csv")))[-1]
+    f = max(glob.glob(os.path.join(src, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     out = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
     with open(out, "w") as w:
@@ -28,6 +29,33 @@ def kernel_stats(src, tag, steps_in_run=27):
                                                    int(r["TotalDurationNs"]) / 1e6 / steps_in_run,
                                                    100.0 * int(r["TotalDurationNs"]) / tot))
     print("wrote", out, "total kernel ms/step %.3f" % (tot / 1e6 / steps_in_run))
+
+
+def replay_stats(src, tag, steps=20):
+    """Per-kernel statistics over the last `steps` hipGraph replays only (the timed region of bench.py), cut out of the
+    kernel trace at the adam_kernel launches: the stats file of the same run also contains the eager warm-up, the
+    capture warm-up, the parity check and the dominant-kernel timing loop."""
+    f = max(glob.glob(os.path.join(src, "*", "*_kernel_trace.csv")), key=os.path.getmtime)
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
+    lo, hi = ends[-steps - 1] + 1, ends[-1] + 1
+    seg = rows[lo:hi]
+    acc = collections.defaultdict(lambda: [0, 0])
+    for r in seg:
+        k = r["Kernel_Name"].split("(")[0]
+        acc[k][0] += 1
+        acc[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    tot = sum(v[1] for v in acc.values())
+    wall = int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])
+    out = os.path.join(ROOT, "profiles", f"{tag}_replay_kernel_stats.csv")
+    with open(out, "w") as w:
+        w.write("# last %d graph replays: %d launches/step, kernel-busy %.3f ms/step, wall %.3f ms/step\n" %
+                (steps, len(seg) // steps, tot / 1e6 / steps, wall / 1e6 / steps))
+        w.write("kernel,calls_per_step,avg_us,ms_per_step,percent\n")
+        for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            w.write('"%s",%.1f,%.2f,%.4f,%.2f\n' % (k, n / steps, t / n / 1e3, t / 1e6 / steps, 100.0 * t / tot))
+    print("wrote", out, "launches/step", len(seg) // steps, "busy ms/step %.3f wall %.3f" % (tot / 1e6 / steps, wall / 1e6 / steps))
 
 
 def pmc(src, tag):
@@ -64,5 +92,7 @@ def pmc(src, tag):
 if __name__ == "__main__":
     if sys.argv[1] == "--pmc":
         pmc(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "--replay":
+        replay_stats(sys.argv[2], sys.argv[3])
     else:
         kernel_stats(sys.argv[1], sys.argv[2])
