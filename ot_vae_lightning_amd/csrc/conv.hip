@@ -42,9 +42,14 @@ static int check_geom(const otvae_conv_geom* g, const char* who) {
     return OTVAE_OK;
 }
 
-static inline int pick_nt(int ncols) {
-    int nnt = cdiv(ncols, 16);
-    return nnt >= 4 ? 4 : nnt;
+// Column tiles (16 wide) per wave.  A wide tile re-uses the staged A rows for more MFMAs, but a layer with few row tiles
+// (deep layers: 1x1 .. 4x4 maps) then runs on a fraction of the 256 CUs with ONE wave per SIMD, where the loop is bound
+// by instruction issue, not by MFMA throughput: narrow the tile until the launch has >= 512 workgroups (2 per CU).
+static inline int pick_nt(int ncols, long row_blocks) {
+    const int nnt = cdiv(ncols, 16);
+    int nt = nnt >= 4 ? 4 : nnt;
+    while (nt > 1 && row_blocks * cdiv(nnt, nt) < 512) --nt;
+    return nt;
 }
 
 #define MAX_TAPS 49
@@ -497,8 +502,8 @@ static void launch_gemm(int NT, dim3 grid, hipStream_t st, Geom g, const float* 
 }
 
 static void fwd_grid(const Geom& g, int& NT, dim3& grid, int& CnPad) {
-    NT = pick_nt(g.Cn);
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
+    NT = pick_nt(g.Cn, cdiv(M, TM));
     const int ny = cdiv(cdiv(g.Cn, 16), NT);
     grid = dim3(imin(cdiv(M, TM), 2048), ny, 1);  // <= 2048 blocks: each may write one statistics partial
     CnPad = ny * 16 * NT;
@@ -590,11 +595,11 @@ extern "C" int otvae_weight_transpose_batched(const float* src_base, float* dst_
 
 // ------------------------------------------------------------------------------------------------ data gradient
 static void dgrad_grid(const Geom& g, int& NT, dim3& grid, int& CsPad) {
-    NT = pick_nt(g.Cs);
     const int Hu = g.Hs * g.up, Wu = g.Ws * g.up;
     const unsigned rows = (g.stride == 2) ? (unsigned)g.N * (g.Hs >> 1) * (g.Ws >> 1) : (unsigned)g.N * Hu * Wu;
-    const int ny = cdiv(cdiv(g.Cs, 16), NT);
     const int nz = g.stride == 2 ? 4 : 1;
+    NT = pick_nt(g.Cs, (long)cdiv(rows, TM) * nz);
+    const int ny = cdiv(cdiv(g.Cs, 16), NT);
     // bounded number of blocks (each writes one BatchNorm partial): <= 1024 over x*z
     grid = dim3(imax(1, imin(cdiv(rows, TM), 1024 / nz)), ny, nz);
     CsPad = ny * 16 * NT;
@@ -949,15 +954,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 static void wgrad_plan(const Geom& g, int has_bias, int& NT, int& P, unsigned& chunk, int& nkb, int& nnb, int& Kp) {
-    NT = pick_nt(g.Cn);
+    const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
     Kp = g.KH * g.KW * g.Cs + (has_bias ? 1 : 0);
     nkb = cdiv(Kp, 64);
+    {
+        const int pix = imax(1, (int)(M / 128)), ws = imax(1, (int)((4u << 20) / ((unsigned)Kp * g.Cn)));
+        NT = pick_nt(g.Cn, (long)nkb * imin(imin(pix, ws), 2048));
+    }
     nnb = cdiv(cdiv(g.Cn, 16), NT);
     if (conv_small_wgrad_ok(g)) {
         conv_small_wgrad_plan(g, P, chunk);
         return;
     }
-    const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
     // enough workgroups to fill the chip several times over (256 CUs x ~3 resident x 4 rounds: the kernel is latency-
     // bound per 32-pixel step, short chains + many resident blocks hide it), pixel chunks of >= 128 pixels,
     // workspace <= 16 MiB, P <= 2048
