@@ -25,70 +25,121 @@ __device__ __forceinline__ float act1(float v, float sc, float sh, bool affine, 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// CS / CN > 0: channel counts known at compile time (inner loops fully unrolled, channel vectors loaded as one 16/32-byte
+// access); 0: read from the geometry (any Cs, Cn <= SMALL_MAXC).
+template <int C>
+__device__ __forceinline__ void load_chan(const float* __restrict__ p, float (&v)[C ? C : SMALL_MAXC], int n) {
+    if constexpr (C == 8) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else if constexpr (C == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    } else if constexpr (C > 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = p[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < SMALL_MAXC; ++c) v[c] = c < n ? p[c] : 0.f;
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void store_chan(float* __restrict__ p, const float (&v)[C ? C : SMALL_MAXC], int n) {
+    if constexpr (C == 8) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else if constexpr (C == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (C > 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) p[c] = v[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < SMALL_MAXC; ++c)
+            if (c < n) p[c] = v[c];
+    }
+}
+
+template <int CS, int CN>
 __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const float* __restrict__ x,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int relu, const float* __restrict__ wT,
                                                              const float* __restrict__ bias, const float* __restrict__ res,
                                                              float* __restrict__ y, double* __restrict__ partial, int CnPad) {
-    __shared__ float w_s[SMALL_MAXW];
+    constexpr int CSM = CS ? CS : SMALL_MAXC, CNM = CN ? CN : SMALL_MAXC;
+    const int Cs = CS ? CS : g.Cs, Cn = CN ? CN : g.Cn;
+    __shared__ __align__(16) float w_s[SMALL_MAXW];  // [tap][c][CNM]  (row padded to CNM when CN is generic)
     __shared__ double redf[4][2][SMALL_MAXC];
     __shared__ float sc_s[SMALL_MAXC], sh_s[SMALL_MAXC], b_s[SMALL_MAXC];
     const int T = g.KH * g.KW;
-    for (int i = threadIdx.x; i < T * g.Cs * g.Cn; i += 256) w_s[i] = wT[i];
+    for (int i = threadIdx.x; i < T * Cs * Cn; i += 256) w_s[i] = wT[i];
     if (threadIdx.x < SMALL_MAXC) {
         const int c = threadIdx.x;
-        sc_s[c] = (scale && c < g.Cs) ? scale[c] : 1.f;
-        sh_s[c] = (scale && c < g.Cs) ? shift[c] : 0.f;
-        b_s[c] = (bias && c < g.Cn) ? bias[c] : 0.f;
+        sc_s[c] = (scale && c < Cs) ? scale[c] : 1.f;
+        sh_s[c] = (scale && c < Cs) ? shift[c] : 0.f;
+        b_s[c] = (bias && c < Cn) ? bias[c] : 0.f;
     }
     __syncthreads();
     const bool affine = scale != nullptr;
+    float sc[CSM], sh[CSM];
+#pragma unroll
+    for (int c = 0; c < CSM; ++c) {
+        sc[c] = sc_s[c];
+        sh[c] = sh_s[c];
+    }
     const int Hu = g.Hs * g.up, Wu = g.Ws * g.up, ush = g.up - 1;
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
-    double s1[SMALL_MAXC], s2[SMALL_MAXC];
+    double s1[CNM], s2[CNM];
 #pragma unroll
-    for (int j = 0; j < SMALL_MAXC; ++j) s1[j] = s2[j] = 0.0;
+    for (int j = 0; j < CNM; ++j) s1[j] = s2[j] = 0.0;
     for (unsigned m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
         const int ox = m % g.Wo;
         const unsigned t0 = m / g.Wo;
         const int oy = t0 % g.Ho;
         const int n = t0 / g.Ho;
-        float acc[SMALL_MAXC];
+        float acc[CNM];
 #pragma unroll
-        for (int j = 0; j < SMALL_MAXC; ++j) acc[j] = b_s[j];
+        for (int j = 0; j < CNM; ++j) acc[j] = b_s[j];
         for (int kh = 0; kh < g.KH; ++kh) {
             const int iy = oy * g.stride + kh - g.pad;
             if ((unsigned)iy >= (unsigned)Hu) continue;
             for (int kw = 0; kw < g.KW; ++kw) {
                 const int ix = ox * g.stride + kw - g.pad;
                 if ((unsigned)ix >= (unsigned)Wu) continue;
-                const float* xp = x + ((size_t)((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * g.Cs;
-                const float* wp = w_s + (kh * g.KW + kw) * g.Cs * g.Cn;
-                for (int c = 0; c < g.Cs; ++c) {
-                    const float a = act1(xp[c], sc_s[c], sh_s[c], affine, relu);
+                float xv[CSM];
+                load_chan<CS>(x + ((size_t)((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * Cs, xv, Cs);
+                const float* wp = w_s + (kh * g.KW + kw) * Cs * Cn;
 #pragma unroll
-                    for (int j = 0; j < SMALL_MAXC; ++j)
-                        if (j < g.Cn) acc[j] = fmaf(a, wp[c * g.Cn + j], acc[j]);
+                for (int c = 0; c < CSM; ++c) {
+                    if (CS || c < Cs) {
+                        const float a = act1(xv[c], sc[c], sh[c], affine, relu);
+#pragma unroll
+                        for (int j = 0; j < CNM; ++j)
+                            if (CN || j < Cn) acc[j] = fmaf(a, wp[c * Cn + j], acc[j]);
+                    }
                 }
             }
         }
-        float* yp = y + (size_t)m * g.Cn;
-        const float* rp = res ? res + (size_t)m * g.Cn : nullptr;
+        if (res) {
+            float rv[CNM];
+            load_chan<CN>(res + (size_t)m * Cn, rv, Cn);
 #pragma unroll
-        for (int j = 0; j < SMALL_MAXC; ++j)
-            if (j < g.Cn) {
-                const float v = acc[j] + (rp ? rp[j] : 0.f);
-                yp[j] = v;
-                if (partial) {
-                    s1[j] += (double)v;
-                    s2[j] += (double)v * (double)v;
-                }
+            for (int j = 0; j < CNM; ++j) acc[j] += rv[j];
+        }
+        store_chan<CN>(y + (size_t)m * Cn, acc, Cn);
+        if (partial) {
+#pragma unroll
+            for (int j = 0; j < CNM; ++j) {
+                s1[j] += (double)acc[j];
+                s2[j] += (double)acc[j] * (double)acc[j];
             }
+        }
     }
     if (partial) {  // per-channel sums of the output = the next layer's BatchNorm statistics
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-        for (int j = 0; j < SMALL_MAXC; ++j) {
+        for (int j = 0; j < CNM; ++j) {
             const double a = wave_sum(s1[j]), b = wave_sum(s2[j]);
             if (lane == 0) {
                 redf[wave][0][j] = a;
@@ -98,46 +149,72 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const 
         __syncthreads();
         if (threadIdx.x < 2 * SMALL_MAXC) {
             const int which = threadIdx.x / SMALL_MAXC, c = threadIdx.x % SMALL_MAXC;
-            partial[((size_t)which * CnPad + c) * gridDim.x + blockIdx.x] =
-                (redf[0][which][c] + redf[1][which][c]) + (redf[2][which][c] + redf[3][which][c]);
+            if (c < Cn)
+                partial[((size_t)which * CnPad + c) * gridDim.x + blockIdx.x] =
+                    (redf[0][which][c] + redf[1][which][c]) + (redf[2][which][c] + redf[3][which][c]);
         }
     }
 }
 
+// channel-count specialisations: the MNIST (1 <-> 8, 1 -> 1, 1 -> 3) and RGB (3 <-> 8, 3 -> 3) image-side layers
+#define SMALL_DISPATCH(KERNEL, ...)                                            \
+    do {                                                                       \
+        if (g.Cs == 1 && g.Cn == 8) KERNEL<1, 8> __VA_ARGS__;                  \
+        else if (g.Cs == 8 && g.Cn == 1) KERNEL<8, 1> __VA_ARGS__;             \
+        else if (g.Cs == 1 && g.Cn == 1) KERNEL<1, 1> __VA_ARGS__;             \
+        else if (g.Cs == 1 && g.Cn == 3) KERNEL<1, 3> __VA_ARGS__;             \
+        else if (g.Cs == 3 && g.Cn == 8) KERNEL<3, 8> __VA_ARGS__;             \
+        else if (g.Cs == 8 && g.Cn == 3) KERNEL<8, 3> __VA_ARGS__;             \
+        else if (g.Cs == 3 && g.Cn == 3) KERNEL<3, 3> __VA_ARGS__;             \
+        else KERNEL<0, 0> __VA_ARGS__;                                         \
+    } while (0)
+
 int conv_small_fwd(const SmallGeom& g, int nblocks, const float* x, const float* scale, const float* shift, int relu,
                    const float* wT, const float* bias, const float* res, float* y, double* partial, int CnPad,
                    hipStream_t st) {
-    conv_small_fwd_kernel<<<nblocks, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y, partial, CnPad);
+    SMALL_DISPATCH(conv_small_fwd_kernel, <<<nblocks, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y, partial, CnPad));
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ data gradient
 // one lane per SOURCE position (parent pixel when up == 2): all Cs channels, children summed in registers
+template <int CS, int CN>
 __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, const float* __restrict__ gy,
                                                                const float* __restrict__ wD, const float* __restrict__ x,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                int relu, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, float* __restrict__ gv,
                                                                double* __restrict__ partial, int CsPad) {
-    __shared__ float w_s[SMALL_MAXW];  // wD[t][co][c]
+    constexpr int CSM = CS ? CS : SMALL_MAXC, CNM = CN ? CN : SMALL_MAXC;
+    const int Cs = CS ? CS : g.Cs, Cn = CN ? CN : g.Cn;
+    __shared__ __align__(16) float w_s[SMALL_MAXW];  // wD[t][co][c]
     __shared__ double red[4][2][SMALL_MAXC];
     const int T = g.KH * g.KW;
-    for (int i = threadIdx.x; i < T * g.Cs * g.Cn; i += 256) w_s[i] = wD[i];
+    for (int i = threadIdx.x; i < T * Cs * Cn; i += 256) w_s[i] = wD[i];
     __syncthreads();
+    float sc[CSM], sh[CSM], mu[CSM], is[CSM];
+#pragma unroll
+    for (int c = 0; c < CSM; ++c) {
+        const bool in = CS || c < Cs;
+        sc[c] = (scale && in) ? scale[c] : 1.f;
+        sh[c] = (scale && in) ? shift[c] : 0.f;
+        mu[c] = (mean && in) ? mean[c] : 0.f;
+        is[c] = (mean && in) ? invstd[c] : 0.f;
+    }
     const unsigned P = (unsigned)g.N * g.Hs * g.Ws;
     const int nchild = g.up * g.up;
     const int smask = g.stride - 1, sshift = g.stride - 1;
-    double s1[SMALL_MAXC], s2[SMALL_MAXC];
+    double s1[CSM], s2[CSM];
 #pragma unroll
-    for (int c = 0; c < SMALL_MAXC; ++c) s1[c] = s2[c] = 0.0;
+    for (int c = 0; c < CSM; ++c) s1[c] = s2[c] = 0.0;
     for (unsigned p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
         const int sx = p % g.Ws;
         const unsigned t0 = p / g.Ws;
         const int sy = t0 % g.Hs;
         const int n = t0 / g.Hs;
-        float acc[SMALL_MAXC];
+        float acc[CSM];
 #pragma unroll
-        for (int c = 0; c < SMALL_MAXC; ++c) acc[c] = 0.f;
+        for (int c = 0; c < CSM; ++c) acc[c] = 0.f;
         for (int ch = 0; ch < nchild; ++ch) {
             const int iy = sy * g.up + (ch >> 1), ix = sx * g.up + (ch & 1);
             for (int kh = 0; kh < g.KH; ++kh) {
@@ -150,40 +227,44 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
                     if (tx < 0 || (tx & smask) != 0) continue;
                     const int ox = tx >> sshift;
                     if (ox >= g.Wo) continue;
-                    const float* gp = gy + ((size_t)((unsigned)n * g.Ho + oy) * g.Wo + ox) * g.Cn;
-                    const float* wp = w_s + (kh * g.KW + kw) * g.Cn * g.Cs;
-                    for (int co = 0; co < g.Cn; ++co) {
-                        const float gvv = gp[co];
+                    float gg[CNM];
+                    load_chan<CN>(gy + ((size_t)((unsigned)n * g.Ho + oy) * g.Wo + ox) * Cn, gg, Cn);
+                    const float* wp = w_s + (kh * g.KW + kw) * Cn * Cs;
 #pragma unroll
-                        for (int c = 0; c < SMALL_MAXC; ++c)
-                            if (c < g.Cs) acc[c] = fmaf(gvv, wp[co * g.Cs + c], acc[c]);
+                    for (int co = 0; co < CNM; ++co) {
+                        if (CN || co < Cn) {
+#pragma unroll
+                            for (int c = 0; c < CSM; ++c)
+                                if (CS || c < Cs) acc[c] = fmaf(gg[co], wp[co * Cs + c], acc[c]);
+                        }
                     }
                 }
             }
         }
-        const size_t o = (size_t)p * g.Cs;
+        const size_t o = (size_t)p * Cs;
+        float xv[CSM];
+        if (relu || mean) load_chan<CS>(x + o, xv, Cs);
 #pragma unroll
-        for (int c = 0; c < SMALL_MAXC; ++c) {
-            if (c < g.Cs) {
+        for (int c = 0; c < CSM; ++c) {
+            if (CS || c < Cs) {
                 float val = acc[c];
-                float xv = 0.f;
-                if (relu || mean) xv = x[o + c];
                 if (relu) {
-                    const float v = scale ? fmaf(xv, scale[c], shift[c]) : xv;
+                    const float v = scale ? fmaf(xv[c], sc[c], sh[c]) : xv[c];
                     val = v > 0.f ? val : 0.f;
                 }
-                gv[o + c] = val;
+                acc[c] = val;
                 if (mean) {
                     s1[c] += (double)val;
-                    s2[c] += (double)val * (double)((xv - mean[c]) * invstd[c]);
+                    s2[c] += (double)val * (double)((xv[c] - mu[c]) * is[c]);
                 }
             }
         }
+        store_chan<CS>(gv + o, acc, Cs);
     }
     if (mean) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-        for (int c = 0; c < SMALL_MAXC; ++c) {
+        for (int c = 0; c < CSM; ++c) {
             const double a = wave_sum(s1[c]), b = wave_sum(s2[c]);
             if (lane == 0) {
                 red[wave][0][c] = a;
@@ -193,17 +274,19 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
         __syncthreads();
         if (threadIdx.x < 2 * SMALL_MAXC) {
             const int which = threadIdx.x / SMALL_MAXC, c = threadIdx.x % SMALL_MAXC;
-            const double t = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
-            partial[((size_t)which * CsPad + c) * gridDim.x + blockIdx.x] = t;
+            if (c < Cs) {
+                const double t = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+                partial[((size_t)which * CsPad + c) * gridDim.x + blockIdx.x] = t;
+            }
         }
-        // columns [SMALL_MAXC, CsPad) of the partial rows are never read (finalize only touches c < Cs)
     }
 }
 
 int conv_small_dgrad(const SmallGeom& g, int nblocks, const float* gy, const float* wD, const float* x, const float* scale,
                      const float* shift, int relu, const float* mean, const float* invstd, float* gv, double* partial,
                      int CsPad, hipStream_t st) {
-    conv_small_dgrad_kernel<<<nblocks, 256, 0, st>>>(g, gy, wD, x, scale, shift, relu, mean, invstd, gv, partial, CsPad);
+    SMALL_DISPATCH(conv_small_dgrad_kernel,
+                   <<<nblocks, 256, 0, st>>>(g, gy, wD, x, scale, shift, relu, mean, invstd, gv, partial, CsPad));
     return 0;
 }
 
