@@ -101,6 +101,42 @@ int otvae_conv_bwd_weight(const otvae_conv_geom* g, const float* x, const float*
 int otvae_wgrad_reduce_batched(int n, const float* const* partial, const int* P, const int* K, const int* Kp,
                                const int* Cn, float* const* gw, float* const* gb, void* stream);
 
+/* ---- several independent ConvLayer kernels in ONE launch ----------------------------------------------------
+ * The two branches of a ConvBlock (block[0] and skip read the same x, networks/cnn.py:311-335) in the forward pass,
+ * and the weight- and data-gradient of every branch in the backward pass, are independent of each other; at the
+ * layer sizes of this model each one alone fills a fraction of the 256 CUs.  otvae_conv_multi gives exactly the
+ * results of otvae_conv_fwd / otvae_conv_bwd_data / otvae_conv_bwd_weight called once per job (same kernels bodies,
+ * same fixed-order reductions, same workspace layouts), but packs the MFMA-path jobs into one launch whose workgroups
+ * are divided among the jobs; jobs on another path (tiny channel counts) are launched one by one.  No job may read
+ * what another job of the same call writes.  `jobs` is a HOST array. */
+#define OTVAE_JOB_FWD 0
+#define OTVAE_JOB_BWD_DATA 1
+#define OTVAE_JOB_BWD_WEIGHT 2
+typedef struct otvae_conv_job {
+    int32_t kind;               /* OTVAE_JOB_* */
+    int32_t relu;               /* ReLU after the (optional) affine of the layer INPUT x */
+    int32_t has_bias;           /* BWD_WEIGHT */
+    int32_t defer_reduce;       /* BWD_WEIGHT */
+    otvae_conv_geom geom;
+    const float* x;             /* layer input [N][Hs][Ws][Cs] (BWD_DATA: only for the ReLU mask / BatchNorm sums) */
+    const float* scale;         /* BatchNorm scale/shift of x, or NULL */
+    const float* shift;
+    const float* w;             /* FWD: HWIO weight; BWD_DATA: dgrad-layout weight (otvae_weight_transpose) */
+    const float* bias;          /* FWD */
+    const float* residual;      /* FWD */
+    float* y;                   /* FWD */
+    double* stat_partial;       /* FWD (nullable) */
+    const float* gy;            /* BWD_DATA / BWD_WEIGHT: gradient of the layer output */
+    const float* mean;          /* BWD_DATA (nullable, with invstd and bn_partial) */
+    const float* invstd;
+    float* gv;                  /* BWD_DATA */
+    double* bn_partial;
+    float* wpartial;            /* BWD_WEIGHT workspace */
+    float* gw;                  /* BWD_WEIGHT */
+    float* gb;
+} otvae_conv_job;
+int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream);
+
 /* ---- QKVAttention (networks/nets_utils.py:63-82) ---------------------------------------------------------- */
 /* qkv [N][T][3*H*C] (channel = which*H*C + h*C + c) -> out [N][T][H*C]; lse [N][H][T] saved for backward. */
 int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, void* stream);

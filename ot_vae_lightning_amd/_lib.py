@@ -26,6 +26,17 @@ class ConvGeom(C.Structure):
 
 pg = C.POINTER(ConvGeom)
 
+JOB_FWD, JOB_BWD_DATA, JOB_BWD_WEIGHT = 0, 1, 2
+
+
+class ConvJob(C.Structure):  # otvae_conv_job
+    _fields_ = ([(n, C.c_int32) for n in ("kind", "relu", "has_bias", "defer_reduce")] + [("geom", ConvGeom)] +
+                [(n, C.c_void_p) for n in ("x", "scale", "shift", "w", "bias", "residual", "y", "stat_partial", "gy",
+                                           "mean", "invstd", "gv", "bn_partial", "wpartial", "gw", "gb")])
+
+
+pj = C.POINTER(ConvJob)
+
 # name -> (restype, argtypes); mirrors include/otvae.h one to one (tests/test_abi.py checks both directions)
 SIGNATURES = {
     "otvae_abi_version": (i32, []),
@@ -45,6 +56,7 @@ SIGNATURES = {
     "otvae_conv_bwd_weight_ws": (i32, [pg, i32, pi32]),
     "otvae_conv_bwd_weight": (i32, [pg, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
     "otvae_wgrad_reduce_batched": (i32, [i32, pp, pi32, pi32, pi32, pi32, pp, pp, vp]),
+    "otvae_conv_multi": (i32, [i32, pj, vp]),
     "otvae_attn_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvae_attn_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "otvae_gaussian_prior_fwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),

@@ -92,35 +92,56 @@ __device__ __forceinline__ void dgrad_row_to_pos(const Geom& g, unsigned row, in
     }
 }
 
+// LDS layout of one workgroup (carved out of a raw buffer so that the same body can run inside the multi-job kernel)
+template <int NT>
+struct GemmSmem {
+    static constexpr int BN = 16 * NT;
+    static constexpr int LDA = KC + 2;
+    static constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 0);
+    static constexpr size_t as_off = 0;
+    static constexpr size_t bs_off = as_off + sizeof(float) * 2 * TM * LDA;
+    static constexpr size_t red_off = bs_off + sizeof(float) * 2 * KC * LDB;
+    static constexpr size_t tap_off = red_off + sizeof(double) * 4 * 2 * BN;
+    static constexpr size_t row_off = tap_off + sizeof(int) * (3 * MAX_TAPS + 1);
+    static constexpr size_t bytes = (row_off + sizeof(int) * 3 * TM + 15) / 16 * 16;
+};
+
+// (bx, by, bz) / (gx, gz): the block's coordinates and the extent of the (virtual) grid of THIS layer
 template <int MODE, int NT, bool VEC>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __restrict__ S, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, int relu,
-                                                        const float* __restrict__ Bmat,
-                                                        // FWD epilogue
-                                                        const float* __restrict__ bias, const float* __restrict__ res,
-                                                        float* __restrict__ y,
-                                                        // DGRAD epilogue
-                                                        const float* __restrict__ xin, const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd, float* __restrict__ gv,
-                                                        double* __restrict__ partial, int CsPad) {
-    constexpr int BN = 16 * NT;
-    constexpr int LDA = KC + 2;
-    constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 0);
+__device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Geom& g, const float* __restrict__ S,
+                                               const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                               const float* __restrict__ Bmat,
+                                               // FWD epilogue
+                                               const float* __restrict__ bias, const float* __restrict__ res,
+                                               float* __restrict__ y,
+                                               // DGRAD epilogue
+                                               const float* __restrict__ xin, const float* __restrict__ mean,
+                                               const float* __restrict__ invstd, float* __restrict__ gv,
+                                               double* __restrict__ partial, int CsPad, int bx, int by, int bz, int gx,
+                                               int gz) {
+    using SM = GemmSmem<NT>;
+    constexpr int BN = SM::BN;
+    constexpr int LDA = SM::LDA;
+    constexpr int LDB = SM::LDB;
     constexpr int NB_ELEMS = KC * BN / 256;  // weight-tile elements staged per thread per chunk
-    __shared__ __align__(16) float As[2][TM * LDA];
-    __shared__ __align__(16) float Bs[2][KC * LDB];
-    __shared__ int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_w[MAX_TAPS];
-    __shared__ int s_ntaps;
-    __shared__ int row_n[TM], row_y[TM], row_x[TM];
-    __shared__ double red[4 * 2 * BN];
+    float(*As)[TM * LDA] = reinterpret_cast<float(*)[TM * LDA]>(smem + SM::as_off);
+    float(*Bs)[KC * LDB] = reinterpret_cast<float(*)[KC * LDB]>(smem + SM::bs_off);
+    double* red = reinterpret_cast<double*>(smem + SM::red_off);
+    int* tap_dy = reinterpret_cast<int*>(smem + SM::tap_off);
+    int* tap_dx = tap_dy + MAX_TAPS;
+    int* tap_w = tap_dx + MAX_TAPS;
+    int& s_ntaps = tap_w[MAX_TAPS];
+    int* row_n = reinterpret_cast<int*>(smem + SM::row_off);
+    int* row_y = row_n + TM;
+    int* row_x = row_y + TM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int cls = blockIdx.z, py = cls >> 1, px = cls & 1;
+    const int cls = bz, py = cls >> 1, px = cls & 1;
     const int Hu = g.Hs * g.up, Wu = g.Ws * g.up;
     const int CK = MODE == 0 ? g.Cs : g.Cn;
     const int NC = MODE == 0 ? g.Cn : g.Cs;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = by * BN;
     // source geometry seen by the gather: a tap is in range iff 0 <= t < lim, source coordinate = t >> sh
     const int lim_y = MODE == 0 ? Hu : g.Ho * g.stride, lim_x = MODE == 0 ? Wu : g.Wo * g.stride;
     const int sh = MODE == 0 ? g.up - 1 : g.stride - 1;
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
 #pragma unroll
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.0;
 
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (unsigned tile = bx; tile < ntiles; tile += gx) {
         __syncthreads();  // readers of row_* / LDS buffers of the previous tile are done
         if (tid < TM) {
             const unsigned row = tile * TM + tid;
@@ -464,11 +485,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
             const int which = tid / BN, cc = tid % BN;
             const double t = (red[(0 * 2 + which) * BN + cc] + red[(1 * 2 + which) * BN + cc]) +
                              (red[(2 * 2 + which) * BN + cc] + red[(3 * 2 + which) * BN + cc]);
-            const unsigned p = blockIdx.z * gridDim.x + blockIdx.x;
-            const unsigned Ptot = gridDim.x * gridDim.z;
+            const unsigned p = bz * gx + bx;
+            const unsigned Ptot = gx * gz;
             partial[((size_t)which * CsPad + n0 + cc) * Ptot + p] = t;  // [2][CsPad][P]
         }
     }
+}
+
+template <int MODE, int NT, bool VEC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __restrict__ S, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int relu,
+                                                        const float* __restrict__ Bmat, const float* __restrict__ bias,
+                                                        const float* __restrict__ res, float* __restrict__ y,
+                                                        const float* __restrict__ xin, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ gv,
+                                                        double* __restrict__ partial, int CsPad) {
+    __shared__ __align__(16) char smem[GemmSmem<NT>::bytes];
+    conv_gemm_body<MODE, NT, VEC>(smem, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad,
+                                  blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
 }
 
 template <int MODE, bool VEC>
@@ -648,23 +682,35 @@ extern "C" int otvae_conv_bwd_data(const otvae_conv_geom* gg, const float* gy, c
 // Block = 64 k-rows x (16*NT) n-cols, reduction over one pixel chunk in sub-chunks of 32 pixels staged in LDS
 // (At[pixel][k], Gt[pixel][n], double-buffered).  Row K (after the last tap*channel row) is the bias row: A = 1.
 #define PC 32
+template <int NT>
+struct WgradSmem {
+    static constexpr int BN = 16 * NT;
+    static constexpr int LDA = 64 + 16;
+    static constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 0);
+    static constexpr size_t at_off = 0;
+    static constexpr size_t gt_off = at_off + sizeof(float) * 2 * PC * LDA;
+    static constexpr size_t live_off = gt_off + sizeof(float) * 2 * PC * LDB;
+    static constexpr size_t bytes = live_off + 16;
+};
+
 template <int NT, bool VEC>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, int relu,
-                                                         const float* __restrict__ gy, float* __restrict__ partial, int Kp,
-                                                         int has_bias, unsigned chunk) {
-    constexpr int BN = 16 * NT;
-    constexpr int LDA = 64 + 16;
-    constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 0);
+__device__ __forceinline__ void conv_wgrad_body(char* __restrict__ smem, const Geom& g, const float* __restrict__ x,
+                                                const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                const float* __restrict__ gy, float* __restrict__ partial, int Kp,
+                                                int has_bias, unsigned chunk, int bx, int by, int bz) {
+    using SM = WgradSmem<NT>;
+    constexpr int BN = SM::BN;
+    constexpr int LDA = SM::LDA;
+    constexpr int LDB = SM::LDB;
     constexpr int NB_ELEMS = PC * BN / 256;
-    __shared__ __align__(16) float At[2][PC * LDA];
-    __shared__ __align__(16) float Gt[2][PC * LDB];
-    __shared__ int s_live[4];
+    float(*At)[PC * LDA] = reinterpret_cast<float(*)[PC * LDA]>(smem + SM::at_off);
+    float(*Gt)[PC * LDB] = reinterpret_cast<float(*)[PC * LDB]>(smem + SM::gt_off);
+    int* s_live = reinterpret_cast<int*>(smem + SM::live_off);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int kb = blockIdx.x, n0 = blockIdx.y * BN;
-    const unsigned pc = blockIdx.z;
+    const int kb = bx, n0 = by * BN;
+    const unsigned pc = bz;
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
     const unsigned mbeg = pc * chunk, mend = min(M, mbeg + chunk);
     const int K = g.KH * g.KW * g.Cs;
@@ -910,6 +956,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
     }
 }
 
+template <int NT, bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int relu,
+                                                         const float* __restrict__ gy, float* __restrict__ partial, int Kp,
+                                                         int has_bias, unsigned chunk) {
+    __shared__ __align__(16) char smem[WgradSmem<NT>::bytes];
+    conv_wgrad_body<NT, VEC>(smem, g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk, blockIdx.x, blockIdx.y,
+                             blockIdx.z);
+}
+
 // out[e] = sum_p partial[p][e] in a fixed order.
 //   few partials : 4 interleaved p-lanes per element, then p-lane 0..3 through LDS
 //   many partials: one wave per element, lanes stride over p, shuffle tree
@@ -1108,4 +1164,211 @@ extern "C" int otvae_wgrad_reduce_batched(int n, const float* const* partial, co
         OTVAE_CHECK_LAUNCH("otvae_wgrad_reduce_batched");
     }
     return OTVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-job launch
+// Up to CJ_MAX independent ConvLayer kernels (forward / data-gradient / weight-gradient bodies above, vector path) in
+// ONE launch: block b belongs to the job j with block0[j] <= b < block0[j+1] and runs that job's body with its own
+// virtual (bx, by, bz).  At this model's layer sizes a single job leaves most of the 256 CUs idle (10-500 workgroups),
+// and every launch costs ~4-5 us of fixed dispatch/flush time; the two branches of a ConvBlock and the wgrad/dgrad
+// pairs of the backward pass are independent, so they share a launch.
+#define CJ_MAX 4
+struct DevJob {
+    Geom g;
+    const float* a0;      // fwd: x            dgrad: gy           wgrad: x
+    const float* scale;
+    const float* shift;
+    const float* b0;      // fwd: HWIO weight  dgrad: wD           wgrad: gy
+    const float* bias;    // fwd
+    const float* res;     // fwd
+    const float* xin;     // dgrad: x
+    const float* mean;    // dgrad
+    const float* invstd;  // dgrad
+    float* out;           // fwd: y            dgrad: gv           wgrad: partial workspace
+    double* partial;      // fwd: stat partial dgrad: bn partial
+    int kind, NT, relu, cpad, Kp, has_bias;
+    unsigned chunk;
+    int gx, gy, gz, block0;
+};
+struct DevJobs {
+    int n;
+    DevJob j[CJ_MAX];
+};
+
+__global__ __launch_bounds__(256) void conv_jobs_kernel(DevJobs t) {
+    extern __shared__ __align__(16) char jobs_smem[];
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < CJ_MAX; ++i)
+        if (i < t.n && (int)blockIdx.x >= t.j[i].block0) ji = i;
+    const DevJob& J = t.j[ji];
+    const int lb = (int)blockIdx.x - J.block0;
+    const int bx = lb % J.gx;
+    const int r = lb / J.gx;
+    const int by = r % J.gy, bz = r / J.gy;
+#define CJ_FWD(N_)                                                                                                        \
+    conv_gemm_body<0, N_, true>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, J.bias, J.res, J.out, nullptr, nullptr, \
+                                nullptr, nullptr, J.partial, J.cpad, bx, by, bz, J.gx, J.gz)
+#define CJ_DGRAD(N_)                                                                                                      \
+    conv_gemm_body<1, N_, true>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, nullptr, nullptr, nullptr, J.xin,     \
+                                J.mean, J.invstd, J.out, J.partial, J.cpad, bx, by, bz, J.gx, J.gz)
+#define CJ_WGRAD(N_) \
+    conv_wgrad_body<N_, true>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, J.out, J.Kp, J.has_bias, J.chunk, bx, by, bz)
+    switch (J.kind * 4 + J.NT - 1) {
+        case 0: CJ_FWD(1); break;
+        case 1: CJ_FWD(2); break;
+        case 2: CJ_FWD(3); break;
+        case 3: CJ_FWD(4); break;
+        case 4: CJ_DGRAD(1); break;
+        case 5: CJ_DGRAD(2); break;
+        case 6: CJ_DGRAD(3); break;
+        case 7: CJ_DGRAD(4); break;
+        case 8: CJ_WGRAD(1); break;
+        case 9: CJ_WGRAD(2); break;
+        case 10: CJ_WGRAD(3); break;
+        default: CJ_WGRAD(4); break;
+    }
+#undef CJ_FWD
+#undef CJ_DGRAD
+#undef CJ_WGRAD
+}
+
+static size_t job_smem_bytes(int kind, int NT) {
+    if (kind == OTVAE_JOB_BWD_WEIGHT) {
+        switch (NT) {
+            case 1: return WgradSmem<1>::bytes;
+            case 2: return WgradSmem<2>::bytes;
+            case 3: return WgradSmem<3>::bytes;
+            default: return WgradSmem<4>::bytes;
+        }
+    }
+    switch (NT) {
+        case 1: return GemmSmem<1>::bytes;
+        case 2: return GemmSmem<2>::bytes;
+        case 3: return GemmSmem<3>::bytes;
+        default: return GemmSmem<4>::bytes;
+    }
+}
+
+static int run_single_job(const otvae_conv_job& jb, void* stream) {
+    switch (jb.kind) {
+        case OTVAE_JOB_FWD:
+            return otvae_conv_fwd(&jb.geom, jb.x, jb.scale, jb.shift, jb.relu, jb.w, jb.bias, jb.residual, jb.y,
+                                  jb.stat_partial, stream);
+        case OTVAE_JOB_BWD_DATA:
+            return otvae_conv_bwd_data(&jb.geom, jb.gy, jb.w, jb.x, jb.scale, jb.shift, jb.relu, jb.mean, jb.invstd, jb.gv,
+                                       jb.bn_partial, stream);
+        default:
+            return otvae_conv_bwd_weight(&jb.geom, jb.x, jb.scale, jb.shift, jb.relu, jb.gy, jb.has_bias, jb.wpartial, jb.gw,
+                                         jb.gb, jb.defer_reduce, stream);
+    }
+}
+
+extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream) {
+    OTVAE_REQUIRE(n > 0 && jobs, "otvae_conv_multi: no jobs");
+    hipStream_t st = (hipStream_t)stream;
+    DevJobs pack = {};
+    size_t smem = 0;
+    int nblocks = 0;
+    int packed_idx[CJ_MAX];
+    auto flush = [&]() -> int {
+        if (pack.n == 0) return OTVAE_OK;
+        if (pack.n == 1) {  // nothing to share a launch with: the dedicated kernel (static LDS, same body)
+            int rc = run_single_job(jobs[packed_idx[0]], stream);
+            pack = {};
+            smem = 0;
+            nblocks = 0;
+            return rc;
+        }
+        conv_jobs_kernel<<<nblocks, 256, smem, st>>>(pack);
+        OTVAE_CHECK_LAUNCH("otvae_conv_multi");
+        for (int i = 0; i < pack.n; ++i) {  // immediate reductions of the packed weight-gradient jobs
+            const otvae_conv_job& jb = jobs[packed_idx[i]];
+            if (jb.kind != OTVAE_JOB_BWD_WEIGHT || jb.defer_reduce) continue;
+            const DevJob& d = pack.j[i];
+            const size_t total = (size_t)d.Kp * d.g.Cn;
+            wgrad_reduce_kernel<<<imin(cdiv(total, d.gz >= 32 ? 4 : 64), 2048), 256, 0, st>>>(
+                jb.wpartial, d.gz, d.Kp - (jb.has_bias ? 1 : 0), d.Kp, d.g.Cn, jb.gw, jb.gb);
+            OTVAE_CHECK_LAUNCH("otvae_conv_multi(reduce)");
+        }
+        pack = {};
+        smem = 0;
+        nblocks = 0;
+        return OTVAE_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        const otvae_conv_job& jb = jobs[i];
+        OTVAE_REQUIRE(jb.kind >= OTVAE_JOB_FWD && jb.kind <= OTVAE_JOB_BWD_WEIGHT, "otvae_conv_multi: job %d: bad kind %d", i,
+                      jb.kind);
+        int rc = check_geom(&jb.geom, "otvae_conv_multi");
+        if (rc) return rc;
+        OTVAE_REQUIRE((jb.scale == nullptr) == (jb.shift == nullptr), "otvae_conv_multi: job %d: scale/shift must come together", i);
+        Geom g = to_geom(&jb.geom);
+        DevJob d = {};
+        d.g = g;
+        d.kind = jb.kind;
+        d.relu = jb.relu;
+        d.scale = jb.scale;
+        d.shift = jb.shift;
+        bool packable = false;
+        const bool ch4 = (g.Cs % 4 == 0) && (g.Cn % 4 == 0);
+        if (jb.kind == OTVAE_JOB_FWD) {
+            OTVAE_REQUIRE(jb.x && jb.w && jb.y, "otvae_conv_multi: job %d (forward): NULL tensor", i);
+            dim3 grid;
+            fwd_grid(g, d.NT, grid, d.cpad);
+            packable = !conv_small_ok(g) && ch4 && aligned16(jb.x) && aligned16(jb.w) &&
+                       (jb.scale == nullptr || (aligned16(jb.scale) && aligned16(jb.shift)));
+            d.a0 = jb.x;
+            d.b0 = jb.w;
+            d.bias = jb.bias;
+            d.res = jb.residual;
+            d.out = jb.y;
+            d.partial = jb.stat_partial;
+            d.gx = grid.x, d.gy = grid.y, d.gz = grid.z;
+        } else if (jb.kind == OTVAE_JOB_BWD_DATA) {
+            OTVAE_REQUIRE(jb.gy && jb.w && jb.gv, "otvae_conv_multi: job %d (data gradient): NULL tensor", i);
+            OTVAE_REQUIRE((jb.mean == nullptr) == (jb.invstd == nullptr), "otvae_conv_multi: job %d: mean/invstd must come together", i);
+            OTVAE_REQUIRE(!(jb.relu || jb.mean) || jb.x, "otvae_conv_multi: job %d: x needed for the ReLU mask / BatchNorm sums", i);
+            OTVAE_REQUIRE(!jb.mean || jb.bn_partial, "otvae_conv_multi: job %d: bn_partial workspace missing", i);
+            dim3 grid;
+            dgrad_grid(g, d.NT, grid, d.cpad);
+            packable = !conv_small_ok(g) && ch4 && aligned16(jb.gy) && aligned16(jb.w);
+            d.a0 = jb.gy;
+            d.b0 = jb.w;
+            d.xin = jb.x;
+            d.mean = jb.mean;
+            d.invstd = jb.invstd;
+            d.out = jb.gv;
+            d.partial = jb.bn_partial;
+            d.gx = grid.x, d.gy = grid.y, d.gz = grid.z;
+        } else {
+            OTVAE_REQUIRE(jb.x && jb.gy && jb.wpartial && jb.gw, "otvae_conv_multi: job %d (weight gradient): NULL tensor", i);
+            OTVAE_REQUIRE(!jb.has_bias || jb.gb, "otvae_conv_multi: job %d: gb missing", i);
+            int P, nkb, nnb;
+            wgrad_plan(g, jb.has_bias, d.NT, P, d.chunk, nkb, nnb, d.Kp);
+            packable = !conv_small_wgrad_ok(g) && ch4 && aligned16(jb.x) && aligned16(jb.gy) &&
+                       (jb.scale == nullptr || (aligned16(jb.scale) && aligned16(jb.shift)));
+            d.a0 = jb.x;
+            d.b0 = jb.gy;
+            d.out = jb.wpartial;
+            d.has_bias = jb.has_bias;
+            d.gx = nkb, d.gy = nnb, d.gz = P;
+        }
+        if (!packable) {
+            rc = run_single_job(jb, stream);
+            if (rc) return rc;
+            continue;
+        }
+        if (pack.n == CJ_MAX) {
+            rc = flush();
+            if (rc) return rc;
+        }
+        d.block0 = nblocks;
+        nblocks += d.gx * d.gy * d.gz;
+        const size_t need = job_smem_bytes(d.kind, d.NT);
+        if (need > smem) smem = need;
+        packed_idx[pack.n] = i;
+        pack.j[pack.n++] = d;
+    }
+    return flush();
 }

@@ -9,7 +9,6 @@ Nothing here computes on the CPU: tensors must be on the GPU and the HIP library
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -136,59 +135,6 @@ def bn_eval_affine(branch: BNBranch):
 
 
 # ------------------------------------------------------------------------------------------------ side stream
-class _SideStream:
-    """Fork/join helper for work that is off the critical path of backward (weight gradients).
-
-    ``with _SideStream(device) as side:`` makes the side stream wait for everything queued so far on the current
-    stream and switches to it; tensors passed to ``side.keep`` stay referenced until the join so that the caching
-    allocator cannot hand their memory to a later kernel of the main stream.  The join (main stream waits for the side
-    stream) is queued once per backward pass as an autograd-engine callback, i.e. before ``backward()`` returns and,
-    under hipGraph capture, before the capture ends (the side stream forks from and rejoins the capturing stream).
-    Measured on MI355X (round 1): the ~50 fork/join edges per step cost more than the overlap wins inside a captured
-    step (5.51 vs 5.01 ms), so it is OFF by default; ``OTVAE_SIDE_STREAM=1`` enables it."""
-    _state = {}
-    enabled = os.environ.get("OTVAE_SIDE_STREAM", "0") == "1"
-
-    def __init__(self, device):
-        self.device = device
-        st = _SideStream._state.get(device)
-        if st is None:
-            st = {"stream": torch.cuda.Stream(device=device), "keep": [], "pending": False}
-            _SideStream._state[device] = st
-        self.st = st
-        self.ctx = None
-
-    def keep(self, *tensors):
-        if _SideStream.enabled:
-            self.st["keep"].extend(t for t in tensors if t is not None)
-
-    def __enter__(self):
-        if not _SideStream.enabled:
-            return self
-        side = self.st["stream"]
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        if not self.st["pending"]:
-            self.st["pending"] = True
-            torch.autograd.Variable._execution_engine.queue_callback(lambda dev=self.device: _SideStream.join(dev))
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-    @staticmethod
-    def join(device):
-        st = _SideStream._state.get(device)
-        if st is None or not st["pending"]:
-            return
-        torch.cuda.current_stream(device).wait_stream(st["stream"])
-        st["keep"].clear()
-        st["pending"] = False
-
-
 class _PendingReduce:
     """Weight-gradient partials of the current backward pass whose destination is a trainer-owned flat gradient
     buffer, reduced together by ``flush`` (queued as an autograd-engine callback and called by the trainer before the
@@ -207,7 +153,6 @@ class _PendingReduce:
         st = _PendingReduce._state.get(device)
         if not st:
             return
-        _SideStream.join(device)
         lib = _lib.load()
         n = len(st)
         ia = lambda i: (C.c_int * n)(*[e[i] for e in st])  # noqa: E731
@@ -248,6 +193,8 @@ class _ConvBNFn(torch.autograd.Function):
         outs = []
         geoms = []
         ctx.out_stats = []
+        jobs = (_lib.ConvJob * nbr)()
+        keep = []
         for b, sp in enumerate(specs):
             w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
             g, ho, wo = _geom(x, w, sp.stride, sp.pad, sp.up)
@@ -258,12 +205,18 @@ class _ConvBNFn(torch.autograd.Function):
                 check(lib.otvae_conv_fwd_stats_ws(C.byref(g), C.byref(p_s), C.byref(ld)), "otvae_conv_fwd_stats_ws")
                 part = torch.empty((p_s.value, 2, ld.value), device=x.device, dtype=torch.float64)
                 st = (part, p_s.value, ld.value)
-            check(lib.otvae_conv_fwd(C.byref(g), ptr(x), ptr(scales[b]) if sp.has_norm else None,
-                                     ptr(shifts[b]) if sp.has_norm else None, int(sp.relu), ptr(w), ptr(bias), ptr(res),
-                                     ptr(y), ptr(part), stream()), "otvae_conv_fwd")
+            jb = jobs[b]
+            jb.kind, jb.relu, jb.geom = _lib.JOB_FWD, int(sp.relu), g
+            jb.x = ptr(x)
+            jb.scale = ptr(scales[b]) if sp.has_norm else None
+            jb.shift = ptr(shifts[b]) if sp.has_norm else None
+            jb.w, jb.bias, jb.residual, jb.y, jb.stat_partial = ptr(w), ptr(bias), ptr(res), ptr(y), ptr(part)
+            keep.append(part)
             outs.append(y)
             geoms.append(g)
             ctx.out_stats.append(st)
+        # both branches of a ConvBlock read the same x and are independent: one launch (otvae_conv_multi)
+        check(lib.otvae_conv_multi(nbr, jobs, stream()), "otvae_conv_multi(forward)")
         ctx.geoms = geoms
         stats_out.extend(ctx.out_stats)
         ctx.out_stats = None
@@ -285,6 +238,14 @@ class _ConvBNFn(torch.autograd.Function):
         gvs, partials, ps = [], [], []
         cspad = 0
         per_branch = []
+        # Weight- and data-gradient of every branch are independent of each other: all of them go into ONE launch
+        # (otvae_conv_multi).  When the weight gradient lands in a trainer-owned flat buffer (persistent memory, read by
+        # the optimizer and not through autograd's accumulation) its partial -> gradient reduction is deferred so that
+        # all layers of the backward pass reduce in one launch; otherwise it runs right after the multi launch:
+        # autograd may clone / accumulate the returned tensor before a deferred kernel would have filled it.
+        jobs = (_lib.ConvJob * (2 * nbr))()
+        njobs = 0
+        keep = []
         for b, sp in enumerate(specs):
             w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
             pw, pb, pgam, pbet = ctx.params_ref[b]
@@ -300,21 +261,16 @@ class _ConvBNFn(torch.autograd.Function):
             wpart = torch.empty((p_w.value, kk, g.Cn), device=x.device, dtype=torch.float32)
             gw = _grad_buffer(pw, w)
             gb = _grad_buffer(pb, bias) if sp.has_bias else None
-            # The weight gradient is a leaf of the backward graph (only the optimizer reads it), while the data gradient
-            # below is on the critical path: run it on a side HIP stream so the two overlap (every launch here is a
-            # few dozen workgroups, far from filling 256 CUs).  Joined at the end of the backward pass.
-            # When the gradient lands in a trainer-owned flat buffer (persistent memory, read by the optimizer and not
-            # through autograd's accumulation), the partial -> gradient reduction is deferred so that all layers of the
-            # backward pass reduce in ONE launch.  Otherwise it runs right away: autograd may clone / accumulate the
-            # returned tensor before a deferred kernel would have filled it.
             defer = (pw is not None and getattr(pw, "_otvae_grad_view", None) is not None and
                      (not sp.has_bias or getattr(pb, "_otvae_grad_view", None) is not None))
-            with _SideStream(x.device) as side:
-                side.keep(x, gy, wpart, gw, gb, scales[b], shifts[b])
-                check(lib.otvae_conv_bwd_weight(C.byref(g), ptr(x), ptr(scales[b]) if sp.has_norm else None,
-                                                ptr(shifts[b]) if sp.has_norm else None, int(sp.relu), ptr(gy),
-                                                int(sp.has_bias), ptr(wpart), ptr(gw), ptr(gb), int(defer), stream()),
-                      "otvae_conv_bwd_weight")
+            jb = jobs[njobs]
+            njobs += 1
+            jb.kind, jb.relu, jb.has_bias, jb.defer_reduce, jb.geom = _lib.JOB_BWD_WEIGHT, int(sp.relu), int(sp.has_bias), int(defer), g
+            jb.x, jb.gy = ptr(x), ptr(gy)
+            jb.scale = ptr(scales[b]) if sp.has_norm else None
+            jb.shift = ptr(shifts[b]) if sp.has_norm else None
+            jb.wpartial, jb.gw, jb.gb = ptr(wpart), ptr(gw), ptr(gb)
+            keep += [wpart, gy]
             if defer:
                 _PendingReduce.add(x.device, wpart, p_w.value, kk - (1 if sp.has_bias else 0), kk, g.Cn,
                                    gw.data_ptr(), gb.data_ptr() if gb is not None else None)
@@ -333,14 +289,19 @@ class _ConvBNFn(torch.autograd.Function):
                 if sp.has_norm:
                     part = torch.empty((p_d.value, 2, cp.value), device=x.device, dtype=torch.float64)
                     cspad = cp.value
-                check(lib.otvae_conv_bwd_data(C.byref(g), ptr(gy), ptr(wd), ptr(x),
-                                              ptr(scales[b]) if sp.has_norm else None,
-                                              ptr(shifts[b]) if sp.has_norm else None, int(sp.relu),
-                                              ptr(mean) if sp.has_norm else None, ptr(invstd) if sp.has_norm else None,
-                                              ptr(gv), ptr(part), stream()), "otvae_conv_bwd_data")
-                if sp.has_norm:
                     ps.append(p_d.value)
+                jb = jobs[njobs]
+                njobs += 1
+                jb.kind, jb.relu, jb.geom = _lib.JOB_BWD_DATA, int(sp.relu), g
+                jb.gy, jb.w, jb.x = ptr(gy), ptr(wd), ptr(x)
+                jb.scale = ptr(scales[b]) if sp.has_norm else None
+                jb.shift = ptr(shifts[b]) if sp.has_norm else None
+                jb.mean = ptr(mean) if sp.has_norm else None
+                jb.invstd = ptr(invstd) if sp.has_norm else None
+                jb.gv, jb.bn_partial = ptr(gv), ptr(part)
+                keep.append(wd)
             per_branch.append((gw, gb, gv, part, gy if sp.has_residual else None))
+        check(lib.otvae_conv_multi(njobs, jobs, stream()), "otvae_conv_multi(backward)")
         # --- BatchNorm backward over the branches that have one
         bn_idx = [b for b, sp in enumerate(specs) if sp.has_norm]
         dgam = {b: None for b in range(nbr)}
