@@ -18,6 +18,7 @@
 // dropped from K at kernel start.
 #include "common.h"
 #include "conv_small.h"  // struct Geom + the direct VALU kernels used when both channel counts are tiny
+#include "conv_tile.h"   // image-tile MFMA convolution (whole images in LDS) for maps up to 16x16
 
 static inline Geom to_geom(const otvae_conv_geom* g) {
     Geom r = {g->N, g->Hs, g->Ws, g->Cs, g->up, g->Ho, g->Wo, g->Cn, g->KH, g->KW, g->stride, g->pad};
@@ -551,6 +552,13 @@ extern "C" int otvae_conv_fwd_stats_ws(const otvae_conv_geom* gg, int* P, int* C
     dim3 grid;
     fwd_grid(g, NT, grid, cp);
     if (conv_small_ok(g)) grid.x = imin(grid.x, 1024);
+    TilePlan pl;
+    dim3 tg;
+    size_t sm;
+    if (!conv_small_ok(g) && conv_tile_plan(g, 0, pl, tg, sm)) {
+        grid.x = tg.x * tg.z;
+        cp = pl.cpad;
+    }
     if (P) *P = grid.x;
     if (CnPad) *CnPad = cp;
     return OTVAE_OK;
@@ -572,6 +580,20 @@ extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const f
                        (hipStream_t)stream);
         OTVAE_CHECK_LAUNCH("otvae_conv_fwd(small)");
         return OTVAE_OK;
+    }
+    {
+        TilePlan pl;
+        dim3 tg;
+        size_t sm;
+        if (conv_tile_plan(g, 0, pl, tg, sm)) {
+            OTVAE_REQUIRE(aligned16(x) && aligned16(wT) && aligned16(y) && (!bias || aligned16(bias)) &&
+                              (!residual || aligned16(residual)) && (!scale || (aligned16(scale) && aligned16(shift))),
+                          "otvae_conv_fwd: tensors of a layer with channel counts %% 4 == 0 must be 16-byte aligned");
+            rc = conv_tile_fwd(pl, tg, sm, (hipStream_t)stream, x, scale, shift, relu, wT, bias, residual, y, stat_partial);
+            OTVAE_REQUIRE(rc == 0, "otvae_conv_fwd: no image-tile kernel for nt=%d rbw=%d", pl.nt, pl.rbw);
+            OTVAE_CHECK_LAUNCH("otvae_conv_fwd(tile)");
+            return OTVAE_OK;
+        }
     }
     launch_gemm<0>(NT, grid, (hipStream_t)stream, g, x, scale, shift, relu, wT, bias, residual, y, nullptr, nullptr, nullptr,
                    nullptr, stat_partial, CnPad);
@@ -647,6 +669,13 @@ extern "C" int otvae_conv_bwd_data_ws(const otvae_conv_geom* gg, int* P, int* Cs
     dim3 grid;
     int cp;
     dgrad_grid(g, NT, grid, cp);
+    TilePlan pl;
+    dim3 tg;
+    size_t sm;
+    if (!conv_small_ok(g) && conv_tile_plan(g, 1, pl, tg, sm)) {
+        grid = tg;
+        cp = pl.cpad;
+    }
     if (P) *P = grid.x * grid.z;
     if (CsPad) *CsPad = cp;
     return OTVAE_OK;
@@ -671,6 +700,20 @@ extern "C" int otvae_conv_bwd_data(const otvae_conv_geom* gg, const float* gy, c
                          (hipStream_t)stream);
         OTVAE_CHECK_LAUNCH("otvae_conv_bwd_data(small)");
         return OTVAE_OK;
+    }
+    {
+        TilePlan pl;
+        dim3 tg;
+        size_t sm;
+        if (conv_tile_plan(g, 1, pl, tg, sm)) {
+            OTVAE_REQUIRE(aligned16(gy) && aligned16(wD) && aligned16(gv) && (!x || aligned16(x)) &&
+                              (!scale || (aligned16(scale) && aligned16(shift))) && (!mean || (aligned16(mean) && aligned16(invstd))),
+                          "otvae_conv_bwd_data: tensors of a layer with channel counts %% 4 == 0 must be 16-byte aligned");
+            rc = conv_tile_dgrad(pl, tg, sm, (hipStream_t)stream, gy, wD, x, scale, shift, relu, mean, invstd, gv, bn_partial);
+            OTVAE_REQUIRE(rc == 0, "otvae_conv_bwd_data: no image-tile kernel for nt=%d rbw=%d", pl.nt, pl.rbw);
+            OTVAE_CHECK_LAUNCH("otvae_conv_bwd_data(tile)");
+            return OTVAE_OK;
+        }
     }
     launch_gemm<1>(NT, grid, (hipStream_t)stream, g, gy, scale, shift, relu, wD, nullptr, nullptr, nullptr, x, mean, invstd, gv,
                    bn_partial, CsPad);
@@ -1022,12 +1065,12 @@ static void wgrad_plan(const Geom& g, int has_bias, int& NT, int& P, unsigned& c
         conv_small_wgrad_plan(g, P, chunk);
         return;
     }
-    // enough workgroups to fill the chip several times over (256 CUs x ~3 resident x 4 rounds: the kernel is latency-
-    // bound per 32-pixel step, short chains + many resident blocks hide it), pixel chunks of >= 128 pixels,
-    // workspace <= 16 MiB, P <= 2048
-    int want = cdiv(3072, nkb * nnb);
+    // ~1024 workgroups (4 per CU; measured on MI355X: 768..3072 are within 1 % of each other for the whole step, fewer
+    // partials mean less workspace traffic), pixel chunks of >= 128 pixels, workspace <= 16 MiB, P <= 2048
+    const unsigned ws_cap = 4u << 20;
+    int want = cdiv(1024, nkb * nnb);
     int maxp_pix = imax(1, (int)(M / 128));
-    int maxp_ws = imax(1, (int)((4u << 20) / ((unsigned)Kp * g.Cn)));
+    int maxp_ws = imax(1, (int)(ws_cap / ((unsigned)Kp * g.Cn)));
     P = imax(1, imin(imin(want, maxp_pix), imin(maxp_ws, 2048)));
     chunk = ((M + P - 1) / P + PC - 1) / PC * PC;
     P = cdiv(M, chunk);
@@ -1108,6 +1151,7 @@ struct WrbDesc {
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
+    __shared__ float red[4][64];
     const int l = blockIdx.y;
     const float* __restrict__ partial = d.partial[l];
     float* __restrict__ gw = d.gw[l];
@@ -1115,7 +1159,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
     const int P = d.P[l], K = d.K[l], Cn = d.Cn[l];
     const size_t total = (size_t)d.Kp[l] * Cn;
     const int lane = threadIdx.x & 63;
-    if (P >= 16) {  // one wave per element
+    if (total >= 4096 && P >= 16) {
+        // large gradient: partial rows are far apart (total*4 bytes), so lanes run along e (coalesced 256-byte reads)
+        // and the 4 waves split the partials; fixed order: p ascending within a wave, then waves 0..3 through LDS
+        const int pg = threadIdx.x >> 6;
+        for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
+            const size_t e = e0 + lane;
+            float s = 0.f;
+            if (e < total) {
+                int p = pg;
+                for (; p + 12 < P; p += 16) {
+                    const float a0 = partial[(size_t)p * total + e], a1 = partial[(size_t)(p + 4) * total + e];
+                    const float a2 = partial[(size_t)(p + 8) * total + e], a3 = partial[(size_t)(p + 12) * total + e];
+                    s += a0;
+                    s += a1;
+                    s += a2;
+                    s += a3;
+                }
+                for (; p < P; p += 4) s += partial[(size_t)p * total + e];
+            }
+            red[pg][lane] = s;
+            __syncthreads();
+            if (pg == 0 && e < total) {
+                const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+                const int k = e / Cn;
+                if (k < K) gw[e] = t;
+                else if (gb) gb[e - (size_t)K * Cn] = t;
+            }
+            __syncthreads();
+        }
+    } else if (P >= 16) {  // small gradient, many partials: one wave per element (neighbouring waves share the lines)
         for (size_t e = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (size_t)gridDim.x * 4) {
             float s = 0.f;
             for (int p = lane; p < P; p += 64) s += partial[(size_t)p * total + e];
@@ -1156,7 +1229,7 @@ extern "C" int otvae_wgrad_reduce_batched(int n, const float* const* partial, co
             d.Kp[i] = Kp[j];
             d.Cn[i] = Cn[j];
             const size_t total = (size_t)Kp[j] * Cn[j];
-            const size_t work = P[j] >= 16 ? cdiv(total, 4) : cdiv(total, 256);
+            const size_t work = P[j] < 16 ? cdiv(total, 256) : (total >= 4096 ? cdiv(total, 64) : cdiv(total, 4));
             if (work > maxwork) maxwork = work;
         }
         dim3 grid(imin((int)maxwork, 512), m);
@@ -1318,6 +1391,12 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             fwd_grid(g, d.NT, grid, d.cpad);
             packable = !conv_small_ok(g) && ch4 && aligned16(jb.x) && aligned16(jb.w) &&
                        (jb.scale == nullptr || (aligned16(jb.scale) && aligned16(jb.shift)));
+            {
+                TilePlan pl;
+                dim3 tg;
+                size_t sm;
+                if (packable && conv_tile_plan(g, 0, pl, tg, sm)) packable = false;  // image-tile kernel: own launch
+            }
             d.a0 = jb.x;
             d.b0 = jb.w;
             d.bias = jb.bias;
@@ -1333,6 +1412,12 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             dim3 grid;
             dgrad_grid(g, d.NT, grid, d.cpad);
             packable = !conv_small_ok(g) && ch4 && aligned16(jb.gy) && aligned16(jb.w);
+            {
+                TilePlan pl;
+                dim3 tg;
+                size_t sm;
+                if (packable && conv_tile_plan(g, 1, pl, tg, sm)) packable = false;  // image-tile kernel: own launch
+            }
             d.a0 = jb.gy;
             d.b0 = jb.w;
             d.xin = jb.x;
