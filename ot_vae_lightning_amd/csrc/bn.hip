@@ -73,36 +73,51 @@ struct BnFin {
     float* shift[2];
 };
 
-// one wave per channel: lanes stride over the <= 256 partials, fixed-order shuffle tree
+// WPC waves per channel (1 when there are few partials, 4 = one block per channel otherwise): lanes stride over the
+// partials, fixed-order shuffle tree, then (WPC == 4) the 4 waves through LDS in wave order
+template <int WPC>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int P, int ld, int64_t M, int C,
                                                           float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                           int n_bn, BnFin f) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = WPC == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int sub = WPC == 4 ? wave : 0;
+    double s = 0.0, q = 0.0;
     if (c < C) {
-        double s = 0.0, q = 0.0;
-        for (int p = lane; p < P; p += 64) {
-            s += partial[((size_t)0 * ld + c) * P + p];  // [2][ld][P]: lanes read consecutive p
-            q += partial[((size_t)1 * ld + c) * P + p];
+        const double* ps = partial + ((size_t)0 * ld + c) * P;  // [2][ld][P]: lanes read consecutive p
+        const double* pq = partial + ((size_t)1 * ld + c) * P;
+        for (int p = sub * 64 + lane; p < P; p += 64 * WPC) {
+            s += ps[p];
+            q += pq[p];
         }
         s = wave_sum(s);
         q = wave_sum(q);
+    }
+    if (WPC == 4) {
         if (lane == 0) {
-            const double mu = s / (double)M;
-            double var = q / (double)M - mu * mu;
-            if (var < 0.0) var = 0.0;
-            const float fmu = (float)mu;
-            const float fis = (float)(1.0 / sqrt(var + (double)eps));
-            mean[c] = fmu;
-            invstd[c] = fis;
-            const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-            for (int b = 0; b < n_bn; ++b) {
-                const float sc = f.gamma[b][c] * fis;
-                f.scale[b][c] = sc;
-                f.shift[b][c] = fmaf(-fmu, sc, f.beta[b][c]);
-                if (f.rmean[b]) f.rmean[b][c] = (1.f - momentum) * f.rmean[b][c] + momentum * fmu;
-                if (f.rvar[b]) f.rvar[b][c] = (1.f - momentum) * f.rvar[b][c] + momentum * (float)unbiased;
-            }
+            red[wave][0] = s;
+            red[wave][1] = q;
+        }
+        __syncthreads();
+        s = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        q = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+    if (c < C && lane == 0 && sub == 0) {
+        const double mu = s / (double)M;
+        double var = q / (double)M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float fmu = (float)mu;
+        const float fis = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = fmu;
+        invstd[c] = fis;
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        for (int b = 0; b < n_bn; ++b) {
+            const float sc = f.gamma[b][c] * fis;
+            f.scale[b][c] = sc;
+            f.shift[b][c] = fmaf(-fmu, sc, f.beta[b][c]);
+            if (f.rmean[b]) f.rmean[b][c] = (1.f - momentum) * f.rmean[b][c] + momentum * fmu;
+            if (f.rvar[b]) f.rvar[b][c] = (1.f - momentum) * f.rvar[b][c] + momentum * (float)unbiased;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -127,7 +142,10 @@ extern "C" int otvae_bn_finalize(const double* partial, int P, int ld, int64_t M
         f.scale[b] = scale[b];
         f.shift[b] = shift[b];
     }
-    bn_finalize_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partial, P, ld, M, C, eps, momentum, mean, invstd, n_bn, f);
+    if (P >= 256)
+        bn_finalize_kernel<4><<<C, 256, 0, (hipStream_t)stream>>>(partial, P, ld, M, C, eps, momentum, mean, invstd, n_bn, f);
+    else
+        bn_finalize_kernel<1><<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partial, P, ld, M, C, eps, momentum, mean, invstd, n_bn, f);
     OTVAE_CHECK_LAUNCH("otvae_bn_finalize");
     return OTVAE_OK;
 }
@@ -146,37 +164,56 @@ struct BnBwdFin {
     float* dbeta[2];
 };
 
+template <int WPC>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int nb, BnBwdFin f, int CsPad, int64_t M, int C,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               float* __restrict__ coef) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ double red[2][4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = WPC == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int sub = WPC == 4 ? wave : 0;
+    const bool in = c < C;
+    double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+    for (int b = 0; b < nb; ++b) {
+        if (in) {
+            const double* p1 = f.partial[b] + ((size_t)0 * CsPad + c) * f.P[b];
+            const double* p2 = f.partial[b] + ((size_t)1 * CsPad + c) * f.P[b];
+            double a = 0.0, q = 0.0;
+            for (int p = sub * 64 + lane; p < f.P[b]; p += 64 * WPC) {
+                a += p1[p];
+                q += p2[p];
+            }
+            s1[b] = wave_sum(a);
+            s2[b] = wave_sum(q);
+        }
+    }
+    if (WPC == 4) {
+        if (lane == 0)
+            for (int b = 0; b < nb; ++b) {
+                red[b][wave][0] = s1[b];
+                red[b][wave][1] = s2[b];
+            }
+        __syncthreads();
+        for (int b = 0; b < nb; ++b) {
+            s1[b] = (red[b][0][0] + red[b][1][0]) + (red[b][2][0] + red[b][3][0]);
+            s2[b] = (red[b][0][1] + red[b][1][1]) + (red[b][2][1] + red[b][3][1]);
+        }
+    }
+    if (!in || lane != 0 || sub != 0) return;
     const double is = (double)invstd[c], mu = (double)mean[c];
     double A = 0.0, B = 0.0;
     for (int b = 0; b < nb; ++b) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int p = lane; p < f.P[b]; p += 64) {
-            s1 += f.partial[b][((size_t)0 * CsPad + c) * f.P[b] + p];
-            s2 += f.partial[b][((size_t)1 * CsPad + c) * f.P[b] + p];
-        }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
         const double k = (double)f.gamma[b][c] * is;
-        if (lane == 0) {
-            if (f.dbeta[b]) f.dbeta[b][c] = (float)s1;
-            if (f.dgamma[b]) f.dgamma[b][c] = (float)s2;
-            coef[(size_t)(2 + b) * C + c] = (float)k;
-        }
-        A += k * s2;
-        B += k * s1;
+        if (f.dbeta[b]) f.dbeta[b][c] = (float)s1[b];
+        if (f.dgamma[b]) f.dgamma[b][c] = (float)s2[b];
+        coef[(size_t)(2 + b) * C + c] = (float)k;
+        A += k * s2[b];
+        B += k * s1[b];
     }
-    if (lane == 0) {
-        A = A * is / (double)M;
-        B = B / (double)M - A * mu;
-        coef[c] = (float)A;
-        coef[(size_t)C + c] = (float)B;
-    }
+    A = A * is / (double)M;
+    B = B / (double)M - A * mu;
+    coef[c] = (float)A;
+    coef[(size_t)C + c] = (float)B;
 }
 
 extern "C" int otvae_bn_bwd_finalize(int nb, const double* const* bn_partial, const int* P, int CsPad, int64_t M, int C,
@@ -194,7 +231,10 @@ extern "C" int otvae_bn_bwd_finalize(int nb, const double* const* bn_partial, co
         f.dgamma[b] = dgamma ? dgamma[b] : nullptr;
         f.dbeta[b] = dbeta ? dbeta[b] : nullptr;
     }
-    bn_bwd_finalize_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(nb, f, CsPad, M, C, mean, invstd, coef);
+    if (imax(P[0], nb > 1 ? P[1] : 0) >= 256)
+        bn_bwd_finalize_kernel<4><<<C, 256, 0, (hipStream_t)stream>>>(nb, f, CsPad, M, C, mean, invstd, coef);
+    else
+        bn_bwd_finalize_kernel<1><<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(nb, f, CsPad, M, C, mean, invstd, coef);
     OTVAE_CHECK_LAUNCH("otvae_bn_bwd_finalize");
     return OTVAE_OK;
 }
