@@ -163,15 +163,26 @@ extern "C" int otvae_mean_cov(const double* n_obs, const double* sum_x, const do
 #define EIGH_MAX_D 128
 #define EIGH_MAX_SWEEPS 24
 
+#define EIGB 16                 // block size of the block-Jacobi driver (D > EIGH_MAX_D): 32 x 32 sub-problems
+#define EIGH_BLOCK_MAX_D 2048
+#define EIGH_BLOCK_SWEEPS 14
+
+static int eigb_dp(int D) { return (D + 2 * EIGB - 1) / (2 * EIGB) * (2 * EIGB); }
+
 extern "C" int64_t otvae_eigh_ws(int nb, int D) {
     if (nb <= 0 || D <= 0) return -1;
-    return (int64_t)nb * D * D * (int64_t)sizeof(double);
+    if (D <= EIGH_MAX_D) return (int64_t)nb * D * D * (int64_t)sizeof(double);
+    // block driver (one matrix at a time): Aw[Dp][Dp], Vt[Dp][Dp], S and U [Dp/32][32][32], sub-eigenvalues, dense
+    // D x D copies for the f(A) product, convergence flag
+    const int64_t Dp = eigb_dp(D), np = Dp / (2 * EIGB);
+    return (2 * Dp * Dp + 2 * np * 4 * EIGB * EIGB + np * 2 * EIGB + 2 * (int64_t)D * D + 8) * (int64_t)sizeof(double);
 }
 
 __global__ __launch_bounds__(EIGH_THREADS) void eigh_kernel(const double* __restrict__ Ain, int D, int fn,
                                                             double* __restrict__ out, double* __restrict__ eigvals,
-                                                            double* __restrict__ vt_ws) {
+                                                            double* __restrict__ vt_ws, const int* __restrict__ skip) {
     extern __shared__ __align__(16) double lds[];
+    if (skip != nullptr && *skip) return;  // block-Jacobi driver: the big matrix has already converged
     const int LD = D + 1;
     const int De = (D + 1) & ~1;  // even number of players; index D (if De > D) is a dummy
     const int half = De / 2;
@@ -298,6 +309,147 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_kernel(const double* __rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ D > 128: block Jacobi
+// Two-sided block Jacobi with the parallel (round-robin) ordering: the index set is cut into blocks of EIGB; a round
+// pairs the blocks into Dp/(2 EIGB) disjoint pairs (I, J); each pair's 32 x 32 sub-matrix [A_II A_IJ; A_JI A_JJ] is
+// diagonalised in LDS by eigh_kernel (U = its eigenvector rows), then rows I u J of A and of V^T are replaced by
+// U * rows, and columns I u J of A by cols * U^T.  A and V^T (8 MiB each at D = 1024) stay L2/MALL-resident.  No host
+// synchronisation: convergence is a device flag that turns the remaining launches into no-ops.
+__device__ __forceinline__ void eb_pair(int round, int k, int nblk, int& I, int& J) {
+    const int m = nblk - 1;
+    if (k == 0) {
+        I = m;
+        J = round % m;
+    } else {
+        I = (round + k) % m;
+        J = (round - k + m) % m;
+    }
+    if (I > J) {
+        const int t = I;
+        I = J;
+        J = t;
+    }
+}
+__device__ __forceinline__ int eb_index(int a, int I, int J) { return a < EIGB ? I * EIGB + a : J * EIGB + (a - EIGB); }
+
+__global__ __launch_bounds__(256) void eb_init_kernel(const double* __restrict__ Ain, int D, int Dp, double* __restrict__ Aw,
+                                                      double* __restrict__ Vt, int* __restrict__ done) {
+    for (size_t e = blockIdx.x * 256 + threadIdx.x; e < (size_t)Dp * Dp; e += (size_t)gridDim.x * 256) {
+        const int i = e / Dp, j = e - (size_t)i * Dp;
+        double v = 0.0;
+        if (i < D && j < D) v = (i >= j) ? Ain[(size_t)i * D + j] : Ain[(size_t)j * D + i];
+        Aw[e] = v;
+        Vt[e] = (i == j) ? 1.0 : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *done = 0;
+}
+
+__global__ __launch_bounds__(1024) void eb_conv_kernel(const double* __restrict__ Aw, int Dp, int* __restrict__ done) {
+    __shared__ double red[2][16];
+    if (*done) return;
+    double off = 0.0, tot = 0.0;
+    for (size_t e = threadIdx.x; e < (size_t)Dp * Dp; e += 1024) {
+        const int i = e / Dp, j = e - (size_t)i * Dp;
+        const double v = Aw[e];
+        tot += v * v;
+        if (i != j) off += v * v;
+    }
+    off = wave_sum(off);
+    tot = wave_sum(tot);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = off;
+        red[1][threadIdx.x >> 6] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double o = 0.0, t = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            o += red[0][w];
+            t += red[1][w];
+        }
+        if (o <= 1e-27 * t || t == 0.0) *done = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void eb_gather_kernel(const double* __restrict__ Aw, int Dp, int round, int nblk,
+                                                        double* __restrict__ S, const int* __restrict__ done) {
+    if (*done) return;
+    int I, J;
+    eb_pair(round, blockIdx.x, nblk, I, J);
+    double* Sk = S + (size_t)blockIdx.x * 4 * EIGB * EIGB;
+    for (int e = threadIdx.x; e < 4 * EIGB * EIGB; e += 256) {
+        const int a = e / (2 * EIGB), c = e - a * (2 * EIGB);
+        Sk[e] = Aw[(size_t)eb_index(a, I, J) * Dp + eb_index(c, I, J)];
+    }
+}
+
+// rows I u J of M (= A for blockIdx.z == 0, V^T for 1) <- U_k * rows; one thread per column
+__global__ __launch_bounds__(256) void eb_rows_kernel(double* __restrict__ Aw, double* __restrict__ Vt, const double* __restrict__ U,
+                                                      int Dp, int round, int nblk, const int* __restrict__ done) {
+    __shared__ double Us[2 * EIGB][2 * EIGB + 1];
+    if (*done) return;
+    int I, J;
+    eb_pair(round, blockIdx.y, nblk, I, J);
+    const double* Uk = U + (size_t)blockIdx.y * 4 * EIGB * EIGB;
+    for (int e = threadIdx.x; e < 4 * EIGB * EIGB; e += 256) Us[e / (2 * EIGB)][e % (2 * EIGB)] = Uk[e];
+    __syncthreads();
+    double* M = blockIdx.z == 0 ? Aw : Vt;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Dp) return;
+    double v[2 * EIGB];
+#pragma unroll
+    for (int c = 0; c < 2 * EIGB; ++c) v[c] = M[(size_t)eb_index(c, I, J) * Dp + j];
+    for (int r = 0; r < 2 * EIGB; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 2 * EIGB; ++c) s = fma(Us[r][c], v[c], s);
+        M[(size_t)eb_index(r, I, J) * Dp + j] = s;
+    }
+}
+
+// columns I u J of A <- cols * U_k^T; one thread per row
+__global__ __launch_bounds__(256) void eb_cols_kernel(double* __restrict__ Aw, const double* __restrict__ U, int Dp, int round,
+                                                      int nblk, const int* __restrict__ done) {
+    __shared__ double Us[2 * EIGB][2 * EIGB + 1];
+    if (*done) return;
+    int I, J;
+    eb_pair(round, blockIdx.y, nblk, I, J);
+    const double* Uk = U + (size_t)blockIdx.y * 4 * EIGB * EIGB;
+    for (int e = threadIdx.x; e < 4 * EIGB * EIGB; e += 256) Us[e / (2 * EIGB)][e % (2 * EIGB)] = Uk[e];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Dp) return;
+    double v[2 * EIGB];
+    double* row = Aw + (size_t)i * Dp;
+#pragma unroll
+    for (int c = 0; c < 2 * EIGB; ++c) v[c] = row[eb_index(c, I, J)];
+    for (int r = 0; r < 2 * EIGB; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 2 * EIGB; ++c) s = fma(v[c], Us[r][c], s);
+        row[eb_index(r, I, J)] = s;
+    }
+}
+
+// eigenvalues, and dense D x D operands of f(A) = Vd^T (diag(f(lambda)) Vd)
+__global__ __launch_bounds__(256) void eb_finish_kernel(const double* __restrict__ Aw, const double* __restrict__ Vt, int D, int Dp,
+                                                        int fn, double* __restrict__ eigvals, double* __restrict__ Vd,
+                                                        double* __restrict__ Td) {
+    for (size_t e = blockIdx.x * 256 + threadIdx.x; e < (size_t)D * D; e += (size_t)gridDim.x * 256) {
+        const int k = e / D, j = e - (size_t)k * D;
+        const double lam = Aw[(size_t)k * Dp + k];
+        if (j == 0) eigvals[k] = lam;
+        if (fn != 0) {
+            const double v = Vt[(size_t)k * Dp + j];
+            Vd[e] = v;
+            Td[e] = ((fn == 1) ? sqrt(lam) : 1.0 / sqrt(lam)) * v;
+        }
+    }
+}
+
+static int eigh_block(const double* A, int nb, int D, int fn, double* out, double* eigvals, double* ws, hipStream_t st);
+
 static size_t eigh_lds_bytes(int D) {
     const int De = (D + 1) & ~1, half = De / 2;
     return ((size_t)D * (D + 1) + 2 * half + 16) * sizeof(double) + (2 * half + 2) * sizeof(int);
@@ -308,10 +460,7 @@ extern "C" int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out
     OTVAE_REQUIRE(A && eigvals && ws && nb > 0 && D > 0, "otvae_eigh_fn: bad argument");
     OTVAE_REQUIRE(fn >= 0 && fn <= 2, "otvae_eigh_fn: fn must be 0, 1 or 2");
     OTVAE_REQUIRE(fn == 0 || out, "otvae_eigh_fn: out missing");
-    if (D > EIGH_MAX_D) {
-        otvae_set_error("otvae_eigh_fn: D = %d > %d is not implemented (matrix must fit LDS)", D, EIGH_MAX_D);
-        return OTVAE_EUNSUPPORTED;
-    }
+    if (D > EIGH_MAX_D) return eigh_block(A, nb, D, fn, out, eigvals, (double*)ws, (hipStream_t)stream);
     const size_t lds = eigh_lds_bytes(D);
     if (lds > 65536 && lds > g_eigh_lds_set) {
         if (hipFuncSetAttribute((const void*)eigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -320,7 +469,7 @@ extern "C" int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out
         }
         g_eigh_lds_set = 160 * 1024;
     }
-    eigh_kernel<<<nb, EIGH_THREADS, lds, (hipStream_t)stream>>>(A, D, fn, out, eigvals, (double*)ws);
+    eigh_kernel<<<nb, EIGH_THREADS, lds, (hipStream_t)stream>>>(A, D, fn, out, eigvals, (double*)ws, nullptr);
     OTVAE_CHECK_LAUNCH("otvae_eigh_fn");
     return OTVAE_OK;
 }
@@ -393,6 +542,43 @@ extern "C" int otvae_gemm_f64(int transA, int transB, int nb, int m, int n, int 
     gemm_f64_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(transA, transB, m, n, k, alpha, A, a_bcast ? 0 : (size_t)m * k, B,
                                                           b_bcast ? 0 : (size_t)k * n, beta, C);
     OTVAE_CHECK_LAUNCH("otvae_gemm_f64");
+    return OTVAE_OK;
+}
+
+static int eigh_block(const double* A, int nb, int D, int fn, double* out, double* eigvals, double* ws, hipStream_t st) {
+    if (D > EIGH_BLOCK_MAX_D) {
+        otvae_set_error("otvae_eigh_fn: D = %d > %d is not implemented", D, EIGH_BLOCK_MAX_D);
+        return OTVAE_EUNSUPPORTED;
+    }
+    const int Dp = eigb_dp(D), nblk = Dp / EIGB, np = nblk / 2, S2 = 2 * EIGB;
+    double* Aw = ws;
+    double* Vt = Aw + (size_t)Dp * Dp;
+    double* S = Vt + (size_t)Dp * Dp;
+    double* U = S + (size_t)np * S2 * S2;
+    double* evs = U + (size_t)np * S2 * S2;
+    double* Vd = evs + (size_t)np * S2;
+    double* Td = Vd + (size_t)D * D;
+    int* done = reinterpret_cast<int*>(Td + (size_t)D * D);
+    const size_t lds = eigh_lds_bytes(S2);
+    const int chunks = cdiv(Dp, 256);
+    for (int b = 0; b < nb; ++b) {
+        const double* Ab = A + (size_t)b * D * D;
+        eb_init_kernel<<<imin(cdiv((size_t)Dp * Dp, 256), 2048), 256, 0, st>>>(Ab, D, Dp, Aw, Vt, done);
+        for (int sweep = 0; sweep < EIGH_BLOCK_SWEEPS; ++sweep) {
+            eb_conv_kernel<<<1, 1024, 0, st>>>(Aw, Dp, done);
+            for (int round = 0; round < nblk - 1; ++round) {
+                eb_gather_kernel<<<np, 256, 0, st>>>(Aw, Dp, round, nblk, S, done);
+                eigh_kernel<<<np, EIGH_THREADS, lds, st>>>(S, S2, 0, nullptr, evs, U, done);
+                eb_rows_kernel<<<dim3(chunks, np, 2), 256, 0, st>>>(Aw, Vt, U, Dp, round, nblk, done);
+                eb_cols_kernel<<<dim3(chunks, np), 256, 0, st>>>(Aw, U, Dp, round, nblk, done);
+            }
+        }
+        eb_finish_kernel<<<imin(cdiv((size_t)D * D, 256), 2048), 256, 0, st>>>(Aw, Vt, D, Dp, fn, eigvals + (size_t)b * D, Vd, Td);
+        if (fn != 0)  // out = Vd^T * Td
+            gemm_f64_kernel<<<dim3(cdiv(D, 16), cdiv(D, 16), 1), 256, 0, st>>>(1, 0, D, D, D, 1.0, Vd, 0, Td, 0, 0.0,
+                                                                             out + (size_t)b * D * D);
+        OTVAE_CHECK_LAUNCH("otvae_eigh_fn(block)");
+    }
     return OTVAE_OK;
 }
 

@@ -455,3 +455,51 @@ def test_empirical_cov_streaming_matches_full(A):
     assert (mean - mean_all).norm() / mean_all.norm() < 1e-8
     assert (cov - cov_all).norm() / cov_all.norm() < 1e-8
     assert A.w2_gaussian(mean_all, mean, cov_all, cov, make_pd=True).abs().item() < 1e-4
+
+
+@pytest.mark.parametrize("D", [129, 200, 512, 1024])
+def test_block_jacobi_eigh_large_D(A, D):
+    """eigh-based matrix functions for D > 128 (tests/test_latent_transport.py:70 of the
+    reference transports 64x4x4 = 1024-dimensional latents).  Checker: torch.linalg.eigh on the CPU in fp64."""
+    from ot_vae_lightning_amd.ot import matrix_utils as MU
+    rep = Report(f"block-Jacobi eigh D={D} vs torch.linalg.eigh (CPU, fp64)")
+    g = torch.Generator().manual_seed(100 + D)
+    x = torch.randn(3 * D, D, generator=g, dtype=torch.float64) * torch.linspace(0.2, 3.0, D, dtype=torch.float64)
+    cov = (x.T @ x) / x.shape[0]
+    lam, vec = torch.linalg.eigh(cov)
+    ev, sq = MU.eigvals_and_fn(cov.cuda(), 1)
+    rep.check("eigenvalues (sorted)", torch.sort(ev.cpu())[0], lam, tol=1e-10)
+    want = (vec * lam.sqrt()) @ vec.T
+    rep.check("sqrtm", sq, want, tol=1e-9)
+    rep.check("sqrtm @ sqrtm == cov", (sq @ sq), cov, tol=1e-9)
+    isq = MU.invsqrtm(cov.cuda())
+    rep.check("invsqrtm", isq, (vec / lam.sqrt()) @ vec.T, tol=1e-8)
+    # lower triangle is what counts (torch.linalg.eigh UPLO='L'): garbage in the strict upper triangle is ignored
+    junk = cov.clone()
+    junk[torch.triu(torch.ones(D, D, dtype=torch.bool), 1)] = 7.0
+    rep.check("UPLO='L'", MU.eigvals_and_fn(junk.cuda(), 1)[1], want, tol=1e-9)
+    rep.finish()
+
+
+def test_gaussian_transport_1024_dims_vs_oracle(A):
+    """W2 + transport operator at the reference's latent-transport test size (D = 1024, transport_dims (1,2,3))."""
+    import otvae_oracle as O
+    rep = Report("GaussianTransport D=1024 vs CPU oracle (fp64)")
+    D, B = 1024, 3000
+    g = torch.Generator().manual_seed(9)
+    mix = torch.randn(D, D, generator=g, dtype=torch.float64) / D ** 0.5
+    src = torch.randn(B, D, generator=g, dtype=torch.float64) @ mix * 1.5 + 0.3
+    tgt = torch.randn(B, D, generator=g, dtype=torch.float64)
+    op = A.GaussianTransport(D, source_cfg=dict(dtype=torch.double), target_cfg=dict(dtype=torch.double),
+                             transport_cfg=dict(make_pd=True)).cuda()
+    op.update(source_samples=src.cuda(), target_samples=tgt.cuda())
+    w2 = op.compute()
+    n_s, sx_s, sxx_s = O.gaussian_stats(src)
+    n_t, sx_t, sxx_t = O.gaussian_stats(tgt)
+    ms, cs = O.gaussian_fit(n_s, sx_s, sxx_s)
+    mt, ct = O.gaussian_fit(n_t, sx_t, sxx_t)
+    rep.check("W2^2", w2, O.w2_gaussian(ms, mt, cs, ct, make_pd=True), tol=1e-8)
+    T = O.transport_operator_full(cs, ct)
+    probe = src[:64]
+    rep.check("transported samples", op.transport(probe.cuda()), O.apply_transport(probe, ms, mt, T), tol=1e-7)
+    rep.finish()
