@@ -204,5 +204,8 @@ def test_error_behaviour(A):
     with pytest.raises(ValueError):
         A.sinkhorn_log(a, a, torch.rand(3, 4, device="cuda"))
     with pytest.raises(NotImplementedError):
-        A.w2_gaussian(torch.zeros(200, device="cuda"), torch.zeros(200, device="cuda"),
-                      torch.eye(200, device="cuda"), torch.eye(200, device="cuda"))   # D > 128 this round
+        A.w2_gaussian(torch.zeros(2100, device="cuda"), torch.zeros(2100, device="cuda"),
+                      torch.eye(2100, device="cuda"), torch.eye(2100, device="cuda"))   # D > 2048: not implemented
+    w = A.w2_gaussian(torch.zeros(200, device="cuda"), torch.ones(200, device="cuda"),
+                      torch.eye(200, device="cuda"), torch.eye(200, device="cuda"))   # block-Jacobi path
+    assert abs(float(w) - 200.0) < 1e-9
