@@ -51,11 +51,43 @@ def host_threads() -> int:
     return max(1, min(n, 16))
 
 
-def build_model(A, seed=0):
+def build_model(A, seed=0, workload="gaussian"):
     torch.manual_seed(seed)
-    enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
     dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    if workload == "sinkhorn":  # BASELINE configs[2]: deterministic encoder + entropic OT prior (eps 0.05, 50 iterations)
+        enc = A.CNN(1, 128, 32, 1, capacity=8, down_sample=True, residual="add")
+        return A.VAE(encoder=enc, decoder=dec, prior=A.SinkhornPrior(reg=0.05, max_iter=50, threshold=0.0))
+    enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
     return A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1))
+
+
+def time_sinkhorn(A, n=1024, d=128, iters=50, reps=20):
+    """The OT term alone (configs[2] shapes): cost matrix + 50 log-domain Sinkhorn iterations + sum(C * pi), HIP events."""
+    from ot_vae_lightning_amd.ot import w2_utils as W
+    g = torch.Generator().manual_seed(7)
+    z = torch.randn(n, d, generator=g).cuda()
+    y = torch.randn(n, d, generator=g).cuda()
+    a = torch.full((n,), 1.0 / n, device="cuda")
+
+    def solve():
+        C = W.sq_euclidean_cost(z, y)
+        pi = W.sinkhorn_log(a, a, C / C.max(), reg=0.05, max_iter=iters, threshold=0.0)
+        return W.ot_cost(C, pi)
+
+    for _ in range(3):
+        solve()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        cost = solve()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    # per iteration: one log-sum-exp pass over the rows of Cr and one over its transposed copy (SURVEY section 8d)
+    return {"n": n, "m": n, "iterations": iters, "ms_per_solve": round(ms, 4), "us_per_iteration": round(ms * 1e3 / iters, 3),
+            "exp_per_s": round(2.0 * n * n * iters / (ms * 1e-3), 1),
+            "l2_resident_read_gbytes_per_s": round(2.0 * n * n * 4 * iters / (ms * 1e-3) / 1e9, 1), "ot_cost": float(cost)}
 
 
 def cpu_baseline(A, batch=250, steps=3, warmup=1):
@@ -162,6 +194,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--workload", choices=["gaussian", "sinkhorn"], default="gaussian",
+                    help="gaussian = BASELINE configs[1] (the metric's configuration, default); sinkhorn = configs[2]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,7 +217,7 @@ def main():
     from ot_vae_lightning_amd.utils.synthetic import mnist_like
 
     B = PER_GPU_BATCH
-    model = build_model(A).cuda().train()
+    model = build_model(A, workload=args.workload).cuda().train()
     A.broadcast_module(model, src=0)  # identical replicas (no-op for one rank)
     latent_model = A.GaussianTransport(128, source_cfg=dict(dtype=torch.double, reduce_on_update=False),
                                        target_cfg=dict(dtype=torch.double, reduce_on_update=False),
@@ -222,8 +256,11 @@ def main():
             "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MNIST-32 CNN VAE (capacity 8, latent 128x1x1, residual=add) + GaussianPrior("
-                                   "loss_coeff=0.1): fwd+bwd+Adam + latent Gaussian statistics update, hipGraph replay",
+            "config": {"workload": ("MNIST-32 CNN VAE (capacity 8, latent 128x1x1, residual=add) + GaussianPrior("
+                                    "loss_coeff=0.1): fwd+bwd+Adam + latent Gaussian statistics update, hipGraph replay")
+                       if args.workload == "gaussian" else
+                       ("MNIST-32 CNN VAE (capacity 8, latent 128x1x1, residual=add) + Sinkhorn OT prior (eps=0.05, "
+                        "50 iterations, 1024x1024 plan): fwd+bwd+Adam + latent Gaussian statistics update"),
                        "per_gpu_batch": B, "global_batch": world * B,
                        "parallelism": f"dp{world}" if world > 1 else "single GPU"},
             "final_loss": final_loss,
@@ -238,6 +275,8 @@ def main():
                                  "%.2f T (query,key) pair evaluations/s (each: 1 v_exp_f32 + ~5 VALU); its HBM traffic "
                                  "equals its algorithmic bytes" % (dom["pair_evals"] / dom["ms"] / 1e9)},
         }
+        if args.workload == "sinkhorn":
+            line["sinkhorn"] = time_sinkhorn(A)
         if world == 1:
             try:
                 line["parity"] = parity_check(A)
