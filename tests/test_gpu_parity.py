@@ -503,3 +503,32 @@ def test_gaussian_transport_1024_dims_vs_oracle(A):
     probe = src[:64]
     rep.check("transported samples", op.transport(probe.cuda()), O.apply_transport(probe, ms, mt, T), tol=1e-7)
     rep.finish()
+
+
+def test_sinkhorn_persistent_equals_multilaunch(A):
+    """The opt-in one-launch solver (grid barrier, rows in registers; slower on MI355X, see sinkhorn.hip) and the default
+    launch-per-half-iteration solver run the same arithmetic per row: plan, potentials and iteration count must be
+    identical bits, including the early exit."""
+    import os
+    from ot_vae_lightning_amd.ot import w2_utils as W
+    cases = [((), 1024, 1024, torch.float32, 0.05, 50, 0.0),      # bench shape: rows cached in registers
+             ((), 100, 37, torch.float64, 0.1, 200, 1e-9),         # non-square, early exit
+             ((2, 3), 33, 65, torch.float32, 0.05, 300, 1e-3),     # batched: min-over-batch early exit
+             ((), 1500, 700, torch.float32, 0.05, 20, 0.0),        # more rows than resident waves, rows > 1024
+             ((), 7, 5, torch.float64, 1.0, 0, 0.0)]               # no iteration at all
+    for lead, n, m, dt, reg, it, thr in cases:
+        a, b, C = _sinkhorn_problem(lead, n, m, dt, seed=n + m)
+        a, b, C = a.cuda(), b.cuda(), C.cuda()
+        if dt == torch.float32 and reg < 0.1:
+            C = C / C.max()
+        ref = W.sinkhorn_log_potentials(a, b, C, reg=reg, max_iter=it, threshold=thr)
+        os.environ["OTVAE_SK_PERSISTENT"] = "1"
+        try:
+            got = W.sinkhorn_log_potentials(a, b, C, reg=reg, max_iter=it, threshold=thr)
+        finally:
+            del os.environ["OTVAE_SK_PERSISTENT"]
+        torch.cuda.synchronize()
+        assert int(got[3]) == int(ref[3]) and int(got[3]) >= 0, (n, m, int(got[3]), int(ref[3]))
+        for g, r, name in zip(got[:3], ref[:3], ("pi", "u", "v")):
+            assert torch.equal(g, r), (n, m, name, float((g - r).abs().max()))
+        assert torch.isfinite(got[0]).all()
