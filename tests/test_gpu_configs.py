@@ -209,3 +209,37 @@ def test_error_behaviour(A):
     w = A.w2_gaussian(torch.zeros(200, device="cuda"), torch.ones(200, device="cuda"),
                       torch.eye(200, device="cuda"), torch.eye(200, device="cuda"))   # block-Jacobi path
     assert abs(float(w) - 200.0) < 1e-9
+
+
+@pytest.mark.parametrize("D", [128, 256])
+def test_config5_latent_transport_token_shape_vs_oracle(A, D):
+    """BASELINE configs[4] / SURVEY 8(d) C5: ViT token latents [512, 1, D] (one token per image: leading shape (1,),
+    samples laid out [tokens, batch, D] as `permute_and_flatten(batch_first=False)` gives them), a GaussianModel.update
+    per training step for source and target, one GaussianTransport.compute at validation, transport of a batch."""
+    rep = Report(f"config 5 latent transport, tokens [512, 1, {D}] vs CPU oracle")
+    steps, B = 4, 512
+    g = torch.Generator().manual_seed(45)
+    src = [(torch.randn(1, B, D, generator=g) * 2 + 1) for _ in range(steps)]
+    tgt = [torch.randn(1, B, D, generator=g) for _ in range(steps)]
+    op = A.GaussianTransport(1, D, source_cfg=dict(dtype=torch.double), target_cfg=dict(dtype=torch.double),
+                             transport_cfg=dict(make_pd=True)).cuda()
+    for s, t in zip(src, tgt):
+        op.update(source_samples=s.cuda(), target_samples=t.cuda())
+    w2 = op.compute()
+    n = torch.zeros(1, dtype=torch.float64)
+    acc = {k: [torch.zeros(1, dtype=torch.float64), torch.zeros(1, D, dtype=torch.float64),
+               torch.zeros(1, D, D, dtype=torch.float64)] for k in ("s", "t")}
+    for s, t in zip(src, tgt):
+        for k, x in (("s", s), ("t", t)):
+            ni, sx, sxx = O.gaussian_stats(x)
+            acc[k][0] += ni
+            acc[k][1] += sx
+            acc[k][2] += sxx
+    ms, cs = O.gaussian_fit(*acc["s"])
+    mt, ct = O.gaussian_fit(*acc["t"])
+    rep.check("W2^2", w2, O.w2_gaussian(ms, mt, cs, ct, make_pd=True), tol=1e-8)
+    T = O.transport_operator_full(cs, ct)
+    rep.check("transport operator", op.transport_operator, T, tol=1e-7)
+    probe = src[0][:, :32]
+    rep.check("transported tokens", op.transport(probe.cuda()), O.apply_transport(probe.double(), ms, mt, T).float(), tol=1e-5)
+    rep.finish()
