@@ -16,6 +16,8 @@
 // Same arithmetic as conv.hip (reference networks/cnn.py:183-192 and its autograd backward): products accumulate in
 // fp32 over k = (tap, channel) in the same tap-major order; BatchNorm / BatchNorm-backward partial sums in fp64 with the
 // fixed lane -> wave -> block order; workspace layouts ([2][cpad][P]) identical to the implicit-GEMM kernels.
+#include <type_traits>
+
 #include "common.h"
 #include "conv_tile.h"
 
@@ -175,18 +177,30 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float
         for (int tl = 0; tl < tcount; ++tl) {
             const int toff = tp.off[t0 + tl];
             const float* wr = Wl + (size_t)(tl * CK + kq) * BN + r16;
-#pragma unroll 4
-            for (int c0 = 0; c0 < CK; c0 += 4) {
-                float w[NT];
+            // KS k-steps (4 channels each) per trip: all LDS reads of the trip are issued before its MFMAs, so one
+            // lgkmcnt wait covers KS*(NT+RBW) reads instead of one wait per MFMA group (the loop is latency-bound at
+            // one wave per SIMD otherwise).  Accumulation order over k is unchanged.
+            auto ksteps = [&](int c0, auto ks_tag) {
+                constexpr int KS = decltype(ks_tag)::value;
+                float w[KS][NT], a[KS][RBW];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) w[j] = wr[c0 * BN + j * 16];
+                for (int s = 0; s < KS; ++s) {
 #pragma unroll
-                for (int i = 0; i < RBW; ++i) {
-                    const float a = V[pixbase[i] + toff + c0];
+                    for (int j = 0; j < NT; ++j) w[s][j] = wr[(c0 + 4 * s) * BN + j * 16];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(w[j], a, acc[i][j]);
+                    for (int i = 0; i < RBW; ++i) a[s][i] = V[pixbase[i] + toff + c0 + 4 * s];
                 }
-            }
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int i = 0; i < RBW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(w[s][j], a[s][i], acc[i][j]);
+            };
+            int c0 = 0;
+            for (; c0 + 16 <= CK; c0 += 16) ksteps(c0, std::integral_constant<int, 4>{});
+            for (; c0 + 8 <= CK; c0 += 8) ksteps(c0, std::integral_constant<int, 2>{});
+            for (; c0 < CK; c0 += 4) ksteps(c0, std::integral_constant<int, 1>{});
         }
         if (ch + 1 < nchunk) {
             __syncthreads();
@@ -294,11 +308,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double a = s1[j][r], b = s2[j][r];
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    a += __shfl_xor(a, m, 64);
-                    b += __shfl_xor(b, m, 64);
-                }
+                a += __shfl_xor(a, 1, 64), b += __shfl_xor(b, 1, 64);
+                a += __shfl_xor(a, 2, 64), b += __shfl_xor(b, 2, 64);
+                a += __shfl_xor(a, 4, 64), b += __shfl_xor(b, 4, 64);
+                a += __shfl_xor(a, 8, 64), b += __shfl_xor(b, 8, 64);
                 if (r16 == 0) {
                     red[(wave * 2 + 0) * BN + j * 16 + kq * 4 + r] = a;
                     red[(wave * 2 + 1) * BN + j * 16 + kq * 4 + r] = b;
