@@ -219,6 +219,14 @@ int otvae_apply_transport(int dtype, const void* x, const double* ms, const doub
  *      base.py:216-233): x[nb][B][d], codebook[nb][K][d] -> idx[nb][B] (int64), enc[nb][B][d] = codebook[idx] */
 int otvae_codebook_assign(const float* x, const float* codebook, int nb, int B, int K, int d, float temperature,
                           int64_t* idx, float* enc, void* stream);
+/* The assignment distribution itself (base.py:216-224): probs[nb][B][K] = softmax_k(energy/temperature), and
+ * (nullable) entropy[nb][B] = -sum_k p log p, which the CodebookPrior 'kl' loss uses (prior/codebook.py:81-82). */
+int otvae_codebook_probs(const float* x, const float* codebook, int nb, int B, int K, int d, float temperature,
+                         float* probs, float* entropy, void* stream);
+/* k-means sufficient statistics for one-hot ('argmax') assignments (MixtureMixin.kmean_iteration, base.py:241-252):
+ * counts[nb][K] = number of samples per atom, sums[nb][K][d] = their sum, members added in increasing sample order. */
+int otvae_codebook_kmeans(const float* x, const int64_t* idx, int nb, int B, int K, int d, float* counts, float* sums,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ Fixtures:
   gaussian_ot.npz    GaussianModel.update/fit, mean_cov, w2_gaussian, compute_transport_operators,
                      apply_transport, GaussianTransport.compute/transport
   codebook.npz       CodebookModel.predict argmax indices + encodings
+  codebook_kmeans.npz  CodebookModel.update/fit/predict/w2 (streaming k-means)
 """
 import math
 import os
@@ -405,7 +406,48 @@ def gen_codebook():
     save("codebook.npz", out)
 
 
+def gen_codebook_kmeans():
+    """G9: CodebookModel.update x 6 (streaming k-means, with and without EMA decay) -> fit -> predict /
+    distribution / w2, driven through the reference's own class in 'argmax' mode."""
+    cb = R.ref("ot.distribution_models.codebook_model")
+    out = {}
+    for tag, lead, K, d, B, decay in (("sum", (2,), 6, 4, 64, None), ("ema", (1,), 10, 3, 128, 0.9)):
+        torch.manual_seed(5)
+        model = cb.CodebookModel(*lead, d, update_decay=decay,
+                                 mixture_cfg=dict(n_components=K, training_mode="argmax", inference_mode="argmax"))
+        model.train()
+        g = torch.Generator().manual_seed(11)
+        centres = torch.randn(*lead, K, d, generator=g) * 3.0
+        out[f"{tag}/cfg"] = np.array([K, d, B, -1.0 if decay is None else decay])
+        out[f"{tag}/vec_init"], out[f"{tag}/mat_init"] = npy(model.vec_init), npy(model.mat_init)
+        batches = []
+        for step in range(6):
+            which = torch.randint(0, K, (*lead, B), generator=g)
+            x = torch.gather(centres, -2, which.unsqueeze(-1).expand(*lead, B, d)) + 0.3 * torch.randn(*lead, B, d, generator=g)
+            batches.append(x)
+            if step == 0:
+                torch.manual_seed(1234)  # the randperm of _init_parameters draws from the host generator
+            model.update(x)
+            out[f"{tag}/step{step}/codebook"] = npy(model.codebook).copy()  # buffers are updated in place: snapshot
+            out[f"{tag}/step{step}/n_obs"] = npy(model._n_obs).copy()
+            out[f"{tag}/step{step}/running_sum"] = npy(model._running_sum).copy()
+        out[f"{tag}/batches"] = npy(torch.stack(batches))
+        model.fit()
+        out[f"{tag}/fit/codebook"] = npy(model.codebook)
+        model.eval()
+        probe = batches[-1]
+        preds, _, dist = model.predict(probe)
+        out[f"{tag}/predict/preds"], out[f"{tag}/predict/probs"] = npy(preds), npy(dist.probs)
+        out[f"{tag}/predict/entropy"] = npy(dist.entropy())
+        out[f"{tag}/weights"] = npy(model.weights)
+        other = cb.CategoricalEmbeddings(centres, probs=torch.ones(*lead, K) / K)
+        out[f"{tag}/centres"] = npy(centres)
+        out[f"{tag}/w2"] = npy(model.w2(other))
+    save("codebook_kmeans.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook"]
+    which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
+                             "codebook_kmeans"]
     for w in which:
         globals()["gen_" + w]()

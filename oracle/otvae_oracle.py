@@ -377,3 +377,60 @@ def codebook_assign(x: Tensor, codebook: Tensor, temperature: float = 1.0, p: fl
     idx = weights.argmax(-1)
     onehot = F.one_hot(idx, energy.size(-1)).to(weights.dtype)
     return onehot @ codebook, idx
+
+
+# ------------------------------------------------------------------------------------------------ codebook k-means
+def codebook_probs(x: Tensor, codebook: Tensor, temperature: float = 1.0) -> Tensor:
+    """``MixtureMixin.assign`` soft weights (base.py:216-224) with ``CodebookModel.energy`` (codebook_model.py:150-156):
+    softmax_k((1 / (cdist(x, c) + 1e-8)) / T)."""
+    energy = 1 / (torch.cdist(x, codebook, 2.0) + 1e-8)
+    return torch.softmax(energy / temperature, dim=-1)
+
+
+def codebook_kmeans_stats(x: Tensor, codebook: Tensor, temperature: float = 1.0):
+    """``kmean_iteration`` with one-hot ('argmax') weights (base.py:241-252): (counts [*, K], sums [*, K, d])."""
+    w = torch.nn.functional.one_hot(codebook_probs(x, codebook, temperature).argmax(-1), codebook.shape[-2]).type_as(x)
+    return w.sum(-2), w.transpose(-1, -2) @ x
+
+
+def _laplace(x: Tensor, n_categories: int, eps: Optional[float] = 1e-5) -> Tensor:
+    """utils/__init__.py:209-218"""
+    if eps is None:
+        return x
+    return (x + eps) / (x.sum(-1, keepdim=True) + n_categories * eps) * x.sum(-1, keepdim=True)
+
+
+def codebook_update(state: Dict[str, Tensor], x: Tensor, decay: Optional[float], rand_indices: Optional[Tensor] = None,
+                    temperature: float = 1.0, laplace_eps: Optional[float] = 1e-5) -> Dict[str, Tensor]:
+    """``CodebookModel.update`` (codebook_model.py:121-130, 189-214) on a state {codebook, vec_init, n_obs, running_sum}:
+    first-call initialisation from ``rand_indices`` (the reference draws them with torch.randperm), one-hot k-means
+    statistics, (EMA) accumulation into the buffers of the observed atoms, codebook = running_sum / smoothed counts."""
+    st = {k: v.clone() for k, v in state.items()}
+    K = st["codebook"].shape[-2]
+    if torch.allclose(st["codebook"], st["vec_init"]):
+        st["codebook"] = x[..., rand_indices, :].clone()
+        st["n_obs"] = st["n_obs"] + 1
+    counts, sums = codebook_kmeans_stats(x, st["codebook"], temperature)
+    hit = counts > 1e-8
+    st["n_obs"][hit] = ema(st["n_obs"][hit], counts[hit], decay)
+    st["running_sum"][hit] = ema(st["running_sum"][hit], sums[hit], decay)
+    hit2 = st["n_obs"] > 1e-8
+    st["codebook"][hit2] = st["running_sum"][hit2] / _laplace(st["n_obs"][hit2], K, laplace_eps).unsqueeze(-1)
+    return st
+
+
+def codebook_fit(state: Dict[str, Tensor], laplace_eps: Optional[float] = 1e-5) -> Dict[str, Tensor]:
+    """``CodebookModel.fit()`` without samples (codebook_model.py:132-143): the codebook recomputed from the buffers."""
+    st = {k: v.clone() for k, v in state.items()}
+    K = st["codebook"].shape[-2]
+    hit = st["n_obs"] > 1e-8
+    st["codebook"][hit] = st["running_sum"][hit] / _laplace(st["n_obs"][hit], K, laplace_eps).unsqueeze(-1)
+    return st
+
+
+def codebook_w2(codebook: Tensor, weights: Tensor, other_atoms: Tensor, other_probs: Tensor) -> Tensor:
+    """``CodebookModel.w2`` (codebook_model.py:175-182): entropic OT (reg 1e-5, 100 iterations, threshold 1e-3) between
+    the atom sets with cost 1 / (energy + 1e-8)."""
+    cost = 1 / (1 / (torch.cdist(other_atoms, codebook, 2.0) + 1e-8) + 1e-8)
+    plan = sinkhorn_log(weights, other_probs, cost, reg=1e-5, max_iter=100, threshold=1e-3)
+    return torch.sum(cost * plan, dim=(-2, -1))

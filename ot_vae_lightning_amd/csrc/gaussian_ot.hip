@@ -686,3 +686,98 @@ extern "C" int otvae_codebook_assign(const float* x, const float* codebook, int 
     OTVAE_CHECK_LAUNCH("otvae_codebook_assign");
     return OTVAE_OK;
 }
+
+// probs[b][r][k] = softmax_k((1 / (|x_r - c_k|_2 + 1e-8)) / temperature) (MixtureMixin.assign, base.py:216-224) and,
+// optionally, its entropy per sample (CodebookPrior 'kl' loss, prior/codebook.py:81-82).  One wave per sample.
+__global__ __launch_bounds__(256) void codebook_probs_kernel(const float* __restrict__ x, const float* __restrict__ cb, int B,
+                                                             int K, int d, float inv_temp, float* __restrict__ probs,
+                                                             float* __restrict__ entropy) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (r >= B) return;
+    const float* xr = x + ((size_t)b * B + r) * d;
+    const float* cbb = cb + (size_t)b * K * d;
+    float* pr = probs + ((size_t)b * B + r) * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) {
+        float s = 0.f;
+        for (int j = 0; j < d; ++j) {
+            const float t = xr[j] - cbb[(size_t)k * d + j];
+            s = fmaf(t, t, s);
+        }
+        const float e = (1.f / (sqrtf(s) + 1e-8f)) * inv_temp;
+        pr[k] = e;  // energies first, normalised below (same lane re-reads its own stores)
+        mx = fmaxf(mx, e);
+    }
+    mx = wave_max(mx);
+    float z = 0.f;
+    for (int k = lane; k < K; k += 64) z += __expf(pr[k] - mx);
+    z = wave_sum(z);
+    const float inv_z = 1.f / z, logz = __logf(z);
+    float h = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float t = pr[k] - mx;
+        const float p = __expf(t) * inv_z;
+        pr[k] = p;
+        h -= p * (t - logz);  // -sum p log p with log p = t - log z
+    }
+    h = wave_sum(h);
+    if (entropy != nullptr && lane == 0) entropy[(size_t)b * B + r] = h;
+}
+
+extern "C" int otvae_codebook_probs(const float* x, const float* codebook, int nb, int B, int K, int d, float temperature,
+                                    float* probs, float* entropy, void* stream) {
+    OTVAE_REQUIRE(x && codebook && probs && nb > 0 && B > 0 && K > 0 && d > 0, "otvae_codebook_probs: bad argument");
+    OTVAE_REQUIRE(temperature > 0.f, "otvae_codebook_probs: temperature must be positive");
+    codebook_probs_kernel<<<dim3(cdiv(B, 4), nb), 256, 0, (hipStream_t)stream>>>(x, codebook, B, K, d, 1.f / temperature, probs,
+                                                                               entropy);
+    OTVAE_CHECK_LAUNCH("otvae_codebook_probs");
+    return OTVAE_OK;
+}
+
+// One-hot k-means accumulation (MixtureMixin.kmean_iteration with 'argmax' weights, base.py:241-252):
+// counts[b][k] = #{r : idx_r = k}, sums[b][k][:] = sum_{r : idx_r = k} x_r, members added in increasing r (fixed order).
+// One block per (atom, problem): the block scans the index vector once, then its threads own the d coordinates.
+__global__ __launch_bounds__(256) void codebook_kmeans_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int B,
+                                                              int K, int d, float* __restrict__ counts, float* __restrict__ sums) {
+    extern __shared__ int members[];  // rows assigned to this atom, ascending
+    __shared__ int s_n;
+    const int k = blockIdx.x, b = blockIdx.y;
+    const int64_t* ib = idx + (size_t)b * B;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // ordered compaction, 256 rows per round: ballot per wave, wave offsets through LDS
+    __shared__ int wcount[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r0 = 0; r0 < B; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        const bool hit = r < B && ib[r] == (int64_t)k;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int base = s_n;
+        for (int w = 0; w < wave; ++w) base += wcount[w];
+        if (hit) members[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        if (threadIdx.x == 0) s_n += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    const int n = s_n;
+    if (threadIdx.x == 0) counts[(size_t)b * K + k] = (float)n;
+    const float* xb = x + (size_t)b * B * d;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        float s = 0.f;
+        for (int m = 0; m < n; ++m) s += xb[(size_t)members[m] * d + j];
+        sums[((size_t)b * K + k) * d + j] = s;
+    }
+}
+
+extern "C" int otvae_codebook_kmeans(const float* x, const int64_t* idx, int nb, int B, int K, int d, float* counts, float* sums,
+                                     void* stream) {
+    OTVAE_REQUIRE(x && idx && counts && sums && nb > 0 && B > 0 && K > 0 && d > 0, "otvae_codebook_kmeans: bad argument");
+    OTVAE_REQUIRE((size_t)B * sizeof(int) <= 60 * 1024, "otvae_codebook_kmeans: more than 15360 samples per call unsupported");
+    codebook_kmeans_kernel<<<dim3(K, nb), 256, (size_t)B * sizeof(int), (hipStream_t)stream>>>(x, idx, B, K, d, counts, sums);
+    OTVAE_CHECK_LAUNCH("otvae_codebook_kmeans");
+    return OTVAE_OK;
+}

@@ -1,0 +1,252 @@
+"""``CodebookModel`` / ``CategoricalEmbeddings`` with the reference's contract
+(ot/distribution_models/codebook_model.py:25-214, mixture behaviour from base.py:165-262): a set of K atoms per
+leading index, fitted by (EMA) k-means on streaming batches, queried by nearest-atom assignment.
+
+MI355X path: the O(B*K*d) work -- energies, arg-max assignment, the assignment distribution and the k-means sufficient
+statistics -- runs in HIP kernels (``otvae_codebook_assign / _probs / _kmeans``); the O(K*d) buffer arithmetic that
+follows is a handful of tiny tensor expressions kept in the reference's own order (boolean-mask updates, Laplace
+smoothing over the observed atoms), and ``w2`` composes the HIP Sinkhorn solver exactly as the reference does.
+
+Supported: ``metric='euclidean'``, ``p=2``, ``topk=None``, one-hot modes (``'argmax'``) for training and inference,
+``update_with_autograd=False``.  The stochastic / soft modes of the reference ('sample', 'mean', 'gumbel-*') belong to its
+DAD models (out of scope) and raise ``NotImplementedError``."""
+from functools import partial
+from typing import Optional, Tuple
+
+import torch
+import torch.distributions as D
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from ... import _lib, utils
+from ..._lib import check, ptr, stream
+from ..w2_utils import sinkhorn_log
+from .base import DistributionModel
+
+__all__ = ["CodebookModel", "CategoricalEmbeddings"]
+
+
+class CategoricalEmbeddings(D.Categorical):
+    """Categorical over K atoms that samples / averages the atoms themselves (codebook_model.py:25-63)."""
+
+    def __init__(self, embeddings: Tensor, probs: Optional[Tensor] = None, logits: Optional[Tensor] = None) -> None:
+        super().__init__(probs, logits)
+        self.embeddings = embeddings
+        if self.probs.shape != self.embeddings.shape[:-1]:
+            raise ValueError("`probs` and `embeddings` should have the same leading dimensions")
+
+    def _select(self, weights: Tensor) -> Tensor:
+        return (weights.unsqueeze(-2).type_as(self.embeddings) @ self.embeddings).squeeze(-2)
+
+    def _select_one_hot(self, index_list: Tensor) -> Tensor:
+        return self._select(F.one_hot(index_list, self._num_events).type_as(index_list))
+
+    @property
+    def mean(self):
+        return self._select(self.probs)
+
+    @property
+    def mode(self):
+        return self._select_one_hot(self.probs.argmax(-1))
+
+    def sample(self, sample_shape=torch.Size()) -> Tensor:
+        return self._select_one_hot(super().sample(sample_shape))
+
+
+_ONE_HOT_MODES = ("argmax",)
+
+
+class CodebookModel(DistributionModel):
+    Distribution = CategoricalEmbeddings
+
+    def __init__(self, *size: int, mixture_cfg={}, **kwargs) -> None:
+        cfg = dict(n_components=None, metric="euclidean", p=2., topk=None, temperature=1., training_mode="argmax",
+                   inference_mode="argmax", kmeans_iter=100, laplace_eps=1e-5)
+        unknown = set(mixture_cfg) - set(cfg)
+        if unknown:
+            raise TypeError(f"unexpected mixture_cfg keys: {sorted(unknown)}")
+        cfg.update(mixture_cfg)
+        if cfg["n_components"] is None:
+            raise TypeError("mixture_cfg must give `n_components`")
+        if cfg["metric"] != "euclidean" or float(cfg["p"]) != 2.0 or cfg["topk"] not in (None, 0):
+            raise NotImplementedError("the MI355X CodebookModel implements metric='euclidean', p=2, topk=None")
+        for m in (cfg["training_mode"], cfg["inference_mode"]):
+            if m not in _ONE_HOT_MODES:
+                raise NotImplementedError(f"assignment mode {m!r}: only {_ONE_HOT_MODES} run on the MI355X path")
+        if kwargs.get("update_with_autograd", False):
+            raise NotImplementedError("update_with_autograd=True is not implemented on the MI355X path")
+        self.n_components = int(cfg["n_components"])
+        self.metric, self.p, self.topk = cfg["metric"], float(cfg["p"]), cfg["topk"]
+        self.temperature = float(cfg["temperature"])
+        self.training_mode, self.inference_mode = cfg["training_mode"], cfg["inference_mode"]
+        self.kmeans_iter = int(cfg["kmeans_iter"])
+        self.laplace_smoothing = partial(utils.laplace_smoothing, n_categories=self.n_components, eps=cfg["laplace_eps"])
+        DistributionModel.__init__(self, *size, **kwargs)
+        w = torch.ones(*self.leading_shape, self.n_components)
+        self.register_buffer("weight_init", (w / w.sum(-1, keepdim=True)).type_as(self.vec_init))
+        self.codebook = nn.Parameter(self.vec_init.clone(), requires_grad=False)
+        self.register_buffer("_running_sum", torch.zeros_like(self.vec_init))
+        self.register_buffer("_n_obs", torch.zeros(*self.leading_shape, self.n_components).type_as(self.vec_init))
+
+    # ---- shapes / distributions
+    @property
+    def vec_shape(self):
+        return (*self.leading_shape, self.n_components, self.dim)
+
+    @property
+    def weights(self) -> Tensor:
+        if torch.allclose(self._n_obs, torch.zeros_like(self._n_obs)):
+            return self.weight_init.type_as(self.codebook)
+        return self._n_obs.type_as(self.codebook) / self._n_obs.sum(-1, keepdim=True)
+
+    @property
+    def distribution(self) -> CategoricalEmbeddings:
+        return CategoricalEmbeddings(self.codebook, probs=self.weights)
+
+    @property
+    def batched_distribution(self) -> CategoricalEmbeddings:
+        return CategoricalEmbeddings(self.codebook.unsqueeze(-3), probs=self.weights.unsqueeze(-2))
+
+    @torch.no_grad()
+    def reset(self) -> None:
+        self.codebook.copy_(self.vec_init)
+        self._running_sum.zero_()
+        self._n_obs.zero_()
+
+    # ---- HIP-side pieces
+    def _flat(self, samples: Tensor):
+        """samples [*lead', B, d] (lead' broadcastable to leading_shape) -> ([nb, B, d] fp32, [nb, K, d] fp32, lead)"""
+        _lib.require_cuda(samples, "samples")
+        lead = torch.broadcast_shapes(samples.shape[:-2], self.leading_shape)
+        bsz = samples.shape[-2]
+        x3 = samples.float().expand(*lead, bsz, self.dim).reshape(-1, bsz, self.dim).contiguous()
+        c3 = self.codebook.detach().float().expand(*lead, self.n_components, self.dim) \
+            .reshape(-1, self.n_components, self.dim).contiguous()
+        return x3, c3, lead
+
+    def _argmax(self, samples: Tensor) -> Tuple[Tensor, Tensor]:
+        lib = _lib.load()
+        x3, c3, lead = self._flat(samples)
+        nb, bsz = x3.shape[0], x3.shape[1]
+        idx = torch.empty((nb, bsz), device=x3.device, dtype=torch.int64)
+        enc = torch.empty_like(x3)
+        check(lib.otvae_codebook_assign(ptr(x3), ptr(c3), nb, bsz, self.n_components, self.dim, self.temperature, ptr(idx),
+                                        ptr(enc), stream()), "otvae_codebook_assign")
+        return enc.reshape(*lead, bsz, self.dim), idx.reshape(*lead, bsz)
+
+    def assignment_probs(self, samples: Tensor, with_entropy: bool = False):
+        """softmax(energy / temperature) [*, B, K] (and its entropy [*, B])"""
+        lib = _lib.load()
+        x3, c3, lead = self._flat(samples)
+        nb, bsz = x3.shape[0], x3.shape[1]
+        probs = torch.empty((nb, bsz, self.n_components), device=x3.device, dtype=torch.float32)
+        ent = torch.empty((nb, bsz), device=x3.device, dtype=torch.float32) if with_entropy else None
+        check(lib.otvae_codebook_probs(ptr(x3), ptr(c3), nb, bsz, self.n_components, self.dim, self.temperature, ptr(probs),
+                                       ptr(ent), stream()), "otvae_codebook_probs")
+        probs = probs.reshape(*lead, bsz, self.n_components)
+        return (probs, ent.reshape(*lead, bsz)) if with_entropy else probs
+
+    def energy(self, samples: Tensor) -> Tensor:
+        """1 / (|x - c_k|_2 + 1e-8) [*, B, K] (codebook_model.py:150-156); only the tiny atoms-vs-atoms case of ``w2``
+        goes through here, the assignment kernels never materialise it."""
+        self._validate_samples(samples)
+        return 1 / (torch.cdist(samples.type_as(self.codebook), self.codebook, self.p) + 1e-8)
+
+    def assign(self, samples: Tensor):
+        """(one-hot weights [*, B, K], sampled indices [*, B], Categorical(softmax weights)) -- base.py:206-239 in
+        'argmax' mode.  As in the reference the returned ``indices`` are a draw from the distribution (they come from
+        this device's generator, so they are not comparable across devices); the deterministic nearest-atom indices
+        are ``weights.argmax(-1)``."""
+        probs = self.assignment_probs(samples)
+        distribution = D.Categorical(probs)
+        indices = distribution.sample()
+        _, idx = self._argmax(samples)
+        weights = F.one_hot(idx, self.n_components).type_as(probs)
+        return weights, indices, distribution
+
+    def predict(self, features: Tensor):
+        """(codebook[argmax], sampled indices, assignment distribution) -- codebook_model.py:145-148"""
+        self._validate_samples(features)
+        preds, _ = self._argmax(features)
+        probs = self.assignment_probs(features)
+        distribution = D.Categorical(probs)
+        return preds.type_as(self.codebook), distribution.sample(), distribution
+
+    def nearest(self, features: Tensor) -> Tuple[Tensor, Tensor]:
+        """(codebook[argmax], argmax indices): the deterministic part of ``predict``"""
+        return self._argmax(features)
+
+    def kmean_iteration(self, samples: Optional[Tensor]):
+        if samples is None:
+            return self._n_obs, self._running_sum
+        lib = _lib.load()
+        x3, c3, lead = self._flat(samples)
+        nb, bsz = x3.shape[0], x3.shape[1]
+        _, idx = self._argmax(samples)
+        idx = idx.reshape(nb, bsz).contiguous()
+        counts = torch.empty((nb, self.n_components), device=x3.device, dtype=torch.float32)
+        sums = torch.empty((nb, self.n_components, self.dim), device=x3.device, dtype=torch.float32)
+        check(lib.otvae_codebook_kmeans(ptr(x3), ptr(idx), nb, bsz, self.n_components, self.dim, ptr(counts), ptr(sums),
+                                        stream()), "otvae_codebook_kmeans")
+        return (counts.reshape(*lead, self.n_components).type_as(self._n_obs),
+                sums.reshape(*lead, self.n_components, self.dim).type_as(self._running_sum))
+
+    # ---- fitting (codebook_model.py:121-143, 189-214)
+    @torch.no_grad()
+    def update(self, samples: Tensor) -> None:
+        self._validate_samples(samples)
+        samples = samples.detach().type_as(self._running_sum)
+        self._init_parameters(samples)
+        res = self.kmean_iteration(samples)
+        if self.reduce_on_update:
+            res = [self.reduce(r) for r in res]
+        buffers = self._update_buffers(*res, decay=True)
+        self._update_parameters(*buffers)
+
+    @torch.no_grad()
+    def fit(self, samples: Optional[Tensor] = None) -> None:
+        if samples is not None:
+            self._validate_samples(samples)
+            samples = samples.detach().type_as(self._running_sum)
+            self._init_parameters(samples)
+        res = None
+        for _ in range(self.kmeans_iter):
+            res = self.kmean_iteration(samples)
+            self._update_parameters(*[self.reduce(r) for r in res])
+            if samples is None:
+                break  # the statistics are the stored buffers: every further iteration recomputes the same codebook
+        if self.kmeans_iter > 0:
+            self._update_buffers(*res, decay=False)
+
+    def _update_parameters(self, weights_sum: Tensor, samples_sum: Tensor) -> None:
+        hit = weights_sum > 1e-8  # only the observed atoms move
+        self.codebook.data[hit] = (samples_sum[hit] / self.laplace_smoothing(weights_sum[hit]).unsqueeze(-1)) \
+            .type_as(self.codebook)
+
+    def _update_buffers(self, weights_sum: Tensor, samples_sum: Tensor, decay: bool = False):
+        hit = weights_sum > 1e-8
+        if decay:
+            self._n_obs[hit] = self.ema_update(self._n_obs[hit], weights_sum[hit])
+            self._running_sum[hit] = self.ema_update(self._running_sum[hit], samples_sum[hit])
+        else:
+            self._n_obs[hit] = weights_sum[hit]
+            self._running_sum[hit] = samples_sum[hit]
+        return self._n_obs, self._running_sum
+
+    def _init_parameters(self, samples: Tensor) -> None:
+        if torch.allclose(self.codebook, self.vec_init):
+            rand_indices = torch.randperm(samples.size(-2))[:self.n_components]  # host generator, as the reference
+            self.codebook.copy_(samples[..., rand_indices.to(samples.device), :])
+            self._n_obs += 1
+
+    def w2(self, other: CategoricalEmbeddings) -> Tensor:
+        """entropic OT between the two atom sets (codebook_model.py:175-182)"""
+        cost = 1 / (self.energy(other.embeddings) + 1e-8)
+        plan = sinkhorn_log(self.distribution.probs, other.probs, cost, reg=1e-5, max_iter=100, threshold=1e-3)
+        return torch.sum(cost * plan, dim=(-2, -1))
+
+    def extra_repr(self) -> str:
+        return (DistributionModel.extra_repr(self) + f", num_components={self.n_components}, metric={self.metric}, "
+                f"p={self.p}, temperature={self.temperature}, training_mode={self.training_mode}, "
+                f"inference_mode={self.inference_mode}")

@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch import Tensor
 
 __all__ = ["DDPMixin", "FilterKwargs", "hasarg", "replicate_batch", "mean_replicated_batch", "std_replicated_batch",
-           "ema", "permute_and_flatten", "unflatten_and_unpermute", "unsqueeze_like", "ddp_reduce_sum",
+           "ema", "laplace_smoothing", "permute_and_flatten", "unflatten_and_unpermute", "unsqueeze_like", "ddp_reduce_sum",
            "ddp_gather_all", "apply_to_collection"]
 
 
@@ -119,6 +119,14 @@ def ema(moving_avg, new, decay):
     if decay is None:
         return moving_avg + new
     return moving_avg * decay + new * (1 - decay)
+
+
+def laplace_smoothing(x, n_categories, eps=1e-5):
+    """Additive smoothing of a count vector that keeps its total (reference utils/__init__.py:209-218)."""
+    if eps is None:
+        return x
+    total = x.sum(-1, keepdim=True)
+    return (x + eps) / (total + n_categories * eps) * total
 
 
 def permute_and_flatten(x: Tensor, permute_dims: Sequence[int], batch_first: bool = True,

@@ -532,3 +532,69 @@ def test_sinkhorn_persistent_equals_multilaunch(A):
         for g, r, name in zip(got[:3], ref[:3], ("pi", "u", "v")):
             assert torch.equal(g, r), (n, m, name, float((g - r).abs().max()))
         assert torch.isfinite(got[0]).all()
+
+
+# ------------------------------------------------------------------------------------------------ G9 codebook k-means
+@pytest.mark.parametrize("tag", ["sum", "ema"])
+def test_codebook_model_kmeans_vs_reference_golden(A, tag):
+    """CodebookModel.update x 6 -> fit -> predict / distribution / w2 against the reference's own class
+    (same vec_init through load_state_dict, same host randperm seed for the first-call initialisation)."""
+    g = group(load_golden("codebook_kmeans.npz"), tag)
+    rep = Report(f"CodebookModel streaming k-means ({tag}) vs reference golden")
+    K, d, B, decay = g["cfg"].tolist()
+    K, d, B = int(K), int(d), int(B)
+    decay = None if decay < 0 else float(decay)
+    batches = g["batches"]
+    lead = tuple(batches.shape[1:-2])
+    model = A.CodebookModel(*lead, d, update_decay=decay,
+                            mixture_cfg=dict(n_components=K, training_mode="argmax", inference_mode="argmax"))
+    sd = model.state_dict()
+    sd["vec_init"], sd["mat_init"], sd["codebook"] = g["vec_init"], g["mat_init"], g["vec_init"].clone()
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    for step in range(batches.shape[0]):
+        if step == 0:
+            torch.manual_seed(1234)
+        model.update(batches[step].cuda())
+        rep.check(f"step{step}/n_obs", model._n_obs, g[f"step{step}/n_obs"], 1e-6)
+        rep.check(f"step{step}/running_sum", model._running_sum, g[f"step{step}/running_sum"], 1e-5)
+        rep.check(f"step{step}/codebook", model.codebook, g[f"step{step}/codebook"], 1e-5)
+    model.fit()
+    rep.check("fit/codebook", model.codebook, g["fit/codebook"], 1e-5)
+    model.eval()
+    probe = batches[-1].cuda()
+    preds, sampled, dist = model.predict(probe)
+    rep.check("predict/preds", preds, g["predict/preds"], 1e-5)
+    # the weights are softmax(1/distance): a distance error e moves the exponent by e/distance^2.  The reference's
+    # torch.cdist takes the |x|^2 + |c|^2 - 2 x.c route for more than 25 rows, whose cancellation error (~1e-6 at these
+    # magnitudes) is amplified ~10-100x for samples within 0.1-0.3 of an atom; the kernel differences coordinates directly.
+    rep.check("predict/probs", dist.probs, g["predict/probs"], 5e-4)
+    _, ent = model.assignment_probs(probe, with_entropy=True)
+    rep.check("predict/entropy", ent, g["predict/entropy"], 5e-4, floor=1e-3)
+    assert sampled.shape == probe.shape[:-1] and int(sampled.min()) >= 0 and int(sampled.max()) < K
+    enc, idx = model.nearest(probe)
+    assert torch.equal(idx.cpu(), g["predict/probs"].argmax(-1))
+    rep.check("weights", model.weights, g["weights"], 1e-6)
+    other = A.CategoricalEmbeddings(g["centres"].cuda(), probs=(torch.ones(*lead, K) / K).cuda())
+    rep.check("w2", model.w2(other), g["w2"], 1e-4)
+    rep.finish()
+
+
+def test_codebook_model_recovers_mixture_centres(A):
+    """The reference's own acceptance test (tests/test_distribution_models.py:190-211): stream batches of a mixture
+    through update(), fit(), then the entropic W2 to the true atoms must be small."""
+    torch.manual_seed(0)
+    K, d, N = 8, 2, 8000
+    g = torch.Generator().manual_seed(3)
+    centres = torch.randn(K, d, generator=g) * 6
+    which = torch.randint(0, K, (N,), generator=g)
+    samples = centres[which] + 0.2 * torch.randn(N, d, generator=g)
+    model = A.CodebookModel(d, mixture_cfg=dict(n_components=K, training_mode="argmax")).cuda().train()
+    for i in range(0, N, 100):
+        model.update(samples[i:i + 100].cuda())
+    model.fit()
+    w2 = model.w2(A.CategoricalEmbeddings(centres.cuda(), probs=(torch.ones(K) / K).cuda()))
+    # k-means from a random initialisation may merge two clusters; the streaming estimate must still be close
+    assert float(w2) < 3.0, float(w2)
+    enc, idx = model.nearest(samples[:512].cuda())
+    assert float((enc - samples[:512].cuda()).norm(dim=-1).mean()) < 2.0

@@ -268,3 +268,36 @@ def test_codebook_indices_bit_exact(tag):
     preds, idx = O.codebook_assign(g["x"], g["codebook"])
     assert torch.equal(idx, g["indices"])
     assert torch.equal(preds, g["preds"])
+
+
+# ------------------------------------------------------------------------------------------------ G9 codebook k-means
+def _randperm_indices(n, k):
+    torch.manual_seed(1234)  # the seed gen_golden.py set before the reference's first update
+    return torch.randperm(n)[:k]
+
+
+@pytest.mark.parametrize("tag", ["sum", "ema"])
+def test_codebook_kmeans_update_fit_predict_w2(tag):
+    g = group(load_golden("codebook_kmeans.npz"), tag)
+    K, d, B, decay = g["cfg"].tolist()
+    K, B = int(K), int(B)
+    decay = None if decay < 0 else float(decay)
+    batches = g["batches"]
+    lead = batches.shape[1:-2]
+    st = {"codebook": g["vec_init"].clone(), "vec_init": g["vec_init"], "n_obs": torch.zeros(*lead, K),
+          "running_sum": torch.zeros_like(g["vec_init"])}
+    for step in range(batches.shape[0]):
+        st = O.codebook_update(st, batches[step], decay, rand_indices=_randperm_indices(B, K) if step == 0 else None)
+        assert rel_err(st["n_obs"], g[f"step{step}/n_obs"]) < 1e-6, step
+        assert rel_err(st["running_sum"], g[f"step{step}/running_sum"]) < 2e-6, step
+        assert rel_err(st["codebook"], g[f"step{step}/codebook"]) < 2e-6, step
+    st = O.codebook_fit(st)
+    assert rel_err(st["codebook"], g["fit/codebook"]) < 2e-6
+    probs = O.codebook_probs(batches[-1], st["codebook"])
+    assert rel_err(probs, g["predict/probs"]) < 2e-6
+    preds, _ = O.codebook_assign(batches[-1], st["codebook"])
+    assert torch.equal(preds, g["predict/preds"])
+    weights = st["n_obs"] / st["n_obs"].sum(-1, keepdim=True)
+    assert rel_err(weights, g["weights"]) < 1e-6
+    w2 = O.codebook_w2(st["codebook"], weights, g["centres"], torch.ones(*lead, K) / K)
+    assert rel_err(w2, g["w2"]) < 1e-4
