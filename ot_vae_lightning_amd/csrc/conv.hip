@@ -19,6 +19,7 @@
 #include "common.h"
 #include "conv_small.h"  // struct Geom + the direct VALU kernels used when both channel counts are tiny
 #include "conv_tile.h"   // image-tile MFMA convolution (whole images in LDS) for maps up to 16x16
+#include "conv_wtile.h"  // image-tile MFMA weight gradient
 
 static inline Geom to_geom(const otvae_conv_geom* g) {
     Geom r = {g->N, g->Hs, g->Ws, g->Cs, g->up, g->Ho, g->Wo, g->Cn, g->KH, g->KW, g->stride, g->pad};
@@ -1083,6 +1084,12 @@ extern "C" int otvae_conv_bwd_weight_ws(const otvae_conv_geom* gg, int has_bias,
     int NT, p, nkb, nnb, Kp;
     unsigned chunk;
     wgrad_plan(g, has_bias, NT, p, chunk, nkb, nnb, Kp);
+    {
+        WTilePlan wp;
+        int nbk;
+        size_t sm;
+        if (conv_wtile_plan(g, has_bias, wp, nbk, sm)) p = conv_wtile_nparts(nbk);
+    }
     if (P) *P = p;
     return OTVAE_OK;
 }
@@ -1101,6 +1108,23 @@ extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, 
     wgrad_plan(g, has_bias, NT, P, chunk, nkb, nnb, Kp);
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)Kp * g.Cn;
+    {
+        WTilePlan wp;
+        int nbk;
+        size_t sm;
+        if (conv_wtile_plan(g, has_bias, wp, nbk, sm)) {
+            OTVAE_REQUIRE(!wp.vec4 || (aligned16(x) && (!scale || (aligned16(scale) && aligned16(shift)))),
+                          "otvae_conv_bwd_weight: x / scale / shift of a layer with Cs %% 4 == 0 must be 16-byte aligned");
+            conv_wtile(wp, nbk, sm, st, x, scale, shift, relu, gy, partial);
+            OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(tile)");
+            if (defer_reduce) return OTVAE_OK;
+            P = conv_wtile_nparts(nbk);
+            wgrad_reduce_kernel<<<imin(cdiv(total, P >= 32 ? 4 : 64), 2048), 256, 0, st>>>(partial, P, Kp - (has_bias ? 1 : 0),
+                                                                                         Kp, g.Cn, gw, gb);
+            OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(reduce)");
+            return OTVAE_OK;
+        }
+    }
     if (conv_small_wgrad_ok(g)) {
         conv_small_wgrad(g, x, scale, shift, relu, gy, has_bias, partial, st);
         OTVAE_CHECK_LAUNCH("otvae_conv_bwd_weight(small)");
@@ -1433,6 +1457,12 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             wgrad_plan(g, jb.has_bias, d.NT, P, d.chunk, nkb, nnb, d.Kp);
             packable = !conv_small_wgrad_ok(g) && ch4 && aligned16(jb.x) && aligned16(jb.gy) &&
                        (jb.scale == nullptr || (aligned16(jb.scale) && aligned16(jb.shift)));
+            {
+                WTilePlan wp;
+                int nbk;
+                size_t sm;
+                if (conv_wtile_plan(g, jb.has_bias, wp, nbk, sm)) packable = false;  // image-tile kernel: own launch
+            }
             d.a0 = jb.x;
             d.b0 = jb.gy;
             d.out = jb.wpartial;

@@ -1,6 +1,6 @@
 """GPU tests of the convolution entry points of the C ABI, called directly through ctypes (no autograd, no modules):
 
-  * every kernel family that can serve a layer (image-tile MFMA, implicit-GEMM MFMA, direct VALU) against a plain torch
+  * every kernel family that can serve a layer (image-tile MFMA fwd/dgrad/wgrad, implicit-GEMM MFMA, direct VALU) against a plain torch
     float64 restatement of ConvLayer.forward / its backward (reference networks/cnn.py:183-192) on the same inputs;
   * image-tile vs implicit-GEMM outputs of the same call, which must agree BIT FOR BIT (same k order, same fp32 MFMA);
   * otvae_conv_multi vs one call per job (bit for bit, including the BatchNorm partial sums);
@@ -193,8 +193,9 @@ def test_conv_entry_points_vs_float64(lib, case):
     c = make_case(n, cs, cn, hs, k, s, p, up, seed=sum(case))
     y64, gv64, gw64, gb64 = ref64(c)
     dv = Dev(c)
-    variants = [dict(OTVAE_NO_TILE=None, OTVAE_TILE_ALL=None), dict(OTVAE_NO_TILE="1", OTVAE_TILE_ALL=None),
-                dict(OTVAE_NO_TILE=None, OTVAE_TILE_ALL="1")]
+    variants = [dict(OTVAE_NO_TILE=None, OTVAE_TILE_ALL=None, OTVAE_NO_WTILE=None, OTVAE_WTILE_ALL=None),
+                dict(OTVAE_NO_TILE="1", OTVAE_TILE_ALL=None, OTVAE_NO_WTILE="1", OTVAE_WTILE_ALL=None),  # implicit GEMM only
+                dict(OTVAE_NO_TILE=None, OTVAE_TILE_ALL="1", OTVAE_NO_WTILE=None, OTVAE_WTILE_ALL="1")]  # tile kernels wherever they can run
     outs = []
     for v in variants:
         with env(**v):
