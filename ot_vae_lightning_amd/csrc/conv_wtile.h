@@ -13,7 +13,7 @@ struct WTilePlan {
     int rowsH, rowsW, rowsPI, rowsPIp, rstride;  // output positions per image (padded to a multiple of 4)
     int vec4;                 // Cs % 4 == 0: float4 staging
     int K, Kp, has_bias;      // k-rows: taps * Cs (+ 1 bias row)
-    int nkt, nn, n0, CnP;     // 16-row k tiles, 16-col n tiles, first column, padded row length of G
+    int nkt, nn, ny, CnP;     // 16-row k tiles, 16-col n tiles per block, blocks along n, padded row length of G
     int IPB, vfloats, gfloats;
     int tapoff[WT_MAXT];      // LDS float offset of each tap (kh*KW + kw) inside the virtual grid, -1 = never touches
 };

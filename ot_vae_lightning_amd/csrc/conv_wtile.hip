@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void conv_wtile_kernel(WTilePlan pl, const flo
     const int CK = pl.CK, CKp = pl.CKp, Cn = pl.Cn, CnP = pl.CnP;
     const int rowsPI = pl.rowsPI, rowsPIp = pl.rowsPIp;
     const int ZERO = pl.vfloats, ONE = pl.vfloats + 1;
+    const int n0 = blockIdx.y * NN * 16;  // this block's first output channel
 
     // position table: float offset of each output position's origin inside one image's virtual grid
     for (int r = tid; r < rowsPIp; r += 256) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_wtile_kernel(WTilePlan pl, const flo
         constexpr int QU = (KTM * NN <= 6) ? 4 : 2;
         for (int img = 0; img < pl.IPB; ++img) {
             const int vb = img * img_floats;
-            const float* Gi = G + (size_t)img * rowsPIp * CnP + pl.n0 + r16;
+            const float* Gi = G + (size_t)img * rowsPIp * CnP + n0 + r16;
             for (int q0 = wave; q0 < nquads; q0 += 4 * QU) {
                 int pt[QU], pp[QU];
 #pragma unroll
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void conv_wtile_kernel(WTilePlan pl, const flo
                     const int pb = vb + pt[u];
 #pragma unroll
                     for (int j = 0; j < NN; ++j)
-                        b[u][j] = (live && pl.n0 + j * 16 + r16 < CnP) ? Gi[(size_t)pp[u] * CnP + j * 16] : 0.f;
+                        b[u][j] = (live && n0 + j * 16 + r16 < CnP) ? Gi[(size_t)pp[u] * CnP + j * 16] : 0.f;
 #pragma unroll
                     for (int t = 0; t < KTM; ++t) a[u][t] = V[live ? rmul[t] * pb + roff[t] : ZERO];
                 }
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_wtile_kernel(WTilePlan pl, const flo
         if (t >= pl.nkt) continue;
 #pragma unroll
         for (int j = 0; j < NN; ++j) {
-            const int n = pl.n0 + j * 16 + r16;
+            const int n = n0 + j * 16 + r16;
             if (n >= Cn) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -271,9 +272,14 @@ bool conv_wtile_plan(const Geom& g, int has_bias, WTilePlan& pl, int& nblocks, s
     pl.Kp = pl.K + pl.has_bias;
     pl.nkt = cdiv(pl.Kp, 16);
     const int nnt = cdiv(g.Cn, 16);
-    if (nnt > 3 || pl.nkt > 18 || pl.nkt * nnt > 20) return false;
-    pl.nn = nnt;
-    pl.n0 = 0;
+    if (pl.nkt > 18) return false;
+    // column tiles per block: as many as the accumulator budget (20 tiles) allows, the rest over blockIdx.y
+    int nn = imin(3, nnt);
+    while (nn > 1 && pl.nkt * nn > 20) --nn;
+    if (nn == 3 && pl.nkt > 6) nn = 2;
+    if (nn == 2 && pl.nkt > 10) nn = 1;
+    pl.nn = nn;
+    pl.ny = cdiv(nnt, nn);
     pl.CnP = (g.Cn + 3) & ~3;  // columns beyond it read as zero
     // taps that can touch the image for some output position; crop the virtual grid to their bounding box
     int tdy[WT_MAXT], tdx[WT_MAXT];
@@ -322,7 +328,7 @@ int conv_wtile(const WTilePlan& pl, int nblocks, size_t smem, hipStream_t st, co
                                       128 * 1024);                                                                        \
             attr_done = true;                                                                                             \
         }                                                                                                                 \
-        conv_wtile_kernel<K_, N_><<<nblocks, 256, smem, st>>>(pl, x, scale, shift, relu, gy, partial);                    \
+        conv_wtile_kernel<K_, N_><<<dim3(nblocks, pl.ny), 256, smem, st>>>(pl, x, scale, shift, relu, gy, partial);                    \
     } while (0)
     const int kt = pl.nkt;
     if (pl.nn == 1) {

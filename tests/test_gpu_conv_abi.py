@@ -176,6 +176,7 @@ CASES = [
     (6, 8, 16, 16, 4, 2, 1, 1),     # stride 2 (4 parity classes in the data gradient)
     (9, 16, 8, 8, 3, 1, 1, 2),      # nearest x2 up-sampling
     (3, 16, 16, 8, 3, 1, 1, 1),     # 8x8 maps
+    (6, 16, 32, 16, 4, 2, 1, 1),    # K = 257 rows x 32 columns: tile wgrad splits the columns over blockIdx.y
     (21, 32, 32, 4, 3, 1, 1, 1),    # 4x4 maps: implicit GEMM by default, image-tile with OTVAE_TILE_ALL
     (37, 64, 64, 2, 3, 1, 1, 1),    # 2x2
     (70, 128, 64, 1, 3, 1, 1, 2),   # decoder entry: 1x1 -> 2x2
