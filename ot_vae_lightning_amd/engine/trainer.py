@@ -139,12 +139,12 @@ class HipTrainer:
         loss.backward()
         from ..functional import _PendingReduce
         _PendingReduce.flush(self.device)  # normally already done by the autograd-engine callback at the end of backward
-        self._logs = logs
+        self._logs = {k: v.detach() for k, v in logs.items()}  # no reference into the autograd graph survives the step
         self.latents = art["latents"].detach()
         if self.latent_stats is not None:
             lat = self.latents.flatten(1)  # [B, D] with transport_dims = (1, 2, 3)
             self.latent_stats.update(target_samples=lat)
-        return logs
+        return self._logs
 
     def _adam(self):
         check(self.lib.otvae_adam_step(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
