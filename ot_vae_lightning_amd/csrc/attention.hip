@@ -32,19 +32,28 @@ struct Rec {
     static constexpr int QG = (2 * C + 2 + 3) & ~3;      // {q/C [C], gout[C], lse, delta} padded to 16 bytes
 };
 
+// floor(k / d) by one multiply for 0 <= k < 2^22 (exact, see fast_div in conv.hip); the staging loops decode
+// (slice, token, channel) per element and a 64-bit udiv there costs more than the element's share of the main loop
+__device__ __forceinline__ int adiv(int k, int d, float inv_d) {
+    return k < (1 << 22) ? (int)(((float)k + 0.5f) * inv_d) : k / d;
+}
+
 // stage {k, v} records of the block's slices: sm[sl][t][2C]
 template <int C>
 __device__ __forceinline__ void stage_kv(float* __restrict__ sm, const float* __restrict__ qkv, long slice0, int nsl, int T,
                                          int H) {
     const int HC = H * C, W3 = 3 * HC;
     const int per = T * 2 * C;
+    const float inv_per = 1.0f / (float)per, inv_h = 1.0f / (float)H;
+    const int n0 = (int)(slice0 / H), h0 = (int)(slice0 - (long)n0 * H);  // once per block
     for (int e = threadIdx.x; e < nsl * per; e += 256) {
-        const int sl = e / per, r = e - sl * per;
-        const int t = r / (2 * C), j = r - t * 2 * C;
+        const int sl = adiv(e, per, inv_per), r = e - sl * per;
+        const int t = r / (2 * C), j = r - t * 2 * C;  // compile-time divisor
         const int which = j / C, c = j - which * C;
-        const long gs = slice0 + sl;
-        const long n = gs / H;
-        const int h = (int)(gs - n * H);
+        const int hs = h0 + sl;                          // < H + slices per block
+        const int dn = adiv(hs, H, inv_h);
+        const long n = n0 + dn;
+        const int h = hs - dn * H;
         sm[e] = qkv[(n * T + t) * W3 + (1 + which) * HC + h * C + c];
     }
 }
@@ -60,12 +69,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const int nsl = (int)min((long)SPB, total - slice0);
     stage_kv<C>(sm, qkv, slice0, nsl, T, H);
     __syncthreads();
-    const int sl = threadIdx.x / TPS;
+    const int sl = adiv((int)threadIdx.x, TPS, 1.0f / (float)TPS);
     if (sl >= nsl) return;
     const int t0 = (threadIdx.x - sl * TPS) * QPT;
-    const long gs = slice0 + sl;
-    const long n = gs / H;
-    const int h = (int)(gs - n * H);
+    long n;
+    int h;
+    {
+        const int bn0 = (int)(slice0 / H), bh0 = (int)(slice0 - (long)bn0 * H);  // block-uniform (scalar unit)
+        const int hs = bh0 + sl;
+        const int dn = adiv(hs, H, 1.0f / (float)H);
+        n = bn0 + dn;
+        h = hs - dn * H;
+    }
     // scores are kept in the log2 domain (q pre-multiplied by log2(e)/C) so that exp is a bare v_exp_f32
     const float inv_c = LOG2E / (float)C;
     const float* kv = sm + (size_t)sl * T * Rec<C>::KV;
@@ -143,11 +158,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const float inv_c = 1.f / (float)C;
     stage_kv<C>(s_kv, qkv, slice0, nsl, T, H);
     // query records {q/C, gout, lse, delta = sum_c gout*out}
+    const float inv_t = 1.0f / (float)T, inv_hq = 1.0f / (float)H;
+    const int qn0 = (int)(slice0 / H), qh0 = (int)(slice0 - (long)qn0 * H);
     for (int it = threadIdx.x; it < nsl * T; it += 256) {
-        const int sl = it / T, t = it - sl * T;
-        const long gs = slice0 + sl;
-        const long n = gs / H;
-        const int h = (int)(gs - n * H);
+        const int sl = adiv(it, T, inv_t), t = it - sl * T;
+        const int hs = qh0 + sl;
+        const int dn = adiv(hs, H, inv_hq);
+        const long n = qn0 + dn;
+        const int h = hs - dn * H;
         float* r = s_qg + (size_t)it * RQG;
         const float* qp = qkv + (n * T + t) * W3 + h * C;
         const float* gp = gout + (n * T + t) * HC + h * C;
@@ -164,12 +182,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         r[2 * C + 1] = d;
     }
     __syncthreads();
-    const int sl = threadIdx.x / TPS;
+    const int sl = adiv((int)threadIdx.x, TPS, 1.0f / (float)TPS);
     if (sl >= nsl) return;
     const int t0 = (threadIdx.x - sl * TPS) * QPT;
-    const long gs = slice0 + sl;
-    const long n = gs / H;
-    const int h = (int)(gs - n * H);
+    long n;
+    int h;
+    {
+        const int bn0 = (int)(slice0 / H), bh0 = (int)(slice0 - (long)bn0 * H);  // block-uniform (scalar unit)
+        const int hs = bh0 + sl;
+        const int dn = adiv(hs, H, 1.0f / (float)H);
+        n = bn0 + dn;
+        h = hs - dn * H;
+    }
     const float* kv = s_kv + (size_t)sl * T * RKV;
     const float* qg = s_qg + (size_t)sl * T * RQG;
 

@@ -60,37 +60,58 @@ static inline int pick_nt(int ncols, long row_blocks) {
 #define PAD_MARK 0x7fc00001  // NaN payload marking "padding / out of range": becomes an exact 0 AFTER the activation
 #define ONE_MARK 0x7fc00002  // bias row of the weight gradient: exact 1
 
-// exact floor(k / d) for 0 <= k < 2^17, 1 <= d <= 2^11 with one multiply: (k+0.5)/d is at least 0.5/d away from an
-// integer while the float product is off by < 2^-23 * k/d, so truncation cannot cross an integer boundary.
+// exact floor(k / d) for 0 <= k < 2^22, d >= 1 with one multiply: (k+0.5)/d is at least 0.5/d away from an integer
+// while the float product (rounded reciprocal, rounded product) is off by < 2^-23 * (k+0.5)/d, which is < 0.5/d.
 __device__ __forceinline__ int fast_div(int k, float inv_d) { return (int)(((float)k + 0.5f) * inv_d); }
+__device__ __forceinline__ int imax_dev(int a, int b) { return a > b ? a : b; }
 
 // ------------------------------------------------------------------------------------------------ fwd + dgrad
 // MODE 0 (FWD):   S = x  [N][Hs][Ws][Cs], CK = Cs, NC = Cn, Bmat = HWIO weight [T][Cs][Cn]
 // MODE 1 (DGRAD): S = gy [N][Ho][Wo][Cn], CK = Cn, NC = Cs, Bmat = wD [T][Cn][Cs]
 // Rows of DGRAD are grouped so that a lane's 4 accumulator registers are the 4 nearest-upsample children of one source
 // pixel (up == 2), or 4 positions of ONE stride-parity class (stride == 2, class = blockIdx.z).
-__device__ __forceinline__ void dgrad_row_to_pos(const Geom& g, unsigned row, int py, int px, int& n, int& iy, int& ix) {
+// Row index -> (image, y, x) decodes divide by launch constants.  A 32-bit udiv expands to ~25 vector instructions and
+// these decodes sit in per-tile / per-output-element code of kernels that are bound by vector-instruction issue, so
+// they go through fast_div (one multiply) whenever the row count is below 2^22 (exactness bound of fast_div).
+struct RowDiv {
+    float iWo, iHo, iWs, iHs, iW2, iH2;
+    bool small;
+};
+__device__ __forceinline__ RowDiv make_rowdiv(const Geom& g, unsigned rows_max) {
+    RowDiv r;
+    r.iWo = 1.0f / (float)g.Wo, r.iHo = 1.0f / (float)g.Ho;
+    r.iWs = 1.0f / (float)g.Ws, r.iHs = 1.0f / (float)g.Hs;
+    r.iW2 = 1.0f / (float)imax_dev(g.Ws >> 1, 1), r.iH2 = 1.0f / (float)imax_dev(g.Hs >> 1, 1);
+    r.small = rows_max < (1u << 22);
+    return r;
+}
+__device__ __forceinline__ unsigned rdiv(unsigned k, unsigned d, float inv_d, bool small) {
+    return small ? (unsigned)fast_div((int)k, inv_d) : k / d;
+}
+
+__device__ __forceinline__ void dgrad_row_to_pos(const Geom& g, const RowDiv& rd, unsigned row, int py, int px, int& n, int& iy,
+                                                 int& ix) {
     if (g.up == 2) {
         const unsigned parent = row >> 2, child = row & 3;
-        const int sx = parent % g.Ws;
-        const unsigned t = parent / g.Ws;
-        const int sy = t % g.Hs;
-        n = t / g.Hs;
+        const unsigned t = rdiv(parent, g.Ws, rd.iWs, rd.small);
+        const int sx = parent - t * g.Ws;
+        n = rdiv(t, g.Hs, rd.iHs, rd.small);
+        const int sy = t - (unsigned)n * g.Hs;
         iy = 2 * sy + (child >> 1);
         ix = 2 * sx + (child & 1);
     } else if (g.stride == 2) {
         const int W2 = g.Ws >> 1, H2 = g.Hs >> 1;
-        const int jx = row % W2;
-        const unsigned t = row / W2;
-        const int jy = t % H2;
-        n = t / H2;
+        const unsigned t = rdiv(row, W2, rd.iW2, rd.small);
+        const int jx = row - t * W2;
+        n = rdiv(t, H2, rd.iH2, rd.small);
+        const int jy = t - (unsigned)n * H2;
         iy = 2 * jy + py;
         ix = 2 * jx + px;
     } else {
-        ix = row % g.Ws;
-        const unsigned t = row / g.Ws;
-        iy = t % g.Hs;
-        n = t / g.Hs;
+        const unsigned t = rdiv(row, g.Ws, rd.iWs, rd.small);
+        ix = row - t * g.Ws;
+        n = rdiv(t, g.Hs, rd.iHs, rd.small);
+        iy = t - (unsigned)n * g.Hs;
     }
 }
 
@@ -151,6 +172,7 @@ __device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Ge
     const unsigned rows = MODE == 0 ? (unsigned)g.N * g.Ho * g.Wo
                                     : (g.stride == 2 ? (unsigned)g.N * (g.Hs >> 1) * (g.Ws >> 1) : (unsigned)g.N * Hu * Wu);
     const unsigned ntiles = (rows + TM - 1) / TM;
+    const RowDiv rd = make_rowdiv(g, rows);
 
     // ---- valid tap list (uniform over the launch, resp. over the parity class)
     if (tid == 0) {
@@ -201,15 +223,15 @@ __device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Ge
             int n = -1, ry = 0, rx = 0;
             if (row < rows) {
                 if (MODE == 0) {
-                    const int ox = row % g.Wo;
-                    const unsigned t = row / g.Wo;
-                    const int oy = t % g.Ho;
-                    n = t / g.Ho;
+                    const unsigned t = rdiv(row, g.Wo, rd.iWo, rd.small);
+                    const int ox = row - t * g.Wo;
+                    n = rdiv(t, g.Ho, rd.iHo, rd.small);
+                    const int oy = t - (unsigned)n * g.Ho;
                     ry = oy * g.stride;
                     rx = ox * g.stride;
                 } else {
                     int iy, ix;
-                    dgrad_row_to_pos(g, row, py, px, n, iy, ix);
+                    dgrad_row_to_pos(g, rd, row, py, px, n, iy, ix);
                     ry = iy;
                     rx = ix;
                 }
@@ -445,9 +467,14 @@ __device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Ge
                     for (int r = 0; r < 4; ++r) {
                         const unsigned rr = row0 + r;
                         if (rr < rows) {
-                            int pn, piy, pix;
-                            dgrad_row_to_pos(g, rr, py, px, pn, piy, pix);
-                            const size_t o = ((size_t)((unsigned)pn * g.Hs + piy) * g.Ws + pix) * g.Cs + col;
+                            size_t o;
+                            if (g.stride == 1) {  // rows enumerate the input positions in memory order
+                                o = (size_t)rr * g.Cs + col;
+                            } else {
+                                int pn, piy, pix;
+                                dgrad_row_to_pos(g, rd, rr, py, px, pn, piy, pix);
+                                o = ((size_t)((unsigned)pn * g.Hs + piy) * g.Ws + pix) * g.Cs + col;
+                            }
                             float val = acc[j][r];
                             float xv = 0.f;
                             if (relu || mean) xv = xin[o];
@@ -757,6 +784,7 @@ __device__ __forceinline__ void conv_wgrad_body(char* __restrict__ smem, const G
     const unsigned pc = bz;
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
     const unsigned mbeg = pc * chunk, mend = min(M, mbeg + chunk);
+    const RowDiv wrd = make_rowdiv(g, M + 64);
     const int K = g.KH * g.KW * g.Cs;
     const int Hu = g.Hs * g.up, Wu = g.Ws * g.up;
     const int ush = g.up - 1;
@@ -834,10 +862,10 @@ __device__ __forceinline__ void conv_wgrad_body(char* __restrict__ smem, const G
         const unsigned mb = mbeg + (unsigned)sub * PC;
         if constexpr (VEC) {
             unsigned m = mb + v_p0;
-            int ox = m % g.Wo;
-            unsigned t = m / g.Wo;
-            int oy = t % g.Ho;
-            int n = t / g.Ho;
+            unsigned t = rdiv(m, g.Wo, wrd.iWo, wrd.small);
+            int ox = m - t * g.Wo;
+            int n = rdiv(t, g.Ho, wrd.iHo, wrd.small);
+            int oy = t - (unsigned)n * g.Ho;
             a_ok = 0;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -877,10 +905,10 @@ __device__ __forceinline__ void conv_wgrad_body(char* __restrict__ smem, const G
         }
         // A: pixels mb + a_p0 + 4 i: decode the first, then step by 4 pixels
         unsigned m = mb + a_p0;
-        int ox = m % g.Wo;
-        unsigned t = m / g.Wo;
-        int oy = t % g.Ho;
-        int n = t / g.Ho;
+        unsigned t = rdiv(m, g.Wo, wrd.iWo, wrd.small);
+        int ox = m - t * g.Wo;
+        int n = rdiv(t, g.Ho, wrd.iHo, wrd.small);
+        int oy = t - (unsigned)n * g.Ho;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float v = __int_as_float(PAD_MARK);

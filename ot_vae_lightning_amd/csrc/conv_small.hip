@@ -18,6 +18,12 @@ bool conv_small_ok(const SmallGeom& g) {
     return true;
 }
 
+// (image, y, x) of a flat position index: one multiply per division while the index is below 2^22 (see fast_div in
+// conv.hip), the udiv expansion (~25 instructions each, a third of a 1-channel layer's per-pixel work) otherwise
+__device__ __forceinline__ unsigned sdiv(unsigned k, unsigned d, float inv_d, bool small) {
+    return small ? (unsigned)(int)(((float)(int)k + 0.5f) * inv_d) : k / d;
+}
+
 __device__ __forceinline__ float act1(float v, float sc, float sh, bool affine, int relu) {
     if (affine) v = fmaf(v, sc, sh);
     if (relu) v = fmaxf(v, 0.f);
@@ -90,14 +96,16 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const 
     }
     const int Hu = g.Hs * g.up, Wu = g.Ws * g.up, ush = g.up - 1;
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
+    const float inv_wo = 1.0f / (float)g.Wo, inv_ho = 1.0f / (float)g.Ho;
+    const bool small = M < (1u << 22);
     double s1[CNM], s2[CNM];
 #pragma unroll
     for (int j = 0; j < CNM; ++j) s1[j] = s2[j] = 0.0;
     for (unsigned m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
-        const int ox = m % g.Wo;
-        const unsigned t0 = m / g.Wo;
-        const int oy = t0 % g.Ho;
-        const int n = t0 / g.Ho;
+        const unsigned t0 = sdiv(m, g.Wo, inv_wo, small);
+        const int ox = m - t0 * g.Wo;
+        const int n = sdiv(t0, g.Ho, inv_ho, small);
+        const int oy = t0 - (unsigned)n * g.Ho;
         float acc[CNM];
 #pragma unroll
         for (int j = 0; j < CNM; ++j) acc[j] = b_s[j];
@@ -202,16 +210,18 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
         is[c] = (mean && in) ? invstd[c] : 0.f;
     }
     const unsigned P = (unsigned)g.N * g.Hs * g.Ws;
+    const float inv_ws = 1.0f / (float)g.Ws, inv_hs = 1.0f / (float)g.Hs;
+    const bool small = P < (1u << 22);
     const int nchild = g.up * g.up;
     const int smask = g.stride - 1, sshift = g.stride - 1;
     double s1[CSM], s2[CSM];
 #pragma unroll
     for (int c = 0; c < CSM; ++c) s1[c] = s2[c] = 0.0;
     for (unsigned p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
-        const int sx = p % g.Ws;
-        const unsigned t0 = p / g.Ws;
-        const int sy = t0 % g.Hs;
-        const int n = t0 / g.Hs;
+        const unsigned t0 = sdiv(p, g.Ws, inv_ws, small);
+        const int sx = p - t0 * g.Ws;
+        const int n = sdiv(t0, g.Hs, inv_hs, small);
+        const int sy = t0 - (unsigned)n * g.Hs;
         float acc[CSM];
 #pragma unroll
         for (int c = 0; c < CSM; ++c) acc[c] = 0.f;
@@ -319,12 +329,14 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallGeom g, cons
 
     const int Hu = g.Hs * g.up, Wu = g.Ws * g.up, ush = g.up - 1;
     const unsigned M = (unsigned)g.N * g.Ho * g.Wo;
+    const float inv_wo = 1.0f / (float)g.Wo, inv_ho = 1.0f / (float)g.Ho;
+    const bool small = M < (1u << 22);
     const unsigned mbeg = blockIdx.x * chunk, mend = min(M, mbeg + chunk);
     for (unsigned m = mbeg + threadIdx.x; m < mend; m += 256) {
-        const int ox = m % g.Wo;
-        const unsigned t0 = m / g.Wo;
-        const int oy = t0 % g.Ho;
-        const int n = t0 / g.Ho;
+        const unsigned t0 = sdiv(m, g.Wo, inv_wo, small);
+        const int ox = m - t0 * g.Wo;
+        const int n = sdiv(t0, g.Ho, inv_ho, small);
+        const int oy = t0 - (unsigned)n * g.Ho;
         float gg[CN];
 #pragma unroll
         for (int j = 0; j < CN; ++j) {

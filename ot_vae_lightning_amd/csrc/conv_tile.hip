@@ -23,7 +23,8 @@
 
 #define TILE_WMAX 4096  // floats of one weight chunk in LDS (16 KiB)
 
-__device__ __forceinline__ int tdiv(int k, float inv_d) { return (int)(((float)k + 0.5f) * inv_d); }  // exact, see conv.hip
+__device__ __forceinline__ int tdiv(int k, float inv_d) { return (int)(((float)k + 0.5f) * inv_d); }  // exact for k < 2^22
+__device__ __forceinline__ int imax_d(int a, int b) { return a > b ? a : b; }
 
 template <int MODE, int NT, int RBW>
 __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float* __restrict__ S,
@@ -104,6 +105,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float
 
     // ---- this wave's row blocks: lane (r16) <-> one output position of each
     const int rows_blk = pl.IPB * pl.rowsPI;
+    // integer divisions by launch constants go through one float multiply (exact: tdiv), not the ~25-instruction
+    // udiv expansion; they sit in per-row-block code that would otherwise out-weigh the MFMAs of a small layer
+    const float inv_rpi = 1.0f / (float)pl.rowsPI, inv_rw = 1.0f / (float)pl.rowsW;
+    const float inv_ws = 1.0f / (float)imax_d(pl.rowsW >> 1, 1);
     int pixbase[RBW];  // float offset of the position's virtual-grid origin
     int rloc[RBW];     // row within the block, or -1
 #pragma unroll
@@ -113,17 +118,17 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float
         int pb = 0;
         int ok = -1;
         if (rl < rows_blk) {
-            const int img = rl / pl.rowsPI;
+            const int img = tdiv(rl, inv_rpi);
             const int r = rl - img * pl.rowsPI;
             int ry, rx;
             if (pl.childmode) {
                 const int parent = r >> 2, child = r & 3;
                 const int ws = pl.rowsW >> 1;
-                const int sy = parent / ws, sx = parent - sy * ws;
+                const int sy = tdiv(parent, inv_ws), sx = parent - sy * ws;
                 ry = 2 * sy + (child >> 1);
                 rx = 2 * sx + (child & 1);
             } else {
-                ry = r / pl.rowsW;
+                ry = tdiv(r, inv_rw);
                 rx = r - ry * pl.rowsW;
             }
             pb = ((img * pl.Hv + ry * pl.rstride) * pl.Wv + rx * pl.rstride) * CKp;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float
         // position decode (again; cheap, once per row block)
         int img = 0, r = 0;
         if (rl >= 0) {
-            img = rl / pl.rowsPI;
+            img = tdiv(rl, inv_rpi);
             r = rl - img * pl.rowsPI;
         }
         const unsigned gimg = img0 + img;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float
                     writer = writer && ((r16 & 3) == 0);
                     o = ((size_t)gimg * (pl.rowsPI >> 2) + (r >> 2)) * NC + ch;
                 } else if (pl.s2) {
-                    const int ry = r / pl.rowsW, rx = r - ry * pl.rowsW;
+                    const int ry = tdiv(r, inv_rw), rx = r - ry * pl.rowsW;
                     const int py = cls >> 1, px = cls & 1;
                     o = (((size_t)gimg * (2 * pl.rowsH) + 2 * ry + py) * (2 * pl.rowsW) + 2 * rx + px) * NC + ch;
                 } else {
