@@ -64,6 +64,7 @@ static inline int pick_nt(int ncols, long row_blocks) {
 // while the float product (rounded reciprocal, rounded product) is off by < 2^-23 * (k+0.5)/d, which is < 0.5/d.
 __device__ __forceinline__ int fast_div(int k, float inv_d) { return (int)(((float)k + 0.5f) * inv_d); }
 __device__ __forceinline__ int imax_dev(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin_dev(int a, int b) { return a < b ? a : b; }
 
 // ------------------------------------------------------------------------------------------------ fwd + dgrad
 // MODE 0 (FWD):   S = x  [N][Hs][Ws][Cs], CK = Cs, NC = Cn, Bmat = HWIO weight [T][Cs][Cn]
@@ -130,7 +131,7 @@ struct GemmSmem {
 };
 
 // (bx, by, bz) / (gx, gz): the block's coordinates and the extent of the (virtual) grid of THIS layer
-template <int MODE, int NT, bool VEC>
+template <int MODE, int NT, bool VEC, bool UT = false>
 __device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Geom& g, const float* __restrict__ S,
                                                const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                const float* __restrict__ Bmat,
@@ -208,7 +209,7 @@ __device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Ge
     const int K = ntaps * CK;
     const int nch = (K + KC - 1) / KC;
     const float inv_ck = 1.0f / (float)CK;
-    const bool ut = VEC && (CK % KC == 0);
+    // UT (host-selected when VEC and CK % KC == 0): the uniform-tap pipeline below replaces the general staging
     const int cpt = CK / KC;  // chunks per tap (ut)
     const float inv_cpt = 1.0f / (float)(cpt > 0 ? cpt : 1);
 
@@ -278,43 +279,6 @@ __device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Ge
         unsigned u_off[2] = {0u, 0u};
         auto stage_load = [&](int ch) {
             if constexpr (VEC) {
-                if (ut) {
-                    const int tl = fast_div(ch, inv_cpt);
-                    const int cb = (ch - tl * cpt) * KC;
-                    if (tl != u_tl) {  // uniform over the block
-                        u_tl = tl;
-                        const int dy = tap_dy[tl], dx = tap_dx[tl];
-                        u_tw = tap_w[tl] * CK;
-                        u_ok = 0;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const int ty = vr_y[i] + dy, tx = vr_x[i] + dx;
-                            const bool valid = vr_n[i] >= 0 && (unsigned)ty < (unsigned)lim_y && (unsigned)tx < (unsigned)lim_x;
-                            u_off[i] = valid ? (((unsigned)vr_n[i] * srcH + (ty >> sh)) * srcW + (tx >> sh)) * (unsigned)CK : 0u;
-                            u_ok |= (valid ? 1 : 0) << i;
-                        }
-                    }
-                    const int c = cb + v_k4 * 4;
-                    if (MODE == 0 && scale != nullptr) {
-                        a_sc4 = *reinterpret_cast<const float4*>(scale + c);
-                        a_sh4 = *reinterpret_cast<const float4*>(shift + c);
-                    }
-                    a_ok = u_ok;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        areg4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if ((u_ok >> i) & 1) areg4[i] = *reinterpret_cast<const float4*>(S + (size_t)u_off[i] + c);
-                    }
-                    const float* brow = Bmat + (size_t)(u_tw + cb) * NC + n0;
-#pragma unroll
-                    for (int j = 0; j < NBV; ++j) {
-                        const int e = tid + 256 * j;
-                        const int kb = e / (BN / 4), c4 = e - kb * (BN / 4);
-                        breg4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (e < 8 * BN && n0 + c4 * 4 < NC) breg4[j] = *reinterpret_cast<const float4*>(brow + (size_t)kb * NC + c4 * 4);
-                    }
-                    return;
-                }
                 const int k = ch * KC + v_k4 * 4;
                 const bool kv = k < K;
                 const int tl = kv ? fast_div(k, inv_ck) : 0;
@@ -440,33 +404,145 @@ __device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Ge
             }
         };
 
-        if (nch > 0) {
-            stage_load(0);
-            stage_store(0);
-        }
-        __syncthreads();
-        for (int ch = 0; ch < nch; ++ch) {
-            const int buf = ch & 1;
-            if (ch + 1 < nch) stage_load(ch + 1);  // global loads of the next chunk fly under this chunk's MFMAs
-            const float* Ab = &As[buf][(wave * 16 + r16) * LDA + kq];
-            const float* Bb = &Bs[buf][kq * LDB + r16];
-            // all LDS operand reads of the chunk first, then the MFMAs back to back: with one wave per SIMD a
-            // read -> wait -> MFMA chain per k-step leaves the matrix pipe idle for the LDS latency 8 times per chunk
+        if constexpr (VEC && UT) {
             {
-                float av[KC / 4], bv[KC / 4][NT];
+                // Uniform-tap pipeline, TWO chunks of operands in flight in registers (set = chunk & 1) on top of the
+                // double-buffered LDS tile.  Measured on a 64->64 3x3 layer at 2x2 (18 chunks, one wave per SIMD):
+                // of 18.3 us, 6 us were the exposed part of the load latency with one chunk in flight.  Every global
+                // load here is unconditional (out-of-range slots read offset 0 and are zeroed at the LDS store), so the
+                // vmcnt wait before a set is consumed counts exactly the one younger chunk.
+                float4 ra[2][2], rb[2][NBV], rsc[2], rsh[2];
+                int rok[2];
+                auto ut_load = [&](int ch, float4(&a)[2], float4(&b)[NBV], float4& sc4, float4& sh4, int& ok) {
+                    const int tl = fast_div(ch, inv_cpt);
+                    const int cb = (ch - tl * cpt) * KC;
+                    if (tl != u_tl) {  // uniform over the block; no global loads inside
+                        u_tl = tl;
+                        const int dy = tap_dy[tl], dx = tap_dx[tl];
+                        u_tw = tap_w[tl] * CK;
+                        u_ok = 0;
 #pragma unroll
-                for (int ks = 0; ks < KC / 4; ++ks) {
-                    av[ks] = Ab[ks * 4];
+                        for (int i = 0; i < 2; ++i) {
+                            const int ty = vr_y[i] + dy, tx = vr_x[i] + dx;
+                            const bool valid = vr_n[i] >= 0 && (unsigned)ty < (unsigned)lim_y && (unsigned)tx < (unsigned)lim_x;
+                            u_off[i] = valid ? (((unsigned)vr_n[i] * srcH + (ty >> sh)) * srcW + (tx >> sh)) * (unsigned)CK : 0u;
+                            u_ok |= (valid ? 1 : 0) << i;
+                        }
+                    }
+                    const int c = cb + v_k4 * 4;
+                    if (MODE == 0 && scale != nullptr) {
+                        sc4 = *reinterpret_cast<const float4*>(scale + c);
+                        sh4 = *reinterpret_cast<const float4*>(shift + c);
+                    }
+                    ok = u_ok;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) bv[ks][j] = Bb[ks * 4 * LDB + j * 16];
+                    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(S + (size_t)u_off[i] + c);
+                    const float* brow = Bmat + (size_t)(u_tw + cb) * NC + n0;
+#pragma unroll
+                    for (int j = 0; j < NBV; ++j) {
+                        const int e = tid + 256 * j;
+                        const int kb = e / (BN / 4), c4 = e - kb * (BN / 4);
+                        const bool valid = e < 8 * BN && n0 + c4 * 4 < NC;
+                        b[j] = *reinterpret_cast<const float4*>(valid ? brow + (size_t)kb * NC + c4 * 4 : Bmat);
+                        ok |= (valid ? 1 : 0) << (2 + j);
+                    }
+                };
+                auto ut_store = [&](const float4(&a)[2], const float4(&b)[NBV], const float4& sc4, const float4& sh4, int ok,
+                                    int buf) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float4 v = a[i];
+                        if (MODE == 0) {
+                            if (scale != nullptr) {
+                                v.x = fmaf(v.x, sc4.x, sh4.x);
+                                v.y = fmaf(v.y, sc4.y, sh4.y);
+                                v.z = fmaf(v.z, sc4.z, sh4.z);
+                                v.w = fmaf(v.w, sc4.w, sh4.w);
+                            }
+                            if (relu) {
+                                v.x = fmaxf(v.x, 0.f);
+                                v.y = fmaxf(v.y, 0.f);
+                                v.z = fmaxf(v.z, 0.f);
+                                v.w = fmaxf(v.w, 0.f);
+                            }
+                        }
+                        if (!((ok >> i) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);  // padding is zero AFTER the activation
+                        float* dst = &As[buf][(v_r0 + 32 * i) * LDA + v_k4 * 4];  // 8-byte aligned (LDA even)
+                        *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+                        *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NBV; ++j) {
+                        const int e = tid + 256 * j;
+                        if (e < 8 * BN) {
+                            const int kb = e / (BN / 4), c4 = e - kb * (BN / 4);
+                            const float4 v = ((ok >> (2 + j)) & 1) ? b[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            *reinterpret_cast<float4*>(&Bs[buf][kb * LDB + c4 * 4]) = v;  // LDB % 4 == 0
+                        }
+                    }
+                };
+                const int last = nch - 1;
+                ut_load(0, ra[0], rb[0], rsc[0], rsh[0], rok[0]);
+                ut_load(imin_dev(1, last), ra[1], rb[1], rsc[1], rsh[1], rok[1]);
+                ut_store(ra[0], rb[0], rsc[0], rsh[0], rok[0], 0);
+                __syncthreads();
+                for (int ch0 = 0; ch0 < nch; ch0 += 2) {
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const int ch = ch0 + d;
+                        if (ch < nch) {
+                            const int buf = d;  // == ch & 1
+                            ut_load(imin_dev(ch + 2, last), ra[d], rb[d], rsc[d], rsh[d], rok[d]);
+                            {
+                                const float* Ab = &As[buf][(wave * 16 + r16) * LDA + kq];
+                                const float* Bb = &Bs[buf][kq * LDB + r16];
+                                float av[KC / 4], bv[KC / 4][NT];
+#pragma unroll
+                                for (int ks = 0; ks < KC / 4; ++ks) {
+                                    av[ks] = Ab[ks * 4];
+#pragma unroll
+                                    for (int j = 0; j < NT; ++j) bv[ks][j] = Bb[ks * 4 * LDB + j * 16];
+                                }
+#pragma unroll
+                                for (int ks = 0; ks < KC / 4; ++ks)
+#pragma unroll
+                                    for (int j = 0; j < NT; ++j) acc[j] = mfma16(av[ks], bv[ks][j], acc[j]);
+                            }
+                            if (ch + 1 < nch) ut_store(ra[d ^ 1], rb[d ^ 1], rsc[d ^ 1], rsh[d ^ 1], rok[d ^ 1], buf ^ 1);
+                            __syncthreads();
+                        }
+                    }
                 }
-#pragma unroll
-                for (int ks = 0; ks < KC / 4; ++ks)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[j] = mfma16(av[ks], bv[ks][j], acc[j]);
             }
-            if (ch + 1 < nch) stage_store(buf ^ 1);
+        } else {
+            if (nch > 0) {
+                stage_load(0);
+                stage_store(0);
+            }
             __syncthreads();
+            for (int ch = 0; ch < nch; ++ch) {
+                const int buf = ch & 1;
+                if (ch + 1 < nch) stage_load(ch + 1);  // global loads of the next chunk fly under this chunk's MFMAs
+                // all LDS operand reads of the chunk first, then the MFMAs back to back: with one wave per SIMD a
+                // read -> wait -> MFMA chain per k-step leaves the matrix pipe idle for the LDS latency 8 times per chunk
+                {
+                    const float* Ab = &As[buf][(wave * 16 + r16) * LDA + kq];
+                    const float* Bb = &Bs[buf][kq * LDB + r16];
+                    float av[KC / 4], bv[KC / 4][NT];
+#pragma unroll
+                    for (int ks = 0; ks < KC / 4; ++ks) {
+                        av[ks] = Ab[ks * 4];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) bv[ks][j] = Bb[ks * 4 * LDB + j * 16];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KC / 4; ++ks)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[j] = mfma16(av[ks], bv[ks][j], acc[j]);
+                }
+                if (ch + 1 < nch) stage_store(buf ^ 1);
+                __syncthreads();
+            }
         }
 
         // ---- epilogue
@@ -576,7 +652,7 @@ __device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Ge
     }
 }
 
-template <int MODE, int NT, bool VEC>
+template <int MODE, int NT, bool VEC, bool UT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __restrict__ S, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int relu,
                                                         const float* __restrict__ Bmat, const float* __restrict__ bias,
@@ -585,16 +661,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __r
                                                         const float* __restrict__ invstd, float* __restrict__ gv,
                                                         double* __restrict__ partial, int CsPad) {
     __shared__ __align__(16) char smem[GemmSmem<NT>::bytes];
-    conv_gemm_body<MODE, NT, VEC>(smem, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad,
+    conv_gemm_body<MODE, NT, VEC, UT>(smem, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad,
                                   blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
 }
 
-template <int MODE, bool VEC>
+template <int MODE, bool VEC, bool UT>
 static void launch_gemm_v(int NT, dim3 grid, hipStream_t st, Geom g, const float* S, const float* scale, const float* shift,
                           int relu, const float* Bmat, const float* bias, const float* res, float* y, const float* xin,
                           const float* mean, const float* invstd, float* gv, double* partial, int CsPad) {
 #define OTVAE_CG(N_)                                                                                                      \
-    conv_gemm_kernel<MODE, N_, VEC><<<grid, 256, 0, st>>>(g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, \
+    conv_gemm_kernel<MODE, N_, VEC, UT><<<grid, 256, 0, st>>>(g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, \
                                                           gv, partial, CsPad)
     switch (NT) {
         case 1: OTVAE_CG(1); break;
@@ -613,10 +689,13 @@ static void launch_gemm(int NT, dim3 grid, hipStream_t st, Geom g, const float* 
                         const float* mean, const float* invstd, float* gv, double* partial, int CsPad) {
     const bool vec = (g.Cs % 4 == 0) && (g.Cn % 4 == 0) && aligned16(S) && aligned16(Bmat) &&
                      (scale == nullptr || (aligned16(scale) && aligned16(shift)));
-    if (vec)
-        launch_gemm_v<MODE, true>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
+    const int CK = MODE == 0 ? g.Cs : g.Cn;
+    if (vec && CK % KC == 0)  // a K-chunk lies inside one tap: uniform-tap pipeline
+        launch_gemm_v<MODE, true, true>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
+    else if (vec)
+        launch_gemm_v<MODE, true, false>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
     else
-        launch_gemm_v<MODE, false>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
+        launch_gemm_v<MODE, false, false>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
 }
 
 static void fwd_grid(const Geom& g, int& NT, dim3& grid, int& CnPad) {
@@ -1380,6 +1459,7 @@ struct DevJobs {
     DevJob j[CJ_MAX];
 };
 
+template <bool UT>
 __global__ __launch_bounds__(256) void conv_jobs_kernel(DevJobs t) {
     extern __shared__ __align__(16) char jobs_smem[];
     int ji = 0;
@@ -1392,10 +1472,10 @@ __global__ __launch_bounds__(256) void conv_jobs_kernel(DevJobs t) {
     const int r = lb / J.gx;
     const int by = r % J.gy, bz = r / J.gy;
 #define CJ_FWD(N_)                                                                                                        \
-    conv_gemm_body<0, N_, true>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, J.bias, J.res, J.out, nullptr, nullptr, \
+    conv_gemm_body<0, N_, true, UT>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, J.bias, J.res, J.out, nullptr, nullptr, \
                                 nullptr, nullptr, J.partial, J.cpad, bx, by, bz, J.gx, J.gz)
 #define CJ_DGRAD(N_)                                                                                                      \
-    conv_gemm_body<1, N_, true>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, nullptr, nullptr, nullptr, J.xin,     \
+    conv_gemm_body<1, N_, true, UT>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, nullptr, nullptr, nullptr, J.xin,     \
                                 J.mean, J.invstd, J.out, J.partial, J.cpad, bx, by, bz, J.gx, J.gz)
 #define CJ_WGRAD(N_) \
     conv_wgrad_body<N_, true>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, J.out, J.Kp, J.has_bias, J.chunk, bx, by, bz)
@@ -1456,6 +1536,7 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
     size_t smem = 0;
     int nblocks = 0;
     int packed_idx[CJ_MAX];
+    int pack_ut = -1;  // uniform-tap flavour of the packed forward / data-gradient jobs (-1: none yet)
     auto flush = [&]() -> int {
         if (pack.n == 0) return OTVAE_OK;
         if (pack.n == 1) {  // nothing to share a launch with: the dedicated kernel (static LDS, same body)
@@ -1463,9 +1544,13 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             pack = {};
             smem = 0;
             nblocks = 0;
+            pack_ut = -1;
             return rc;
         }
-        conv_jobs_kernel<<<nblocks, 256, smem, st>>>(pack);
+        if (pack_ut == 1)
+            conv_jobs_kernel<true><<<nblocks, 256, smem, st>>>(pack);
+        else
+            conv_jobs_kernel<false><<<nblocks, 256, smem, st>>>(pack);
         OTVAE_CHECK_LAUNCH("otvae_conv_multi");
         for (int i = 0; i < pack.n; ++i) {  // immediate reductions of the packed weight-gradient jobs
             const otvae_conv_job& jb = jobs[packed_idx[i]];
@@ -1479,6 +1564,7 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
         pack = {};
         smem = 0;
         nblocks = 0;
+        pack_ut = -1;
         return OTVAE_OK;
     };
     for (int i = 0; i < n; ++i) {
@@ -1562,10 +1648,13 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             if (rc) return rc;
             continue;
         }
-        if (pack.n == CJ_MAX) {
+        int job_ut = -1;
+        if (jb.kind != OTVAE_JOB_BWD_WEIGHT) job_ut = ((jb.kind == OTVAE_JOB_FWD ? g.Cs : g.Cn) % KC == 0) ? 1 : 0;
+        if (pack.n == CJ_MAX || (job_ut >= 0 && pack_ut >= 0 && job_ut != pack_ut)) {
             rc = flush();
             if (rc) return rc;
         }
+        if (job_ut >= 0) pack_ut = job_ut;
         d.block0 = nblocks;
         nblocks += d.gx * d.gy * d.gz;
         const size_t need = job_smem_bytes(d.kind, d.NT);
