@@ -227,14 +227,15 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
         for (int c = 0; c < CSM; ++c) acc[c] = 0.f;
         for (int ch = 0; ch < nchild; ++ch) {
             const int iy = sy * g.up + (ch >> 1), ix = sx * g.up + (ch & 1);
-            for (int kh = 0; kh < g.KH; ++kh) {
+            // stride 2: only the taps of this position's parity class contribute; start there and step by the stride
+            for (int kh = (iy + g.pad) & smask; kh < g.KH; kh += g.stride) {
                 const int ty = iy + g.pad - kh;
-                if (ty < 0 || (ty & smask) != 0) continue;  // stride is 1 or 2
+                if (ty < 0) break;  // kh only grows
                 const int oy = ty >> sshift;
                 if (oy >= g.Ho) continue;
-                for (int kw = 0; kw < g.KW; ++kw) {
+                for (int kw = (ix + g.pad) & smask; kw < g.KW; kw += g.stride) {
                     const int tx = ix + g.pad - kw;
-                    if (tx < 0 || (tx & smask) != 0) continue;
+                    if (tx < 0) break;
                     const int ox = tx >> sshift;
                     if (ox >= g.Wo) continue;
                     float gg[CNM];
