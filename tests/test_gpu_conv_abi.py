@@ -185,6 +185,8 @@ CASES = [
     (4, 8, 1, 16, 3, 1, 1, 2),
     (2, 3, 8, 32, 4, 2, 1, 1),      # RGB
     (1, 12, 20, 8, 3, 1, 1, 1),     # channel counts % 4 == 0 but not powers of two, a single image
+    (4100, 1, 1, 32, 3, 1, 1, 1),   # > 2^22 positions: the direct kernels' integer-division fallback
+    (4100, 4, 4, 32, 3, 1, 1, 1),   # > 2^22 rows in the implicit GEMM (row decode falls back to udiv)
 ]
 
 
