@@ -11,7 +11,8 @@ struct WTilePlan {
     int Hv, Wv, CKp;          // virtual grid of act(x) in LDS
     int voffy, voffx, ush, limH, limW;
     int rowsH, rowsW, rowsPI, rowsPIp, rstride;  // output positions per image (padded to a multiple of 4)
-    int vec4;                 // Cs % 4 == 0: float4 staging
+    int vec4;                 // Cs % 4 == 0: float4 staging of x
+    int gvec;                 // gy rows contiguous and Cn % 4 == 0: float4 staging of gy
     int K, Kp, has_bias;      // k-rows: taps * Cs (+ 1 bias row)
     int nkt, nn, ny, CnP;     // 16-row k tiles, 16-col n tiles per block, blocks along n, padded row length of G
     int IPB, vfloats, gfloats;

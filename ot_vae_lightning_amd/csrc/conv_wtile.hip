@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_wtile_kernel(WTilePlan pl, const flo
             }
         }
         // ---- G: output gradient [IPB][rowsPIp][CnP], zero in the channel / position / image padding
-        if (CnP == Cn && rowsPIp == rowsPI) {  // rows are contiguous in memory: a float4 copy
+        if (pl.gvec) {  // rows are contiguous in memory (and 16-byte aligned): a float4 copy
             const int total4 = (pl.IPB * rowsPI * Cn) >> 2, have4 = (nimg * rowsPI * Cn) >> 2;
             const float4* src = reinterpret_cast<const float4*>(gy + (size_t)img0 * rowsPI * Cn);
             float4* dstg = reinterpret_cast<float4*>(G);
@@ -281,6 +281,7 @@ bool conv_wtile_plan(const Geom& g, int has_bias, WTilePlan& pl, int& nblocks, s
     pl.nn = nn;
     pl.ny = cdiv(nnt, nn);
     pl.CnP = (g.Cn + 3) & ~3;  // columns beyond it read as zero
+    pl.gvec = (pl.CnP == g.Cn && pl.rowsPIp == pl.rowsPI) ? 1 : 0;
     // taps that can touch the image for some output position; crop the virtual grid to their bounding box
     int tdy[WT_MAXT], tdx[WT_MAXT];
     int ylo = 1 << 30, yhi = -1, xlo = 1 << 30, xhi = -1;
@@ -318,8 +319,10 @@ bool conv_wtile_plan(const Geom& g, int has_bias, WTilePlan& pl, int& nblocks, s
 
 int conv_wtile_nparts(int nblocks) { return nblocks; }
 
-int conv_wtile(const WTilePlan& pl, int nblocks, size_t smem, hipStream_t st, const float* x, const float* scale,
+int conv_wtile(const WTilePlan& plan, int nblocks, size_t smem, hipStream_t st, const float* x, const float* scale,
                const float* shift, int relu, const float* gy, float* partial) {
+    WTilePlan pl = plan;
+    if (((uintptr_t)gy & 15) != 0) pl.gvec = 0;  // unaligned output gradient: element-wise staging
 #define WT(K_, N_)                                                                                                        \
     do {                                                                                                                  \
         static bool attr_done = false;                                                                                    \
