@@ -262,7 +262,9 @@ def main():
                        ("MNIST-32 CNN VAE (capacity 8, latent 128x1x1, residual=add) + Sinkhorn OT prior (eps=0.05, "
                         "50 iterations, 1024x1024 plan): fwd+bwd+Adam + latent Gaussian statistics update"),
                        "per_gpu_batch": B, "global_batch": world * B,
-                       "parallelism": f"dp{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world}: one process per GPU, flat-gradient all-reduce over RCCL"
+                                       + (", decoder half overlapped with the encoder's backward" if trainer.dp_overlap else ""))
+                       if world > 1 else "single GPU"},
             "final_loss": final_loss,
             "step_roofline": {"alg_gbytes_per_s": round(ips * ALG_BYTES_PER_IMAGE_FWD_BWD / 1e9 / world, 2),
                               "frac_of_hbm_peak": round(ips / world * ALG_BYTES_PER_IMAGE_FWD_BWD / 1e9 / HBM_PEAK_GBS, 5),

@@ -25,12 +25,33 @@ class FlatGradReducer:
     def __init__(self, flat: Tensor, group=None):
         self.flat, self.group = flat, group
         self.world = world_size(group)
-        self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and self.world > 1) else None
+        # a 1-rank process group still runs the collective (used to rehearse the multi-GPU call sequence on one GPU)
+        self.active = dist.is_available() and dist.is_initialized()
+        self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and self.active) else None
 
     @property
     def grad_scale(self) -> float:
         """what Adam multiplies the summed gradient with: DDP averages over ranks"""
         return 1.0 / self.world
+
+    def allreduce_range(self, lo: int, hi: int, wait: bool = True) -> None:
+        """all-reduce(SUM) of flat[lo:hi] on the reducer's stream, ordered after everything queued so far on the current
+        stream; with ``wait=False`` the current stream is NOT made to wait (call ``join()`` before consuming)."""
+        if hi <= lo or not self.active:
+            return
+        part = self.flat[lo:hi]
+        if self.stream is None:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        if wait:
+            self.join()
+
+    def join(self) -> None:
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
 
     def allreduce(self) -> None:
         if self.world == 1:

@@ -17,6 +17,7 @@ Design (DESIGN.md section "engine"):
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -66,7 +67,7 @@ class HipTrainer:
     """
 
     def __init__(self, model, batch_shape, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, use_graph: bool = True, latent_stats=None):
+                 process_group=None, use_graph: bool = True, latent_stats=None, dp_overlap: Optional[bool] = None):
         self.lib = _lib.load()
         self.model = model
         self.params = list(model.optim_parameters())
@@ -104,6 +105,16 @@ class HipTrainer:
         self.group = process_group
         self.reducer = FlatGradReducer(self.gflat, process_group)
         self.world = self.reducer.world
+        # Data-parallel overlap: backward runs in two phases cut at the encoder's output (loss, decoder and prior side
+        # first); the decoder's gradient range is all-reduced on the reducer's stream WHILE the encoder's backward runs,
+        # the rest afterwards.
+        # Default: on for world > 1 when the model exposes encoder/decoder and their gradients are contiguous ranges of
+        # the flat buffer; OTVAE_DP_OVERLAP=0 (or dp_overlap=False) keeps the single all-reduce after backward.
+        if dp_overlap is None:
+            dp_overlap = self.world > 1 and os.environ.get("OTVAE_DP_OVERLAP", "1") != "0"
+        self._dec_range = self._decoder_range() if dp_overlap else None
+        self.dp_overlap = self._dec_range is not None
+        self._graph_b2 = None
         # static I/O
         self.x = torch.zeros(batch_shape, device=dev, dtype=torch.float32)
         lat = (batch_shape[0], *model.latent_size)
@@ -146,6 +157,65 @@ class HipTrainer:
             self.latent_stats.update(target_samples=lat)
         return self._logs
 
+    def _decoder_range(self):
+        """(lo, hi) of the decoder's gradients in the flat buffer, or None when they are not one contiguous range"""
+        dec = getattr(self.model, "decoder", None)
+        if dec is None or not hasattr(self.model, "encoder"):
+            return None
+        ids = {id(p) for p in dec.parameters()}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        lo = self.offsets[idx[0]]
+        hi = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.params) else self.gflat.numel()
+        enc_ids = {id(p) for p in self.model.encoder.parameters()}
+        self._enc_params = [p for p in self.params if id(p) in enc_ids]
+        self._post_params = [p for p in self.params if id(p) not in enc_ids]  # decoder, prior: downstream of the cut
+        if not self._enc_params:
+            return None
+        return lo, hi
+
+    def _phase1(self):
+        """forward + backward of everything downstream of the encoder's output h (loss, decoder, prior): gradients of
+        their parameters and dL/dh.  Same kernels in the same order as ``_forward_backward`` up to the cut."""
+        check(self.lib.otvae_step_begin(ptr(self.step_count), stream()), "otvae_step_begin")
+        self._refresh_wd()
+        for p in self.params:
+            p.grad = None
+        batch = {"samples": self.x, "target": self.x, "kwargs": {"eps": self.eps}}
+        loss, logs, art = self.model.nelbo(batch, 0)
+        h = getattr(self.model, "_last_cut", None)
+        if h is None:  # nothing upstream of the cut needs a gradient: one-phase backward
+            loss.backward()
+        else:
+            # retain_graph: without it the engine also releases the saved tensors of the node that produced h
+            torch.autograd.backward(loss, inputs=self._post_params + [h], retain_graph=True)
+        self._cut = h
+        from ..functional import _PendingReduce
+        _PendingReduce.flush(self.device)  # the decoder's weight gradients are complete before their all-reduce starts
+        self._logs = {k: v.detach() for k, v in logs.items()}
+        self.latents = art["latents"].detach()
+        return self._logs
+
+    def _phase2(self):
+        """the encoder's backward, from dL/dh that phase 1 left at the cut"""
+        h = self._cut
+        if h is not None:
+            torch.autograd.backward(h, h.grad, inputs=self._enc_params)
+            h.grad = None
+            from ..functional import _PendingReduce
+            _PendingReduce.flush(self.device)
+        self._cut = None
+        self.model._last_cut = None
+        if self.latent_stats is not None:
+            self.latent_stats.update(target_samples=self.latents.flatten(1))
+
+    def _allreduce_split_tail(self):
+        lo, hi = self._dec_range
+        self.reducer.allreduce_range(0, lo, wait=False)
+        self.reducer.allreduce_range(hi, self.gflat.numel(), wait=False)
+        self.reducer.join()
+
     def _adam(self):
         check(self.lib.otvae_adam_step(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
                                        ptr(self.hyper), ptr(self.step_count), self.reducer.grad_scale, stream()),
@@ -155,8 +225,14 @@ class HipTrainer:
         self.reducer.allreduce()
 
     def _eager_step(self):
-        logs = self._forward_backward()
-        self._allreduce()
+        if self.dp_overlap:
+            logs = self._phase1()
+            self.reducer.allreduce_range(*self._dec_range, wait=False)  # flies under phase 2
+            self._phase2()
+            self._allreduce_split_tail()
+        else:
+            logs = self._forward_backward()
+            self._allreduce()
         self._adam()
         return logs
 
@@ -182,7 +258,17 @@ class HipTrainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph_fb = torch.cuda.CUDAGraph()
-        if self.world == 1:
+        if self.dp_overlap:
+            with torch.cuda.graph(self._graph_fb):
+                logs = self._phase1()
+                self._out_static = self._loss_vector(logs)
+            self._graph_b2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_b2, pool=self._graph_fb.pool()):  # the cut tensors live in graph 1's pool
+                self._phase2()
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt, pool=self._graph_fb.pool()):
+                self._adam()
+        elif self.world == 1 and not self.reducer.active:
             with torch.cuda.graph(self._graph_fb):
                 logs = self._forward_backward()
                 self._adam()
@@ -225,7 +311,12 @@ class HipTrainer:
             if not self._captured:
                 self.capture()
             self._graph_fb.replay()
-            if self.world > 1:
+            if self.dp_overlap:
+                self.reducer.allreduce_range(*self._dec_range, wait=False)  # side stream, under the encoder's backward
+                self._graph_b2.replay()
+                self._allreduce_split_tail()
+                self._graph_opt.replay()
+            elif self._graph_opt is not None:
                 self._allreduce()
                 self._graph_opt.replay()
             out = self._out_static

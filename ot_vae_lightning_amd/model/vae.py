@@ -105,6 +105,9 @@ class VAE(VisionModule):
     def encode(self, samples: Tensor, return_prior_artifacts: bool = False, expand: bool = False, **kwargs):
         with self._filter(self._encode_func, kwargs.keys()) as encode:
             encodings = encode(samples, **kwargs)
+        # handle for a two-phase backward (engine.HipTrainer overlaps the gradient all-reduce of everything downstream
+        # of the encoder with the encoder's own backward): the ONE tensor through which the loss depends on the encoder
+        self._last_cut = encodings if encodings.requires_grad else None
         if expand:
             encodings, kwargs = self._expand(encodings), self._expand(kwargs)
         if self.prior is None:

@@ -243,3 +243,38 @@ def test_config5_latent_transport_token_shape_vs_oracle(A, D):
     probe = src[0][:, :32]
     rep.check("transported tokens", op.transport(probe.cuda()), O.apply_transport(probe.double(), ms, mt, T).float(), tol=1e-5)
     rep.finish()
+
+
+def test_dp_overlap_two_phase_backward_equals_single_phase(A):
+    """Data-parallel overlap path (backward cut at the encoder output, decoder gradients all-reduced under the encoder's
+    backward, three captured graphs) rehearsed on ONE GPU with a 1-rank RCCL process group: parameters, moments and
+    losses must be identical bits to the single-graph path, eager and captured."""
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    x = [mnist_like(64, 90 + i).cuda() for i in range(3)]
+    eps = [normal((64, 128, 1, 1), 95 + i).cuda() for i in range(3)]
+
+    def run(overlap, graph):
+        torch.manual_seed(11)
+        enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+        dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+        model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+        tr = A.HipTrainer(model, batch_shape=(64, 1, 32, 32), use_graph=graph, dp_overlap=overlap)
+        assert tr.dp_overlap == overlap
+        losses = [tr.step(x[i], eps[i]).clone() for i in range(3)]
+        torch.cuda.synchronize()
+        return tr.pflat.clone(), tr.m.clone(), tr.v.clone(), torch.stack(losses)
+
+    ref = run(False, False)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        for graph in (False, True):
+            got = run(True, graph)
+            for g, r, name in zip(got, ref, ("params", "m", "v", "losses")):
+                assert torch.equal(g, r), (graph, name, float((g - r).abs().max()))
+        plain = run(False, True)  # the two-graph path with the collective in between (what world > 1 ran before)
+        for g, r in zip(plain, ref):
+            assert torch.equal(g, r)
+    finally:
+        dist.destroy_process_group()
