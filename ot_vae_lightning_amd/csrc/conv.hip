@@ -46,11 +46,12 @@ static int check_geom(const otvae_conv_geom* g, const char* who) {
 
 // Column tiles (16 wide) per wave.  A wide tile re-uses the staged A rows for more MFMAs, but a layer with few row tiles
 // (deep layers: 1x1 .. 4x4 maps) then runs on a fraction of the 256 CUs with ONE wave per SIMD, where the loop is bound
-// by instruction issue, not by MFMA throughput: narrow the tile until the launch has >= 512 workgroups (2 per CU).
+// by instruction issue, not by MFMA throughput: narrow the tile until the launch has >= 256 workgroups (one per CU;
+// measured: thresholds of 192..384 are within 1 % of each other for the whole step, 128 and 1024 are 2 % slower).
 static inline int pick_nt(int ncols, long row_blocks) {
     const int nnt = cdiv(ncols, 16);
     int nt = nnt >= 4 ? 4 : nnt;
-    while (nt > 1 && row_blocks * cdiv(nnt, nt) < 512) --nt;
+    while (nt > 1 && row_blocks * cdiv(nnt, nt) < 256) --nt;
     return nt;
 }
 
