@@ -305,3 +305,41 @@ def test_conv_multi_rejects_bad_jobs(lib):
     jobs[0].geom = L.ConvGeom(2, 8, 8, 8, 1, 8, 8, 8, 3, 3, 1, 1)
     assert lib.otvae_conv_multi(1, jobs, None) != 0  # NULL tensors
     assert lib.otvae_conv_multi(0, jobs, None) != 0
+
+
+# ---- BASELINE batch size (1024): size-independent properties of the three passes ----------------------------------------
+FULL = [
+    (1024, 8, 8, 16, 3, 1, 1, 1),     # image-tile kernels (forward, data gradient, weight gradient)
+    (1024, 16, 32, 8, 4, 2, 1, 1),    # stride 2, weight-gradient columns over blockIdx.y
+    (1024, 64, 64, 2, 3, 1, 1, 1),    # deep layer: uniform-tap implicit GEMM
+    (1024, 128, 64, 1, 3, 1, 1, 2),   # decoder entry with up-sampling
+    (1024, 1, 8, 32, 4, 2, 1, 1),     # image side: direct kernels + tile weight gradient
+    (1024, 8, 1, 16, 3, 1, 1, 2),     # reconstruction side
+]
+
+
+@pytest.mark.parametrize("case", FULL, ids=lambda c: "n%d_%dto%d_%dx%d_k%ds%dp%du%d" % (c[0], c[1], c[2], c[3], c[3], c[4], c[5], c[6], c[7]))
+def test_full_batch_adjoint_and_equivariance(lib, case):
+    """At batch 1024 (too large for a float64 restatement in seconds): with the activation removed the layer is linear, so
+    <gy, conv(x)> = <dgrad(gy), x> = <wgrad(x, gy), w> + <gy, bias>  (the three passes are adjoints of one another), and
+    permuting the images of the batch permutes the outputs (bit for bit: images never mix)."""
+    n, cs, cn, hs, k, s, p, up = case
+    c = make_case(n, cs, cn, hs, k, s, p, up, norm=False, relu=False, bias=True, res=False, seed=7)
+    dv = Dev(c)
+    y, _ = run_fwd(dv, stats=False)
+    gv, _, _, _ = run_dgrad(dv, sums=False)
+    gw, gb = run_wgrad(dv)
+    gyd, xd = raw(dv.gy).double(), raw(dv.x).double()
+    lhs = float((gyd * (raw(y).double() - dv.bias.double())).sum())          # <gy, conv(x)> without the bias term
+    via_x = float((raw(gv).double() * xd).sum())
+    via_w = float((gw.double() * dv.w_hwio.double()).sum())
+    scale = float(gyd.abs().sum()) * float(raw(y).abs().max()) / gyd.numel() ** 0.5 + 1e-30
+    assert abs(lhs - via_x) < 2e-5 * max(abs(lhs), scale), (lhs, via_x)
+    assert abs(lhs - via_w) < 2e-5 * max(abs(lhs), scale), (lhs, via_w)
+    assert rel(gb, gyd.reshape(-1, cn).sum(0)) < 1e-5
+    # batch-permutation equivariance
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).cuda()
+    dv2 = Dev(c)
+    dv2.x = nhwc(dv.x[perm])
+    y2, _ = run_fwd(dv2, stats=False)
+    assert torch.equal(y2, nhwc(y[perm]))

@@ -598,3 +598,45 @@ def test_codebook_model_recovers_mixture_centres(A):
     assert float(w2) < 3.0, float(w2)
     enc, idx = model.nearest(samples[:512].cuda())
     assert float((enc - samples[:512].cuda()).norm(dim=-1).mean()) < 2.0
+
+
+@pytest.mark.parametrize("T,H,C", [(1024, 1, 1), (256, 4, 2), (64, 4, 4), (1, 16, 16)])
+def test_attention_full_batch_properties(A, T, H, C):
+    """Batch 1024 (BASELINE size), the (T, heads, width) shapes of the MNIST network: properties that need no restatement.
+    (a) the attention weights of a row sum to one: v == const  =>  out == const, and then d out / d(q, k) == 0 while the
+    v-gradient of every (image, head, channel) sums to the sum of the output gradient; (b) images never mix: permuting the
+    batch permutes out and the gradient (bit for bit); (c) against the float64 formula on 4 images (reference
+    networks/nets_utils.py:63-82)."""
+    rep = Report(f"attention properties at batch 1024, T={T} H={H} C={C}")
+    N = 1024
+    g = torch.Generator().manual_seed(T + H + C)
+    qkv = torch.randn(N, 3 * H * C, T, generator=g).cuda()     # [N, 3*H*C, T] as QKVAttention takes it
+    gout = torch.randn(N, H * C, T, generator=g).cuda()
+    attn = A.QKVAttention(H)
+    # (a)
+    const = qkv.clone()
+    const[:, 2 * H * C:] = 0.75
+    const.requires_grad_(True)
+    out = attn(const)
+    # fp32 accumulation of T weighted terms and of their normaliser: <= ~T^(1/2) ulp typical, T/4 ulp worst case
+    rep.check("v const -> out const", out, torch.full_like(out, 0.75), max(2e-6, T * 1.5e-8))
+    out.backward(gout)
+    gq = const.grad
+    rep.check("v const -> d/dq, d/dk = 0", gq[:, :2 * H * C], torch.zeros_like(gq[:, :2 * H * C]), 1e-5, floor=float(gout.abs().max()))
+    rep.check("sum_s dv_s = sum_t gout_t", gq[:, 2 * H * C:].double().sum(2), gout.double().sum(2), 1e-5)
+    # (b)
+    x1 = qkv.clone().requires_grad_(True)
+    o1 = attn(x1)
+    o1.backward(gout)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(2)).cuda()
+    x2 = qkv[perm].clone().requires_grad_(True)
+    o2 = attn(x2)
+    o2.backward(gout[perm])
+    assert torch.equal(o2, o1[perm]) and torch.equal(x2.grad, x1.grad[perm])
+    # (c) float64 formula on the first 4 images
+    q, k, v = qkv[:4].double().cpu().reshape(4, 3, H, C, T).unbind(1)   # chunk(3) along channels, then head-major
+    sc = 1.0 / C ** 0.5  # the reference scales q AND k by C^-1/2 (nets_utils.py:72-73)
+    w = torch.einsum("nhct,nhcs->nhts", q * sc, k * sc).softmax(-1)
+    ref = torch.einsum("nhts,nhcs->nhct", w, v).reshape(4, H * C, T)
+    rep.check("float64 formula (4 images)", o1[:4], ref, 1e-5)
+    rep.finish()
