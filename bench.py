@@ -155,23 +155,36 @@ def parity_check(A, batch=64):
 
 def time_dominant_kernel(A, trainer, iters=30):
     """Average duration of the dominant kernel of the step (profiles/: attention backward of the decoder's last
-    block, T=1024 tokens, 1 head, 1 channel), launched back to back on the current stream between two HIP events."""
+    block, T=1024 tokens, 1 head, 1 channel), launched back to back through the C ABI between two HIP events on the
+    stream the kernel runs on."""
     from ot_vae_lightning_amd import functional as HF
-    n = PER_GPU_BATCH
-    qkv = torch.randn(n, 3, 32, 32, device="cuda")
-    qkv = HF.as_nhwc(qkv).requires_grad_(True)
-    out = HF.qkv_attention(qkv, 1)
+    from ot_vae_lightning_amd import _lib as L
+    lib = L.load()
+    n, t, heads, c = PER_GPU_BATCH, 1024, 1, 1
+    qkv = HF.as_nhwc(torch.randn(n, 3, 32, 32, device="cuda"))
+    out = HF.qkv_attention(qkv, 1)                       # forward once: out and the log-sum-exp it saved
+    lse = torch.empty((n, heads, t), device="cuda")
+    L.check(lib.otvae_attn_fwd(L.ptr(qkv), n, t, heads, c, L.ptr(out), L.ptr(lse), L.stream()), "otvae_attn_fwd")
     g = torch.randn_like(out)
-    def fn(gg):
-        return torch.autograd.grad(out, qkv, gg, retain_graph=True)
+    gqkv = torch.empty_like(qkv)
+
+    def launch():
+        L.check(lib.otvae_attn_bwd(L.ptr(qkv), L.ptr(out), L.ptr(lse), L.ptr(g), n, t, heads, c, L.ptr(gqkv), L.stream()),
+                "otvae_attn_bwd")
 
     for _ in range(3):
-        fn(g)
+        launch()
+    torch.cuda.synchronize()
+    # `iters` launches captured into one hipGraph: the events then bracket kernel time only (no host launch gaps)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(iters):
+            launch()
+    graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn(g)
+    graph.replay()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
