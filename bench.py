@@ -164,12 +164,13 @@ def time_dominant_kernel(A, trainer, iters=30):
     qkv = HF.as_nhwc(torch.randn(n, 3, 32, 32, device="cuda"))
     out = HF.qkv_attention(qkv, 1)                       # forward once: out and the log-sum-exp it saved
     lse = torch.empty((n, heads, t), device="cuda")
-    L.check(lib.otvae_attn_fwd(L.ptr(qkv), n, t, heads, c, L.ptr(out), L.ptr(lse), L.stream()), "otvae_attn_fwd")
+    aux = torch.empty((n, heads, t, c * c), device="cuda")  # key moments: the training path's backward uses them
+    L.check(lib.otvae_attn_fwd(L.ptr(qkv), n, t, heads, c, L.ptr(out), L.ptr(lse), L.ptr(aux), L.stream()), "otvae_attn_fwd")
     g = torch.randn_like(out)
     gqkv = torch.empty_like(qkv)
 
     def launch():
-        L.check(lib.otvae_attn_bwd(L.ptr(qkv), L.ptr(out), L.ptr(lse), L.ptr(g), n, t, heads, c, L.ptr(gqkv), L.stream()),
+        L.check(lib.otvae_attn_bwd(L.ptr(qkv), L.ptr(out), L.ptr(lse), L.ptr(g), L.ptr(aux), n, t, heads, c, L.ptr(gqkv), L.stream()),
                 "otvae_attn_bwd")
 
     for _ in range(3):

@@ -138,9 +138,13 @@ typedef struct otvae_conv_job {
 int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream);
 
 /* ---- QKVAttention (networks/nets_utils.py:63-82) ---------------------------------------------------------- */
-/* qkv [N][T][3*H*C] (channel = which*H*C + h*C + c) -> out [N][T][H*C]; lse [N][H][T] saved for backward. */
-int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, void* stream);
-int otvae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* gout,
+/* qkv [N][T][3*H*C] (channel = which*H*C + h*C + c) -> out [N][T][H*C]; lse [N][H][T] saved for backward.
+ * aux (nullable; honoured for head widths C <= 2, ignored otherwise): [N][H][T][C*C] per-query covariance of values and
+ * keys under the attention weights, D[c'][c] = sum_s p_s (v_s[c'] - out[c']) k_s[c].  Passing the same buffer to
+ * otvae_attn_bwd lets it form dq[c] = sum_c' gout[c'] D[c'][c] without a pass over the keys; with aux == NULL it
+ * recomputes the pairs. */
+int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, float* aux, void* stream);
+int otvae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux,
                    int N, int T, int H, int C, float* gqkv, void* stream);
 
 /* ---- GaussianPrior (prior/gaussian.py:63-96) + Prior.forward scaling (prior/base.py:74-78) ---------------- */

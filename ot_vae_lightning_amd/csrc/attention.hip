@@ -39,7 +39,9 @@ __device__ __forceinline__ int adiv(int k, int d, float inv_d) {
 }
 
 // stage {k, v} records of the block's slices: sm[sl][t][2C]
-template <int C>
+// CENTER: the value entries are stored minus the slice's first value v_0 (a pivot for the shifted-data covariance of the
+// AUX forward kernel; any constant near the values works, v_0 needs no reduction)
+template <int C, bool CENTER = false>
 __device__ __forceinline__ void stage_kv(float* __restrict__ sm, const float* __restrict__ qkv, long slice0, int nsl, int T,
                                          int H) {
     const int HC = H * C, W3 = 3 * HC;
@@ -54,13 +56,25 @@ __device__ __forceinline__ void stage_kv(float* __restrict__ sm, const float* __
         const int dn = adiv(hs, H, inv_h);
         const long n = n0 + dn;
         const int h = hs - dn * H;
-        sm[e] = qkv[(n * T + t) * W3 + (1 + which) * HC + h * C + c];
+        float val = qkv[(n * T + t) * W3 + (1 + which) * HC + h * C + c];
+        if (CENTER && which == 1) val -= qkv[(n * T) * W3 + 2 * HC + h * C + c];
+        sm[e] = val;
     }
 }
 
-template <int C, int QPT>
+// AUX (head widths 1 and 2, training): besides out the forward pass also accumulates, per query, the covariance of values
+// and keys under its attention weights, D[c'][c] = sum_s p_s (v_s[c'] - out[c']) k_s[c].  The query gradient is
+//   dq[c] = sum_s p_s (go . v_s - go . out) k_s[c] = sum_c' go[c'] D[c'][c],
+// so the backward pass needs no pass over the keys for it (it was 47 % of the backward kernel): C*C + C extra FMAs per
+// pair here against 2C + 1 FMAs, a multiply AND the v_exp_f32 per pair there.  D is accumulated as shifted-data moments
+// around the plain mean vbar of the slice's values, D = sum p (v - vbar) k - (out - vbar) sum p k, which keeps the
+// cancellation error proportional to the spread of v rather than to its magnitude (a cheaper pivot, the slice's first
+// value, was 10x less accurate on the whole-network gradient of the ill-conditioned residual=None configuration).
+// aux[n][h][t][C*C] = D row-major.
+template <int C, int QPT, bool AUX>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int N, int T, int H, int SPB,
-                                                       float* __restrict__ out, float* __restrict__ lse) {
+                                                       float* __restrict__ out, float* __restrict__ lse,
+                                                       float* __restrict__ aux) {
     extern __shared__ __align__(16) float sm[];
     const int HC = H * C, W3 = 3 * HC;
     const int TPS = T / QPT;  // threads per slice
@@ -85,7 +99,46 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const float inv_c = LOG2E / (float)C;
     const float* kv = sm + (size_t)sl * T * Rec<C>::KV;
 
-    float q[QPT][C], acc[QPT][C], mx[QPT], l[QPT];
+    constexpr int NA = AUX ? C * C + C : 1;
+    float q[QPT][C], acc[QPT][C], mx[QPT], l[QPT], am[QPT][NA];
+    // AUX: vbar = plain mean of the slice's values, the pivot of the shifted-data covariance.  Every lane sums the values
+    // of its own QPT tokens; the TPS lanes of the slice then combine (a wave or the whole block when QPT == 4, a
+    // power-of-two lane group otherwise).
+    float vbar[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) vbar[c] = 0.f;
+    if constexpr (AUX) {
+        __shared__ float vred[4][C];
+#pragma unroll
+        for (int i = 0; i < QPT; ++i)
+#pragma unroll
+            for (int c = 0; c < C; ++c) vbar[c] += kv[(size_t)(t0 + i) * Rec<C>::KV + C + c];
+        if (TPS >= 64) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) vbar[c] = wave_sum(vbar[c]);
+            if (TPS > 64) {  // TPS == 256: one slice per block, nobody returned early
+                if ((threadIdx.x & 63) == 0)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) vred[threadIdx.x >> 6][c] = vbar[c];
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < C; ++c) vbar[c] = (vred[0][c] + vred[1][c]) + (vred[2][c] + vred[3][c]);
+            }
+        } else if ((TPS & (TPS - 1)) == 0) {
+            for (int m = 1; m < TPS; m <<= 1)
+#pragma unroll
+                for (int c = 0; c < C; ++c) vbar[c] += __shfl_xor(vbar[c], m, 64);
+        } else {  // odd slice sizes: every lane walks the keys
+#pragma unroll
+            for (int c = 0; c < C; ++c) vbar[c] = 0.f;
+            for (int s = 0; s < T; ++s)
+#pragma unroll
+                for (int c = 0; c < C; ++c) vbar[c] += kv[(size_t)s * Rec<C>::KV + C + c];
+        }
+        const float inv_t = 1.f / (float)T;
+#pragma unroll
+        for (int c = 0; c < C; ++c) vbar[c] *= inv_t;
+    }
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
 #pragma unroll
@@ -93,6 +146,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             q[i][c] = qkv[(n * T + t0 + i) * W3 + h * C + c] * inv_c;
             acc[i][c] = 0.f;
         }
+#pragma unroll
+        for (int a = 0; a < NA; ++a) am[i][a] = 0.f;
         l[i] = 0.f;
         mx[i] = -INFINITY;
     }
@@ -115,11 +170,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll 4
     for (int s = 0; s < T; ++s) {
         const float* r = kv + s * Rec<C>::KV;
-        float kk[C], vv[C];
+        float kk[C], vv[C], vc[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             kk[c] = r[c];
             vv[c] = r[C + c];
+            vc[c] = vv[c] - vbar[c];  // once per key, shared by the lane's QPT queries
         }
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -130,6 +186,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             l[i] += p;
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[i][c] = fmaf(p, vv[c], acc[i][c]);
+            if constexpr (AUX) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float pk = p * kk[c];
+                    am[i][C * C + c] += pk;
+#pragma unroll
+                    for (int c2 = 0; c2 < C; ++c2) am[i][c2 * C + c] = fmaf(pk, vc[c2], am[i][c2 * C + c]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -139,13 +204,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int c = 0; c < C; ++c) o[c] = acc[i][c] * rl;
         lse[(n * H + h) * T + t0 + i] = mx[i] * LN2 + __logf(l[i]);  // natural-log LSE
+        if constexpr (AUX) {
+            float* ao = aux + (((size_t)n * H + h) * T + t0 + i) * (C * C);
+#pragma unroll
+            for (int c2 = 0; c2 < C; ++c2)
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    ao[c2 * C + c] = (am[i][c2 * C + c] - (acc[i][c2] * rl - vbar[c2]) * am[i][C * C + c]) * rl;
+        }
     }
 }
 
-template <int C, int QPT>
+template <int C, int QPT, bool AUX>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                        const float* __restrict__ lse_g, const float* __restrict__ gout,
-                                                       int N, int T, int H, int SPB, float* __restrict__ gqkv) {
+                                                       const float* __restrict__ aux, int N, int T, int H, int SPB,
+                                                       float* __restrict__ gqkv) {
     extern __shared__ __align__(16) float sm[];
     constexpr int RKV = Rec<C>::KV, RQG = Rec<C>::QG;
     const int HC = H * C, W3 = 3 * HC;
@@ -197,8 +271,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const float* kv = s_kv + (size_t)sl * T * RKV;
     const float* qg = s_qg + (size_t)sl * T * RQG;
 
-    // ---- phase A: this lane's QPT queries against every key -> dQ
-    {
+    // ---- phase A: dQ.  With the forward pass's key moments (AUX) it is a few FMAs per query; otherwise this lane's QPT
+    // queries against every key
+    if constexpr (AUX) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const float* r = qg + (size_t)(t0 + i) * RQG;
+            const float* dm = aux + (((size_t)n * H + h) * T + t0 + i) * (C * C);
+            float* o = gqkv + (n * T + t0 + i) * W3 + h * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float s = 0.f;
+#pragma unroll
+                for (int c2 = 0; c2 < C; ++c2) s = fmaf(r[C + c2], dm[c2 * C + c], s);
+                o[c] = s * inv_c;
+            }
+        }
+    } else {
         float q[QPT][C], go[QPT][C], dq[QPT][C], ls[QPT], dl[QPT];
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -334,7 +423,7 @@ static int attn_check(const char* who, int N, int T, int H, int C, int floats_pe
     return OTVAE_OK;
 }
 
-extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, void* stream) {
+extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, float* aux, void* stream) {
     OTVAE_REQUIRE(qkv && out && lse, "otvae_attn_fwd: NULL tensor");
     int qpt, spb;
     int rc = attn_check("otvae_attn_fwd", N, T, H, C, 2 * C, &qpt, &spb);
@@ -345,10 +434,16 @@ extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, floa
 #define FWD_K(CC)                                                                                   \
     do {                                                                                            \
         if (qpt == 4) {                                                                             \
-            if constexpr (CC <= 4) attn_fwd_kernel<CC, 4><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse); \
+            if constexpr (CC <= 2) {                                                                \
+                if (aux) attn_fwd_kernel<CC, 4, true><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, aux); \
+                else attn_fwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr); \
+            } else if constexpr (CC <= 4) attn_fwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr); \
             else { otvae_set_error("otvae_attn_fwd: T >= 256 with head width %d > 4 unsupported", CC); return OTVAE_EUNSUPPORTED; } \
         } else {                                                                                    \
-            attn_fwd_kernel<CC, 1><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse);              \
+            if constexpr (CC <= 2) {                                                                \
+                if (aux) attn_fwd_kernel<CC, 1, true><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, aux); \
+                else attn_fwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr); \
+            } else attn_fwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr); \
         }                                                                                           \
     } while (0)
     ATTN_C_SWITCH(C, FWD_K)
@@ -357,8 +452,8 @@ extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, floa
     return OTVAE_OK;
 }
 
-extern "C" int otvae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* gout, int N, int T, int H,
-                              int C, float* gqkv, void* stream) {
+extern "C" int otvae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux, int N,
+                              int T, int H, int C, float* gqkv, void* stream) {
     OTVAE_REQUIRE(qkv && out && lse && gout && gqkv, "otvae_attn_bwd: NULL tensor");
     int qpt, spb;
     const int rqg = (2 * C + 2 + 3) & ~3;
@@ -370,10 +465,16 @@ extern "C" int otvae_attn_bwd(const float* qkv, const float* out, const float* l
 #define BWD_K(CC)                                                                                   \
     do {                                                                                            \
         if (qpt == 4) {                                                                             \
-            if constexpr (CC <= 4) attn_bwd_kernel<CC, 4><<<grid, 256, lds, st>>>(qkv, out, lse, gout, N, T, H, spb, gqkv); \
+            if constexpr (CC <= 2) {                                                                \
+                if (aux) attn_bwd_kernel<CC, 4, true><<<grid, 256, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv); \
+                else attn_bwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv); \
+            } else if constexpr (CC <= 4) attn_bwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv); \
             else { otvae_set_error("otvae_attn_bwd: T >= 256 with head width %d > 4 unsupported", CC); return OTVAE_EUNSUPPORTED; } \
         } else {                                                                                    \
-            attn_bwd_kernel<CC, 1><<<grid, 256, lds, st>>>(qkv, out, lse, gout, N, T, H, spb, gqkv);  \
+            if constexpr (CC <= 2) {                                                                \
+                if (aux) attn_bwd_kernel<CC, 1, true><<<grid, 256, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv); \
+                else attn_bwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv); \
+            } else attn_bwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv); \
         }                                                                                           \
     } while (0)
     ATTN_C_SWITCH(C, BWD_K)

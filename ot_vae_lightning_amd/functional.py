@@ -399,19 +399,26 @@ class _AttentionFn(torch.autograd.Function):
         c = width // (3 * heads)
         out = empty_nhwc(n, heads * c, h, w, qkv)
         lse = torch.empty((n, heads, t), device=qkv.device, dtype=torch.float32)
-        check(lib.otvae_attn_fwd(ptr(qkv), n, t, heads, c, ptr(out), ptr(lse), stream()), "otvae_attn_fwd")
-        ctx.save_for_backward(qkv, out, lse)
+        # head widths 1 and 2 (the 32x32 and 16x16 blocks, 83 % of the attention time): the forward pass also emits the
+        # per-query key moments from which the backward pass forms dq without another pass over the keys
+        aux = None
+        if c <= 2 and ctx.needs_input_grad[0]:
+            aux = torch.empty((n, heads, t, c * c), device=qkv.device, dtype=torch.float32)
+        check(lib.otvae_attn_fwd(ptr(qkv), n, t, heads, c, ptr(out), ptr(lse), ptr(aux), stream()), "otvae_attn_fwd")
+        ctx.save_for_backward(qkv, out, lse, aux) if aux is not None else ctx.save_for_backward(qkv, out, lse)
         ctx.dims = (n, t, heads, c)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.load()
-        qkv, out, lse = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        qkv, out, lse = saved[:3]
+        aux = saved[3] if len(saved) > 3 else None
         n, t, heads, c = ctx.dims
         gout = as_nhwc(gout)
         gqkv = torch.empty_strided(qkv.shape, qkv.stride(), device=qkv.device, dtype=qkv.dtype)
-        check(lib.otvae_attn_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(gout), n, t, heads, c, ptr(gqkv), stream()),
+        check(lib.otvae_attn_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(gout), ptr(aux), n, t, heads, c, ptr(gqkv), stream()),
               "otvae_attn_bwd")
         return gqkv, None
 
