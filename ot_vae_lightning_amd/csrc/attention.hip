@@ -38,10 +38,9 @@ __device__ __forceinline__ int adiv(int k, int d, float inv_d) {
     return k < (1 << 22) ? (int)(((float)k + 0.5f) * inv_d) : k / d;
 }
 
-// stage {k, v} records of the block's slices: sm[sl][t][2C]
-// CENTER: the value entries are stored minus the slice's first value v_0 (a pivot for the shifted-data covariance of the
-// AUX forward kernel; any constant near the values works, v_0 needs no reduction)
-template <int C, bool CENTER = false>
+// stage {k, v} records of the block's slices: sm[sl][t][STRIDE], the first 2C floats of each record (STRIDE > 2C leaves
+// room for the per-key products of the AUX forward kernel)
+template <int C, int STRIDE = 2 * C>
 __device__ __forceinline__ void stage_kv(float* __restrict__ sm, const float* __restrict__ qkv, long slice0, int nsl, int T,
                                          int H) {
     const int HC = H * C, W3 = 3 * HC;
@@ -56,35 +55,41 @@ __device__ __forceinline__ void stage_kv(float* __restrict__ sm, const float* __
         const int dn = adiv(hs, H, inv_h);
         const long n = n0 + dn;
         const int h = hs - dn * H;
-        float val = qkv[(n * T + t) * W3 + (1 + which) * HC + h * C + c];
-        if (CENTER && which == 1) val -= qkv[(n * T) * W3 + 2 * HC + h * C + c];
-        sm[e] = val;
+        sm[STRIDE == 2 * C ? e : (sl * T + t) * STRIDE + j] = qkv[(n * T + t) * W3 + (1 + which) * HC + h * C + c];
     }
 }
 
 // AUX (head widths 1 and 2, training): besides out the forward pass also accumulates, per query, the covariance of values
 // and keys under its attention weights, D[c'][c] = sum_s p_s (v_s[c'] - out[c']) k_s[c].  The query gradient is
 //   dq[c] = sum_s p_s (go . v_s - go . out) k_s[c] = sum_c' go[c'] D[c'][c],
-// so the backward pass needs no pass over the keys for it (it was 47 % of the backward kernel): C*C + C extra FMAs per
-// pair here against 2C + 1 FMAs, a multiply AND the v_exp_f32 per pair there.  D is accumulated as shifted-data moments
-// around the plain mean vbar of the slice's values, D = sum p (v - vbar) k - (out - vbar) sum p k, which keeps the
-// cancellation error proportional to the spread of v rather than to its magnitude (a cheaper pivot, the slice's first
-// value, was 10x less accurate on the whole-network gradient of the ill-conditioned residual=None configuration).
+// so the backward pass needs no pass over the keys for it (it was 47 % of the backward kernel).  D is accumulated as
+// shifted-data moments around the plain mean vbar of the slice's values, D = sum p (v - vbar) k - (out - vbar) sum p k,
+// which keeps the cancellation error proportional to the spread of v rather than to its magnitude (a cheaper pivot, the
+// slice's first value, was 10x less accurate on the whole-network gradient of the ill-conditioned residual=None
+// configuration).  The per-key products u[c'][c] = (v[c'] - vbar[c']) k[c] are formed once per key and stored in its LDS
+// record {k[C], v[C], u[C*C]} (padded to 16 bytes), so that a (query, key) pair costs C*C + C extra FMAs and nothing else.
 // aux[n][h][t][C*C] = D row-major.
+template <int C, bool AUX>
+struct FwdRec {
+    static constexpr int KV = AUX ? ((2 * C + C * C + 3) & ~3) : 2 * C;
+};
+
 template <int C, int QPT, bool AUX>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int N, int T, int H, int SPB,
                                                        float* __restrict__ out, float* __restrict__ lse,
                                                        float* __restrict__ aux) {
     extern __shared__ __align__(16) float sm[];
+    constexpr int KVS = FwdRec<C, AUX>::KV;
     const int HC = H * C, W3 = 3 * HC;
     const int TPS = T / QPT;  // threads per slice
     const long total = (long)N * H;
     const long slice0 = (long)blockIdx.x * SPB;
     const int nsl = (int)min((long)SPB, total - slice0);
-    stage_kv<C>(sm, qkv, slice0, nsl, T, H);
+    stage_kv<C, KVS>(sm, qkv, slice0, nsl, T, H);
     __syncthreads();
     const int sl = adiv((int)threadIdx.x, TPS, 1.0f / (float)TPS);
-    if (sl >= nsl) return;
+    const bool active = sl < nsl;
+    if (!AUX && !active) return;  // AUX: idle lanes stay for the block barrier below, they touch slice 0 read-only
     const int t0 = (threadIdx.x - sl * TPS) * QPT;
     long n;
     int h;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
     // scores are kept in the log2 domain (q pre-multiplied by log2(e)/C) so that exp is a bare v_exp_f32
     const float inv_c = LOG2E / (float)C;
-    const float* kv = sm + (size_t)sl * T * Rec<C>::KV;
+    float* kv = sm + (size_t)(active ? sl : 0) * T * KVS;
 
     constexpr int NA = AUX ? C * C + C : 1;
     float q[QPT][C], acc[QPT][C], mx[QPT], l[QPT], am[QPT][NA];
@@ -112,11 +117,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < QPT; ++i)
 #pragma unroll
-            for (int c = 0; c < C; ++c) vbar[c] += kv[(size_t)(t0 + i) * Rec<C>::KV + C + c];
+            for (int c = 0; c < C; ++c) vbar[c] += kv[(size_t)(t0 + i) * KVS + C + c];
         if (TPS >= 64) {
 #pragma unroll
             for (int c = 0; c < C; ++c) vbar[c] = wave_sum(vbar[c]);
-            if (TPS > 64) {  // TPS == 256: one slice per block, nobody returned early
+            if (TPS > 64) {  // TPS == 256: one slice per block
                 if ((threadIdx.x & 63) == 0)
 #pragma unroll
                     for (int c = 0; c < C; ++c) vred[threadIdx.x >> 6][c] = vbar[c];
@@ -133,11 +138,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             for (int c = 0; c < C; ++c) vbar[c] = 0.f;
             for (int s = 0; s < T; ++s)
 #pragma unroll
-                for (int c = 0; c < C; ++c) vbar[c] += kv[(size_t)s * Rec<C>::KV + C + c];
+                for (int c = 0; c < C; ++c) vbar[c] += kv[(size_t)s * KVS + C + c];
         }
         const float inv_t = 1.f / (float)T;
 #pragma unroll
         for (int c = 0; c < C; ++c) vbar[c] *= inv_t;
+        // the per-key products of this lane's own tokens
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                float* r = kv + (size_t)(t0 + i) * KVS;
+#pragma unroll
+                for (int c2 = 0; c2 < C; ++c2)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) r[2 * C + c2 * C + c] = (r[C + c2] - vbar[c2]) * r[c];
+            }
+        }
+        __syncthreads();
+        if (!active) return;
     }
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
@@ -154,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     if constexpr (C == 1) {
         float kmax = -INFINITY, kmin = INFINITY;
         for (int s = 0; s < T; ++s) {
-            const float k = kv[s * 2];
+            const float k = kv[s * KVS];
             kmax = fmaxf(kmax, k);
             kmin = fminf(kmin, k);
         }
@@ -162,20 +180,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         for (int i = 0; i < QPT; ++i) mx[i] = fmaxf(q[i][0] * kmax, q[i][0] * kmin);
     } else {
         for (int s = 0; s < T; ++s) {
-            const float* r = kv + s * Rec<C>::KV;
+            const float* r = kv + s * KVS;
 #pragma unroll
             for (int i = 0; i < QPT; ++i) mx[i] = fmaxf(mx[i], dotc<C>(q[i], r));
         }
     }
 #pragma unroll 4
     for (int s = 0; s < T; ++s) {
-        const float* r = kv + s * Rec<C>::KV;
-        float kk[C], vv[C], vc[C];
+        const float* r = kv + s * KVS;
+        float kk[C], vv[C], uu[AUX ? C * C : 1];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             kk[c] = r[c];
             vv[c] = r[C + c];
-            vc[c] = vv[c] - vbar[c];  // once per key, shared by the lane's QPT queries
+        }
+        if constexpr (AUX) {
+#pragma unroll
+            for (int a = 0; a < C * C; ++a) uu[a] = r[2 * C + a];
         }
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -188,12 +209,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             for (int c = 0; c < C; ++c) acc[i][c] = fmaf(p, vv[c], acc[i][c]);
             if constexpr (AUX) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float pk = p * kk[c];
-                    am[i][C * C + c] += pk;
+                for (int c = 0; c < C; ++c) am[i][C * C + c] = fmaf(p, kk[c], am[i][C * C + c]);
 #pragma unroll
-                    for (int c2 = 0; c2 < C; ++c2) am[i][c2 * C + c] = fmaf(pk, vc[c2], am[i][c2 * C + c]);
-                }
+                for (int a = 0; a < C * C; ++a) am[i][a] = fmaf(p, uu[a], am[i][a]);
             }
         }
     }
@@ -426,11 +444,13 @@ static int attn_check(const char* who, int N, int T, int H, int C, int floats_pe
 extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, float* aux, void* stream) {
     OTVAE_REQUIRE(qkv && out && lse, "otvae_attn_fwd: NULL tensor");
     int qpt, spb;
-    int rc = attn_check("otvae_attn_fwd", N, T, H, C, 2 * C, &qpt, &spb);
+    if (C > 2) aux = nullptr;
+    const int rkv = aux ? ((2 * C + C * C + 3) & ~3) : 2 * C;  // FwdRec<C, AUX>::KV
+    int rc = attn_check("otvae_attn_fwd", N, T, H, C, rkv, &qpt, &spb);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int grid = cdiv((int64_t)N * H, spb);
-    const size_t lds = (size_t)spb * T * 2 * C * sizeof(float);
+    const size_t lds = (size_t)spb * T * rkv * sizeof(float);
 #define FWD_K(CC)                                                                                   \
     do {                                                                                            \
         if (qpt == 4) {                                                                             \
