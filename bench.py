@@ -181,23 +181,26 @@ def time_dominant_kernel(A, trainer, iters=30):
     with torch.cuda.graph(graph):
         for _ in range(iters):
             launch()
-    graph.replay()
+    for _ in range(10):     # the set-up above left the GPU idle: bring the clocks back to the training loop's state
+        graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    graph.replay()
+    for _ in range(4):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    # algorithmic work of this launch: reads qkv (3 floats/token), out, lse, gout, writes gqkv -> 9 floats per token;
-    # arithmetic: T*T pair evaluations per image, each recomputed twice (dQ pass, dK/dV pass)
+    ms = e0.elapsed_time(e1) / (4 * iters)
+    # algorithmic work of this launch: reads qkv (3 floats/token), out, lse, gout, the forward's key moments (1 float for
+    # one channel), writes gqkv (3) -> 10 floats per token; arithmetic: T*T pair evaluations per image (one dK/dV pass;
+    # dQ comes from the moments)
     tokens = n * 1024
-    alg_bytes = tokens * 9 * 4
-    pair_evals = 2 * n * 1024 * 1024
+    alg_bytes = tokens * 10 * 4
+    pair_evals = n * 1024 * 1024
     # HBM traffic of this launch from the PMC passes (profiles/r01_pmc_per_kernel.csv: FETCH_SIZE 12376 KiB -> x2 gfx950
     # correction, WRITE_SIZE 12288 KiB, separate --pmc runs as MI355X_MICROARCH.md prescribes) = 36.17 MB: the kernel
     # moves its algorithmic bytes exactly once; what bounds it is v_exp_f32 / VALU issue, not HBM.
-    return {"kernel": "attn_bwd_kernel<1,4> (T=1024,H=1,C=1)", "ms": ms, "alg_bytes": alg_bytes, "pair_evals": pair_evals,
+    return {"kernel": "attn_bwd_kernel<1,4,true> (T=1024,H=1,C=1)", "ms": ms, "alg_bytes": alg_bytes, "pair_evals": pair_evals,
             "pmc_traffic_bytes": (2 * 12376.0 + 12288.0) * 1024}
 
 

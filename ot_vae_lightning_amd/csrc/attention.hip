@@ -169,6 +169,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         l[i] = 0.f;
         mx[i] = -INFINITY;
     }
+    // scores of two queries at a time as one packed FMA (the compiler does not pair them by itself: it folds the
+    // subtraction of the maximum into a source-negation modifier, which v_pk_fma_f32 would have to apply to both halves)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int QP = QPT / 2;
+    f2 q2[QP > 0 ? QP : 1][C], nm2[QP > 0 ? QP : 1];
+#pragma unroll
+    for (int j = 0; j < QP; ++j)
+#pragma unroll
+        for (int c = 0; c < C; ++c) q2[j][c] = (f2){q[2 * j][c], q[2 * j + 1][c]};
     if constexpr (C == 1) {
         float kmax = -INFINITY, kmin = INFINITY;
         for (int s = 0; s < T; ++s) {
@@ -178,6 +187,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int i = 0; i < QPT; ++i) mx[i] = fmaxf(q[i][0] * kmax, q[i][0] * kmin);
+    } else if constexpr (QP > 0) {
+#pragma unroll 2
+        for (int s = 0; s < T; ++s) {
+            const float* r = kv + s * KVS;
+#pragma unroll
+            for (int j = 0; j < QP; ++j) {
+                f2 d = q2[j][0] * (f2){r[0], r[0]};
+#pragma unroll
+                for (int c = 1; c < C; ++c) d = __builtin_elementwise_fma(q2[j][c], (f2){r[c], r[c]}, d);
+                mx[2 * j] = fmaxf(mx[2 * j], d.x);
+                mx[2 * j + 1] = fmaxf(mx[2 * j + 1], d.y);
+            }
+        }
     } else {
         for (int s = 0; s < T; ++s) {
             const float* r = kv + s * KVS;
@@ -185,6 +207,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             for (int i = 0; i < QPT; ++i) mx[i] = fmaxf(mx[i], dotc<C>(q[i], r));
         }
     }
+#pragma unroll
+    for (int j = 0; j < QP; ++j) nm2[j] = (f2){-mx[2 * j], -mx[2 * j + 1]};
 #pragma unroll 4
     for (int s = 0; s < T; ++s) {
         const float* r = kv + s * KVS;
@@ -198,12 +222,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int a = 0; a < C * C; ++a) uu[a] = r[2 * C + a];
         }
+        float scs[QPT];
+        if constexpr (QP > 0) {
+#pragma unroll
+            for (int j = 0; j < QP; ++j) {
+                f2 sc = nm2[j];
+#pragma unroll
+                for (int c = 0; c < C; ++c) sc = __builtin_elementwise_fma(q2[j][c], (f2){kk[c], kk[c]}, sc);
+                scs[2 * j] = sc.x;
+                scs[2 * j + 1] = sc.y;
+            }
+        } else {
+            float sc = -mx[0];
+#pragma unroll
+            for (int c = 0; c < C; ++c) sc = fmaf(q[0][c], kk[c], sc);
+            scs[0] = sc;
+        }
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            float sc = -mx[i];
-#pragma unroll
-            for (int c = 0; c < C; ++c) sc = fmaf(q[i][c], kk[c], sc);
-            const float p = EXP2(sc);
+            const float p = EXP2(scs[i]);
             l[i] += p;
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[i][c] = fmaf(p, vv[c], acc[i][c]);
@@ -348,8 +385,64 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             for (int c = 0; c < C; ++c) o[c] = dq[i][c] * inv_c;
         }
     }
-    // ---- phase B: this lane's QPT keys against every query -> dK, dV
-    {
+    // ---- phase B: this lane's QPT keys against every query -> dK, dV.  Two keys at a time in packed registers (spelled
+    // out: left to itself the compiler folds the "- lse" / "- delta" into source-negation modifiers of scalar FMAs and
+    // packs only the accumulations)
+    if constexpr (QPT % 2 == 0) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        constexpr int QP = QPT / 2;
+        f2 k2[QP][C], v2[QP][C], dk2[QP][C], dv2[QP][C];
+#pragma unroll
+        for (int j = 0; j < QP; ++j) {
+            const float* r0 = kv + (size_t)(t0 + 2 * j) * RKV;
+            const float* r1 = r0 + RKV;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                k2[j][c] = (f2){r0[c] * LOG2E, r1[c] * LOG2E};
+                v2[j][c] = (f2){r0[C + c], r1[C + c]};
+                dk2[j][c] = dv2[j][c] = (f2){0.f, 0.f};
+            }
+        }
+#pragma unroll 4
+        for (int t = 0; t < T; ++t) {
+            const float* r = qg + (size_t)t * RQG;
+            f2 qq[C], gg[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                qq[c] = (f2){r[c], r[c]};
+                gg[c] = (f2){r[C + c], r[C + c]};
+            }
+            const float nls = -r[2 * C], ndl = -r[2 * C + 1];
+#pragma unroll
+            for (int j = 0; j < QP; ++j) {
+                f2 sc = (f2){nls, nls}, dp = (f2){ndl, ndl};
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    sc = __builtin_elementwise_fma(k2[j][c], qq[c], sc);
+                    dp = __builtin_elementwise_fma(v2[j][c], gg[c], dp);
+                }
+                const f2 p = (f2){EXP2(sc.x), EXP2(sc.y)};
+                const f2 ds = p * dp;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    dv2[j][c] = __builtin_elementwise_fma(p, gg[c], dv2[j][c]);
+                    dk2[j][c] = __builtin_elementwise_fma(ds, qq[c], dk2[j][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QP; ++j) {
+            float* o0 = gqkv + (n * T + t0 + 2 * j) * W3 + h * C;
+            float* o1 = o0 + W3;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                o0[HC + c] = dk2[j][c].x;
+                o1[HC + c] = dk2[j][c].y;
+                o0[2 * HC + c] = dv2[j][c].x;
+                o1[2 * HC + c] = dv2[j][c].y;
+            }
+        }
+    } else {
         float k[QPT][C], v[QPT][C], dk[QPT][C], dv[QPT][C];
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
