@@ -59,6 +59,31 @@ __device__ __forceinline__ void stage_kv(float* __restrict__ sm, const float* __
     }
 }
 
+// Combine one value per lane over the TPS consecutive lanes of a slice (OP 0 sum, 1 max, 2 min).  All 256 threads of the
+// block call it together; TPS must be a multiple of 64 or a power of two below 64 (slice_reduce_ok).
+__device__ __forceinline__ bool slice_reduce_ok(int TPS) { return TPS % 64 == 0 || (TPS < 64 && (TPS & (TPS - 1)) == 0); }
+template <int OP>
+__device__ __forceinline__ float slice_combine(float a, float b) {
+    return OP == 0 ? a + b : OP == 1 ? fmaxf(a, b) : fminf(a, b);
+}
+template <int OP>
+__device__ __forceinline__ float slice_reduce(float v, int TPS, float* red /* 4 floats of LDS */) {
+    if (TPS % 64 == 0) {
+        v = OP == 0 ? wave_sum(v) : OP == 1 ? wave_max(v) : wave_min(v);
+        if (TPS > 64) {
+            __syncthreads();  // the previous call's readers are done with red
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+            __syncthreads();
+            const int wps = TPS >> 6, w0 = (int)(threadIdx.x >> 6) / wps * wps;  // the waves of this lane's slice
+            v = red[w0];
+            for (int w = 1; w < wps; ++w) v = slice_combine<OP>(v, red[w0 + w]);
+        }
+    } else {
+        for (int m = 1; m < TPS; m <<= 1) v = slice_combine<OP>(v, __shfl_xor(v, m, 64));
+    }
+    return v;
+}
+
 // AUX (head widths 1 and 2, training): besides out the forward pass also accumulates, per query, the covariance of values
 // and keys under its attention weights, D[c'][c] = sum_s p_s (v_s[c'] - out[c']) k_s[c].  The query gradient is
 //   dq[c] = sum_s p_s (go . v_s - go . out) k_s[c] = sum_c' go[c'] D[c'][c],
@@ -89,7 +114,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     __syncthreads();
     const int sl = adiv((int)threadIdx.x, TPS, 1.0f / (float)TPS);
     const bool active = sl < nsl;
-    if (!AUX && !active) return;  // AUX: idle lanes stay for the block barrier below, they touch slice 0 read-only
     const int t0 = (threadIdx.x - sl * TPS) * QPT;
     long n;
     int h;
@@ -106,40 +130,49 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 
     constexpr int NA = AUX ? C * C + C : 1;
     float q[QPT][C], acc[QPT][C], mx[QPT], l[QPT], am[QPT][NA];
-    // AUX: vbar = plain mean of the slice's values, the pivot of the shifted-data covariance.  Every lane sums the values
-    // of its own QPT tokens; the TPS lanes of the slice then combine (a wave or the whole block when QPT == 4, a
-    // power-of-two lane group otherwise).
-    float vbar[C];
+    // Slice-wide quantities, each from one value per lane combined over the slice's lanes (every lane walks all keys only
+    // for slice sizes slice_reduce cannot split): vbar (AUX) = plain mean of the slice's values, the pivot of the
+    // shifted-data covariance; kmax / kmin (C == 1) = the extreme keys, which give the row maxima in closed form.
+    __shared__ float red[4];
+    const bool fast = slice_reduce_ok(TPS);
+    float vbar[C], kmax = -INFINITY, kmin = INFINITY;
 #pragma unroll
     for (int c = 0; c < C; ++c) vbar[c] = 0.f;
-    if constexpr (AUX) {
-        __shared__ float vred[4][C];
+    if (fast) {
 #pragma unroll
-        for (int i = 0; i < QPT; ++i)
+        for (int i = 0; i < QPT; ++i) {
+            const float* r = kv + (size_t)(t0 + i) * KVS;
+            if constexpr (AUX) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) vbar[c] += kv[(size_t)(t0 + i) * KVS + C + c];
-        if (TPS >= 64) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) vbar[c] = wave_sum(vbar[c]);
-            if (TPS > 64) {  // TPS == 256: one slice per block
-                if ((threadIdx.x & 63) == 0)
-#pragma unroll
-                    for (int c = 0; c < C; ++c) vred[threadIdx.x >> 6][c] = vbar[c];
-                __syncthreads();
-#pragma unroll
-                for (int c = 0; c < C; ++c) vbar[c] = (vred[0][c] + vred[1][c]) + (vred[2][c] + vred[3][c]);
+                for (int c = 0; c < C; ++c) vbar[c] += r[C + c];
             }
-        } else if ((TPS & (TPS - 1)) == 0) {
-            for (int m = 1; m < TPS; m <<= 1)
-#pragma unroll
-                for (int c = 0; c < C; ++c) vbar[c] += __shfl_xor(vbar[c], m, 64);
-        } else {  // odd slice sizes: every lane walks the keys
-#pragma unroll
-            for (int c = 0; c < C; ++c) vbar[c] = 0.f;
-            for (int s = 0; s < T; ++s)
-#pragma unroll
-                for (int c = 0; c < C; ++c) vbar[c] += kv[(size_t)s * KVS + C + c];
+            if constexpr (C == 1) {
+                kmax = fmaxf(kmax, r[0]);
+                kmin = fminf(kmin, r[0]);
+            }
         }
+        if constexpr (AUX) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) vbar[c] = slice_reduce<0>(vbar[c], TPS, red);
+        }
+        if constexpr (C == 1) {
+            kmax = slice_reduce<1>(kmax, TPS, red);
+            kmin = slice_reduce<2>(kmin, TPS, red);
+        }
+    } else if (AUX || C == 1) {
+        for (int s = 0; s < T; ++s) {
+            const float* r = kv + (size_t)s * KVS;
+            if constexpr (AUX) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) vbar[c] += r[C + c];
+            }
+            if constexpr (C == 1) {
+                kmax = fmaxf(kmax, r[0]);
+                kmin = fminf(kmin, r[0]);
+            }
+        }
+    }
+    if constexpr (AUX) {
         const float inv_t = 1.f / (float)T;
 #pragma unroll
         for (int c = 0; c < C; ++c) vbar[c] *= inv_t;
@@ -155,8 +188,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             }
         }
         __syncthreads();
-        if (!active) return;
     }
+    if (!active) return;  // idle lanes stayed for the block barriers above; they read slice 0 and wrote nothing
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
 #pragma unroll
@@ -179,12 +212,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int c = 0; c < C; ++c) q2[j][c] = (f2){q[2 * j][c], q[2 * j + 1][c]};
     if constexpr (C == 1) {
-        float kmax = -INFINITY, kmin = INFINITY;
-        for (int s = 0; s < T; ++s) {
-            const float k = kv[s * KVS];
-            kmax = fmaxf(kmax, k);
-            kmin = fminf(kmin, k);
-        }
 #pragma unroll
         for (int i = 0; i < QPT; ++i) mx[i] = fmaxf(q[i][0] * kmax, q[i][0] * kmin);
     } else if constexpr (QP > 0) {

@@ -600,6 +600,33 @@ def test_codebook_model_recovers_mixture_centres(A):
     assert float((enc - samples[:512].cuda()).norm(dim=-1).mean()) < 2.0
 
 
+@pytest.mark.parametrize("T,H,C", [(512, 1, 1), (512, 2, 2), (260, 2, 1), (260, 1, 2), (48, 3, 2), (36, 2, 1), (1024, 2, 2),
+                                   (5, 1, 1), (128, 3, 1), (768, 1, 2)])
+def test_attention_slice_layouts_vs_float64(A, T, H, C):
+    """Head widths 1 and 2 (the kernels that carry the forward key moments) at token counts that put 1, 2, 4 ... slices
+    in a workgroup, slices that straddle waves (T/4 = 65), non-power-of-two lane groups (48, 36) and a last workgroup
+    with fewer slices than the others (3 images): forward and the three gradients against the float64 formula
+    (reference networks/nets_utils.py:63-82) through autograd."""
+    import otvae_oracle as oracle
+    rep = Report(f"attention slice layouts T={T} H={H} C={C}")
+    N = 3
+    g = torch.Generator().manual_seed(7 * T + H + C)
+    qkv = torch.randn(N, 3 * H * C, T, generator=g)
+    qkv[:, 2 * H * C:] += 3.0            # values far from zero: the shifted-data moments must not lose the spread
+    gout = torch.randn(N, H * C, T, generator=g)
+    ref_in = qkv.double().requires_grad_(True)
+    ref = oracle.qkv_attention(ref_in, H)
+    ref.backward(gout.double())
+    x = qkv.cuda().requires_grad_(True)
+    out = A.QKVAttention(H)(x)
+    out.backward(gout.cuda())
+    rep.check("out", out, ref.detach(), 1e-5)
+    w = 2 * H * C
+    rep.check("d/dq, d/dk", x.grad[:, :w], ref_in.grad[:, :w], 2e-5, floor=float(ref_in.grad[:, :w].abs().max()))
+    rep.check("d/dv", x.grad[:, w:], ref_in.grad[:, w:], 1e-5)
+    rep.finish()
+
+
 @pytest.mark.parametrize("T,H,C", [(1024, 1, 1), (256, 4, 2), (64, 4, 4), (1, 16, 16)])
 def test_attention_full_batch_properties(A, T, H, C):
     """Batch 1024 (BASELINE size), the (T, heads, width) shapes of the MNIST network: properties that need no restatement.
