@@ -97,9 +97,18 @@ int otvae_conv_bwd_weight(const otvae_conv_geom* g, const float* x, const float*
                           const float* gy, int has_bias, float* partial, float* gw, float* gb, int defer_reduce,
                           void* stream);
 /* With defer_reduce != 0 only the partials are written; the caller later reduces any number of layers in one launch
- * (host arrays of n entries; K = KH*KW*Cs, Kp = K + has_bias, P from otvae_conv_bwd_weight_ws): */
+ * (host arrays of n entries; K = KH*KW*Cs, Kp = K + has_bias, P from otvae_conv_bwd_weight_ws).
+ * Taps that touch the image for no output position (8 of the 9 taps of a 3x3 layer on a 1x1 map, 12 of the 16 of a
+ * 4x4 stride-2 layer from 2x2 to 1x1) have an exactly zero gradient: otvae_conv_dead_taps returns them (bit kh*KW+kw).
+ * With defer_reduce == OTVAE_DEFER_SPARSE the weight-gradient kernels may leave the partial rows of those taps
+ * unwritten; the caller must then pass the layer's Cs and mask to otvae_wgrad_reduce_batched, which writes zeros there
+ * without reading the partials (Cs and dead may both be NULL: every row is read). */
+#define OTVAE_DEFER_DENSE 1
+#define OTVAE_DEFER_SPARSE 2
+int otvae_conv_dead_taps(const otvae_conv_geom* g, uint32_t* mask);
 int otvae_wgrad_reduce_batched(int n, const float* const* partial, const int* P, const int* K, const int* Kp,
-                               const int* Cn, float* const* gw, float* const* gb, void* stream);
+                               const int* Cn, float* const* gw, float* const* gb, const int* Cs, const uint32_t* dead,
+                               void* stream);
 
 /* ---- several independent ConvLayer kernels in ONE launch ----------------------------------------------------
  * The two branches of a ConvBlock (block[0] and skip read the same x, networks/cnn.py:311-335) in the forward pass,
@@ -116,7 +125,7 @@ typedef struct otvae_conv_job {
     int32_t kind;               /* OTVAE_JOB_* */
     int32_t relu;               /* ReLU after the (optional) affine of the layer INPUT x */
     int32_t has_bias;           /* BWD_WEIGHT */
-    int32_t defer_reduce;       /* BWD_WEIGHT */
+    int32_t defer_reduce;       /* BWD_WEIGHT: 0, OTVAE_DEFER_DENSE or OTVAE_DEFER_SPARSE */
     otvae_conv_geom geom;
     const float* x;             /* layer input [N][Hs][Ws][Cs] (BWD_DATA: only for the ReLU mask / BatchNorm sums) */
     const float* scale;         /* BatchNorm scale/shift of x, or NULL */

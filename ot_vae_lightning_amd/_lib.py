@@ -18,6 +18,7 @@ _lib = None
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 pp = C.POINTER(C.c_void_p)  # host array of device pointers
 pi32 = C.POINTER(C.c_int)
+pu32 = C.POINTER(C.c_uint32)
 
 
 class ConvGeom(C.Structure):
@@ -27,6 +28,7 @@ class ConvGeom(C.Structure):
 pg = C.POINTER(ConvGeom)
 
 JOB_FWD, JOB_BWD_DATA, JOB_BWD_WEIGHT = 0, 1, 2
+DEFER_DENSE, DEFER_SPARSE = 1, 2  # otvae_conv_job.defer_reduce (include/otvae.h)
 
 
 class ConvJob(C.Structure):  # otvae_conv_job
@@ -55,7 +57,8 @@ SIGNATURES = {
     "otvae_bn_bwd_apply": (i32, [i32, pp, vp, vp, i64, i32, vp, vp]),
     "otvae_conv_bwd_weight_ws": (i32, [pg, i32, pi32]),
     "otvae_conv_bwd_weight": (i32, [pg, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
-    "otvae_wgrad_reduce_batched": (i32, [i32, pp, pi32, pi32, pi32, pi32, pp, pp, vp]),
+    "otvae_wgrad_reduce_batched": (i32, [i32, pp, pi32, pi32, pi32, pi32, pp, pp, pi32, pu32, vp]),
+    "otvae_conv_dead_taps": (i32, [pg, pu32]),
     "otvae_conv_multi": (i32, [i32, pj, vp]),
     "otvae_attn_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "otvae_attn_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),

@@ -903,7 +903,7 @@ template <int NT, bool VEC>
 __device__ __forceinline__ void conv_wgrad_body(char* __restrict__ smem, const Geom& g, const float* __restrict__ x,
                                                 const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                 const float* __restrict__ gy, float* __restrict__ partial, int Kp,
-                                                int has_bias, unsigned chunk, int bx, int by, int bz) {
+                                                int has_bias, int skip_dead, unsigned chunk, int bx, int by, int bz) {
     using SM = WgradSmem<NT>;
     constexpr int BN = SM::BN;
     constexpr int LDA = SM::LDA;
@@ -1154,7 +1154,9 @@ __device__ __forceinline__ void conv_wgrad_body(char* __restrict__ smem, const G
         if (sub + 1 < nsub) stage_store(buf ^ 1);
         __syncthreads();
     }
-    // partial[pc][k][n]
+    // partial[pc][k][n].  A 16-row tile without a live row holds only rows of taps that never touch the image (or rows
+    // past Kp): with skip_dead the reduction knows them (otvae_conv_dead_taps) and does not read them
+    if (skip_dead && !live) return;
     float* out = partial + (size_t)pc * Kp * g.Cn;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -1172,10 +1174,10 @@ template <int NT, bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int relu,
                                                          const float* __restrict__ gy, float* __restrict__ partial, int Kp,
-                                                         int has_bias, unsigned chunk) {
+                                                         int has_bias, int skip_dead, unsigned chunk) {
     __shared__ __align__(16) char smem[WgradSmem<NT>::bytes];
-    conv_wgrad_body<NT, VEC>(smem, g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk, blockIdx.x, blockIdx.y,
-                             blockIdx.z);
+    conv_wgrad_body<NT, VEC>(smem, g, x, scale, shift, relu, gy, partial, Kp, has_bias, skip_dead, chunk, blockIdx.x,
+                             blockIdx.y, blockIdx.z);
 }
 
 // out[e] = sum_p partial[p][e] in a fixed order.
@@ -1306,7 +1308,8 @@ extern "C" int otvae_conv_bwd_weight(const otvae_conv_geom* gg, const float* x, 
     const bool vec = (g.Cs % 4 == 0) && (g.Cn % 4 == 0) && aligned16(x) && aligned16(gy) &&
                      (scale == nullptr || (aligned16(scale) && aligned16(shift)));
 #define OTVAE_WG(N_, V_) \
-    conv_wgrad_kernel<N_, V_><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, chunk)
+    conv_wgrad_kernel<N_, V_><<<grid, 256, 0, st>>>(g, x, scale, shift, relu, gy, partial, Kp, has_bias, \
+                                                    defer_reduce == OTVAE_DEFER_SPARSE, chunk)
     if (vec) {
         switch (NT) {
             case 1: OTVAE_WG(1, true); break;
@@ -1340,6 +1343,8 @@ struct WrbDesc {
     float* gw[WRB_MAX];
     float* gb[WRB_MAX];
     int P[WRB_MAX], K[WRB_MAX], Kp[WRB_MAX], Cn[WRB_MAX];
+    int Cs[WRB_MAX];         // rows per tap (0: no dead-tap information)
+    unsigned dead[WRB_MAX];  // bit t: tap t never touches the image, its Cs rows are zero and may be unwritten
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
@@ -1351,6 +1356,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
     const int P = d.P[l], K = d.K[l], Cn = d.Cn[l];
     const size_t total = (size_t)d.Kp[l] * Cn;
     const int lane = threadIdx.x & 63;
+    const unsigned dead = d.dead[l];
+    const int rows_per_tap = d.Cs[l];
+    // element e lies in a row of a dead tap: exactly zero, and the partials may hold garbage there
+    auto is_dead = [&](size_t e) -> bool {
+        if (dead == 0u) return false;
+        const int k = (int)(e / (size_t)Cn);
+        return k < K && ((dead >> (k / rows_per_tap)) & 1u);
+    };
     if (total >= 4096 && P >= 16) {
         // large gradient: partial rows are far apart (total*4 bytes), so lanes run along e (coalesced 256-byte reads)
         // and the 4 waves split the partials; fixed order: p ascending within a wave, then waves 0..3 through LDS
@@ -1358,7 +1371,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
         for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
             const size_t e = e0 + lane;
             float s = 0.f;
-            if (e < total) {
+            if (e < total && !is_dead(e)) {
                 int p = pg;
                 for (; p + 12 < P; p += 16) {
                     const float a0 = partial[(size_t)p * total + e], a1 = partial[(size_t)(p + 4) * total + e];
@@ -1383,7 +1396,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
     } else if (P >= 16) {  // small gradient, many partials: one wave per element (neighbouring waves share the lines)
         for (size_t e = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (size_t)gridDim.x * 4) {
             float s = 0.f;
-            for (int p = lane; p < P; p += 64) s += partial[(size_t)p * total + e];
+            if (!is_dead(e))
+                for (int p = lane; p < P; p += 64) s += partial[(size_t)p * total + e];
             s = wave_sum(s);
             if (lane == 0) {
                 const int k = e / Cn;
@@ -1394,7 +1408,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
     } else {  // one lane per element, serial over the few partials
         for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
             float s = 0.f;
-            for (int p = 0; p < P; ++p) s += partial[(size_t)p * total + e];
+            if (!is_dead(e))
+                for (int p = 0; p < P; ++p) s += partial[(size_t)p * total + e];
             const int k = e / Cn;
             if (k < K) gw[e] = s;
             else if (gb) gb[e - (size_t)K * Cn] = s;
@@ -1402,9 +1417,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
     }
 }
 
+// The taps of a layer that touch the image for no output position (the predicate of conv_wgrad_body): bit kh*KW + kw.
+static unsigned dead_taps(const Geom& g) {
+    const int Hu = g.Hs * g.up, Wu = g.Ws * g.up;
+    unsigned m = 0;
+    if (g.KH * g.KW > 32) return 0;
+    for (int kh = 0; kh < g.KH; ++kh)
+        for (int kw = 0; kw < g.KW; ++kw) {
+            const int dy = kh - g.pad, dx = kw - g.pad;
+            const bool ytouch = (dy + (g.Ho - 1) * g.stride >= 0) && (dy < Hu);
+            const bool xtouch = (dx + (g.Wo - 1) * g.stride >= 0) && (dx < Wu);
+            if (!(ytouch && xtouch)) m |= 1u << (kh * g.KW + kw);
+        }
+    return m;
+}
+
+extern "C" int otvae_conv_dead_taps(const otvae_conv_geom* gg, uint32_t* mask) {
+    int rc = check_geom(gg, "otvae_conv_dead_taps");
+    if (rc) return rc;
+    OTVAE_REQUIRE(mask, "otvae_conv_dead_taps: NULL mask");
+    *mask = dead_taps(to_geom(gg));
+    return OTVAE_OK;
+}
+
 extern "C" int otvae_wgrad_reduce_batched(int n, const float* const* partial, const int* P, const int* K, const int* Kp,
-                                          const int* Cn, float* const* gw, float* const* gb, void* stream) {
+                                          const int* Cn, float* const* gw, float* const* gb, const int* Cs,
+                                          const uint32_t* dead, void* stream) {
     OTVAE_REQUIRE(n > 0 && partial && P && K && Kp && Cn && gw && gb, "otvae_wgrad_reduce_batched: bad argument");
+    OTVAE_REQUIRE((Cs == nullptr) == (dead == nullptr), "otvae_wgrad_reduce_batched: Cs and dead come together");
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += WRB_MAX) {
         WrbDesc d = {};
@@ -1420,6 +1460,11 @@ extern "C" int otvae_wgrad_reduce_batched(int n, const float* const* partial, co
             d.K[i] = K[j];
             d.Kp[i] = Kp[j];
             d.Cn[i] = Cn[j];
+            if (dead && dead[j]) {
+                OTVAE_REQUIRE(Cs[j] > 0 && K[j] % Cs[j] == 0 && K[j] / Cs[j] <= 32, "otvae_wgrad_reduce_batched: entry %d: Cs", j);
+                d.Cs[i] = Cs[j];
+                d.dead[i] = dead[j];
+            }
             const size_t total = (size_t)Kp[j] * Cn[j];
             const size_t work = P[j] < 16 ? cdiv(total, 256) : (total >= 4096 ? cdiv(total, 64) : cdiv(total, 4));
             if (work > maxwork) maxwork = work;
@@ -1451,7 +1496,7 @@ struct DevJob {
     const float* invstd;  // dgrad
     float* out;           // fwd: y            dgrad: gv           wgrad: partial workspace
     double* partial;      // fwd: stat partial dgrad: bn partial
-    int kind, NT, relu, cpad, Kp, has_bias;
+    int kind, NT, relu, cpad, Kp, has_bias, skip_dead;
     unsigned chunk;
     int gx, gy, gz, block0;
 };
@@ -1479,7 +1524,8 @@ __global__ __launch_bounds__(256) void conv_jobs_kernel(DevJobs t) {
     conv_gemm_body<1, N_, true, UT>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, nullptr, nullptr, nullptr, J.xin,     \
                                 J.mean, J.invstd, J.out, J.partial, J.cpad, bx, by, bz, J.gx, J.gz)
 #define CJ_WGRAD(N_) \
-    conv_wgrad_body<N_, true>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, J.out, J.Kp, J.has_bias, J.chunk, bx, by, bz)
+    conv_wgrad_body<N_, true>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, J.out, J.Kp, J.has_bias, J.skip_dead, \
+                              J.chunk, bx, by, bz)
     switch (J.kind * 4 + J.NT - 1) {
         case 0: CJ_FWD(1); break;
         case 1: CJ_FWD(2); break;
@@ -1642,6 +1688,7 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             d.b0 = jb.gy;
             d.out = jb.wpartial;
             d.has_bias = jb.has_bias;
+            d.skip_dead = jb.defer_reduce == OTVAE_DEFER_SPARSE;
             d.gx = nkb, d.gy = nnb, d.gz = P;
         }
         if (!packable) {

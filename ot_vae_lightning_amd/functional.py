@@ -9,6 +9,7 @@ Nothing here computes on the CPU: tensors must be on the GPU and the HIP library
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -135,6 +136,9 @@ def bn_eval_affine(branch: BNBranch):
 
 
 # ------------------------------------------------------------------------------------------------ side stream
+_DENSE_REDUCE = os.environ.get("OTVAE_DENSE_REDUCE", "0") == "1"  # A/B switch: ignore the dead-tap information
+
+
 class _PendingReduce:
     """Weight-gradient partials of the current backward pass whose destination is a trainer-owned flat gradient
     buffer, reduced together by ``flush`` (queued as an autograd-engine callback and called by the trainer before the
@@ -142,11 +146,11 @@ class _PendingReduce:
     _state = {}
 
     @staticmethod
-    def add(device, partial, p, k, kp, cn, gw, gb):
+    def add(device, partial, p, k, kp, cn, gw, gb, cs, dead):
         st = _PendingReduce._state.setdefault(device, [])
         if not st:
             torch.autograd.Variable._execution_engine.queue_callback(lambda dev=device: _PendingReduce.flush(dev))
-        st.append((partial, p, k, kp, cn, gw, gb))
+        st.append((partial, p, k, kp, cn, gw, gb, cs, dead))
 
     @staticmethod
     def flush(device):
@@ -163,7 +167,8 @@ class _PendingReduce:
             return arr
 
         check(lib.otvae_wgrad_reduce_batched(n, ptr_array([e[0] for e in st]), ia(1), ia(2), ia(3), ia(4),
-                                             raw([e[5] for e in st]), raw([e[6] for e in st]), stream()),
+                                             raw([e[5] for e in st]), raw([e[6] for e in st]), ia(7),
+                                             (C.c_uint32 * n)(*[e[8] for e in st]), stream()),
               "otvae_wgrad_reduce_batched")
         st.clear()
 
@@ -265,15 +270,20 @@ class _ConvBNFn(torch.autograd.Function):
                      (not sp.has_bias or getattr(pb, "_otvae_grad_view", None) is not None))
             jb = jobs[njobs]
             njobs += 1
-            jb.kind, jb.relu, jb.has_bias, jb.defer_reduce, jb.geom = _lib.JOB_BWD_WEIGHT, int(sp.relu), int(sp.has_bias), int(defer), g
+            # deferred reductions know the taps that never touch the image (1x1 / 2x2 maps): their partial rows may stay unwritten
+            jb.kind, jb.relu, jb.has_bias, jb.geom = _lib.JOB_BWD_WEIGHT, int(sp.relu), int(sp.has_bias), g
+            jb.defer_reduce = (_lib.DEFER_DENSE if _DENSE_REDUCE else _lib.DEFER_SPARSE) if defer else 0
             jb.x, jb.gy = ptr(x), ptr(gy)
             jb.scale = ptr(scales[b]) if sp.has_norm else None
             jb.shift = ptr(shifts[b]) if sp.has_norm else None
             jb.wpartial, jb.gw, jb.gb = ptr(wpart), ptr(gw), ptr(gb)
             keep += [wpart, gy]
             if defer:
+                dead = C.c_uint32(0)
+                if not _DENSE_REDUCE:
+                    check(lib.otvae_conv_dead_taps(C.byref(g), C.byref(dead)), "otvae_conv_dead_taps")
                 _PendingReduce.add(x.device, wpart, p_w.value, kk - (1 if sp.has_bias else 0), kk, g.Cn,
-                                   gw.data_ptr(), gb.data_ptr() if gb is not None else None)
+                                   gw.data_ptr(), gb.data_ptr() if gb is not None else None, g.Cs, dead.value)
             # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
             gv = None
             part = None

@@ -295,6 +295,65 @@ def test_conv_multi_equals_single_calls(lib):
             assert torch.equal(part[:, :dv.cs].sum(-1), singles[i][5])
 
 
+@pytest.mark.parametrize("shape", [(64, 256, 256, 1, 3, 1, 1, 1), (64, 64, 128, 2, 4, 2, 1, 1), (64, 32, 64, 2, 3, 1, 1, 1)],
+                         ids=["3x3_on_1x1", "4x4s2_2x2_to_1x1", "3x3_on_2x2_no_dead_tap"])
+def test_deferred_sparse_reduce_skips_dead_taps(lib, shape):
+    """Layers whose map is smaller than the kernel: the taps that never touch the image have a zero gradient.  With
+    defer_reduce = OTVAE_DEFER_SPARSE the kernels may leave those partial rows unwritten (the workspace is pre-filled with
+    NaN here) and otvae_wgrad_reduce_batched, given the mask of otvae_conv_dead_taps, must produce exactly the gradient of
+    the immediate (dense) path."""
+    L = _L()
+    n, cs, cn, hs, k, s, p, up = shape
+    dv = Dev(make_case(n, cs, cn, hs, k, s, p, up, seed=11))
+    gw_ref, gb_ref = run_wgrad(dv)
+    dead = C.c_uint32(0)
+    L.check(lib.otvae_conv_dead_taps(C.byref(dv.geom), C.byref(dead)), "dead taps")
+    ho = dv.c["ho"]
+    expect = 0
+    for kh in range(k):
+        for kw in range(k):
+            touch = lambda d: (d + (ho - 1) * s >= 0) and (d < hs * up)  # noqa: E731
+            if not (touch(kh - p) and touch(kw - p)):
+                expect |= 1 << (kh * k + kw)
+    assert dead.value == expect
+    has_bias = dv.bias is not None
+    pw = C.c_int(0)
+    L.check(lib.otvae_conv_bwd_weight_ws(C.byref(dv.geom), int(has_bias), C.byref(pw)), "ws")
+    kk = k * k * cs + (1 if has_bias else 0)
+    wpart = torch.full((pw.value, kk, cn), float("nan"), device="cuda")
+    gw = torch.full_like(dv.w_hwio, float("nan"))
+    gb = torch.full((cn,), float("nan"), device="cuda") if has_bias else None
+    jobs = (L.ConvJob * 1)()
+    jb = jobs[0]
+    jb.kind, jb.relu, jb.has_bias, jb.defer_reduce, jb.geom = L.JOB_BWD_WEIGHT, int(dv.c["relu"]), int(has_bias), L.DEFER_SPARSE, dv.geom
+    jb.x, jb.gy, jb.scale, jb.shift = L.ptr(dv.x), L.ptr(dv.gy), L.ptr(dv.scale), L.ptr(dv.shift)
+    jb.wpartial, jb.gw, jb.gb = L.ptr(wpart), L.ptr(gw), L.ptr(gb)
+    L.check(lib.otvae_conv_multi(1, jobs, L.stream()), "multi wgrad, deferred")
+    one = lambda v: (C.c_int * 1)(v)  # noqa: E731
+    L.check(lib.otvae_wgrad_reduce_batched(1, L.ptr_array([wpart]), one(pw.value), one(kk - int(has_bias)), one(kk), one(cn),
+                                           L.ptr_array([gw]), L.ptr_array([gb]), one(cs), (C.c_uint32 * 1)(dead.value),
+                                           L.stream()), "reduce")
+    torch.cuda.synchronize()
+    assert torch.equal(gw, gw_ref)
+    if has_bias:
+        assert torch.equal(gb, gb_ref)
+    if dead.value:
+        g4 = gw.reshape(k * k, cs, cn)
+        for t in range(k * k):
+            if (dead.value >> t) & 1:
+                assert not g4[t].any()
+        assert torch.isnan(wpart).any()      # the kernels really skipped the dead rows
+    # the dense deferred form (every row written and read) must agree too
+    wpart2 = torch.full((pw.value, kk, cn), float("nan"), device="cuda")
+    gw2 = torch.empty_like(gw)
+    jb.defer_reduce, jb.wpartial = L.DEFER_DENSE, L.ptr(wpart2)
+    L.check(lib.otvae_conv_multi(1, jobs, L.stream()), "multi wgrad, deferred dense")
+    L.check(lib.otvae_wgrad_reduce_batched(1, L.ptr_array([wpart2]), one(pw.value), one(kk - int(has_bias)), one(kk), one(cn),
+                                           L.ptr_array([gw2]), L.ptr_array([gb]), None, None, L.stream()), "reduce dense")
+    torch.cuda.synchronize()
+    assert torch.equal(gw2, gw_ref) and not torch.isnan(wpart2).any()
+
+
 def test_conv_multi_rejects_bad_jobs(lib):
     L = _L()
     jobs = (L.ConvJob * 1)()
