@@ -153,6 +153,10 @@ def parity_check(A, batch=64):
             "tolerance": 1e-4, "batch": batch}
 
 
+# vector-issue bound of the dominant kernel: 1024 SIMDs x 2.4 GHz x 64 lanes / (36 issue cycles per 2 pairs / 2)
+ISSUE_BOUND_TPAIRS = 1024 * 2.4e9 * 64 / 18.0 / 1e12
+
+
 def time_dominant_kernel(A, trainer, iters=30):
     """Average duration of the dominant kernel of the step (profiles/: attention backward of the decoder's last
     block, T=1024 tokens, 1 head, 1 channel), launched back to back through the C ABI between two HIP events on the
@@ -197,11 +201,23 @@ def time_dominant_kernel(A, trainer, iters=30):
     tokens = n * 1024
     alg_bytes = tokens * 10 * 4
     pair_evals = n * 1024 * 1024
-    # HBM traffic of this launch from the PMC passes (profiles/r01_pmc_per_kernel.csv: FETCH_SIZE 12376 KiB -> x2 gfx950
-    # correction, WRITE_SIZE 12288 KiB, separate --pmc runs as MI355X_MICROARCH.md prescribes) = 36.17 MB: the kernel
-    # moves its algorithmic bytes exactly once; what bounds it is v_exp_f32 / VALU issue, not HBM.
     return {"kernel": "attn_bwd_kernel<1,4,true> (T=1024,H=1,C=1)", "ms": ms, "alg_bytes": alg_bytes, "pair_evals": pair_evals,
-            "pmc_traffic_bytes": (2 * 12376.0 + 12288.0) * 1024}
+            "pmc_traffic_bytes": pmc_traffic("attn_bwd_kernel<1, 4, true>")}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/r01_pmc_per_kernel.csv, written by
+    tools/summarize_profiles.py --pmc from three separate rocprofv3 --pmc passes of this same command: FETCH_SIZE with
+    the x2 gfx950 correction + WRITE_SIZE, KiB -> bytes, as MI355X_MICROARCH.md prescribes); None if not collected."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_per_kernel.csv")
+    try:
+        for row in csv.reader(open(path)):
+            if row and row[0].strip().endswith(kernel):
+                return (2.0 * float(row[2]) + float(row[4])) * 1024.0
+    except OSError:
+        pass
+    return None
 
 
 def main():
@@ -291,8 +307,9 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": dom["pmc_traffic_bytes"], "avg_launch_ms": round(dom["ms"], 4),
                          "note": "dominant kernel of the step is exp/VALU-issue bound, not HBM/MFMA bound: "
-                                 "%.2f T (query,key) pair evaluations/s (each: 1 v_exp_f32 + ~5 VALU); its HBM traffic "
-                                 "equals its algorithmic bytes" % (dom["pair_evals"] / dom["ms"] / 1e9)},
+                                 "%.2f T (query,key) pair evaluations/s of %.2f T/s the vector issue port allows "
+                                 "(per 2 pairs: 2 v_exp_f32 at 8 cycles + 5 packed FMA/MUL at 4..5, tools/probe/mfma4x4.hip)"
+                                 % (dom["pair_evals"] / dom["ms"] / 1e9, ISSUE_BOUND_TPAIRS)},
         }
         if args.workload == "sinkhorn":
             line["sinkhorn"] = time_sinkhorn(A)

@@ -355,18 +355,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 
     // ---- phase A: dQ.  With the forward pass's key moments (AUX) it is a few FMAs per query; otherwise this lane's QPT
     // queries against every key
+    // (kept in registers: this lane's queries are also its keys of phase B, so the three gradients of a token are
+    // stored together at the end -- whole q|k|v rows instead of three strided partial-line passes)
+    float dqv[QPT][C];
     if constexpr (AUX) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const float* r = qg + (size_t)(t0 + i) * RQG;
             const float* dm = aux + (((size_t)n * H + h) * T + t0 + i) * (C * C);
-            float* o = gqkv + (n * T + t0 + i) * W3 + h * C;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 float s = 0.f;
 #pragma unroll
                 for (int c2 = 0; c2 < C; ++c2) s = fmaf(r[C + c2], dm[c2 * C + c], s);
-                o[c] = s * inv_c;
+                dqv[i][c] = s * inv_c;
             }
         }
     } else {
@@ -406,11 +408,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             }
         }
 #pragma unroll
-        for (int i = 0; i < QPT; ++i) {
-            float* o = gqkv + (n * T + t0 + i) * W3 + h * C;
+        for (int i = 0; i < QPT; ++i)
 #pragma unroll
-            for (int c = 0; c < C; ++c) o[c] = dq[i][c] * inv_c;
-        }
+            for (int c = 0; c < C; ++c) dqv[i][c] = dq[i][c] * inv_c;
     }
     // ---- phase B: this lane's QPT keys against every query -> dK, dV.  Two keys at a time in packed registers (spelled
     // out: left to itself the compiler folds the "- lse" / "- delta" into source-negation modifiers of scalar FMAs and
@@ -457,12 +457,35 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 }
             }
         }
+        if constexpr (C == 1 && QPT == 4) {
+            // one head of one channel, the whole workgroup on one image (T = 1024): the lane's 4 tokens are 12 consecutive
+            // floats q|k|v q|k|v ..., a wave's 3 KiB are contiguous.  They pass through LDS (the staging area is free now)
+            // so that every store instruction writes 1 KiB of consecutive addresses, 16 bytes per lane.
+            if (H == 1 && T == 1024 && (reinterpret_cast<uintptr_t>(gqkv) & 15) == 0) {
+                __syncthreads();  // every wave is done with the key / query records
+                float* w = sm + (threadIdx.x >> 6) * (64 * 12);
+                float4* wl = reinterpret_cast<float4*>(w + (threadIdx.x & 63) * 12);
+                wl[0] = make_float4(dqv[0][0], dk2[0][0].x, dv2[0][0].x, dqv[1][0]);
+                wl[1] = make_float4(dk2[0][0].y, dv2[0][0].y, dqv[2][0], dk2[1][0].x);
+                wl[2] = make_float4(dv2[1][0].x, dqv[3][0], dk2[1][0].y, dv2[1][0].y);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float4* o = reinterpret_cast<float4*>(gqkv + (n * T + (t0 - (int)(threadIdx.x & 63) * 4)) * 3);
+                const float4* r4 = reinterpret_cast<const float4*>(w);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[k * 64 + (threadIdx.x & 63)] = r4[k * 64 + (threadIdx.x & 63)];
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < QP; ++j) {
             float* o0 = gqkv + (n * T + t0 + 2 * j) * W3 + h * C;
             float* o1 = o0 + W3;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
+                o0[c] = dqv[2 * j][c];
+                o1[c] = dqv[2 * j + 1][c];
                 o0[HC + c] = dk2[j][c].x;
                 o1[HC + c] = dk2[j][c].y;
                 o0[2 * HC + c] = dv2[j][c].x;
@@ -513,6 +536,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             float* o = gqkv + (n * T + t0 + i) * W3 + h * C;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
+                o[c] = dqv[i][c];
                 o[HC + c] = dk[i][c];
                 o[2 * HC + c] = dv[i][c];
             }
