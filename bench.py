@@ -236,10 +236,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # Rehearsal of the N > 1 call sequence on a one-GPU box (OTVAE_BENCH_SHARE_GPU=1): every rank uses cuda:0 and the
+    # collectives go over gloo (RCCL refuses two ranks on one device).  The line it prints is marked and is not a result.
+    share_gpu = world > 1 and os.environ.get("OTVAE_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ot_vae_lightning_amd import build as otbuild
     if rank == 0 and not os.path.exists(otbuild.LIB):
@@ -299,6 +307,8 @@ def main():
                                        + (", decoder half overlapped with the encoder's backward" if trainer.dp_overlap else ""))
                        if world > 1 else "single GPU"},
             "final_loss": final_loss,
+            **({"rehearsal": "ranks share cuda:0, collectives over gloo: call-sequence check, not a measurement"}
+               if share_gpu else {}),
             "step_roofline": {"alg_gbytes_per_s": round(ips * ALG_BYTES_PER_IMAGE_FWD_BWD / 1e9 / world, 2),
                               "frac_of_hbm_peak": round(ips / world * ALG_BYTES_PER_IMAGE_FWD_BWD / 1e9 / HBM_PEAK_GBS, 5),
                               "alg_tflops": round(ips / world * ALG_FLOP_PER_IMAGE_FWD_BWD / 1e12, 3),
