@@ -245,6 +245,86 @@ def test_config5_latent_transport_token_shape_vs_oracle(A, D):
     rep.finish()
 
 
+def test_latent_transport_callback_validation_epoch_vs_oracle(A):
+    """The reference's tests/test_latent_transport.py:44-79 set-up for the Gaussian operator: AutoEncoder(1 -> 64x4x4,
+    capacity 4, residual add), LatentTransport(GaussianTransport, transport_dims=(1, 2, 3)  =>  D = 1024, common operator,
+    unpaired: even validation batches give the target, blurred odd ones the source).  The latents are stochastic as a
+    VAE's are (z = encoder(x) + 0.5 eps), which also keeps the 1024x1024 covariances well conditioned.  One validation
+    epoch driven through the callback hooks; W2^2, the operator and the transported latents against the CPU oracle on the
+    same latents, plus the push-forward property (T Sigma_s T' = Sigma_t, transported mean = target mean) and the reset
+    at the next epoch start."""
+    import torch.nn.functional as F
+    rep = Report("LatentTransport callback: validation epoch, D=1024 Gaussian operator vs CPU oracle")
+    torch.manual_seed(3)
+    ae = A.AutoEncoder(1, 64, 32, 4, capacity=4, double_encoded_features=False, down_up_sample=True, residual="add")
+    vae = A.VAE(autoencoder=ae, prior=None).cuda().eval()
+
+    class StochasticLatents:
+        """module stand-in handed to the hooks: encode = VAE.encode + fixed-scale noise, every result recorded"""
+        training, device = False, torch.device("cuda")
+
+        def __init__(self):
+            self.gen, self.record = torch.Generator(device="cuda").manual_seed(5), []
+
+        def encode(self, x, **kw):
+            z = vae.encode(x, **kw)
+            z = z + 0.5 * torch.randn(z.shape, generator=self.gen, device=z.device)
+            self.record.append(z.flatten(1).double().cpu())
+            return z
+
+        def decode(self, z, **kw):
+            return vae.decode(z, **kw)
+
+    model = StochasticLatents()
+    kern = torch.tensor([1., 4., 6., 4., 1.])
+    kern = (kern[:, None] * kern[None, :] / 256.0)[None, None].cuda()
+    blur = lambda x: F.conv2d(F.pad(x, (2, 2, 2, 2), mode="reflect"), kern)  # noqa: E731  (stands in for GaussianBlur(5))
+    w2_cfg = dict(diag=False, stochastic=False, pg_star=0., make_pd=True, verbose=False, dtype=torch.double)
+    cb = A.LatentTransport(size=vae.latent_size, transport_operator=A.GaussianTransport, transport_dims=(1, 2, 3),
+                           logging_prefix="gaussian", transport_cfg=w2_cfg, source_cfg=dict(dtype=torch.double),
+                           target_cfg=dict(dtype=torch.double), transformations=blur, source_latents_from_train=False,
+                           target_latents_from_train=False, unpaired=True, common_operator=True)
+    assert tuple(vae.latent_size) == (64, 4, 4) and cb.dim == 1024
+    cb.on_fit_start(None, model)
+    cb.on_validation_epoch_start(None, model)
+    with torch.no_grad():
+        for i in range(12):
+            cb.on_validation_batch_end(None, model, {"samples": mnist_like(512, seed=500 + i).cuda()}, None, i)
+        cb.on_validation_epoch_end(None, model)
+    lat = {"t": model.record[0::2], "s": model.record[1::2]}   # unpaired: even batches target, odd batches source
+    cost = cb.logged["transport/gaussian/gaussian/avg_transport_cost"]
+    fit = {}
+    for k in ("s", "t"):
+        acc = None
+        for x in lat[k]:
+            st = O.gaussian_stats(x)
+            acc = list(st) if acc is None else [a + b for a, b in zip(acc, st)]
+        fit[k] = O.gaussian_fit(*acc)
+    (ms, cs), (mt, ct) = fit["s"], fit["t"]
+    rep.check("avg_transport_cost = W2^2", cost, O.w2_gaussian(ms, mt, cs, ct, make_pd=True), tol=1e-8)
+    op = cb.transport_operator
+    T = O.transport_operator_full(cs, ct)
+    rep.check("transport operator", op.transport_operator, T, tol=1e-7)
+    x_src = torch.cat(lat["s"])[:256]
+    z_src = x_src.float().reshape(-1, 64, 4, 4).cuda()
+    with torch.no_grad():
+        moved = cb.transport(z_src)
+    assert moved.shape == z_src.shape
+    rep.check("transported latents", moved.flatten(1), O.apply_transport(x_src, ms, mt, T).float(), tol=1e-5)
+    Tg = op.transport_operator.double().cpu()
+    # exact up to the 1e-8 I the operator adds to Sigma_s before its inverse square root (w2_utils.py:755): ~1e-8 / 0.25
+    rep.check("push-forward: T Sigma_s T' = Sigma_t", Tg @ cs @ Tg.transpose(-1, -2), ct, tol=1e-6)
+    all_src = torch.cat(lat["s"])
+    with torch.no_grad():
+        moved_all = torch.cat([cb.transport(all_src[j:j + 512].float().reshape(-1, 64, 4, 4).cuda()).flatten(1).double().cpu()
+                               for j in range(0, all_src.shape[0], 512)])
+    rep.check("mean of the transported source = target mean", moved_all.mean(0), mt, tol=1e-5)
+    assert cb.sample(4, "target").shape == (4, 64, 4, 4)
+    cb.on_validation_epoch_start(None, model)
+    assert op.transport_operator is None and float(op.source_model._n_obs.sum()) == 0 and float(op.target_model._n_obs.sum()) == 0
+    rep.finish()
+
+
 def test_dp_overlap_two_phase_backward_equals_single_phase(A):
     """Data-parallel overlap path (backward cut at the encoder output, decoder gradients all-reduced under the encoder's
     backward, three captured graphs) rehearsed on ONE GPU with a 1-rank RCCL process group: parameters, moments and
