@@ -19,6 +19,7 @@ Fixtures:
                      apply_transport, GaussianTransport.compute/transport
   codebook.npz       CodebookModel.predict argmax indices + encodings
   codebook_kmeans.npz  CodebookModel.update/fit/predict/w2 (streaming k-means)
+  discrete.npz       CodebookModel in 'mean' mode, DiscreteTransport.compute/transport, CodebookPrior.forward
 """
 import math
 import os
@@ -446,8 +447,95 @@ def gen_codebook_kmeans():
     save("codebook_kmeans.npz", out)
 
 
+def _clusters(g, lead, K, d, B, centres, noise=0.3):
+    which = torch.randint(0, K, (*lead, B), generator=g)
+    return torch.gather(centres, -2, which.unsqueeze(-1).expand(*lead, B, d)) + noise * torch.randn(*lead, B, d, generator=g)
+
+
+def gen_discrete():
+    """G10: the soft 'mean' mode of CodebookModel (update / predict), DiscreteTransport.compute / transport
+    for transport_type 'mean' and 'argmax' (reference tests/test_latent_transport.py:92-101 uses training_mode 'mean',
+    temperature 1e-2), and CodebookPrior.forward (one-hot mode, 'l2' loss: values, straight-through gradient, codebook
+    after the step; evaluation-mode 'kl' loss)."""
+    cb = R.ref("ot.distribution_models.codebook_model")
+    dt = R.ref("ot.transport.discrete_transport")
+    pr = R.ref("prior.codebook")
+    out = {}
+    # ---- (a) soft k-means
+    lead, K, d, B = (2,), 5, 3, 48
+    g = torch.Generator().manual_seed(21)
+    centres = torch.randn(*lead, K, d, generator=g) * 2.0
+    model = cb.CodebookModel(*lead, d, mixture_cfg=dict(n_components=K, training_mode="mean", inference_mode="mean",
+                                                       temperature=0.5))
+    model.train()
+    xs = [_clusters(g, lead, K, d, B, centres) for _ in range(3)]
+    out["mean/batches"], out["mean/cfg"] = npy(torch.stack(xs)), np.array([K, d, B, 0.5])
+    for i, x in enumerate(xs):
+        if i == 0:
+            torch.manual_seed(77)
+        model.update(x)
+        out[f"mean/step{i}/codebook"], out[f"mean/step{i}/n_obs"] = npy(model.codebook).copy(), npy(model._n_obs).copy()
+    model.eval()
+    preds, _, dist = model.predict(xs[-1])
+    out["mean/predict/preds"], out["mean/predict/probs"] = npy(preds), npy(dist.probs)
+    # ---- (b) DiscreteTransport
+    for ttype in ("mean", "argmax"):
+        K, d, B = 8, 3, 96
+        g = torch.Generator().manual_seed(31)
+        cs, ct = torch.randn(K, d, generator=g) * 2.0, torch.randn(K, d, generator=g) * 2.0 + 1.0
+        mix = dict(n_components=K, training_mode="mean", inference_mode="argmax", temperature=1e-2)
+        op = dt.DiscreteTransport(d, source_cfg=dict(mixture_cfg=mix), target_cfg=dict(mixture_cfg=mix), transport_type=ttype,
+                                  sinkhorn_reg=1e-2, sinkhorn_max_iter=200, sinkhorn_threshold=1e-9)
+        op.train()
+        src = [_clusters(g, (), K, d, B, cs) for _ in range(3)]
+        tgt = [_clusters(g, (), K, d, B, ct) for _ in range(3)]
+        for i, (a, b) in enumerate(zip(src, tgt)):
+            # the first update of each model draws its initial atoms with torch.randperm from the host generator (and the
+            # soft assignment then samples indices from it): seed each first call separately
+            if i == 0:
+                torch.manual_seed(78)
+            op.update(source_samples=a)
+            if i == 0:
+                torch.manual_seed(178)
+            op.update(target_samples=b)
+        cost = op.compute()
+        probe = _clusters(g, (), K, d, 40, cs)
+        out[f"dt_{ttype}/src"], out[f"dt_{ttype}/tgt"] = npy(torch.stack(src)), npy(torch.stack(tgt))
+        out[f"dt_{ttype}/source_codebook"], out[f"dt_{ttype}/target_codebook"] = npy(op.source_model.codebook), npy(op.target_model.codebook)
+        out[f"dt_{ttype}/source_probs"], out[f"dt_{ttype}/target_probs"] = npy(op.source_distribution.probs), npy(op.target_distribution.probs)
+        out[f"dt_{ttype}/cost"], out[f"dt_{ttype}/plan"] = npy(cost), npy(op.transport_matrix)
+        out[f"dt_{ttype}/probe"], out[f"dt_{ttype}/moved"] = npy(probe), npy(op.transport(probe))
+    # ---- (c) CodebookPrior
+    # (the reference's first update copies samples[..., randperm(B)[:K], :] into the single shared codebook, which only
+    # fits when the latent is embedded as a whole -- one position -- and B >= K)
+    size, K, Bp = (6, 2, 2), 8, 16
+    prior = pr.CodebookPrior(size, (1, 2, 3), loss="l2", loss_coeff=0.5, annealing_steps=10,
+                             mixture_cfg=dict(n_components=K, training_mode="argmax", inference_mode="argmax"))
+    prior.train()
+    g = torch.Generator().manual_seed(41)
+    w = torch.randn(Bp, *size, generator=g)
+    for step in range(2):
+        x = (torch.randn(Bp, *size, generator=g) * 1.5).requires_grad_(True)
+        if step == 0:
+            torch.manual_seed(79)
+        z, loss, art = prior(x, step=3 + step)
+        ((z * w).sum() + loss.sum()).backward()
+        out[f"prior/step{step}/x"], out[f"prior/step{step}/z"], out[f"prior/step{step}/loss"] = npy(x), npy(z), npy(loss)
+        out[f"prior/step{step}/gx"], out[f"prior/step{step}/probs"] = npy(x.grad), npy(art["distribution"].probs)
+        out[f"prior/step{step}/codebook"] = npy(prior.codebook_model.codebook).copy()
+    out["prior/w"] = npy(w)
+    prior.eval()
+    prior.loss = "kl"
+    x = torch.randn(Bp, *size, generator=g)
+    z, loss, art = prior(x, step=100)
+    out["prior/eval/x"], out["prior/eval/z"], out["prior/eval/loss_kl"] = npy(x), npy(z), npy(loss)
+    prior.loss = "first_kl"
+    out["prior/eval/loss_first_kl"] = npy(prior(x, step=100)[1])
+    save("discrete.npz", out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans"]
+                             "codebook_kmeans", "discrete"]
     for w in which:
         globals()["gen_" + w]()

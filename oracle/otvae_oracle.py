@@ -387,9 +387,12 @@ def codebook_probs(x: Tensor, codebook: Tensor, temperature: float = 1.0) -> Ten
     return torch.softmax(energy / temperature, dim=-1)
 
 
-def codebook_kmeans_stats(x: Tensor, codebook: Tensor, temperature: float = 1.0):
-    """``kmean_iteration`` with one-hot ('argmax') weights (base.py:241-252): (counts [*, K], sums [*, K, d])."""
-    w = torch.nn.functional.one_hot(codebook_probs(x, codebook, temperature).argmax(-1), codebook.shape[-2]).type_as(x)
+def codebook_kmeans_stats(x: Tensor, codebook: Tensor, temperature: float = 1.0, mode: str = "argmax"):
+    """``kmean_iteration`` (base.py:241-252) with one-hot ('argmax') or soft ('mean') weights:
+    (counts [*, K], sums [*, K, d])."""
+    w = codebook_probs(x, codebook, temperature)
+    if mode == "argmax":
+        w = torch.nn.functional.one_hot(w.argmax(-1), codebook.shape[-2]).type_as(x)
     return w.sum(-2), w.transpose(-1, -2) @ x
 
 
@@ -401,7 +404,7 @@ def _laplace(x: Tensor, n_categories: int, eps: Optional[float] = 1e-5) -> Tenso
 
 
 def codebook_update(state: Dict[str, Tensor], x: Tensor, decay: Optional[float], rand_indices: Optional[Tensor] = None,
-                    temperature: float = 1.0, laplace_eps: Optional[float] = 1e-5) -> Dict[str, Tensor]:
+                    temperature: float = 1.0, laplace_eps: Optional[float] = 1e-5, mode: str = "argmax") -> Dict[str, Tensor]:
     """``CodebookModel.update`` (codebook_model.py:121-130, 189-214) on a state {codebook, vec_init, n_obs, running_sum}:
     first-call initialisation from ``rand_indices`` (the reference draws them with torch.randperm), one-hot k-means
     statistics, (EMA) accumulation into the buffers of the observed atoms, codebook = running_sum / smoothed counts."""
@@ -410,7 +413,7 @@ def codebook_update(state: Dict[str, Tensor], x: Tensor, decay: Optional[float],
     if torch.allclose(st["codebook"], st["vec_init"]):
         st["codebook"] = x[..., rand_indices, :].clone()
         st["n_obs"] = st["n_obs"] + 1
-    counts, sums = codebook_kmeans_stats(x, st["codebook"], temperature)
+    counts, sums = codebook_kmeans_stats(x, st["codebook"], temperature, mode)
     hit = counts > 1e-8
     st["n_obs"][hit] = ema(st["n_obs"][hit], counts[hit], decay)
     st["running_sum"][hit] = ema(st["running_sum"][hit], sums[hit], decay)
@@ -434,3 +437,53 @@ def codebook_w2(codebook: Tensor, weights: Tensor, other_atoms: Tensor, other_pr
     cost = 1 / (1 / (torch.cdist(other_atoms, codebook, 2.0) + 1e-8) + 1e-8)
     plan = sinkhorn_log(weights, other_probs, cost, reg=1e-5, max_iter=100, threshold=1e-3)
     return torch.sum(cost * plan, dim=(-2, -1))
+
+
+# ------------------------------------------------------------------------------------------------ discrete transport
+def codebook_weights(n_obs: Tensor) -> Tensor:
+    """``CodebookModel.weights`` (codebook_model.py:96-100): uniform before the first observation, else n_obs / sum."""
+    if torch.allclose(n_obs, torch.zeros_like(n_obs)):
+        return torch.ones_like(n_obs) / n_obs.shape[-1]
+    return n_obs / n_obs.sum(-1, keepdim=True)
+
+
+def discrete_transport_compute(source_codebook: Tensor, source_probs: Tensor, target_codebook: Tensor, target_probs: Tensor,
+                               reg: float = 1e-5, max_iter: int = 1000, threshold: float = 1e-6):
+    """``DiscreteTransport.compute`` after the models are fitted (ot/transport/discrete_transport.py:56-69):
+    cost = source energy of the target atoms = 1 / (cdist(target, source) + 1e-8)  [K_t x K_s as the reference lays it
+    out: rows are the atoms handed to ``energy``], plan = sinkhorn_log(source probs, target probs, cost), total = <cost, plan>."""
+    cost = 1 / (torch.cdist(target_codebook, source_codebook, 2.0) + 1e-8)
+    plan = sinkhorn_log(source_probs, target_probs, cost, reg=reg, max_iter=max_iter, threshold=threshold)
+    return torch.sum(cost * plan, dim=(-2, -1)), plan
+
+
+def discrete_transport_apply(x: Tensor, source_codebook: Tensor, plan: Tensor, target_codebook: Tensor,
+                             temperature: float = 1.0, inference_mode: str = "argmax", transport_type: str = "mean") -> Tensor:
+    """``DiscreteTransport.transport`` (discrete_transport.py:71-95) for the deterministic choices: inputs -> assignment
+    to source atoms (inference mode 'argmax' or 'mean') -> @ plan -> ('argmax': one-hot of the best coupled target atom)
+    -> @ target atoms."""
+    w = codebook_probs(x, source_codebook, temperature)
+    if inference_mode == "argmax":
+        w = F.one_hot(w.argmax(-1), w.size(-1)).type_as(w)
+    moved = w @ plan
+    if transport_type == "argmax":
+        moved = F.one_hot(moved.argmax(-1), moved.size(-1)).type_as(moved)
+    return moved @ target_codebook
+
+
+def codebook_prior_encode(x: Tensor, codebook: Tensor, temperature: float = 1.0, loss: Optional[str] = None,
+                          coeff: float = 1.0):
+    """``CodebookPrior.encode`` + ``Prior.forward`` scaling (prior/codebook.py:75-105, prior/base.py:74-78) for a latent
+    embedded as a whole (x [B, dim], one shared codebook [1, K, dim]) in a one-hot mode: (z = straight-through
+    encodings [1, B, dim], loss [B] * coeff, assignment probabilities [1, B, K])."""
+    probs = codebook_probs(x.detach(), codebook, temperature)                    # [1, B, K]
+    enc = F.one_hot(probs.argmax(-1), probs.size(-1)).type_as(x) @ codebook
+    if loss is None:
+        val = torch.zeros(x.size(-2)).type_as(x)
+    elif loss == "l2":
+        val = F.mse_loss(x.expand_as(enc), enc.detach(), reduction="none").mean(-1).sum(0)
+    else:
+        gap = math.log(codebook.shape[-2]) - torch.distributions.Categorical(probs).entropy()
+        val = gap.sum(0) if loss == "kl" else gap[0]
+    z = x + (enc - x).detach()
+    return z, val * coeff, probs

@@ -7,9 +7,11 @@ statistics -- runs in HIP kernels (``otvae_codebook_assign / _probs / _kmeans``)
 follows is a handful of tiny tensor expressions kept in the reference's own order (boolean-mask updates, Laplace
 smoothing over the observed atoms), and ``w2`` composes the HIP Sinkhorn solver exactly as the reference does.
 
-Supported: ``metric='euclidean'``, ``p=2``, ``topk=None``, one-hot modes (``'argmax'``) for training and inference,
-``update_with_autograd=False``.  The stochastic / soft modes of the reference ('sample', 'mean', 'gumbel-*') belong to its
-DAD models (out of scope) and raise ``NotImplementedError``."""
+Supported: ``metric='euclidean'``, ``p=2``, ``topk=None``, the assignment modes ``'argmax'``, ``'sample'`` (one-hot) and
+``'mean'`` (soft: the assignment distribution itself, as ``DiscreteTransport`` uses it in the reference's
+tests/test_latent_transport.py:92-101; its weighted sums are ``probs^T @ samples``, a plain library GEMM on the HIP
+kernel's probabilities), ``update_with_autograd=False``.  The Gumbel modes of the reference's DAD models (out
+of scope) raise ``NotImplementedError``."""
 from functools import partial
 from typing import Optional, Tuple
 
@@ -54,7 +56,7 @@ class CategoricalEmbeddings(D.Categorical):
         return self._select_one_hot(super().sample(sample_shape))
 
 
-_ONE_HOT_MODES = ("argmax",)
+_MODES = ("argmax", "sample", "mean")
 
 
 class CodebookModel(DistributionModel):
@@ -72,8 +74,8 @@ class CodebookModel(DistributionModel):
         if cfg["metric"] != "euclidean" or float(cfg["p"]) != 2.0 or cfg["topk"] not in (None, 0):
             raise NotImplementedError("the MI355X CodebookModel implements metric='euclidean', p=2, topk=None")
         for m in (cfg["training_mode"], cfg["inference_mode"]):
-            if m not in _ONE_HOT_MODES:
-                raise NotImplementedError(f"assignment mode {m!r}: only {_ONE_HOT_MODES} run on the MI355X path")
+            if m not in _MODES:
+                raise NotImplementedError(f"assignment mode {m!r}: only {_MODES} run on the MI355X path")
         if kwargs.get("update_with_autograd", False):
             raise NotImplementedError("update_with_autograd=True is not implemented on the MI355X path")
         self.n_components = int(cfg["n_components"])
@@ -153,25 +155,39 @@ class CodebookModel(DistributionModel):
         self._validate_samples(samples)
         return 1 / (torch.cdist(samples.type_as(self.codebook), self.codebook, self.p) + 1e-8)
 
+    @property
+    def mode(self) -> str:
+        return self.training_mode if self.training else self.inference_mode
+
     def assign(self, samples: Tensor):
-        """(one-hot weights [*, B, K], sampled indices [*, B], Categorical(softmax weights)) -- base.py:206-239 in
-        'argmax' mode.  As in the reference the returned ``indices`` are a draw from the distribution (they come from
-        this device's generator, so they are not comparable across devices); the deterministic nearest-atom indices
-        are ``weights.argmax(-1)``."""
+        """(assignment weights [*, B, K], sampled indices [*, B], Categorical(softmax weights)) -- base.py:206-239.
+        'argmax' / 'sample': one-hot weights of the nearest / the sampled atom; 'mean': the softmax weights themselves.
+        As in the reference the returned ``indices`` are a draw from the distribution (they come from this device's
+        generator, so they are not comparable across devices); the deterministic nearest-atom indices are
+        ``nearest(samples)[1]``."""
         probs = self.assignment_probs(samples)
         distribution = D.Categorical(probs)
         indices = distribution.sample()
-        _, idx = self._argmax(samples)
-        weights = F.one_hot(idx, self.n_components).type_as(probs)
+        mode = self.mode
+        if mode == "mean":
+            weights = probs
+        elif mode == "sample":
+            weights = F.one_hot(indices, self.n_components).type_as(probs)
+        else:
+            _, idx = self._argmax(samples)
+            weights = F.one_hot(idx, self.n_components).type_as(probs)
         return weights, indices, distribution
 
     def predict(self, features: Tensor):
-        """(codebook[argmax], sampled indices, assignment distribution) -- codebook_model.py:145-148"""
+        """(weights @ codebook, sampled indices, assignment distribution) -- codebook_model.py:145-148.  In 'argmax'
+        mode the product with a one-hot matrix is the gather the assignment kernel already did."""
         self._validate_samples(features)
-        preds, _ = self._argmax(features)
-        probs = self.assignment_probs(features)
-        distribution = D.Categorical(probs)
-        return preds.type_as(self.codebook), distribution.sample(), distribution
+        if self.mode == "argmax":
+            preds, _ = self._argmax(features)
+            distribution = D.Categorical(self.assignment_probs(features))
+            return preds.type_as(self.codebook), distribution.sample(), distribution
+        weights, indices, distribution = self.assign(features)
+        return (weights.type_as(self.codebook) @ self.codebook), indices, distribution
 
     def nearest(self, features: Tensor) -> Tuple[Tensor, Tensor]:
         """(codebook[argmax], argmax indices): the deterministic part of ``predict``"""
@@ -183,7 +199,16 @@ class CodebookModel(DistributionModel):
         lib = _lib.load()
         x3, c3, lead = self._flat(samples)
         nb, bsz = x3.shape[0], x3.shape[1]
-        _, idx = self._argmax(samples)
+        mode = self.mode
+        if mode == "mean":  # soft assignment: sums of the probabilities and probs^T @ samples (base.py:241-251)
+            probs = self.assignment_probs(samples).reshape(nb, bsz, self.n_components)
+            counts, sums = probs.sum(-2), probs.transpose(-1, -2) @ x3
+            return (counts.reshape(*lead, self.n_components).type_as(self._n_obs),
+                    sums.reshape(*lead, self.n_components, self.dim).type_as(self._running_sum))
+        if mode == "sample":
+            idx = D.Categorical(self.assignment_probs(samples)).sample()
+        else:
+            _, idx = self._argmax(samples)
         idx = idx.reshape(nb, bsz).contiguous()
         counts = torch.empty((nb, self.n_components), device=x3.device, dtype=torch.float32)
         sums = torch.empty((nb, self.n_components, self.dim), device=x3.device, dtype=torch.float32)

@@ -1,3 +1,4 @@
 from .base import *  # noqa: F401,F403
 from .gaussian import *  # noqa: F401,F403
 from .sinkhorn import *  # noqa: F401,F403
+from .codebook import *  # noqa: F401,F403

@@ -667,3 +667,137 @@ def test_attention_full_batch_properties(A, T, H, C):
     ref = torch.einsum("nhts,nhcs->nhct", w, v).reshape(4, H * C, T)
     rep.check("float64 formula (4 images)", o1[:4], ref, 1e-5)
     rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G10 discrete transport
+def _zero_init(model):
+    sd = model.state_dict()
+    sd["codebook"] = sd["vec_init"].clone()
+    model.load_state_dict(sd)
+    return model
+
+
+def test_codebook_model_mean_mode_vs_reference_golden(A):
+    """Soft ('mean') assignment: three streaming updates and the inference prediction against the reference's class.
+    Temperature 0.5 keeps softmax(1 / distance / T) insensitive to the rounding of the reference's cdist."""
+    g = group(load_golden("discrete.npz"), "mean")
+    rep = Report("CodebookModel 'mean' mode vs reference golden")
+    K, d, B, temp = g["cfg"].tolist()
+    K, d = int(K), int(d)
+    batches = g["batches"]
+    lead = tuple(batches.shape[1:-2])
+    model = _zero_init(A.CodebookModel(*lead, d, mixture_cfg=dict(n_components=K, training_mode="mean", inference_mode="mean",
+                                                                  temperature=temp))).cuda().train()
+    for step in range(batches.shape[0]):
+        if step == 0:
+            torch.manual_seed(77)
+        model.update(batches[step].cuda())
+        rep.check(f"step{step}/n_obs", model._n_obs, g[f"step{step}/n_obs"], 2e-5)
+        rep.check(f"step{step}/codebook", model.codebook, g[f"step{step}/codebook"], 2e-5)
+    model.eval()
+    preds, sampled, dist = model.predict(batches[-1].cuda())
+    rep.check("predict/probs", dist.probs, g["predict/probs"], 5e-5)
+    rep.check("predict/preds", preds, g["predict/preds"], 2e-5)
+    rep.finish()
+
+
+@pytest.mark.parametrize("ttype", ["mean", "argmax"])
+def test_discrete_transport_vs_reference_golden(A, ttype):
+    """DiscreteTransport (reference ot/transport/discrete_transport.py; configuration of tests/test_latent_transport.py:
+    92-101: soft training mode at temperature 1e-2): three updates per side, compute (atom-to-atom cost, Sinkhorn plan,
+    total), transport of a probe batch.  At temperature 1e-2 the soft weights are softmax(100 / distance): the ~1e-6
+    cancellation error of the reference's cdist (|x|^2 + |c|^2 - 2 x.c for more than 25 rows) moves an exponent by up to
+    1e-2 for samples close to an atom, so the fitted codebooks are compared at 2e-3; everything downstream is compared
+    at tight tolerance GIVEN the reference's codebooks (loaded into the operator)."""
+    import otvae_oracle as O
+    g = group(load_golden("discrete.npz"), f"dt_{ttype}")
+    rep = Report(f"DiscreteTransport transport_type={ttype} vs reference golden")
+    K, d = g["source_codebook"].shape
+    mix = dict(n_components=K, training_mode="mean", inference_mode="argmax", temperature=1e-2)
+    op = A.DiscreteTransport(d, source_cfg=dict(mixture_cfg=mix), target_cfg=dict(mixture_cfg=mix), transport_type=ttype,
+                             sinkhorn_reg=1e-2, sinkhorn_max_iter=200, sinkhorn_threshold=1e-9)
+    _zero_init(op.source_model)
+    _zero_init(op.target_model)
+    op = op.cuda().train()
+    for i in range(g["src"].shape[0]):
+        if i == 0:
+            torch.manual_seed(78)
+        op.update(source_samples=g["src"][i].cuda())
+        if i == 0:
+            torch.manual_seed(178)
+        op.update(target_samples=g["tgt"][i].cuda())
+    cost = op.compute()
+    rep.check("fitted source codebook", op.source_model.codebook, g["source_codebook"], 2e-3)
+    rep.check("fitted target codebook", op.target_model.codebook, g["target_codebook"], 2e-3)
+    rep.check("source probs", op.source_distribution.probs, g["source_probs"], 2e-3)
+    rep.check("total cost (own codebooks)", cost, g["cost"], 5e-3)
+    # the same updates in float64 on the CPU (the formula without cdist's shortcut): the kernels must sit on it
+    for side, model, seed in (("src", op.source_model, 78), ("tgt", op.target_model, 178)):
+        B = g[side].shape[-2]
+        torch.manual_seed(seed)
+        idx = torch.randperm(B)[:K]
+        st = {"codebook": torch.zeros(K, d, dtype=torch.float64), "vec_init": torch.zeros(K, d, dtype=torch.float64),
+              "n_obs": torch.zeros(K, dtype=torch.float64), "running_sum": torch.zeros(K, d, dtype=torch.float64)}
+        for i in range(g[side].shape[0]):
+            st = O.codebook_update(st, g[side][i].double(), None, rand_indices=idx if i == 0 else None, temperature=1e-2, mode="mean")
+        rep.check(f"{side}: codebook vs float64 formula", model.codebook, O.codebook_fit(st)["codebook"], 2e-5)
+    # downstream of the reference's own codebooks
+    with torch.no_grad():
+        op.source_model.codebook.copy_(g["source_codebook"].cuda())
+        op.target_model.codebook.copy_(g["target_codebook"].cuda())
+        op.source_model._n_obs.copy_(g["source_probs"].cuda() * op.source_model._n_obs.sum())
+        op.target_model._n_obs.copy_(g["target_probs"].cuda() * op.target_model._n_obs.sum())
+        op.source_model._running_sum.copy_(op.source_model.codebook * 0)   # fit() must leave the loaded atoms alone
+        op.target_model._running_sum.copy_(op.target_model.codebook * 0)
+    op.source_model.kmeans_iter = op.target_model.kmeans_iter = 0
+    cost = op.compute()
+    rep.check("plan", op.transport_matrix, g["plan"], 1e-5)
+    rep.check("total cost", cost, g["cost"], 1e-5)
+    moved = op.transport(g["probe"].cuda())
+    rep.check("transported probe", moved, g["moved"], 1e-5)
+    assert op.training
+    op.reset()
+    assert op.transport_matrix is None
+    with pytest.raises(RuntimeError):
+        op.transport(g["probe"].cuda())
+    rep.finish()
+
+
+def test_codebook_prior_vs_reference_golden(A):
+    """CodebookPrior (reference prior/codebook.py) in the one-hot mode: two training steps (streaming k-means update of
+    the shared codebook, quantised latents, 'l2' loss with cosine annealing, straight-through gradient) and the
+    evaluation-mode entropy losses."""
+    g = group(load_golden("discrete.npz"), "prior")
+    rep = Report("CodebookPrior vs reference golden")
+    size, K = tuple(g["step0/x"].shape[1:]), g["step0/codebook"].shape[-2]
+    prior = A.CodebookPrior(size, (1, 2, 3), loss="l2", loss_coeff=0.5, annealing_steps=10,
+                            mixture_cfg=dict(n_components=K, training_mode="argmax", inference_mode="argmax"))
+    _zero_init(prior.codebook_model)
+    prior = prior.cuda().train()
+    w = g["w"].cuda()
+    for step in range(2):
+        x = g[f"step{step}/x"].cuda().requires_grad_(True)
+        if step == 0:
+            torch.manual_seed(79)
+        z, loss, art = prior(x, step=3 + step)
+        ((z * w).sum() + loss.sum()).backward()
+        rep.check(f"step{step}/z", z, g[f"step{step}/z"], 1e-6)
+        rep.check(f"step{step}/loss", loss, g[f"step{step}/loss"], 1e-5)
+        rep.check(f"step{step}/dx", x.grad, g[f"step{step}/gx"], 1e-5)
+        rep.check(f"step{step}/probs", art["distribution"].probs, g[f"step{step}/probs"], 5e-4)
+        rep.check(f"step{step}/codebook", prior.codebook_model.codebook, g[f"step{step}/codebook"], 1e-5)
+        assert art["indices"].shape == (x.shape[0], 1)
+    prior.eval()
+    xe = g["eval/x"].cuda()
+    for kind in ("kl", "first_kl"):
+        prior.loss = kind
+        z, loss, _ = prior(xe, step=100)
+        # log K - entropy of softmax(1 / distance): inherits the rounding of the reference's cdist (see the k-means test)
+        rep.check(f"eval/loss_{kind}", loss, g[f"eval/loss_{kind}"], 2e-3)
+    rep.check("eval/z", z, g["eval/z"], 1e-6)
+    with pytest.raises(NotImplementedError):
+        prior(xe.clone().requires_grad_(True), step=100)       # entropy losses have no backward pass here
+    assert prior.sample((4, *size), "cuda").shape == (4, *size)
+    with pytest.raises(ValueError):
+        A.CodebookPrior(size, (4,), mixture_cfg=dict(n_components=K))
+    rep.finish()

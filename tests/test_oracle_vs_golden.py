@@ -301,3 +301,76 @@ def test_codebook_kmeans_update_fit_predict_w2(tag):
     assert rel_err(weights, g["weights"]) < 1e-6
     w2 = O.codebook_w2(st["codebook"], weights, g["centres"], torch.ones(*lead, K) / K)
     assert rel_err(w2, g["w2"]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ G10 discrete transport
+def _seeded_randperm(seed, n, k, times=1):
+    torch.manual_seed(seed)
+    return [torch.randperm(n)[:k] for _ in range(times)]
+
+
+def test_codebook_mean_mode_update_predict():
+    g = group(load_golden("discrete.npz"), "mean")
+    K, d, B, temp = g["cfg"].tolist()
+    K, B = int(K), int(B)
+    batches = g["batches"]
+    lead = batches.shape[1:-2]
+    vec_init = torch.zeros(*lead, K, int(d))
+    st = {"codebook": vec_init.clone(), "vec_init": vec_init, "n_obs": torch.zeros(*lead, K), "running_sum": torch.zeros_like(vec_init)}
+    for step in range(batches.shape[0]):
+        st = O.codebook_update(st, batches[step], None, rand_indices=_seeded_randperm(77, B, K)[0] if step == 0 else None,
+                               temperature=temp, mode="mean")
+        assert rel_err(st["n_obs"], g[f"step{step}/n_obs"]) < 2e-6, step
+        assert rel_err(st["codebook"], g[f"step{step}/codebook"]) < 5e-6, step
+    probs = O.codebook_probs(batches[-1], st["codebook"], temp)
+    assert rel_err(probs, g["predict/probs"]) < 1e-5
+    assert rel_err(probs @ st["codebook"], g["predict/preds"]) < 1e-5
+
+
+@pytest.mark.parametrize("ttype", ["mean", "argmax"])
+def test_discrete_transport_compute_and_transport(ttype):
+    g = group(load_golden("discrete.npz"), f"dt_{ttype}")
+    cost, plan = O.discrete_transport_compute(g["source_codebook"], g["source_probs"], g["target_codebook"], g["target_probs"],
+                                              reg=1e-2, max_iter=200, threshold=1e-9)
+    assert rel_err(plan, g["plan"]) < 1e-5 and rel_err(cost, g["cost"]) < 1e-5
+    moved = O.discrete_transport_apply(g["probe"], g["source_codebook"], g["plan"], g["target_codebook"], temperature=1e-2,
+                                       inference_mode="argmax", transport_type=ttype)
+    assert rel_err(moved, g["moved"]) < 1e-5
+    # the fitted codebooks themselves: three soft k-means updates per side from the seeded initialisation
+    K, d = g["source_codebook"].shape
+    B = g["src"].shape[-2]
+    idx_s, idx_t = _seeded_randperm(78, B, K)[0], _seeded_randperm(178, B, K)[0]
+    for side, idx in (("src", idx_s), ("tgt", idx_t)):
+        vec_init = torch.zeros(K, d)
+        st = {"codebook": vec_init.clone(), "vec_init": vec_init, "n_obs": torch.zeros(K), "running_sum": torch.zeros(K, d)}
+        for step in range(g[side].shape[0]):
+            st = O.codebook_update(st, g[side][step], None, rand_indices=idx if step == 0 else None, temperature=1e-2, mode="mean")
+        st = O.codebook_fit(st)
+        name = "source" if side == "src" else "target"
+        assert rel_err(st["codebook"], g[f"{name}_codebook"]) < 1e-5
+        assert rel_err(O.codebook_weights(st["n_obs"]), g[f"{name}_probs"]) < 1e-5
+
+
+def test_codebook_prior_forward_and_straight_through_gradient():
+    g = group(load_golden("discrete.npz"), "prior")
+    K = g["step0/codebook"].shape[-2]
+    B, dim = g["step0/x"].shape[0], g["step0/codebook"].shape[-1]
+    vec_init = torch.zeros(1, K, dim)
+    st = {"codebook": vec_init.clone(), "vec_init": vec_init, "n_obs": torch.zeros(1, K), "running_sum": torch.zeros(1, K, dim)}
+    for step in range(2):
+        x = g[f"step{step}/x"].clone().requires_grad_(True)
+        flat = x.flatten(1)
+        st = O.codebook_update(st, flat.detach().unsqueeze(0), None, rand_indices=_seeded_randperm(79, B, K)[0] if step == 0 else None)
+        assert rel_err(st["codebook"], g[f"step{step}/codebook"]) < 2e-6
+        coeff = 0.5 * O.prior_annealing(3 + step, 10)
+        z, loss, probs = O.codebook_prior_encode(flat, st["codebook"], loss="l2", coeff=coeff)
+        z = z.reshape(g[f"step{step}/z"].shape)
+        ((z * g["w"]).sum() + loss.sum()).backward()
+        assert rel_err(z, g[f"step{step}/z"]) < 1e-6 and rel_err(loss, g[f"step{step}/loss"]) < 1e-5
+        assert rel_err(x.grad, g[f"step{step}/gx"]) < 1e-5
+        assert rel_err(probs.transpose(0, 1), g[f"step{step}/probs"]) < 1e-5
+    xe = g["eval/x"].flatten(1)
+    for kind in ("kl", "first_kl"):
+        z, loss, _ = O.codebook_prior_encode(xe, st["codebook"], loss=kind, coeff=0.5)
+        assert rel_err(loss, g[f"eval/loss_{kind}"]) < 1e-5
+    assert rel_err(z.reshape(g["eval/z"].shape), g["eval/z"]) < 1e-6
