@@ -120,6 +120,8 @@ class HipTrainer:
         lat = (batch_shape[0], *model.latent_size)
         self.eps = torch.zeros(lat, device=dev, dtype=torch.float32)
         self.latent_stats = latent_stats  # optional TransportOperator fed with the step's latents (LatentTransport)
+        # [1, 0, 0]: the gradient of the loss with respect to the nelbo kernel's output vector (resident: see _backward)
+        self._seed = torch.tensor([1.0, 0.0, 0.0], device=self.device, dtype=torch.float32)
         self.out: Optional[Tensor] = None
         self.latents: Optional[Tensor] = None
         self.use_graph = use_graph
@@ -147,7 +149,7 @@ class HipTrainer:
             p.grad = None
         batch = {"samples": self.x, "target": self.x, "kwargs": {"eps": self.eps}}
         loss, logs, art = self.model.nelbo(batch, 0)
-        loss.backward()
+        self._backward(loss)
         from ..functional import _PendingReduce
         _PendingReduce.flush(self.device)  # normally already done by the autograd-engine callback at the end of backward
         self._logs = {k: v.detach() for k, v in logs.items()}  # no reference into the autograd graph survives the step
@@ -156,6 +158,16 @@ class HipTrainer:
             lat = self.latents.flatten(1)  # [B, D] with transport_dims = (1, 2, 3)
             self.latent_stats.update(target_samples=lat)
         return self._logs
+
+    def _backward(self, loss, **kw) -> None:
+        """``loss.backward()`` seeded at the nelbo kernel's [total, recon, prior] vector with a resident [1, 0, 0]: the
+        select / ones_like / zeros that autograd would build between the forward and the backward pass are three launches."""
+        out3 = getattr(self.model, "_last_nelbo", None)
+        if out3 is None:
+            torch.autograd.backward(loss, **kw)
+            return
+        torch.autograd.backward(out3, grad_tensors=[self._seed], **kw)
+        self.model._last_nelbo = None
 
     def _decoder_range(self):
         """(lo, hi) of the decoder's gradients in the flat buffer, or None when they are not one contiguous range"""
@@ -186,10 +198,10 @@ class HipTrainer:
         loss, logs, art = self.model.nelbo(batch, 0)
         h = getattr(self.model, "_last_cut", None)
         if h is None:  # nothing upstream of the cut needs a gradient: one-phase backward
-            loss.backward()
+            self._backward(loss)
         else:
             # retain_graph: without it the engine also releases the saved tensors of the node that produced h
-            torch.autograd.backward(loss, inputs=self._post_params + [h], retain_graph=True)
+            self._backward(loss, inputs=self._post_params + [h], retain_graph=True)
         self._cut = h
         from ..functional import _PendingReduce
         _PendingReduce.flush(self.device)  # the decoder's weight gradients are complete before their all-reduce starts

@@ -90,6 +90,7 @@ class VAE(VisionModule):
         reconstructions_mean = self._reduce_mean(reconstructions)
         out3 = HF.nelbo_loss(reconstructions_mean, target, prior_loss)   # [total, recon, prior/(C*H*W)]
         self._last_out3 = out3.detach()
+        self._last_nelbo = out3 if out3.requires_grad else None  # engine.HipTrainer seeds the backward pass here
         loss = out3[0]
         logs = {"train/loss/total": loss, "train/loss/recon": out3[1], "train/loss/prior": out3[2]}
         artifacts = {"preds": reconstructions[:batch_size], "latents": latents[:batch_size],
