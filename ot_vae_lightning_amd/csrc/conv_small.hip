@@ -7,6 +7,7 @@
 // Reference arithmetic: networks/cnn.py:183-192 and its autograd backward.
 #include "common.h"
 #include "conv_small.h"
+#include <type_traits>
 
 #define SMALL_MAXC 8
 #define SMALL_MAXW 1024
@@ -67,7 +68,11 @@ __device__ __forceinline__ void store_chan(float* __restrict__ p, const float (&
     }
 }
 
-template <int CS, int CN>
+// KS > 0 (with CS, CN > 0): square KS x KS kernel known at compile time.  The taps' loads are then issued back to back
+// from clamped (always valid) addresses and masked afterwards; the generic tap loop below branches around out-of-image
+// taps, which makes every tap's load wait for the previous tap's arithmetic (9-16 exposed L2 latencies per position:
+// the layers at 32x32 ran at 0.7-1.7 TB/s).
+template <int CS, int CN, int KS>
 __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const float* __restrict__ x,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int relu, const float* __restrict__ wT,
@@ -109,22 +114,44 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const 
         float acc[CNM];
 #pragma unroll
         for (int j = 0; j < CNM; ++j) acc[j] = b_s[j];
-        for (int kh = 0; kh < g.KH; ++kh) {
-            const int iy = oy * g.stride + kh - g.pad;
-            if ((unsigned)iy >= (unsigned)Hu) continue;
-            for (int kw = 0; kw < g.KW; ++kw) {
-                const int ix = ox * g.stride + kw - g.pad;
-                if ((unsigned)ix >= (unsigned)Wu) continue;
-                float xv[CSM];
-                load_chan<CS>(x + ((size_t)((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * Cs, xv, Cs);
-                const float* wp = w_s + (kh * g.KW + kw) * Cs * Cn;
+        if constexpr (KS > 0 && CS > 0 && CN > 0) {
+            float xv[KS * KS][CS];
+            bool ok[KS * KS];
 #pragma unroll
-                for (int c = 0; c < CSM; ++c) {
-                    if (CS || c < Cs) {
-                        const float a = act1(xv[c], sc[c], sh[c], affine, relu);
+            for (int t = 0; t < KS * KS; ++t) {
+                const int iy = oy * g.stride + t / KS - g.pad, ix = ox * g.stride + t % KS - g.pad;
+                ok[t] = (unsigned)iy < (unsigned)Hu && (unsigned)ix < (unsigned)Wu;
+                const int cy = min(max(iy, 0), Hu - 1) >> ush, cx = min(max(ix, 0), Wu - 1) >> ush;
+                load_chan<CS>(x + ((size_t)((unsigned)n * g.Hs + cy) * g.Ws + cx) * CS, xv[t], CS);
+            }
 #pragma unroll
-                        for (int j = 0; j < CNM; ++j)
-                            if (CN || j < Cn) acc[j] = fmaf(a, wp[c * Cn + j], acc[j]);
+            for (int t = 0; t < KS * KS; ++t) {
+                const float* wp = w_s + t * CS * CN;
+#pragma unroll
+                for (int c = 0; c < CS; ++c) {
+                    const float a = ok[t] ? act1(xv[t][c], sc[c], sh[c], affine, relu) : 0.f;
+#pragma unroll
+                    for (int j = 0; j < CN; ++j) acc[j] = fmaf(a, wp[c * CN + j], acc[j]);
+                }
+            }
+        } else {
+            for (int kh = 0; kh < g.KH; ++kh) {
+                const int iy = oy * g.stride + kh - g.pad;
+                if ((unsigned)iy >= (unsigned)Hu) continue;
+                for (int kw = 0; kw < g.KW; ++kw) {
+                    const int ix = ox * g.stride + kw - g.pad;
+                    if ((unsigned)ix >= (unsigned)Wu) continue;
+                    float xv[CSM];
+                    load_chan<CS>(x + ((size_t)((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * Cs, xv, Cs);
+                    const float* wp = w_s + (kh * g.KW + kw) * Cs * Cn;
+#pragma unroll
+                    for (int c = 0; c < CSM; ++c) {
+                        if (CS || c < Cs) {
+                            const float a = act1(xv[c], sc[c], sh[c], affine, relu);
+#pragma unroll
+                            for (int j = 0; j < CNM; ++j)
+                                if (CN || j < Cn) acc[j] = fmaf(a, wp[c * Cn + j], acc[j]);
+                        }
                     }
                 }
             }
@@ -167,26 +194,38 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const 
 // channel-count specialisations: the MNIST (1 <-> 8, 1 -> 1, 1 -> 3) and RGB (3 <-> 8, 3 -> 3) image-side layers
 #define SMALL_DISPATCH(KERNEL, ...)                                            \
     do {                                                                       \
-        if (g.Cs == 1 && g.Cn == 8) KERNEL<1, 8> __VA_ARGS__;                  \
-        else if (g.Cs == 8 && g.Cn == 1) KERNEL<8, 1> __VA_ARGS__;             \
-        else if (g.Cs == 1 && g.Cn == 1) KERNEL<1, 1> __VA_ARGS__;             \
-        else if (g.Cs == 1 && g.Cn == 3) KERNEL<1, 3> __VA_ARGS__;             \
-        else if (g.Cs == 3 && g.Cn == 8) KERNEL<3, 8> __VA_ARGS__;             \
-        else if (g.Cs == 8 && g.Cn == 3) KERNEL<8, 3> __VA_ARGS__;             \
-        else if (g.Cs == 3 && g.Cn == 3) KERNEL<3, 3> __VA_ARGS__;             \
-        else KERNEL<0, 0> __VA_ARGS__;                                         \
+        if (g.Cs == 1 && g.Cn == 8) KERNEL<1, 8, 0> __VA_ARGS__;               \
+        else if (g.Cs == 8 && g.Cn == 1) KERNEL<8, 1, 0> __VA_ARGS__;          \
+        else if (g.Cs == 1 && g.Cn == 1) KERNEL<1, 1, 0> __VA_ARGS__;          \
+        else if (g.Cs == 1 && g.Cn == 3) KERNEL<1, 3, 0> __VA_ARGS__;          \
+        else if (g.Cs == 3 && g.Cn == 8) KERNEL<3, 8, 0> __VA_ARGS__;          \
+        else if (g.Cs == 8 && g.Cn == 3) KERNEL<8, 3, 0> __VA_ARGS__;          \
+        else if (g.Cs == 3 && g.Cn == 3) KERNEL<3, 3, 0> __VA_ARGS__;          \
+        else KERNEL<0, 0, 0> __VA_ARGS__;                                      \
     } while (0)
+// (Cs, Cn, kernel size) of the layers the two configurations really have: tap loops unrolled, loads up front
+#define SMALL_KS_CASES(X) X(1, 8, 4) X(8, 1, 3) X(8, 1, 1) X(1, 1, 3) X(1, 1, 1) X(1, 3, 1) X(3, 3, 3) X(3, 3, 1)
 
 int conv_small_fwd(const SmallGeom& g, int nblocks, const float* x, const float* scale, const float* shift, int relu,
                    const float* wT, const float* bias, const float* res, float* y, double* partial, int CnPad,
                    hipStream_t st) {
+#define X(CS_, CN_, KS_)                                                                                          \
+    if (g.Cs == CS_ && g.Cn == CN_ && g.KH == KS_ && g.KW == KS_) {                                               \
+        conv_small_fwd_kernel<CS_, CN_, KS_><<<nblocks, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y, partial, \
+                                                                       CnPad);                                    \
+        return 0;                                                                                                 \
+    }
+    SMALL_KS_CASES(X)
+#undef X
     SMALL_DISPATCH(conv_small_fwd_kernel, <<<nblocks, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y, partial, CnPad));
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ data gradient
 // one lane per SOURCE position (parent pixel when up == 2): all Cs channels, children summed in registers
-template <int CS, int CN>
+// KSU = 0: generic tap loops.  KSU = KS * 16 + STRIDE * 4 + UP (all > 0): square kernel, stride and up-sampling factor
+// known at compile time; the (children x parity-class taps) loads are issued up front from clamped addresses and masked.
+template <int CS, int CN, int KSU>
 __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, const float* __restrict__ gy,
                                                                const float* __restrict__ wD, const float* __restrict__ x,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
@@ -225,6 +264,35 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
         float acc[CSM];
 #pragma unroll
         for (int c = 0; c < CSM; ++c) acc[c] = 0.f;
+        if constexpr (KSU > 0 && CS > 0 && CN > 0) {
+            constexpr int KS = KSU >> 4, STRIDE = (KSU >> 2) & 3, UP = KSU & 3;
+            constexpr int NT1 = (KS + STRIDE - 1) / STRIDE;  // taps of one parity class per dimension
+            constexpr int NL = UP * UP * NT1 * NT1;
+            float gg[NL][CN];
+            int tap[NL];  // kh * KS + kw, or -1 when the tap does not reach an output position
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const int ch = l / (NT1 * NT1), a = (l / NT1) % NT1, b = l % NT1;
+                const int iy = sy * UP + ch / UP, ix = sx * UP + ch % UP;
+                const int kh = ((iy + g.pad) & (STRIDE - 1)) + a * STRIDE, kw = ((ix + g.pad) & (STRIDE - 1)) + b * STRIDE;
+                const int ty = iy + g.pad - kh, tx = ix + g.pad - kw;
+                const int oy = ty >> (STRIDE - 1), ox = tx >> (STRIDE - 1);
+                const bool ok = kh < KS && kw < KS && ty >= 0 && tx >= 0 && oy < g.Ho && ox < g.Wo;
+                tap[l] = ok ? kh * KS + kw : -1;
+                const int cy = min(max(oy, 0), g.Ho - 1), cx = min(max(ox, 0), g.Wo - 1);
+                load_chan<CN>(gy + ((size_t)((unsigned)n * g.Ho + cy) * g.Wo + cx) * CN, gg[l], CN);
+            }
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const float* wp = w_s + max(tap[l], 0) * CN * CS;
+#pragma unroll
+                for (int co = 0; co < CN; ++co) {
+                    const float gval = tap[l] >= 0 ? gg[l][co] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) acc[c] = fmaf(gval, wp[co * CS + c], acc[c]);
+                }
+            }
+        } else
         for (int ch = 0; ch < nchild; ++ch) {
             const int iy = sy * g.up + (ch >> 1), ix = sx * g.up + (ch & 1);
             // stride 2: only the taps of this position's parity class contribute; start there and step by the stride
@@ -296,6 +364,21 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
 int conv_small_dgrad(const SmallGeom& g, int nblocks, const float* gy, const float* wD, const float* x, const float* scale,
                      const float* shift, int relu, const float* mean, const float* invstd, float* gv, double* partial,
                      int CsPad, hipStream_t st) {
+#define X(CS_, CN_, KS_)                                                                                             \
+    if (g.Cs == CS_ && g.Cn == CN_ && g.KH == KS_ && g.KW == KS_ && g.stride <= 2 && g.up <= 2) {                    \
+        constexpr int K16 = KS_ * 16;                                                                                \
+        auto go = [&](auto tag) {                                                                                    \
+            conv_small_dgrad_kernel<CS_, CN_, decltype(tag)::value><<<nblocks, 256, 0, st>>>(                        \
+                g, gy, wD, x, scale, shift, relu, mean, invstd, gv, partial, CsPad);                                 \
+        };                                                                                                           \
+        if (g.stride == 1 && g.up == 1) go(std::integral_constant<int, K16 + 4 + 1>{});                              \
+        else if (g.stride == 1 && g.up == 2) go(std::integral_constant<int, K16 + 4 + 2>{});                         \
+        else if (g.stride == 2 && g.up == 1) go(std::integral_constant<int, K16 + 8 + 1>{});                         \
+        else go(std::integral_constant<int, K16 + 8 + 2>{});                                                         \
+        return 0;                                                                                                    \
+    }
+    SMALL_KS_CASES(X)
+#undef X
     SMALL_DISPATCH(conv_small_dgrad_kernel,
                    <<<nblocks, 256, 0, st>>>(g, gy, wD, x, scale, shift, relu, mean, invstd, gv, partial, CsPad));
     return 0;
@@ -344,18 +427,25 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallGeom g, cons
             gg[j] = gy[(size_t)m * CN + j];
             accb[j] += gg[j];
         }
+        // every tap's load is issued from a clamped (always valid) address before any of the arithmetic, out-of-image
+        // taps are masked afterwards: a branch per tap would expose one load latency per tap
+        float xv[T][CS];
+        bool ok[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int kh = t / g.KW, kw = t - kh * g.KW;
             const int iy = oy * g.stride + kh - g.pad, ix = ox * g.stride + kw - g.pad;
-            if ((unsigned)iy < (unsigned)Hu && (unsigned)ix < (unsigned)Wu) {
-                const float* xp = x + ((size_t)((unsigned)n * g.Hs + (iy >> ush)) * g.Ws + (ix >> ush)) * CS;
+            ok[t] = (unsigned)iy < (unsigned)Hu && (unsigned)ix < (unsigned)Wu;
+            const int cy = min(max(iy, 0), Hu - 1) >> ush, cx = min(max(ix, 0), Wu - 1) >> ush;
+            load_chan<CS>(x + ((size_t)((unsigned)n * g.Hs + cy) * g.Ws + cx) * CS, xv[t], CS);
+        }
 #pragma unroll
-                for (int c = 0; c < CS; ++c) {
-                    const float a = act1(xp[c], sc[c], sh[c], affine, relu);
+        for (int t = 0; t < T; ++t) {
 #pragma unroll
-                    for (int j = 0; j < CN; ++j) acc[t][c][j] = fmaf(a, gg[j], acc[t][c][j]);
-                }
+            for (int c = 0; c < CS; ++c) {
+                const float a = ok[t] ? act1(xv[t][c], sc[c], sh[c], affine, relu) : 0.f;
+#pragma unroll
+                for (int j = 0; j < CN; ++j) acc[t][c][j] = fmaf(a, gg[j], acc[t][c][j]);
             }
         }
     }
