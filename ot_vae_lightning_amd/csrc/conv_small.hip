@@ -10,6 +10,10 @@
 #include <type_traits>
 
 #define SMALL_MAXC 8
+// The weights stay in LDS: left alone the compiler hoists the (loop-invariant) LDS weight reads of the unrolled tap loops
+// out of the position loop into 130-330 registers, which costs the occupancy these latency-bound kernels live on.
+#define SMALL_REREAD_LDS() asm volatile("" ::: "memory")
+#define SMALL_OCC
 #define SMALL_MAXW 1024
 
 bool conv_small_ok(const SmallGeom& g) {
@@ -73,7 +77,7 @@ __device__ __forceinline__ void store_chan(float* __restrict__ p, const float (&
 // taps, which makes every tap's load wait for the previous tap's arithmetic (9-16 exposed L2 latencies per position:
 // the layers at 32x32 ran at 0.7-1.7 TB/s).
 template <int CS, int CN, int KS>
-__global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const float* __restrict__ x,
+__global__ __launch_bounds__(256) SMALL_OCC void conv_small_fwd_kernel(SmallGeom g, const float* __restrict__ x,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int relu, const float* __restrict__ wT,
                                                              const float* __restrict__ bias, const float* __restrict__ res,
@@ -115,23 +119,31 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallGeom g, const 
 #pragma unroll
         for (int j = 0; j < CNM; ++j) acc[j] = b_s[j];
         if constexpr (KS > 0 && CS > 0 && CN > 0) {
-            float xv[KS * KS][CS];
-            bool ok[KS * KS];
+            // taps in groups whose loads (<= 32 registers) are in flight together; the clobber keeps a group's loads from
+            // drifting above the previous group's arithmetic (and the weights in LDS, see SMALL_REREAD_LDS)
+            constexpr int GS = (KS * KS * CS <= 32) ? KS * KS : KS;  // all taps at once, or one kernel row at a time
 #pragma unroll
-            for (int t = 0; t < KS * KS; ++t) {
-                const int iy = oy * g.stride + t / KS - g.pad, ix = ox * g.stride + t % KS - g.pad;
-                ok[t] = (unsigned)iy < (unsigned)Hu && (unsigned)ix < (unsigned)Wu;
-                const int cy = min(max(iy, 0), Hu - 1) >> ush, cx = min(max(ix, 0), Wu - 1) >> ush;
-                load_chan<CS>(x + ((size_t)((unsigned)n * g.Hs + cy) * g.Ws + cx) * CS, xv[t], CS);
-            }
+            for (int t0g = 0; t0g < KS * KS; t0g += GS) {
+                SMALL_REREAD_LDS();
+                float xv[GS][CS];
+                int ok[GS];  // all-ones / zero bit mask: applied with an AND (a select here becomes a branch per channel)
 #pragma unroll
-            for (int t = 0; t < KS * KS; ++t) {
-                const float* wp = w_s + t * CS * CN;
+                for (int i = 0; i < GS; ++i) {
+                    const int t = t0g + i;
+                    const int iy = oy * g.stride + t / KS - g.pad, ix = ox * g.stride + t % KS - g.pad;
+                    ok[i] = ((unsigned)iy < (unsigned)Hu && (unsigned)ix < (unsigned)Wu) ? -1 : 0;
+                    const int cy = min(max(iy, 0), Hu - 1) >> ush, cx = min(max(ix, 0), Wu - 1) >> ush;
+                    load_chan<CS>(x + ((size_t)((unsigned)n * g.Hs + cy) * g.Ws + cx) * CS, xv[i], CS);
+                }
 #pragma unroll
-                for (int c = 0; c < CS; ++c) {
-                    const float a = ok[t] ? act1(xv[t][c], sc[c], sh[c], affine, relu) : 0.f;
+                for (int i = 0; i < GS; ++i) {
+                    const float* wp = w_s + (t0g + i) * CS * CN;
 #pragma unroll
-                    for (int j = 0; j < CN; ++j) acc[j] = fmaf(a, wp[c * CN + j], acc[j]);
+                    for (int c = 0; c < CS; ++c) {
+                        const float a = __int_as_float(__float_as_int(act1(xv[i][c], sc[c], sh[c], affine, relu)) & ok[i]);
+#pragma unroll
+                        for (int j = 0; j < CN; ++j) acc[j] = fmaf(a, wp[c * CN + j], acc[j]);
+                    }
                 }
             }
         } else {
@@ -226,7 +238,7 @@ int conv_small_fwd(const SmallGeom& g, int nblocks, const float* x, const float*
 // KSU = 0: generic tap loops.  KSU = KS * 16 + STRIDE * 4 + UP (all > 0): square kernel, stride and up-sampling factor
 // known at compile time; the (children x parity-class taps) loads are issued up front from clamped addresses and masked.
 template <int CS, int CN, int KSU>
-__global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, const float* __restrict__ gy,
+__global__ __launch_bounds__(256) SMALL_OCC void conv_small_dgrad_kernel(SmallGeom g, const float* __restrict__ gy,
                                                                const float* __restrict__ wD, const float* __restrict__ x,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                int relu, const float* __restrict__ mean,
@@ -268,28 +280,34 @@ __global__ __launch_bounds__(256) void conv_small_dgrad_kernel(SmallGeom g, cons
             constexpr int KS = KSU >> 4, STRIDE = (KSU >> 2) & 3, UP = KSU & 3;
             constexpr int NT1 = (KS + STRIDE - 1) / STRIDE;  // taps of one parity class per dimension
             constexpr int NL = UP * UP * NT1 * NT1;
-            float gg[NL][CN];
-            int tap[NL];  // kh * KS + kw, or -1 when the tap does not reach an output position
+            constexpr int GS = (NL * CN <= 32) ? NL : NT1 * NT1;  // everything at once, or one child at a time
+#pragma unroll 1  // a real loop over the children: unrolled, the address arithmetic of all NL taps is live at once
+            for (int l0 = 0; l0 < NL; l0 += GS) {
+                SMALL_REREAD_LDS();
+                float gg[GS][CN];
+                int tap[GS];  // kh * KS + kw, or -1 when the tap does not reach an output position
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const int ch = l / (NT1 * NT1), a = (l / NT1) % NT1, b = l % NT1;
-                const int iy = sy * UP + ch / UP, ix = sx * UP + ch % UP;
-                const int kh = ((iy + g.pad) & (STRIDE - 1)) + a * STRIDE, kw = ((ix + g.pad) & (STRIDE - 1)) + b * STRIDE;
-                const int ty = iy + g.pad - kh, tx = ix + g.pad - kw;
-                const int oy = ty >> (STRIDE - 1), ox = tx >> (STRIDE - 1);
-                const bool ok = kh < KS && kw < KS && ty >= 0 && tx >= 0 && oy < g.Ho && ox < g.Wo;
-                tap[l] = ok ? kh * KS + kw : -1;
-                const int cy = min(max(oy, 0), g.Ho - 1), cx = min(max(ox, 0), g.Wo - 1);
-                load_chan<CN>(gy + ((size_t)((unsigned)n * g.Ho + cy) * g.Wo + cx) * CN, gg[l], CN);
-            }
+                for (int i = 0; i < GS; ++i) {
+                    const int l = l0 + i;
+                    const int ch = l / (NT1 * NT1), a = (l / NT1) % NT1, b = l % NT1;
+                    const int iy = sy * UP + ch / UP, ix = sx * UP + ch % UP;
+                    const int kh = ((iy + g.pad) & (STRIDE - 1)) + a * STRIDE, kw = ((ix + g.pad) & (STRIDE - 1)) + b * STRIDE;
+                    const int ty = iy + g.pad - kh, tx = ix + g.pad - kw;
+                    const int oy = ty >> (STRIDE - 1), ox = tx >> (STRIDE - 1);
+                    const bool ok = kh < KS && kw < KS && ty >= 0 && tx >= 0 && oy < g.Ho && ox < g.Wo;
+                    tap[i] = ok ? kh * KS + kw : -1;
+                    const int cy = min(max(oy, 0), g.Ho - 1), cx = min(max(ox, 0), g.Wo - 1);
+                    load_chan<CN>(gy + ((size_t)((unsigned)n * g.Ho + cy) * g.Wo + cx) * CN, gg[i], CN);
+                }
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const float* wp = w_s + max(tap[l], 0) * CN * CS;
+                for (int i = 0; i < GS; ++i) {
+                    const float* wp = w_s + max(tap[i], 0) * CN * CS;
 #pragma unroll
-                for (int co = 0; co < CN; ++co) {
-                    const float gval = tap[l] >= 0 ? gg[l][co] : 0.f;
+                    for (int co = 0; co < CN; ++co) {
+                        const float gval = __int_as_float(__float_as_int(gg[i][co]) & ~(tap[i] >> 31));
 #pragma unroll
-                    for (int c = 0; c < CS; ++c) acc[c] = fmaf(gval, wp[co * CS + c], acc[c]);
+                        for (int c = 0; c < CS; ++c) acc[c] = fmaf(gval, wp[co * CS + c], acc[c]);
+                    }
                 }
             }
         } else
@@ -388,7 +406,7 @@ int conv_small_dgrad(const SmallGeom& g, int nblocks, const float* gy, const flo
 // one lane per output pixel (grid-stride), every weight element accumulated in a register, then one fixed-order
 // wave/LDS reduction per block -> partial[block][K+hasb][Cn] (reduced over blocks by wgrad_reduce_kernel)
 template <int T, int CS, int CN>
-__global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallGeom g, const float* __restrict__ x,
+__global__ __launch_bounds__(256) SMALL_OCC void conv_small_wgrad_kernel(SmallGeom g, const float* __restrict__ x,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                int relu, const float* __restrict__ gy,
                                                                float* __restrict__ partial, int has_bias, unsigned chunk) {
@@ -427,25 +445,31 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallGeom g, cons
             gg[j] = gy[(size_t)m * CN + j];
             accb[j] += gg[j];
         }
-        // every tap's load is issued from a clamped (always valid) address before any of the arithmetic, out-of-image
-        // taps are masked afterwards: a branch per tap would expose one load latency per tap
-        float xv[T][CS];
-        bool ok[T];
+        // the taps' loads are issued from clamped (always valid) addresses ahead of the arithmetic, in groups of <= 32
+        // registers, and out-of-image taps are masked afterwards: a branch per tap exposes one load latency per tap
+        constexpr int GS = (T * CS <= 32) ? T : (T % 3 == 0 ? 3 : (T % 4 == 0 ? 4 : 1));
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int kh = t / g.KW, kw = t - kh * g.KW;
-            const int iy = oy * g.stride + kh - g.pad, ix = ox * g.stride + kw - g.pad;
-            ok[t] = (unsigned)iy < (unsigned)Hu && (unsigned)ix < (unsigned)Wu;
-            const int cy = min(max(iy, 0), Hu - 1) >> ush, cx = min(max(ix, 0), Wu - 1) >> ush;
-            load_chan<CS>(x + ((size_t)((unsigned)n * g.Hs + cy) * g.Ws + cx) * CS, xv[t], CS);
-        }
+        for (int t0g = 0; t0g < T; t0g += GS) {
+            asm volatile("" ::: "memory");
+            float xv[GS][CS];
+            int ok[GS];  // all-ones / zero bit mask
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+            for (int i = 0; i < GS; ++i) {
+                const int t = t0g + i;
+                const int kh = t / g.KW, kw = t - kh * g.KW;
+                const int iy = oy * g.stride + kh - g.pad, ix = ox * g.stride + kw - g.pad;
+                ok[i] = ((unsigned)iy < (unsigned)Hu && (unsigned)ix < (unsigned)Wu) ? -1 : 0;
+                const int cy = min(max(iy, 0), Hu - 1) >> ush, cx = min(max(ix, 0), Wu - 1) >> ush;
+                load_chan<CS>(x + ((size_t)((unsigned)n * g.Hs + cy) * g.Ws + cx) * CS, xv[i], CS);
+            }
 #pragma unroll
-            for (int c = 0; c < CS; ++c) {
-                const float a = ok[t] ? act1(xv[t][c], sc[c], sh[c], affine, relu) : 0.f;
+            for (int i = 0; i < GS; ++i) {
 #pragma unroll
-                for (int j = 0; j < CN; ++j) acc[t][c][j] = fmaf(a, gg[j], acc[t][c][j]);
+                for (int c = 0; c < CS; ++c) {
+                    const float a = __int_as_float(__float_as_int(act1(xv[i][c], sc[c], sh[c], affine, relu)) & ok[i]);
+#pragma unroll
+                    for (int j = 0; j < CN; ++j) acc[t0g + i][c][j] = fmaf(a, gg[j], acc[t0g + i][c][j]);
+                }
             }
         }
     }
