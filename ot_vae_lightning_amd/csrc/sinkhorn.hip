@@ -57,15 +57,18 @@ __global__ __launch_bounds__(256) void sk_init_mat(const T* __restrict__ Cm, int
 
 template <typename T>
 __global__ void sk_init_vec(const T* __restrict__ a, const T* __restrict__ b, int nb, int N, int M, T* __restrict__ loga,
-                            T* __restrict__ logb, T* __restrict__ u, T* __restrict__ v, SkCtl* ctl, int preset_iters) {
+                            T* __restrict__ logb, T* __restrict__ u, T* __restrict__ v, SkCtl* ctl, int preset_iters,
+                            unsigned long long* __restrict__ tu, unsigned long long* __restrict__ tv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nb * N) {
         loga[i] = MathT<T>::log(a[i] + (T)1e-8);
         u[i] = (T)0;
+        if (tu) tu[i] = 0ull;  // {epoch 0, +0.0f}: the tagged potentials of sk_persistent_tagged
     }
     if (i < nb * M) {
         logb[i] = MathT<T>::log(b[i] + (T)1e-8);
         v[i] = (T)0;
+        if (tv) tv[i] = 0ull;
     }
     if (i == 0) {
         ctl->done = 0;
@@ -209,45 +212,70 @@ __device__ __forceinline__ bool sk_grid_barrier(SkCtl* ctl, unsigned nblocks, un
 
 #define SK_EPL 16  // row elements per lane that may live in registers (rows up to 1024)
 
-template <typename T, bool CACHE>
-__global__ __launch_bounds__(256) void sk_persistent(T* __restrict__ pi_cr, const T* __restrict__ crt, const T* __restrict__ loga,
+// NTH threads per workgroup (NTH / 64 waves), every wave owns RPW rows of Cr and RPW rows of Cr^T (rows wave_g + q * nwaves)
+// and, with CACHE, keeps them in registers for the whole solve.  POTLDS: the potential of the other side is fetched ONCE per
+// workgroup and half-iteration (one coherent load per thread) into LDS instead of 16 coherent loads per lane and row.
+// Few large workgroups (32 x 1024 threads for a 1024 x 1024 problem) keep the barrier cheap: its cost is the serialised
+// arrivals on one counter plus one round trip, and it was ~10 us with 256 workgroups.
+template <typename T, bool CACHE, int RPW, int NTH, bool POTLDS>
+__global__ __launch_bounds__(NTH) void sk_persistent(T* __restrict__ pi_cr, const T* __restrict__ crt, const T* __restrict__ loga,
                                                      const T* __restrict__ logb, T* __restrict__ u, T* __restrict__ v,
                                                      T* __restrict__ adu, T* __restrict__ adv, int nb, int N, int M, int max_iter,
                                                      double threshold, SkCtl* ctl) {
+    extern __shared__ __align__(16) char sk_smem[];
+    T* pot = reinterpret_cast<T*>(sk_smem);  // POTLDS: nb * max(N, M) entries
     __shared__ double red[4];
     __shared__ double s_best;
+    constexpr int WPB = NTH / 64;
     const int lane = threadIdx.x & 63;
-    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int wave_g = blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = gridDim.x * WPB;
     const bool track = threshold > 0.0;
     unsigned epoch = 0;
     const int RU = nb * N, RV = nb * M;  // rows of the u pass (rows of Cr) / of the v pass (rows of Cr^T)
 
-    // register-resident rows (CACHE: one row of each matrix per wave at most)
-    T cr_row[CACHE ? SK_EPL : 1], ct_row[CACHE ? SK_EPL : 1];
+    // register-resident rows (CACHE: RPW rows of each matrix per wave at most)
+    constexpr int NC = CACHE ? RPW : 1, EC = CACHE ? SK_EPL : 1;
+    T cr_row[NC][EC], ct_row[NC][EC];
     if constexpr (CACHE) {
 #pragma unroll
-        for (int k = 0; k < SK_EPL; ++k) {
-            const int l = lane + 64 * k;
-            cr_row[k] = (wave_g < RU && l < M) ? pi_cr[(size_t)wave_g * M + l] : MathT<T>::ninf();
-            ct_row[k] = (wave_g < RV && l < N) ? crt[(size_t)wave_g * N + l] : MathT<T>::ninf();
+        for (int q = 0; q < RPW; ++q) {
+            const int r = wave_g + q * nwaves;
+#pragma unroll
+            for (int k = 0; k < SK_EPL; ++k) {
+                const int l = lane + 64 * k;
+                cr_row[q][k] = (r < RU && l < M) ? pi_cr[(size_t)r * M + l] : MathT<T>::ninf();
+                ct_row[q][k] = (r < RV && l < N) ? crt[(size_t)r * N + l] : MathT<T>::ninf();
+            }
         }
     }
 
-    // one row: out[r] = logm[r] - LSE_l(row[l] + add[l]) with the potential `add` read coherently
-    auto row_pass = [&](const T* __restrict__ mat, const T (&cached)[CACHE ? SK_EPL : 1], const T* __restrict__ add,
+    // one pass: out[r] = logm[r] - LSE_l(row[l] + add[l]) with the potential `add` read coherently
+    auto row_pass = [&](const T* __restrict__ mat, const T (&cached)[NC][EC], const T* __restrict__ add,
                         const T* __restrict__ logm, int R, int L, int rows_per_problem, T* __restrict__ out, T* __restrict__ absd) {
-        for (int r = wave_g; r < R; r += nwaves) {
+        if constexpr (POTLDS) {
+            __syncthreads();  // the previous pass's readers are done with pot
+            for (int i = threadIdx.x; i < nb * L; i += NTH) pot[i] = CohT<T>::ld(add + i);
+            __syncthreads();
+        }
+        int q = 0;
+        for (int r = wave_g; r < R; r += nwaves, ++q) {
             const int b = r / rows_per_problem;
             const T* ad = add + (size_t)b * L;
+            const T* pl = pot + (size_t)b * L;
+            auto potential = [&](int l) -> T { return POTLDS ? pl[l] : CohT<T>::ld(ad + l); };
             T mx = MathT<T>::ninf();
             T s = (T)0;
             if constexpr (CACHE) {
                 T x[SK_EPL];
 #pragma unroll
-                for (int k = 0; k < SK_EPL; ++k) {
-                    const int l = lane + 64 * k;
-                    x[k] = l < L ? cached[k] + CohT<T>::ld(ad + l) : MathT<T>::ninf();
-                    mx = x[k] > mx ? x[k] : mx;
+                for (int qq = 0; qq < RPW; ++qq) {  // q is wave-uniform: a compile-time index into the register rows
+                    if (qq != q) continue;
+#pragma unroll
+                    for (int k = 0; k < SK_EPL; ++k) {
+                        const int l = lane + 64 * k;
+                        x[k] = l < L ? cached[qq][k] + potential(l) : MathT<T>::ninf();
+                        mx = x[k] > mx ? x[k] : mx;
+                    }
                 }
                 mx = wave_max(mx);
 #pragma unroll
@@ -256,11 +284,11 @@ __global__ __launch_bounds__(256) void sk_persistent(T* __restrict__ pi_cr, cons
             } else {
                 const T* row = mat + (size_t)r * L;
                 for (int l = lane; l < L; l += 64) {
-                    const T x = row[l] + CohT<T>::ld(ad + l);
+                    const T x = row[l] + potential(l);
                     mx = x > mx ? x : mx;
                 }
                 mx = wave_max(mx);
-                for (int l = lane; l < L; l += 64) s += MathT<T>::exp(row[l] + CohT<T>::ld(ad + l) - mx);
+                for (int l = lane; l < L; l += 64) s += MathT<T>::exp(row[l] + potential(l) - mx);
             }
             s = wave_sum(s);
             if (lane == 0) {
@@ -285,15 +313,17 @@ __global__ __launch_bounds__(256) void sk_persistent(T* __restrict__ pi_cr, cons
         if (!alive) break;
         if (track) {
             // every block evaluates the same test on the same numbers in the same order: a uniform decision without
-            // another exchange (sk_check's arithmetic)
+            // another exchange (sk_check's arithmetic: 256 threads, 4 waves, whatever the workgroup size)
             if (threadIdx.x == 0) s_best = INFINITY;
             __syncthreads();
             for (int b = 0; b < nb; ++b) {
-                double s = 0.0;
-                for (int i = threadIdx.x; i < N; i += 256) s += (double)CohT<T>::ld(adu + (size_t)b * N + i);
-                for (int i = threadIdx.x; i < M; i += 256) s += (double)CohT<T>::ld(adv + (size_t)b * M + i);
-                s = wave_sum(s);
-                if (lane == 0) red[threadIdx.x >> 6] = s;
+                if (threadIdx.x < 256) {
+                    double s = 0.0;
+                    for (int i = threadIdx.x; i < N; i += 256) s += (double)CohT<T>::ld(adu + (size_t)b * N + i);
+                    for (int i = threadIdx.x; i < M; i += 256) s += (double)CohT<T>::ld(adv + (size_t)b * M + i);
+                    s = wave_sum(s);
+                    if (lane == 0) red[threadIdx.x >> 6] = s;
+                }
                 __syncthreads();
                 if (threadIdx.x == 0) {
                     const T d = (T)((red[0] + red[1]) + (red[2] + red[3]));
@@ -315,19 +345,156 @@ __global__ __launch_bounds__(256) void sk_persistent(T* __restrict__ pi_cr, cons
         return;
     }
     // pi = exp(u_i + v_j + Cr_ij), rows of Cr
-    for (int r = wave_g; r < RU; r += nwaves) {
+    int q = 0;
+    for (int r = wave_g; r < RU; r += nwaves, ++q) {
         const int b = r / N;
         const T ui = CohT<T>::ld(u + r);
         const T* vb = v + (size_t)b * M;
         T* row = pi_cr + (size_t)r * M;
         if constexpr (CACHE) {
 #pragma unroll
-            for (int k = 0; k < SK_EPL; ++k) {
-                const int l = lane + 64 * k;
-                if (l < M) row[l] = MathT<T>::exp(ui + CohT<T>::ld(vb + l) + cr_row[k]);
+            for (int qq = 0; qq < RPW; ++qq) {
+                if (qq != q) continue;
+#pragma unroll
+                for (int k = 0; k < SK_EPL; ++k) {
+                    const int l = lane + 64 * k;
+                    if (l < M) row[l] = MathT<T>::exp(ui + CohT<T>::ld(vb + l) + cr_row[qq][k]);
+                }
             }
         } else {
             for (int l = lane; l < M; l += 64) row[l] = MathT<T>::exp(ui + CohT<T>::ld(vb + l) + row[l]);
+        }
+    }
+}
+
+// Flag-in-data variant (fp32, fixed iteration count): every potential entry travels as ONE 64-bit word {epoch, value}
+// written with a single agent-scope store, and the consumers poll the words they need until the epoch of the phase
+// they wait for shows up.  There is no barrier: a half-iteration costs one store -> poll round trip instead of store ->
+// arrive -> poll the counter -> reload (4 round trips, ~5.7 us).  A workgroup may only write epoch p+1 of a potential
+// after it has read every entry of the OTHER potential at epoch p, which every workgroup writes only after reading the
+// first one at epoch p-1: the data dependence itself keeps a word from being overwritten before all its readers have
+// it.  Every poll is bounded (SK_SPIN_LIMIT); the arithmetic per row is sk_pass's.
+template <int RPW, int NTH>
+__global__ __launch_bounds__(NTH) void sk_persistent_tagged(float* __restrict__ pi_cr, const float* __restrict__ crt,
+                                                            const float* __restrict__ loga, const float* __restrict__ logb,
+                                                            float* __restrict__ u, float* __restrict__ v,
+                                                            unsigned long long* __restrict__ tu, unsigned long long* __restrict__ tv,
+                                                            int nb, int N, int M, int max_iter, SkCtl* ctl) {
+    extern __shared__ __align__(16) char sk_smem[];
+    float* pot = reinterpret_cast<float*>(sk_smem);
+    __shared__ int s_fail;
+    constexpr int WPB = NTH / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave_g = blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = gridDim.x * WPB;
+    const int RU = nb * N, RV = nb * M;
+    float cr_row[RPW][SK_EPL], ct_row[RPW][SK_EPL];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = wave_g + q * nwaves;
+#pragma unroll
+        for (int k = 0; k < SK_EPL; ++k) {
+            const int l = lane + 64 * k;
+            cr_row[q][k] = (r < RU && l < M) ? pi_cr[(size_t)r * M + l] : -INFINITY;
+            ct_row[q][k] = (r < RV && l < N) ? crt[(size_t)r * N + l] : -INFINITY;
+        }
+    }
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+
+    // fetch all `count` entries of a tagged potential at epoch `want` into LDS; false (block-uniform) if a poll ran out
+    auto fetch = [&](const unsigned long long* __restrict__ src, int count, unsigned want) -> bool {
+        __syncthreads();  // the previous pass's readers are done with pot
+        // a thread polls up to 4 words at once (their loads in flight together), round after round
+        for (int i0 = threadIdx.x; i0 < count; i0 += 4 * NTH) {
+            unsigned long long w[4];
+            unsigned pending = 0, spins = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j * NTH < count) pending |= 1u << j;
+            while (pending) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (pending & (1u << j)) w[j] = __hip_atomic_load(src + i0 + j * NTH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((pending & (1u << j)) && (unsigned)(w[j] >> 32) == want) {
+                        pot[i0 + j * NTH] = __uint_as_float((unsigned)w[j]);
+                        pending &= ~(1u << j);
+                    }
+                if (pending) {
+                    if (++spins > SK_SPIN_LIMIT || __hip_atomic_load(&ctl->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        s_fail = 1;
+                        __hip_atomic_store(&ctl->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        }
+        __syncthreads();
+        return s_fail == 0;
+    };
+    float own_u[RPW];  // the u this wave computed last for the rows it owns (all lanes): what the plan needs at the end
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) own_u[q] = 0.f;
+    auto rows_pass = [&](const float (&cached)[RPW][SK_EPL], const float* __restrict__ logm, int R, int L, int rows_per_problem,
+                         float* __restrict__ out, unsigned long long* __restrict__ tout, unsigned epoch, bool keep) {
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int r = wave_g + q * nwaves;
+            if (r >= R) continue;
+            const float* pl = pot + (size_t)(r / rows_per_problem) * L;
+            float x[SK_EPL], mx = -INFINITY, s = 0.f;
+#pragma unroll
+            for (int k = 0; k < SK_EPL; ++k) {
+                const int l = lane + 64 * k;
+                x[k] = l < L ? cached[q][k] + pl[l] : -INFINITY;
+                mx = x[k] > mx ? x[k] : mx;
+            }
+            mx = wave_max(mx);
+#pragma unroll
+            for (int k = 0; k < SK_EPL; ++k)
+                if (lane + 64 * k < L) s += MathT<float>::exp(x[k] - mx);
+            s = wave_sum(s);
+            const float nv = logm[r] - (mx + MathT<float>::log(s));  // every lane holds the wave-wide mx and s
+            if (keep) own_u[q] = nv;
+            if (lane == 0) {
+                __hip_atomic_store(tout + r, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(nv),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out[r] = nv;
+            }
+        }
+    };
+
+    bool alive = true;
+    unsigned epoch = 0;  // epoch of the last completed half-iteration
+    for (int it = 0; it < max_iter && alive; ++it) {
+        alive = fetch(tu, RU, epoch == 0 ? 0u : epoch);          // u as of the previous u pass (epoch 2 it), 0 initially
+        if (!alive) break;
+        rows_pass(ct_row, logb, RV, N, M, v, tv, epoch + 1, false);  // v pass = epoch 2 it + 1
+        alive = fetch(tv, RV, epoch + 1);
+        if (!alive) break;
+        rows_pass(cr_row, loga, RU, M, N, u, tu, epoch + 2, true);   // u pass = epoch 2 it + 2
+        epoch += 2;
+    }
+    if (!alive) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl->iters = -1;
+        return;
+    }
+    // pi = exp(u_i + v_j + Cr_ij): the final v is in LDS already (fetched for the last u pass); the final u of the other
+    // workgroups' rows is not needed -- every wave writes the rows it owns, whose u it computed itself
+    if (max_iter == 0) alive = fetch(tv, RV, 0u);  // v = 0 everywhere
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = wave_g + q * nwaves;
+        if (r >= RU) continue;
+        const float ui = own_u[q];
+        const float* pl = pot + (size_t)(r / N) * M;
+        float* row = pi_cr + (size_t)r * M;
+#pragma unroll
+        for (int k = 0; k < SK_EPL; ++k) {
+            const int l = lane + 64 * k;
+            if (l < M) row[l] = MathT<float>::exp(ui + pl[l] + cr_row[q][k]);
         }
     }
 }
@@ -341,7 +508,9 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" int64_t otvae_sinkhorn_ws(int dtype, int nb, int N, int M) {
     if (nb <= 0 || N <= 0 || M <= 0 || dtype < 0 || dtype > 1) return -1;
     const size_t es = dtype ? 8 : 4;
-    return (int64_t)(align256((size_t)nb * N * M * es) + 4 * align256((size_t)nb * (N > M ? N : M) * es) + 256);
+    // Cr^T, log a, log b, |du|, |dv|, the two tagged potentials of the flag-in-data solver, the control block
+    return (int64_t)(align256((size_t)nb * N * M * es) + 4 * align256((size_t)nb * (N > M ? N : M) * es) +
+                     2 * align256((size_t)nb * (N > M ? N : M) * 8) + 256);
 }
 
 template <typename T>
@@ -359,13 +528,18 @@ static int sinkhorn_impl(const T* a, const T* b, const T* Cm, int nb, int N, int
     w += vs;
     T* adv = (T*)w;
     w += vs;
+    const size_t ts = align256((size_t)nb * (N > M ? N : M) * 8);
+    unsigned long long* tu = (unsigned long long*)w;
+    w += ts;
+    unsigned long long* tv = (unsigned long long*)w;
+    w += ts;
     SkCtl* ctl = (SkCtl*)w;
     const bool track = threshold > 0.0;
 
     sk_init_mat<T><<<dim3(cdiv(M, 32), cdiv(N, 32), nb), 256, 0, st>>>(Cm, N, M, (T)(-1.0 / reg), pi, crt);
     OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(init_mat)");
     const int nv = nb * (N > M ? N : M);
-    sk_init_vec<T><<<cdiv(nv, 256), 256, 0, st>>>(a, b, nb, N, M, loga, logb, u, v, ctl, track ? 0 : max_iter);
+    sk_init_vec<T><<<cdiv(nv, 256), 256, 0, st>>>(a, b, nb, N, M, loga, logb, u, v, ctl, track ? 0 : max_iter, tu, tv);
     OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(init_vec)");
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -373,19 +547,52 @@ static int sinkhorn_impl(const T* a, const T* b, const T* Cm, int nb, int N, int
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n_cu = v;
         if (n_cu <= 0) n_cu = 1;
     }
-    // Measured on MI355X (1024 x 1024 fp32, 50 iterations): persistent 1.09 ms vs 0.91 ms for one launch per
-    // half-iteration -- a grid barrier + coherent (L2-bypassing) reads of the potential cost ~10 us per phase across
-    // 8 XCDs, more than the ~5 us launch ramp they replace -- so the persistent solver is opt-in (OTVAE_SK_PERSISTENT=1).
-    if (getenv("OTVAE_SK_PERSISTENT") && !getenv("OTVAE_SK_MULTILAUNCH")) {
-        // one resident workgroup per CU at most (256 threads, no dynamic LDS: always co-resident), bounded waits
-        const int rows = nb * (N > M ? N : M);
-        int G = imax(1, imin(n_cu, cdiv(rows, 4)));
-        if (getenv("OTVAE_SK_BLOCKS")) G = imax(1, imin(G, atoi(getenv("OTVAE_SK_BLOCKS"))));
-        const bool cache = (nb * N <= 4 * G) && (nb * M <= 4 * G) && N <= 64 * SK_EPL && M <= 64 * SK_EPL;
-        if (cache)
-            sk_persistent<T, true><<<G, 256, 0, st>>>(pi, crt, loga, logb, u, v, adu, adv, nb, N, M, max_iter, threshold, ctl);
-        else
-            sk_persistent<T, false><<<G, 256, 0, st>>>(pi, crt, loga, logb, u, v, adu, adv, nb, N, M, max_iter, threshold, ctl);
+    // Persistent solver: few LARGE workgroups (512 threads = 8 waves), up to 4 (fp32) / 1 (fp64) rows of each matrix per
+    // wave in registers, the potential through LDS.  Eligible when a row fits 16 registers per lane (N, M <= 1024), the
+    // rows fit <= 128 workgroups and the potentials fit the default 64 KiB of dynamic LDS.  OTVAE_SK_MULTILAUNCH=1 forces
+    // one launch per half-iteration; OTVAE_SK_PERSISTENT=256 selects the first-generation shape (one 256-thread workgroup
+    // per CU, one row per wave, no LDS staging), which measured 1.09 ms against 0.91 ms for the launches on the
+    // 1024 x 1024 fp32 problem; OTVAE_SK_RPW=n fixes the rows per wave (experiments).
+    const int rows = nb * (N > M ? N : M);
+    constexpr int RPWMAX = sizeof(T) == 4 ? 4 : 1;  // registers: 2 x RPW x 16 (x 2 for fp64) of the 256 a 512-thread workgroup has
+    const char* pers = getenv("OTVAE_SK_PERSISTENT");
+    const bool legacy = pers && atoi(pers) == 256;
+    int rpw = 1;
+    // One row per wave while that needs <= 128 workgroups.  Measured (1024 x 1024 fp32, 50 iterations, ms per solve):
+    // launches 0.87; 512 threads x 1 row/wave (128 workgroups) 0.57, x 2 (64) 0.70, x 4 (32) 1.09; 1024 threads x 1 (64)
+    // 0.59; 256 threads x 1 (256) 0.78 -- the rows a wave walks serially cost more than the extra barrier arrivals.
+    while (rpw < RPWMAX && cdiv(rows, 8 * rpw) > 128) rpw *= 2;
+    if (const char* e = getenv("OTVAE_SK_RPW")) {
+        const int want = atoi(e);
+        if (want == 1 || want == 2 || (want == 4 && RPWMAX == 4)) rpw = want;
+    }
+    const int G = cdiv(rows, 8 * rpw);
+    const size_t pot_bytes = (size_t)rows * sizeof(T);
+    const bool eligible = N <= 64 * SK_EPL && M <= 64 * SK_EPL && G <= 128 && pot_bytes <= 60 * 1024;
+    if (!getenv("OTVAE_SK_MULTILAUNCH") && (legacy || (eligible && !(pers && atoi(pers) == 0)))) {
+        if (legacy) {
+            int G1 = imax(1, imin(n_cu, cdiv(rows, 4)));
+            const bool cache = (nb * N <= 4 * G1) && (nb * M <= 4 * G1) && N <= 64 * SK_EPL && M <= 64 * SK_EPL;
+            if (cache)
+                sk_persistent<T, true, 1, 256, false><<<G1, 256, 0, st>>>(pi, crt, loga, logb, u, v, adu, adv, nb, N, M, max_iter, threshold, ctl);
+            else
+                sk_persistent<T, false, 1, 256, false><<<G1, 256, 0, st>>>(pi, crt, loga, logb, u, v, adu, adv, nb, N, M, max_iter, threshold, ctl);
+        } else if (sizeof(T) == 4 && !track && !getenv("OTVAE_SK_BARRIER")) {
+            // fixed iteration count in fp32 (the training configuration): flag-in-data exchange, no barrier
+            float* fpi = reinterpret_cast<float*>(pi);
+            const float *fcrt = reinterpret_cast<const float*>(crt), *fla = reinterpret_cast<const float*>(loga),
+                        *flb = reinterpret_cast<const float*>(logb);
+            float *fu = reinterpret_cast<float*>(u), *fv = reinterpret_cast<float*>(v);
+            if (rpw == 1) sk_persistent_tagged<1, 512><<<G, 512, pot_bytes, st>>>(fpi, fcrt, fla, flb, fu, fv, tu, tv, nb, N, M, max_iter, ctl);
+            else if (rpw == 2) sk_persistent_tagged<2, 512><<<G, 512, pot_bytes, st>>>(fpi, fcrt, fla, flb, fu, fv, tu, tv, nb, N, M, max_iter, ctl);
+            else sk_persistent_tagged<4, 512><<<G, 512, pot_bytes, st>>>(fpi, fcrt, fla, flb, fu, fv, tu, tv, nb, N, M, max_iter, ctl);
+        } else if (rpw == 1) {
+            sk_persistent<T, true, 1, 512, true><<<G, 512, pot_bytes, st>>>(pi, crt, loga, logb, u, v, adu, adv, nb, N, M, max_iter, threshold, ctl);
+        } else if (rpw == 2) {
+            sk_persistent<T, true, 2, 512, true><<<G, 512, pot_bytes, st>>>(pi, crt, loga, logb, u, v, adu, adv, nb, N, M, max_iter, threshold, ctl);
+        } else {
+            sk_persistent<T, true, RPWMAX, 512, true><<<G, 512, pot_bytes, st>>>(pi, crt, loga, logb, u, v, adu, adv, nb, N, M, max_iter, threshold, ctl);
+        }
         OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(persistent)");
     } else {
         for (int it = 0; it < max_iter; ++it) {

@@ -506,32 +506,47 @@ def test_gaussian_transport_1024_dims_vs_oracle(A):
 
 
 def test_sinkhorn_persistent_equals_multilaunch(A):
-    """The opt-in one-launch solver (grid barrier, rows in registers; slower on MI355X, see sinkhorn.hip) and the default
-    launch-per-half-iteration solver run the same arithmetic per row: plan, potentials and iteration count must be
-    identical bits, including the early exit."""
+    """The one-launch solvers (rows in registers, the potential in LDS: the flag-in-data exchange that fp32 problems with
+    a fixed iteration count take by default, the grid-barrier exchange (OTVAE_SK_BARRIER, and whenever an early exit is
+    tracked), each rows-per-wave variant, the first-generation 256-thread shape) and the launch-per-half-iteration solver
+    run the same arithmetic per row: plan, potentials and iteration count must be identical bits, including the early
+    exit.  Problems the persistent shapes cannot hold (rows > 1024, more rows than 128 workgroups take) fall back to
+    launches by themselves."""
     import os
     from ot_vae_lightning_amd.ot import w2_utils as W
-    cases = [((), 1024, 1024, torch.float32, 0.05, 50, 0.0),      # bench shape: rows cached in registers
+    cases = [((), 1024, 1024, torch.float32, 0.05, 50, 0.0),      # bench shape: 1 row per wave, 128 workgroups
+             ((), 256, 256, torch.float32, 0.05, 50, 0.0),         # CIFAR per-GPU batch: 1 row per wave
+             ((3,), 200, 300, torch.float32, 0.05, 7, 0.0),        # batched, non-square, fixed count: flag-in-data, 2 rows/wave
+             ((), 64, 1000, torch.float32, 0.05, 0, 0.0),          # no iteration, flag-in-data plan
              ((), 100, 37, torch.float64, 0.1, 200, 1e-9),         # non-square, early exit
              ((2, 3), 33, 65, torch.float32, 0.05, 300, 1e-3),     # batched: min-over-batch early exit
-             ((), 1500, 700, torch.float32, 0.05, 20, 0.0),        # more rows than resident waves, rows > 1024
+             ((), 1024, 1024, torch.float64, 0.05, 10, 0.0),       # fp64 at the bench shape: 128 workgroups
+             ((), 1500, 700, torch.float32, 0.05, 20, 0.0),        # rows > 1024: not register-resident
              ((), 7, 5, torch.float64, 1.0, 0, 0.0)]               # no iteration at all
+    variants = [{}, {"OTVAE_SK_RPW": "2"}, {"OTVAE_SK_RPW": "4"}, {"OTVAE_SK_BARRIER": "1"}, {"OTVAE_SK_BARRIER": "1", "OTVAE_SK_RPW": "2"},
+                {"OTVAE_SK_PERSISTENT": "256"}]
     for lead, n, m, dt, reg, it, thr in cases:
         a, b, C = _sinkhorn_problem(lead, n, m, dt, seed=n + m)
         a, b, C = a.cuda(), b.cuda(), C.cuda()
         if dt == torch.float32 and reg < 0.1:
             C = C / C.max()
-        ref = W.sinkhorn_log_potentials(a, b, C, reg=reg, max_iter=it, threshold=thr)
-        os.environ["OTVAE_SK_PERSISTENT"] = "1"
+        os.environ["OTVAE_SK_MULTILAUNCH"] = "1"
         try:
-            got = W.sinkhorn_log_potentials(a, b, C, reg=reg, max_iter=it, threshold=thr)
+            ref = W.sinkhorn_log_potentials(a, b, C, reg=reg, max_iter=it, threshold=thr)
         finally:
-            del os.environ["OTVAE_SK_PERSISTENT"]
-        torch.cuda.synchronize()
-        assert int(got[3]) == int(ref[3]) and int(got[3]) >= 0, (n, m, int(got[3]), int(ref[3]))
-        for g, r, name in zip(got[:3], ref[:3], ("pi", "u", "v")):
-            assert torch.equal(g, r), (n, m, name, float((g - r).abs().max()))
-        assert torch.isfinite(got[0]).all()
+            del os.environ["OTVAE_SK_MULTILAUNCH"]
+        for env in variants:
+            os.environ.update(env)
+            try:
+                got = W.sinkhorn_log_potentials(a, b, C, reg=reg, max_iter=it, threshold=thr)
+            finally:
+                for k in env:
+                    del os.environ[k]
+            torch.cuda.synchronize()
+            assert int(got[3]) == int(ref[3]) and int(got[3]) >= 0, (n, m, env, int(got[3]), int(ref[3]))
+            for g, r, name in zip(got[:3], ref[:3], ("pi", "u", "v")):
+                assert torch.equal(g, r), (n, m, env, name, float((g - r).abs().max()))
+            assert torch.isfinite(got[0]).all()
 
 
 # ------------------------------------------------------------------------------------------------ G9 codebook k-means

@@ -1,5 +1,6 @@
-import sys, time, torch
-sys.path.insert(0, '.')
+"""BASELINE configs[3] shape on one GPU: CIFAR-sized CNN VAE (3 channels, capacity 16, latent 256) + Sinkhorn prior, batch 256."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ot_vae_lightning_amd as A
 torch.manual_seed(0)
 B = 256
