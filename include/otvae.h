@@ -241,6 +241,13 @@ int otvae_codebook_probs(const float* x, const float* codebook, int nb, int B, i
 int otvae_codebook_kmeans(const float* x, const int64_t* idx, int nb, int B, int K, int d, float* counts, float* sums,
                           void* stream);
 
+/* ---- Gaussian mixture (diagonal covariances): GaussianMixtureModel.energy, gassian_mixture_model.py:91-99 ------------
+ * energy[nb][B][K] = log N(x_b; mean_k, diag var_k) + log w_k for x [nb][B][d], mean / var [nb][K][d], logw [nb][K];
+ * dtype 0 = fp32, 1 = fp64 (all tensors).  The assignment (softmax / argmax over K) and the weighted sufficient
+ * statistics that follow are [B][K]-sized library reductions on the caller's side. */
+int otvae_gmm_diag_energy(int dtype, const void* x, const void* mean, const void* var, const void* logw, int nb, int B, int K,
+                          int d, void* energy, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ Fixtures:
   codebook.npz       CodebookModel.predict argmax indices + encodings
   codebook_kmeans.npz  CodebookModel.update/fit/predict/w2 (streaming k-means)
   discrete.npz       CodebookModel in 'mean' mode, DiscreteTransport.compute/transport, CodebookPrior.forward
+  gmm.npz            GaussianMixtureModel (diagonal) update/fit/energy/w2, GMMTransport.compute/transport
 """
 import math
 import os
@@ -534,8 +535,72 @@ def gen_discrete():
     save("discrete.npz", out)
 
 
+def gen_gmm():
+    """G11: GaussianMixtureModel with diagonal covariances (update x 3 -> fit -> energy / assign / w2) and
+    GMMTransport.compute / transport ('argmax'), configured as the reference's tests/test_latent_transport.py:80-91
+    (diag=True, argmax modes, double precision)."""
+    gm = R.ref("ot.distribution_models.gassian_mixture_model")
+    gt = R.ref("ot.transport.gmm_transport")
+    out = {}
+    w2_cfg = dict(diag=True, stochastic=False, pg_star=0., make_pd=True, verbose=False, dtype=torch.double)
+    mix = dict(metric="euclidean", p=2., topk=None, temperature=1., training_mode="argmax", inference_mode="argmax")
+    # ---- the model alone, with a leading dimension and an EMA variant
+    for tag, lead, K, d, B, decay in (("sum", (2,), 4, 3, 64, None), ("ema", (), 5, 2, 96, 0.8)):
+        g = torch.Generator().manual_seed(51)
+        centres = torch.randn(*lead, K, d, generator=g, dtype=torch.double) * 3.0
+        model = gm.GaussianMixtureModel(*lead, d, mixture_cfg={**mix, "n_components": K}, w2_cfg=w2_cfg, update_decay=decay,
+                                        dtype=torch.double)
+        model.train()
+        out[f"{tag}/cfg"] = np.array([K, d, B, -1.0 if decay is None else decay])
+        out[f"{tag}/vec_init"] = npy(model.vec_init)
+        xs = [_clusters(g, lead, K, d, B, centres.float(), noise=0.4).double() for _ in range(3)]
+        out[f"{tag}/batches"] = npy(torch.stack(xs))
+        for i, x in enumerate(xs):
+            if i == 0:
+                torch.manual_seed(81)
+            model.update(x)
+            out[f"{tag}/step{i}/mean"], out[f"{tag}/step{i}/cov"] = npy(model.mean).copy(), npy(model.cov).copy()
+            out[f"{tag}/step{i}/weights"], out[f"{tag}/step{i}/n_obs"] = npy(model.weights).copy(), npy(model._n_obs).copy()
+        model.fit()
+        out[f"{tag}/fit/mean"], out[f"{tag}/fit/cov"], out[f"{tag}/fit/weights"] = npy(model.mean), npy(model.cov), npy(model.weights)
+        model.eval()
+        energy = model.energy(xs[-1])
+        weights, _, dist = model.assign(xs[-1])
+        out[f"{tag}/energy"], out[f"{tag}/assign_onehot"], out[f"{tag}/assign_probs"] = npy(energy), npy(weights), npy(dist.probs)
+        other = torch.distributions.MixtureSameFamily(
+            torch.distributions.Categorical(torch.ones(*lead, K, dtype=torch.double) / K),
+            torch.distributions.Independent(torch.distributions.Normal(centres, torch.full_like(centres, 0.4)), 1))
+        out[f"{tag}/centres"] = npy(centres)
+        out[f"{tag}/w2"] = npy(model.w2(other))
+    # ---- the transport operator
+    K, d, B = 6, 4, 128
+    g = torch.Generator().manual_seed(61)
+    cs, ct = torch.randn(K, d, generator=g) * 2.5, torch.randn(K, d, generator=g) * 2.5 + 1.5
+    cfg = dict(update_decay=None, update_with_autograd=False, dtype=torch.double, mixture_cfg={**mix, "n_components": K})
+    op = gt.GMMTransport(d, transport_type="argmax", transport_cfg=w2_cfg, source_cfg=cfg, target_cfg=cfg)
+    op.train()
+    src = [_clusters(g, (), K, d, B, cs, noise=0.5).double() for _ in range(3)]
+    tgt = [(_clusters(g, (), K, d, B, ct, noise=0.3) * torch.tensor([1.0, 0.5, 2.0, 1.0])).double() for _ in range(3)]
+    for i, (a, b) in enumerate(zip(src, tgt)):
+        if i == 0:
+            torch.manual_seed(82)
+        op.update(source_samples=a)
+        if i == 0:
+            torch.manual_seed(182)
+        op.update(target_samples=b)
+    total = op.compute()
+    op.eval()
+    probe = _clusters(g, (), K, d, 48, cs, noise=0.5)
+    out["tr/src"], out["tr/tgt"], out["tr/probe"] = npy(torch.stack(src)), npy(torch.stack(tgt)), npy(probe)
+    for side, m in (("source", op.source_model), ("target", op.target_model)):
+        out[f"tr/{side}_mean"], out[f"tr/{side}_cov"], out[f"tr/{side}_weights"] = npy(m.mean), npy(m.cov), npy(m.weights)
+    out["tr/total"], out["tr/coupling"] = npy(total), npy(op.transport_matrix)
+    out["tr/moved"] = npy(op.transport(probe))
+    save("gmm.npz", out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete"]
+                             "codebook_kmeans", "discrete", "gmm"]
     for w in which:
         globals()["gen_" + w]()

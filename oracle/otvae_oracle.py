@@ -487,3 +487,100 @@ def codebook_prior_encode(x: Tensor, codebook: Tensor, temperature: float = 1.0,
         val = gap.sum(0) if loss == "kl" else gap[0]
     z = x + (enc - x).detach()
     return z, val * coeff, probs
+
+
+# ------------------------------------------------------------------------------------------------ Gaussian mixtures (diag)
+def gmm_diag_energy(x: Tensor, mean: Tensor, var: Tensor, weights: Tensor) -> Tensor:
+    """``GaussianMixtureModel.energy`` (ot/distribution_models/gassian_mixture_model.py:91-99) for diagonal covariances:
+    log N(x_b; mean_k, diag var_k) + log w_k.  x [*, B, d], mean / var [*, K, d], weights [*, K] -> [*, B, K]."""
+    comp = torch.distributions.Independent(torch.distributions.Normal(mean.unsqueeze(-3), var.unsqueeze(-3) ** 0.5), 1)
+    return comp.log_prob(x.unsqueeze(-2)) + torch.log_softmax(torch.log(weights.unsqueeze(-2)), dim=-1)
+
+
+def gmm_assign(x: Tensor, mean: Tensor, var: Tensor, weights: Tensor, temperature: float = 1.0, mode: str = "argmax") -> Tensor:
+    """``MixtureMixin.assign`` weights (base.py:216-235) on the mixture energy: soft-max, one-hot of its arg-max in 'argmax'."""
+    w = torch.softmax(gmm_diag_energy(x, mean, var, weights) / temperature, dim=-1)
+    if mode == "argmax":
+        w = F.one_hot(w.argmax(-1), w.size(-1)).type_as(w)
+    return w
+
+
+def _cov_read(raw: Tensor) -> Tensor:
+    """the ``MakePositiveDefinite(diag=True, strict=True)`` parametrisation every read of ``cov`` goes through
+    (gaussian_model.py:204-214, matrix_utils.py:123-142): + |min(var, 0)| + 1e-8 per component"""
+    return raw + (raw.min(-1)[0].clamp(max=0).abs() + STABILITY_CONST)[..., None]
+
+
+def _norm_sum(raw: Tensor) -> Tensor:
+    """the ``NormSum`` parametrisation of the mixture weights (gassian_mixture_model.py:180-189)"""
+    return raw / raw.sum(-1, keepdim=True)
+
+
+def _gmm_update_parameters(st: Dict[str, Tensor], n_obs: Tensor, s1: Tensor, s2: Tensor, laplace_eps: Optional[float]):
+    """``_update_parameters`` (gassian_mixture_model.py:146-151): mean / variance / weight of the observed components from
+    Laplace-smoothed counts; parameters are read back through their parametrisations and written raw, as the reference."""
+    K = n_obs.shape[-1]
+    n = _laplace(n_obs, K, laplace_eps)
+    if bool((n == 0).all()):
+        return
+    seen = n > 1e-8
+    mean, cov = mean_cov(s1[seen], s2[seen], n[seen], diag=True)
+    st["mean"][seen] = mean
+    tmp = _cov_read(st["cov_raw"])
+    tmp[seen] = cov
+    st["cov_raw"] = tmp
+    tmp = _norm_sum(st["w_raw"])
+    tmp[seen] = n_obs[seen]
+    st["w_raw"] = tmp
+
+
+def gmm_update(state: Dict[str, Tensor], x: Tensor, decay: Optional[float], rand_indices: Optional[Tensor] = None,
+               temperature: float = 1.0, laplace_eps: Optional[float] = 1e-5, mode: str = "argmax") -> Dict[str, Tensor]:
+    """``GaussianMixtureModel.update`` (= ``CodebookModel.update``, codebook_model.py:121-130, with the mixture's
+    kmean_iteration / _update_buffers / _update_parameters, gassian_mixture_model.py:108-176) on a state
+    {mean, vec_init, cov_raw, w_raw, n_obs, s1, s2}."""
+    st = {k: v.clone() for k, v in state.items()}
+    if torch.allclose(st["mean"], st["vec_init"]):
+        st["mean"] = x[..., rand_indices, :].clone()
+        st["n_obs"] = st["n_obs"] + 1
+    w = gmm_assign(x, st["mean"], _cov_read(st["cov_raw"]), _norm_sum(st["w_raw"]), temperature, mode)
+    ws, s1, s2 = w.sum(-2), w.transpose(-1, -2) @ x, w.transpose(-1, -2) @ (x ** 2)
+    hit = ws > 1e-8
+    st["n_obs"][hit] = ema(st["n_obs"][hit], ws[hit], decay)
+    st["s1"][hit] = ema(st["s1"][hit], s1[hit], decay)
+    st["s2"][hit] = ema(st["s2"][hit], s2[hit], decay)
+    _gmm_update_parameters(st, st["n_obs"], st["s1"], st["s2"], laplace_eps)
+    return st
+
+
+def gmm_fit(state: Dict[str, Tensor], laplace_eps: Optional[float] = 1e-5, iters: int = 100) -> Dict[str, Tensor]:
+    """``fit()`` without samples (codebook_model.py:132-143): the parameters recomputed from the buffers -- once per
+    k-means iteration in the reference, and every recomputation reads the parameters back through their parametrisations
+    (so the unobserved components' variances creep by 1e-8 per iteration: ``iters`` matters)."""
+    st = {k: v.clone() for k, v in state.items()}
+    for _ in range(iters):
+        _gmm_update_parameters(st, st["n_obs"], st["s1"], st["s2"], laplace_eps)
+    return st
+
+
+def batch_ot_gmm_diag(mean_s: Tensor, mean_t: Tensor, var_s: Tensor, var_t: Tensor, w_s: Tensor, w_t: Tensor, **sinkhorn_kwargs):
+    """``batch_ot_gmm`` with diag=True (ot/w2_utils.py:197-270): ground cost = componentwise Gaussian W2^2
+    (batch_w2_dissimilarity_gaussian_diag, :164-191), coupling = sinkhorn_log on the cost over its maximum."""
+    cost = sq_euclidean_cost(mean_s, mean_t) + sq_euclidean_cost(var_s.sqrt(), var_t.sqrt())
+    cmax = cost.max(-2, keepdim=True)[0].max(-1, keepdim=True)[0]
+    coupling = sinkhorn_log(w_s, w_t, cost / cmax, **sinkhorn_kwargs)
+    return torch.sum(cost * coupling, dim=(-2, -1)), coupling
+
+
+def gmm_transport_apply(x: Tensor, src: Dict[str, Tensor], tgt: Dict[str, Tensor], coupling: Tensor) -> Tensor:
+    """``GMMTransport.transport`` with transport_type='argmax' (ot/transport/gmm_transport.py:82-118): per input the
+    likeliest source component, the target component it is most coupled with, and the diagonal Gaussian map between
+    the two, T = sqrt(var_t / var_s + 1e-8) (w2_utils.py:737-741)."""
+    xs = x.to(coupling.dtype)
+    a = gmm_assign(xs, src["mean"], src["cov"], src["weights"])
+    ms, vs = a @ src["mean"], a @ src["cov"]
+    moved = a @ coupling
+    b = F.one_hot(moved.argmax(-1), moved.size(-1)).type_as(moved)
+    mt, vt = b @ tgt["mean"], b @ tgt["cov"]
+    T = torch.sqrt(vt / vs + STABILITY_CONST)
+    return (T * (xs - ms) + mt).type_as(x)

@@ -59,6 +59,7 @@ SIGNATURES = {
     "otvae_conv_bwd_weight": (i32, [pg, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
     "otvae_wgrad_reduce_batched": (i32, [i32, pp, pi32, pi32, pi32, pi32, pp, pp, pi32, pu32, vp]),
     "otvae_conv_dead_taps": (i32, [pg, pu32]),
+    "otvae_gmm_diag_energy": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "otvae_conv_multi": (i32, [i32, pj, vp]),
     "otvae_attn_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "otvae_attn_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),

@@ -781,3 +781,43 @@ extern "C" int otvae_codebook_kmeans(const float* x, const int64_t* idx, int nb,
     OTVAE_CHECK_LAUNCH("otvae_codebook_kmeans");
     return OTVAE_OK;
 }
+
+
+// ---- Gaussian-mixture energy (reference ot/distribution_models/gassian_mixture_model.py:91-99, diagonal covariances) ----
+// energy[nb][B][K] = log N(x_b; mean_k, diag var_k) + log w_k
+//                  = -1/2 sum_c ((x_bc - mean_kc)^2 / var_kc + log var_kc) - d/2 log(2 pi) + log w_k
+// One lane per (sample, component); a block's samples and one component's parameters stay in L1/L2.
+template <typename T>
+__global__ __launch_bounds__(256) void gmm_diag_energy_kernel(const T* __restrict__ x, const T* __restrict__ mean,
+                                                              const T* __restrict__ var, const T* __restrict__ logw, int B, int K,
+                                                              int d, T* __restrict__ out) {
+    const int nbi = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K, k = i - b * K;
+    const T* xp = x + ((size_t)nbi * B + b) * d;
+    const T* mp = mean + ((size_t)nbi * K + k) * d;
+    const T* vp = var + ((size_t)nbi * K + k) * d;
+    T acc = (T)0;
+    for (int c = 0; c < d; ++c) {
+        const T diff = xp[c] - mp[c];
+        acc += diff * diff / vp[c] + log(vp[c]);
+    }
+    out[((size_t)nbi * B + b) * K + k] = (T)-0.5 * (acc + (T)d * (T)1.8378770664093454835606594728112) + logw[(size_t)nbi * K + k];
+}
+
+extern "C" int otvae_gmm_diag_energy(int dtype, const void* x, const void* mean, const void* var, const void* logw, int nb,
+                                     int B, int K, int d, void* energy, void* stream) {
+    OTVAE_REQUIRE(x && mean && var && logw && energy && nb > 0 && B > 0 && K > 0 && d > 0, "otvae_gmm_diag_energy: bad argument");
+    OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_gmm_diag_energy: dtype must be 0 (fp32) or 1 (fp64)");
+    const dim3 grid(cdiv((int64_t)B * K, 256), nb);
+    if (dtype == 0)
+        gmm_diag_energy_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, (const float*)mean, (const float*)var,
+                                                                         (const float*)logw, B, K, d, (float*)energy);
+    else
+        gmm_diag_energy_kernel<double><<<grid, 256, 0, (hipStream_t)stream>>>((const double*)x, (const double*)mean,
+                                                                          (const double*)var, (const double*)logw, B, K, d,
+                                                                          (double*)energy);
+    OTVAE_CHECK_LAUNCH("otvae_gmm_diag_energy");
+    return OTVAE_OK;
+}

@@ -1,0 +1,250 @@
+"""``GaussianMixtureModel`` with diagonal covariances (reference ot/distribution_models/gassian_mixture_model.py:28-177,
+mixture behaviour from base.py:165-262, fitting loop from codebook_model.py:121-143): K Gaussians per leading index
+fitted by (EMA) k-means style updates on streaming batches -- every sample is assigned to components by its
+log-likelihood + log-weight, the assignment weights accumulate (count, sum x, sum x^2) per component, and mean /
+variance / mixture weight of the OBSERVED components follow from the Laplace-smoothed counts.
+
+MI355X path: the O(B K d) energies come from ``otvae_gmm_diag_energy``; the [B, K] soft-max / arg-max and the three
+weighted sums (``weights^T @ x``: plain library GEMMs) are small tensor expressions kept in the reference's order, and
+``w2`` composes ``batch_ot_gmm`` (HIP pairwise-distance + Sinkhorn kernels).  Full covariance mixtures are not
+implemented (the reference marks its own full-covariance GMM cost as producing NaN, ot/w2_utils.py:262)."""
+from functools import partial
+from typing import Optional, Tuple
+
+import torch
+import torch.distributions as D
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.nn.utils.parametrize as P
+from torch import Tensor
+
+from ... import _lib, utils
+from ..._lib import check, ptr, stream
+from ..w2_utils import W2Mixin, batch_ot_gmm
+from .base import DistributionModel
+from .gaussian_model import MakePositiveDefinite
+
+__all__ = ["GaussianMixtureModel"]
+
+_MODES = ("argmax", "sample", "mean")
+
+
+class NormSum(nn.Module):
+    """weights parametrisation: read back normalised to sum ``val`` (gassian_mixture_model.py:180-189)"""
+
+    def __init__(self, val: float = 1.):
+        super().__init__()
+        self.val = val
+
+    def forward(self, X):
+        return self.val * X / X.sum(-1, keepdim=True)
+
+    def right_inverse(self, X):
+        return X
+
+
+class GaussianMixtureModel(DistributionModel, W2Mixin):
+    Distribution = D.MixtureSameFamily
+
+    def __init__(self, *size: int, mixture_cfg={}, w2_cfg={}, **kwargs) -> None:
+        cfg = dict(n_components=None, metric="euclidean", p=2., topk=None, temperature=1., training_mode="argmax",
+                   inference_mode="argmax", kmeans_iter=100, laplace_eps=1e-5)
+        unknown = set(mixture_cfg) - set(cfg)
+        if unknown:
+            raise TypeError(f"unexpected mixture_cfg keys: {sorted(unknown)}")
+        cfg.update(mixture_cfg)
+        if cfg["n_components"] is None:
+            raise TypeError("mixture_cfg must give `n_components`")
+        if cfg["topk"] not in (None, 0):
+            raise NotImplementedError("topk assignment is not implemented on the MI355X path")
+        for m in (cfg["training_mode"], cfg["inference_mode"]):
+            if m not in _MODES:
+                raise NotImplementedError(f"assignment mode {m!r}: only {_MODES} run on the MI355X path")
+        if kwargs.get("update_with_autograd", False):
+            raise NotImplementedError("update_with_autograd=True is not implemented on the MI355X path")
+        self.n_components = int(cfg["n_components"])
+        self.temperature = float(cfg["temperature"])
+        self.training_mode, self.inference_mode = cfg["training_mode"], cfg["inference_mode"]
+        self.kmeans_iter = int(cfg["kmeans_iter"])
+        self.laplace_smoothing = partial(utils.laplace_smoothing, n_categories=self.n_components, eps=cfg["laplace_eps"])
+        DistributionModel.__init__(self, *size, **kwargs)
+        W2Mixin.__init__(self, **dict(w2_cfg))
+        if not self.diag:
+            raise NotImplementedError("GaussianMixtureModel on the MI355X path needs diagonal covariances (w2_cfg diag=True)")
+        self.batch_dim = -3
+        self.register_buffer("cov_init", torch.ones_like(self.vec_init))
+        w = torch.ones(*self.leading_shape, self.n_components)
+        self.register_buffer("weight_init", (w / w.sum(-1, keepdim=True)).type_as(self.vec_init))
+        self.mean = nn.Parameter(self.vec_init.clone(), requires_grad=False)
+        self.cov = nn.Parameter(self.cov_init.clone(), requires_grad=False)
+        self._weights = nn.Parameter(self.weight_init.clone(), requires_grad=False)
+        self.register_buffer("_running_sum", torch.zeros_like(self.mean.data))
+        self.register_buffer("_running_sum_cov", torch.zeros_like(self.cov.data))
+        self.register_buffer("_n_obs", torch.zeros(self.vec_shape[:-1], dtype=self.vec_init.dtype))
+        P.register_parametrization(self, "cov", MakePositiveDefinite(diag=True, strict=True))
+        P.register_parametrization(self, "_weights", NormSum(1.))
+
+    # ---- shapes / distributions
+    @property
+    def vec_shape(self):
+        return (*self.leading_shape, self.n_components, self.dim)
+
+    @property
+    def weights(self) -> Tensor:
+        return self._weights
+
+    @property
+    def variances(self) -> Tensor:
+        return self.cov
+
+    @property
+    def batched_variances(self) -> Tensor:
+        return self.cov.unsqueeze(-3)
+
+    @property
+    def mode(self) -> str:
+        return self.training_mode if self.training else self.inference_mode
+
+    def _components(self, batched: bool):
+        mean, cov = (self.mean.unsqueeze(-3), self.cov.unsqueeze(-3)) if batched else (self.mean, self.cov)
+        return D.Independent(D.Normal(mean, cov ** 0.5), 1)
+
+    @property
+    def distribution(self) -> D.MixtureSameFamily:
+        return D.MixtureSameFamily(D.Categorical(self.weights), self._components(False))
+
+    @property
+    def batched_distribution(self) -> D.MixtureSameFamily:
+        return D.MixtureSameFamily(D.Categorical(self.weights.unsqueeze(-2)), self._components(True))
+
+    @torch.no_grad()
+    def reset(self) -> None:
+        self.mean.copy_(self.vec_init)
+        self.cov = self.cov_init
+        self._weights = self.weight_init
+        self._running_sum.zero_()
+        self._running_sum_cov.zero_()
+        self._n_obs.zero_()
+
+    # ---- assignment
+    def energy(self, samples: Tensor) -> Tensor:
+        """log N(x; mean_k, var_k) + log w_k, [*, B, K] (gassian_mixture_model.py:91-99)"""
+        self._validate_samples(samples)
+        lib = _lib.load()
+        _lib.require_cuda(samples, "samples")
+        dt = self.mean.dtype
+        if dt not in (torch.float32, torch.float64):
+            raise TypeError("GaussianMixtureModel parameters must be float32 or float64")
+        lead = torch.broadcast_shapes(samples.shape[:-2], self.leading_shape)
+        bsz, K, d = samples.shape[-2], self.n_components, self.dim
+        x3 = samples.to(dt).expand(*lead, bsz, d).reshape(-1, bsz, d).contiguous()
+        nb = x3.shape[0]
+        flat = lambda t, tail: t.detach().to(dt).expand(*lead, *tail).reshape(nb, *tail).contiguous()  # noqa: E731
+        mean, var = flat(self.mean, (K, d)), flat(self.cov, (K, d))
+        logw = flat(torch.log_softmax(torch.log(self.weights), dim=-1), (K,))
+        out = torch.empty((nb, bsz, K), device=x3.device, dtype=dt)
+        check(lib.otvae_gmm_diag_energy(0 if dt == torch.float32 else 1, ptr(x3), ptr(mean), ptr(var), ptr(logw), nb, bsz, K, d,
+                                        ptr(out), stream()), "otvae_gmm_diag_energy")
+        return out.reshape(*lead, bsz, K).type_as(samples if samples.is_floating_point() else out)
+
+    def assign(self, samples: Tensor):
+        """(assignment weights [*, B, K], sampled indices [*, B], Categorical(softmax weights)) -- base.py:206-239"""
+        energy = self.energy(samples)
+        weights = torch.softmax(energy / self.temperature, dim=-1)
+        distribution = D.Categorical(weights)
+        indices = distribution.sample()
+        mode = self.mode
+        if mode == "sample":
+            weights = F.one_hot(indices, self.n_components).type_as(weights)
+        elif mode == "argmax":
+            weights = F.one_hot(weights.argmax(-1), self.n_components).type_as(weights)
+        return weights, indices, distribution
+
+    def predict_mean_var(self, assignments: Tensor) -> Tuple[Tensor, Tensor]:
+        """per-sample mean and variance of the assigned component(s): assignments [*, B, K] -> [*, B, d] each"""
+        mean = assignments.type_as(self.mean) @ self.mean
+        var = assignments.type_as(self.cov) @ self.cov
+        return mean.type_as(assignments), var.type_as(assignments)
+
+    def predict(self, samples: Tensor):
+        weights, indices, distribution = self.assign(samples)
+        return weights.type_as(self.mean) @ self.mean, indices, distribution
+
+    # ---- fitting (codebook_model.py:121-143 driving gassian_mixture_model.py:108-170)
+    def kmean_iteration(self, samples: Optional[Tensor]):
+        if samples is None:
+            return self._n_obs, self._running_sum, self._running_sum_cov
+        weights, _, _ = self.assign(samples)                               # [*, B, K]
+        wt = weights.transpose(-1, -2).type_as(samples)
+        return weights.sum(-2).type_as(samples), wt @ samples, wt @ (samples ** 2)
+
+    def _init_parameters(self, samples: Tensor) -> None:
+        if torch.allclose(self.mean, self.vec_init):
+            rand_indices = torch.randperm(samples.size(-2))[:self.n_components]  # host generator, as the reference
+            self.mean.copy_(samples[..., rand_indices.to(samples.device), :].type_as(self.mean))
+            self._n_obs += 1
+
+    def _update_buffers(self, weights_sum: Tensor, samples_sum: Tensor, samples_cov_sum: Tensor, decay: bool = False):
+        hit = weights_sum > 1e-8
+        if decay:
+            self._n_obs[hit] = self.ema_update(self._n_obs[hit], weights_sum[hit])
+            self._running_sum[hit] = self.ema_update(self._running_sum[hit], samples_sum[hit])
+            self._running_sum_cov[hit] = self.ema_update(self._running_sum_cov[hit], samples_cov_sum[hit])
+        else:
+            self._n_obs[hit] = weights_sum[hit]
+            self._running_sum[hit] = samples_sum[hit]
+            self._running_sum_cov[hit] = samples_cov_sum[hit]
+        return self._n_obs, self._running_sum, self._running_sum_cov
+
+    def _update_parameters(self, weights_sum: Tensor, samples_sum: Tensor, samples_cov_sum: Tensor) -> None:
+        n_obs = self.laplace_smoothing(weights_sum)
+        if bool((n_obs == 0).all()):
+            return
+        seen = n_obs > 1e-8
+        mean, cov = self.mean_cov(samples_sum[seen], samples_cov_sum[seen], n_obs[seen])
+        self.mean.data[seen] = mean.type_as(self.mean)
+        tmp = self.cov
+        tmp[seen] = cov.type_as(tmp)
+        self.cov = tmp
+        tmp = self._weights                        # normalised read-back ...
+        tmp[seen] = weights_sum[seen].type_as(tmp)  # ... with the raw counts of the observed components, as the reference
+        self._weights = tmp
+
+    @torch.no_grad()
+    def update(self, samples: Tensor) -> None:
+        self._validate_samples(samples)
+        samples = samples.detach().type_as(self._running_sum)
+        self._init_parameters(samples)
+        res = self.kmean_iteration(samples)
+        if self.reduce_on_update:
+            res = [self.reduce(r) for r in res]
+        self._update_parameters(*self._update_buffers(*res, decay=True))
+
+    @torch.no_grad()
+    def fit(self, samples: Optional[Tensor] = None) -> None:
+        if samples is not None:
+            self._validate_samples(samples)
+            samples = samples.detach().type_as(self._running_sum)
+            self._init_parameters(samples)
+        res = None
+        for _ in range(self.kmeans_iter):
+            res = self.kmean_iteration(samples)
+            res_r = [self.reduce(r) for r in res]
+            self._update_parameters(*res_r)
+            # From the stored buffers every iteration recomputes the same values for the observed components; only the
+            # unobserved ones drift (their variance is read back + 1e-8, their weight re-normalised), so the loop runs on
+            # for them alone -- as the reference's does.
+            if samples is None and bool((self.laplace_smoothing(res_r[0]) > 1e-8).all()):
+                break
+        if self.kmeans_iter > 0:
+            self._update_buffers(*res, decay=False)
+
+    def w2(self, other: D.MixtureSameFamily) -> Tensor:
+        total, _ = batch_ot_gmm(self.mean, other.component_distribution.mean, self.variances,
+                                other.component_distribution.variance, diag=True, weight_source=self.weights,
+                                weight_target=other.mixture_distribution.probs, dtype=self.dtype, max_iter=100)
+        return total
+
+    def extra_repr(self) -> str:
+        return (DistributionModel.extra_repr(self) + ", " + W2Mixin.__repr__(self) + f", num_components={self.n_components}, "
+                f"temperature={self.temperature}, training_mode={self.training_mode}, inference_mode={self.inference_mode}")

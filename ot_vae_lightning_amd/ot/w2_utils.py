@@ -16,7 +16,7 @@ from .._lib import check, ptr, stream
 from .matrix_utils import *  # noqa: F401,F403
 from .matrix_utils import STABILITY_CONST, eigvals_and_fn, eye_like, is_symmetric, matmul64, mean_cov
 
-__all__ = ["w2_gaussian", "batch_w2_dissimilarity_gaussian_diag", "sinkhorn_log", "sinkhorn_log_potentials",
+__all__ = ["w2_gaussian", "batch_w2_dissimilarity_gaussian_diag", "batch_ot_gmm", "sinkhorn_log", "sinkhorn_log_potentials",
            "sq_euclidean_cost", "ot_cost", "compute_transport_operators", "apply_transport", "W2Mixin"]
 
 _DT = {torch.float32: 0, torch.float64: 1}
@@ -147,6 +147,47 @@ def batch_w2_dissimilarity_gaussian_diag(mean_source: Tensor, mean_target: Tenso
         raise ValueError("variances are expected to have positive entries.")
     return sq_euclidean_cost(mean_source.to(dtype), mean_target.to(dtype)) + \
         sq_euclidean_cost(var_source.to(dtype).sqrt(), var_target.to(dtype).sqrt())
+
+
+def _check_mixture(mean: Tensor, var: Tensor, weight: Tensor, side: str, tol: float = 1e-5):
+    """the argument checks of the reference's ``_validate_args`` for ('vec', 'var', 'prob') triples (w2_utils.py:605-708)"""
+    for t, name in ((mean, f"mean_{side}"), (var, f"cov_{side}"), (weight, f"weight_{side}")):
+        if not isinstance(t, Tensor):
+            raise ValueError(f"`{name}` is expected to be a torch.Tensor, got `{type(t)}` instead.")
+    if mean.dim() < 2 or var.dim() < 2:
+        raise ValueError(f"`mean_{side}` / `cov_{side}` should be 1-dim vectors with a leading component dimension")
+    if bool((var < 0).any()):
+        raise ValueError(f"`cov_{side}` is expected to be a valid variance vector with positive entries.")
+    total = weight.sum(-1)
+    if bool((weight < -tol).any()) or bool((total < 1 - tol).any()) or bool((total > 1 + tol).any()):
+        raise ValueError(f"`weight_{side}` is expected to be a valid probability vector with positive entries that sum up to 1.")
+    if mean.size(-1) != var.size(-1):
+        raise ValueError(f"All the inputs dimensionalities should match, got {[mean.size(-1), var.size(-1)]}")
+    if not (mean.size(-2) == var.size(-2) == weight.size(-1)):
+        raise ValueError(f"All the inputs component dimension should match, got {[mean.size(-2), var.size(-2), weight.size(-1)]}")
+
+
+def batch_ot_gmm(mean_source: Tensor, mean_target: Tensor, cov_source: Tensor, cov_target: Tensor, diag: bool,
+                 weight_source: Optional[Tensor] = None, weight_target: Optional[Tensor] = None, verbose: bool = False,
+                 dtype=torch.double, **sinkhorn_kwargs) -> Tuple[Tensor, Tensor]:
+    """Entropy-regularised W2^2 upper bound between two Gaussian mixtures (reference ot/w2_utils.py:197-270): the
+    component-to-component Gaussian W2^2 as ground cost, the coupling of the mixture weights from ``sinkhorn_log`` on the
+    cost scaled by its maximum, total = <cost, coupling>.  means [*, N, D] / [*, M, D], variances alike (diag=True; full
+    covariances are not implemented -- the reference flags its own full-covariance cost as producing NaN)."""
+    if not diag:
+        raise NotImplementedError("batch_ot_gmm on the MI355X path takes diagonal covariances (diag=True)")
+    if weight_source is None:
+        weight_source = torch.ones_like(mean_source.select(dim=-1, index=0)) / mean_source.size(-2)
+    if weight_target is None:
+        weight_target = torch.ones_like(mean_target.select(dim=-1, index=0)) / mean_target.size(-2)
+    _check_mixture(mean_source, cov_source, weight_source, "source")
+    _check_mixture(mean_target, cov_target, weight_target, "target")
+    if mean_source.size(-1) != mean_target.size(-1):
+        raise ValueError("All the inputs dimensionalities should match")
+    cost = batch_w2_dissimilarity_gaussian_diag(mean_source, mean_target, cov_source, cov_target, dtype=dtype)
+    max_per_mat = cost.max(-2, keepdim=True)[0].max(-1, keepdim=True)[0]
+    coupling = sinkhorn_log(weight_source.to(dtype), weight_target.to(dtype), cost / max_per_mat, **sinkhorn_kwargs)
+    return torch.sum(cost * coupling, dim=(-2, -1)), coupling
 
 
 def compute_transport_operators(cov_source: Tensor, cov_target: Tensor, stochastic: bool, diag: bool,

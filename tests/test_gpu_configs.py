@@ -325,6 +325,56 @@ def test_latent_transport_callback_validation_epoch_vs_oracle(A):
     rep.finish()
 
 
+def test_latent_transport_callback_with_gmm_and_discrete_operators(A):
+    """The other two operators of the reference's tests/test_latent_transport.py:80-101 behind the same callback: a
+    GMMTransport per latent needle (transport_dims=(1,), 10 components, diagonal) and a DiscreteTransport per channel map
+    (transport_dims=(2, 3), soft 'mean' training mode at temperature 1e-2), one common operator each.  A validation epoch
+    through the hooks, then the transported latents must be finite, have the latent shape, and land nearer (on average)
+    to the target latents' mean than the source latents were."""
+    import torch.nn.functional as F
+    torch.manual_seed(4)
+    ae = A.AutoEncoder(1, 64, 32, 4, capacity=4, double_encoded_features=False, down_up_sample=True, residual="add")
+    vae = A.VAE(autoencoder=ae, prior=None).cuda().eval()
+    kern = torch.tensor([1., 4., 6., 4., 1.])
+    kern = (kern[:, None] * kern[None, :] / 256.0)[None, None].cuda()
+    shift_blur = lambda x: F.conv2d(F.pad(x, (2, 2, 2, 2), mode="reflect"), kern) * 0.5 - 0.7  # noqa: E731
+    w2_cfg = dict(diag=True, stochastic=False, pg_star=0., make_pd=True, verbose=False, dtype=torch.double)
+    mix = dict(metric="euclidean", p=2., topk=None, temperature=1., training_mode="argmax", inference_mode="argmax")
+    base = dict(update_decay=None, update_with_autograd=False, dtype=torch.double)
+    common = dict(size=vae.latent_size, transformations=shift_blur, source_latents_from_train=False,
+                  target_latents_from_train=False, unpaired=True, common_operator=True)
+    cbs = [A.LatentTransport(transport_operator=A.GMMTransport, transport_dims=(1,), logging_prefix="gmm", transport_type="argmax",
+                             transport_cfg=w2_cfg, source_cfg={**base, "mixture_cfg": {**mix, "n_components": 10}},
+                             target_cfg={**base, "mixture_cfg": {**mix, "n_components": 10}}, **common),
+           A.LatentTransport(transport_operator=A.DiscreteTransport, transport_dims=(2, 3), logging_prefix="discrete",
+                             transport_type="mean",
+                             source_cfg={**base, "mixture_cfg": {**mix, "training_mode": "mean", "n_components": 64, "temperature": 1e-2}},
+                             target_cfg={**base, "mixture_cfg": {**mix, "training_mode": "mean", "n_components": 64, "temperature": 1e-2}},
+                             **common)]
+    assert cbs[0].dim == 64 and cbs[1].dim == 16
+    with torch.no_grad():
+        for cb in cbs:
+            cb.on_fit_start(None, vae)
+            cb.on_validation_epoch_start(None, vae)
+        for i in range(6):
+            x = mnist_like(256, seed=700 + i).cuda()
+            for cb in cbs:
+                cb.on_validation_batch_end(None, vae, {"samples": x}, None, i)
+        x = mnist_like(128, seed=800).cuda()
+        z_tgt, z_src = vae.encode(x), vae.encode(shift_blur(x))
+        for cb in cbs:
+            cb.on_validation_epoch_end(None, vae)
+            cost = cb.logged[cb.logging_prefix + "avg_transport_cost"]
+            assert torch.isfinite(cost) and float(cost) >= 0
+            moved = cb.transport(z_src)
+            assert moved.shape == z_src.shape and moved.dtype == z_src.dtype and torch.isfinite(moved).all()
+            axes = (0, 2, 3) if cb.transport_dims == (1,) else (0, 1)     # what the common operator pools over
+            before = (z_src.mean(axes) - z_tgt.mean(axes)).norm()
+            after = (moved.mean(axes) - z_tgt.mean(axes)).norm()
+            assert float(after) < 0.5 * float(before), (cb.logging_prefix, float(before), float(after))
+            assert vae.decode(moved).shape == x.shape
+
+
 _DP_OVERLAP_CHECK = r"""
 import os, sys, torch
 import torch.distributed as dist

@@ -816,3 +816,89 @@ def test_codebook_prior_vs_reference_golden(A):
     with pytest.raises(ValueError):
         A.CodebookPrior(size, (4,), mixture_cfg=dict(n_components=K))
     rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G11 Gaussian mixtures
+_GMM_W2 = dict(diag=True, stochastic=False, pg_star=0., make_pd=True, verbose=False, dtype=torch.double)
+_GMM_MIX = dict(metric="euclidean", p=2., topk=None, temperature=1., training_mode="argmax", inference_mode="argmax")
+
+
+@pytest.mark.parametrize("tag", ["sum", "ema"])
+def test_gaussian_mixture_model_vs_reference_golden(A, tag):
+    """GaussianMixtureModel with diagonal covariances (reference gassian_mixture_model.py): three streaming updates (with
+    and without EMA decay, with a leading dimension), fit, the mixture energy / assignment of a batch and w2 against
+    another mixture -- golden vectors from the reference's own class, double precision."""
+    g = group(load_golden("gmm.npz"), tag)
+    rep = Report(f"GaussianMixtureModel ({tag}) vs reference golden")
+    K, d, B, decay = g["cfg"].tolist()
+    K, d = int(K), int(d)
+    decay = None if decay < 0 else float(decay)
+    batches = g["batches"]
+    lead = tuple(batches.shape[1:-2])
+    model = A.GaussianMixtureModel(*lead, d, mixture_cfg={**_GMM_MIX, "n_components": K}, w2_cfg=_GMM_W2, update_decay=decay,
+                                   dtype=torch.double).cuda().train()
+    for step in range(batches.shape[0]):
+        if step == 0:
+            torch.manual_seed(81)
+        model.update(batches[step].cuda())
+        rep.check(f"step{step}/n_obs", model._n_obs, g[f"step{step}/n_obs"], 1e-12)
+        rep.check(f"step{step}/mean", model.mean, g[f"step{step}/mean"], 1e-12)
+        rep.check(f"step{step}/cov", model.cov, g[f"step{step}/cov"], 1e-11)
+        rep.check(f"step{step}/weights", model.weights, g[f"step{step}/weights"], 1e-12)
+    model.fit()
+    rep.check("fit/mean", model.mean, g["fit/mean"], 1e-12)
+    rep.check("fit/cov", model.cov, g["fit/cov"], 1e-11)
+    rep.check("fit/weights", model.weights, g["fit/weights"], 1e-12)
+    model.eval()
+    x = batches[-1].cuda()
+    rep.check("energy", model.energy(x), g["energy"], 1e-12)
+    weights, sampled, dist = model.assign(x)
+    rep.check("assignment one-hot", weights, g["assign_onehot"], exact=True)
+    rep.check("assignment probabilities", dist.probs, g["assign_probs"], 1e-10)
+    assert sampled.shape == x.shape[:-1]
+    centres = g["centres"].cuda()
+    other = torch.distributions.MixtureSameFamily(
+        torch.distributions.Categorical((torch.ones(*lead, K, dtype=torch.double) / K).cuda()),
+        torch.distributions.Independent(torch.distributions.Normal(centres, torch.full_like(centres, 0.4)), 1))
+    rep.check("w2", model.w2(other), g["w2"], 1e-8)
+    model.reset()
+    assert float(model._n_obs.sum()) == 0 and torch.allclose(model.mean, model.vec_init)
+    rep.finish()
+
+
+def test_gmm_transport_vs_reference_golden(A):
+    """GMMTransport (reference ot/transport/gmm_transport.py, configured as tests/test_latent_transport.py:80-91): three
+    updates per side, compute (component coupling from the HIP Sinkhorn solver on the diagonal-Gaussian W2 cost),
+    transport of a probe batch ('argmax': likeliest source component -> most coupled target component -> closed-form
+    diagonal map)."""
+    g = group(load_golden("gmm.npz"), "tr")
+    rep = Report("GMMTransport vs reference golden")
+    K, d = g["source_mean"].shape
+    cfg = dict(update_decay=None, update_with_autograd=False, dtype=torch.double, mixture_cfg={**_GMM_MIX, "n_components": K})
+    op = A.GMMTransport(d, transport_type="argmax", transport_cfg=_GMM_W2, source_cfg=cfg, target_cfg=cfg).cuda().train()
+    for i in range(g["src"].shape[0]):
+        if i == 0:
+            torch.manual_seed(82)
+        op.update(source_samples=g["src"][i].cuda())
+        if i == 0:
+            torch.manual_seed(182)
+        op.update(target_samples=g["tgt"][i].cuda())
+    total = op.compute()
+    for side, m in (("source", op.source_model), ("target", op.target_model)):
+        rep.check(f"{side} means", m.mean, g[f"{side}_mean"], 1e-12)
+        rep.check(f"{side} variances", m.cov, g[f"{side}_cov"], 1e-11)
+        rep.check(f"{side} weights", m.weights, g[f"{side}_weights"], 1e-12)
+    rep.check("coupling", op.transport_matrix, g["coupling"], 1e-8)
+    rep.check("total cost", total, g["total"], 1e-8)
+    op.eval()
+    moved = op.transport(g["probe"].cuda())
+    assert moved.dtype == torch.float32
+    rep.check("transported probe", moved, g["moved"], 1e-5)
+    op.reset()
+    with pytest.raises(RuntimeError):
+        op.transport(g["probe"].cuda())
+    with pytest.raises(NotImplementedError):
+        A.GMMTransport(d, transport_type="barycenter", transport_cfg=_GMM_W2, source_cfg=cfg, target_cfg=cfg)
+    with pytest.raises(NotImplementedError):
+        A.GMMTransport(d, transport_type="argmax", transport_cfg={**_GMM_W2, "diag": False}, source_cfg=cfg, target_cfg=cfg)
+    rep.finish()

@@ -374,3 +374,61 @@ def test_codebook_prior_forward_and_straight_through_gradient():
         z, loss, _ = O.codebook_prior_encode(xe, st["codebook"], loss=kind, coeff=0.5)
         assert rel_err(loss, g[f"eval/loss_{kind}"]) < 1e-5
     assert rel_err(z.reshape(g["eval/z"].shape), g["eval/z"]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ G11 Gaussian mixtures
+def _gmm_state(vec_init):
+    lead_k = vec_init.shape[:-1]
+    return {"mean": vec_init.clone(), "vec_init": vec_init, "cov_raw": torch.ones_like(vec_init),
+            "w_raw": torch.ones(*lead_k, dtype=vec_init.dtype) / lead_k[-1], "n_obs": torch.zeros(*lead_k, dtype=vec_init.dtype),
+            "s1": torch.zeros_like(vec_init), "s2": torch.zeros_like(vec_init)}
+
+
+@pytest.mark.parametrize("tag", ["sum", "ema"])
+def test_gmm_update_fit_energy_w2(tag):
+    g = group(load_golden("gmm.npz"), tag)
+    K, d, B, decay = g["cfg"].tolist()
+    K, B = int(K), int(B)
+    decay = None if decay < 0 else float(decay)
+    st = _gmm_state(g["vec_init"])
+    for step in range(g["batches"].shape[0]):
+        st = O.gmm_update(st, g["batches"][step], decay, rand_indices=_seeded_randperm(81, B, K)[0] if step == 0 else None)
+        assert rel_err(st["n_obs"], g[f"step{step}/n_obs"]) < 1e-12, step
+        assert rel_err(st["mean"], g[f"step{step}/mean"]) < 1e-12, step
+        assert rel_err(O._cov_read(st["cov_raw"]), g[f"step{step}/cov"]) < 1e-12, step
+        assert rel_err(O._norm_sum(st["w_raw"]), g[f"step{step}/weights"]) < 1e-12, step
+    st = O.gmm_fit(st)
+    mean, cov, w = st["mean"], O._cov_read(st["cov_raw"]), O._norm_sum(st["w_raw"])
+    assert rel_err(mean, g["fit/mean"]) < 1e-12 and rel_err(cov, g["fit/cov"]) < 1e-12 and rel_err(w, g["fit/weights"]) < 1e-12
+    x = g["batches"][-1]
+    assert rel_err(O.gmm_diag_energy(x, mean, cov, w), g["energy"]) < 1e-12
+    assert torch.equal(O.gmm_assign(x, mean, cov, w), g["assign_onehot"])
+    assert rel_err(torch.softmax(O.gmm_diag_energy(x, mean, cov, w), -1), g["assign_probs"]) < 1e-10
+    lead = g["centres"].shape[:-2]
+    total, _ = O.batch_ot_gmm_diag(mean, g["centres"], cov, torch.full_like(g["centres"], 0.16), w,
+                                   torch.ones(*lead, K, dtype=torch.float64) / K, max_iter=100)
+    assert rel_err(total, g["w2"]) < 1e-9
+
+
+def test_gmm_transport_compute_and_transport():
+    g = group(load_golden("gmm.npz"), "tr")
+    K, d = g["source_mean"].shape
+    B = g["src"].shape[-2]
+    fitted = {}
+    for side, seed in (("src", 82), ("tgt", 182)):
+        st = _gmm_state(torch.zeros(K, d, dtype=torch.float64))
+        # the reference draws vec_init with randn: only "has the mean been initialised" matters, which the first update decides
+        st["vec_init"] = st["mean"].clone()
+        for step in range(g[side].shape[0]):
+            st = O.gmm_update(st, g[side][step], None, rand_indices=_seeded_randperm(seed, B, K)[0] if step == 0 else None)
+        st = O.gmm_fit(st)
+        name = "source" if side == "src" else "target"
+        fitted[name] = {"mean": st["mean"], "cov": O._cov_read(st["cov_raw"]), "weights": O._norm_sum(st["w_raw"])}
+        for k in ("mean", "cov", "weights"):
+            assert rel_err(fitted[name][k], g[f"{name}_{k}"]) < 1e-12, (name, k)
+    total, coupling = O.batch_ot_gmm_diag(fitted["source"]["mean"], fitted["target"]["mean"], fitted["source"]["cov"],
+                                          fitted["target"]["cov"], fitted["source"]["weights"], fitted["target"]["weights"],
+                                          max_iter=100)
+    assert rel_err(coupling, g["coupling"]) < 1e-9 and rel_err(total, g["total"]) < 1e-9
+    moved = O.gmm_transport_apply(g["probe"], fitted["source"], fitted["target"], g["coupling"])
+    assert rel_err(moved, g["moved"]) < 1e-5
