@@ -155,6 +155,25 @@ int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream);
 int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, float* aux, void* stream);
 int otvae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux,
                    int N, int T, int H, int C, float* gqkv, void* stream);
+/* The same kernels with an explicit score scale: scores = scale * q.k (otvae_attn_fwd / _bwd use 1/C, the product of the
+ * two C^-1/2 factors of QKVAttention; torch.nn.MultiheadAttention inside the reference's ViT, networks/vit.py:169-172,
+ * uses 1/sqrt(C)). */
+int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int C, float scale, float* out, float* lse, float* aux,
+                          void* stream);
+int otvae_attn_bwd_scaled(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux, int N,
+                          int T, int H, int C, float scale, float* gqkv, void* stream);
+
+/* ---- LayerNorm over the last dimension (the token streams of the ViT: networks/vit.py:38,54 and the two norms of each
+ * nn.TransformerEncoderLayer, :169-172; torch.nn.functional.layer_norm arithmetic) ---------------------------------------
+ * y[m][:] = (s - mean(s)) * rstd(s) * gamma + beta with s = x[m][:] + res[m][:] (res nullable: the "x + sublayer(x)" of the
+ * post-norm block summed in; s is written to sum_out [M][D], which otvae_layernorm_bwd takes as xs; without a residual
+ * sum_out may be NULL and xs = x).  mean / rstd [M] are saved for backward.  D <= 2048.
+ * Backward: gx [M][D] (the gradient of both x and res), dgamma / dbeta [D]; ws: otvae_layernorm_bwd_ws(M, D) floats. */
+int otvae_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, int M, int D, float eps,
+                        float* sum_out, float* y, float* mean, float* rstd, void* stream);
+int otvae_layernorm_bwd_ws(int M, int D);
+int otvae_layernorm_bwd(const float* xs, const float* gy, const float* gamma, const float* mean, const float* rstd, int M, int D,
+                        float* gx, float* dgamma, float* dbeta, float* ws, void* stream);
 
 /* ---- GaussianPrior (prior/gaussian.py:63-96) + Prior.forward scaling (prior/base.py:74-78) ---------------- */
 /* h [B][S][2D] (S = H*W positions, channels-last) ; eps,z [B][S][D]; loss[B] = coeff * KL(q||N(0,I)) */

@@ -34,6 +34,20 @@ def fill_state_dict(sd) -> None:
             raise KeyError(k)
 
 
+def fill_vit_state_dict(sd) -> None:
+    """In-place fill of a ViT ``state_dict``: Linear / in_proj weights ~ 1.7 / sqrt(fan_in), LayerNorm weights around 1,
+    biases small, embeddings and the learned tokens of amplitude 0.5."""
+    for j, (k, t) in enumerate(sd.items()):
+        if k.endswith("bias"):
+            fill_tensor(t, j, 0.05)
+        elif t.dim() == 1:
+            fill_tensor(t, j, 0.2, 1.0)
+        elif k.endswith("embed_token") or "position_embeddings" in k or k.startswith("class_token"):
+            fill_tensor(t, j, 0.5)
+        else:
+            fill_tensor(t, j, 1.7 / math.sqrt(t.shape[-1]))
+
+
 def det_input(shape, phase: float = 0.0, amp: float = 1.0, dtype=torch.float32) -> torch.Tensor:
     n = 1
     for s in shape:

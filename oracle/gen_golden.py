@@ -21,6 +21,7 @@ Fixtures:
   codebook_kmeans.npz  CodebookModel.update/fit/predict/w2 (streaming k-means)
   discrete.npz       CodebookModel in 'mean' mode, DiscreteTransport.compute/transport, CodebookPrior.forward
   gmm.npz            GaussianMixtureModel (diagonal) update/fit/energy/w2, GMMTransport.compute/transport
+  vit.npz            ViT encoder / decoder (reference networks/vit.py) fwd + input and parameter gradients, dropout 0
 """
 import math
 import os
@@ -32,7 +33,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_import as R  # noqa: E402
-from detfill import fill_state_dict, det_input, mnist_like, normal  # noqa: E402
+from detfill import fill_state_dict, fill_vit_state_dict, det_input, mnist_like, normal  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -599,8 +600,50 @@ def gen_gmm():
     save("gmm.npz", out)
 
 
+VIT_CASES = [
+    # tag, common cfg, batch
+    ("d32", dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, dropout=0.0, emb_dropout=0.,
+                 num_classes=10), 3),
+    ("d128", dict(image_size=32, patch_size=8, dim=128, depth=1, heads=4, mlp_dim=256, channels=3, dropout=0.0, emb_dropout=0.,
+                  num_classes=None), 2),
+]
+
+
+def gen_vit():
+    """G12: the reference's ViT as encoder (patches + 2 embed tokens (+ class token) -> the embed tokens)
+    and as decoder (1 latent token + learned patch tokens -> image), configured like tests/test_conditional_vit_vae.py:
+    41-67 with dropout 0 and deterministic closed-form weights: outputs, input gradient, every parameter gradient."""
+    vit = R.ref("networks.vit")
+    out = {}
+    for tag, cfg, B in VIT_CASES:
+        enc = vit.ViT(n_embed_tokens=2, n_input_tokens=None, output_tokens="embed", patch_to_embed=True, embed_to_patch=False,
+                      **cfg)
+        dec = vit.ViT(n_embed_tokens=None, n_input_tokens=1, output_tokens="embed", patch_to_embed=False, embed_to_patch=True,
+                      **cfg)
+        labels = torch.arange(B) % 10 if cfg["num_classes"] else None
+        nets = [(enc, "enc", det_input((B, cfg["channels"], cfg["image_size"], cfg["image_size"]), 0.3)),
+                (dec, "dec", det_input((B, 1, cfg["dim"]), 0.8))]
+        for net, nm, xin in nets:
+            net.train()
+            fill_vit_state_dict(net.state_dict())
+            x = xin.clone().requires_grad_(True)
+            y = net(x, labels=labels)
+            g = det_input(tuple(y.shape), 1.1, 0.5)
+            y.backward(g)
+            out[f"{tag}/{nm}/x"], out[f"{tag}/{nm}/y"], out[f"{tag}/{nm}/gy"], out[f"{tag}/{nm}/gx"] = npy(x), npy(y), npy(g), npy(x.grad)
+            for k, p in net.named_parameters():
+                if p.numel() <= 4096:
+                    out[f"{tag}/{nm}/grad/{k}"] = npy(p.grad)
+                else:  # large matrices: checksums (sum, L2, the first 16 entries) keep the fixture small
+                    gd = p.grad.double().flatten()
+                    out[f"{tag}/{nm}/gradsum/{k}"] = np.concatenate([[gd.sum().item(), gd.norm().item()], gd[:16].numpy()])
+        if labels is not None:
+            out[f"{tag}/labels"] = npy(labels)
+    save("vit.npz", out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm"]
+                             "codebook_kmeans", "discrete", "gmm", "vit"]
     for w in which:
         globals()["gen_" + w]()

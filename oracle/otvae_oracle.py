@@ -584,3 +584,52 @@ def gmm_transport_apply(x: Tensor, src: Dict[str, Tensor], tgt: Dict[str, Tensor
     mt, vt = b @ tgt["mean"], b @ tgt["cov"]
     T = torch.sqrt(vt / vs + STABILITY_CONST)
     return (T * (xs - ms) + mt).type_as(x)
+
+
+# ------------------------------------------------------------------------------------------------ ViT
+def transformer_encoder_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int) -> Tensor:
+    """One post-norm ``nn.TransformerEncoderLayer(dim, heads, mlp_dim, dropout=0, batch_first=True)`` as the reference's ViT
+    builds them (networks/vit.py:169-172): x = LN1(x + out_proj(MHA(x))); x = LN2(x + linear2(relu(linear1(x)))), with
+    ``nn.MultiheadAttention``'s packed in-projection (q | k | v, head-major channels) and 1/sqrt(head width) scores."""
+    n, t, d = x.shape
+    hd = d // heads
+    qkv = F.linear(x, p[prefix + "self_attn.in_proj_weight"], p[prefix + "self_attn.in_proj_bias"])
+    q, k, v = (z.reshape(n, t, heads, hd).transpose(1, 2) for z in qkv.chunk(3, dim=-1))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ v
+    sa = F.linear(att.transpose(1, 2).reshape(n, t, d), p[prefix + "self_attn.out_proj.weight"], p[prefix + "self_attn.out_proj.bias"])
+    x = F.layer_norm(x + sa, (d,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], 1e-5)
+    ff = F.linear(torch.relu(F.linear(x, p[prefix + "linear1.weight"], p[prefix + "linear1.bias"])),
+                  p[prefix + "linear2.weight"], p[prefix + "linear2.bias"])
+    return F.layer_norm(x + ff, (d,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], 1e-5)
+
+
+def vit_forward(x: Tensor, p: Dict[str, Tensor], *, image_size: int, patch_size: int, dim: int, depth: int, heads: int,
+                channels: int, n_embed_tokens: Optional[int], n_input_tokens: Optional[int], patch_to_embed: bool,
+                embed_to_patch: bool, labels: Optional[Tensor] = None) -> Tensor:
+    """``ViT.forward`` (networks/vit.py:225-246) for output_tokens='embed', no time token, no causal mask, dropout 0:
+    [patchify + Linear] -> append the learned embed tokens (and the class token) -> + positions, LayerNorm
+    (PositionalEmbedding :41-58) -> the encoder layers -> the embed tokens -> [Linear + un-patchify]."""
+    ps = patch_size
+    nh = image_size // ps
+    num_patches = nh * nh
+    if patch_to_embed:
+        b, c = x.shape[:2]
+        x = x.reshape(b, c, nh, ps, nh, ps).permute(0, 2, 4, 3, 5, 1).reshape(b, num_patches, ps * ps * c)
+        x = F.linear(x, p["patch_to_embed.1.weight"], p["patch_to_embed.1.bias"])
+    n_in = num_patches if n_input_tokens is None else n_input_tokens
+    n_emb = num_patches if n_embed_tokens is None else n_embed_tokens
+    if n_emb > 0:
+        x = torch.cat((x, p["embed_token"].expand(x.size(0), -1, -1)), dim=1)
+    if labels is not None:
+        x = torch.cat((x, p["class_token.weight"][labels].unsqueeze(1)), dim=1)
+    x = x + p["positional_embed.position_embeddings.weight"][:x.size(1)].unsqueeze(0)
+    x = F.layer_norm(x, (dim,), p["positional_embed.LayerNorm.weight"], p["positional_embed.LayerNorm.bias"], 1e-5)
+    for i in range(depth):
+        x = transformer_encoder_layer(x, p, f"transformer.layers.{i}.", heads)
+    out = x[:, n_in:n_in + n_emb]
+    if embed_to_patch:
+        out = out[:, -num_patches:]
+        out = F.linear(out, p["embed_to_patch.0.weight"], p["embed_to_patch.0.bias"])
+        b = out.size(0)
+        out = out.reshape(b, nh, nh, ps, ps, channels).permute(0, 5, 1, 3, 2, 4).reshape(b, channels, nh * ps, nh * ps)
+    return out

@@ -63,6 +63,11 @@ SIGNATURES = {
     "otvae_conv_multi": (i32, [i32, pj, vp]),
     "otvae_attn_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "otvae_attn_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "otvae_attn_fwd_scaled": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "otvae_attn_bwd_scaled": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]),
+    "otvae_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]),
+    "otvae_layernorm_bwd_ws": (i32, [i32, i32]),
+    "otvae_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "otvae_gaussian_prior_fwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),
     "otvae_gaussian_prior_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     "otvae_nelbo_ws": (i32, []),

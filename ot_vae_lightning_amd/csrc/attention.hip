@@ -102,7 +102,7 @@ struct FwdRec {
 template <int C, int QPT, bool AUX>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int N, int T, int H, int SPB,
                                                        float* __restrict__ out, float* __restrict__ lse,
-                                                       float* __restrict__ aux) {
+                                                       float* __restrict__ aux, float qk_scale) {
     extern __shared__ __align__(16) float sm[];
     constexpr int KVS = FwdRec<C, AUX>::KV;
     const int HC = H * C, W3 = 3 * HC;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         h = hs - dn * H;
     }
     // scores are kept in the log2 domain (q pre-multiplied by log2(e)/C) so that exp is a bare v_exp_f32
-    const float inv_c = LOG2E / (float)C;
+    const float inv_c = LOG2E * qk_scale;  // qk_scale = 1/C for the CNN's QKVAttention, 1/sqrt(C) for nn.MultiheadAttention
     float* kv = sm + (size_t)(active ? sl : 0) * T * KVS;
 
     constexpr int NA = AUX ? C * C + C : 1;
@@ -301,7 +301,7 @@ template <int C, int QPT, bool AUX>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                        const float* __restrict__ lse_g, const float* __restrict__ gout,
                                                        const float* __restrict__ aux, int N, int T, int H, int SPB,
-                                                       float* __restrict__ gqkv) {
+                                                       float* __restrict__ gqkv, float qk_scale) {
     extern __shared__ __align__(16) float sm[];
     constexpr int RKV = Rec<C>::KV, RQG = Rec<C>::QG;
     const int HC = H * C, W3 = 3 * HC;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const int nsl = (int)min((long)SPB, total - slice0);
     float* s_kv = sm;
     float* s_qg = sm + (size_t)SPB * T * RKV;
-    const float inv_c = 1.f / (float)C;
+    const float inv_c = qk_scale;
     stage_kv<C>(s_kv, qkv, slice0, nsl, T, H);
     // query records {q/C, gout, lse, delta = sum_c gout*out}
     const float inv_t = 1.0f / (float)T, inv_hq = 1.0f / (float)H;
@@ -585,8 +585,17 @@ static int attn_check(const char* who, int N, int T, int H, int C, int floats_pe
     return OTVAE_OK;
 }
 
+extern "C" int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int C, float scale, float* out, float* lse, float* aux,
+                                     void* stream);
 extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, float* out, float* lse, float* aux, void* stream) {
+    OTVAE_REQUIRE(C > 0, "otvae_attn_fwd: bad sizes");
+    return otvae_attn_fwd_scaled(qkv, N, T, H, C, 1.f / (float)C, out, lse, aux, stream);
+}
+
+extern "C" int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int C, float scale, float* out, float* lse, float* aux,
+                                     void* stream) {
     OTVAE_REQUIRE(qkv && out && lse, "otvae_attn_fwd: NULL tensor");
+    OTVAE_REQUIRE(scale > 0.f, "otvae_attn_fwd: scale must be positive");
     int qpt, spb;
     if (C > 2) aux = nullptr;
     const int rkv = aux ? ((2 * C + C * C + 3) & ~3) : 2 * C;  // FwdRec<C, AUX>::KV
@@ -599,15 +608,15 @@ extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, floa
     do {                                                                                            \
         if (qpt == 4) {                                                                             \
             if constexpr (CC <= 2) {                                                                \
-                if (aux) attn_fwd_kernel<CC, 4, true><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, aux); \
-                else attn_fwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr); \
-            } else if constexpr (CC <= 4) attn_fwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr); \
+                if (aux) attn_fwd_kernel<CC, 4, true><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, aux, scale); \
+                else attn_fwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
+            } else if constexpr (CC <= 4) attn_fwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
             else { otvae_set_error("otvae_attn_fwd: T >= 256 with head width %d > 4 unsupported", CC); return OTVAE_EUNSUPPORTED; } \
         } else {                                                                                    \
             if constexpr (CC <= 2) {                                                                \
-                if (aux) attn_fwd_kernel<CC, 1, true><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, aux); \
-                else attn_fwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr); \
-            } else attn_fwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr); \
+                if (aux) attn_fwd_kernel<CC, 1, true><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, aux, scale); \
+                else attn_fwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
+            } else attn_fwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
         }                                                                                           \
     } while (0)
     ATTN_C_SWITCH(C, FWD_K)
@@ -616,9 +625,18 @@ extern "C" int otvae_attn_fwd(const float* qkv, int N, int T, int H, int C, floa
     return OTVAE_OK;
 }
 
+extern "C" int otvae_attn_bwd_scaled(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux, int N,
+                                     int T, int H, int C, float scale, float* gqkv, void* stream);
 extern "C" int otvae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux, int N,
                               int T, int H, int C, float* gqkv, void* stream) {
+    OTVAE_REQUIRE(C > 0, "otvae_attn_bwd: bad sizes");
+    return otvae_attn_bwd_scaled(qkv, out, lse, gout, aux, N, T, H, C, 1.f / (float)C, gqkv, stream);
+}
+
+extern "C" int otvae_attn_bwd_scaled(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux, int N,
+                                     int T, int H, int C, float scale, float* gqkv, void* stream) {
     OTVAE_REQUIRE(qkv && out && lse && gout && gqkv, "otvae_attn_bwd: NULL tensor");
+    OTVAE_REQUIRE(scale > 0.f, "otvae_attn_bwd: scale must be positive");
     int qpt, spb;
     const int rqg = (2 * C + 2 + 3) & ~3;
     int rc = attn_check("otvae_attn_bwd", N, T, H, C, 2 * C + rqg, &qpt, &spb);
@@ -630,15 +648,15 @@ extern "C" int otvae_attn_bwd(const float* qkv, const float* out, const float* l
     do {                                                                                            \
         if (qpt == 4) {                                                                             \
             if constexpr (CC <= 2) {                                                                \
-                if (aux) attn_bwd_kernel<CC, 4, true><<<grid, 256, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv); \
-                else attn_bwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv); \
-            } else if constexpr (CC <= 4) attn_bwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv); \
+                if (aux) attn_bwd_kernel<CC, 4, true><<<grid, 256, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv, scale); \
+                else attn_bwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
+            } else if constexpr (CC <= 4) attn_bwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
             else { otvae_set_error("otvae_attn_bwd: T >= 256 with head width %d > 4 unsupported", CC); return OTVAE_EUNSUPPORTED; } \
         } else {                                                                                    \
             if constexpr (CC <= 2) {                                                                \
-                if (aux) attn_bwd_kernel<CC, 1, true><<<grid, 256, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv); \
-                else attn_bwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv); \
-            } else attn_bwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv); \
+                if (aux) attn_bwd_kernel<CC, 1, true><<<grid, 256, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv, scale); \
+                else attn_bwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
+            } else attn_bwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
         }                                                                                           \
     } while (0)
     ATTN_C_SWITCH(C, BWD_K)

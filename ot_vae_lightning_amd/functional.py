@@ -9,6 +9,7 @@ Nothing here computes on the CPU: tensors must be on the GPU and the HIP library
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -400,7 +401,7 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
 # ------------------------------------------------------------------------------------------------ attention
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, heads):
+    def forward(ctx, qkv, heads, scale=None):
         lib = _lib.load()
         n, width, h, w = qkv.shape
         t = h * w
@@ -414,9 +415,10 @@ class _AttentionFn(torch.autograd.Function):
         aux = None
         if c <= 2 and ctx.needs_input_grad[0]:
             aux = torch.empty((n, heads, t, c * c), device=qkv.device, dtype=torch.float32)
-        check(lib.otvae_attn_fwd(ptr(qkv), n, t, heads, c, ptr(out), ptr(lse), ptr(aux), stream()), "otvae_attn_fwd")
+        scale = 1.0 / c if scale is None else float(scale)  # 1/C = the two C^-1/2 factors of QKVAttention
+        check(lib.otvae_attn_fwd_scaled(ptr(qkv), n, t, heads, c, scale, ptr(out), ptr(lse), ptr(aux), stream()), "otvae_attn_fwd")
         ctx.save_for_backward(qkv, out, lse, aux) if aux is not None else ctx.save_for_backward(qkv, out, lse)
-        ctx.dims = (n, t, heads, c)
+        ctx.dims = (n, t, heads, c, scale)
         return out
 
     @staticmethod
@@ -425,12 +427,12 @@ class _AttentionFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         qkv, out, lse = saved[:3]
         aux = saved[3] if len(saved) > 3 else None
-        n, t, heads, c = ctx.dims
+        n, t, heads, c, scale = ctx.dims
         gout = as_nhwc(gout)
         gqkv = torch.empty_strided(qkv.shape, qkv.stride(), device=qkv.device, dtype=qkv.dtype)
-        check(lib.otvae_attn_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(gout), ptr(aux), n, t, heads, c, ptr(gqkv), stream()),
-              "otvae_attn_bwd")
-        return gqkv, None
+        check(lib.otvae_attn_bwd_scaled(ptr(qkv), ptr(out), ptr(lse), ptr(gout), ptr(aux), n, t, heads, c, scale, ptr(gqkv),
+                                        stream()), "otvae_attn_bwd")
+        return gqkv, None, None
 
 
 def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:
@@ -440,11 +442,90 @@ def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:
     if qkv.dim() == 3:
         n, width, t = qkv.shape
         q4 = as_nhwc(qkv.unsqueeze(-1))
-        return _AttentionFn.apply(q4, n_heads).squeeze(-1)
-    return _AttentionFn.apply(as_nhwc(qkv), n_heads)
+        return _AttentionFn.apply(q4, n_heads, None).squeeze(-1)
+    return _AttentionFn.apply(as_nhwc(qkv), n_heads, None)
 
 
 # ------------------------------------------------------------------------------------------------ prior / loss
+# ------------------------------------------------------------------------------------------------ token streams (ViT)
+def tokens_as_nhwc(x: Tensor) -> Tensor:
+    """[N, T, D] contiguous tokens seen as the logical [N, D, T, 1] image the convolution kernels take (same memory)."""
+    return x.contiguous().permute(0, 2, 1).unsqueeze(-1)
+
+
+def nhwc_as_tokens(y: Tensor) -> Tensor:
+    """inverse of ``tokens_as_nhwc`` for a kernel output: logical [N, D, T, 1] on NHWC memory -> [N, T, D] (a view)"""
+    return as_nhwc(y).squeeze(-1).permute(0, 2, 1)
+
+
+def linear_tokens(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu_input: bool = False) -> Tensor:
+    """``F.linear(relu(x) if relu_input else x, weight, bias)`` on [N, T, D_in] tokens through the 1x1 convolution kernels
+    (the reference's ViT: patch embedding, the MultiheadAttention projections and the feed-forward pair of every
+    nn.TransformerEncoderLayer, networks/vit.py:157-172).  ``weight`` is the logical [D_out, D_in] matrix; kept on
+    [D_in][D_out] memory (``new_linear_weight``) it is consumed without a copy."""
+    w4 = weight.unsqueeze(-1).unsqueeze(-1)
+    y = conv_layers(tokens_as_nhwc(x), [dict(weight=w4, bias=bias, stride=1, pad=0, up=1, relu=relu_input)],
+                    training=torch.is_grad_enabled())[0]
+    return nhwc_as_tokens(y)
+
+
+def new_linear_weight(d_out: int, d_in: int, device=None) -> Tensor:
+    """logical [d_out, d_in] on [d_in][d_out] memory = the HWIO layout of a 1x1 convolution"""
+    return torch.empty((d_in, d_out), device=device, dtype=torch.float32).t()
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        lib = _lib.load()
+        d = x.shape[-1]
+        m = x.numel() // d
+        x2 = x.reshape(m, d).contiguous()
+        r2 = res.reshape(m, d).contiguous() if res is not None else None
+        y = torch.empty_like(x2)
+        s = torch.empty_like(x2) if r2 is not None else None
+        mean = torch.empty(m, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(m, device=x.device, dtype=torch.float32)
+        check(lib.otvae_layernorm_fwd(ptr(x2), ptr(r2), ptr(gamma), ptr(beta), m, d, float(eps), ptr(s), ptr(y), ptr(mean),
+                                      ptr(rstd), stream()), "otvae_layernorm_fwd")
+        ctx.save_for_backward(s if s is not None else x2, gamma, mean, rstd)
+        ctx.has_res = res is not None
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xs, gamma, mean, rstd = ctx.saved_tensors
+        m, d = xs.shape
+        g2 = gy.reshape(m, d).contiguous()
+        gx = torch.empty_like(xs)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(lib.otvae_layernorm_bwd_ws(m, d), device=xs.device, dtype=torch.float32)
+        check(lib.otvae_layernorm_bwd(ptr(xs), ptr(g2), ptr(gamma), ptr(mean), ptr(rstd), m, d, ptr(gx), ptr(dgamma), ptr(dbeta),
+                                      ptr(ws), stream()), "otvae_layernorm_bwd")
+        gx = gx.reshape(gy.shape)
+        return gx, (gx if ctx.has_res else None), dgamma, dbeta, None
+
+
+def layer_norm_tokens(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, residual: Optional[Tensor] = None) -> Tensor:
+    """LayerNorm over the last dimension of ``x (+ residual)`` (torch.nn.functional.layer_norm arithmetic)."""
+    _lib.require_cuda(x, "layer_norm input")
+    if x.dtype != torch.float32:
+        raise TypeError("the MI355X LayerNorm computes in fp32")
+    if residual is not None and residual.shape != x.shape:
+        raise ValueError("`residual` must have the shape of `x`")
+    return _LayerNormFn.apply(x, residual, gamma, beta, eps)
+
+
+def mha_attention_tokens(qkv: Tensor, n_heads: int) -> Tensor:
+    """softmax(q k^T / sqrt(C)) v per head on in-projected tokens [N, T, 3*H*C] (q | k | v, head-major: the layout of
+    nn.MultiheadAttention's in_proj) -> [N, T, H*C]; the fused attention kernels with the 1/sqrt(C) score scale."""
+    _lib.require_cuda(qkv, "qkv")
+    c = qkv.shape[-1] // (3 * n_heads)
+    out = _AttentionFn.apply(tokens_as_nhwc(qkv), n_heads, 1.0 / math.sqrt(c))
+    return nhwc_as_tokens(out)
+
+
 class _GaussianPriorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, eps, coeff):

@@ -1,0 +1,256 @@
+"""``ViT`` / ``PositionalEmbedding`` with the reference's constructor, token bookkeeping and ``state_dict`` keys
+(networks/vit.py:33-248), running on the MI355X kernels: every Linear (patch embedding, attention projections,
+feed-forward pairs, patch read-out) goes through the 1x1 convolution kernels (bias, the feed-forward ReLU fused as the
+next layer's input activation), every LayerNorm through ``otvae_layernorm_*`` with the block's residual sum folded in,
+and the attention through the fused QKV kernels with the 1/sqrt(head width) scale of ``nn.MultiheadAttention``.
+
+The transformer is the reference's ``nn.TransformerEncoder`` of post-norm ``nn.TransformerEncoderLayer``s (ReLU,
+``batch_first``): x = norm1(x + out_proj(attn(in_proj(x)))); x = norm2(x + linear2(relu(linear1(x)))).  Parameters are
+drawn by constructing the very torch modules the reference constructs, in its order, so a seeded construction gives the
+reference's initial weights (note that ``nn.TransformerEncoder`` deep-copies ONE layer: all layers start identical).
+
+Not implemented (they raise): the cross-attention variant (``preprocess_depth``), ``causal_mask``, ``time_dependant``.
+Dropout > 0 in training mode is applied with ``torch.nn.functional.dropout`` between the kernels (its random stream
+differs from the CPU's anyway); parity tests run with dropout 0 or in eval mode."""
+import warnings
+from typing import Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import functional as HF
+
+__all__ = ["PositionalEmbedding", "ViT", "TokenLinear", "TokenLayerNorm", "TokenEncoderLayer"]
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+def _adopt(weight: Tensor) -> nn.Parameter:
+    """a torch-initialised [out, in] Linear weight moved onto [in][out] memory (what the 1x1 kernels read directly)"""
+    w = HF.new_linear_weight(weight.shape[0], weight.shape[1])
+    with torch.no_grad():
+        w.copy_(weight)
+    return nn.Parameter(w)
+
+
+class TokenLinear(nn.Module):
+    """``nn.Linear`` on [N, T, D_in] tokens (keys ``weight``, ``bias``)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, like: Optional[nn.Linear] = None):
+        super().__init__()
+        like = like if like is not None else nn.Linear(in_features, out_features, bias=bias)
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = _adopt(like.weight.data)
+        self.bias = nn.Parameter(like.bias.data.clone()) if like.bias is not None else None
+
+    def forward(self, x: Tensor, relu_input: bool = False) -> Tensor:
+        return HF.linear_tokens(x, self.weight, self.bias, relu_input=relu_input)
+
+
+class TokenLayerNorm(nn.Module):
+    """``nn.LayerNorm(dim)`` (keys ``weight``, ``bias``) with an optional residual summed in before normalising."""
+
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.weight, self.bias, self.eps = nn.Parameter(torch.ones(dim)), nn.Parameter(torch.zeros(dim)), eps
+
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+        return HF.layer_norm_tokens(x, self.weight, self.bias, self.eps, residual)
+
+
+class _SelfAttention(nn.Module):
+    """parameter holder with ``nn.MultiheadAttention``'s names: in_proj_weight / in_proj_bias / out_proj.{weight,bias}"""
+
+    def __init__(self, like: nn.MultiheadAttention):
+        super().__init__()
+        self.embed_dim, self.num_heads = like.embed_dim, like.num_heads
+        self.in_proj_weight = _adopt(like.in_proj_weight.data)
+        self.in_proj_bias = nn.Parameter(like.in_proj_bias.data.clone())
+        self.out_proj = TokenLinear(like.embed_dim, like.embed_dim, like=like.out_proj)
+
+    def forward(self, x: Tensor) -> Tensor:
+        qkv = HF.linear_tokens(x, self.in_proj_weight, self.in_proj_bias)
+        return self.out_proj(HF.mha_attention_tokens(qkv, self.num_heads))
+
+
+class TokenEncoderLayer(nn.Module):
+    """post-norm ``nn.TransformerEncoderLayer(dim, heads, mlp_dim, dropout, batch_first=True)`` (ReLU feed-forward)"""
+
+    def __init__(self, like: nn.TransformerEncoderLayer):
+        super().__init__()
+        if getattr(like, "norm_first", False):
+            raise NotImplementedError("norm_first transformer layers are not implemented on the MI355X path")
+        self.self_attn = _SelfAttention(like.self_attn)
+        self.linear1 = TokenLinear(like.linear1.in_features, like.linear1.out_features, like=like.linear1)
+        self.linear2 = TokenLinear(like.linear2.in_features, like.linear2.out_features, like=like.linear2)
+        self.norm1 = TokenLayerNorm(like.norm1.normalized_shape[0], like.norm1.eps)
+        self.norm2 = TokenLayerNorm(like.norm2.normalized_shape[0], like.norm2.eps)
+        self.p = float(like.dropout.p)
+
+    def _drop(self, x: Tensor) -> Tensor:
+        return F.dropout(x, self.p, True) if (self.training and self.p > 0) else x
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = self.norm1(self._drop(self.self_attn(x)), residual=x)
+        h = self.linear1(x)
+        if self.training and self.p > 0:  # dropout sits between the ReLU and linear2: the activation cannot stay fused
+            f = self.linear2(self._drop(torch.relu(h)))
+        else:
+            f = self.linear2(h, relu_input=True)
+        return self.norm2(self._drop(f), residual=x)
+
+
+class _Encoder(nn.Module):
+    """``nn.TransformerEncoder``: keys ``layers.{i}.*``"""
+
+    def __init__(self, like: nn.TransformerEncoder):
+        super().__init__()
+        self.layers = nn.ModuleList([TokenEncoderLayer(layer) for layer in like.layers])
+        if like.norm is not None:
+            raise NotImplementedError("a final norm on the TransformerEncoder is not part of the reference's ViT")
+
+    def forward(self, x: Tensor) -> Tensor:
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class PositionalEmbedding(nn.Module):
+    """learned positions added to the tokens, then LayerNorm (+ dropout): reference networks/vit.py:33-58"""
+
+    def __init__(self, max_length: int, d_model: int, dropout: float, batch_first: bool, device=None, dtype=None):
+        super().__init__()
+        self.d_model, self.batch_first = d_model, batch_first
+        self.position_embeddings = nn.Embedding(max_length, d_model, device=device, dtype=dtype)
+        self.LayerNorm = TokenLayerNorm(d_model)
+        self.p = float(dropout)
+
+    def forward(self, input: Tensor) -> Tensor:
+        if input.size(-1) != self.d_model:
+            raise RuntimeError("the feature number of `input` must be equal to d_model")
+        batched = input.dim() == 3
+        seq_dim = int(batched and self.batch_first)
+        pos = self.position_embeddings.weight[:input.shape[seq_dim]]
+        if batched:
+            pos = pos.unsqueeze(int(not self.batch_first))
+        out = self.LayerNorm(input, residual=pos.expand_as(input))
+        return F.dropout(out, self.p, True) if (self.training and self.p > 0) else out
+
+
+class _Patchify(nn.Module):
+    """'b c (h p1) (w p2) -> b (h w) (p1 p2 c)'"""
+
+    def __init__(self, p1: int, p2: int):
+        super().__init__()
+        self.p1, self.p2 = p1, p2
+
+    def forward(self, x: Tensor) -> Tensor:
+        b, c, hh, ww = x.shape
+        h, w = hh // self.p1, ww // self.p2
+        return x.reshape(b, c, h, self.p1, w, self.p2).permute(0, 2, 4, 3, 5, 1).reshape(b, h * w, self.p1 * self.p2 * c)
+
+
+class _Unpatchify(nn.Module):
+    """'b (h w) (p1 p2 c) -> b c (h p1) (w p2)'"""
+
+    def __init__(self, h: int, p1: int, p2: int):
+        super().__init__()
+        self.h, self.p1, self.p2 = h, p1, p2
+
+    def forward(self, x: Tensor) -> Tensor:
+        b, n, d = x.shape
+        h, w = self.h, n // self.h
+        c = d // (self.p1 * self.p2)
+        return x.reshape(b, h, w, self.p1, self.p2, c).permute(0, 5, 1, 3, 2, 4).reshape(b, c, h * self.p1, w * self.p2)
+
+
+class ViT(nn.Module):
+    def __init__(self, image_size: Union[int, Tuple[int, int]], dim: int, patch_size: Optional[Union[int, Tuple[int, int]]] = None,
+                 depth: int = 6, preprocess_depth: Optional[int] = None, heads: int = 8, mlp_dim: Optional[int] = None,
+                 channels: int = 3, dropout: float = 0.1, emb_dropout: float = 0., n_embed_tokens: Optional[Union[int, str]] = 1,
+                 n_input_tokens: Optional[Union[int, str]] = None, output_tokens: Union[str, Sequence[str]] = "embed",
+                 patch_to_embed: bool = True, embed_to_patch: bool = False, num_classes: Optional[int] = None,
+                 time_dependant: bool = False, causal_mask: bool = False):
+        super().__init__()
+        if preprocess_depth is not None:
+            raise NotImplementedError("the cross-attention ViT (`preprocess_depth`) is not implemented on the MI355X path")
+        if causal_mask:
+            raise NotImplementedError("`causal_mask` is not implemented on the MI355X path")
+        if time_dependant:
+            raise NotImplementedError("`time_dependant` (Fourier time token) is not implemented on the MI355X path")
+        self.dim, self.causal_mask = dim, causal_mask
+        image_height, image_width = pair(image_size)
+        mlp_dim = mlp_dim or dim * 4
+        if patch_size is None:
+            patch_size = min(image_height // 4, 16), min(image_width // 4, 16)
+        patch_height, patch_width = pair(patch_size)
+        if image_height % patch_height or image_width % patch_width:
+            raise ValueError("Image dimensions must be divisible by the patch size.")
+        n_patch_h, n_patch_w = image_height // patch_height, image_width // patch_width
+        self.num_patches, self.patch_dim = n_patch_h * n_patch_w, channels * patch_height * patch_width
+        self.n_tokens = {"input": self.num_patches if n_input_tokens is None else n_input_tokens,
+                         "embed": self.num_patches if n_embed_tokens is None else n_embed_tokens,
+                         "class": int(num_classes is not None), "time": 0}
+        self.total_num_tokens = sum(self.n_tokens.values())
+        self.token_indices, at = {}, 0
+        for kind, count in self.n_tokens.items():
+            self.token_indices[kind] = list(range(at, at + count))
+            at += count
+        output_tokens = [output_tokens] if isinstance(output_tokens, str) else list(output_tokens)
+        if not all(kind in self.token_indices for kind in output_tokens):
+            raise ValueError(f"`output_tokens` must contain only keys within {self.token_indices.keys()}")
+        self.output_tokens_indices, self.cross_tokens_indices = [], []
+        for kind, idx in self.token_indices.items():
+            (self.output_tokens_indices if kind in output_tokens else self.cross_tokens_indices).extend(idx)
+
+        # the reference's construction order (= its random-number consumption order): patch_to_embed, embed_to_patch,
+        # embed_token, class_token, positional_embed, transformer
+        self.patch_to_embed = nn.Sequential(_Patchify(patch_height, patch_width), TokenLinear(self.patch_dim, dim)) \
+            if patch_to_embed else nn.Identity()
+        self.embed_to_patch = nn.Sequential(TokenLinear(dim, self.patch_dim), _Unpatchify(n_patch_h, patch_height, patch_width)) \
+            if embed_to_patch else nn.Identity()
+        self.embed_token = nn.Parameter(torch.randn(1, self.n_tokens["embed"], dim)) if self.n_tokens["embed"] > 0 else None
+        self.class_token = nn.Embedding(num_classes, dim) if self.n_tokens["class"] > 0 else None
+        self.time_token = None
+        self.positional_embed = PositionalEmbedding(self.total_num_tokens, dim, emb_dropout, True)
+        self.prepocess = None
+        self.transformer = _Encoder(nn.TransformerEncoder(
+            encoder_layer=nn.TransformerEncoderLayer(dim, heads, mlp_dim, dropout, batch_first=True), num_layers=depth,
+            enable_nested_tensor=False))
+        self.out_size = torch.Size([channels, image_height, image_width]) if embed_to_patch else \
+            torch.Size([len(self.output_tokens_indices), dim])
+
+    def _add_class_token(self, x: Tensor, labels: Optional[Tensor]) -> Tensor:
+        if labels is not None and self.class_token is None:
+            warnings.warn("given conditional argument `labels` but `self.class_token` is None. To enable a class-conditioned "
+                          "ViT, use `ViT(num_classes=...)`.")
+        if self.class_token is not None:
+            if labels is None:
+                raise ValueError("`num_classes` specified but `labels` is None. Can't infer the class token.")
+            x = torch.cat((x, self.class_token(labels).unsqueeze(1)), dim=1)
+        return x
+
+    def _add_time_token(self, x: Tensor, time: Optional[Tensor]) -> Tensor:
+        if time is not None:
+            warnings.warn("given conditional argument `time` but `self.time_token` is None.")
+        return x
+
+    def _add_embed_token(self, x: Tensor) -> Tensor:
+        if self.embed_token is not None:
+            x = torch.cat((x, self.embed_token.expand(x.size(0), -1, -1)), dim=1)
+        return x
+
+    def forward(self, x: Tensor, labels: Optional[Tensor] = None, time: Optional[Tensor] = None) -> Tensor:
+        x = self.patch_to_embed(x)
+        x = self._add_embed_token(x)
+        x = self._add_class_token(x, labels)
+        x = self._add_time_token(x, time)
+        x = self.positional_embed(x)
+        out = self.transformer(x)[:, self.output_tokens_indices]
+        if not isinstance(self.embed_to_patch, nn.Identity):
+            out = out[:, -self.num_patches:]
+        return self.embed_to_patch(out)

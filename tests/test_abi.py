@@ -27,6 +27,37 @@ def test_header_matches_python_binding():
     assert _header_functions() == set(_lib.SIGNATURES)
 
 
+def _header_prototypes():
+    """name -> list of parameter declarations, parsed from include/otvae.h"""
+    src = open(os.path.join(ROOT, "include", "otvae.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(otvae_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        params = [p.strip() for p in m.group(2).replace("\n", " ").split(",")]
+        protos[m.group(1)] = [] if params in ([""], ["void"]) else params
+    return protos
+
+
+def test_python_binding_matches_header_prototypes():
+    """Arity and the pointer / integer / float class of every parameter: a mismatch here is a host-side segfault (or a
+    silently shifted argument list) at the first call."""
+    import ctypes as C
+    from ot_vae_lightning_amd import _lib
+    protos = _header_prototypes()
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        params = protos[name]
+        assert len(params) == len(argtypes), f"{name}: header has {len(params)} parameters, the binding {len(argtypes)}"
+        for i, (decl, at) in enumerate(zip(params, argtypes)):
+            is_ptr = "*" in decl
+            at_ptr = at in (C.c_void_p, C.c_char_p) or hasattr(at, "contents") or getattr(at, "_type_", None) == "P"
+            assert is_ptr == bool(at_ptr), f"{name} parameter {i} ({decl!r}): pointer-ness differs from {at}"
+            if not is_ptr:
+                is_float = re.match(r"(const\s+)?(float|double)\b", decl) is not None
+                assert is_float == (at in (C.c_float, C.c_double)), f"{name} parameter {i} ({decl!r}) vs {at}"
+                if is_float:
+                    assert (decl.split()[-2] == "double") == (at is C.c_double), f"{name} parameter {i} ({decl!r}) vs {at}"
+
+
 def test_library_exports_every_declared_symbol(lib_path):
     lib = ctypes.CDLL(lib_path)
     for name in sorted(_header_functions()):

@@ -902,3 +902,36 @@ def test_gmm_transport_vs_reference_golden(A):
     with pytest.raises(NotImplementedError):
         A.GMMTransport(d, transport_type="argmax", transport_cfg={**_GMM_W2, "diag": False}, source_cfg=cfg, target_cfg=cfg)
     rep.finish()
+
+
+# ------------------------------------------------------------------------------------------------ G12 ViT
+@pytest.mark.parametrize("tag", ["d32", "d128"])
+@pytest.mark.parametrize("role", ["enc", "dec"])
+def test_vit_vs_reference_golden(A, tag, role):
+    """The reference's ViT (networks/vit.py) as encoder and as decoder, configured like tests/test_conditional_vit_vae.py:
+    41-67 with dropout 0: same constructor arguments, the reference's state_dict keys filled with the closed-form weights,
+    forward output, input gradient and every parameter gradient against the golden vectors.  d32: head width 8, 22
+    tokens, class token; d128: head width 32 (the attention kernel's widest instantiation), 18 tokens."""
+    from detfill import fill_vit_state_dict
+    from test_oracle_vs_golden import VIT_CASES, VIT_ROLES, check_vit_grads, vit_param_shapes
+    g = load_golden("vit.npz")
+    g = {k[len(tag) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "/")}
+    rep = Report(f"ViT {tag} {role} vs reference golden")
+    cfg = VIT_CASES[tag]
+    net = A.ViT(output_tokens="embed", dropout=0.0, emb_dropout=0., **cfg, **VIT_ROLES[role])
+    want = vit_param_shapes(cfg, role)
+    sd = net.state_dict()
+    assert set(sd.keys()) == set(want.keys()) and all(tuple(sd[k].shape) == tuple(s) for k, s in want.items())
+    ordered = {k: torch.zeros(s) for k, s in want.items()}          # the reference's key order decides the fill phases
+    fill_vit_state_dict(ordered)
+    net.load_state_dict(ordered)
+    net = net.cuda().train()
+    x = g[f"{role}/x"].cuda().requires_grad_(True)
+    labels = g["labels"].cuda() if "labels" in g else None
+    y = net(x, labels=labels)
+    y.backward(g[f"{role}/gy"].cuda())
+    rep.check("output", y, g[f"{role}/y"], 1e-5)
+    rep.check("input gradient", x.grad, g[f"{role}/gx"], 1e-4)
+    rep.finish()
+    check_vit_grads(g, role, {k: p.grad for k, p in net.named_parameters()}, 5e-4)  # column sums with cancellation
+    assert tuple(net.out_size) == tuple(y.shape[1:])

@@ -432,3 +432,77 @@ def test_gmm_transport_compute_and_transport():
     assert rel_err(coupling, g["coupling"]) < 1e-9 and rel_err(total, g["total"]) < 1e-9
     moved = O.gmm_transport_apply(g["probe"], fitted["source"], fitted["target"], g["coupling"])
     assert rel_err(moved, g["moved"]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ G12 ViT
+VIT_CASES = {
+    "d32": dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, num_classes=10),
+    "d128": dict(image_size=32, patch_size=8, dim=128, depth=1, heads=4, mlp_dim=256, channels=3, num_classes=None),
+}
+VIT_ROLES = {"enc": dict(n_embed_tokens=2, n_input_tokens=None, patch_to_embed=True, embed_to_patch=False),
+             "dec": dict(n_embed_tokens=None, n_input_tokens=1, patch_to_embed=False, embed_to_patch=True)}
+
+
+def vit_param_shapes(cfg, role):
+    """state_dict key -> shape of the reference's ViT for this configuration (insertion order = the reference's)"""
+    d, m, ps, c = cfg["dim"], cfg["mlp_dim"], cfg["patch_size"], cfg["channels"]
+    npatch = (cfg["image_size"] // ps) ** 2
+    r = VIT_ROLES[role]
+    n_in = npatch if r["n_input_tokens"] is None else r["n_input_tokens"]
+    n_emb = npatch if r["n_embed_tokens"] is None else r["n_embed_tokens"]
+    total = n_in + n_emb + int(cfg["num_classes"] is not None)
+    shapes = {"embed_token": (1, n_emb, d)}
+    if r["patch_to_embed"]:
+        shapes.update({"patch_to_embed.1.weight": (d, ps * ps * c), "patch_to_embed.1.bias": (d,)})
+    if r["embed_to_patch"]:
+        shapes.update({"embed_to_patch.0.weight": (ps * ps * c, d), "embed_to_patch.0.bias": (ps * ps * c,)})
+    if cfg["num_classes"] is not None:
+        shapes["class_token.weight"] = (cfg["num_classes"], d)
+    shapes.update({"positional_embed.position_embeddings.weight": (total, d), "positional_embed.LayerNorm.weight": (d,),
+                   "positional_embed.LayerNorm.bias": (d,)})
+    for i in range(cfg["depth"]):
+        pre = f"transformer.layers.{i}."
+        shapes.update({pre + "self_attn.in_proj_weight": (3 * d, d), pre + "self_attn.in_proj_bias": (3 * d,),
+                       pre + "self_attn.out_proj.weight": (d, d), pre + "self_attn.out_proj.bias": (d,),
+                       pre + "linear1.weight": (m, d), pre + "linear1.bias": (m,), pre + "linear2.weight": (d, m),
+                       pre + "linear2.bias": (d,), pre + "norm1.weight": (d,), pre + "norm1.bias": (d,),
+                       pre + "norm2.weight": (d,), pre + "norm2.bias": (d,)})
+    return shapes
+
+
+def check_vit_grads(g, prefix, grads, tol):
+    """full gradients where the fixture holds them, (sum, L2, first 16 entries) for the large matrices"""
+    seen = 0
+    for k, gr in grads.items():
+        if f"{prefix}/grad/{k}" in g:
+            assert rel_err(gr, g[f"{prefix}/grad/{k}"]) < tol, k
+        else:
+            want = g[f"{prefix}/gradsum/{k}"].double()
+            gd = gr.double().flatten().cpu()
+            got = torch.cat([torch.stack([gd.sum(), gd.norm()]), gd[:16]])
+            scale = float(want[1]) + 1e-30
+            assert float((got - want).abs().max()) / scale < tol, (k, got[:3], want[:3])
+        seen += 1
+    assert seen == len(grads)
+
+
+@pytest.mark.parametrize("tag", ["d32", "d128"])
+@pytest.mark.parametrize("role", ["enc", "dec"])
+def test_vit_forward_backward(tag, role):
+    from detfill import fill_vit_state_dict
+    g = load_golden("vit.npz")
+    g = {k[len(tag) + 1:]: v for k, v in ((k, torch.from_numpy(g[k])) for k in g.files) if k.startswith(tag + "/")}
+    cfg = VIT_CASES[tag]
+    p = {k: torch.zeros(s) for k, s in vit_param_shapes(cfg, role).items()}
+    fill_vit_state_dict(p)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    x = g[f"{role}/x"].clone().requires_grad_(True)
+    labels = g["labels"] if "labels" in g else None
+    y = O.vit_forward(x, p, image_size=cfg["image_size"], patch_size=cfg["patch_size"], dim=cfg["dim"], depth=cfg["depth"],
+                      heads=cfg["heads"], channels=cfg["channels"], labels=labels, **VIT_ROLES[role])
+    y.backward(g[f"{role}/gy"])
+    # fp32 on both sides, but torch's nn.MultiheadAttention / TransformerEncoderLayer (what the reference runs) and this
+    # op-by-op restatement round differently: 1e-4 is the north-star tolerance
+    assert rel_err(y, g[f"{role}/y"]) < 1e-5
+    assert rel_err(x.grad, g[f"{role}/gx"]) < 1e-4
+    check_vit_grads(g, role, {k: v.grad for k, v in p.items() if v.grad is not None}, 5e-4)  # column sums with cancellation
