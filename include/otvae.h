@@ -182,6 +182,16 @@ int otvae_gaussian_prior_fwd(const float* h, const float* eps, int B, int S, int
 int otvae_gaussian_prior_bwd(const float* h, const float* eps, const float* gz, const float* gloss,
                              int B, int S, int D, float coeff, float* gh, void* stream);
 
+/* ---- ConditionalGaussianPrior (prior/conditional_gaussian.py:84-93): the same re-parametrisation against a per-sample
+ * diagonal prior N(prior_mean, exp(prior_log_std)^2) (rows of the class embeddings gathered by label).  h [B][2n]
+ * (mu | log_var), eps, z, prior_mean, prior_log_std [B][n]; loss[B] = coeff * KL(q || p).  Backward also returns the
+ * gradients of the gathered prior rows (nullable). */
+int otvae_gaussian_prior_cond_fwd(const float* h, const float* eps, const float* prior_mean, const float* prior_log_std, int B,
+                                  int n, float coeff, float* z, float* loss, void* stream);
+int otvae_gaussian_prior_cond_bwd(const float* h, const float* eps, const float* prior_mean, const float* prior_log_std,
+                                  const float* gz, const float* gloss, int B, int n, float coeff, float* gh,
+                                  float* g_prior_mean, float* g_prior_log_std, void* stream);
+
 /* ---- VAE.nelbo reduction (model/vae.py:158-176) ----------------------------------------------------------- */
 /* out[3] = {total, recon, prior}: recon = mean((pred-target)^2), prior = mean_B(prior_loss)/chw.
  * ws: double[otvae_nelbo_ws()] scratch. */

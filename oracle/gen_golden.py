@@ -22,6 +22,7 @@ Fixtures:
   discrete.npz       CodebookModel in 'mean' mode, DiscreteTransport.compute/transport, CodebookPrior.forward
   gmm.npz            GaussianMixtureModel (diagonal) update/fit/energy/w2, GMMTransport.compute/transport
   vit.npz            ViT encoder / decoder (reference networks/vit.py) fwd + input and parameter gradients, dropout 0
+  vit_vae.npz        ConditionalGaussianPrior fwd/bwd (+ EMA variant) and VAE.nelbo of the conditional ViT VAE
 """
 import math
 import os
@@ -642,8 +643,77 @@ def gen_vit():
     save("vit.npz", out)
 
 
+def gen_vit_vae():
+    """G13: ConditionalGaussianPrior alone (learned embeddings: z, loss, gradients of x and of the two
+    embeddings; EMA embeddings: the buffers after two training steps) and VAE.nelbo of the conditional ViT VAE of
+    tests/test_conditional_vit_vae.py:41-85 (dropout 0, dim 32 / 16x16 images to keep the fixture small, closed-form
+    weights, explicit eps): the three loss scalars, preds, latents and gradient checksums."""
+    vit, pc, vae = R.ref("networks.vit"), R.ref("prior.conditional_gaussian"), R.ref("model.vae")
+    out = {}
+    # ---- the prior alone
+    B, D, C = 6, 8, 4
+    labels = torch.tensor([0, 3, 1, 1, 2, 0])
+    x = det_input((B, 2, D), 0.4).requires_grad_(True)
+    eps = normal((B, 1, D), 91)
+    torch.manual_seed(7)
+    prior = pc.ConditionalGaussianPrior(dim=(1, D), num_classes=C, loss_coeff=0.3, annealing_steps=10)
+    prior.train()
+    with _FixedEps(eps):
+        z, loss, _ = prior(x, step=4, labels=labels)
+    w = det_input((B, 1, D), 2.2)
+    ((z * w).sum() + loss.sum()).backward()
+    out["prior/x"], out["prior/eps"], out["prior/labels"], out["prior/w"] = npy(x), npy(eps), npy(labels), npy(w)
+    out["prior/mu_weight"], out["prior/log_std_weight"] = npy(prior._mu.weight), npy(prior._log_std.weight)
+    out["prior/z"], out["prior/loss"], out["prior/gx"] = npy(z), npy(loss), npy(x.grad)
+    out["prior/g_mu"], out["prior/g_log_std"] = npy(prior._mu.weight.grad), npy(prior._log_std.weight.grad)
+    torch.manual_seed(8)
+    ema = pc.ConditionalGaussianPrior(dim=(1, D), num_classes=C, loss_coeff=1.0, embedding_ema_decay=0.9)
+    ema.train()
+    out["ema/mu_weight0"], out["ema/log_std_weight0"] = npy(ema._mu.weight).copy(), npy(ema._log_std.weight).copy()
+    for step in range(2):
+        xs = det_input((B, 2, D), 0.4 + step)
+        es = normal((B, 1, D), 92 + step)
+        with _FixedEps(es):
+            z, loss, _ = ema(xs, step=0, labels=labels)
+        out[f"ema/step{step}/x"], out[f"ema/step{step}/eps"] = npy(xs), npy(es)
+        out[f"ema/step{step}/z"], out[f"ema/step{step}/loss"] = npy(z), npy(loss)
+        out[f"ema/step{step}/mu"], out[f"ema/step{step}/log_std"] = npy(ema._mu.weight).copy(), npy(ema._log_std.weight).copy()
+        out[f"ema/step{step}/size"] = npy(ema._size).copy()
+    # ---- the conditional ViT VAE
+    cfg = dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, dropout=0.0, emb_dropout=0.,
+               num_classes=10)
+    enc = vit.ViT(n_embed_tokens=2, n_input_tokens=None, output_tokens="embed", patch_to_embed=True, embed_to_patch=False, **cfg)
+    dec = vit.ViT(n_embed_tokens=None, n_input_tokens=1, output_tokens="embed", patch_to_embed=False, embed_to_patch=True, **cfg)
+    fill_vit_state_dict(enc.state_dict())
+    fill_vit_state_dict(dec.state_dict())
+    torch.manual_seed(9)
+    prior = pc.ConditionalGaussianPrior(dim=(1, 32), num_classes=10, loss_coeff=0.1, empirical_kl=False, reparam_dim=1,
+                                        annealing_steps=1000)
+    m = vae.VAE(metrics=R._MetricCollection(), encoder=enc, decoder=dec, prior=prior, conditional=True)
+    m.train()
+    B = 5
+    x = det_input((B, 3, 16, 16), 0.6)
+    labels = torch.tensor([3, 0, 9, 3, 7])
+    eps = normal((B, 1, 32), 95)
+    with _FixedEps(eps):
+        loss, logs, art = m.nelbo({"samples": x, "target": x, "kwargs": {"labels": labels}}, 0)
+    loss.backward()
+    out["vae/x"], out["vae/labels"], out["vae/eps"] = npy(x), npy(labels), npy(eps)
+    out["vae/mu_weight"], out["vae/log_std_weight"] = npy(prior._mu.weight), npy(prior._log_std.weight)
+    out["vae/loss"] = npy(torch.stack([logs["train/loss/total"], logs["train/loss/recon"], logs["train/loss/prior"]]))
+    out["vae/preds"], out["vae/latents"] = npy(art["preds"]), npy(art["latents"])
+    names, gsum, gl2 = [], [], []
+    for pre, net in (("encoder.", m.encoder), ("decoder.", m.decoder), ("prior.", m.prior)):
+        for k, p in net.named_parameters():
+            names.append(pre + k)
+            gsum.append(p.grad.double().sum().item())
+            gl2.append(p.grad.double().norm().item())
+    out["vae/param_names"], out["vae/grad_sum"], out["vae/grad_l2"] = np.array(names), np.array(gsum), np.array(gl2)
+    save("vit_vae.npz", out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae"]
     for w in which:
         globals()["gen_" + w]()

@@ -633,3 +633,50 @@ def vit_forward(x: Tensor, p: Dict[str, Tensor], *, image_size: int, patch_size:
         b = out.size(0)
         out = out.reshape(b, nh, nh, ps, ps, channels).permute(0, 5, 1, 3, 2, 4).reshape(b, channels, nh * ps, nh * ps)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ conditional prior, ViT VAE
+def cond_gaussian_prior_encode(x: Tensor, eps: Tensor, mu_weight: Tensor, log_std_weight: Tensor, labels: Tensor,
+                               loss_coeff: float = 1.0, step: int = 0, annealing_steps: int = 0) -> Tuple[Tensor, Tensor]:
+    """``ConditionalGaussianPrior.encode`` + ``Prior.forward`` (prior/conditional_gaussian.py:81-93, prior/base.py:74-78)
+    with the N(0,1) draw explicit: q = N(mu, exp(log_var/2)) from chunk(x, 2, dim=1), p = N(mu_y, exp(log_std_y)) from
+    the class embeddings, z = mu + eps std, loss = sum KL(q || p) over the non-batch dims (torch's Normal-Normal KL)."""
+    mu, log_var = torch.chunk(x, 2, dim=1)
+    std = (log_var / 2).exp()
+    z = mu + eps * std
+    pm = mu_weight[labels].reshape(mu.shape)
+    ps = log_std_weight[labels].reshape(mu.shape).exp()
+    var_ratio = (std / ps) ** 2
+    t1 = ((mu - pm) / ps) ** 2
+    kl = torch.sum(0.5 * (var_ratio + t1 - 1 - var_ratio.log()), dim=list(range(1, mu.dim())))
+    return z, kl * (loss_coeff * prior_annealing(step, annealing_steps))
+
+
+def cond_prior_ema_update(state: Dict[str, Tensor], x: Tensor, labels: Tensor, decay: float, eps_smooth: float = 1e-5):
+    """``ConditionalGaussianPrior.ema_update`` (prior/conditional_gaussian.py:98-113) on {size, mu_avg, log_std_avg}:
+    per-class sums of the posterior means / log standard deviations, EMA into the buffers, embeddings = averages over
+    Laplace-smoothed class counts.  Returns (new state, mu embedding, log_std embedding)."""
+    st = {k: v.clone() for k, v in state.items()}
+    C = st["size"].shape[0]
+    mu, log_var = torch.chunk(x, 2, dim=1)
+    one_hot = F.one_hot(labels, num_classes=C).type(mu.dtype)
+    st["size"] = st["size"] * decay + one_hot.sum(0) * (1 - decay)
+    st["mu_avg"] = st["mu_avg"] * decay + (one_hot.t() @ mu.flatten(1)) * (1 - decay)
+    st["log_std_avg"] = st["log_std_avg"] * decay + (one_hot.t() @ (log_var / 2).exp().log().flatten(1)) * (1 - decay)
+    sizes = _laplace(st["size"], C, eps_smooth)
+    return st, st["mu_avg"] / sizes.unsqueeze(-1), st["log_std_avg"] / sizes.unsqueeze(-1)
+
+
+def vit_vae_nelbo(x: Tensor, eps: Tensor, labels: Tensor, enc: Dict[str, Tensor], dec: Dict[str, Tensor], mu_weight: Tensor,
+                  log_std_weight: Tensor, cfg: dict, loss_coeff: float, step: int, annealing_steps: int):
+    """``VAE.nelbo`` (model/vae.py:165-189) of the conditional ViT VAE of tests/test_conditional_vit_vae.py: the encoder
+    ViT's two embed tokens are (mu | log_var), the decoder ViT turns the latent token back into the image; both receive
+    the class token, the prior is conditioned on the label."""
+    vit = dict(image_size=cfg["image_size"], patch_size=cfg["patch_size"], dim=cfg["dim"], depth=cfg["depth"], heads=cfg["heads"],
+               channels=cfg["channels"], labels=labels)
+    h = vit_forward(x, enc, n_embed_tokens=2, n_input_tokens=None, patch_to_embed=True, embed_to_patch=False, **vit)
+    z, prior = cond_gaussian_prior_encode(h, eps, mu_weight, log_std_weight, labels, loss_coeff, step, annealing_steps)
+    preds = vit_forward(z, dec, n_embed_tokens=None, n_input_tokens=1, patch_to_embed=False, embed_to_patch=True, **vit)
+    prior_loss = prior.mean() / float(x[0].numel())
+    recon_loss = F.mse_loss(preds, x)
+    return dict(loss=recon_loss + prior_loss, recon=recon_loss, prior=prior_loss, preds=preds, latents=z)

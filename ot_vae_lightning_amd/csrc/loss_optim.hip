@@ -64,6 +64,70 @@ extern "C" int otvae_gaussian_prior_bwd(const float* h, const float* eps, const 
     return OTVAE_OK;
 }
 
+// ---- ConditionalGaussianPrior (prior/conditional_gaussian.py:84-93): KL(q || p_y) against a per-sample diagonal prior ----
+// h [B][2n] (mu | log_var), eps / z [B][n], prior mean pm and log standard deviation pl [B][n] (rows gathered by label):
+//   KL = sum_i  pl_i - lv_i/2 + (exp(lv_i) + (mu_i - pm_i)^2) / (2 exp(2 pl_i)) - 1/2
+__global__ __launch_bounds__(256) void gaussian_prior_cond_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                                                      const float* __restrict__ pm, const float* __restrict__ pl,
+                                                                      int n, float coeff, float* __restrict__ z,
+                                                                      float* __restrict__ loss) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* hb = h + (size_t)b * 2 * n;
+    float kl = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float mu = hb[i], lv = hb[n + i];
+        const float sd = __expf(0.5f * lv), var = sd * sd;
+        const float dm = mu - pm[(size_t)b * n + i], l = pl[(size_t)b * n + i];
+        z[(size_t)b * n + i] = fmaf(eps[(size_t)b * n + i], sd, mu);
+        kl += l - 0.5f * lv + 0.5f * (var + dm * dm) * __expf(-2.f * l) - 0.5f;
+    }
+    kl = wave_sum(kl);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kl;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[b] = coeff * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void gaussian_prior_cond_bwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                                                      const float* __restrict__ pm, const float* __restrict__ pl,
+                                                                      const float* __restrict__ gz, const float* __restrict__ gloss,
+                                                                      int n, float coeff, float* __restrict__ gh,
+                                                                      float* __restrict__ gpm, float* __restrict__ gpl) {
+    const int b = blockIdx.x;
+    const float* hb = h + (size_t)b * 2 * n;
+    float* gb = gh + (size_t)b * 2 * n;
+    const float gl = (gloss ? gloss[b] : 0.f) * coeff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float mu = hb[i], lv = hb[n + i];
+        const float sd = __expf(0.5f * lv), var = sd * sd;
+        const float dm = mu - pm[(size_t)b * n + i], l = pl[(size_t)b * n + i];
+        const float ip = __expf(-2.f * l);  // 1 / sigma_p^2
+        const float g = gz ? gz[(size_t)b * n + i] : 0.f;
+        gb[i] = fmaf(gl, dm * ip, g);
+        gb[n + i] = 0.5f * (g * eps[(size_t)b * n + i] * sd + gl * (var * ip - 1.f));
+        if (gpm) gpm[(size_t)b * n + i] = -gl * dm * ip;
+        if (gpl) gpl[(size_t)b * n + i] = gl * (1.f - (var + dm * dm) * ip);
+    }
+}
+
+extern "C" int otvae_gaussian_prior_cond_fwd(const float* h, const float* eps, const float* prior_mean, const float* prior_log_std,
+                                             int B, int n, float coeff, float* z, float* loss, void* stream) {
+    OTVAE_REQUIRE(h && eps && prior_mean && prior_log_std && z && loss && B > 0 && n > 0, "otvae_gaussian_prior_cond_fwd: bad argument");
+    gaussian_prior_cond_fwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(h, eps, prior_mean, prior_log_std, n, coeff, z, loss);
+    OTVAE_CHECK_LAUNCH("otvae_gaussian_prior_cond_fwd");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_gaussian_prior_cond_bwd(const float* h, const float* eps, const float* prior_mean, const float* prior_log_std,
+                                             const float* gz, const float* gloss, int B, int n, float coeff, float* gh,
+                                             float* g_prior_mean, float* g_prior_log_std, void* stream) {
+    OTVAE_REQUIRE(h && eps && prior_mean && prior_log_std && gh && B > 0 && n > 0, "otvae_gaussian_prior_cond_bwd: bad argument");
+    gaussian_prior_cond_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(h, eps, prior_mean, prior_log_std, gz, gloss, n, coeff, gh,
+                                                                       g_prior_mean, g_prior_log_std);
+    OTVAE_CHECK_LAUNCH("otvae_gaussian_prior_cond_bwd");
+    return OTVAE_OK;
+}
+
 // ---- nelbo ---------------------------------------------------------------------------------------------------
 #define NELBO_PARTS 256
 extern "C" int otvae_nelbo_ws(void) { return NELBO_PARTS + 8; }

@@ -553,14 +553,58 @@ class _GaussianPriorFn(torch.autograd.Function):
         return gh, None, None
 
 
+class _CondGaussianPriorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, eps, pm, pl, coeff):
+        lib = _lib.load()
+        b, n = eps.shape
+        z = torch.empty_like(eps)
+        loss = torch.empty(b, device=h.device, dtype=torch.float32)
+        check(lib.otvae_gaussian_prior_cond_fwd(ptr(h), ptr(eps), ptr(pm), ptr(pl), b, n, float(coeff), ptr(z), ptr(loss),
+                                                stream()), "otvae_gaussian_prior_cond_fwd")
+        ctx.save_for_backward(h, eps, pm, pl)
+        ctx.coeff = float(coeff)
+        return z, loss
+
+    @staticmethod
+    def backward(ctx, gz, gloss):
+        lib = _lib.load()
+        h, eps, pm, pl = ctx.saved_tensors
+        b, n = eps.shape
+        gz = gz.contiguous() if gz is not None else None
+        gloss = gloss.contiguous() if gloss is not None else None
+        gh = torch.empty_like(h)
+        gpm = torch.empty_like(pm) if ctx.needs_input_grad[2] else None
+        gpl = torch.empty_like(pl) if ctx.needs_input_grad[3] else None
+        check(lib.otvae_gaussian_prior_cond_bwd(ptr(h), ptr(eps), ptr(pm), ptr(pl), ptr(gz), ptr(gloss), b, n, ctx.coeff, ptr(gh),
+                                                ptr(gpm), ptr(gpl), stream()), "otvae_gaussian_prior_cond_bwd")
+        return gh, None, gpm, gpl, None
+
+
+def gaussian_prior_conditional(h: Tensor, eps: Tensor, prior_mean: Tensor, prior_log_std: Tensor, coeff: float):
+    """(z, coeff * KL(q || N(prior_mean, exp(prior_log_std)^2))[B]) for h [B, 2, ...] re-parametrised on dim 1, everything
+    else flattened (reference prior/conditional_gaussian.py:84-93)."""
+    _lib.require_cuda(h, "prior input")
+    b = h.shape[0]
+    out_shape = list(h.shape)
+    out_shape[1] //= 2
+    flat = lambda t: t.reshape(b, -1).contiguous().float()  # noqa: E731
+    z, loss = _CondGaussianPriorFn.apply(flat(h), flat(eps), flat(prior_mean), flat(prior_log_std), coeff)
+    return z.reshape(out_shape), loss
+
+
 def gaussian_prior(h: Tensor, eps: Tensor, coeff: float) -> Tuple[Tensor, Tensor]:
     """(z, coeff*KL[B]) for the re-parametrised diagonal Gaussian (reference prior/gaussian.py:63-96)."""
     _lib.require_cuda(h, "prior input")
     if h.dim() == 2:
         z, loss = _GaussianPriorFn.apply(as_nhwc(h[:, :, None, None]), as_nhwc(eps[:, :, None, None]), coeff)
         return z[:, :, 0, 0], loss
+    if h.dim() == 3:  # tokens [B, 2S, D] (the ViT's embed tokens): mu = the first S tokens, log_var = the last S
+        b, s2, d = h.shape
+        z, loss = gaussian_prior(h.reshape(b, s2 * d), eps.reshape(b, -1), coeff)
+        return z.reshape(b, s2 // 2, d), loss
     if h.dim() != 4:
-        raise ValueError("GaussianPrior on the MI355X path expects [B, 2D] or [B, 2D, H, W] with reparam_dim=1")
+        raise ValueError("GaussianPrior on the MI355X path expects [B, 2D], [B, 2S, D] or [B, 2D, H, W] with reparam_dim=1")
     return _GaussianPriorFn.apply(as_nhwc(h), as_nhwc(eps), coeff)
 
 

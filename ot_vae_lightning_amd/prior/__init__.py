@@ -2,3 +2,4 @@ from .base import *  # noqa: F401,F403
 from .gaussian import *  # noqa: F401,F403
 from .sinkhorn import *  # noqa: F401,F403
 from .codebook import *  # noqa: F401,F403
+from .conditional_gaussian import *  # noqa: F401,F403

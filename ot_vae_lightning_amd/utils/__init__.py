@@ -121,6 +121,14 @@ def ema(moving_avg, new, decay):
     return moving_avg * decay + new * (1 - decay)
 
 
+def ema_inplace(moving_avg, new, decay):
+    """in-place counterpart of ``ema`` (reference utils/__init__.py:190-201)"""
+    if decay is None:
+        moving_avg.data.add_(new)
+    else:
+        moving_avg.data.mul_(decay).add_(new, alpha=(1 - decay))
+
+
 def laplace_smoothing(x, n_categories, eps=1e-5):
     """Additive smoothing of a count vector that keeps its total (reference utils/__init__.py:209-218)."""
     if eps is None:

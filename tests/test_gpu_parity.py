@@ -935,3 +935,84 @@ def test_vit_vs_reference_golden(A, tag, role):
     rep.finish()
     check_vit_grads(g, role, {k: p.grad for k, p in net.named_parameters()}, 5e-4)  # column sums with cancellation
     assert tuple(net.out_size) == tuple(y.shape[1:])
+
+
+# ------------------------------------------------------------------------------------------------ G13 conditional prior, ViT VAE
+def test_conditional_gaussian_prior_vs_reference_golden(A):
+    """ConditionalGaussianPrior (reference prior/conditional_gaussian.py): learned class embeddings (z, loss with cosine
+    annealing, gradients of the input and of both embeddings) and the EMA-tracked variant over two training steps."""
+    z_ = load_golden("vit_vae.npz")
+    g, e = group(z_, "prior"), group(z_, "ema")
+    rep = Report("ConditionalGaussianPrior vs reference golden")
+    C, n = g["mu_weight"].shape
+    prior = A.ConditionalGaussianPrior(dim=(1, n), num_classes=C, loss_coeff=0.3, annealing_steps=10)
+    with torch.no_grad():
+        prior._mu.weight.copy_(g["mu_weight"])
+        prior._log_std.weight.copy_(g["log_std_weight"])
+    prior = prior.cuda().train()
+    x = g["x"].cuda().requires_grad_(True)
+    labels = g["labels"].cuda()
+    z, loss, art = prior(x, step=4, labels=labels, eps=g["eps"].cuda())
+    ((z * g["w"].cuda()).sum() + loss.sum()).backward()
+    rep.check("z", z, g["z"], 1e-6)
+    rep.check("loss", loss, g["loss"], 1e-5)
+    rep.check("d/dx", x.grad, g["gx"], 1e-5)
+    rep.check("d/d mu embedding", prior._mu.weight.grad, g["g_mu"], 1e-5)
+    rep.check("d/d log_std embedding", prior._log_std.weight.grad, g["g_log_std"], 1e-5)
+    assert art["prior"].mean.shape == z.shape and prior.sample((6, 1, n), "cuda", labels=labels).shape == (6, 1, n)
+    ema = A.ConditionalGaussianPrior(dim=(1, n), num_classes=C, loss_coeff=1.0, embedding_ema_decay=0.9)
+    with torch.no_grad():
+        ema._mu.weight.copy_(e["mu_weight0"])
+        ema._log_std.weight.copy_(e["log_std_weight0"])
+    ema = ema.cuda().train()
+    assert not ema._mu.weight.requires_grad
+    for step in range(2):
+        z, loss, _ = ema(e[f"step{step}/x"].cuda(), step=0, labels=labels, eps=e[f"step{step}/eps"].cuda())
+        rep.check(f"ema step{step}/z", z, e[f"step{step}/z"], 1e-6)
+        rep.check(f"ema step{step}/loss", loss, e[f"step{step}/loss"], 1e-5)
+        rep.check(f"ema step{step}/size", ema._size, e[f"step{step}/size"], 1e-6)
+        rep.check(f"ema step{step}/mu", ema._mu.weight, e[f"step{step}/mu"], 1e-5)
+        rep.check(f"ema step{step}/log_std", ema._log_std.weight, e[f"step{step}/log_std"], 1e-5)
+    rep.finish()
+
+
+def test_conditional_vit_vae_nelbo_vs_reference_golden(A):
+    """VAE.nelbo of the conditional ViT VAE (reference tests/test_conditional_vit_vae.py:41-85 at dim 32, dropout 0):
+    ViT encoder -> ConditionalGaussianPrior -> ViT decoder, class labels to all three, through the reference-named VAE
+    module: the three losses, reconstructions, latents, and the gradient norm of every parameter."""
+    from detfill import fill_vit_state_dict
+    from test_oracle_vs_golden import VIT_ROLES, VIT_VAE_CFG, vit_param_shapes
+    z_ = load_golden("vit_vae.npz")
+    g = group(z_, "vae")
+    rep = Report("conditional ViT VAE nelbo vs reference golden")
+    nets = {}
+    for role in ("enc", "dec"):
+        net = A.ViT(output_tokens="embed", dropout=0.0, emb_dropout=0., **VIT_VAE_CFG, **VIT_ROLES[role])
+        ordered = {k: torch.zeros(s) for k, s in vit_param_shapes(VIT_VAE_CFG, role).items()}
+        fill_vit_state_dict(ordered)
+        net.load_state_dict(ordered)
+        nets[role] = net
+    prior = A.ConditionalGaussianPrior(dim=(1, 32), num_classes=10, loss_coeff=0.1, empirical_kl=False, reparam_dim=1,
+                                       annealing_steps=1000)
+    with torch.no_grad():
+        prior._mu.weight.copy_(g["mu_weight"])
+        prior._log_std.weight.copy_(g["log_std_weight"])
+    model = A.VAE(encoder=nets["enc"], decoder=nets["dec"], prior=prior, conditional=True).cuda().train()
+    assert tuple(model.latent_size) == (1, 32)
+    x = g["x"].cuda()
+    batch = {"samples": x, "target": x, "kwargs": {"labels": g["labels"].cuda(), "eps": g["eps"].cuda()}}
+    loss, logs, art = model.nelbo(batch, 0)
+    loss.backward()
+    rep.check("loss [total, recon, prior]", torch.stack([logs["train/loss/total"], logs["train/loss/recon"],
+                                                           logs["train/loss/prior"]]), g["loss"], 1e-5)
+    rep.check("preds", art["preds"], g["preds"], 1e-5)
+    rep.check("latents", art["latents"], g["latents"], 1e-5)
+    grads = {}
+    for pre, net in (("encoder.", model.encoder), ("decoder.", model.decoder), ("prior.", model.prior)):
+        for k, p in net.named_parameters():
+            grads[pre + k] = p.grad
+    names = [str(n) for n in z_["vae/param_names"]]
+    assert set(names) == set(grads)
+    l2 = torch.tensor([grads[n].double().norm().item() if grads[n] is not None else 0.0 for n in names])
+    rep.check("gradient norms (all parameters)", l2, g["grad_l2"], 5e-4)
+    rep.finish()

@@ -506,3 +506,49 @@ def test_vit_forward_backward(tag, role):
     assert rel_err(y, g[f"{role}/y"]) < 1e-5
     assert rel_err(x.grad, g[f"{role}/gx"]) < 1e-4
     check_vit_grads(g, role, {k: v.grad for k, v in p.items() if v.grad is not None}, 5e-4)  # column sums with cancellation
+
+
+# ------------------------------------------------------------------------------------------------ G13 conditional prior, ViT VAE
+def test_conditional_gaussian_prior_and_ema():
+    g = group(load_golden("vit_vae.npz"), "prior")
+    x = g["x"].clone().requires_grad_(True)
+    mw, lw = g["mu_weight"].clone().requires_grad_(True), g["log_std_weight"].clone().requires_grad_(True)
+    z, loss = O.cond_gaussian_prior_encode(x, g["eps"], mw, lw, g["labels"], loss_coeff=0.3, step=4, annealing_steps=10)
+    ((z * g["w"]).sum() + loss.sum()).backward()
+    assert rel_err(z, g["z"]) < 1e-6 and rel_err(loss, g["loss"]) < 1e-6
+    assert rel_err(x.grad, g["gx"]) < 1e-5 and rel_err(mw.grad, g["g_mu"]) < 1e-5 and rel_err(lw.grad, g["g_log_std"]) < 1e-5
+    e = group(load_golden("vit_vae.npz"), "ema")
+    C, n = e["mu_weight0"].shape
+    st = {"size": torch.zeros(C), "mu_avg": torch.zeros(C, n), "log_std_avg": torch.zeros(C, n)}
+    mu_w, ls_w = e["mu_weight0"], e["log_std_weight0"]
+    for step in range(2):
+        z, loss = O.cond_gaussian_prior_encode(e[f"step{step}/x"], e[f"step{step}/eps"], mu_w, ls_w, g["labels"])
+        assert rel_err(z, e[f"step{step}/z"]) < 1e-6 and rel_err(loss, e[f"step{step}/loss"]) < 1e-5
+        st, mu_w, ls_w = O.cond_prior_ema_update(st, e[f"step{step}/x"], g["labels"], 0.9)
+        assert rel_err(st["size"], e[f"step{step}/size"]) < 1e-6
+        assert rel_err(mu_w, e[f"step{step}/mu"]) < 1e-5 and rel_err(ls_w, e[f"step{step}/log_std"]) < 1e-5
+
+
+VIT_VAE_CFG = dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, num_classes=10)
+
+
+def test_conditional_vit_vae_nelbo():
+    from detfill import fill_vit_state_dict
+    g = group(load_golden("vit_vae.npz"), "vae")
+    nets = {}
+    for role in ("enc", "dec"):
+        p = {k: torch.zeros(s) for k, s in vit_param_shapes(VIT_VAE_CFG, role).items()}
+        fill_vit_state_dict(p)
+        nets[role] = {k: v.requires_grad_(True) for k, v in p.items()}
+    mw, lw = g["mu_weight"].clone().requires_grad_(True), g["log_std_weight"].clone().requires_grad_(True)
+    r = O.vit_vae_nelbo(g["x"], g["eps"], g["labels"], nets["enc"], nets["dec"], mw, lw, VIT_VAE_CFG, loss_coeff=0.1, step=0,
+                        annealing_steps=1000)
+    r["loss"].backward()
+    assert rel_err(torch.stack([r["loss"], r["recon"], r["prior"]]), g["loss"]) < 1e-5
+    assert rel_err(r["preds"], g["preds"]) < 1e-5 and rel_err(r["latents"], g["latents"]) < 1e-5
+    grads = {"encoder." + k: v.grad for k, v in nets["enc"].items()}
+    grads.update({"decoder." + k: v.grad for k, v in nets["dec"].items()})
+    grads.update({"prior._mu.weight": mw.grad, "prior._log_std.weight": lw.grad})
+    names = [str(n) for n in load_golden("vit_vae.npz")["vae/param_names"]]
+    l2 = torch.tensor([grads[n].double().norm().item() if grads[n] is not None else 0.0 for n in names])
+    assert rel_err(l2, g["grad_l2"]) < 5e-4
