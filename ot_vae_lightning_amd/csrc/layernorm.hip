@@ -80,7 +80,7 @@ extern "C" int otvae_layernorm_fwd(const float* x, const float* res, const float
     return OTVAE_OK;
 }
 
-#define LN_ROWS_PER_BLOCK 64  // rows a block of the backward kernel walks (16 per wave)
+#define LN_ROWS_PER_BLOCK 16  // rows a block of the backward kernel walks (4 per wave): enough blocks to fill the chip at ~5k rows
 
 // partial[block][2][D]: column sums of g * xhat (d gamma) and of g (d beta) over the block's rows, waves combined in order
 template <int NV>
@@ -138,14 +138,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// dgamma / dbeta = column sums of the per-block partials.  A block owns 16 columns of one of the two vectors; its 16
+// partial-lanes each sum every 16th partial in increasing order, then lane 0 adds the 16 lane sums in order: a fixed
+// summation tree (deterministic) with P/16 dependent loads instead of P.
 __global__ __launch_bounds__(256) void layernorm_param_reduce_kernel(const float* __restrict__ partial, int P, int D,
                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= 2 * D) return;
-    const int which = e / D, c = e - which * D;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + cl;  // column index over [dgamma | dbeta]
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partial[((size_t)p * 2 + which) * D + c];  // fixed order
-    (which == 0 ? dgamma : dbeta)[c] = s;
+    if (e < 2 * D) {
+        const int which = e / D, c = e - which * D;
+        for (int p = pl; p < P; p += 16) s += partial[((size_t)p * 2 + which) * D + c];
+    }
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && e < 2 * D) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][cl];
+        const int which = e / D, c = e - which * D;
+        (which == 0 ? dgamma : dbeta)[c] = t;
+    }
 }
 
 extern "C" int otvae_layernorm_bwd_ws(int M, int D) {
@@ -167,7 +181,7 @@ extern "C" int otvae_layernorm_bwd(const float* xs, const float* gy, const float
     LN_NV_SWITCH(D, LN_BWD)
 #undef LN_BWD
     OTVAE_CHECK_LAUNCH("otvae_layernorm_bwd");
-    layernorm_param_reduce_kernel<<<cdiv(2 * D, 256), 256, 0, st>>>(ws, P, D, dgamma, dbeta);
+    layernorm_param_reduce_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>(ws, P, D, dgamma, dbeta);
     OTVAE_CHECK_LAUNCH("otvae_layernorm_bwd(reduce)");
     return OTVAE_OK;
 }
