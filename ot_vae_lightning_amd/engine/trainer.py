@@ -67,7 +67,8 @@ class HipTrainer:
     """
 
     def __init__(self, model, batch_shape, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, use_graph: bool = True, latent_stats=None, dp_overlap: Optional[bool] = None):
+                 process_group=None, use_graph: bool = True, latent_stats=None, dp_overlap: Optional[bool] = None,
+                 batch_kwargs: Optional[Dict[str, Tensor]] = None):
         self.lib = _lib.load()
         self.model = model
         self.params = list(model.optim_parameters())
@@ -119,6 +120,9 @@ class HipTrainer:
         self.x = torch.zeros(batch_shape, device=dev, dtype=torch.float32)
         lat = (batch_shape[0], *model.latent_size)
         self.eps = torch.zeros(lat, device=dev, dtype=torch.float32)
+        # further per-batch keyword tensors of ``model.nelbo`` (e.g. ``labels`` of a conditional model): resident copies of the
+        # examples given here, refreshed by ``step(..., name=tensor)``
+        self.batch_kwargs = {k: v.to(dev).clone() for k, v in (batch_kwargs or {}).items()}
         self.latent_stats = latent_stats  # optional TransportOperator fed with the step's latents (LatentTransport)
         # [1, 0, 0]: the gradient of the loss with respect to the nelbo kernel's output vector (resident: see _backward)
         self._seed = torch.tensor([1.0, 0.0, 0.0], device=self.device, dtype=torch.float32)
@@ -147,17 +151,32 @@ class HipTrainer:
         self._refresh_wd()
         for p in self.params:
             p.grad = None
-        batch = {"samples": self.x, "target": self.x, "kwargs": {"eps": self.eps}}
-        loss, logs, art = self.model.nelbo(batch, 0)
+        loss, logs, art = self.model.nelbo(self._batch(), 0)
         self._backward(loss)
         from ..functional import _PendingReduce
         _PendingReduce.flush(self.device)  # normally already done by the autograd-engine callback at the end of backward
+        self._collect_loose_grads()
         self._logs = {k: v.detach() for k, v in logs.items()}  # no reference into the autograd graph survives the step
         self.latents = art["latents"].detach()
         if self.latent_stats is not None:
             lat = self.latents.flatten(1)  # [B, D] with transport_dims = (1, 2, 3)
             self.latent_stats.update(target_samples=lat)
         return self._logs
+
+    def _batch(self):
+        return {"samples": self.x, "target": self.x, "kwargs": {"eps": self.eps, **self.batch_kwargs}}
+
+    def _collect_loose_grads(self) -> None:
+        """Gradients that reached a parameter through plain autograd (p.grad) instead of being written into the flat
+        buffer by a kernel (embeddings, learned tokens, LayerNorm weights of the ViT ...): copied into their slot.  The
+        convolution / BatchNorm kernels write their slots directly (then p.grad IS the slot): nothing to do for them."""
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                continue
+            slot = p._otvae_grad_view()
+            if g.data_ptr() != slot.data_ptr():
+                slot.copy_(g)
 
     def _backward(self, loss, **kw) -> None:
         """``loss.backward()`` seeded at the nelbo kernel's [total, recon, prior] vector with a resident [1, 0, 0]: the
@@ -194,8 +213,7 @@ class HipTrainer:
         self._refresh_wd()
         for p in self.params:
             p.grad = None
-        batch = {"samples": self.x, "target": self.x, "kwargs": {"eps": self.eps}}
-        loss, logs, art = self.model.nelbo(batch, 0)
+        loss, logs, art = self.model.nelbo(self._batch(), 0)
         h = getattr(self.model, "_last_cut", None)
         if h is None:  # nothing upstream of the cut needs a gradient: one-phase backward
             self._backward(loss)
@@ -205,6 +223,7 @@ class HipTrainer:
         self._cut = h
         from ..functional import _PendingReduce
         _PendingReduce.flush(self.device)  # the decoder's weight gradients are complete before their all-reduce starts
+        self._collect_loose_grads()
         self._logs = {k: v.detach() for k, v in logs.items()}
         self.latents = art["latents"].detach()
         return self._logs
@@ -217,6 +236,7 @@ class HipTrainer:
             h.grad = None
             from ..functional import _PendingReduce
             _PendingReduce.flush(self.device)
+            self._collect_loose_grads()
         self._cut = None
         self.model._last_cut = None
         if self.latent_stats is not None:
@@ -312,12 +332,16 @@ class HipTrainer:
         else:
             self.eps.normal_()
 
-    def step(self, x: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> Tensor:
+    def step(self, x: Optional[Tensor] = None, eps: Optional[Tensor] = None, **batch_kwargs) -> Tensor:
         """One optimisation step.  Returns a device tensor [total, recon, prior] (valid until the next step)."""
         if x is not None:
             self.load_batch(x, eps)
         elif eps is None:
             self.eps.normal_()
+        for k, v in batch_kwargs.items():
+            if k not in self.batch_kwargs:
+                raise KeyError(f"`{k}` was not declared in HipTrainer(batch_kwargs=...)")
+            self.batch_kwargs[k].copy_(v, non_blocking=True)
         annealing = getattr(getattr(self.model, "prior", None), "annealing_steps", 0) > self.n_steps
         if self.use_graph and not annealing:  # the annealing coefficient is a kernel argument: not replayable
             if not self._captured:

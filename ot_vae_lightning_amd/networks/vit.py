@@ -224,6 +224,13 @@ class ViT(nn.Module):
         self.out_size = torch.Size([channels, image_height, image_width]) if embed_to_patch else \
             torch.Size([len(self.output_tokens_indices), dim])
 
+    def _out_index(self, device) -> Tensor:
+        cached = self.__dict__.get("_out_index_cache")
+        if cached is None or cached.device != device:
+            cached = torch.tensor(self.output_tokens_indices, device=device)
+            self.__dict__["_out_index_cache"] = cached
+        return cached
+
     def _add_class_token(self, x: Tensor, labels: Optional[Tensor]) -> Tensor:
         if labels is not None and self.class_token is None:
             warnings.warn("given conditional argument `labels` but `self.class_token` is None. To enable a class-conditioned "
@@ -250,7 +257,11 @@ class ViT(nn.Module):
         x = self._add_class_token(x, labels)
         x = self._add_time_token(x, time)
         x = self.positional_embed(x)
-        out = self.transformer(x)[:, self.output_tokens_indices]
+        idx = self.output_tokens_indices
+        if idx == list(range(idx[0], idx[0] + len(idx))):  # one run of tokens: a slice (an index LIST would be uploaded from
+            out = self.transformer(x)[:, idx[0]:idx[0] + len(idx)]  # the host on every call, which a graph capture cannot hold)
+        else:
+            out = self.transformer(x)[:, self._out_index(x.device)]
         if not isinstance(self.embed_to_patch, nn.Identity):
             out = out[:, -self.num_patches:]
         return self.embed_to_patch(out)

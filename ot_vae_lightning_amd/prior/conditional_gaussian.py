@@ -14,7 +14,7 @@ from torch.distributions import Normal
 from .. import functional as HF
 from .. import utils
 from .base import Prior
-from .gaussian import GaussianPrior
+from .gaussian import GaussianPrior, _LazyNormal
 
 __all__ = ["ConditionalGaussianPrior"]
 
@@ -50,7 +50,11 @@ class ConditionalGaussianPrior(GaussianPrior, utils.DDPMixin):
         q = self.reparametrization(x.detach())
         if self.decay is not None and self.decay > 0 and self.training:
             self.ema_update(q, labels)
-        return z, loss, {"prior": self.p(labels), "distribution": q}
+        # built on first use: constructing a Normal validates its arguments with a host synchronisation, which a
+        # hipGraph capture of the training step cannot contain
+        prior = _LazyNormal(lambda: self._mu(labels).detach().unflatten(1, self.dim),
+                            lambda: self._log_std(labels).detach().unflatten(1, self.dim).exp())
+        return z, loss, {"prior": prior, "distribution": q}
 
     def encode(self, x: Tensor, labels: Tensor, eps: Optional[Tensor] = None) -> Prior.EncodingResults:  # noqa
         return self._encode(x, 1.0, labels, eps)

@@ -375,6 +375,37 @@ def test_latent_transport_callback_with_gmm_and_discrete_operators(A):
             assert vae.decode(moved).shape == x.shape
 
 
+def test_conditional_vit_vae_trains_through_hip_trainer(A):
+    """The conditional ViT VAE (ViT encoder / decoder + ConditionalGaussianPrior, class labels as a resident batch keyword)
+    through HipTrainer: gradients that arrive by plain autograd (learned tokens, embeddings, LayerNorm weights) are
+    collected into the flat buffer next to the ones the kernels write there; the captured (hipGraph) step must give the
+    bits of the eager one, and the loss must go down."""
+    cfg = dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, dropout=0.0, emb_dropout=0.,
+               num_classes=10)
+    x = normal((64, 3, 16, 16), 71).cuda()
+    eps = [normal((64, 1, 32), 72 + i).cuda() for i in range(6)]
+    y = (torch.arange(64) % 10).cuda()
+
+    def run(graph):
+        torch.manual_seed(5)
+        enc = A.ViT(n_embed_tokens=2, n_input_tokens=None, output_tokens="embed", patch_to_embed=True, embed_to_patch=False, **cfg)
+        dec = A.ViT(n_embed_tokens=None, n_input_tokens=1, output_tokens="embed", patch_to_embed=False, embed_to_patch=True, **cfg)
+        prior = A.ConditionalGaussianPrior(dim=(1, 32), num_classes=10, loss_coeff=0.1)
+        model = A.VAE(encoder=enc, decoder=dec, prior=prior, conditional=True).cuda().train()
+        tr = A.HipTrainer(model, batch_shape=(64, 3, 16, 16), use_graph=graph, batch_kwargs={"labels": y})
+        losses = [tr.step(x, eps[i], labels=y).clone() for i in range(6)]
+        torch.cuda.synchronize()
+        return tr.pflat.clone(), torch.stack(losses)
+
+    p_eager, l_eager = run(False)
+    p_graph, l_graph = run(True)
+    assert torch.equal(l_eager, l_graph) and torch.equal(p_eager, p_graph)
+    assert float(l_eager[-1, 0]) < float(l_eager[0, 0]) and torch.isfinite(p_eager).all()
+    with pytest.raises(KeyError):
+        A.HipTrainer(A.VAE(encoder=A.CNN(1, 16, 16, 1, capacity=2, down_sample=True), decoder=A.CNN(8, 1, 1, 16, capacity=2, up_sample=True),
+                           prior=A.GaussianPrior()).cuda(), batch_shape=(4, 1, 16, 16), use_graph=False).step(labels=y)
+
+
 _DP_OVERLAP_CHECK = r"""
 import os, sys, torch
 import torch.distributed as dist
