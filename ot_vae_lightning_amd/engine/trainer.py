@@ -87,14 +87,17 @@ class HipTrainer:
         for p, off in zip(self.params, self.offsets):
             p._otvae_grad_view = (lambda off=off, p=p: _dense_view(self.gflat, off, p.data))
         # dgrad-layout ([T][Cout][Cin]) copies of every conv weight, refreshed by ONE launch at the start of each step
+        # (the ViT's Linear weights are 1x1 layers on the same kernels: [out, in] = [Cn, Cs], one tap)
         self.conv_weights = [mod.weight for mod in model.modules() if isinstance(mod, ConvLayer)]
+        self.conv_weights += [p_ for n_, p_ in model.named_parameters()
+                              if p_.dim() == 2 and (n_.endswith("in_proj_weight") or getattr(p_, "_otvae_linear", False))]
         flat_ids = {id(p): off for p, off in zip(self.params, self.offsets)}
         wd_total = sum((w.numel() + 3) // 4 * 4 for w in self.conv_weights)
         self.wdflat = torch.empty(max(4, wd_total), device=dev, dtype=torch.float32)
         off, table, self._wd_loose = 0, [], []
         for w in self.conv_weights:
             w._otvae_wd = self.wdflat[off: off + w.numel()]
-            cn, cs, kh, kw = w.shape
+            cn, cs, kh, kw = w.shape if w.dim() == 4 else (*w.shape, 1, 1)
             if id(w) in flat_ids:
                 table.append([flat_ids[id(w)], off, kh * kw, cs, cn])
             else:  # a frozen conv weight is not in the flat buffer: transposed on its own
@@ -142,7 +145,7 @@ class HipTrainer:
                                                      self._wd_table.shape[0], self._wd_max, stream()),
                   "otvae_weight_transpose_batched")
         for w in self._wd_loose:
-            cn, cs, kh, kw = w.shape
+            cn, cs, kh, kw = w.shape if w.dim() == 4 else (*w.shape, 1, 1)
             check(lib.otvae_weight_transpose(ptr(w), ptr(w._otvae_wd), kh * kw, cs, cn, stream()),
                   "otvae_weight_transpose")
 

@@ -464,6 +464,15 @@ def linear_tokens(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu_input:
     nn.TransformerEncoderLayer, networks/vit.py:157-172).  ``weight`` is the logical [D_out, D_in] matrix; kept on
     [D_in][D_out] memory (``new_linear_weight``) it is consumed without a copy."""
     w4 = weight.unsqueeze(-1).unsqueeze(-1)
+    # what a trainer attached to the parameter (its slot in the flat gradient buffer, the resident transposed copy the
+    # data-gradient kernel reads) travels with the 1x1 view, so the weight gradient is written in place and reduced with
+    # the step's other layers
+    slot = getattr(weight, "_otvae_grad_view", None)
+    if slot is not None:
+        w4._otvae_grad_view = lambda: slot().unsqueeze(-1).unsqueeze(-1)
+    wd = getattr(weight, "_otvae_wd", None)
+    if wd is not None:
+        w4._otvae_wd = wd
     y = conv_layers(tokens_as_nhwc(x), [dict(weight=w4, bias=bias, stride=1, pad=0, up=1, relu=relu_input)],
                     training=torch.is_grad_enabled())[0]
     return nhwc_as_tokens(y)

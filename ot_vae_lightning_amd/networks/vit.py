@@ -34,7 +34,9 @@ def _adopt(weight: Tensor) -> nn.Parameter:
     w = HF.new_linear_weight(weight.shape[0], weight.shape[1])
     with torch.no_grad():
         w.copy_(weight)
-    return nn.Parameter(w)
+    p = nn.Parameter(w)
+    p._otvae_linear = True  # engine.HipTrainer keeps a resident transposed copy for the data-gradient kernel
+    return p
 
 
 class TokenLinear(nn.Module):
