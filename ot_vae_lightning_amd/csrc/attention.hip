@@ -544,6 +544,32 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
 }
 
+// T == 1 (the 1x1 bottleneck block of the encoder): one key, so the softmax weight is 1 -- out = v, lse = the single score,
+// dq = dk = 0 and dv = gout.  Elementwise kernels at the launch floor instead of the staged ones (13 + 18 us there).
+__global__ __launch_bounds__(256) void attn_t1_fwd_kernel(const float* __restrict__ qkv, int N, int H, int C, float scale,
+                                                          float* __restrict__ out, float* __restrict__ lse) {
+    const int HC = H * C;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N * HC) {
+        const int n = i / HC, hc = i - n * HC;
+        out[i] = qkv[(size_t)n * 3 * HC + 2 * HC + hc];
+    }
+    if (i < N * H) {
+        const int n = i / H, h = i - n * H;
+        const float* q = qkv + (size_t)n * 3 * HC + h * C;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(q[c], q[HC + c], s);
+        lse[i] = s * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_t1_bwd_kernel(const float* __restrict__ gout, int N, int HC, float* __restrict__ gqkv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * 3 * HC) return;
+    const int n = i / (3 * HC), j = i - n * 3 * HC;
+    gqkv[i] = j >= 2 * HC ? gout[(size_t)n * HC + j - 2 * HC] : 0.f;
+}
+
 // slices per block: as many as 256 threads cover (T/QPT threads each) and as the LDS budget holds
 static int pick_qpt(int T, int C) { return (T >= 256 && T % 4 == 0 && C <= 4) ? 4 : 1; }
 static int pick_spb(int T, int qpt, int floats_per_key) {
@@ -596,6 +622,11 @@ extern "C" int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int 
                                      void* stream) {
     OTVAE_REQUIRE(qkv && out && lse, "otvae_attn_fwd: NULL tensor");
     OTVAE_REQUIRE(scale > 0.f, "otvae_attn_fwd: scale must be positive");
+    if (T == 1 && N > 0 && H > 0 && C > 0) {  // aux stays unwritten: with T == 1 the backward pass does not read it
+        attn_t1_fwd_kernel<<<cdiv((int64_t)N * H * C, 256), 256, 0, (hipStream_t)stream>>>(qkv, N, H, C, scale, out, lse);
+        OTVAE_CHECK_LAUNCH("otvae_attn_fwd(T=1)");
+        return OTVAE_OK;
+    }
     int qpt, spb;
     if (C > 2) aux = nullptr;
     const int rkv = aux ? ((2 * C + C * C + 3) & ~3) : 2 * C;  // FwdRec<C, AUX>::KV
@@ -637,6 +668,11 @@ extern "C" int otvae_attn_bwd_scaled(const float* qkv, const float* out, const f
                                      int T, int H, int C, float scale, float* gqkv, void* stream) {
     OTVAE_REQUIRE(qkv && out && lse && gout && gqkv, "otvae_attn_bwd: NULL tensor");
     OTVAE_REQUIRE(scale > 0.f, "otvae_attn_bwd: scale must be positive");
+    if (T == 1 && N > 0 && H > 0 && C > 0) {
+        attn_t1_bwd_kernel<<<cdiv((int64_t)N * 3 * H * C, 256), 256, 0, (hipStream_t)stream>>>(gout, N, H * C, gqkv);
+        OTVAE_CHECK_LAUNCH("otvae_attn_bwd(T=1)");
+        return OTVAE_OK;
+    }
     int qpt, spb;
     const int rqg = (2 * C + 2 + 3) & ~3;
     int rc = attn_check("otvae_attn_bwd", N, T, H, C, 2 * C + rqg, &qpt, &spb);
