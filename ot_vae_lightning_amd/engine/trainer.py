@@ -173,13 +173,17 @@ class HipTrainer:
         """Gradients that reached a parameter through plain autograd (p.grad) instead of being written into the flat
         buffer by a kernel (embeddings, learned tokens, LayerNorm weights of the ViT ...): copied into their slot.  The
         convolution / BatchNorm kernels write their slots directly (then p.grad IS the slot): nothing to do for them."""
+        loose = self.__dict__.setdefault("_loose_params", set())
         for p in self.params:
             g = p.grad
             if g is None:
+                if id(p) in loose:  # took no part in this step: its slot must not keep the previous step's gradient
+                    p._otvae_grad_view().zero_()
                 continue
             slot = p._otvae_grad_view()
             if g.data_ptr() != slot.data_ptr():
                 slot.copy_(g)
+                loose.add(id(p))
 
     def _backward(self, loss, **kw) -> None:
         """``loss.backward()`` seeded at the nelbo kernel's [total, recon, prior] vector with a resident [1, 0, 0]: the
