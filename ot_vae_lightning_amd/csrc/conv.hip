@@ -1236,7 +1236,7 @@ static void wgrad_plan(const Geom& g, int has_bias, int& NT, int& P, unsigned& c
         conv_small_wgrad_plan(g, P, chunk);
         return;
     }
-    // ~1024 workgroups (4 per CU; measured on MI355X: 768..3072 are within 1 % of each other for the whole step, fewer
+    // ~1024 workgroups (4 per CU; measured on MI355X: 384..3072 are within 1 % of each other for the whole step, fewer
     // partials mean less workspace traffic), pixel chunks of >= 128 pixels, workspace <= 16 MiB, P <= 2048
     const unsigned ws_cap = 4u << 20;
     int want = cdiv(1024, nkb * nnb);
