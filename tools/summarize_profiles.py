@@ -3,6 +3,7 @@
     python tools/summarize_profiles.py <kernel-stats dir> <tag>         # e.g. gpurun_out/prof8 r01_final
     python tools/summarize_profiles.py --replay <kernel-trace dir> <tag> # replayed (timed) steps only
     python tools/summarize_profiles.py --pmc gpurun_out <tag>           # pmc_fetch / pmc_write / pmc_mfma passes
+    python tools/summarize_profiles.py --roofline <tag>                 # joins the replay and PMC summaries
 
 HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
 the bytes of wide coalesced reads, so reads = 2 * FETCH_SIZE KiB; the two counters need separate passes (TCC slots).
@@ -89,7 +90,36 @@ def pmc(src, tag):
     print("wrote", out)
 
 
+def roofline(tag):
+    """Joins <tag>_final_replay_kernel_stats.csv and <tag>_pmc_per_kernel.csv into <tag>_kernel_roofline.csv."""
+    rep = {r["kernel"]: r for r in csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", f"{tag}_final_replay_kernel_stats.csv"))
+                                                  if not l.startswith("#"))}
+    pm = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.csv"))))
+    busy_key = [k for k in pm[0] if k.startswith("mfma_busy_frac")][0]
+    pm = {r["kernel"]: r for r in pm}
+    rows = []
+    for k, r in rep.items():
+        if k in pm:
+            us, mib = float(r["avg_us"]), float(pm[k]["hbm_MB_per_launch"])
+            rows.append((float(r["ms_per_step"]), k, float(r["calls_per_step"]), us, mib, mib * 1.048576 / us if us else 0.0,
+                         float(pm[k][busy_key])))
+    rows.sort(reverse=True)
+    out = os.path.join(ROOT, "profiles", f"{tag}_kernel_roofline.csv")
+    with open(out, "w") as w:
+        w.write("# per kernel of the timed step: average duration (kernel trace, timed replays), HBM MiB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE),\n"
+                "# (the x2 read correction is calibrated for 16-byte-per-lane loads; kernels reading 4 bytes per lane, e.g. the reductions, are\n"
+                "#  over-counted by up to 2x),\n"
+                "# achieved HBM TB/s = bytes / duration (peak 8 TB/s), MFMA busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))\n")
+        w.write("kernel,calls_per_step,avg_us,ms_per_step,hbm_MiB_per_launch,achieved_TB_per_s,frac_of_hbm_peak,mfma_busy_frac\n")
+        for ms, k, c, us, mib, tbs, mf in rows:
+            w.write('"%s",%.0f,%.2f,%.4f,%.2f,%.3f,%.3f,%.4f\n' % (k, c, us, ms, mib, tbs, tbs / 8.0, mf))
+    print("wrote", out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--roofline":
+        roofline(sys.argv[2])
+        sys.exit(0)
     if sys.argv[1] == "--pmc":
         pmc(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "--replay":
