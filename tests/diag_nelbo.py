@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): per-parameter gradient-norm error of the MNIST VAE (B=6 golden) in backward order."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # a test-side diagnostic: it uses the seeded fills under oracle/
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

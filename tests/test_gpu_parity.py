@@ -213,7 +213,7 @@ def test_nelbo_and_adam_vs_reference_golden(A, residual):
     # a deliberately hostile, badly conditioned case.  The golden file records how much the REFERENCE's own fp32 gradients
     # move (a) when the same computation runs in fp64 and (b) when the input is perturbed by one ulp (4 draws); a port is
     # held to that resolution: |ours - ref32| <= max(3e-4 * scale, 5 * fp64 discrepancy, 3 * one-ulp spread).
-    # (tools/diag_nelbo.py prints the per-parameter picture; the well-conditioned batch-256 step below holds 3e-4.)
+    # (tests/diag_nelbo.py prints the per-parameter picture; the well-conditioned batch-256 step below holds 3e-4.)
     def check_grad(name, got, ref32, ref64, spread, floor=0.0):
         denom = max(ref32.double().abs().max().item(), floor, 1e-30)
         noise = (ref32.double() - ref64.double()).abs().max().item() / denom
