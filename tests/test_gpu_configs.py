@@ -452,3 +452,29 @@ def test_dp_overlap_two_phase_backward_equals_single_phase(A):
     r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _DP_OVERLAP_CHECK], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "DP-OVERLAP-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_two_rank_call_sequence_on_one_gpu():
+    """``bench.py --gpus 2`` exactly as the driver launches it (torch.distributed.run, one process per rank), rehearsed on
+    this box's single GPU: both ranks use cuda:0 and the collectives go over gloo (OTVAE_BENCH_SHARE_GPU=1).  Checks the
+    N > 1 call sequence end to end -- rendezvous from the environment, replica broadcast, the three captured graphs with
+    the gradient all-reduce in between, max-over-ranks timing, ONE JSON line from rank 0, exit code 0 -- not performance."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OTVAE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 200
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+                        "--warmup", "3"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 3 and d["scaling"] == "weak" and d["unit"] == "images/s"
+    assert d["config"]["global_batch"] == 2048 and "dp2" in d["config"]["parallelism"] and "rehearsal" in d
+    assert d["value"] > 0 and abs(d["value"] - 2048 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    assert all(0 < v < 10 for v in d["final_loss"])
+    for key in ("roofline", "roofline_issue"):
+        assert key in d
