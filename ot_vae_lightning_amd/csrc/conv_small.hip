@@ -9,7 +9,7 @@
 #include "conv_small.h"
 #include <type_traits>
 
-#define SMALL_MAXC 8
+#define SMALL_MAXC 16
 // The weights stay in LDS: left alone the compiler hoists the (loop-invariant) LDS weight reads of the unrolled tap loops
 // out of the position loop into 130-330 registers, which costs the occupancy these latency-bound kernels live on.
 #define SMALL_REREAD_LDS() asm volatile("" ::: "memory")
@@ -17,10 +17,11 @@
 #define SMALL_MAXW 1024
 
 bool conv_small_ok(const SmallGeom& g) {
-    if (g.Cs > SMALL_MAXC || g.Cn > SMALL_MAXC) return false;
     if (g.KH * g.KW * g.Cs * g.Cn > SMALL_MAXW) return false;
-    if ((g.Cs % 4 == 0) && (g.Cn % 4 == 0)) return false;  // vectorised MFMA path handles these well
-    return true;
+    if (g.Cs <= 8 && g.Cn <= 8) return !((g.Cs % 4 == 0) && (g.Cn % 4 == 0));  // those the vectorised MFMA path handles well
+    // the RGB image-side layers of the capacity-16 (CIFAR) network: 3 -> 16, 16 -> 3, 3 -> 9 (qkv); otherwise they fall to
+    // the scalar-gather implicit GEMM (3 channels cannot be loaded as float4)
+    return (g.Cs == 3 && (g.Cn == 16 || g.Cn == 9)) || (g.Cs == 16 && g.Cn == 3);
 }
 
 // (image, y, x) of a flat position index: one multiply per division while the index is below 2^22 (see fast_div in
@@ -40,7 +41,13 @@ __device__ __forceinline__ float act1(float v, float sc, float sh, bool affine, 
 // access); 0: read from the geometry (any Cs, Cn <= SMALL_MAXC).
 template <int C>
 __device__ __forceinline__ void load_chan(const float* __restrict__ p, float (&v)[C ? C : SMALL_MAXC], int n) {
-    if constexpr (C == 8) {
+    if constexpr (C == 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = reinterpret_cast<const float4*>(p)[q];
+            v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+        }
+    } else if constexpr (C == 8) {
         const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else if constexpr (C == 4) {
@@ -57,7 +64,10 @@ __device__ __forceinline__ void load_chan(const float* __restrict__ p, float (&v
 
 template <int C>
 __device__ __forceinline__ void store_chan(float* __restrict__ p, const float (&v)[C ? C : SMALL_MAXC], int n) {
-    if constexpr (C == 8) {
+    if constexpr (C == 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(p)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else if constexpr (C == 8) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else if constexpr (C == 4) {
@@ -213,10 +223,14 @@ __global__ __launch_bounds__(256) SMALL_OCC void conv_small_fwd_kernel(SmallGeom
         else if (g.Cs == 3 && g.Cn == 8) KERNEL<3, 8, 0> __VA_ARGS__;          \
         else if (g.Cs == 8 && g.Cn == 3) KERNEL<8, 3, 0> __VA_ARGS__;          \
         else if (g.Cs == 3 && g.Cn == 3) KERNEL<3, 3, 0> __VA_ARGS__;          \
+        else if (g.Cs == 3 && g.Cn == 16) KERNEL<3, 16, 0> __VA_ARGS__;        \
+        else if (g.Cs == 16 && g.Cn == 3) KERNEL<16, 3, 0> __VA_ARGS__;        \
+        else if (g.Cs == 3 && g.Cn == 9) KERNEL<3, 9, 0> __VA_ARGS__;          \
         else KERNEL<0, 0, 0> __VA_ARGS__;                                      \
     } while (0)
 // (Cs, Cn, kernel size) of the layers the two configurations really have: tap loops unrolled, loads up front
-#define SMALL_KS_CASES(X) X(1, 8, 4) X(8, 1, 3) X(8, 1, 1) X(1, 1, 3) X(1, 1, 1) X(1, 3, 1) X(3, 3, 3) X(3, 3, 1)
+#define SMALL_KS_CASES(X) \
+    X(1, 8, 4) X(8, 1, 3) X(8, 1, 1) X(1, 1, 3) X(1, 1, 1) X(1, 3, 1) X(3, 3, 3) X(3, 3, 1) X(3, 16, 4) X(16, 3, 3) X(16, 3, 1) X(3, 9, 1)
 
 int conv_small_fwd(const SmallGeom& g, int nblocks, const float* x, const float* scale, const float* shift, int relu,
                    const float* wT, const float* bias, const float* res, float* y, double* partial, int CnPad,

@@ -184,6 +184,10 @@ CASES = [
     (4, 1, 8, 32, 4, 2, 1, 1),      # image side: direct VALU kernels
     (4, 8, 1, 16, 3, 1, 1, 2),
     (2, 3, 8, 32, 4, 2, 1, 1),      # RGB
+    (3, 3, 16, 32, 4, 2, 1, 1),     # RGB image side of the capacity-16 network: 3 -> 16 ...
+    (3, 16, 3, 16, 3, 1, 1, 2),     # ... 16 -> 3 with up-sampling, 3x3 and
+    (3, 16, 3, 16, 1, 1, 0, 2),     # 1x1 (skip), and the
+    (3, 3, 9, 32, 1, 1, 0, 1),      # 3 -> 9 qkv layer
     (1, 12, 20, 8, 3, 1, 1, 1),     # channel counts % 4 == 0 but not powers of two, a single image
     (4100, 1, 1, 32, 3, 1, 1, 1),   # > 2^22 positions: the direct kernels' integer-division fallback
     (4100, 4, 4, 32, 3, 1, 1, 1),   # > 2^22 rows in the implicit GEMM (row decode falls back to udiv)
