@@ -512,7 +512,10 @@ bool conv_small_wgrad_ok(const SmallGeom& g) {
     if (!conv_small_ok(g)) return false;
     const int T = g.KH * g.KW;
     return (T == 16 && g.Cs == 1 && g.Cn == 8) || (T == 9 && g.Cs == 8 && g.Cn == 1) || (T == 9 && g.Cs == 1 && g.Cn == 1) ||
-           (T == 1 && g.Cs == 1 && g.Cn == 3) || (T == 1 && g.Cs == 1 && g.Cn == 1) || (T == 1 && g.Cs == 8 && g.Cn == 1);
+           (T == 1 && g.Cs == 1 && g.Cn == 3) || (T == 1 && g.Cs == 1 && g.Cn == 1) || (T == 1 && g.Cs == 8 && g.Cn == 1) ||
+           // RGB image side (every weight element in a register: T * Cs * Cn <= 81)
+           (T == 9 && g.Cs == 3 && g.Cn == 3) || (T == 1 && g.Cs == 3 && g.Cn == 3) || (T == 1 && g.Cs == 3 && g.Cn == 9) ||
+           (T == 1 && g.Cs == 16 && g.Cn == 3);
 }
 
 void conv_small_wgrad_plan(const SmallGeom& g, int& P, unsigned& chunk) {
@@ -536,6 +539,10 @@ int conv_small_wgrad(const SmallGeom& g, const float* x, const float* scale, con
     else if (T == 1 && g.Cs == 1 && g.Cn == 3) SW(1, 1, 3);
     else if (T == 1 && g.Cs == 1 && g.Cn == 1) SW(1, 1, 1);
     else if (T == 1 && g.Cs == 8 && g.Cn == 1) SW(1, 8, 1);
+    else if (T == 9 && g.Cs == 3 && g.Cn == 3) SW(9, 3, 3);
+    else if (T == 1 && g.Cs == 3 && g.Cn == 3) SW(1, 3, 3);
+    else if (T == 1 && g.Cs == 3 && g.Cn == 9) SW(1, 3, 9);
+    else if (T == 1 && g.Cs == 16 && g.Cn == 3) SW(1, 16, 3);
     else return -1;
 #undef SW
     return P;

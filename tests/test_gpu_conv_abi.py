@@ -188,6 +188,8 @@ CASES = [
     (3, 16, 3, 16, 3, 1, 1, 2),     # ... 16 -> 3 with up-sampling, 3x3 and
     (3, 16, 3, 16, 1, 1, 0, 2),     # 1x1 (skip), and the
     (3, 3, 9, 32, 1, 1, 0, 1),      # 3 -> 9 qkv layer
+    (3, 3, 3, 32, 3, 1, 1, 1),      # 3 -> 3 (3x3 and
+    (3, 3, 3, 32, 1, 1, 0, 1),      # 1x1)
     (1, 12, 20, 8, 3, 1, 1, 1),     # channel counts % 4 == 0 but not powers of two, a single image
     (4100, 1, 1, 32, 3, 1, 1, 1),   # > 2^22 positions: the direct kernels' integer-division fallback
     (4100, 4, 4, 32, 3, 1, 1, 1),   # > 2^22 rows in the implicit GEMM (row decode falls back to udiv)
