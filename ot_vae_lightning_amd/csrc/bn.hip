@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
         sh[0][threadIdx.x] = s;
         sh[1][threadIdx.x] = q;
         __syncthreads();
-        if (threadIdx.x < C) {
+        if ((int)threadIdx.x < C) {
             double ts = 0.0, tq = 0.0;
             for (int r = 0; r < rpb; ++r) {
                 ts += sh[0][r * C + threadIdx.x];
