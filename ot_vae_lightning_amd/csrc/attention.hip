@@ -371,6 +371,53 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 dqv[i][c] = s * inv_c;
             }
         }
+    } else if constexpr (QPT % 2 == 0) {
+        // two queries at a time in packed registers (as the forward pass and phase B)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        constexpr int QP = QPT / 2;
+        f2 q2[QP][C], go2[QP][C], dq2[QP][C], nls2[QP], ndl2[QP];
+#pragma unroll
+        for (int j = 0; j < QP; ++j) {
+            const float* r0 = qg + (size_t)(t0 + 2 * j) * RQG;
+            const float* r1 = r0 + RQG;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                q2[j][c] = (f2){r0[c] * LOG2E, r1[c] * LOG2E};
+                go2[j][c] = (f2){r0[C + c], r1[C + c]};
+                dq2[j][c] = (f2){0.f, 0.f};
+            }
+            nls2[j] = (f2){-r0[2 * C], -r1[2 * C]};
+            ndl2[j] = (f2){-r0[2 * C + 1], -r1[2 * C + 1]};
+        }
+#pragma unroll 4
+        for (int s = 0; s < T; ++s) {
+            const float* r = kv + s * RKV;
+            f2 kk[C], vv[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                kk[c] = (f2){r[c], r[c]};
+                vv[c] = (f2){r[C + c], r[C + c]};
+            }
+#pragma unroll
+            for (int j = 0; j < QP; ++j) {
+                f2 sc = nls2[j], dp = ndl2[j];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    sc = __builtin_elementwise_fma(q2[j][c], kk[c], sc);
+                    dp = __builtin_elementwise_fma(go2[j][c], vv[c], dp);
+                }
+                const f2 ds = (f2){EXP2(sc.x), EXP2(sc.y)} * dp;
+#pragma unroll
+                for (int c = 0; c < C; ++c) dq2[j][c] = __builtin_elementwise_fma(ds, kk[c], dq2[j][c]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QP; ++j)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                dqv[2 * j][c] = dq2[j][c].x * inv_c;
+                dqv[2 * j + 1][c] = dq2[j][c].y * inv_c;
+            }
     } else {
         float q[QPT][C], go[QPT][C], dq[QPT][C], ls[QPT], dl[QPT];
 #pragma unroll
