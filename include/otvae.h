@@ -223,6 +223,10 @@ int otvae_sinkhorn_log(int dtype, const void* a, const void* b, const void* C, i
 int otvae_ot_cost(int dtype, const void* C, const void* pi, int nb, int N, int M, double* ws, void* cost, void* stream);
 /* pairwise squared euclidean cost C[nb][N][M] = |x_i - y_j|^2, x[nb][N][D], y[nb][M][D] */
 int otvae_sqdist(int dtype, const void* x, const void* y, int nb, int N, int M, int D, void* C, void* stream);
+/* Gradient of sum_ij C_ij pi_ij with respect to z for C_ij = |z_i - y_j|^2 and a fixed plan (the minibatch OT prior's
+ * backward, SinkhornPrior): gz[i][d] = 2 g sum_j pi_ij (z_id - y_jd); z [N][D], y [M][D], pi [N][M], g a device scalar. */
+int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int N, int M, int D, void* gz,
+                       void* stream);
 
 /* ---- GaussianModel statistics (ot/distribution_models/gaussian_model.py:99-108,144-157) ------------------- */
 /* samples [nb][B][D] (in_dtype 0=fp32,1=fp64) -> fp64 sum_x[nb][D], sum_xx[nb][D][D] (diag: [nb][D]),

@@ -263,7 +263,10 @@ bool conv_wtile_plan(const Geom& g, int has_bias, WTilePlan& pl, int& nblocks, s
     pl.rowsPIp = (pl.rowsPI + 3) & ~3;
     // deep layers (< 64 positions per image): conv_wgrad_kernel, output-stationary over many blocks; 32x32 maps (1024
     // positions): measured 2.5x slower than the direct / implicit-GEMM kernels (one image per block, staging-bound)
-    if (pl.rowsPI < 64 || (pl.rowsPI > 256 && !getenv("OTVAE_WTILE_ALL"))) return false;
+    // maps above 16x16: only where the alternative is the scalar-gather implicit GEMM (channel counts that are no multiple
+    // of 4 and not served by the direct kernels, e.g. the 16 -> 3 layer of the RGB decoder at 32x32: 95 us there)
+    const bool scalar_gemm_otherwise = ((g.Cs % 4 != 0) || (g.Cn % 4 != 0)) && !conv_small_wgrad_ok(g);
+    if (pl.rowsPI < 64 || (pl.rowsPI > 256 && !scalar_gemm_otherwise && !getenv("OTVAE_WTILE_ALL"))) return false;
     if (pl.rowsPI > 1024) return false;
     pl.vec4 = (g.Cs % 4 == 0) ? 1 : 0;
     pl.CKp = pl.vec4 ? g.Cs + 4 : g.Cs + 1;

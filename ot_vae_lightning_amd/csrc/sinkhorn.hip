@@ -714,3 +714,72 @@ extern "C" int otvae_sqdist(int dtype, const void* x, const void* y, int nb, int
     OTVAE_CHECK_LAUNCH("otvae_sqdist");
     return OTVAE_OK;
 }
+
+
+// ---- gradient of <C, pi> with C_ij = |z_i - y_j|^2 and the plan held fixed (the envelope argument of the OT prior):
+// gz[i][d] = 2 g sum_j pi_ij (z_id - y_jd) = 2 g (z_id sum_j pi_ij - sum_j pi_ij y_jd): a [N x M] x [M x D] product plus the
+// plan's row sums.  32 x 32 output tiles, the plan and y staged through LDS in 32-wide slices of j, 2 x 2 outputs per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void ot_cost_grad_kernel(const T* __restrict__ z, const T* __restrict__ y, const T* __restrict__ pi,
+                                                           const T* __restrict__ g, int N, int M, int D, T* __restrict__ gz) {
+    __shared__ T ps[32][33], ys[32][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
+    T acc[2][2] = {{(T)0, (T)0}, {(T)0, (T)0}}, rs[2] = {(T)0, (T)0};
+    // the next slice's elements travel in registers while the current one is multiplied (4 + 4 per lane)
+    T pn[4], yn[4];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = threadIdx.x + 256 * u, r = e >> 5, c = e & 31;
+            pn[u] = (i0 + r < N && j0 + c < M) ? pi[(size_t)(i0 + r) * M + j0 + c] : (T)0;   // [i][j]
+            yn[u] = (j0 + r < M && d0 + c < D) ? y[(size_t)(j0 + r) * D + d0 + c] : (T)0;    // [j][d]
+        }
+    };
+    fetch(0);
+    for (int j0 = 0; j0 < M; j0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = threadIdx.x + 256 * u, r = e >> 5, c = e & 31;
+            ps[r][c] = pn[u];
+            ys[r][c] = yn[u];
+        }
+        __syncthreads();
+        if (j0 + 32 < M) fetch(j0 + 32);
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) {
+            const T p0 = ps[ty][j], p1 = ps[ty + 16][j], y0 = ys[j][tx], y1 = ys[j][tx + 16];
+            rs[0] += p0;
+            rs[1] += p1;
+            acc[0][0] += p0 * y0;
+            acc[0][1] += p0 * y1;
+            acc[1][0] += p1 * y0;
+            acc[1][1] += p1 * y1;
+        }
+        __syncthreads();
+    }
+    const T two_g = (T)2 * g[0];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int i = i0 + ty + 16 * a, d = d0 + tx + 16 * c;
+            if (i < N && d < D) gz[(size_t)i * D + d] = two_g * (rs[a] * z[(size_t)i * D + d] - acc[a][c]);
+        }
+}
+
+extern "C" int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int N, int M, int D,
+                                  void* gz, void* stream) {
+    OTVAE_REQUIRE(z && y && pi && g && gz && N > 0 && M > 0 && D > 0, "otvae_ot_cost_grad: bad argument");
+    OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_ot_cost_grad: dtype must be 0 or 1");
+    const dim3 grid(cdiv(D, 32), cdiv(N, 32));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        ot_cost_grad_kernel<float><<<grid, 256, 0, st>>>((const float*)z, (const float*)y, (const float*)pi, (const float*)g, N, M, D,
+                                                         (float*)gz);
+    else
+        ot_cost_grad_kernel<double><<<grid, 256, 0, st>>>((const double*)z, (const double*)y, (const double*)pi, (const double*)g, N,
+                                                          M, D, (double*)gz);
+    OTVAE_CHECK_LAUNCH("otvae_ot_cost_grad");
+    return OTVAE_OK;
+}
