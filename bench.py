@@ -182,7 +182,7 @@ def time_dominant_kernel(A, trainer, iters=30):
     torch.cuda.synchronize()
     # `iters` launches captured into one hipGraph: the events then bracket kernel time only (no host launch gaps)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog may poll from its own thread
         for _ in range(iters):
             launch()
     for _ in range(10):     # the set-up above left the GPU idle: bring the clocks back to the training loop's state

@@ -297,27 +297,31 @@ class HipTrainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph_fb = torch.cuda.CUDAGraph()
+        # "thread_local": only this thread's calls are policed while the stream captures.  Under the default ("global")
+        # an event query from another thread -- the RCCL watchdog polling the collectives of earlier steps -- is an
+        # illegal call that kills the capture, and the process with it, whenever the poll happens to land inside it
+        mode = dict(capture_error_mode="thread_local")
         if self.dp_overlap:
-            with torch.cuda.graph(self._graph_fb):
+            with torch.cuda.graph(self._graph_fb, **mode):
                 logs = self._phase1()
                 self._out_static = self._loss_vector(logs)
             self._graph_b2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_b2, pool=self._graph_fb.pool()):  # the cut tensors live in graph 1's pool
+            with torch.cuda.graph(self._graph_b2, pool=self._graph_fb.pool(), **mode):  # the cut tensors live in graph 1's pool
                 self._phase2()
             self._graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_opt, pool=self._graph_fb.pool()):
+            with torch.cuda.graph(self._graph_opt, pool=self._graph_fb.pool(), **mode):
                 self._adam()
         elif self.world == 1 and not self.reducer.active:
-            with torch.cuda.graph(self._graph_fb):
+            with torch.cuda.graph(self._graph_fb, **mode):
                 logs = self._forward_backward()
                 self._adam()
                 self._out_static = self._loss_vector(logs)
         else:
-            with torch.cuda.graph(self._graph_fb):
+            with torch.cuda.graph(self._graph_fb, **mode):
                 logs = self._forward_backward()
                 self._out_static = self._loss_vector(logs)
             self._graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_opt):
+            with torch.cuda.graph(self._graph_opt, **mode):
                 self._adam()
         # the warm-up/capture must not count as training: restore parameters, moments, step and BN buffers
         with torch.no_grad():

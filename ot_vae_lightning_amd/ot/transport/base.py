@@ -1,6 +1,16 @@
-"""``TransportOperator`` abstract base (reference ot/transport/base.py:28-173): owns a source and a target
-``DistributionModel``; ``update(source_samples=, target_samples=)``, ``compute() -> distance``, ``transport(x)``,
-``reset()``.  Sample storing (``store_source/target``) keeps raw samples for models that need them."""
+"""``TransportOperator``: the interface every latent transport implements (reference ot/transport/base.py:28-173).
+
+An operator holds two ``DistributionModel`` s, one per *side* ("source", "target").  Both sides behave identically, so
+the bookkeeping below is written once over ``_SIDES`` instead of twice: per side there is the model
+(``<side>_model``), whether ``reset()`` clears it (``reset_<side>``), and whether raw samples are kept for models that
+are fitted on samples rather than on running statistics (``store_<side>`` -> buffer ``_<side>_samples``, concatenated
+along the sample axis -2 and all-gathered across ranks before ``fit``).
+
+    update(source_samples=None, target_samples=None)   feed [*leading_shape, B, dim] samples to either side
+    compute() -> distance [*leading_shape]              fit both models and build the operator   (abstract)
+    transport(x) / __call__(x)                          push source samples onto the target        (abstract)
+    reset()                                             forget what ``reset_<side>`` allows
+"""
 from abc import ABC, abstractmethod
 from typing import Optional
 
@@ -14,6 +24,8 @@ from ..distribution_models.base import DistributionModel
 
 __all__ = ["TransportOperator"]
 
+_SIDES = ("source", "target")
+
 
 class TransportOperator(nn.Module, utils.DDPMixin, ABC):
     def __init__(self, *size: int, source_model: DistributionModel, target_model: DistributionModel,
@@ -21,74 +33,73 @@ class TransportOperator(nn.Module, utils.DDPMixin, ABC):
                  store_target: bool = False, **ddp_kwargs):
         nn.Module.__init__(self)
         utils.DDPMixin.__init__(self, **ddp_kwargs)
-        self.dim = size[-1]
-        self.leading_shape = size[:-1]
-        self.source_model, self.target_model = source_model, target_model
-        self.reset_source, self.reset_target = reset_source, reset_target
-        self.store_source, self.store_target = store_source, store_target
-        if store_source:
-            self.register_buffer("_source_samples", None)
-        if store_target:
-            self.register_buffer("_target_samples", None)
+        *leading, self.dim = size
+        self.leading_shape = tuple(leading)
+        given = dict(source=(source_model, reset_source, store_source), target=(target_model, reset_target, store_target))
+        for side, (model, resets, stores) in given.items():
+            setattr(self, f"{side}_model", model)
+            setattr(self, f"reset_{side}", resets)
+            setattr(self, f"store_{side}", stores)
+            if stores:
+                self.register_buffer(f"_{side}_samples", None)
         if store_source or store_target:
-            self.warn(f"The transport operator `{self.__class__.__name__}` will save all extracted features in "
-                      "buffers. For large datasets this may lead to a large memory footprint.")
+            self.warn(f"`{type(self).__name__}` keeps every sample it is updated with in a buffer: memory grows with the "
+                      f"dataset")
 
-    def reset(self) -> None:
-        if self.reset_source:
-            if self.store_source:
-                self._source_samples = None
-            self.source_model.reset()
-        if self.reset_target:
-            if self.store_target:
-                self._target_samples = None
-            self.target_model.reset()
+    # ---- per-side accessors
+    def _model(self, side: str) -> DistributionModel:
+        return getattr(self, f"{side}_model")
+
+    def _stored(self, side: str) -> Optional[Tensor]:
+        return getattr(self, f"_{side}_samples") if getattr(self, f"store_{side}") else None
+
+    def _feed(self, side: str, samples: Optional[Tensor]) -> None:
+        if samples is None:
+            return
+        self._model(side).update(samples)
+        if getattr(self, f"store_{side}"):
+            kept, fresh = self._stored(side), samples.detach()
+            setattr(self, f"_{side}_samples", fresh if kept is None else torch.cat([kept, fresh.type_as(kept)], dim=-2))
 
     @property
     def source_distribution(self) -> D.Distribution:
-        return self.source_model.distribution
+        return self._model("source").distribution
 
     @property
     def target_distribution(self) -> D.Distribution:
-        return self.target_model.distribution
+        return self._model("target").distribution
 
-    @staticmethod
-    def _append(store: Optional[Tensor], new: Tensor) -> Tensor:
-        new = new.detach()
-        return new if store is None else torch.cat([store, new.type_as(store)], dim=-2)
-
+    # ---- life cycle
     def update(self, source_samples: Optional[Tensor] = None, target_samples: Optional[Tensor] = None) -> None:
-        if source_samples is not None:
-            self.source_model.update(source_samples)
-            if self.store_source:
-                self._source_samples = self._append(self._source_samples, source_samples)
-        if target_samples is not None:
-            self.target_model.update(target_samples)
-            if self.store_target:
-                self._target_samples = self._append(self._target_samples, target_samples)
+        self._feed("source", source_samples)
+        self._feed("target", target_samples)
 
-    def fit_models(self):
-        src = tgt = None
-        if self.store_source:
-            self._source_samples = torch.cat(self.gather(self._source_samples), dim=-2)
-            src = self._source_samples
-        if self.store_target:
-            self._target_samples = torch.cat(self.gather(self._target_samples), dim=-2)
-            tgt = self._target_samples
-        self.source_model.fit(src)
-        self.target_model.fit(tgt)
+    def reset(self) -> None:
+        for side in _SIDES:
+            if not getattr(self, f"reset_{side}"):
+                continue
+            if getattr(self, f"store_{side}"):
+                setattr(self, f"_{side}_samples", None)
+            self._model(side).reset()
+
+    def fit_models(self) -> None:
+        """all-gather what was stored (sample axis), then ``fit`` each model on it (``None`` when nothing is stored)"""
+        for side in _SIDES:
+            if getattr(self, f"store_{side}"):
+                setattr(self, f"_{side}_samples", torch.cat(self.gather(self._stored(side)), dim=-2))
+            self._model(side).fit(self._stored(side))
 
     @abstractmethod
     def compute(self) -> Tensor:
-        """fit both models, build the transport operators, return the source-target distance"""
+        ...
 
     @abstractmethod
     def transport(self, inputs: Tensor) -> Tensor:
-        """[*leading_shape, (B,) dim] -> transported samples of the same shape"""
+        ...
 
     def forward(self, inputs: Tensor) -> Tensor:
         return self.transport(inputs)
 
     def extra_repr(self) -> str:
-        return (f"leading_dim={tuple(self.leading_shape)}, dim={self.dim}, reset_source={self.reset_source}, "
-                f"reset_target={self.reset_target}, store_source={self.store_source}, store_target={self.store_target}")
+        flags = ", ".join(f"{kind}_{side}={getattr(self, f'{kind}_{side}')}" for kind in ("reset", "store") for side in _SIDES)
+        return f"leading_dim={self.leading_shape}, dim={self.dim}, {flags}"

@@ -1,10 +1,18 @@
 """``DiscreteTransport``: entropic optimal transport between two fitted codebooks (reference
-ot/transport/discrete_transport.py:28-99).  ``compute`` fits both ``CodebookModel``s, takes the atom-to-atom cost the
-reference takes (``source_model.energy(target codebook)``, i.e. 1 / (distance + 1e-8), discrete_transport.py:59) and
-solves for the K x K plan with the HIP Sinkhorn solver; ``transport`` assigns every input to source atoms (HIP
-assignment kernels, inference mode), pushes the assignment through the plan and reads the target atoms."""
+ot/transport/discrete_transport.py:28-99).
+
+    compute()     fit both ``CodebookModel`` s; cost[i, j] = source_model.energy(target atoms) -- the reference's choice
+                  (discrete_transport.py:58), i.e. 1 / (distance + 1e-8), kept as is; plan = HIP log-domain Sinkhorn
+                  (``otvae_sinkhorn_log``) between the two atom-weight vectors; returns <cost, plan> per operator.
+    transport(x)  soft-assign x to the source atoms in inference mode (``otvae_codebook_probs``), push the assignment
+                  through the plan, then read target atoms:
+                      'mean'    the plan-weighted average of the target atoms          (one GEMM)
+                      'argmax'  the single most-coupled target atom                   (row gather, no one-hot GEMM)
+                      'sample'  one target atom drawn from the pushed assignment      (row gather)
+"""
+from contextlib import contextmanager
+
 import torch
-import torch.nn.functional as F
 from torch import Tensor
 from torch.distributions import Categorical
 
@@ -14,17 +22,27 @@ from .base import TransportOperator
 
 __all__ = ["DiscreteTransport"]
 
+_TRANSPORT_TYPES = ("sample", "argmax", "mean")
+
+
+def _rows(table: Tensor, index: Tensor) -> Tensor:
+    """table [*, K, d], index [*, B] -> table rows [*, B, d]"""
+    return torch.gather(table, -2, index.unsqueeze(-1).expand(*index.shape, table.size(-1)))
+
 
 class DiscreteTransport(TransportOperator):
     def __init__(self, *size: int, source_cfg={}, target_cfg={}, transport_type: str, sinkhorn_reg: float = 1e-5,
                  sinkhorn_max_iter: int = 1000, sinkhorn_threshold: float = 1e-6, **kwargs):
-        if transport_type not in ("sample", "argmax", "mean"):
-            raise NotImplementedError(f"`transport_type` must be 'sample', 'argmax' or 'mean', got {transport_type!r}")
-        super().__init__(*size, source_model=CodebookModel(*size, **source_cfg),
-                         target_model=CodebookModel(*size, **target_cfg), **kwargs)
+        if transport_type not in _TRANSPORT_TYPES:
+            raise NotImplementedError(f"`transport_type` must be one of {_TRANSPORT_TYPES}, got {transport_type!r}")
+        codebooks = dict(source_model=CodebookModel(*size, **source_cfg), target_model=CodebookModel(*size, **target_cfg))
+        super().__init__(*size, **codebooks, **kwargs)
         self.transport_type = transport_type
         self.sinkhorn_reg, self.sinkhorn_max_iter, self.sinkhorn_threshold = sinkhorn_reg, sinkhorn_max_iter, sinkhorn_threshold
-        self.transport_matrix = None
+        self.transport_matrix = None            # [*, K_source, K_target] after compute()
+
+    def _sinkhorn_cfg(self) -> dict:
+        return dict(reg=self.sinkhorn_reg, max_iter=self.sinkhorn_max_iter, threshold=self.sinkhorn_threshold)
 
     def reset(self) -> None:
         super().reset()
@@ -32,28 +50,35 @@ class DiscreteTransport(TransportOperator):
 
     def compute(self) -> Tensor:
         self.fit_models()
-        cost = self.source_model.energy(self.target_model.codebook)                       # [*, K_s, K_t]
-        self.transport_matrix = sinkhorn_log(self.source_distribution.probs, self.target_distribution.probs, cost,
-                                             reg=self.sinkhorn_reg, max_iter=self.sinkhorn_max_iter,
-                                             threshold=self.sinkhorn_threshold)
-        return torch.sum(cost * self.transport_matrix, dim=(-2, -1))
+        cost = self.source_model.energy(self.target_model.codebook)
+        weights = self.source_distribution.probs, self.target_distribution.probs
+        self.transport_matrix = plan = sinkhorn_log(*weights, cost, **self._sinkhorn_cfg())
+        return (cost * plan).sum(dim=(-2, -1))
+
+    @contextmanager
+    def _inference_mode(self):
+        was_training = self.training
+        self.eval()
+        try:
+            yield
+        finally:
+            self.train(was_training)
 
     def transport(self, inputs: Tensor) -> Tensor:
-        if self.transport_matrix is None:
+        plan = self.transport_matrix
+        if plan is None:
             raise RuntimeError("call `compute()` before `transport()`")
-        training = self.training
-        self.eval()                                                                       # inference-mode assignment
-        try:
-            assignments, _, _ = self.source_model.assign(inputs)                          # [*, B, K_s]
-        finally:
-            self.train(training)
-        moved = assignments.type_as(self.transport_matrix) @ self.transport_matrix        # [*, B, K_t]
-        if self.transport_type == "argmax":       # every input goes to the target atom it is most coupled with
-            moved = F.one_hot(moved.argmax(-1), moved.size(-1)).type_as(moved)
-        elif self.transport_type == "sample":     # ... or to one drawn from its row of the plan
-            moved = F.one_hot(Categorical(moved).sample(), moved.size(-1)).type_as(moved)
-        return (moved.type_as(self.target_model.codebook) @ self.target_model.codebook).type_as(inputs)
+        with self._inference_mode():
+            assignment = self.source_model.assign(inputs)[0]                    # [*, B, K_source]
+        pushed = assignment.type_as(plan) @ plan                                # [*, B, K_target]
+        atoms = self.target_model.codebook
+        if self.transport_type == "mean":
+            moved = pushed.type_as(atoms) @ atoms
+        else:
+            chosen = pushed.argmax(-1) if self.transport_type == "argmax" else Categorical(pushed).sample()
+            moved = _rows(atoms, chosen)
+        return moved.type_as(inputs)
 
     def extra_repr(self) -> str:
-        return super().extra_repr() + (f", sinkhorn_reg={self.sinkhorn_reg}, sinkhorn_max_iter={self.sinkhorn_max_iter}, "
-                                       f"sinkhorn_threshold={self.sinkhorn_threshold}")
+        cfg = ", ".join(f"sinkhorn_{k}={v}" for k, v in self._sinkhorn_cfg().items())
+        return f"{super().extra_repr()}, transport_type={self.transport_type}, {cfg}"

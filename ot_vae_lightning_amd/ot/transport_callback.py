@@ -41,20 +41,15 @@ class LatentTransport:
                  source_latents_from_train: bool = False, unpaired: bool = True, num_samples_to_log: int = 8,
                  verbose: bool = False, class_idx: Optional[int] = None, conditional_key: str = "y",
                  **transport_operator_kwargs) -> None:
-        size = tuple(int(s) for s in size)
-        every = list(range(1, len(size) + 1))
-        if not set(transport_dims).issubset(every):
-            raise ValueError(f"`size`={size}: inputs have {len(size) + 1} dimensions with the batch; `transport_dims` must be "
-                             f"a subset of {every}, given {tuple(transport_dims)}")
         if (source_latents_from_train or target_latents_from_train) and verbose:
             warnings.warn("latents of TRAINING samples will feed the transport operator: source and target are then not "
                           "unseen data, which biases the transport experiment")
-        self.size, self.transport_dims = size, tuple(transport_dims)
+        # [B, C, H, W] -> [H*W, B, C] for per-position operators; [B*H*W, C] for one common operator
+        self.layout = utils.VectorLayout(size, transport_dims, "transport_dims", batch_first=common_operator,
+                                         flatten_batch=common_operator)
+        self.size, self.transport_dims, self.batch_dims = self.layout.size, self.layout.vector_dims, self.layout.position_dims
+        self.batch_shape, self.event_shape, self.dim = self.layout.batch_shape, self.layout.event_shape, self.layout.dim
         self.transformations, self.common_operator = transformations, common_operator
-        self.batch_dims = tuple(d for d in every if d not in self.transport_dims)
-        self.batch_shape = torch.Size([size[d - 1] for d in self.batch_dims])
-        self.event_shape = torch.Size([size[d - 1] for d in self.transport_dims])
-        self.dim = int(np.prod(self.event_shape))
         op_size = (self.dim,) if common_operator else (*self.batch_shape, self.dim)
         self.transport_operator = transport_operator(*op_size, **transport_operator_kwargs)
         self.unpaired = unpaired
@@ -67,16 +62,13 @@ class LatentTransport:
         self.class_idx, self.conditional_key = class_idx, conditional_key
         self.test_metrics = None            # optional callable(pred, target) with .compute() / .reset()
         self.logged: Dict[str, Tensor] = {}  # what the hooks would have logged (also sent to pl_module.log if it exists)
-        flat = common_operator and len(size) > len(self.transport_dims)
-        # [B, C, H, W] -> [H*W, B, C] for per-position operators; [B*H*W, C] for one common operator
-        self._layout = dict(permute_dims=self.transport_dims, batch_first=common_operator, flatten_batch=flat)
 
     # ---- layout
     def _permute_and_flatten(self, latents: Tensor) -> Tensor:
-        return utils.permute_and_flatten(latents, **self._layout)
+        return self.layout.split(latents)
 
     def _unflatten_and_unpermute(self, flat: Tensor) -> Tensor:
-        return utils.unflatten_and_unpermute(flat, orig_shape=torch.Size([-1, *self.size]), **self._layout)
+        return self.layout.join(flat)
 
     # ---- what the hooks are made of
     def update_transport_operator(self, latents: Tensor, source: bool) -> None:

@@ -2,12 +2,12 @@
 30-123): q(z | x) from the re-parametrised encoder output, p(z | y) = N(mu_y, exp(log_std_y)^2) from two class
 embeddings that are either learned by gradient descent or tracked as exponential moving averages of the observed q's.
 The re-parametrisation and the closed-form KL(q || p_y) (and its backward, including the gradients of the gathered
-embedding rows) run in one HIP kernel each; the EMA update is a [classes x batch] one-hot product on tiny tensors."""
+embedding rows) run in one HIP kernel each; the EMA statistics are one [classes x batch] membership product over the
+packed (mean | log-std | 1) rows, followed by a single all-reduce."""
 from typing import Optional, Tuple
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch import Tensor
 from torch.distributions import Normal
 
@@ -63,17 +63,26 @@ class ConditionalGaussianPrior(GaussianPrior, utils.DDPMixin):
         return self.p(labels).sample().to(device)
 
     @torch.no_grad()
+    def _class_sums(self, q, labels: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        """per class: how many samples of the batch carry it, and the sums of their q means / log-stds.  The three
+        statistics ride in one [B, 2n+1] matrix so that a single [classes x B] membership product and a single
+        all-reduce (one RCCL call per step instead of three) produce them."""
+        n = q.mean[0].numel()
+        rows = torch.cat([q.mean.flatten(1), q.stddev.log().flatten(1), q.mean.new_ones(labels.numel(), 1)], dim=1)
+        member = (torch.arange(self.num_classes, device=labels.device).unsqueeze(1) == labels.unsqueeze(0)).type_as(rows)
+        sums = self.reduce(member @ rows)                                             # [classes, 2n+1]
+        return sums[:, 2 * n], sums[:, :n], sums[:, n:2 * n]
+
+    @torch.no_grad()
     def ema_update(self, q, labels: Tensor) -> None:
-        one_hot = F.one_hot(labels, num_classes=self.num_classes).type(q.mean.dtype)      # [B, classes]
-        sizes = one_hot.sum(dim=0)
-        mu_sum = one_hot.transpose(-2, -1) @ q.mean.flatten(1)
-        log_std_sum = one_hot.transpose(-2, -1) @ q.stddev.log().flatten(1)
-        utils.ema_inplace(self._size, self.reduce(sizes), decay=self.decay)
-        utils.ema_inplace(self._mu_avg, self.reduce(mu_sum), decay=self.decay)
-        utils.ema_inplace(self._log_std_avg, self.reduce(log_std_sum), decay=self.decay)
-        sizes = utils.laplace_smoothing(self._size, self.num_classes, self.eps)
-        self._mu.weight.copy_(self._mu_avg.data / sizes.unsqueeze(-1))
-        self._log_std.weight.copy_(self._log_std_avg.data / sizes.unsqueeze(-1))
+        """moving averages of the class statistics (decay ``embedding_ema_decay``), then embedding row = average sum /
+        Laplace-smoothed average count (reference conditional_gaussian.py:106-120)"""
+        tracked = (self._size, self._mu_avg, self._log_std_avg)
+        for average, batch_sum in zip(tracked, self._class_sums(q, labels)):
+            utils.ema_inplace(average, batch_sum, decay=self.decay)
+        counts = utils.laplace_smoothing(self._size, self.num_classes, self.eps).unsqueeze(-1)
+        for embedding, average in ((self._mu, self._mu_avg), (self._log_std, self._log_std_avg)):
+            embedding.weight.copy_(average / counts)
 
     def forward(self, x: Tensor, step: int, labels: Tensor, eps: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, dict]:  # noqa
         # loss_coeff * annealing is folded into the kernel, as in GaussianPrior.forward

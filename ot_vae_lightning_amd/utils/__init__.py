@@ -16,7 +16,7 @@ from torch import Tensor
 
 __all__ = ["DDPMixin", "FilterKwargs", "hasarg", "replicate_batch", "mean_replicated_batch", "std_replicated_batch",
            "ema", "laplace_smoothing", "permute_and_flatten", "unflatten_and_unpermute", "unsqueeze_like", "ddp_reduce_sum",
-           "ddp_gather_all", "apply_to_collection"]
+           "ddp_gather_all", "apply_to_collection", "ema_inplace", "VectorLayout"]
 
 
 def _dist_on() -> bool:
@@ -178,6 +178,38 @@ def unflatten_and_unpermute(xr: Tensor, orig_shape: Sequence[int], permute_dims:
         else:
             pmap[dim] = len(rest) + 1 + list(permute_dims).index(dim)
     return x.permute(*pmap).contiguous()
+
+
+class VectorLayout:
+    """How a latent tensor [B, *size] is cut into vectors: the axes in ``vector_dims`` (1-based, the batch axis is 0) are
+    flattened into the vector, the remaining ones enumerate *positions*.  Shared by everything that runs a per-vector
+    model over latents (``prior.CodebookPrior``, ``ot.LatentTransport``):
+
+        batch_first=False                      [B, *size] -> [positions, B, dim]    one model per position
+        batch_first=True, flatten_batch=True   [B, *size] -> [B * positions, dim]   one model for all positions
+    """
+
+    def __init__(self, size: Sequence[int], vector_dims: Sequence[int], what: str = "vector_dims", *,
+                 batch_first: bool = False, flatten_batch: bool = False):
+        self.size = tuple(int(s) for s in size)
+        every = list(range(1, len(self.size) + 1))
+        if not set(vector_dims).issubset(every):
+            raise ValueError(f"latents of size {self.size} have {len(self.size) + 1} dimensions with the batch: `{what}` "
+                             f"must be a subset of {every}, given {tuple(vector_dims)}")
+        self.vector_dims = tuple(vector_dims)
+        self.position_dims = tuple(d for d in every if d not in self.vector_dims)
+        self.event_shape = torch.Size([self.size[d - 1] for d in self.vector_dims])
+        self.batch_shape = torch.Size([self.size[d - 1] for d in self.position_dims])
+        self.dim = int(np.prod(self.event_shape))
+        self.positions = int(np.prod(self.batch_shape))
+        self._how = dict(permute_dims=self.vector_dims, batch_first=batch_first,
+                         flatten_batch=flatten_batch and len(self.position_dims) > 0)
+
+    def split(self, latents: Tensor) -> Tensor:
+        return permute_and_flatten(latents, **self._how)
+
+    def join(self, vectors: Tensor) -> Tensor:
+        return unflatten_and_unpermute(vectors, orig_shape=torch.Size([-1, *self.size]), **self._how)
 
 
 def unsqueeze_like(tensor: Tensor, like: Tensor) -> Tensor:

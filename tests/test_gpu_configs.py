@@ -451,6 +451,9 @@ def test_dp_overlap_two_phase_backward_equals_single_phase(A):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _DP_OVERLAP_CHECK], capture_output=True, text=True,
                        timeout=600)
+    if r.returncode != 0 and os.path.isdir(os.path.join(root, "gpurun_out")):
+        with open(os.path.join(root, "gpurun_out", "dp_overlap_fail.log"), "w") as f:
+            f.write(r.stdout + "\n==== stderr ====\n" + r.stderr)
     assert r.returncode == 0 and "DP-OVERLAP-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 
 
