@@ -66,6 +66,32 @@ class VisionModule(_Base):
         self.log_dict(logs, rank_zero_only=True, prog_bar=True, logger=True, sync_dist=False)
         return {"loss": loss, **logs, **pbatch}
 
+    # ---- checkpoints
+    _CARRIED_IN_CHECKPOINT = ("inference_preprocess", "inference_postprocess")
+
+    def setup(self, stage=None):
+        """load every ``{attribute: PartialCheckpoint}`` given at construction (Lightning calls this before fit/test;
+        a host loop calls it once itself)"""
+        for attr, partial in (self.checkpoints or {}).items():
+            partial.load_attribute(self, attr)
+
+    def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        checkpoint.update({k: getattr(self, k) for k in self._CARRIED_IN_CHECKPOINT if getattr(self, k) is not None})
+
+    def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        for k in self._CARRIED_IN_CHECKPOINT:
+            if k in checkpoint:
+                setattr(self, k, checkpoint[k])
+
+    def export_checkpoint(self, path: str) -> None:
+        """what a Lightning ``ModelCheckpoint`` would write for this module, reduced to what another process needs to
+        restore it: ``{'state_dict', 'global_step'}`` plus the inference transforms.  The keys are the reference's, so
+        the file loads into the reference's modules as well (and through ``PartialCheckpoint`` into parts of them)."""
+        blob = {"state_dict": {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                "global_step": int(self.global_step)}
+        self.on_save_checkpoint(blob)
+        torch.save(blob, path)
+
     @property
     def inference(self):
         return self._inference_flag

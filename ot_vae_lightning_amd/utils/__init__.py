@@ -16,7 +16,7 @@ from torch import Tensor
 
 __all__ = ["DDPMixin", "FilterKwargs", "hasarg", "replicate_batch", "mean_replicated_batch", "std_replicated_batch",
            "ema", "laplace_smoothing", "permute_and_flatten", "unflatten_and_unpermute", "unsqueeze_like", "ddp_reduce_sum",
-           "ddp_gather_all", "apply_to_collection", "ema_inplace", "VectorLayout"]
+           "ddp_gather_all", "apply_to_collection", "ema_inplace", "VectorLayout", "PartialCheckpoint", "human_format"]
 
 
 def _dist_on() -> bool:
@@ -217,3 +217,6 @@ def unsqueeze_like(tensor: Tensor, like: Tensor) -> Tensor:
     if n < 0:
         raise ValueError(f"tensor.ndim={tensor.ndim} > like.ndim={like.ndim}")
     return tensor if n == 0 else tensor[(...,) + (None,) * n]
+
+
+from .partial_checkpoint import PartialCheckpoint, human_format  # noqa: E402
