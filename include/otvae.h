@@ -163,6 +163,21 @@ int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int C, float sc
 int otvae_attn_bwd_scaled(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux, int N,
                           int T, int H, int C, float scale, float* gqkv, void* stream);
 
+/* Self-attention with dropout on the attention probabilities: nn.MultiheadAttention(dropout=p) in training mode, which is
+ * how the reference's ViT builds every layer (networks/vit.py:157-172 hand `dropout` to nn.TransformerEncoderLayer;
+ * configs/vae/vit.yaml trains with 0.1).  P = softmax(scale * q k^T), out = (P o keep / (1-p)) v, keep ~ Bernoulli(1-p).
+ * The T x T mask is never stored: keep[t][s] is a counter-based hash of (call key, slice, t, s) that the backward pass
+ * recomputes.  key: device int64[2] {seed, call counter} -- device memory, so that a captured hipGraph draws a fresh mask
+ * on every replay once the host bumps the counter with a captured add; stream_id (0..4094) tells call sites apart.  The
+ * forward writes the call key it derived to used[0] (device int64[1]); the backward and _mask read it from there.
+ * lse is the natural log of the UN-dropped row sums.  T <= 256 and T*(2C+3) <= 16384; C in {1,2,4,8,16,32}.
+ * otvae_attn_dropout_mask writes keep as uint8 [N][H][T][T] (test / debugging aid). */
+int otvae_attn_dropout_fwd(const float* qkv, int N, int T, int H, int C, float scale, float p, const int64_t* key,
+                           int stream_id, float* out, float* lse, int64_t* used, void* stream);
+int otvae_attn_dropout_bwd(const float* qkv, const float* out, const float* lse, const float* gout, int N, int T, int H,
+                           int C, float scale, float p, const int64_t* used, float* gqkv, void* stream);
+int otvae_attn_dropout_mask(int N, int T, int H, float p, const int64_t* used, uint8_t* keep, void* stream);
+
 /* ---- LayerNorm over the last dimension (the token streams of the ViT: networks/vit.py:38,54 and the two norms of each
  * nn.TransformerEncoderLayer, :169-172; torch.nn.functional.layer_norm arithmetic) ---------------------------------------
  * y[m][:] = (s - mean(s)) * rstd(s) * gamma + beta with s = x[m][:] + res[m][:] (res nullable: the "x + sublayer(x)" of the

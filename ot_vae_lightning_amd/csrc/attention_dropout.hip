@@ -1,0 +1,289 @@
+// Self-attention with dropout on the attention probabilities: what nn.MultiheadAttention(dropout=p) computes in training
+// mode, which is how the reference's ViT builds its layers (networks/vit.py:157-172 pass `dropout` to every
+// TransformerEncoderLayer; configs/vae/vit.yaml trains with 0.1).
+//
+//   P = softmax(q k^T * scale);  P' = P o keep / (1 - p);  out = P' v          keep[t][s] ~ Bernoulli(1 - p)
+//
+// The T x T mask is never stored: keep[t][s] is a counter-based hash of (call key, slice, t, s), recomputed by the
+// backward pass.  The call key is derived on the device from `key` = {seed, call counter} (int64[2] in device memory,
+// so that a captured hipGraph draws fresh masks on every replay: the host bumps the counter with a captured add) and a
+// per-call-site `stream_id`; the forward kernel leaves the key it used in `used[0]` for its backward.
+//
+// Same layouts as attention.hip: qkv [N][T][3*H*C] (q | k | v, head-major), out [N][T][H*C], lse [N][H][T] (natural log
+// of the un-dropped row sums).  One thread per (slice, token); a slice = one (image, head), its records staged in LDS.
+// Written for the ViT shapes (T <= 256 tokens, head width up to 32); these are not the CNN's hot attention kernels and
+// carry none of their specialisations.
+#include "common.h"
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+#define ADROP_LDS_FLOATS 16384  // 64 KiB of dynamic LDS
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {  // a full-avalanche 32-bit finaliser
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t call_key(const int64_t* __restrict__ key, int stream_id) {  // splitmix64 finaliser
+    uint64_t s = (uint64_t)key[0] + 0x9E3779B97F4A7C15ull * ((uint64_t)key[1] * 4096ull + (uint64_t)stream_id + 1ull);
+    s ^= s >> 30;
+    s *= 0xBF58476D1CE4E5B9ull;
+    s ^= s >> 27;
+    s *= 0x94D049BB133111EBull;
+    s ^= s >> 31;
+    return s;
+}
+
+// row = slice * T + query token
+__device__ __forceinline__ uint32_t row_hash(uint64_t ck, uint32_t row) { return mix32(row ^ (uint32_t)ck) ^ (uint32_t)(ck >> 32); }
+__device__ __forceinline__ bool keep_pair(uint32_t rh, int s, uint32_t thresh) {
+    return mix32(rh + (uint32_t)s * 0x9E3779B9U) >= thresh;
+}
+
+template <int C>
+__device__ __forceinline__ float dotr(const float (&a)[C], const float* __restrict__ b) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) s = fmaf(a[c], b[c], s);
+    return s;
+}
+
+// {k[C], v[C]} records of the block's slices -> sm[sl][t][RS]
+template <int C, int RS>
+__device__ __forceinline__ void stage_keys(float* __restrict__ sm, const float* __restrict__ qkv, long slice0, int nsl, int T, int H) {
+    const int HC = H * C, W3 = 3 * HC, per = T * 2 * C;
+    for (int e = threadIdx.x; e < nsl * per; e += 256) {
+        const int sl = e / per, r = e - sl * per;
+        const int t = r / (2 * C), j = r - t * 2 * C;
+        const long s = slice0 + sl, n = s / H;
+        const int h = (int)(s - n * H);
+        sm[(sl * T + t) * RS + j] = qkv[(n * T + t) * W3 + HC + (j / C) * HC + h * C + (j % C)];
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void attn_drop_fwd_kernel(const float* __restrict__ qkv, int N, int T, int H, int SPB, float scale,
+                                                            uint32_t thresh, float inv_keep, const int64_t* __restrict__ key,
+                                                            int stream_id, int64_t* __restrict__ used, float* __restrict__ out,
+                                                            float* __restrict__ lse) {
+    extern __shared__ __align__(16) float sm[];
+    constexpr int RS = 2 * C;
+    const int HC = H * C, W3 = 3 * HC;
+    const long total = (long)N * H, slice0 = (long)blockIdx.x * SPB;
+    const int nsl = (int)min((long)SPB, total - slice0);
+    stage_keys<C, RS>(sm, qkv, slice0, nsl, T, H);
+    const uint64_t ck = call_key(key, stream_id);
+    if (blockIdx.x == 0 && threadIdx.x == 0) used[0] = (int64_t)ck;
+    __syncthreads();
+    const int sl = threadIdx.x / T, t = threadIdx.x - sl * T;
+    if (sl >= nsl) return;  // no barrier below
+    const long s = slice0 + sl, n = s / H;
+    const int h = (int)(s - n * H);
+    const float* kv = sm + (size_t)sl * T * RS;
+    float q[C], acc[C];
+    const float qs = scale * LOG2E;  // scores in the log2 domain: exp is a bare v_exp_f32
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        q[c] = qkv[(n * T + t) * W3 + h * C + c] * qs;
+        acc[c] = 0.f;
+    }
+    float mx = -INFINITY;
+    for (int j = 0; j < T; ++j) mx = fmaxf(mx, dotr<C>(q, kv + j * RS));
+    const uint32_t rh = row_hash(ck, (uint32_t)(s * T + t));
+    float l = 0.f;
+    for (int j = 0; j < T; ++j) {
+        const float* r = kv + j * RS;
+        const float p = EXP2(dotr<C>(q, r) - mx);
+        l += p;  // the softmax normaliser sees every key; only the value sum is thinned
+        const float w = keep_pair(rh, j, thresh) ? p : 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = fmaf(w, r[C + c], acc[c]);
+    }
+    const float norm = inv_keep / l;
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[(n * T + t) * HC + h * C + c] = acc[c] * norm;
+    lse[s * T + t] = mx * LN2 + __logf(l);
+}
+
+// Phase A (thread = query t): dq[t] = scale * sum_s dS[t][s] k[s], dS = P o (dP - delta), dP[t][s] = keep/(1-p) * gout[t].v[s],
+//   delta[t] = sum_s P dP = gout[t].out[t]  (P' and dP carry the same mask, so the identity of the un-dropped case holds).
+// Phase B (thread = key s): the block's LDS is re-filled with the query-side records {q, gout, lse, delta, row hash} straight
+//   from the registers of phase A;  dv[s] = sum_t P'[t][s] gout[t],  dk[s] = scale * sum_t dS[t][s] q[t].
+template <int C>
+__global__ __launch_bounds__(256) void attn_drop_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                            const float* __restrict__ lse, const float* __restrict__ gout, int N,
+                                                            int T, int H, int SPB, float scale, uint32_t thresh, float inv_keep,
+                                                            const int64_t* __restrict__ used, float* __restrict__ gqkv) {
+    extern __shared__ __align__(16) float sm[];
+    constexpr int RS = 2 * C + 3;
+    const int HC = H * C, W3 = 3 * HC;
+    const long total = (long)N * H, slice0 = (long)blockIdx.x * SPB;
+    const int nsl = (int)min((long)SPB, total - slice0);
+    stage_keys<C, RS>(sm, qkv, slice0, nsl, T, H);
+    const uint64_t ck = (uint64_t)used[0];
+    __syncthreads();
+    const int sl = threadIdx.x / T, t = threadIdx.x - sl * T;
+    const bool active = sl < nsl;
+    const long s = slice0 + (active ? sl : 0), n = s / H;
+    const int h = (int)(s - n * H);
+    float* rec = sm + (size_t)(active ? sl : 0) * T * RS;
+    const float qs = scale * LOG2E;
+    float q[C], g[C];
+    float L2 = 0.f, delta = 0.f;
+    uint32_t rh = 0;
+    if (active) {
+        float dq[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            q[c] = qkv[(n * T + t) * W3 + h * C + c];
+            g[c] = gout[(n * T + t) * HC + h * C + c];
+            delta = fmaf(g[c], out[(n * T + t) * HC + h * C + c], delta);
+            dq[c] = 0.f;
+        }
+        L2 = lse[s * T + t] * LOG2E;
+        rh = row_hash(ck, (uint32_t)(s * T + t));
+        for (int j = 0; j < T; ++j) {
+            const float* r = rec + j * RS;
+            const float p = EXP2(fmaf(dotr<C>(q, r), qs, -L2));
+            const float dp = keep_pair(rh, j, thresh) ? dotr<C>(g, r + C) * inv_keep : 0.f;
+            const float ds = p * (dp - delta);
+#pragma unroll
+            for (int c = 0; c < C; ++c) dq[c] = fmaf(ds, r[c], dq[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) gqkv[(n * T + t) * W3 + h * C + c] = dq[c] * scale;
+    }
+    __syncthreads();  // every thread of the block: the key records are dead from here on
+    if (active) {
+        float* mine = rec + t * RS;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            mine[c] = q[c];
+            mine[C + c] = g[c];
+        }
+        mine[2 * C] = L2;
+        mine[2 * C + 1] = delta;
+        mine[2 * C + 2] = __uint_as_float(rh);
+    }
+    __syncthreads();
+    if (!active) return;
+    float k[C], v[C], dk[C], dv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        k[c] = qkv[(n * T + t) * W3 + HC + h * C + c];
+        v[c] = qkv[(n * T + t) * W3 + 2 * HC + h * C + c];
+        dk[c] = 0.f;
+        dv[c] = 0.f;
+    }
+    for (int i = 0; i < T; ++i) {
+        const float* r = rec + i * RS;
+        const float p = EXP2(fmaf(dotr<C>(k, r), qs, -r[2 * C]));
+        const bool keep = keep_pair(__float_as_uint(r[2 * C + 2]), t, thresh);
+        const float w = keep ? p * inv_keep : 0.f;
+        const float dp = keep ? dotr<C>(v, r + C) * inv_keep : 0.f;
+        const float ds = p * (dp - r[2 * C + 1]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            dv[c] = fmaf(w, r[C + c], dv[c]);
+            dk[c] = fmaf(ds, r[c], dk[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        gqkv[(n * T + t) * W3 + HC + h * C + c] = dk[c] * scale;
+        gqkv[(n * T + t) * W3 + 2 * HC + h * C + c] = dv[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_drop_mask_kernel(long rows, int T, uint32_t thresh, const int64_t* __restrict__ used,
+                                                             uint8_t* __restrict__ keep) {
+    const uint64_t ck = (uint64_t)used[0];
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * T) return;
+    const long row = e / T;
+    keep[e] = keep_pair(row_hash(ck, (uint32_t)row), (int)(e - row * T), thresh) ? 1 : 0;
+}
+
+static int adrop_plan(const char* who, int N, int T, int H, int C, float p, int rs, int* spb, uint32_t* thresh) {
+    OTVAE_REQUIRE(N > 0 && T > 0 && H > 0 && C > 0, "%s: bad sizes", who);
+    OTVAE_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout probability must be in [0, 1)", who);
+    OTVAE_REQUIRE((int64_t)N * H * T < ((int64_t)1 << 32), "%s: N*H*T must stay below 2^32 (the mask hash counts rows in 32 bits)", who);
+    if (T > 256 || T * rs > ADROP_LDS_FLOATS) {
+        otvae_set_error("%s: a slice of T=%d tokens, head width %d does not fit (T <= 256 and T*(2C+3) <= %d floats of LDS)", who, T,
+                        C, ADROP_LDS_FLOATS);
+        return OTVAE_EUNSUPPORTED;
+    }
+    int s = 256 / T, cap = ADROP_LDS_FLOATS / (T * rs);
+    *spb = s < cap ? s : cap;
+    const double scaled = (double)p * 4294967296.0;
+    *thresh = scaled >= 4294967295.0 ? 4294967295u : (uint32_t)scaled;
+    return OTVAE_OK;
+}
+
+#define ADROP_C_SWITCH(C_, MACRO)                                                                                      \
+    switch (C_) {                                                                                                      \
+        case 1: MACRO(1); break;                                                                                       \
+        case 2: MACRO(2); break;                                                                                       \
+        case 4: MACRO(4); break;                                                                                       \
+        case 8: MACRO(8); break;                                                                                       \
+        case 16: MACRO(16); break;                                                                                     \
+        case 32: MACRO(32); break;                                                                                     \
+        default:                                                                                                       \
+            otvae_set_error("attention with dropout: head width C=%d not instantiated (1,2,4,8,16,32)", C_);           \
+            return OTVAE_EUNSUPPORTED;                                                                                 \
+    }
+
+extern "C" int otvae_attn_dropout_fwd(const float* qkv, int N, int T, int H, int C, float scale, float p, const int64_t* key,
+                                      int stream_id, float* out, float* lse, int64_t* used, void* stream) {
+    OTVAE_REQUIRE(qkv && out && lse && key && used, "otvae_attn_dropout_fwd: NULL tensor");
+    OTVAE_REQUIRE(scale > 0.f && stream_id >= 0 && stream_id < 4095, "otvae_attn_dropout_fwd: bad scale or stream_id");
+    int spb;
+    uint32_t thresh;
+    int rc = adrop_plan("otvae_attn_dropout_fwd", N, T, H, C, p, 2 * C + 3, &spb, &thresh);  // the backward's plan: same slices
+    if (rc) return rc;
+    const int grid = (int)cdiv((int64_t)N * H, spb);
+    const size_t lds = (size_t)spb * T * 2 * C * sizeof(float);
+    const float inv_keep = 1.f / (1.f - p);
+#define FWD_K(CC) \
+    attn_drop_fwd_kernel<CC><<<grid, 256, lds, (hipStream_t)stream>>>(qkv, N, T, H, spb, scale, thresh, inv_keep, key, stream_id, used, out, lse)
+    ADROP_C_SWITCH(C, FWD_K)
+#undef FWD_K
+    OTVAE_CHECK_LAUNCH("otvae_attn_dropout_fwd");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_attn_dropout_bwd(const float* qkv, const float* out, const float* lse, const float* gout, int N, int T, int H,
+                                      int C, float scale, float p, const int64_t* used, float* gqkv, void* stream) {
+    OTVAE_REQUIRE(qkv && out && lse && gout && used && gqkv, "otvae_attn_dropout_bwd: NULL tensor");
+    OTVAE_REQUIRE(scale > 0.f, "otvae_attn_dropout_bwd: scale must be positive");
+    int spb;
+    uint32_t thresh;
+    int rc = adrop_plan("otvae_attn_dropout_bwd", N, T, H, C, p, 2 * C + 3, &spb, &thresh);
+    if (rc) return rc;
+    const int grid = (int)cdiv((int64_t)N * H, spb);
+    const size_t lds = (size_t)spb * T * (2 * C + 3) * sizeof(float);
+    const float inv_keep = 1.f / (1.f - p);
+#define BWD_K(CC) \
+    attn_drop_bwd_kernel<CC><<<grid, 256, lds, (hipStream_t)stream>>>(qkv, out, lse, gout, N, T, H, spb, scale, thresh, inv_keep, used, gqkv)
+    ADROP_C_SWITCH(C, BWD_K)
+#undef BWD_K
+    OTVAE_CHECK_LAUNCH("otvae_attn_dropout_bwd");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_attn_dropout_mask(int N, int T, int H, float p, const int64_t* used, uint8_t* keep, void* stream) {
+    OTVAE_REQUIRE(used && keep, "otvae_attn_dropout_mask: NULL tensor");
+    int spb;
+    uint32_t thresh;
+    int rc = adrop_plan("otvae_attn_dropout_mask", N, T, H, 1, p, 5, &spb, &thresh);
+    if (rc) return rc;
+    const long rows = (long)N * H * T;
+    attn_drop_mask_kernel<<<(int)cdiv((int64_t)rows * T, 256), 256, 0, (hipStream_t)stream>>>(rows, T, thresh, used, keep);
+    OTVAE_CHECK_LAUNCH("otvae_attn_dropout_mask");
+    return OTVAE_OK;
+}

@@ -10,8 +10,11 @@ drawn by constructing the very torch modules the reference constructs, in its or
 reference's initial weights (note that ``nn.TransformerEncoder`` deep-copies ONE layer: all layers start identical).
 
 Not implemented (they raise): the cross-attention variant (``preprocess_depth``), ``causal_mask``, ``time_dependant``.
-Dropout > 0 in training mode is applied with ``torch.nn.functional.dropout`` between the kernels (its random stream
-differs from the CPU's anyway); parity tests run with dropout 0 or in eval mode."""
+Dropout > 0 in training mode: the three dropouts of a layer that act on token tensors are applied with
+``torch.nn.functional.dropout`` between the kernels; the fourth, nn.MultiheadAttention's dropout on the attention
+probabilities, happens inside the attention kernel (``otvae_attn_dropout_*``: the mask is a hash recomputed by the
+backward pass, never stored).  The random streams differ from the CPU reference's, so value parity is tested with
+dropout 0 / eval mode, and the dropout path against a reference that is handed the kernel's own mask."""
 import warnings
 from typing import Optional, Sequence, Tuple, Union
 
@@ -74,9 +77,9 @@ class _SelfAttention(nn.Module):
         self.in_proj_bias = nn.Parameter(like.in_proj_bias.data.clone())
         self.out_proj = TokenLinear(like.embed_dim, like.embed_dim, like=like.out_proj)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, dropout_p: float = 0.0, dropout_key: Optional[Tensor] = None, stream_id: int = 0) -> Tensor:
         qkv = HF.linear_tokens(x, self.in_proj_weight, self.in_proj_bias)
-        return self.out_proj(HF.mha_attention_tokens(qkv, self.num_heads))
+        return self.out_proj(HF.mha_attention_tokens(qkv, self.num_heads, dropout_p, dropout_key, stream_id))
 
 
 class TokenEncoderLayer(nn.Module):
@@ -96,8 +99,10 @@ class TokenEncoderLayer(nn.Module):
     def _drop(self, x: Tensor) -> Tensor:
         return F.dropout(x, self.p, True) if (self.training and self.p > 0) else x
 
-    def forward(self, x: Tensor) -> Tensor:
-        x = self.norm1(self._drop(self.self_attn(x)), residual=x)
+    def forward(self, x: Tensor, dropout_key: Optional[Tensor] = None, stream_id: int = 0) -> Tensor:
+        # nn.MultiheadAttention drops attention probabilities with the layer's p as well: inside the attention kernel
+        p_attn = self.p if (self.training and dropout_key is not None) else 0.0
+        x = self.norm1(self._drop(self.self_attn(x, p_attn, dropout_key, stream_id)), residual=x)
         h = self.linear1(x)
         if self.training and self.p > 0:  # dropout sits between the ReLU and linear2: the activation cannot stay fused
             f = self.linear2(self._drop(torch.relu(h)))
@@ -115,9 +120,9 @@ class _Encoder(nn.Module):
         if like.norm is not None:
             raise NotImplementedError("a final norm on the TransformerEncoder is not part of the reference's ViT")
 
-    def forward(self, x: Tensor) -> Tensor:
-        for layer in self.layers:
-            x = layer(x)
+    def forward(self, x: Tensor, dropout_key: Optional[Tensor] = None) -> Tensor:
+        for i, layer in enumerate(self.layers):
+            x = layer(x, dropout_key, i)
         return x
 
 
@@ -185,6 +190,7 @@ class ViT(nn.Module):
         if time_dependant:
             raise NotImplementedError("`time_dependant` (Fourier time token) is not implemented on the MI355X path")
         self.dim, self.causal_mask = dim, causal_mask
+        self.attn_dropout = float(dropout)
         image_height, image_width = pair(image_size)
         mlp_dim = mlp_dim or dim * 4
         if patch_size is None:
@@ -233,6 +239,18 @@ class ViT(nn.Module):
             self.__dict__["_out_index_cache"] = cached
         return cached
 
+    def _next_dropout_key(self, device) -> Optional[Tensor]:
+        """{seed, call counter} for the attention-probability dropout of this forward pass, or None when nothing is
+        dropped.  Seeded from torch's default generator on first use (an eager step: it reads the host generator); the
+        counter advances by a device-side add, so a captured step draws new masks on every replay."""
+        if not self.training or self.attn_dropout <= 0:
+            return None
+        key = self.__dict__.get("_dropout_key")
+        if key is None or key.device != device:
+            key = self.__dict__["_dropout_key"] = HF.new_dropout_key(device)
+        key[1:].add_(1)
+        return key
+
     def _add_class_token(self, x: Tensor, labels: Optional[Tensor]) -> Tensor:
         if labels is not None and self.class_token is None:
             warnings.warn("given conditional argument `labels` but `self.class_token` is None. To enable a class-conditioned "
@@ -260,10 +278,11 @@ class ViT(nn.Module):
         x = self._add_time_token(x, time)
         x = self.positional_embed(x)
         idx = self.output_tokens_indices
+        tokens = self.transformer(x, self._next_dropout_key(x.device))
         if idx == list(range(idx[0], idx[0] + len(idx))):  # one run of tokens: a slice (an index LIST would be uploaded from
-            out = self.transformer(x)[:, idx[0]:idx[0] + len(idx)]  # the host on every call, which a graph capture cannot hold)
+            out = tokens[:, idx[0]:idx[0] + len(idx)]      # the host on every call, which a graph capture cannot hold)
         else:
-            out = self.transformer(x)[:, self._out_index(x.device)]
+            out = tokens[:, self._out_index(x.device)]
         if not isinstance(self.embed_to_patch, nn.Identity):
             out = out[:, -self.num_patches:]
         return self.embed_to_patch(out)

@@ -406,6 +406,32 @@ def test_conditional_vit_vae_trains_through_hip_trainer(A):
                            prior=A.GaussianPrior()).cuda(), batch_shape=(4, 1, 16, 16), use_graph=False).step(labels=y)
 
 
+def test_vit_vae_with_dropout_draws_fresh_masks_in_a_captured_step(A):
+    """The reference's ViT configuration trains with dropout 0.1 (configs/vae/vit.yaml): token dropouts between the
+    kernels, attention-probability dropout inside ``otvae_attn_dropout_*``.  Through the captured HipTrainer step every
+    replay must draw new masks (the mask key's counter lives in device memory and is advanced by a captured add), so the
+    same batch gives different losses step after step; in eval mode nothing is dropped and the output is deterministic."""
+    cfg = dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, dropout=0.1, emb_dropout=0.1)
+    x = normal((64, 3, 16, 16), 81).cuda()
+    eps = normal((64, 1, 32), 82).cuda()
+    torch.manual_seed(6)
+    enc = A.ViT(n_embed_tokens=2, n_input_tokens=None, output_tokens="embed", patch_to_embed=True, embed_to_patch=False, **cfg)
+    dec = A.ViT(n_embed_tokens=None, n_input_tokens=1, output_tokens="embed", patch_to_embed=False, embed_to_patch=True, **cfg)
+    model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+    tr = A.HipTrainer(model, batch_shape=(64, 3, 16, 16), use_graph=True, lr=0.0)      # lr 0: only the masks differ between steps
+    losses = torch.stack([tr.step(x, eps).clone() for _ in range(5)])[:, 1]           # reconstruction term
+    torch.cuda.synchronize()
+    assert torch.isfinite(losses).all()
+    assert len({float(v) for v in losses}) == 5, losses                                # five replays, five different masks
+    assert float(losses.max() - losses.min()) < 0.2 * float(losses.mean())             # ... of the same model on the same batch
+    key = enc.__dict__["_dropout_key"]
+    assert int(key[1]) >= 5 and key.dtype == torch.int64
+    model.eval()
+    with torch.no_grad():
+        a, b = model.encoder(x), model.encoder(x)
+    assert torch.equal(a, b)
+
+
 _DP_OVERLAP_CHECK = r"""
 import os, sys, torch
 import torch.distributed as dist

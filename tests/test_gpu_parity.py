@@ -1016,3 +1016,66 @@ def test_conditional_vit_vae_nelbo_vs_reference_golden(A):
     l2 = torch.tensor([grads[n].double().norm().item() if grads[n] is not None else 0.0 for n in names])
     rep.check("gradient norms (all parameters)", l2, g["grad_l2"], 5e-4)
     rep.finish()
+
+
+@pytest.mark.parametrize("n,t,heads,c,p", [(3, 65, 8, 32, 0.1), (5, 17, 4, 8, 0.5), (2, 100, 2, 16, 0.25), (7, 9, 3, 4, 0.1),
+                                           (2, 244, 1, 32, 0.1), (4, 33, 2, 1, 0.3)])
+def test_attention_with_dropout_matches_reference_given_its_own_mask(n, t, heads, c, p):
+    """``otvae_attn_dropout_fwd/_bwd`` (nn.MultiheadAttention's dropout on the attention probabilities, reference
+    networks/vit.py:157-172 in training mode) against plain torch arithmetic that is handed the kernel's own keep mask
+    (``otvae_attn_dropout_mask``): out = (softmax(q k^T / sqrt(C)) o keep / (1-p)) v and all three input gradients."""
+    import ot_vae_lightning_amd.functional as HF
+    rep = Report(f"attention with dropout N={n} T={t} H={heads} C={c} p={p}")
+    qkv = normal((n, t, 3 * heads * c), 700 + t).cuda().requires_grad_(True)
+    gout = normal((n, t, heads * c), 701 + t).cuda()
+    key = HF.new_dropout_key(qkv.device, seed=1234)
+    out, used = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=3, return_used=True)
+    (gq,) = torch.autograd.grad(out, qkv, gout)
+    keep = HF.attention_dropout_mask(used, n, t, heads, p)                      # [N, H, T, T]
+    frac = keep.float().mean().item()
+    sigma = (p * (1 - p) / keep.numel()) ** 0.5
+    assert abs(frac - (1 - p)) < 6 * sigma + 1e-3, (frac, 1 - p)                # Bernoulli(1-p), not merely "some mask"
+    assert abs(keep.float().mean(dim=(0, 1, 2)) - (1 - p)).max().item() < 0.2  # no key column is favoured
+    ref_in = qkv.detach().double().requires_grad_(True)
+    q, k, v = (x.reshape(n, t, heads, c).transpose(1, 2) for x in ref_in.chunk(3, dim=-1))      # [N, H, T, C]
+    prob = torch.softmax(q @ k.transpose(-1, -2) / c ** 0.5, dim=-1)
+    ref = ((prob * keep.double() / (1 - p)) @ v).transpose(1, 2).reshape(n, t, heads * c)
+    (gref,) = torch.autograd.grad(ref, ref_in, gout.double())
+    rep.check("out", out, ref.detach(), tol=2e-5)
+    rep.check("dq", gq[..., :heads * c], gref[..., :heads * c], tol=5e-5)
+    rep.check("dk", gq[..., heads * c:2 * heads * c], gref[..., heads * c:2 * heads * c], tol=5e-5)
+    rep.check("dv", gq[..., 2 * heads * c:], gref[..., 2 * heads * c:], tol=5e-5)
+    # same key, same call site: the same mask; another call site or a later counter: another mask
+    out2, used2 = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=3, return_used=True)
+    assert torch.equal(out2, out) and torch.equal(used2, used)
+    other_site = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=4, return_used=True)[1]
+    key[1:].add_(1)
+    later = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=3, return_used=True)[1]
+    masks = [HF.attention_dropout_mask(u, n, t, heads, p) for u in (used, other_site, later)]
+    for a in range(3):
+        for b in range(a + 1, 3):
+            agree = (masks[a] == masks[b]).float().mean().item()
+            assert abs(agree - (p * p + (1 - p) ** 2)) < 0.05, (a, b, agree)    # independent masks agree by chance only
+    rep.finish()
+
+
+def test_attention_dropout_zero_probability_is_the_plain_kernel_and_bad_arguments_are_refused():
+    import ot_vae_lightning_amd.functional as HF
+    from ot_vae_lightning_amd import _lib as L
+    qkv = normal((3, 20, 3 * 2 * 8), 711).cuda()
+    key = HF.new_dropout_key(qkv.device, seed=7)
+    lib = L.load()
+    out = torch.empty(3, 20, 16, device="cuda")
+    lse = torch.empty(3, 2, 20, device="cuda")
+    used = torch.empty(1, dtype=torch.int64, device="cuda")
+    rc = lib.otvae_attn_dropout_fwd(L.ptr(qkv), 3, 20, 2, 8, 8 ** -0.5, 0.0, L.ptr(key), 0, L.ptr(out), L.ptr(lse), L.ptr(used), L.stream())
+    assert rc == 0
+    plain = HF.mha_attention_tokens(qkv, 2)
+    assert (out - plain).abs().max().item() < 1e-6
+    assert HF.attention_dropout_mask(used, 3, 20, 2, 0.0).all()
+    for bad in (dict(p=1.0), dict(p=-0.1), dict(t=300), dict(c=5)):
+        t, c, p = bad.get("t", 20), bad.get("c", 8), bad.get("p", 0.1)
+        rc = lib.otvae_attn_dropout_fwd(L.ptr(qkv), 1, t, 1, c, 1.0, p, L.ptr(key), 0, L.ptr(out), L.ptr(lse), L.ptr(used), L.stream())
+        assert rc != 0, bad
+    with pytest.raises(ValueError):
+        HF.mha_attention_tokens(qkv, 2, 0.1)
