@@ -163,6 +163,15 @@ int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int C, float sc
 int otvae_attn_bwd_scaled(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux, int N,
                           int T, int H, int C, float scale, float* gqkv, void* stream);
 
+/* Element-wise dropout with the same counter-based masks (keep(row, col) of a [rows][D] tensor, D % 4 == 0), optionally
+ * fused with the ReLU in front of it: y = keep ? act(x)/(1-p) : 0.  relu != 0: the dropout(relu(linear1(x))) of a training-
+ * mode nn.TransformerEncoderLayer; relu == 0: PositionalEmbedding's embedding dropout (networks/vit.py:54-58).  The backward
+ * recomputes the mask from used[0] and reads x for the ReLU gate; otvae_layernorm_dropout_mask returns the same mask. */
+int otvae_dropout_fwd(const float* x, int64_t rows, int D, int relu, float p, const int64_t* key, int stream_id, float* y,
+                      int64_t* used, void* stream);
+int otvae_dropout_bwd(const float* x, const float* gy, int64_t rows, int D, int relu, float p, const int64_t* used, float* gx,
+                      void* stream);
+
 /* Self-attention with dropout on the attention probabilities: nn.MultiheadAttention(dropout=p) in training mode, which is
  * how the reference's ViT builds every layer (networks/vit.py:157-172 hand `dropout` to nn.TransformerEncoderLayer;
  * configs/vae/vit.yaml trains with 0.1).  P = softmax(scale * q k^T), out = (P o keep / (1-p)) v, keep ~ Bernoulli(1-p).
@@ -189,6 +198,18 @@ int otvae_layernorm_fwd(const float* x, const float* res, const float* gamma, co
 int otvae_layernorm_bwd_ws(int M, int D);
 int otvae_layernorm_bwd(const float* xs, const float* gy, const float* gamma, const float* mean, const float* rstd, int M, int D,
                         float* gx, float* dgamma, float* dbeta, float* ws, void* stream);
+/* The "x + dropout(sublayer(x))" of a training-mode nn.TransformerEncoderLayer (networks/vit.py:157-172 with dropout > 0)
+ * folded into the same kernels: s = res + x o keep / (1-p), y = LayerNorm(s).  keep(row, col) is the counter-based hash of
+ * otvae_attn_dropout_* (key = device int64[2] {seed, call counter}, stream_id per call site, the forward leaves its call key
+ * in used[0]); nothing but s is stored.  The backward returns gx = dL/ds (the residual's gradient) and
+ * gx_dropped = gx o keep / (1-p) (the sublayer output's).  otvae_layernorm_dropout_mask: keep as uint8 [M][D] (test aid). */
+int otvae_layernorm_dropout_fwd(const float* x, const float* res, const float* gamma, const float* beta, int M, int D,
+                                float eps, float p, const int64_t* key, int stream_id, float* sum_out, float* y, float* mean,
+                                float* rstd, int64_t* used, void* stream);
+int otvae_layernorm_dropout_bwd(const float* xs, const float* gy, const float* gamma, const float* mean, const float* rstd,
+                                int M, int D, float p, const int64_t* used, float* gx, float* gx_dropped, float* dgamma,
+                                float* dbeta, float* ws, void* stream);
+int otvae_layernorm_dropout_mask(int M, int D, float p, const int64_t* used, uint8_t* keep, void* stream);
 
 /* ---- GaussianPrior (prior/gaussian.py:63-96) + Prior.forward scaling (prior/base.py:74-78) ---------------- */
 /* h [B][S][2D] (S = H*W positions, channels-last) ; eps,z [B][S][D]; loss[B] = coeff * KL(q||N(0,I)) */

@@ -71,6 +71,11 @@ SIGNATURES = {
     "otvae_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]),
     "otvae_layernorm_bwd_ws": (i32, [i32, i32]),
     "otvae_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "otvae_layernorm_dropout_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "otvae_layernorm_dropout_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "otvae_layernorm_dropout_mask": (i32, [i32, i32, f32, vp, vp, vp]),
+    "otvae_dropout_fwd": (i32, [vp, i64, i32, i32, f32, vp, i32, vp, vp, vp]),
+    "otvae_dropout_bwd": (i32, [vp, vp, i64, i32, i32, f32, vp, vp, vp]),
     "otvae_gaussian_prior_fwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),
     "otvae_gaussian_prior_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     "otvae_gaussian_prior_cond_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp]),

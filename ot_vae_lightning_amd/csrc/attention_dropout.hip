@@ -14,36 +14,12 @@
 // Written for the ViT shapes (T <= 256 tokens, head width up to 32); these are not the CNN's hot attention kernels and
 // carry none of their specialisations.
 #include "common.h"
+#include "dropout_hash.h"
 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
 #define ADROP_LDS_FLOATS 16384  // 64 KiB of dynamic LDS
-
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {  // a full-avalanche 32-bit finaliser
-    x ^= x >> 16;
-    x *= 0x7feb352dU;
-    x ^= x >> 15;
-    x *= 0x846ca68bU;
-    x ^= x >> 16;
-    return x;
-}
-
-__device__ __forceinline__ uint64_t call_key(const int64_t* __restrict__ key, int stream_id) {  // splitmix64 finaliser
-    uint64_t s = (uint64_t)key[0] + 0x9E3779B97F4A7C15ull * ((uint64_t)key[1] * 4096ull + (uint64_t)stream_id + 1ull);
-    s ^= s >> 30;
-    s *= 0xBF58476D1CE4E5B9ull;
-    s ^= s >> 27;
-    s *= 0x94D049BB133111EBull;
-    s ^= s >> 31;
-    return s;
-}
-
-// row = slice * T + query token
-__device__ __forceinline__ uint32_t row_hash(uint64_t ck, uint32_t row) { return mix32(row ^ (uint32_t)ck) ^ (uint32_t)(ck >> 32); }
-__device__ __forceinline__ bool keep_pair(uint32_t rh, int s, uint32_t thresh) {
-    return mix32(rh + (uint32_t)s * 0x9E3779B9U) >= thresh;
-}
 
 template <int C>
 __device__ __forceinline__ float dotr(const float (&a)[C], const float* __restrict__ b) {
@@ -219,9 +195,10 @@ static int adrop_plan(const char* who, int N, int T, int H, int C, float p, int 
         return OTVAE_EUNSUPPORTED;
     }
     int s = 256 / T, cap = ADROP_LDS_FLOATS / (T * rs);
-    *spb = s < cap ? s : cap;
-    const double scaled = (double)p * 4294967296.0;
-    *thresh = scaled >= 4294967295.0 ? 4294967295u : (uint32_t)scaled;
+    s = s < cap ? s : cap;
+    while (s > 1 && cdiv((int64_t)N * H, s) < 512) s >>= 1;  // few slices: rather thinner blocks than idle CUs (256 of them)
+    *spb = s;
+    *thresh = dropout_threshold(p);
     return OTVAE_OK;
 }
 

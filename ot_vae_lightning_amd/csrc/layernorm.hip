@@ -6,6 +6,7 @@
 // wave reductions.  Backward: dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)); the parameter gradients are
 // column sums over all rows -- per-block partials in fixed order, then one fixed-order reduction (deterministic).
 #include "common.h"
+#include "dropout_hash.h"
 
 #define LN_MAXV 32  // values per lane (template parameter NV = 1, 2, 4 ... 32): D <= 2048
 // values per lane as a compile-time constant (the row must stay in registers: a runtime-indexed array would go to scratch)
@@ -21,13 +22,29 @@
     }
 
 
-template <int NV>
+// DROP: the sublayer output x is thinned before the residual is summed in, s = res + x o keep / (1-p) -- the
+// "x + dropout(sublayer(x))" of a training-mode nn.TransformerEncoderLayer; keep(row, col) is the hash of dropout_hash.h
+struct LnDrop {
+    uint32_t thresh;
+    float inv_keep;
+    const int64_t* key;  // forward: {seed, counter}; backward: the call key the forward left in `used`
+    int stream_id;
+    int64_t* used;
+};
+
+template <int NV, bool DROP>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int M,
                                                             int D, float eps, float* __restrict__ sum_out, float* __restrict__ y,
-                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, LnDrop dr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t rh = 0;
+    if constexpr (DROP) {
+        const uint64_t ck = call_key(dr.key, dr.stream_id);
+        if (blockIdx.x == 0 && threadIdx.x == 0) dr.used[0] = (int64_t)ck;
+        rh = row_hash(ck, (uint32_t)row);
+    }
     if (row >= M) return;
     const float* xr = x + (size_t)row * D;
     const float* rr = res ? res + (size_t)row * D : nullptr;
@@ -38,6 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     for (int k = 0; k < nv; ++k) {
         const int c = lane + 64 * k;
         float t = c < D ? xr[c] : 0.f;
+        if constexpr (DROP) t = keep_pair(rh, c, dr.thresh) ? t * dr.inv_keep : 0.f;
         if (rr && c < D) t += rr[c];
         v[k] = t;
         s += t;
@@ -73,21 +91,41 @@ extern "C" int otvae_layernorm_fwd(const float* x, const float* res, const float
     }
     OTVAE_REQUIRE(!res || sum_out, "otvae_layernorm_fwd: a residual needs sum_out (x + res is what backward reads)");
     hipStream_t st = (hipStream_t)stream;
-#define LN_FWD(NV_) layernorm_fwd_kernel<NV_><<<cdiv(M, 4), 256, 0, st>>>(x, res, gamma, beta, M, D, eps, sum_out, y, mean, rstd)
+#define LN_FWD(NV_) layernorm_fwd_kernel<NV_, false><<<cdiv(M, 4), 256, 0, st>>>(x, res, gamma, beta, M, D, eps, sum_out, y, mean, rstd, LnDrop{})
     LN_NV_SWITCH(D, LN_FWD)
 #undef LN_FWD
     OTVAE_CHECK_LAUNCH("otvae_layernorm_fwd");
     return OTVAE_OK;
 }
 
+extern "C" int otvae_layernorm_dropout_fwd(const float* x, const float* res, const float* gamma, const float* beta, int M, int D,
+                                           float eps, float p, const int64_t* key, int stream_id, float* sum_out, float* y, float* mean,
+                                           float* rstd, int64_t* used, void* stream) {
+    OTVAE_REQUIRE(x && res && gamma && beta && sum_out && y && mean && rstd && key && used && M > 0 && D > 0,
+                  "otvae_layernorm_dropout_fwd: bad argument (the residual and sum_out are required)");
+    OTVAE_REQUIRE(p >= 0.f && p < 1.f && stream_id >= 0 && stream_id < 4095, "otvae_layernorm_dropout_fwd: bad p or stream_id");
+    if (D > 64 * LN_MAXV) {
+        otvae_set_error("otvae_layernorm_dropout_fwd: D = %d unsupported (D <= %d)", D, 64 * LN_MAXV);
+        return OTVAE_EUNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const LnDrop dr = {dropout_threshold(p), 1.f / (1.f - p), key, stream_id, used};
+#define LN_FWD(NV_) layernorm_fwd_kernel<NV_, true><<<cdiv(M, 4), 256, 0, st>>>(x, res, gamma, beta, M, D, eps, sum_out, y, mean, rstd, dr)
+    LN_NV_SWITCH(D, LN_FWD)
+#undef LN_FWD
+    OTVAE_CHECK_LAUNCH("otvae_layernorm_dropout_fwd");
+    return OTVAE_OK;
+}
+
 #define LN_ROWS_PER_BLOCK 16  // rows a block of the backward kernel walks (4 per wave): enough blocks to fill the chip at ~5k rows
 
 // partial[block][2][D]: column sums of g * xhat (d gamma) and of g (d beta) over the block's rows, waves combined in order
-template <int NV>
+// DROP: gx is the gradient of the summed row (= of the residual); gxd = gx o keep / (1-p) is that of the thinned operand
+template <int NV, bool DROP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ gy,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int M, int D, float* __restrict__ gx,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, float* __restrict__ gxd, LnDrop dr) {
     extern __shared__ float ln_red[];  // [4 waves][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int nv = NV;
@@ -118,7 +156,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < nv; ++k) {
             const int c = lane + 64 * k;
-            if (c < D) gx[(size_t)row * D + c] = rs * (gg[k] - s1 - xh[k] * s2);
+            if (c < D) {
+                const float d = rs * (gg[k] - s1 - xh[k] * s2);
+                gx[(size_t)row * D + c] = d;
+                if constexpr (DROP)
+                    gxd[(size_t)row * D + c] =
+                        keep_pair(row_hash((uint64_t)dr.key[0], (uint32_t)row), c, dr.thresh) ? d * dr.inv_keep : 0.f;
+            }
         }
     }
 #pragma unroll
@@ -177,11 +221,51 @@ extern "C" int otvae_layernorm_bwd(const float* xs, const float* gy, const float
     }
     hipStream_t st = (hipStream_t)stream;
     const int P = cdiv(M, LN_ROWS_PER_BLOCK);
-#define LN_BWD(NV_) layernorm_bwd_kernel<NV_><<<P, 256, (size_t)8 * D * sizeof(float), st>>>(xs, gy, gamma, mean, rstd, M, D, gx, ws)
+#define LN_BWD(NV_) \
+    layernorm_bwd_kernel<NV_, false><<<P, 256, (size_t)8 * D * sizeof(float), st>>>(xs, gy, gamma, mean, rstd, M, D, gx, ws, nullptr, LnDrop{})
     LN_NV_SWITCH(D, LN_BWD)
 #undef LN_BWD
     OTVAE_CHECK_LAUNCH("otvae_layernorm_bwd");
     layernorm_param_reduce_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>(ws, P, D, dgamma, dbeta);
     OTVAE_CHECK_LAUNCH("otvae_layernorm_bwd(reduce)");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_layernorm_dropout_bwd(const float* xs, const float* gy, const float* gamma, const float* mean, const float* rstd,
+                                           int M, int D, float p, const int64_t* used, float* gx, float* gx_dropped, float* dgamma,
+                                           float* dbeta, float* ws, void* stream) {
+    OTVAE_REQUIRE(xs && gy && gamma && mean && rstd && used && gx && gx_dropped && dgamma && dbeta && ws && M > 0 && D > 0,
+                  "otvae_layernorm_dropout_bwd: bad argument");
+    OTVAE_REQUIRE(p >= 0.f && p < 1.f, "otvae_layernorm_dropout_bwd: dropout probability must be in [0, 1)");
+    if (D > 64 * LN_MAXV || (size_t)8 * D * sizeof(float) > 64 * 1024) {
+        otvae_set_error("otvae_layernorm_dropout_bwd: D = %d unsupported (D <= 2048)", D);
+        return OTVAE_EUNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int P = cdiv(M, LN_ROWS_PER_BLOCK);
+    const LnDrop dr = {dropout_threshold(p), 1.f / (1.f - p), used, 0, nullptr};
+#define LN_BWD(NV_) \
+    layernorm_bwd_kernel<NV_, true><<<P, 256, (size_t)8 * D * sizeof(float), st>>>(xs, gy, gamma, mean, rstd, M, D, gx, ws, gx_dropped, dr)
+    LN_NV_SWITCH(D, LN_BWD)
+#undef LN_BWD
+    OTVAE_CHECK_LAUNCH("otvae_layernorm_dropout_bwd");
+    layernorm_param_reduce_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>(ws, P, D, dgamma, dbeta);
+    OTVAE_CHECK_LAUNCH("otvae_layernorm_dropout_bwd(reduce)");
+    return OTVAE_OK;
+}
+
+// keep mask of a otvae_layernorm_dropout_fwd call as uint8 [M][D] (test aid)
+__global__ __launch_bounds__(256) void layernorm_dropout_mask_kernel(int M, int D, uint32_t thresh, const int64_t* __restrict__ used,
+                                                                     uint8_t* __restrict__ keep) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)M * D) return;
+    const int row = (int)(e / D);
+    keep[e] = keep_pair(row_hash((uint64_t)used[0], (uint32_t)row), (int)(e - (long)row * D), thresh) ? 1 : 0;
+}
+
+extern "C" int otvae_layernorm_dropout_mask(int M, int D, float p, const int64_t* used, uint8_t* keep, void* stream) {
+    OTVAE_REQUIRE(used && keep && M > 0 && D > 0 && p >= 0.f && p < 1.f, "otvae_layernorm_dropout_mask: bad argument");
+    layernorm_dropout_mask_kernel<<<(int)cdiv((int64_t)M * D, 256), 256, 0, (hipStream_t)stream>>>(M, D, dropout_threshold(p), used, keep);
+    OTVAE_CHECK_LAUNCH("otvae_layernorm_dropout_mask");
     return OTVAE_OK;
 }

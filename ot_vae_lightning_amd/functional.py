@@ -516,14 +516,102 @@ class _LayerNormFn(torch.autograd.Function):
         return gx, (gx if ctx.has_res else None), dgamma, dbeta, None
 
 
-def layer_norm_tokens(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, residual: Optional[Tensor] = None) -> Tensor:
-    """LayerNorm over the last dimension of ``x (+ residual)`` (torch.nn.functional.layer_norm arithmetic)."""
+class _LayerNormDropoutFn(torch.autograd.Function):
+    """y = LayerNorm(res + dropout(x)) in one kernel; the mask is a hash the backward kernel recomputes"""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p, key, stream_id):
+        lib = _lib.load()
+        d = x.shape[-1]
+        m = x.numel() // d
+        x2, r2 = x.reshape(m, d).contiguous(), res.reshape(m, d).contiguous()
+        y, s = torch.empty_like(x2), torch.empty_like(x2)
+        mean = torch.empty(m, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(m, device=x.device, dtype=torch.float32)
+        used = torch.empty(1, device=x.device, dtype=torch.int64)
+        check(lib.otvae_layernorm_dropout_fwd(ptr(x2), ptr(r2), ptr(gamma), ptr(beta), m, d, float(eps), float(p), ptr(key),
+                                              int(stream_id), ptr(s), ptr(y), ptr(mean), ptr(rstd), ptr(used), stream()),
+              "otvae_layernorm_dropout_fwd")
+        ctx.save_for_backward(s, gamma, mean, rstd, used)
+        ctx.p = float(p)
+        ctx.mark_non_differentiable(used)
+        return y.reshape(x.shape), used
+
+    @staticmethod
+    def backward(ctx, gy, _gused):
+        lib = _lib.load()
+        xs, gamma, mean, rstd, used = ctx.saved_tensors
+        m, d = xs.shape
+        g2 = gy.reshape(m, d).contiguous()
+        gres, gx = torch.empty_like(xs), torch.empty_like(xs)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(lib.otvae_layernorm_bwd_ws(m, d), device=xs.device, dtype=torch.float32)
+        check(lib.otvae_layernorm_dropout_bwd(ptr(xs), ptr(g2), ptr(gamma), ptr(mean), ptr(rstd), m, d, ctx.p, ptr(used), ptr(gres),
+                                              ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws), stream()), "otvae_layernorm_dropout_bwd")
+        return gx.reshape(gy.shape), gres.reshape(gy.shape), dgamma, dbeta, None, None, None, None
+
+
+def layer_norm_dropout_mask(used: Tensor, m: int, d: int, p: float) -> Tensor:
+    """the keep mask [M, D] (bool) of the ``layer_norm_tokens(dropout_p > 0)`` call that returned ``used`` -- for tests"""
+    lib = _lib.load()
+    keep = torch.empty((m, d), device=used.device, dtype=torch.uint8)
+    check(lib.otvae_layernorm_dropout_mask(m, d, float(p), ptr(used), ptr(keep), stream()), "otvae_layernorm_dropout_mask")
+    return keep.bool()
+
+
+def layer_norm_tokens(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, residual: Optional[Tensor] = None,
+                      dropout_p: float = 0.0, dropout_key: Optional[Tensor] = None, stream_id: int = 0, return_used: bool = False):
+    """LayerNorm over the last dimension of ``x (+ residual)`` (torch.nn.functional.layer_norm arithmetic).  With
+    ``dropout_p > 0`` the kernel computes LayerNorm(residual + dropout(x)) -- the post-norm transformer block in training
+    mode -- with the mask key conventions of ``mha_attention_tokens``."""
     _lib.require_cuda(x, "layer_norm input")
     if x.dtype != torch.float32:
         raise TypeError("the MI355X LayerNorm computes in fp32")
     if residual is not None and residual.shape != x.shape:
         raise ValueError("`residual` must have the shape of `x`")
+    if dropout_p > 0:
+        if residual is None or dropout_key is None:
+            raise ValueError("`dropout_p` > 0 needs the `residual` the thinned `x` is added to, and a `dropout_key`")
+        y, used = _LayerNormDropoutFn.apply(x, residual, gamma, beta, eps, dropout_p, dropout_key, stream_id)
+        return (y, used) if return_used else y
     return _LayerNormFn.apply(x, residual, gamma, beta, eps)
+
+
+class _DropoutFn(torch.autograd.Function):
+    """dropout(relu?(x)) over [..., D] tokens with a recomputed hash mask (no mask tensor)"""
+
+    @staticmethod
+    def forward(ctx, x, p, key, stream_id, relu):
+        lib = _lib.load()
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d).contiguous()
+        y = torch.empty_like(x2)
+        used = torch.empty(1, device=x.device, dtype=torch.int64)
+        check(lib.otvae_dropout_fwd(ptr(x2), x2.shape[0], d, int(relu), float(p), ptr(key), int(stream_id), ptr(y), ptr(used),
+                                    stream()), "otvae_dropout_fwd")
+        ctx.save_for_backward(x2, used)
+        ctx.cfg = (float(p), int(relu))
+        ctx.mark_non_differentiable(used)
+        return y.reshape(x.shape), used
+
+    @staticmethod
+    def backward(ctx, gy, _gused):
+        lib = _lib.load()
+        x2, used = ctx.saved_tensors
+        p, relu = ctx.cfg
+        g2 = gy.reshape(x2.shape).contiguous()
+        gx = torch.empty_like(x2)
+        check(lib.otvae_dropout_bwd(ptr(x2), ptr(g2), x2.shape[0], x2.shape[1], relu, p, ptr(used), ptr(gx), stream()),
+              "otvae_dropout_bwd")
+        return gx.reshape(gy.shape), None, None, None, None
+
+
+def dropout_tokens(x: Tensor, p: float, dropout_key: Tensor, stream_id: int = 0, relu: bool = False, return_used: bool = False):
+    """``dropout(relu(x))`` (``relu=True``) or ``dropout(x)`` over [..., D] tokens, D % 4 == 0, with the mask key conventions
+    of ``mha_attention_tokens``; the mask equals ``layer_norm_dropout_mask(used, rows, D, p)``."""
+    _lib.require_cuda(x, "dropout input")
+    y, used = _DropoutFn.apply(x, p, dropout_key, stream_id, relu)
+    return (y, used) if return_used else y
 
 
 class _AttentionDropoutFn(torch.autograd.Function):

@@ -63,8 +63,9 @@ class TokenLayerNorm(nn.Module):
         super().__init__()
         self.weight, self.bias, self.eps = nn.Parameter(torch.ones(dim)), nn.Parameter(torch.zeros(dim)), eps
 
-    def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
-        return HF.layer_norm_tokens(x, self.weight, self.bias, self.eps, residual)
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None, dropout_p: float = 0.0, dropout_key: Optional[Tensor] = None,
+                stream_id: int = 0) -> Tensor:
+        return HF.layer_norm_tokens(x, self.weight, self.bias, self.eps, residual, dropout_p, dropout_key, stream_id)
 
 
 class _SelfAttention(nn.Module):
@@ -100,15 +101,22 @@ class TokenEncoderLayer(nn.Module):
         return F.dropout(x, self.p, True) if (self.training and self.p > 0) else x
 
     def forward(self, x: Tensor, dropout_key: Optional[Tensor] = None, stream_id: int = 0) -> Tensor:
-        # nn.MultiheadAttention drops attention probabilities with the layer's p as well: inside the attention kernel
-        p_attn = self.p if (self.training and dropout_key is not None) else 0.0
-        x = self.norm1(self._drop(self.self_attn(x, p_attn, dropout_key, stream_id)), residual=x)
+        """``dropout_key`` (training with p > 0): the attention probabilities are thinned inside the attention kernel (what
+        nn.MultiheadAttention does with the layer's p) and the two "x + dropout(sublayer(x))" inside the LayerNorm kernels;
+        the dropout between the ReLU and linear2 is one kernel with the ReLU.  Call sites of one forward pass are told apart
+        by stream ids: layer i uses i (attention), 1024 + 2 i and 1025 + 2 i (the two norms), 2048 + i (feed-forward)."""
+        fused = self.training and self.p > 0 and dropout_key is not None
+        p = self.p if fused else 0.0
+        a = self.self_attn(x, p, dropout_key, stream_id)
+        x = self.norm1(a, x, p, dropout_key, 1024 + 2 * stream_id) if fused else self.norm1(self._drop(a), residual=x)
         h = self.linear1(x)
-        if self.training and self.p > 0:  # dropout sits between the ReLU and linear2: the activation cannot stay fused
+        if fused and h.shape[-1] % 4 == 0:  # dropout sits between the ReLU and linear2: one kernel for the pair
+            f = self.linear2(HF.dropout_tokens(h, p, dropout_key, 2048 + stream_id, relu=True))
+        elif self.training and self.p > 0:
             f = self.linear2(self._drop(torch.relu(h)))
         else:
             f = self.linear2(h, relu_input=True)
-        return self.norm2(self._drop(f), residual=x)
+        return self.norm2(f, x, p, dropout_key, 1025 + 2 * stream_id) if fused else self.norm2(self._drop(f), residual=x)
 
 
 class _Encoder(nn.Module):
@@ -136,7 +144,7 @@ class PositionalEmbedding(nn.Module):
         self.LayerNorm = TokenLayerNorm(d_model)
         self.p = float(dropout)
 
-    def forward(self, input: Tensor) -> Tensor:
+    def forward(self, input: Tensor, dropout_key: Optional[Tensor] = None) -> Tensor:
         if input.size(-1) != self.d_model:
             raise RuntimeError("the feature number of `input` must be equal to d_model")
         batched = input.dim() == 3
@@ -145,7 +153,11 @@ class PositionalEmbedding(nn.Module):
         if batched:
             pos = pos.unsqueeze(int(not self.batch_first))
         out = self.LayerNorm(input, residual=pos.expand_as(input))
-        return F.dropout(out, self.p, True) if (self.training and self.p > 0) else out
+        if not (self.training and self.p > 0):
+            return out
+        if dropout_key is not None and self.d_model % 4 == 0:
+            return HF.dropout_tokens(out, self.p, dropout_key, 4000)
+        return F.dropout(out, self.p, True)
 
 
 class _Patchify(nn.Module):
@@ -243,7 +255,7 @@ class ViT(nn.Module):
         """{seed, call counter} for the attention-probability dropout of this forward pass, or None when nothing is
         dropped.  Seeded from torch's default generator on first use (an eager step: it reads the host generator); the
         counter advances by a device-side add, so a captured step draws new masks on every replay."""
-        if not self.training or self.attn_dropout <= 0:
+        if not self.training or max(self.attn_dropout, self.positional_embed.p) <= 0:
             return None
         key = self.__dict__.get("_dropout_key")
         if key is None or key.device != device:
@@ -276,9 +288,10 @@ class ViT(nn.Module):
         x = self._add_embed_token(x)
         x = self._add_class_token(x, labels)
         x = self._add_time_token(x, time)
-        x = self.positional_embed(x)
+        key = self._next_dropout_key(x.device)
+        x = self.positional_embed(x, key)
         idx = self.output_tokens_indices
-        tokens = self.transformer(x, self._next_dropout_key(x.device))
+        tokens = self.transformer(x, key)
         if idx == list(range(idx[0], idx[0] + len(idx))):  # one run of tokens: a slice (an index LIST would be uploaded from
             out = tokens[:, idx[0]:idx[0] + len(idx)]      # the host on every call, which a graph capture cannot hold)
         else:

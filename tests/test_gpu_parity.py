@@ -1079,3 +1079,58 @@ def test_attention_dropout_zero_probability_is_the_plain_kernel_and_bad_argument
         assert rc != 0, bad
     with pytest.raises(ValueError):
         HF.mha_attention_tokens(qkv, 2, 0.1)
+
+
+@pytest.mark.parametrize("m,d,p", [(1235, 256, 0.1), (77, 32, 0.5), (300, 100, 0.25), (64, 1000, 0.1)])
+def test_layernorm_with_fused_dropout_matches_reference_given_its_own_mask(m, d, p):
+    """``otvae_layernorm_dropout_fwd/_bwd``: y = LayerNorm(res + dropout(x)), the post-norm block of a training-mode
+    nn.TransformerEncoderLayer (reference networks/vit.py:157-172), against torch arithmetic handed the kernel's mask."""
+    import ot_vae_lightning_amd.functional as HF
+    rep = Report(f"LayerNorm(res + dropout(x)) M={m} D={d} p={p}")
+    x = normal((m, d), 720 + d).cuda().requires_grad_(True)
+    res = normal((m, d), 721 + d).cuda().requires_grad_(True)
+    gamma = (1 + 0.1 * normal((d,), 722)).cuda().requires_grad_(True)
+    beta = (0.1 * normal((d,), 723)).cuda().requires_grad_(True)
+    gy = normal((m, d), 724 + d).cuda()
+    key = HF.new_dropout_key(x.device, seed=99)
+    y, used = HF.layer_norm_tokens(x, gamma, beta, 1e-5, res, p, key, stream_id=1027, return_used=True)
+    grads = torch.autograd.grad(y, (x, res, gamma, beta), gy)
+    keep = HF.layer_norm_dropout_mask(used, m, d, p)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 6 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-3, (frac, 1 - p)
+    ref_in = [t.detach().double().requires_grad_(True) for t in (x, res, gamma, beta)]
+    s = ref_in[1] + ref_in[0] * keep.double() / (1 - p)
+    ref = torch.nn.functional.layer_norm(s, (d,), ref_in[2], ref_in[3], 1e-5)
+    gref = torch.autograd.grad(ref, ref_in, gy.double())
+    rep.check("y", y, ref.detach(), tol=2e-5)
+    for name, got, want in zip(("dx (thinned operand)", "dres", "dgamma", "dbeta"), grads, gref):
+        rep.check(name, got, want, tol=5e-5)
+    # a different call site draws an independent mask; without dropout the plain kernel is used
+    other = HF.layer_norm_tokens(x, gamma, beta, 1e-5, res, p, key, stream_id=1028, return_used=True)[1]
+    agree = (HF.layer_norm_dropout_mask(other, m, d, p) == keep).float().mean().item()
+    assert abs(agree - (p * p + (1 - p) ** 2)) < 0.05
+    with pytest.raises(ValueError):
+        HF.layer_norm_tokens(x, gamma, beta, 1e-5, None, p, key)
+    rep.finish()
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_elementwise_dropout_kernels_match_reference_given_their_own_mask(relu):
+    """``otvae_dropout_fwd/_bwd``: dropout(relu(x)) of the feed-forward half / the embedding dropout (reference
+    networks/vit.py:54-58,157-172 in training mode); bit-exact against torch arithmetic with the kernel's mask."""
+    import ot_vae_lightning_amd.functional as HF
+    m, d, p = 999, 512, 0.1
+    x = normal((3, 333, d), 740).cuda().requires_grad_(True)
+    gy = normal((3, 333, d), 741).cuda()
+    key = HF.new_dropout_key(x.device, seed=5)
+    y, used = HF.dropout_tokens(x, p, key, stream_id=2049, relu=relu, return_used=True)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    keep = HF.layer_norm_dropout_mask(used, m, d, p).reshape(3, 333, d)
+    assert abs(keep.float().mean().item() - (1 - p)) < 5e-3
+    inv = torch.tensor(1.0, device="cuda") / (1.0 - torch.tensor(p, device="cuda"))      # the kernel's fp32 1/(1-p)
+    act = torch.relu(x.detach()) if relu else x.detach()
+    gate = keep & (x.detach() > 0) if relu else keep
+    assert torch.equal(y, torch.where(keep, act * inv, torch.zeros_like(act)))
+    assert torch.equal(gx, torch.where(gate, gy * inv, torch.zeros_like(gy)))
+    with pytest.raises(ValueError):
+        HF.dropout_tokens(normal((4, 6), 1).cuda(), p, key)                               # D % 4 != 0
