@@ -69,3 +69,21 @@ def mnist_like(batch: int, seed: int = 42) -> torch.Tensor:
 def normal(shape, seed: int, dtype=torch.float32) -> torch.Tensor:
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g, dtype=dtype)
+
+
+def gmm_recovery_inputs():
+    """the sampling mixture and samples of the reference's tests/test_distribution_models.py:177-181 experiment (leading
+    shape (2,), 16 components, dim 32, 1e4 samples, diagonal covariances), from fixed seeds; shared with the GPU test"""
+    import torch.distributions as D
+    lead, k, dim, n = (2,), 16, 32, 10000
+    gen = torch.Generator().manual_seed(9)
+    mean = torch.randn(*lead, k, dim, generator=gen, dtype=torch.double)
+    g = torch.randn(*lead, k, dim, dim, generator=gen, dtype=torch.double)
+    var = torch.diagonal(g @ g.transpose(-1, -2) / dim + 1e-5 * torch.eye(dim, dtype=torch.double), dim1=-1, dim2=-2).clone()
+    weights = torch.ones(*lead, k, dtype=torch.double) / k
+    truth = D.MixtureSameFamily(D.Categorical(probs=weights), D.Independent(D.Normal(mean, var ** 0.5), 1))
+    torch.manual_seed(102)
+    samples = truth.sample((n,)).permute(1, 0, 2).contiguous()
+    torch.manual_seed(104)
+    order = torch.randperm(n)
+    return (lead, k, dim, n), mean, var, truth, samples, order

@@ -1134,3 +1134,76 @@ def test_elementwise_dropout_kernels_match_reference_given_their_own_mask(relu):
     assert torch.equal(gx, torch.where(gate, gy * inv, torch.zeros_like(gy)))
     with pytest.raises(ValueError):
         HF.dropout_tokens(normal((4, 6), 1).cuda(), p, key)                               # D % 4 != 0
+
+
+# ---- the reference's own statistical tests (tests/test_distribution_models.py), same sizes and tolerance -------------------
+_REF_LEAD, _REF_DIM, _REF_NCOMP, _REF_SAMPLES, _REF_TOL = (2,), 32, 16, 10000, 1e-1
+
+
+def _ref_rand_mean_cov(*shape, diag, seed):
+    """mean ~ N(0, I); cov = G G^T / dim + 1e-5 I (its diagonal when ``diag``): test_distribution_models.py:31-37"""
+    gen = torch.Generator().manual_seed(seed)
+    mean = torch.randn(*shape, generator=gen, dtype=torch.double)
+    g = torch.randn(*shape, shape[-1], generator=gen, dtype=torch.double)
+    cov = g @ g.transpose(-1, -2) / _REF_DIM + 1e-5 * torch.eye(shape[-1], dtype=torch.double)
+    return mean, (torch.diagonal(cov, dim1=-1, dim2=-2).clone() if diag else cov)
+
+
+@pytest.mark.parametrize("diag", [True, False])
+def test_gaussian_model_recovers_the_sampling_distribution(A, diag):
+    """reference tests/test_distribution_models.py:171-174 (``fit`` and ``update`` modes; its third mode,
+    ``update_with_autograd``, is outside the hot path and must say so): 1e4 samples of a known Gaussian per operator,
+    leading shape (2,), dim 32, double -- the fitted model must be within W2 < 0.1 of the truth."""
+    import torch.distributions as D
+    torch.manual_seed(100 + int(diag))
+    size = (*_REF_LEAD, _REF_DIM)
+    mean, cov = _ref_rand_mean_cov(*size, diag=diag, seed=7 + int(diag))
+    truth = D.Independent(D.Normal(mean, cov ** 0.5), 1) if diag else D.MultivariateNormal(mean, cov)
+    samples = truth.sample((_REF_SAMPLES,)).permute(1, 0, 2).contiguous().cuda()           # [2, 1e4, 32]
+    truth_gpu = D.Independent(D.Normal(mean.cuda(), cov.cuda() ** 0.5), 1) if diag else D.MultivariateNormal(mean.cuda(), cov.cuda())
+    kwargs = dict(w2_cfg={"diag": diag}, dtype=torch.double)
+    fitted = A.GaussianModel(*size, **kwargs).cuda()
+    fitted.fit(samples)
+    assert float(fitted.w2(truth_gpu).max()) < _REF_TOL
+    streamed = A.GaussianModel(*size, **kwargs, update_decay=None).cuda()
+    for batch in samples[:, torch.randperm(_REF_SAMPLES, device="cuda")].split(100, dim=-2):     # shuffled batches of 100
+        streamed.update(batch)
+    streamed.fit()
+    assert float(streamed.w2(truth_gpu).max()) < _REF_TOL
+    assert torch.allclose(streamed.mean, fitted.mean, atol=1e-9) and torch.allclose(streamed.cov, fitted.cov, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        A.GaussianModel(*size, **kwargs, update_with_autograd=True)
+
+
+def test_gaussian_mixture_model_on_the_references_recovery_experiment(A):
+    """reference tests/test_distribution_models.py:177-181 (diagonal case, 'argmax', fit and update): 1e4 samples of a
+    16-component mixture per operator.  The reference's test of this cannot run (it names an undefined variable, :180) and
+    its W2 < 0.1 bound is far from what its class reaches (W2 between 1 and 15: k-means from a random start in 32
+    dimensions), so the bar here is the reference class itself: the same seeds, the same W2 (``tests/golden/
+    gmm_recovery.npz``, recorded by oracle/gen_golden.py::gen_gmm_recovery), through the HIP assignment / k-means /
+    Sinkhorn kernels."""
+    from detfill import gmm_recovery_inputs
+    g = load_golden("gmm_recovery.npz")
+    rep = Report("GaussianMixtureModel on the reference's recovery experiment vs the reference class")
+    (lead, k, dim, n), mean, var, truth, samples, order = gmm_recovery_inputs()
+    check = torch.tensor([samples.sum().item(), samples.square().sum().item(), float(order[:16].sum())], dtype=torch.double)
+    rep.check("inputs regenerated from the seeds", check, torch.from_numpy(g["samples_checksum"]), 1e-12)
+    import torch.distributions as D
+    truth_gpu = D.MixtureSameFamily(D.Categorical(probs=truth.mixture_distribution.probs.cuda()),
+                                    D.Independent(D.Normal(mean.cuda(), var.cuda() ** 0.5), 1))
+    cfg = dict(w2_cfg={"diag": True}, dtype=torch.double, mixture_cfg={"n_components": k, "training_mode": "argmax", "topk": None})
+    torch.manual_seed(103)
+    fitted = A.GaussianMixtureModel(*lead, dim, **cfg).cuda().train()
+    fitted.fit(samples.cuda())
+    rep.check("fit: component means", fitted.mean, torch.from_numpy(g["fit_mean"]), 1e-9)
+    rep.check("fit: W2 to the sampling mixture", fitted.w2(truth_gpu), torch.from_numpy(g["w2_fit"]), 1e-6)
+    torch.manual_seed(105)
+    streamed = A.GaussianMixtureModel(*lead, dim, **cfg, update_decay=None).cuda().train()
+    for batch in samples[:, order].cuda().split(100, dim=-2):
+        streamed.update(batch)
+    streamed.fit()
+    rep.check("update: component means", streamed.mean, torch.from_numpy(g["update_mean"]), 1e-9)
+    rep.check("update: W2 to the sampling mixture", streamed.w2(truth_gpu), torch.from_numpy(g["w2_update"]), 1e-6)
+    with pytest.raises(NotImplementedError):
+        A.GaussianMixtureModel(*lead, dim, **{**cfg, "w2_cfg": {"diag": False}})
+    rep.finish()
