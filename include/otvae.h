@@ -179,12 +179,13 @@ int otvae_dropout_bwd(const float* x, const float* gy, int64_t rows, int D, int 
  * recomputes.  key: device int64[2] {seed, call counter} -- device memory, so that a captured hipGraph draws a fresh mask
  * on every replay once the host bumps the counter with a captured add; stream_id (0..4094) tells call sites apart.  The
  * forward writes the call key it derived to used[0] (device int64[1]); the backward and _mask read it from there.
- * lse is the natural log of the UN-dropped row sums.  T <= 256 and T*(2C+3) <= 16384; C in {1,2,4,8,16,32}.
+ * causal != 0 restricts the softmax of token t to tokens s <= t (the ViT's `causal_mask`, networks/vit.py:215-217); p may
+ * then be 0.  lse is the natural log of the UN-dropped row sums.  T <= 256 and T*(2C+3) <= 16384; C in {1,2,4,8,16,32}.
  * otvae_attn_dropout_mask writes keep as uint8 [N][H][T][T] (test / debugging aid). */
-int otvae_attn_dropout_fwd(const float* qkv, int N, int T, int H, int C, float scale, float p, const int64_t* key,
+int otvae_attn_dropout_fwd(const float* qkv, int N, int T, int H, int C, float scale, float p, int causal, const int64_t* key,
                            int stream_id, float* out, float* lse, int64_t* used, void* stream);
 int otvae_attn_dropout_bwd(const float* qkv, const float* out, const float* lse, const float* gout, int N, int T, int H,
-                           int C, float scale, float p, const int64_t* used, float* gqkv, void* stream);
+                           int C, float scale, float p, int causal, const int64_t* used, float* gqkv, void* stream);
 int otvae_attn_dropout_mask(int N, int T, int H, float p, const int64_t* used, uint8_t* keep, void* stream);
 
 /* ---- LayerNorm over the last dimension (the token streams of the ViT: networks/vit.py:38,54 and the two norms of each

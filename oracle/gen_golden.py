@@ -643,6 +643,31 @@ def gen_vit():
     save("vit.npz", out)
 
 
+def gen_vit_causal():
+    """G16: the d32 ViT of G12 with ``causal_mask=True`` (every layer's attention sees tokens <= t only,
+    networks/vit.py:215-217,225): output and input gradient for both roles."""
+    vit = R.ref("networks.vit")
+    out = {}
+    tag, cfg, B = VIT_CASES[0]
+    roles = {"enc": dict(n_embed_tokens=2, n_input_tokens=None, patch_to_embed=True, embed_to_patch=False),
+             "dec": dict(n_embed_tokens=None, n_input_tokens=1, patch_to_embed=False, embed_to_patch=True)}
+    labels = torch.arange(B) % 10
+    for nm, role in roles.items():
+        net = vit.ViT(output_tokens="embed", causal_mask=True, **role, **cfg)
+        net.train()
+        fill_vit_state_dict(net.state_dict())
+        shape = (B, cfg["channels"], cfg["image_size"], cfg["image_size"]) if nm == "enc" else (B, 1, cfg["dim"])
+        x = det_input(shape, 0.3 if nm == "enc" else 0.8).clone().requires_grad_(True)
+        y = net(x, labels=labels)
+        g = det_input(tuple(y.shape), 1.1, 0.5)
+        y.backward(g)
+        out[f"{nm}/x"], out[f"{nm}/y"], out[f"{nm}/gy"], out[f"{nm}/gx"] = npy(x), npy(y), npy(g), npy(x.grad)
+        out[f"{nm}/grad_l2"] = np.array([p.grad.double().norm().item() for _, p in net.named_parameters()])
+    out["labels"] = npy(labels)
+    out["tag"] = np.array([ord(c) for c in tag])
+    save("vit_causal.npz", out)
+
+
 def gen_vit_vae():
     """G13: ConditionalGaussianPrior alone (learned embeddings: z, loss, gradients of x and of the two
     embeddings; EMA embeddings: the buffers after two training steps) and VAE.nelbo of the conditional ViT VAE of
@@ -739,6 +764,6 @@ def gen_gmm_recovery():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal"]
     for w in which:
         globals()["gen_" + w]()

@@ -3,6 +3,7 @@
 // TransformerEncoderLayer; configs/vae/vit.yaml trains with 0.1).
 //
 //   P = softmax(q k^T * scale);  P' = P o keep / (1 - p);  out = P' v          keep[t][s] ~ Bernoulli(1 - p)
+// and, with `causal`, the softmax restricted to s <= t (the ViT's `causal_mask`, networks/vit.py:215-217; p may be 0).
 //
 // The T x T mask is never stored: keep[t][s] is a counter-based hash of (call key, slice, t, s), recomputed by the
 // backward pass.  The call key is derived on the device from `key` = {seed, call counter} (int64[2] in device memory,
@@ -46,7 +47,7 @@ template <int C>
 __global__ __launch_bounds__(256) void attn_drop_fwd_kernel(const float* __restrict__ qkv, int N, int T, int H, int SPB, float scale,
                                                             uint32_t thresh, float inv_keep, const int64_t* __restrict__ key,
                                                             int stream_id, int64_t* __restrict__ used, float* __restrict__ out,
-                                                            float* __restrict__ lse) {
+                                                            float* __restrict__ lse, int causal) {
     extern __shared__ __align__(16) float sm[];
     constexpr int RS = 2 * C;
     const int HC = H * C, W3 = 3 * HC;
@@ -68,11 +69,12 @@ __global__ __launch_bounds__(256) void attn_drop_fwd_kernel(const float* __restr
         q[c] = qkv[(n * T + t) * W3 + h * C + c] * qs;
         acc[c] = 0.f;
     }
-    float mx = -INFINITY;
-    for (int j = 0; j < T; ++j) mx = fmaxf(mx, dotr<C>(q, kv + j * RS));
+    const int jend = causal ? t + 1 : T;  // causal: token t attends to tokens 0..t (the -inf upper triangle of
+    float mx = -INFINITY;                 // nn.Transformer.generate_square_subsequent_mask)
+    for (int j = 0; j < jend; ++j) mx = fmaxf(mx, dotr<C>(q, kv + j * RS));
     const uint32_t rh = row_hash(ck, (uint32_t)(s * T + t));
     float l = 0.f;
-    for (int j = 0; j < T; ++j) {
+    for (int j = 0; j < jend; ++j) {
         const float* r = kv + j * RS;
         const float p = EXP2(dotr<C>(q, r) - mx);
         l += p;  // the softmax normaliser sees every key; only the value sum is thinned
@@ -94,7 +96,7 @@ template <int C>
 __global__ __launch_bounds__(256) void attn_drop_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                             const float* __restrict__ lse, const float* __restrict__ gout, int N,
                                                             int T, int H, int SPB, float scale, uint32_t thresh, float inv_keep,
-                                                            const int64_t* __restrict__ used, float* __restrict__ gqkv) {
+                                                            const int64_t* __restrict__ used, float* __restrict__ gqkv, int causal) {
     extern __shared__ __align__(16) float sm[];
     constexpr int RS = 2 * C + 3;
     const int HC = H * C, W3 = 3 * HC;
@@ -123,7 +125,8 @@ __global__ __launch_bounds__(256) void attn_drop_bwd_kernel(const float* __restr
         }
         L2 = lse[s * T + t] * LOG2E;
         rh = row_hash(ck, (uint32_t)(s * T + t));
-        for (int j = 0; j < T; ++j) {
+        const int jend = causal ? t + 1 : T;
+        for (int j = 0; j < jend; ++j) {
             const float* r = rec + j * RS;
             const float p = EXP2(fmaf(dotr<C>(q, r), qs, -L2));
             const float dp = keep_pair(rh, j, thresh) ? dotr<C>(g, r + C) * inv_keep : 0.f;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_drop_bwd_kernel(const float* __restr
         dk[c] = 0.f;
         dv[c] = 0.f;
     }
-    for (int i = 0; i < T; ++i) {
+    for (int i = causal ? t : 0; i < T; ++i) {  // causal: key t is seen by queries t..T-1
         const float* r = rec + i * RS;
         const float p = EXP2(fmaf(dotr<C>(k, r), qs, -r[2 * C]));
         const bool keep = keep_pair(__float_as_uint(r[2 * C + 2]), t, thresh);
@@ -215,8 +218,8 @@ static int adrop_plan(const char* who, int N, int T, int H, int C, float p, int 
             return OTVAE_EUNSUPPORTED;                                                                                 \
     }
 
-extern "C" int otvae_attn_dropout_fwd(const float* qkv, int N, int T, int H, int C, float scale, float p, const int64_t* key,
-                                      int stream_id, float* out, float* lse, int64_t* used, void* stream) {
+extern "C" int otvae_attn_dropout_fwd(const float* qkv, int N, int T, int H, int C, float scale, float p, int causal,
+                                      const int64_t* key, int stream_id, float* out, float* lse, int64_t* used, void* stream) {
     OTVAE_REQUIRE(qkv && out && lse && key && used, "otvae_attn_dropout_fwd: NULL tensor");
     OTVAE_REQUIRE(scale > 0.f && stream_id >= 0 && stream_id < 4095, "otvae_attn_dropout_fwd: bad scale or stream_id");
     int spb;
@@ -227,7 +230,7 @@ extern "C" int otvae_attn_dropout_fwd(const float* qkv, int N, int T, int H, int
     const size_t lds = (size_t)spb * T * 2 * C * sizeof(float);
     const float inv_keep = 1.f / (1.f - p);
 #define FWD_K(CC) \
-    attn_drop_fwd_kernel<CC><<<grid, 256, lds, (hipStream_t)stream>>>(qkv, N, T, H, spb, scale, thresh, inv_keep, key, stream_id, used, out, lse)
+    attn_drop_fwd_kernel<CC><<<grid, 256, lds, (hipStream_t)stream>>>(qkv, N, T, H, spb, scale, thresh, inv_keep, key, stream_id, used, out, lse, causal)
     ADROP_C_SWITCH(C, FWD_K)
 #undef FWD_K
     OTVAE_CHECK_LAUNCH("otvae_attn_dropout_fwd");
@@ -235,7 +238,7 @@ extern "C" int otvae_attn_dropout_fwd(const float* qkv, int N, int T, int H, int
 }
 
 extern "C" int otvae_attn_dropout_bwd(const float* qkv, const float* out, const float* lse, const float* gout, int N, int T, int H,
-                                      int C, float scale, float p, const int64_t* used, float* gqkv, void* stream) {
+                                      int C, float scale, float p, int causal, const int64_t* used, float* gqkv, void* stream) {
     OTVAE_REQUIRE(qkv && out && lse && gout && used && gqkv, "otvae_attn_dropout_bwd: NULL tensor");
     OTVAE_REQUIRE(scale > 0.f, "otvae_attn_dropout_bwd: scale must be positive");
     int spb;
@@ -246,7 +249,7 @@ extern "C" int otvae_attn_dropout_bwd(const float* qkv, const float* out, const 
     const size_t lds = (size_t)spb * T * (2 * C + 3) * sizeof(float);
     const float inv_keep = 1.f / (1.f - p);
 #define BWD_K(CC) \
-    attn_drop_bwd_kernel<CC><<<grid, 256, lds, (hipStream_t)stream>>>(qkv, out, lse, gout, N, T, H, spb, scale, thresh, inv_keep, used, gqkv)
+    attn_drop_bwd_kernel<CC><<<grid, 256, lds, (hipStream_t)stream>>>(qkv, out, lse, gout, N, T, H, spb, scale, thresh, inv_keep, used, gqkv, causal)
     ADROP_C_SWITCH(C, BWD_K)
 #undef BWD_K
     OTVAE_CHECK_LAUNCH("otvae_attn_dropout_bwd");

@@ -619,17 +619,19 @@ class _AttentionDropoutFn(torch.autograd.Function):
     the backward kernel recomputes from the call key the forward kernel left in ``used``"""
 
     @staticmethod
-    def forward(ctx, qkv, heads, scale, p, key, stream_id):
+    def forward(ctx, qkv, heads, scale, p, key, stream_id, causal):
         lib = _lib.load()
         n, width, h, w = qkv.shape
         t, c = h * w, width // (3 * heads)
+        if key is None:  # nothing is dropped (causal attention only): any key will do
+            key = torch.zeros(2, device=qkv.device, dtype=torch.int64)
         out = empty_nhwc(n, heads * c, h, w, qkv)
         lse = torch.empty((n, heads, t), device=qkv.device, dtype=torch.float32)
         used = torch.empty(1, device=qkv.device, dtype=torch.int64)
-        check(lib.otvae_attn_dropout_fwd(ptr(qkv), n, t, heads, c, float(scale), float(p), ptr(key), int(stream_id), ptr(out),
-                                         ptr(lse), ptr(used), stream()), "otvae_attn_dropout_fwd")
+        check(lib.otvae_attn_dropout_fwd(ptr(qkv), n, t, heads, c, float(scale), float(p), int(causal), ptr(key), int(stream_id),
+                                         ptr(out), ptr(lse), ptr(used), stream()), "otvae_attn_dropout_fwd")
         ctx.save_for_backward(qkv, out, lse, used)
-        ctx.dims = (n, t, heads, c, float(scale), float(p))
+        ctx.dims = (n, t, heads, c, float(scale), float(p), int(causal))
         ctx.mark_non_differentiable(used)
         return out, used
 
@@ -637,12 +639,12 @@ class _AttentionDropoutFn(torch.autograd.Function):
     def backward(ctx, gout, _gused):
         lib = _lib.load()
         qkv, out, lse, used = ctx.saved_tensors
-        n, t, heads, c, scale, p = ctx.dims
+        n, t, heads, c, scale, p, causal = ctx.dims
         gout = as_nhwc(gout)
         gqkv = torch.empty_strided(qkv.shape, qkv.stride(), device=qkv.device, dtype=qkv.dtype)
-        check(lib.otvae_attn_dropout_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(gout), n, t, heads, c, scale, p, ptr(used), ptr(gqkv),
-                                         stream()), "otvae_attn_dropout_bwd")
-        return gqkv, None, None, None, None, None
+        check(lib.otvae_attn_dropout_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(gout), n, t, heads, c, scale, p, causal, ptr(used),
+                                         ptr(gqkv), stream()), "otvae_attn_dropout_bwd")
+        return gqkv, None, None, None, None, None, None
 
 
 def new_dropout_key(device, seed: Optional[int] = None) -> Tensor:
@@ -662,18 +664,19 @@ def attention_dropout_mask(used: Tensor, n: int, t: int, heads: int, p: float) -
 
 
 def mha_attention_tokens(qkv: Tensor, n_heads: int, dropout_p: float = 0.0, dropout_key: Optional[Tensor] = None,
-                         stream_id: int = 0, return_used: bool = False):
+                         stream_id: int = 0, return_used: bool = False, causal: bool = False):
     """softmax(q k^T / sqrt(C)) v per head on in-projected tokens [N, T, 3*H*C] (q | k | v, head-major: the layout of
     nn.MultiheadAttention's in_proj) -> [N, T, H*C]; the fused attention kernels with the 1/sqrt(C) score scale.
     ``dropout_p > 0`` (nn.MultiheadAttention's ``dropout`` in training mode) drops attention probabilities inside the
     kernel; ``dropout_key`` is the device int64[2] {seed, counter} of ``new_dropout_key`` (the caller advances the counter
-    between steps), ``stream_id`` tells the layers sharing one key apart."""
+    between steps), ``stream_id`` tells the layers sharing one key apart.  ``causal``: token t attends to tokens <= t."""
     _lib.require_cuda(qkv, "qkv")
     c = qkv.shape[-1] // (3 * n_heads)
-    if dropout_p > 0:
-        if dropout_key is None:
+    if dropout_p > 0 or causal:
+        if dropout_p > 0 and dropout_key is None:
             raise ValueError("`dropout_p` > 0 needs a `dropout_key` (functional.new_dropout_key)")
-        out, used = _AttentionDropoutFn.apply(tokens_as_nhwc(qkv), n_heads, 1.0 / math.sqrt(c), dropout_p, dropout_key, stream_id)
+        out, used = _AttentionDropoutFn.apply(tokens_as_nhwc(qkv), n_heads, 1.0 / math.sqrt(c), dropout_p, dropout_key, stream_id,
+                                              causal)
         return (nhwc_as_tokens(out), used) if return_used else nhwc_as_tokens(out)
     out = _AttentionFn.apply(tokens_as_nhwc(qkv), n_heads, 1.0 / math.sqrt(c))
     return nhwc_as_tokens(out)

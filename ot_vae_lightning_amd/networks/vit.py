@@ -9,7 +9,8 @@ The transformer is the reference's ``nn.TransformerEncoder`` of post-norm ``nn.T
 drawn by constructing the very torch modules the reference constructs, in its order, so a seeded construction gives the
 reference's initial weights (note that ``nn.TransformerEncoder`` deep-copies ONE layer: all layers start identical).
 
-Not implemented (they raise): the cross-attention variant (``preprocess_depth``), ``causal_mask``, ``time_dependant``.
+Not implemented (they raise): the cross-attention variant (``preprocess_depth``) and ``time_dependant``.  ``causal_mask``
+runs on the generic attention kernels of ``attention_dropout.hip`` (softmax over tokens <= t).
 Dropout > 0 in training mode: the three dropouts of a layer that act on token tensors are applied with
 ``torch.nn.functional.dropout`` between the kernels; the fourth, nn.MultiheadAttention's dropout on the attention
 probabilities, happens inside the attention kernel (``otvae_attn_dropout_*``: the mask is a hash recomputed by the
@@ -78,9 +79,10 @@ class _SelfAttention(nn.Module):
         self.in_proj_bias = nn.Parameter(like.in_proj_bias.data.clone())
         self.out_proj = TokenLinear(like.embed_dim, like.embed_dim, like=like.out_proj)
 
-    def forward(self, x: Tensor, dropout_p: float = 0.0, dropout_key: Optional[Tensor] = None, stream_id: int = 0) -> Tensor:
+    def forward(self, x: Tensor, dropout_p: float = 0.0, dropout_key: Optional[Tensor] = None, stream_id: int = 0,
+                causal: bool = False) -> Tensor:
         qkv = HF.linear_tokens(x, self.in_proj_weight, self.in_proj_bias)
-        return self.out_proj(HF.mha_attention_tokens(qkv, self.num_heads, dropout_p, dropout_key, stream_id))
+        return self.out_proj(HF.mha_attention_tokens(qkv, self.num_heads, dropout_p, dropout_key, stream_id, causal=causal))
 
 
 class TokenEncoderLayer(nn.Module):
@@ -100,14 +102,14 @@ class TokenEncoderLayer(nn.Module):
     def _drop(self, x: Tensor) -> Tensor:
         return F.dropout(x, self.p, True) if (self.training and self.p > 0) else x
 
-    def forward(self, x: Tensor, dropout_key: Optional[Tensor] = None, stream_id: int = 0) -> Tensor:
+    def forward(self, x: Tensor, dropout_key: Optional[Tensor] = None, stream_id: int = 0, causal: bool = False) -> Tensor:
         """``dropout_key`` (training with p > 0): the attention probabilities are thinned inside the attention kernel (what
         nn.MultiheadAttention does with the layer's p) and the two "x + dropout(sublayer(x))" inside the LayerNorm kernels;
         the dropout between the ReLU and linear2 is one kernel with the ReLU.  Call sites of one forward pass are told apart
         by stream ids: layer i uses i (attention), 1024 + 2 i and 1025 + 2 i (the two norms), 2048 + i (feed-forward)."""
         fused = self.training and self.p > 0 and dropout_key is not None
         p = self.p if fused else 0.0
-        a = self.self_attn(x, p, dropout_key, stream_id)
+        a = self.self_attn(x, p, dropout_key, stream_id, causal)
         x = self.norm1(a, x, p, dropout_key, 1024 + 2 * stream_id) if fused else self.norm1(self._drop(a), residual=x)
         h = self.linear1(x)
         if fused and h.shape[-1] % 4 == 0:  # dropout sits between the ReLU and linear2: one kernel for the pair
@@ -128,9 +130,9 @@ class _Encoder(nn.Module):
         if like.norm is not None:
             raise NotImplementedError("a final norm on the TransformerEncoder is not part of the reference's ViT")
 
-    def forward(self, x: Tensor, dropout_key: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Tensor, dropout_key: Optional[Tensor] = None, causal: bool = False) -> Tensor:
         for i, layer in enumerate(self.layers):
-            x = layer(x, dropout_key, i)
+            x = layer(x, dropout_key, i, causal)
         return x
 
 
@@ -197,8 +199,6 @@ class ViT(nn.Module):
         super().__init__()
         if preprocess_depth is not None:
             raise NotImplementedError("the cross-attention ViT (`preprocess_depth`) is not implemented on the MI355X path")
-        if causal_mask:
-            raise NotImplementedError("`causal_mask` is not implemented on the MI355X path")
         if time_dependant:
             raise NotImplementedError("`time_dependant` (Fourier time token) is not implemented on the MI355X path")
         self.dim, self.causal_mask = dim, causal_mask
@@ -291,7 +291,7 @@ class ViT(nn.Module):
         key = self._next_dropout_key(x.device)
         x = self.positional_embed(x, key)
         idx = self.output_tokens_indices
-        tokens = self.transformer(x, key)
+        tokens = self.transformer(x, key, causal=self.causal_mask)
         if idx == list(range(idx[0], idx[0] + len(idx))):  # one run of tokens: a slice (an index LIST would be uploaded from
             out = tokens[:, idx[0]:idx[0] + len(idx)]      # the host on every call, which a graph capture cannot hold)
         else:

@@ -937,6 +937,31 @@ def test_vit_vs_reference_golden(A, tag, role):
     assert tuple(net.out_size) == tuple(y.shape[1:])
 
 
+@pytest.mark.parametrize("role", ["enc", "dec"])
+def test_vit_with_causal_mask_vs_reference_golden(A, role):
+    """``ViT(causal_mask=True)`` (reference networks/vit.py:215-217,225: every layer's attention restricted to tokens <= t)
+    on the d32 configuration: output, input gradient and the L2 norm of every parameter gradient against golden vectors
+    of the reference class (``tests/golden/vit_causal.npz``)."""
+    from detfill import fill_vit_state_dict
+    from test_oracle_vs_golden import VIT_CASES, VIT_ROLES, vit_param_shapes
+    g = {k: torch.from_numpy(v) for k, v in load_golden("vit_causal.npz").items()}
+    rep = Report(f"ViT d32 {role} with causal mask vs reference golden")
+    cfg = VIT_CASES["d32"]
+    net = A.ViT(output_tokens="embed", dropout=0.0, emb_dropout=0., causal_mask=True, **cfg, **VIT_ROLES[role])
+    ordered = {k: torch.zeros(s) for k, s in vit_param_shapes(cfg, role).items()}
+    fill_vit_state_dict(ordered)
+    net.load_state_dict(ordered)
+    net = net.cuda().train()
+    x = g[f"{role}/x"].cuda().requires_grad_(True)
+    y = net(x, labels=g["labels"].cuda())
+    y.backward(g[f"{role}/gy"].cuda())
+    rep.check("output", y, g[f"{role}/y"], 1e-5)
+    rep.check("input gradient", x.grad, g[f"{role}/gx"], 1e-4)
+    rep.check("grad_l2 (all parameters)", torch.tensor([p.grad.double().norm().item() for _, p in net.named_parameters()]),
+              g[f"{role}/grad_l2"], 5e-4)
+    rep.finish()
+
+
 # ------------------------------------------------------------------------------------------------ G13 conditional prior, ViT VAE
 def test_conditional_gaussian_prior_vs_reference_golden(A):
     """ConditionalGaussianPrior (reference prior/conditional_gaussian.py): learned class embeddings (z, loss with cosine
@@ -1018,18 +1043,19 @@ def test_conditional_vit_vae_nelbo_vs_reference_golden(A):
     rep.finish()
 
 
-@pytest.mark.parametrize("n,t,heads,c,p", [(3, 65, 8, 32, 0.1), (5, 17, 4, 8, 0.5), (2, 100, 2, 16, 0.25), (7, 9, 3, 4, 0.1),
-                                           (2, 244, 1, 32, 0.1), (4, 33, 2, 1, 0.3)])
-def test_attention_with_dropout_matches_reference_given_its_own_mask(n, t, heads, c, p):
+@pytest.mark.parametrize("n,t,heads,c,p,causal", [(3, 65, 8, 32, 0.1, False), (5, 17, 4, 8, 0.5, False), (2, 100, 2, 16, 0.25, False),
+                                                  (7, 9, 3, 4, 0.1, False), (2, 244, 1, 32, 0.1, False), (4, 33, 2, 1, 0.3, False),
+                                                  (3, 65, 8, 32, 0.1, True), (2, 50, 2, 16, 0.0, True)])
+def test_attention_with_dropout_matches_reference_given_its_own_mask(n, t, heads, c, p, causal):
     """``otvae_attn_dropout_fwd/_bwd`` (nn.MultiheadAttention's dropout on the attention probabilities, reference
     networks/vit.py:157-172 in training mode) against plain torch arithmetic that is handed the kernel's own keep mask
     (``otvae_attn_dropout_mask``): out = (softmax(q k^T / sqrt(C)) o keep / (1-p)) v and all three input gradients."""
     import ot_vae_lightning_amd.functional as HF
-    rep = Report(f"attention with dropout N={n} T={t} H={heads} C={c} p={p}")
+    rep = Report(f"attention with dropout N={n} T={t} H={heads} C={c} p={p} causal={causal}")
     qkv = normal((n, t, 3 * heads * c), 700 + t).cuda().requires_grad_(True)
     gout = normal((n, t, heads * c), 701 + t).cuda()
     key = HF.new_dropout_key(qkv.device, seed=1234)
-    out, used = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=3, return_used=True)
+    out, used = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=3, return_used=True, causal=causal)
     (gq,) = torch.autograd.grad(out, qkv, gout)
     keep = HF.attention_dropout_mask(used, n, t, heads, p)                      # [N, H, T, T]
     frac = keep.float().mean().item()
@@ -1038,7 +1064,10 @@ def test_attention_with_dropout_matches_reference_given_its_own_mask(n, t, heads
     assert abs(keep.float().mean(dim=(0, 1, 2)) - (1 - p)).max().item() < 0.2  # no key column is favoured
     ref_in = qkv.detach().double().requires_grad_(True)
     q, k, v = (x.reshape(n, t, heads, c).transpose(1, 2) for x in ref_in.chunk(3, dim=-1))      # [N, H, T, C]
-    prob = torch.softmax(q @ k.transpose(-1, -2) / c ** 0.5, dim=-1)
+    scores = q @ k.transpose(-1, -2) / c ** 0.5
+    if causal:                                                                   # the ViT's `causal_mask` (networks/vit.py:215-217)
+        scores = scores + torch.nn.Transformer.generate_square_subsequent_mask(t).to(scores)
+    prob = torch.softmax(scores, dim=-1)
     ref = ((prob * keep.double() / (1 - p)) @ v).transpose(1, 2).reshape(n, t, heads * c)
     (gref,) = torch.autograd.grad(ref, ref_in, gout.double())
     rep.check("out", out, ref.detach(), tol=2e-5)
@@ -1046,8 +1075,11 @@ def test_attention_with_dropout_matches_reference_given_its_own_mask(n, t, heads
     rep.check("dk", gq[..., heads * c:2 * heads * c], gref[..., heads * c:2 * heads * c], tol=5e-5)
     rep.check("dv", gq[..., 2 * heads * c:], gref[..., 2 * heads * c:], tol=5e-5)
     # same key, same call site: the same mask; another call site or a later counter: another mask
-    out2, used2 = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=3, return_used=True)
+    out2, used2 = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=3, return_used=True, causal=causal)
     assert torch.equal(out2, out) and torch.equal(used2, used)
+    if p == 0:
+        rep.finish()
+        return
     other_site = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=4, return_used=True)[1]
     key[1:].add_(1)
     later = HF.mha_attention_tokens(qkv, heads, p, key, stream_id=3, return_used=True)[1]
@@ -1068,14 +1100,14 @@ def test_attention_dropout_zero_probability_is_the_plain_kernel_and_bad_argument
     out = torch.empty(3, 20, 16, device="cuda")
     lse = torch.empty(3, 2, 20, device="cuda")
     used = torch.empty(1, dtype=torch.int64, device="cuda")
-    rc = lib.otvae_attn_dropout_fwd(L.ptr(qkv), 3, 20, 2, 8, 8 ** -0.5, 0.0, L.ptr(key), 0, L.ptr(out), L.ptr(lse), L.ptr(used), L.stream())
+    rc = lib.otvae_attn_dropout_fwd(L.ptr(qkv), 3, 20, 2, 8, 8 ** -0.5, 0.0, 0, L.ptr(key), 0, L.ptr(out), L.ptr(lse), L.ptr(used), L.stream())
     assert rc == 0
     plain = HF.mha_attention_tokens(qkv, 2)
     assert (out - plain).abs().max().item() < 1e-6
     assert HF.attention_dropout_mask(used, 3, 20, 2, 0.0).all()
     for bad in (dict(p=1.0), dict(p=-0.1), dict(t=300), dict(c=5)):
         t, c, p = bad.get("t", 20), bad.get("c", 8), bad.get("p", 0.1)
-        rc = lib.otvae_attn_dropout_fwd(L.ptr(qkv), 1, t, 1, c, 1.0, p, L.ptr(key), 0, L.ptr(out), L.ptr(lse), L.ptr(used), L.stream())
+        rc = lib.otvae_attn_dropout_fwd(L.ptr(qkv), 1, t, 1, c, 1.0, p, 0, L.ptr(key), 0, L.ptr(out), L.ptr(lse), L.ptr(used), L.stream())
         assert rc != 0, bad
     with pytest.raises(ValueError):
         HF.mha_attention_tokens(qkv, 2, 0.1)
