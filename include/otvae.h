@@ -279,7 +279,9 @@ int otvae_mean_cov(const double* n_obs, const double* sum_x, const double* sum_x
 
 /* ---- symmetric eigen-decomposition based matrix functions (ot/matrix_utils.py:37-109) --------------------- */
 /* A[nb][D][D] fp64 symmetric (lower triangle is read, like eigh(UPLO='L')).  fn: 0 = none (eigvals only),
- * 1 = sqrtm, 2 = invsqrtm.  out[nb][D][D] = V f(lambda) V^T, eigvals[nb][D] ascending-unsorted.  D <= 128.
+ * 1 = sqrtm, 2 = invsqrtm: out[nb][D][D] = V f(lambda) V^T; 3 = eigenvectors: out[nb][k][:] is the unit eigenvector of
+ * eigvals[nb][k] (so that callers form several functions of one matrix from a single decomposition).  eigvals[nb][D]
+ * are not sorted.  D <= 128: one workgroup per matrix in LDS; 128 < D <= 2048: block Jacobi.
  * ws: bytes from otvae_eigh_ws. */
 int64_t otvae_eigh_ws(int nb, int D);
 int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, void* stream);

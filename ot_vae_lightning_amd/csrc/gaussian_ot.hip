@@ -294,6 +294,11 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_kernel(const double* __rest
         eigvals[(size_t)blockIdx.x * D + k] = lam;
     }
     if (fn == 0 || out == nullptr) return;
+    if (fn == 3) {  // the eigenvectors themselves, one per row (row k belongs to eigvals[k])
+        double* ob = out + boff;
+        for (int e = tid; e < D * D; e += EIGH_THREADS) ob[e] = VT[e];
+        return;
+    }
     // stash f(lambda) in A's pad column A[k][D]
     for (int k = tid; k < D; k += EIGH_THREADS) {
         const double lam = A[k * LD + k];
@@ -442,8 +447,8 @@ __global__ __launch_bounds__(256) void eb_finish_kernel(const double* __restrict
         if (j == 0) eigvals[k] = lam;
         if (fn != 0) {
             const double v = Vt[(size_t)k * Dp + j];
-            Vd[e] = v;
-            Td[e] = ((fn == 1) ? sqrt(lam) : 1.0 / sqrt(lam)) * v;
+            Vd[e] = v;  // fn == 3: Vd is the caller's `out`
+            if (fn != 3) Td[e] = ((fn == 1) ? sqrt(lam) : 1.0 / sqrt(lam)) * v;
         }
     }
 }
@@ -458,7 +463,7 @@ static size_t g_eigh_lds_set = 0;
 
 extern "C" int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, void* stream) {
     OTVAE_REQUIRE(A && eigvals && ws && nb > 0 && D > 0, "otvae_eigh_fn: bad argument");
-    OTVAE_REQUIRE(fn >= 0 && fn <= 2, "otvae_eigh_fn: fn must be 0, 1 or 2");
+    OTVAE_REQUIRE(fn >= 0 && fn <= 3, "otvae_eigh_fn: fn must be 0, 1, 2 or 3");
     OTVAE_REQUIRE(fn == 0 || out, "otvae_eigh_fn: out missing");
     if (D > EIGH_MAX_D) return eigh_block(A, nb, D, fn, out, eigvals, (double*)ws, (hipStream_t)stream);
     const size_t lds = eigh_lds_bytes(D);
@@ -573,8 +578,9 @@ static int eigh_block(const double* A, int nb, int D, int fn, double* out, doubl
                 eb_cols_kernel<<<dim3(chunks, np), 256, 0, st>>>(Aw, U, Dp, round, nblk, done);
             }
         }
-        eb_finish_kernel<<<imin(cdiv((size_t)D * D, 256), 2048), 256, 0, st>>>(Aw, Vt, D, Dp, fn, eigvals + (size_t)b * D, Vd, Td);
-        if (fn != 0)  // out = Vd^T * Td
+        eb_finish_kernel<<<imin(cdiv((size_t)D * D, 256), 2048), 256, 0, st>>>(Aw, Vt, D, Dp, fn, eigvals + (size_t)b * D,
+                                                                              fn == 3 ? out + (size_t)b * D * D : Vd, Td);
+        if (fn == 1 || fn == 2)  // out = Vd^T * Td
             gemm_f64_kernel<<<dim3(cdiv(D, 16), cdiv(D, 16), 1), 256, 0, st>>>(1, 0, D, D, D, 1.0, Vd, 0, Td, 0, 0.0,
                                                                              out + (size_t)b * D * D);
         OTVAE_CHECK_LAUNCH("otvae_eigh_fn(block)");

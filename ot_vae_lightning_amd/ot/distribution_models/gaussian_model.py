@@ -13,7 +13,7 @@ from torch import Tensor
 
 from ... import _lib
 from ..._lib import check, ptr, stream
-from ..matrix_utils import eye_like, make_psd
+from ..matrix_utils import eigh_vectors, eye_like, make_psd, psd_shift
 from ..w2_utils import W2Mixin
 from .base import DistributionModel
 
@@ -130,6 +130,19 @@ class GaussianModel(DistributionModel, W2Mixin):
         dist = self.instantiate_normal(self.mean.unsqueeze(-2), scale=self.cov.unsqueeze(-2) ** 0.5,
                                        covariance_matrix=self.cov.unsqueeze(-3) if not self.diag else None)
         return dist.log_prob(samples.type_as(self.mean))
+
+    def cov_spectrum(self):
+        """(cov, eigvals, Vt) of the full-matrix model with ONE eigendecomposition: ``cov`` is what the attribute of that
+        name returns (the stored matrix mirrored from its upper triangle, then shifted to be strictly positive definite:
+        the two parametrisations registered in ``__init__``), and (eigvals, Vt) is its spectrum, which the attribute
+        computes too -- to find the shift -- and throws away."""
+        if self.diag:
+            raise ValueError("cov_spectrum is for full covariance matrices")
+        raw = self.parametrizations.cov.original
+        sym = (raw.triu() + raw.triu(1).transpose(-1, -2)).double()
+        lam, vt = eigh_vectors(sym)
+        shift = psd_shift(lam, strict=True, only_if_needed=False)
+        return sym + shift[..., None, None] * eye_like(sym), lam + shift[..., None], vt
 
     def w2(self, other) -> Tensor:
         return self.w2_gaussian(self.mean, other.mean, self.variances, self.get_var_normal(other))

@@ -10,7 +10,7 @@ from .. import _lib
 from .._lib import check, ptr, stream
 
 __all__ = ["eye_like", "sqrtm", "invsqrtm", "is_spd", "is_pd", "is_symmetric", "min_eig", "make_psd", "mean_cov",
-           "STABILITY_CONST", "eigvals_and_fn", "matmul64"]
+           "STABILITY_CONST", "eigvals_and_fn", "matmul64", "eigh_vectors", "spectral_fn", "psd_shift"]
 
 STABILITY_CONST = 1e-8
 
@@ -25,7 +25,7 @@ def _as_batch(m: Tensor) -> Tuple[Tensor, torch.Size]:
 
 
 def eigvals_and_fn(matrices: Tensor, fn: int):
-    """fn: 0 -> eigenvalues only, 1 -> sqrtm, 2 -> invsqrtm.  Returns (eigvals [*, D], f(M) [*, D, D] | None), fp64.
+    """fn: 0 -> eigenvalues only, 1 -> sqrtm, 2 -> invsqrtm, 3 -> eigenvector rows.  Returns (eigvals [*, D], f(M) [*, D, D] | None), fp64.
     Reads the lower triangle like torch.linalg.eigh(UPLO='L') (reference matrix_utils.py:44)."""
     lib = _lib.load()
     a, lead = _as_batch(matrices)
@@ -35,6 +35,34 @@ def eigvals_and_fn(matrices: Tensor, fn: int):
     out = torch.empty_like(a) if fn else None
     check(lib.otvae_eigh_fn(ptr(a), nb, d, fn, ptr(out), ptr(ev), ptr(ws), stream()), "otvae_eigh_fn")
     return ev.reshape(*lead, d), (out.reshape(*lead, d, d) if fn else None)
+
+
+def eigh_vectors(matrices: Tensor) -> Tuple[Tensor, Tensor]:
+    """(eigvals [*, D], Vt [*, D, D]) with Vt[..., k, :] the unit eigenvector of eigvals[..., k]: one decomposition from which
+    several functions of the same matrix can be formed (``spectral_fn``) instead of one Jacobi run per function."""
+    return eigvals_and_fn(matrices, 3)
+
+
+def spectral_fn(f_of_eigvals: Tensor, vt: Tensor) -> Tensor:
+    """V f(lambda) V^T from ``eigh_vectors`` output: [*, D], [*, D, D] -> [*, D, D] (fp64)"""
+    lead, d = vt.shape[:-2], vt.shape[-1]
+    v3 = vt.reshape(-1, d, d)
+    out = matmul64(v3, f_of_eigvals.reshape(-1, d, 1) * v3, trans_a=True)
+    return out.reshape(*lead, d, d)
+
+
+def psd_shift(eigvals: Tensor, strict: bool, only_if_needed: bool) -> Tensor:
+    """the diagonal shift ``make_psd`` adds, from eigenvalues already known ([*, D] -> [*]): |min(lambda_min, 0)| (+1e-8 if
+    strict); with ``only_if_needed`` it is zero unless some matrix of the batch fails the definiteness test.  Device
+    arithmetic only, the same as ``otvae_make_psd``."""
+    lo = eigvals.min(-1)[0]
+    shift = lo.clamp(max=0).abs()
+    if strict:
+        shift = shift + STABILITY_CONST
+    if only_if_needed:
+        bad = ~(lo > 0) if strict else ~(lo >= 0)
+        shift = shift * bad.any().to(shift.dtype)
+    return shift
 
 
 def eye_like(matrices: Tensor) -> Tensor:

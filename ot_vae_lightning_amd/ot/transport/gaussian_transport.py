@@ -4,7 +4,7 @@ Device work, all behind ``W2Mixin`` / ``GaussianModel`` (see ``ot/w2_utils.py`` 
 
     update     otvae_gauss_stats        running sum / outer-product sum per side (fp64 accumulators)
     compute    otvae_mean_cov           -> (mean, cov) per side
-               otvae_eigh_fn, otvae_gemm_f64, otvae_w2_tail, otvae_make_psd
+               otvae_eigh_fn (one decomposition per covariance, eigenvector output), otvae_gemm_f64, otvae_w2_tail
                                         -> squared W2 distance, the eq. 17 operator T and the noise covariance
     transport  otvae_apply_transport    (x - mean_s) @ T^T + mean_t (+ noise)
 
@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 from torch import Tensor
 
 from ..distribution_models.gaussian_model import GaussianModel
-from ..w2_utils import W2Mixin
+from ..w2_utils import W2Mixin, w2_and_transport_operator
 from .base import TransportOperator
 
 __all__ = ["GaussianTransport"]
@@ -44,6 +44,14 @@ class GaussianTransport(TransportOperator, W2Mixin):
 
     def compute(self) -> Tensor:
         self.fit_models()
+        if not (self.diag or self.stochastic):
+            # full matrices: distance and operator share the eigendecompositions of the two covariances (4 Jacobi runs
+            # instead of the 10 that `.cov` + w2_gaussian + compute_transport_operators make between them)
+            s, t = self.source_model, self.target_model
+            distance, operator, noise_cov = w2_and_transport_operator(
+                s.mean, t.mean, s.cov_spectrum(), t.cov_spectrum(), pg_star=self.pg_star, make_pd=self.make_pd, dtype=self.dtype)
+            self._set_operators(operator, noise_cov)
+            return distance
         mean_s, mean_t, cov_s, cov_t = self._moments()
         distance = self.w2_gaussian(mean_s, mean_t, cov_s, cov_t)
         self._set_operators(*self.compute_transport_operators(cov_s, cov_t))
@@ -63,9 +71,9 @@ class GaussianTransport(TransportOperator, W2Mixin):
         axis = self._sample_axis(inputs)
         if self.transport_operator is None:
             raise RuntimeError("call `compute()` before `transport()`")
-        mean_s, mean_t, _, _ = self._moments()
-        moved = self.apply_transport(inputs, mean_s, mean_t, self.transport_operator, self.cov_stochastic_noise,
-                                     batch_dim=axis)
+        # the means only: reading a model's `cov` evaluates its positive-definite parametrisation (an eigendecomposition)
+        moved = self.apply_transport(inputs, self.source_model.mean, self.target_model.mean, self.transport_operator,
+                                     self.cov_stochastic_noise, batch_dim=axis)
         return moved.type_as(inputs)
 
     def extra_repr(self) -> str:

@@ -14,7 +14,8 @@ from torch import Tensor
 from .. import _lib
 from .._lib import check, ptr, stream
 from .matrix_utils import *  # noqa: F401,F403
-from .matrix_utils import STABILITY_CONST, eigvals_and_fn, eye_like, is_symmetric, matmul64, mean_cov
+from .matrix_utils import (STABILITY_CONST, eigh_vectors, eigvals_and_fn, eye_like, is_symmetric, matmul64, mean_cov, psd_shift,
+                           spectral_fn)
 
 __all__ = ["w2_gaussian", "batch_w2_dissimilarity_gaussian_diag", "batch_ot_gmm", "sinkhorn_log", "sinkhorn_log_potentials",
            "sq_euclidean_cost", "ot_cost", "compute_transport_operators", "apply_transport", "W2Mixin"]
@@ -215,6 +216,52 @@ def compute_transport_operators(cov_source: Tensor, cov_target: Tensor, stochast
     T = (1 - pg_star) * matmul64(matmul64(irs, inner), irs) + pg_star * eye_like(cs)
     T = T.reshape(*lead, d, d).to(dtype)
     return T, torch.zeros_like(T)
+
+
+def w2_and_transport_operator(mean_source: Tensor, mean_target: Tensor, spec_source, spec_target, pg_star: float = 0,
+                              make_pd: bool = False, dtype=torch.double) -> Tuple[Tensor, Tensor, Tensor]:
+    """``w2_gaussian`` and the non-stochastic full-matrix ``compute_transport_operators`` of the same pair of Gaussians in
+    one go.  Separately they run ten Jacobi eigendecompositions (definiteness tests, square roots and inverse square
+    roots of the same two covariances, twice over); here each covariance is decomposed once -- ``spec_*`` =
+    (cov, eigvals, Vt) as ``GaussianModel.cov_spectrum`` returns them -- and every function of it is V f(lambda) V^T
+    from that spectrum, which leaves four decompositions (the two covariances and the two inner products).  The
+    arithmetic per step is that of the two functions above (reference ot/w2_utils.py:40-80, 756-769).
+    Returns (W2^2 [*], T [*, D, D], Cw = 0)."""
+    lib = _lib.load()
+    (cs, lam_s, vt_s), (ct, lam_t, vt_t) = spec_source, spec_target
+    lead, d = cs.shape[:-2], cs.shape[-1]
+    eye = eye_like(cs)
+
+    def validated(cov, lam, name):  # the 'spd' argument validation of both functions, from the known spectrum
+        if make_pd:
+            shift = psd_shift(lam, strict=True, only_if_needed=True)
+            return cov + shift[..., None, None] * eye, lam + shift[..., None]
+        if not bool((lam.min(-1)[0] > 0).all()):
+            raise ValueError(f"`{name}` should be symmetric and positive definite. Use `make_pd=True` to automatically add a "
+                             "small value to the matrix diagonals.")
+        return cov, lam
+
+    cs_v, lam_sv = validated(cs, lam_s, "cov_source")
+    ct_v, lam_tv = validated(ct, lam_t, "cov_target")
+    flat = lambda m: m.reshape(-1, d, d).contiguous()  # noqa: E731
+    # squared W2: |ms - mt|^2 + tr(Cs + Ct - 2 (Ct^1/2 Cs Ct^1/2)^1/2)
+    rt = flat(spectral_fn(lam_tv.sqrt(), vt_t))
+    mix = matmul64(matmul64(rt, flat(cs_v)), rt)
+    if not bool(is_symmetric(mix).all()):
+        raise ValueError("`cov_target_sqrt @ cov_source @ cov_target_sqrt` should be symmetric.")
+    sq = eigvals_and_fn(mix, 1)[1]
+    ms = mean_source.double().expand(*lead, d).reshape(-1, d).contiguous()
+    mt = mean_target.double().expand(*lead, d).reshape(-1, d).contiguous()
+    w2 = torch.empty(ms.shape[0], device=ms.device, dtype=torch.float64)
+    check(lib.otvae_w2_tail(ptr(ms), ptr(mt), ptr(flat(cs_v)), ptr(flat(ct_v)), ptr(sq), ms.shape[0], d, ptr(w2), stream()),
+          "otvae_w2_tail")
+    # eq. 17: T = (1 - pg) Cs^-1/2 (Cs^1/2 Ct Cs^1/2)^1/2 Cs^-1/2 + pg I, with Ct as given (only Cs is validated there)
+    rs = flat(spectral_fn(lam_sv.sqrt(), vt_s))
+    irs = flat(spectral_fn((lam_sv + STABILITY_CONST).rsqrt(), vt_s))
+    inner = eigvals_and_fn(matmul64(matmul64(rs, flat(ct)), rs), 1)[1]
+    T = (1 - pg_star) * matmul64(matmul64(irs, inner), irs) + pg_star * flat(eye)
+    T = T.reshape(*lead, d, d).to(dtype)
+    return w2.reshape(lead), T, torch.zeros_like(T)
 
 
 def apply_transport(input: Tensor, mean_source: Tensor, mean_target: Tensor, T: Tensor, Cw: Optional[Tensor] = None,
