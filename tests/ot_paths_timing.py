@@ -2,7 +2,7 @@
 the box's host cores with torch's CPU ops (LAPACK eigh etc.) -- the way the reference runs them when no GPU is present.
 Sizes are the reference's: latent statistics of BASELINE configs[1] (D = 128) and of tests/test_latent_transport.py
 (D = 64*4*4 = 1024, GMM with 10 components on 64-dim needles, codebook of 1024 atoms on 16-dim channels).
-Sanity numbers for the f rows, not the headline metric.  Usage: python tools/ot_bench.py [--no-cpu]"""
+Sanity numbers for the f rows, not the headline metric.  Usage: python tests/ot_paths_timing.py [--no-cpu]"""
 import os
 import sys
 import time
