@@ -115,6 +115,21 @@ def _require_spd(cov: Tensor, name: str, make_pd: bool, strict: bool, verbose: b
     return cov
 
 
+def _spd_and_roots(cov: Tensor, name: str, make_pd: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """the strict 'spd' validation of ``_require_spd`` plus cov^1/2 and (cov + 1e-8 I)^-1/2, all from ONE eigendecomposition
+    ([nb, D, D] -> validated cov, sqrt, inverse sqrt): a diagonal shift moves the eigenvalues and leaves the vectors"""
+    if not bool(is_symmetric(cov).all()):
+        raise ValueError(f"`{name}` should be symmetric.")
+    lam, vt = eigh_vectors(cov)
+    if make_pd:
+        shift = psd_shift(lam, strict=True, only_if_needed=True)
+        cov, lam = cov + shift[..., None, None] * eye_like(cov), lam + shift[..., None]
+    elif not bool((lam.min(-1)[0] > 0).all()):
+        raise ValueError(f"`{name}` should be symmetric and positive definite. "
+                         "Use `make_pd=True` to automatically add a small value to the matrix diagonals.")
+    return cov, spectral_fn(lam.sqrt(), vt), spectral_fn((lam + STABILITY_CONST).rsqrt(), vt)
+
+
 def w2_gaussian(mean_source: Tensor, mean_target: Tensor, cov_source: Tensor, cov_target: Tensor,
                 make_pd: bool = False, verbose: bool = False, dtype=torch.double) -> Tensor:
     """Squared Gelbrich distance |ms-mt|^2 + tr(Cs + Ct - 2 (Ct^1/2 Cs Ct^1/2)^1/2), fp64, batched over leading dims."""
@@ -127,9 +142,7 @@ def w2_gaussian(mean_source: Tensor, mean_target: Tensor, cov_source: Tensor, co
     mt = mean_target.double().expand(*lead, d).reshape(-1, d).contiguous()
     cs = _require_spd(cov_source.double().expand(*lead, d, d).reshape(-1, d, d).contiguous(), "cov_source", make_pd,
                       True, verbose)
-    ct = _require_spd(cov_target.double().expand(*lead, d, d).reshape(-1, d, d).contiguous(), "cov_target", make_pd,
-                      True, verbose)
-    rt = eigvals_and_fn(ct, 1)[1]
+    ct, rt = _spd_and_roots(cov_target.double().expand(*lead, d, d).reshape(-1, d, d).contiguous(), "cov_target", make_pd)[:2]
     mix = matmul64(matmul64(rt, cs), rt)
     if not bool(is_symmetric(mix).all()):
         raise ValueError("`cov_target_sqrt @ cov_source @ cov_target_sqrt` should be symmetric.")
@@ -205,13 +218,10 @@ def compute_transport_operators(cov_source: Tensor, cov_target: Tensor, stochast
         return T, torch.zeros_like(T)
     d = cov_source.shape[-1]
     lead = torch.broadcast_shapes(cov_source.shape[:-2], cov_target.shape[:-2])
-    cs = _require_spd(cov_source.double().expand(*lead, d, d).reshape(-1, d, d).contiguous(), "cov_source", make_pd,
-                      True, verbose)
+    cs, rs, irs = _spd_and_roots(cov_source.double().expand(*lead, d, d).reshape(-1, d, d).contiguous(), "cov_source", make_pd)
     ct = cov_target.double().expand(*lead, d, d).reshape(-1, d, d).contiguous()
     if not bool(is_symmetric(ct).all()):
         raise ValueError("`cov_target` should be symmetric.")
-    rs = eigvals_and_fn(cs, 1)[1]
-    irs = eigvals_and_fn(cs + STABILITY_CONST * eye_like(cs), 2)[1]
     inner = eigvals_and_fn(matmul64(matmul64(rs, ct), rs), 1)[1]
     T = (1 - pg_star) * matmul64(matmul64(irs, inner), irs) + pg_star * eye_like(cs)
     T = T.reshape(*lead, d, d).to(dtype)
