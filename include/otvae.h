@@ -246,6 +246,24 @@ int otvae_nelbo_bwd(const float* pred, const float* target, int64_t numel, int B
 int otvae_step_begin(int32_t* step, void* stream);
 int otvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                     const int32_t* step, float grad_scale, void* stream);
+/* the same update with the gradient scale read from device memory (what otvae_grad_clip_coef leaves in out[0]) */
+int otvae_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                        const int32_t* step, const float* grad_scale_dev, void* stream);
+
+/* ---- global-norm gradient clipping (configs/ddp.yaml:4 `gradient_clip_val: 1.0`, applied by Lightning through
+ * torch.nn.utils.clip_grad_norm_) over the flat gradient buffer -------------------------------------------------- */
+/* g[n] holds the gradient SUM over ranks, grad_scale = 1/world_size.  norm = |g * grad_scale|_2 (fp64 accumulation);
+ * out[0] = grad_scale * min(1, max_norm / (norm + 1e-6)) = the scale otvae_adam_step_dev applies to g; out[1] = norm.
+ * max_norm <= 0: no clipping (out[0] = grad_scale).  ws: otvae_grad_clip_ws() doubles. */
+int otvae_grad_clip_ws(void);
+int otvae_grad_clip_coef(const float* g, int64_t n, float grad_scale, float max_norm, double* ws, float* out,
+                         void* stream);
+
+/* ---- standard-normal draws (prior/gaussian.py:93 `q.rsample()`, the prior samples of the minibatch-OT prior) ---------- */
+/* out[n] ~ N(0, 1) from a counter-based hash of (key[0] = seed, key[1] = call counter, stream_id, element index): the
+ * values do not depend on the launch shape.  key = device int64[3] {seed, counter, 0}; advance != 0: the call's last
+ * workgroup increments the counter, so a captured step draws fresh noise on every replay without host work. */
+int otvae_normal_fill(float* out, int64_t n, int64_t* key, int stream_id, int advance, void* stream);
 
 /* ---- sinkhorn_log (ot/w2_utils.py:276-319) ---------------------------------------------------------------- */
 /* a[nb][N], b[nb][M], C[nb][N][M] -> pi[nb][N][M] (may alias no input), u[nb][N], v[nb][M] potentials.
@@ -256,14 +274,37 @@ int64_t otvae_sinkhorn_ws(int dtype, int nb, int N, int M);
 int otvae_sinkhorn_log(int dtype, const void* a, const void* b, const void* C, int nb, int N, int M,
                        double reg, int max_iter, double threshold, void* ws,
                        void* pi, void* u, void* v, int32_t* iters_done, void* stream);
+/* The same solve on C / max(C) per problem, the `cost_matrix / max_per_mat` of batch_ot_gmm (ot/w2_utils.py:265-266), without
+ * a pass that finds the maximum or divides: pmax[nb][P] are partial maxima of each problem's C (otvae_sqdist_max leaves them),
+ * reduced inside the solver's first kernel; cmax[nb] (may be NULL) receives the maxima.  a / b may be NULL in both entry points:
+ * uniform marginals 1/N, 1/M.
+ * A persistent solve whose bounded wait ran out (OTVAE_SK_SPIN_LIMIT polls, default 2^22) fills pi, u, v with NaN and reports
+ * iters_done = -1: a starved solve cannot pass for a result. */
+int otvae_sinkhorn_log_normalized(int dtype, const void* a, const void* b, const void* C, const void* pmax, int P, int nb,
+                                  int N, int M, double reg, int max_iter, double threshold, void* ws, void* pi, void* u, void* v,
+                                  void* cmax, int32_t* iters_done, void* stream);
+/* The minibatch-OT prior's forward (configs[2]/[3]: BASELINE.json; the arithmetic of ot/w2_utils.py:265-269 on
+ * C_ij = |z_i - y_j|^2 with uniform marginals) in one call: C[N][M], pi[N][M], u[N], v[M], cost[1] = sum C * pi, cmax[1]
+ * (may be NULL).  z[N][D], y[M][D].  cost[cost_rep] = loss_scale * sum C * pi, the same value cost_rep times (the Prior
+ * contract returns one loss entry per sample, prior/base.py:74-78; loss_scale = loss_coeff x annealing).
+ * ws: otvae_sinkhorn_prior_ws bytes. */
+int64_t otvae_sinkhorn_prior_ws(int dtype, int N, int M);
+int otvae_sinkhorn_prior_fwd(int dtype, const void* z, const void* y, int N, int M, int D, double reg, int max_iter,
+                             double threshold, double loss_scale, int cost_rep, void* ws, void* C, void* pi, void* u, void* v,
+                             void* cost, void* cmax, int32_t* iters_done, void* stream);
 /* cost[nb] = sum_ij C*pi (fp64 accumulate, fixed order), out dtype = dtype; ws: double[nb*64] */
 int otvae_ot_cost(int dtype, const void* C, const void* pi, int nb, int N, int M, double* ws, void* cost, void* stream);
 /* pairwise squared euclidean cost C[nb][N][M] = |x_i - y_j|^2, x[nb][N][D], y[nb][M][D] */
 int otvae_sqdist(int dtype, const void* x, const void* y, int nb, int N, int M, int D, void* C, void* stream);
-/* Gradient of sum_ij C_ij pi_ij with respect to z for C_ij = |z_i - y_j|^2 and a fixed plan (the minibatch OT prior's
- * backward, SinkhornPrior): gz[i][d] = 2 g sum_j pi_ij (z_id - y_jd); z [N][D], y [M][D], pi [N][M], g a device scalar. */
-int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int N, int M, int D, void* gz,
-                       void* stream);
+/* the same, also leaving the maximum of every output tile in pmax[nb][otvae_sqdist_max_parts(dtype, N, M)] */
+int otvae_sqdist_max_parts(int dtype, int N, int M);
+int otvae_sqdist_max(int dtype, const void* x, const void* y, int nb, int N, int M, int D, void* C, void* pmax, void* stream);
+/* Gradient of scale * sum_ij C_ij pi_ij with respect to z for C_ij = |z_i - y_j|^2 and a fixed plan (the minibatch OT prior's
+ * backward, SinkhornPrior): gz[i][d] = 2 scale (sum_q g[q]) sum_j pi_ij (z_id - y_jd); z [N][D], y [M][D], pi [N][M]; g[ng] =
+ * the upstream gradients of the ng replicas of the cost that the forward handed out (device memory).  fp32 runs on the
+ * matrix cores (16 x 16 x 4 MFMA tiles, fixed summation order). */
+int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int ng, double scale, int N,
+                       int M, int D, void* gz, void* stream);
 
 /* ---- GaussianModel statistics (ot/distribution_models/gaussian_model.py:99-108,144-157) ------------------- */
 /* samples [nb][B][D] (in_dtype 0=fp32,1=fp64) -> fp64 sum_x[nb][D], sum_xx[nb][D][D] (diag: [nb][D]),

@@ -85,11 +85,20 @@ SIGNATURES = {
     "otvae_nelbo_bwd": (i32, [vp, vp, i64, i32, f32, vp, vp, vp, vp]),
     "otvae_step_begin": (i32, [vp, vp]),
     "otvae_adam_step": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp]),
+    "otvae_adam_step_dev": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "otvae_grad_clip_ws": (i32, []),
+    "otvae_grad_clip_coef": (i32, [vp, i64, f32, f32, vp, vp, vp]),
     "otvae_sinkhorn_ws": (i64, [i32, i32, i32, i32]),
     "otvae_sinkhorn_log": (i32, [i32, vp, vp, vp, i32, i32, i32, f64, i32, f64, vp, vp, vp, vp, vp, vp]),
+    "otvae_sinkhorn_log_normalized": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, f64, i32, f64, vp, vp, vp, vp, vp, vp, vp]),
+    "otvae_sinkhorn_prior_ws": (i64, [i32, i32, i32]),
+    "otvae_sinkhorn_prior_fwd": (i32, [i32, vp, vp, i32, i32, i32, f64, i32, f64, f64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "otvae_sqdist_max_parts": (i32, [i32, i32, i32]),
+    "otvae_sqdist_max": (i32, [i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "otvae_normal_fill": (i32, [vp, i64, vp, i32, i32, vp]),
     "otvae_ot_cost": (i32, [i32, vp, vp, i32, i32, i32, vp, vp, vp]),
     "otvae_sqdist": (i32, [i32, vp, vp, i32, i32, i32, i32, vp, vp]),
-    "otvae_ot_cost_grad": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "otvae_ot_cost_grad": (i32, [i32, vp, vp, vp, vp, i32, f64, i32, i32, i32, vp, vp]),
     "otvae_gauss_stats_ws": (i64, [i32, i32, i32, i32]),
     "otvae_gauss_stats": (i32, [i32, vp, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp]),
     "otvae_mean_cov": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -221,7 +221,9 @@ extern "C" int otvae_step_begin(int32_t* step, void* stream) {
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, const float* __restrict__ hyper,
-                                                   const int32_t* __restrict__ step, float grad_scale) {
+                                                   const int32_t* __restrict__ step, float grad_scale,
+                                                   const float* __restrict__ scale_dev) {
+    if (scale_dev) grad_scale = *scale_dev;  // clip coefficient x 1/world, left by grad_clip_final_kernel
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
     const int t = *step;
     const float bc1 = 1.f - powf(b1, (float)t);
@@ -262,7 +264,70 @@ extern "C" int otvae_adam_step(float* p, const float* g, float* m, float* v, int
     OTVAE_REQUIRE(p && g && m && v && hyper && step && n > 0, "otvae_adam_step: bad argument");
     OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                   "otvae_adam_step: buffers must be 16-byte aligned");
-    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, step, grad_scale);
+    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, step, grad_scale, nullptr);
     OTVAE_CHECK_LAUNCH("otvae_adam_step");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                                   const int32_t* step, const float* grad_scale_dev, void* stream) {
+    OTVAE_REQUIRE(p && g && m && v && hyper && step && grad_scale_dev && n > 0, "otvae_adam_step_dev: bad argument");
+    OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                  "otvae_adam_step_dev: buffers must be 16-byte aligned");
+    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, step, 1.f, grad_scale_dev);
+    OTVAE_CHECK_LAUNCH("otvae_adam_step_dev");
+    return OTVAE_OK;
+}
+
+// ---- global-norm gradient clipping (reference configs/ddp.yaml:4 `gradient_clip_val: 1.0` -> Lightning ->
+// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (|g|_2 + 1e-6)), g *= coef) over the flat gradient buffer.
+// g holds the SUM over ranks; the gradient that is clipped is g * grad_scale (the mean).  The scale Adam then applies
+// to g is grad_scale * coef: no pass that rewrites g.
+#define CLIP_PARTS 512
+__global__ __launch_bounds__(256) void grad_sqnorm_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ ws) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 q = reinterpret_cast<const float4*>(g)[i];
+        s += (double)(q.x * q.x + q.y * q.y) + (double)(q.z * q.z + q.w * q.w);
+    }
+    for (int64_t i = (n4 << 2) + blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)(g[i] * g[i]);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void grad_clip_final_kernel(const double* __restrict__ ws, int parts, float grad_scale,
+                                                              float max_norm, float* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < parts; i += 256) s += ws[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3])) * grad_scale;
+        float coef = max_norm / (norm + 1e-6f);
+        coef = coef < 1.f ? coef : 1.f;
+        if (!(max_norm > 0.f)) coef = 1.f;  // max_norm <= 0: report the norm only
+        out[0] = grad_scale * coef;
+        out[1] = norm;
+    }
+}
+
+extern "C" int otvae_grad_clip_ws(void) { return CLIP_PARTS; }
+
+extern "C" int otvae_grad_clip_coef(const float* g, int64_t n, float grad_scale, float max_norm, double* ws, float* out,
+                                    void* stream) {
+    OTVAE_REQUIRE(g && ws && out && n > 0, "otvae_grad_clip_coef: bad argument");
+    OTVAE_REQUIRE((uintptr_t)g % 16 == 0, "otvae_grad_clip_coef: the gradient buffer must be 16-byte aligned");
+    const int parts = imin(CLIP_PARTS, cdiv(n, 4096));
+    hipStream_t st = (hipStream_t)stream;
+    grad_sqnorm_partial_kernel<<<parts, 256, 0, st>>>(g, n, ws);
+    OTVAE_CHECK_LAUNCH("otvae_grad_clip_coef(partial)");
+    grad_clip_final_kernel<<<1, 256, 0, st>>>(ws, parts, grad_scale, max_norm, out);
+    OTVAE_CHECK_LAUNCH("otvae_grad_clip_coef(final)");
     return OTVAE_OK;
 }

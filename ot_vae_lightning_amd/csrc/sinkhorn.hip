@@ -29,23 +29,49 @@ struct SkCtl {
     int done;            // set by sk_check when the batch-min difference drops below the threshold
     int iters;           // iterations actually performed
     unsigned bar_count;  // persistent kernel: monotone arrival counter of the grid barrier
-    int timeout;         // persistent kernel: a barrier wait ran out (results invalid; iters reports -1)
+    int timeout;         // persistent kernel: a wait ran out (the plan, the potentials and the cost are poisoned with NaN; iters = -1)
+    unsigned spin_limit; // persistent kernel: polls a wait may spend before it gives up (OTVAE_SK_SPIN_LIMIT, default 2^22)
 };
 
-// Cr = -C/reg (row major, into `cr`) and its transpose (into `crt`), 32x32 tiles through LDS
+// Cr = -C/(reg * cmax) (row major, into `cr`) and its transpose (into `crt`), 32x32 tiles through LDS.  cmax = the
+// maximum of problem b's cost matrix, reduced here from the P partial maxima its producer left (otvae_sqdist's epilogue),
+// or 1 when pmax == NULL: the `cost_matrix / max_per_mat` of batch_ot_gmm (ot/w2_utils.py:265-266) without a pass of its
+// own.  The blocks of the first tile row / column also initialise the potentials and the log-marginals (a, b == NULL:
+// uniform 1/N, 1/M), block (0,0,0) the control block.
 template <typename T>
-__global__ __launch_bounds__(256) void sk_init_mat(const T* __restrict__ Cm, int N, int M, T neg_inv_reg, T* __restrict__ cr,
-                                                   T* __restrict__ crt) {
+__global__ __launch_bounds__(256) void sk_init_mat(const T* __restrict__ Cm, int N, int M, T inv_reg, const T* __restrict__ pmax, int P,
+                                                   T* __restrict__ cr, T* __restrict__ crt, const T* __restrict__ a,
+                                                   const T* __restrict__ b, T* __restrict__ loga, T* __restrict__ logb,
+                                                   T* __restrict__ u, T* __restrict__ v, SkCtl* ctl, int preset_iters,
+                                                   unsigned spin_limit, unsigned long long* __restrict__ tu,
+                                                   unsigned long long* __restrict__ tv, T* __restrict__ scale_out) {
     __shared__ T tile[32][33];
-    const size_t boff = (size_t)blockIdx.z * N * M;
+    __shared__ T s_red[4];
+    const int pb = blockIdx.z;
+    const size_t boff = (size_t)pb * N * M;
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    T neg_scale = -inv_reg;
+    if (pmax) {
+        T mx = MathT<T>::ninf();
+        for (int i = threadIdx.x; i < P; i += 256) {
+            const T q = pmax[(size_t)pb * P + i];
+            mx = q > mx ? q : mx;
+        }
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        const T m01 = s_red[0] > s_red[1] ? s_red[0] : s_red[1], m23 = s_red[2] > s_red[3] ? s_red[2] : s_red[3];
+        const T cmax = m01 > m23 ? m01 : m23;
+        neg_scale = -inv_reg / cmax;
+        if (scale_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[pb] = cmax;
+    }
     for (int r = ty; r < 32; r += 8) {
         const int i = i0 + r, j = j0 + tx;
         if (i < N && j < M) {
-            const T v = Cm[boff + (size_t)i * M + j] * neg_inv_reg;
-            cr[boff + (size_t)i * M + j] = v;
-            tile[r][tx] = v;
+            const T val = Cm[boff + (size_t)i * M + j] * neg_scale;
+            cr[boff + (size_t)i * M + j] = val;
+            tile[r][tx] = val;
         }
     }
     __syncthreads();
@@ -53,28 +79,24 @@ __global__ __launch_bounds__(256) void sk_init_mat(const T* __restrict__ Cm, int
         const int j = j0 + r, i = i0 + tx;
         if (i < N && j < M) crt[boff + (size_t)j * N + i] = tile[tx][r];
     }
-}
-
-template <typename T>
-__global__ void sk_init_vec(const T* __restrict__ a, const T* __restrict__ b, int nb, int N, int M, T* __restrict__ loga,
-                            T* __restrict__ logb, T* __restrict__ u, T* __restrict__ v, SkCtl* ctl, int preset_iters,
-                            unsigned long long* __restrict__ tu, unsigned long long* __restrict__ tv) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nb * N) {
-        loga[i] = MathT<T>::log(a[i] + (T)1e-8);
+    if (blockIdx.x == 0 && threadIdx.x < 32 && i0 + (int)threadIdx.x < N) {
+        const size_t i = (size_t)pb * N + i0 + threadIdx.x;
+        loga[i] = MathT<T>::log((a ? a[i] : (T)1 / (T)N) + (T)1e-8);
         u[i] = (T)0;
         if (tu) tu[i] = 0ull;  // {epoch 0, +0.0f}: the tagged potentials of sk_persistent_tagged
     }
-    if (i < nb * M) {
-        logb[i] = MathT<T>::log(b[i] + (T)1e-8);
-        v[i] = (T)0;
-        if (tv) tv[i] = 0ull;
+    if (blockIdx.y == 0 && threadIdx.x >= 64 && threadIdx.x < 96 && j0 + (int)threadIdx.x - 64 < M) {
+        const size_t j = (size_t)pb * M + j0 + threadIdx.x - 64;
+        logb[j] = MathT<T>::log((b ? b[j] : (T)1 / (T)M) + (T)1e-8);
+        v[j] = (T)0;
+        if (tv) tv[j] = 0ull;
     }
-    if (i == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 128) {
         ctl->done = 0;
         ctl->iters = preset_iters;
         ctl->bar_count = 0;
         ctl->timeout = 0;
+        ctl->spin_limit = spin_limit;
     }
 }
 
@@ -181,7 +203,7 @@ struct CohT<double> {
     }
 };
 
-#define SK_SPIN_LIMIT (1u << 22)
+#define SK_SPIN_LIMIT (1u << 22)  // default of SkCtl::spin_limit
 
 // returns false (in every thread of the block) if the wait ran out
 __device__ __forceinline__ bool sk_grid_barrier(SkCtl* ctl, unsigned nblocks, unsigned& epoch) {
@@ -194,9 +216,10 @@ __device__ __forceinline__ bool sk_grid_barrier(SkCtl* ctl, unsigned nblocks, un
         const unsigned prev = __hip_atomic_fetch_add(&ctl->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev + 1 < target) {
             unsigned spins = 0;
+            const unsigned limit = ctl->spin_limit;
             while (__hip_atomic_load(&ctl->bar_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > SK_SPIN_LIMIT) {
+                if (++spins > limit) {
                     ok = 0;
                     __hip_atomic_store(&ctl->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -399,6 +422,7 @@ __global__ __launch_bounds__(NTH) void sk_persistent_tagged(float* __restrict__ 
         }
     }
     if (threadIdx.x == 0) s_fail = 0;
+    const unsigned spin_limit = ctl->spin_limit;
     __syncthreads();
 
     // fetch all `count` entries of a tagged potential at epoch `want` into LDS; false (block-uniform) if a poll ran out
@@ -422,7 +446,7 @@ __global__ __launch_bounds__(NTH) void sk_persistent_tagged(float* __restrict__ 
                         pending &= ~(1u << j);
                     }
                 if (pending) {
-                    if (++spins > SK_SPIN_LIMIT || __hip_atomic_load(&ctl->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (++spins > spin_limit || __hip_atomic_load(&ctl->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                         s_fail = 1;
                         __hip_atomic_store(&ctl->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
@@ -503,7 +527,37 @@ __global__ void sk_copy_iters(const SkCtl* ctl, int32_t* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = ctl->iters;
 }
 
+// A persistent solve whose wait ran out has produced nothing: make that impossible to miss.  The plan and the potentials
+// become NaN (so does every loss computed from them) and iters reports -1; the host wrapper raises when it can look.
+template <typename T>
+__global__ __launch_bounds__(256) void sk_finish(SkCtl* ctl, T* __restrict__ pi, size_t total, T* __restrict__ u, size_t nu,
+                                                 T* __restrict__ v, size_t nv) {
+    if (!__hip_atomic_load(&ctl->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const T nan = (T)NAN;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) pi[e] = nan;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < nu; e += (size_t)gridDim.x * 256) u[e] = nan;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < nv; e += (size_t)gridDim.x * 256) v[e] = nan;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->iters = -1;
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static unsigned sk_spin_limit() {
+    if (const char* e = getenv("OTVAE_SK_SPIN_LIMIT")) {
+        const long long q = atoll(e);
+        if (q >= 0 && q <= 0x7fffffffLL) return (unsigned)q;
+    }
+    return SK_SPIN_LIMIT;
+}
+
+// workgroups of `kernel` (NTH threads, `lds` bytes of dynamic LDS) the device can hold at once: a kernel whose
+// workgroups wait for each other must not be launched with more
+template <typename K>
+static int sk_resident_blocks(K kernel, int nth, size_t lds, int n_cu) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nth, lds) != hipSuccess || per_cu <= 0) return 0;
+    return per_cu * n_cu;
+}
 
 extern "C" int64_t otvae_sinkhorn_ws(int dtype, int nb, int N, int M) {
     if (nb <= 0 || N <= 0 || M <= 0 || dtype < 0 || dtype > 1) return -1;
@@ -515,7 +569,7 @@ extern "C" int64_t otvae_sinkhorn_ws(int dtype, int nb, int N, int M) {
 
 template <typename T>
 static int sinkhorn_impl(const T* a, const T* b, const T* Cm, int nb, int N, int M, double reg, int max_iter, double threshold,
-                         void* ws, T* pi, T* u, T* v, int32_t* iters_done, hipStream_t st) {
+                         const T* pmax, int P, T* cmax_out, void* ws, T* pi, T* u, T* v, int32_t* iters_done, hipStream_t st) {
     char* w = (char*)ws;
     T* crt = (T*)w;
     w += align256((size_t)nb * N * M * sizeof(T));
@@ -536,11 +590,9 @@ static int sinkhorn_impl(const T* a, const T* b, const T* Cm, int nb, int N, int
     SkCtl* ctl = (SkCtl*)w;
     const bool track = threshold > 0.0;
 
-    sk_init_mat<T><<<dim3(cdiv(M, 32), cdiv(N, 32), nb), 256, 0, st>>>(Cm, N, M, (T)(-1.0 / reg), pi, crt);
-    OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(init_mat)");
-    const int nv = nb * (N > M ? N : M);
-    sk_init_vec<T><<<cdiv(nv, 256), 256, 0, st>>>(a, b, nb, N, M, loga, logb, u, v, ctl, track ? 0 : max_iter, tu, tv);
-    OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(init_vec)");
+    sk_init_mat<T><<<dim3(cdiv(M, 32), cdiv(N, 32), nb), 256, 0, st>>>(Cm, N, M, (T)(1.0 / reg), pmax, P, pi, crt, a, b, loga, logb, u, v,
+                                                                       ctl, track ? 0 : max_iter, sk_spin_limit(), tu, tv, cmax_out);
+    OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(init)");
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0, v = 0;
@@ -568,7 +620,20 @@ static int sinkhorn_impl(const T* a, const T* b, const T* Cm, int nb, int N, int
     }
     const int G = cdiv(rows, 8 * rpw);
     const size_t pot_bytes = (size_t)rows * sizeof(T);
-    const bool eligible = N <= 64 * SK_EPL && M <= 64 * SK_EPL && G <= 128 && pot_bytes <= 60 * 1024;
+    bool eligible = N <= 64 * SK_EPL && M <= 64 * SK_EPL && G <= 128 && pot_bytes <= 60 * 1024;
+    if (eligible) {
+        // the workgroups of a persistent solve wait for each other: all G must be resident at once
+        int cap;
+        if (sizeof(T) == 4 && !track && !getenv("OTVAE_SK_BARRIER"))
+            cap = rpw == 1 ? sk_resident_blocks(sk_persistent_tagged<1, 512>, 512, pot_bytes, n_cu)
+                  : rpw == 2 ? sk_resident_blocks(sk_persistent_tagged<2, 512>, 512, pot_bytes, n_cu)
+                             : sk_resident_blocks(sk_persistent_tagged<4, 512>, 512, pot_bytes, n_cu);
+        else
+            cap = rpw == 1 ? sk_resident_blocks(sk_persistent<T, true, 1, 512, true>, 512, pot_bytes, n_cu)
+                  : rpw == 2 ? sk_resident_blocks(sk_persistent<T, true, 2, 512, true>, 512, pot_bytes, n_cu)
+                             : sk_resident_blocks(sk_persistent<T, true, RPWMAX, 512, true>, 512, pot_bytes, n_cu);
+        if (G > cap) eligible = false;
+    }
     if (!getenv("OTVAE_SK_MULTILAUNCH") && (legacy || (eligible && !(pers && atoi(pers) == 0)))) {
         if (legacy) {
             int G1 = imax(1, imin(n_cu, cdiv(rows, 4)));
@@ -594,6 +659,8 @@ static int sinkhorn_impl(const T* a, const T* b, const T* Cm, int nb, int N, int
             sk_persistent<T, true, RPWMAX, 512, true><<<G, 512, pot_bytes, st>>>(pi, crt, loga, logb, u, v, adu, adv, nb, N, M, max_iter, threshold, ctl);
         }
         OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(persistent)");
+        sk_finish<T><<<64, 256, 0, st>>>(ctl, pi, (size_t)nb * N * M, u, (size_t)nb * N, v, (size_t)nb * M);
+        OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(finish)");
     } else {
         for (int it = 0; it < max_iter; ++it) {
             // v_j = log b_j - LSE_i(Cr_ij + u_i): rows of CrT
@@ -616,17 +683,33 @@ static int sinkhorn_impl(const T* a, const T* b, const T* Cm, int nb, int N, int
 extern "C" int otvae_sinkhorn_log(int dtype, const void* a, const void* b, const void* C, int nb, int N, int M, double reg,
                                   int max_iter, double threshold, void* ws, void* pi, void* u, void* v, int32_t* iters_done,
                                   void* stream) {
-    OTVAE_REQUIRE(a && b && C && ws && pi && u && v, "otvae_sinkhorn_log: NULL argument");
+    OTVAE_REQUIRE(C && ws && pi && u && v, "otvae_sinkhorn_log: NULL argument");
     OTVAE_REQUIRE(nb > 0 && N > 0 && M > 0 && max_iter >= 0, "otvae_sinkhorn_log: bad sizes");
     OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_sinkhorn_log: dtype must be 0 (fp32) or 1 (fp64)");
     OTVAE_REQUIRE(reg > 0.0, "otvae_sinkhorn_log: reg must be positive");
     OTVAE_REQUIRE(pi != C, "otvae_sinkhorn_log: pi must not alias C");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
-        return sinkhorn_impl<float>((const float*)a, (const float*)b, (const float*)C, nb, N, M, reg, max_iter, threshold, ws,
-                                    (float*)pi, (float*)u, (float*)v, iters_done, st);
-    return sinkhorn_impl<double>((const double*)a, (const double*)b, (const double*)C, nb, N, M, reg, max_iter, threshold, ws,
-                                 (double*)pi, (double*)u, (double*)v, iters_done, st);
+        return sinkhorn_impl<float>((const float*)a, (const float*)b, (const float*)C, nb, N, M, reg, max_iter, threshold, nullptr, 0,
+                                    nullptr, ws, (float*)pi, (float*)u, (float*)v, iters_done, st);
+    return sinkhorn_impl<double>((const double*)a, (const double*)b, (const double*)C, nb, N, M, reg, max_iter, threshold, nullptr, 0,
+                                 nullptr, ws, (double*)pi, (double*)u, (double*)v, iters_done, st);
+}
+
+extern "C" int otvae_sinkhorn_log_normalized(int dtype, const void* a, const void* b, const void* C, const void* pmax, int P, int nb,
+                                             int N, int M, double reg, int max_iter, double threshold, void* ws, void* pi, void* u,
+                                             void* v, void* cmax, int32_t* iters_done, void* stream) {
+    OTVAE_REQUIRE(C && pmax && P > 0 && ws && pi && u && v, "otvae_sinkhorn_log_normalized: NULL argument");
+    OTVAE_REQUIRE(nb > 0 && N > 0 && M > 0 && max_iter >= 0, "otvae_sinkhorn_log_normalized: bad sizes");
+    OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_sinkhorn_log_normalized: dtype must be 0 (fp32) or 1 (fp64)");
+    OTVAE_REQUIRE(reg > 0.0, "otvae_sinkhorn_log_normalized: reg must be positive");
+    OTVAE_REQUIRE(pi != C, "otvae_sinkhorn_log_normalized: pi must not alias C");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        return sinkhorn_impl<float>((const float*)a, (const float*)b, (const float*)C, nb, N, M, reg, max_iter, threshold,
+                                    (const float*)pmax, P, (float*)cmax, ws, (float*)pi, (float*)u, (float*)v, iters_done, st);
+    return sinkhorn_impl<double>((const double*)a, (const double*)b, (const double*)C, nb, N, M, reg, max_iter, threshold,
+                                 (const double*)pmax, P, (double*)cmax, ws, (double*)pi, (double*)u, (double*)v, iters_done, st);
 }
 
 // ---- sum_ij C*pi ---------------------------------------------------------------------------------------------
@@ -644,29 +727,36 @@ __global__ __launch_bounds__(256) void ot_cost_partial(const T* __restrict__ Cm,
     __syncthreads();
     if (threadIdx.x == 0) ws[(size_t)blockIdx.y * COST_PARTS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// cost[b * rep + r] = scale * sum of problem b's partials, r < rep (the prior hands the VAE one loss entry per sample)
 template <typename T>
-__global__ void ot_cost_final(const double* __restrict__ ws, int parts, int nb, T* __restrict__ cost) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+__global__ void ot_cost_final(const double* __restrict__ ws, int parts, int nb, T* __restrict__ cost, double scale, int rep_n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nb * rep_n) return;
+    const int b = e / rep_n;
     double s = 0.0;
     for (int p = 0; p < parts; ++p) s += ws[(size_t)b * COST_PARTS + p];
-    cost[b] = (T)s;
+    cost[e] = (T)(scale * s);  // a timed-out solve left NaN in the plan (sk_finish): the cost is NaN
+}
+
+static int ot_cost_launch(int dtype, const void* C, const void* pi, int nb, int N, int M, double* ws, void* cost, double scale,
+                          int rep_n, hipStream_t st) {
+    const size_t total = (size_t)N * M;
+    const int parts = imin(COST_PARTS, cdiv(total, 1024));
+    if (dtype == 0) {
+        ot_cost_partial<float><<<dim3(parts, nb), 256, 0, st>>>((const float*)C, (const float*)pi, total, ws);
+        ot_cost_final<float><<<cdiv(nb * rep_n, 64), 64, 0, st>>>(ws, parts, nb, (float*)cost, scale, rep_n);
+    } else {
+        ot_cost_partial<double><<<dim3(parts, nb), 256, 0, st>>>((const double*)C, (const double*)pi, total, ws);
+        ot_cost_final<double><<<cdiv(nb * rep_n, 64), 64, 0, st>>>(ws, parts, nb, (double*)cost, scale, rep_n);
+    }
+    return OTVAE_OK;
 }
 
 extern "C" int otvae_ot_cost(int dtype, const void* C, const void* pi, int nb, int N, int M, double* ws, void* cost,
                              void* stream) {
     OTVAE_REQUIRE(C && pi && ws && cost && nb > 0 && N > 0 && M > 0, "otvae_ot_cost: bad argument");
     OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_ot_cost: dtype must be 0 or 1");
-    const size_t total = (size_t)N * M;
-    const int parts = imin(COST_PARTS, cdiv(total, 1024));
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0) {
-        ot_cost_partial<float><<<dim3(parts, nb), 256, 0, st>>>((const float*)C, (const float*)pi, total, ws);
-        ot_cost_final<float><<<cdiv(nb, 64), 64, 0, st>>>(ws, parts, nb, (float*)cost);
-    } else {
-        ot_cost_partial<double><<<dim3(parts, nb), 256, 0, st>>>((const double*)C, (const double*)pi, total, ws);
-        ot_cost_final<double><<<cdiv(nb, 64), 64, 0, st>>>(ws, parts, nb, (double*)cost);
-    }
+    ot_cost_launch(dtype, C, pi, nb, N, M, ws, cost, 1.0, 1, (hipStream_t)stream);
     OTVAE_CHECK_LAUNCH("otvae_ot_cost");
     return OTVAE_OK;
 }
@@ -674,8 +764,9 @@ extern "C" int otvae_ot_cost(int dtype, const void* C, const void* pi, int nb, i
 // ---- pairwise squared euclidean cost: |x_i|^2 + |y_j|^2 - 2 x_i.y_j (same expansion as ot/w2_utils.py:121-125) --
 template <typename T>
 __global__ __launch_bounds__(256) void sqdist_kernel(const T* __restrict__ x, const T* __restrict__ y, int N, int M, int D,
-                                                     T* __restrict__ Cm) {
+                                                     T* __restrict__ Cm, T* __restrict__ pmax) {
     __shared__ T xs[16][33], ys[16][33];
+    __shared__ T s_mx[4];
     const int b = blockIdx.z;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
@@ -699,19 +790,158 @@ __global__ __launch_bounds__(256) void sqdist_kernel(const T* __restrict__ x, co
         }
         __syncthreads();
     }
-    if (i < N && j < M) Cm[((size_t)b * N + i) * M + j] = xx + yy - (T)2 * dot;
+    const T val = xx + yy - (T)2 * dot;
+    if (i < N && j < M) Cm[((size_t)b * N + i) * M + j] = val;
+    if (pmax) {  // this tile's maximum (the per-matrix maximum is the maximum of these: sk_init_mat)
+        T mx = wave_max((i < N && j < M) ? val : MathT<T>::ninf());
+        if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const T m01 = s_mx[0] > s_mx[1] ? s_mx[0] : s_mx[1], m23 = s_mx[2] > s_mx[3] ? s_mx[2] : s_mx[3];
+            pmax[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m01 > m23 ? m01 : m23;
+        }
+    }
+}
+
+// fp32 on the matrix cores: a workgroup owns a 64 x 64 tile of C (4 waves, 32 x 32 each = 2 x 2 MFMA 16x16x4 tiles), K = D
+// walked in chunks of 32 staged through LDS with coalesced float4 rows.  A lane reads its A / B operands of four
+// consecutive MFMA steps as ONE ds_read_b128 along k (the k index an MFMA step sees is 4*(lane>>4) + step for A and B
+// alike, so the products pair up correctly whatever the order of k).  The row norms come from the same LDS tiles.
+#define SQ_KC 32
+#define SQ_LD 36  // floats per LDS row: 16-byte aligned rows, 4 banks apart
+__global__ __launch_bounds__(256) void sqdist_mfma_kernel(const float* __restrict__ x, const float* __restrict__ y, int N, int M, int D,
+                                                          float* __restrict__ Cm, float* __restrict__ pmax) {
+    __shared__ __align__(16) float xs[64 * SQ_LD], ys[64 * SQ_LD];
+    __shared__ float nx[64], ny[64], s_mx[4];
+    const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wi = w >> 1, wj = w & 1;
+    const float* xb = x + (size_t)b * N * D;
+    const float* yb = y + (size_t)b * M * D;
+    const bool vec = (D & 3) == 0;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float nrm = 0.f;  // thread t: half (t & 1) of row (t >> 1) of the 128 staged rows (0..63 of x, 64..127 of y)
+    auto load4 = [&](const float* base, int row, int rows, int d) -> float4 {
+        if (row >= rows) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* p = base + (size_t)row * D + d;
+        if (vec && d + 3 < D) return *reinterpret_cast<const float4*>(p);
+        return make_float4(d < D ? p[0] : 0.f, d + 1 < D ? p[1] : 0.f, d + 2 < D ? p[2] : 0.f, d + 3 < D ? p[3] : 0.f);
+    };
+    const int sr = t >> 3, sc = (t & 7) * 4;  // staging: rows sr, sr + 32; 4 floats at column sc
+    float4 px[2], py[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        px[u] = load4(xb, i0 + sr + 32 * u, N, sc);
+        py[u] = load4(yb, j0 + sr + 32 * u, M, sc);
+    }
+    for (int d0 = 0; d0 < D; d0 += SQ_KC) {
+        __syncthreads();  // the previous chunk's readers are done
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<float4*>(&xs[(sr + 32 * u) * SQ_LD + sc]) = px[u];
+            *reinterpret_cast<float4*>(&ys[(sr + 32 * u) * SQ_LD + sc]) = py[u];
+        }
+        __syncthreads();
+        if (d0 + SQ_KC < D) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                px[u] = load4(xb, i0 + sr + 32 * u, N, d0 + SQ_KC + sc);
+                py[u] = load4(yb, j0 + sr + 32 * u, M, d0 + SQ_KC + sc);
+            }
+        }
+        {
+            const int rr = t >> 1;
+            const float* src = (rr < 64 ? xs + rr * SQ_LD : ys + (rr - 64) * SQ_LD) + (t & 1) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 f = *reinterpret_cast<const float4*>(src + 4 * q);
+                nrm += (f.x * f.x + f.y * f.y) + (f.z * f.z + f.w * f.w);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < SQ_KC; kk += 16) {
+            float4 av[2], bv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                av[a] = *reinterpret_cast<const float4*>(&xs[(wi * 32 + a * 16 + (lane & 15)) * SQ_LD + kk + 4 * (lane >> 4)]);
+                bv[a] = *reinterpret_cast<const float4*>(&ys[(wj * 32 + a * 16 + (lane & 15)) * SQ_LD + kk + 4 * (lane >> 4)]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    acc[a][c] = mfma16(av[a].x, bv[c].x, acc[a][c]);
+                    acc[a][c] = mfma16(av[a].y, bv[c].y, acc[a][c]);
+                    acc[a][c] = mfma16(av[a].z, bv[c].z, acc[a][c]);
+                    acc[a][c] = mfma16(av[a].w, bv[c].w, acc[a][c]);
+                }
+        }
+    }
+    nrm += __shfl_xor(nrm, 1, 64);
+    if ((t & 1) == 0) {
+        if ((t >> 1) < 64) nx[t >> 1] = nrm;
+        else ny[(t >> 1) - 64] = nrm;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int li = wi * 32 + a * 16 + (lane >> 4) * 4 + r, lj = wj * 32 + c * 16 + (lane & 15);
+                const float val = nx[li] + ny[lj] - 2.f * acc[a][c][r];
+                if (i0 + li < N && j0 + lj < M) {
+                    Cm[((size_t)b * N + i0 + li) * M + j0 + lj] = val;
+                    mx = val > mx ? val : mx;
+                }
+            }
+    if (pmax) {
+        mx = wave_max(mx);
+        if (lane == 0) s_mx[w] = mx;
+        __syncthreads();
+        if (t == 0) pmax[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+    }
+}
+
+static int sqdist_tile(int dtype) { return dtype == 0 ? 64 : 16; }
+
+extern "C" int otvae_sqdist_max_parts(int dtype, int N, int M) {
+    if (N <= 0 || M <= 0 || dtype < 0 || dtype > 1) return -1;
+    const int t = sqdist_tile(dtype);
+    return cdiv(N, t) * cdiv(M, t);
+}
+
+static int sqdist_launch(int dtype, const void* x, const void* y, int nb, int N, int M, int D, void* C, void* pmax, hipStream_t st) {
+    const int t = sqdist_tile(dtype);
+    dim3 grid(cdiv(M, t), cdiv(N, t), nb);
+    if (dtype == 0)
+        sqdist_mfma_kernel<<<grid, 256, 0, st>>>((const float*)x, (const float*)y, N, M, D, (float*)C, (float*)pmax);
+    else
+        sqdist_kernel<double><<<grid, 256, 0, st>>>((const double*)x, (const double*)y, N, M, D, (double*)C, (double*)pmax);
+    return OTVAE_OK;
 }
 
 extern "C" int otvae_sqdist(int dtype, const void* x, const void* y, int nb, int N, int M, int D, void* C, void* stream) {
     OTVAE_REQUIRE(x && y && C && nb > 0 && N > 0 && M > 0 && D > 0, "otvae_sqdist: bad argument");
     OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_sqdist: dtype must be 0 or 1");
-    dim3 grid(cdiv(M, 16), cdiv(N, 16), nb);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0)
-        sqdist_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)y, N, M, D, (float*)C);
-    else
-        sqdist_kernel<double><<<grid, 256, 0, st>>>((const double*)x, (const double*)y, N, M, D, (double*)C);
+    OTVAE_REQUIRE(dtype == 1 || ((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0), "otvae_sqdist: fp32 inputs must be 16-byte aligned");
+    sqdist_launch(dtype, x, y, nb, N, M, D, C, nullptr, (hipStream_t)stream);
     OTVAE_CHECK_LAUNCH("otvae_sqdist");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_sqdist_max(int dtype, const void* x, const void* y, int nb, int N, int M, int D, void* C, void* pmax,
+                                void* stream) {
+    OTVAE_REQUIRE(x && y && C && pmax && nb > 0 && N > 0 && M > 0 && D > 0, "otvae_sqdist_max: bad argument");
+    OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_sqdist_max: dtype must be 0 or 1");
+    OTVAE_REQUIRE(dtype == 1 || ((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0), "otvae_sqdist_max: fp32 inputs must be 16-byte aligned");
+    sqdist_launch(dtype, x, y, nb, N, M, D, C, pmax, (hipStream_t)stream);
+    OTVAE_CHECK_LAUNCH("otvae_sqdist_max");
     return OTVAE_OK;
 }
 
@@ -721,7 +951,8 @@ extern "C" int otvae_sqdist(int dtype, const void* x, const void* y, int nb, int
 // plan's row sums.  32 x 32 output tiles, the plan and y staged through LDS in 32-wide slices of j, 2 x 2 outputs per lane.
 template <typename T>
 __global__ __launch_bounds__(256) void ot_cost_grad_kernel(const T* __restrict__ z, const T* __restrict__ y, const T* __restrict__ pi,
-                                                           const T* __restrict__ g, int N, int M, int D, T* __restrict__ gz) {
+                                                           const T* __restrict__ g, int ng, T scale, int N, int M, int D,
+                                                           T* __restrict__ gz) {
     __shared__ T ps[32][33], ys[32][33];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
@@ -758,7 +989,9 @@ __global__ __launch_bounds__(256) void ot_cost_grad_kernel(const T* __restrict__
         }
         __syncthreads();
     }
-    const T two_g = (T)2 * g[0];
+    T gs = (T)0;  // the upstream gradient of every replica of the cost, summed in index order by every thread alike
+    for (int q = 0; q < ng; ++q) gs += g[q];
+    const T two_g = (T)2 * scale * gs;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -768,18 +1001,138 @@ __global__ __launch_bounds__(256) void ot_cost_grad_kernel(const T* __restrict__
         }
 }
 
-extern "C" int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int N, int M, int D,
-                                  void* gz, void* stream) {
-    OTVAE_REQUIRE(z && y && pi && g && gz && N > 0 && M > 0 && D > 0, "otvae_ot_cost_grad: bad argument");
+// fp32 on the matrix cores.  A workgroup of 2 waves owns 16 rows of gz and 32 of its columns (a 16 x 16 MFMA tile per
+// wave), K = M walked in chunks of 64: the plan's 16 x 64 slice and y's 64 x 32 slice staged through LDS (coalesced float4
+// rows, next chunk in registers while this one is multiplied).  A-operands of four consecutive MFMA steps are one
+// ds_read_b128 along k (see sqdist_mfma_kernel); the plan's row sums fall out of the same A values.  The sums run in a
+// fixed order: bit-identical from run to run.
+#define CG_KC 64
+#define CG_LDA 68  // floats per LDS row of the plan slice (16-byte aligned, 4 banks apart)
+#define CG_LDB 36  // floats per LDS row of the y slice
+__global__ __launch_bounds__(128) void ot_cost_grad_mfma_kernel(const float* __restrict__ z, const float* __restrict__ y,
+                                                                const float* __restrict__ pi, const float* __restrict__ g, int ng,
+                                                                float scale, int N, int M, int D, float* __restrict__ gz) {
+    __shared__ __align__(16) float as[16 * CG_LDA], bs[CG_KC * CG_LDB];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i0 = blockIdx.y * 16, d0 = blockIdx.x * 32;
+    const bool vecm = (M & 3) == 0, vecd = (D & 3) == 0;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float rs = 0.f;
+    auto load4 = [&](const float* base, int row, int rows, int col, int cols, bool vec) -> float4 {
+        if (row >= rows) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* p = base + (size_t)row * cols + col;
+        if (vec && col + 3 < cols) return *reinterpret_cast<const float4*>(p);
+        return make_float4(col < cols ? p[0] : 0.f, col + 1 < cols ? p[1] : 0.f, col + 2 < cols ? p[2] : 0.f, col + 3 < cols ? p[3] : 0.f);
+    };
+    // staging: plan slice 16 x 64 = 256 float4 (2 per thread), y slice 64 x 32 = 512 float4 (4 per thread)
+    float4 pa[2], pb[4];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = t + 128 * u;
+            pa[u] = load4(pi, i0 + (e >> 4), N, j0 + (e & 15) * 4, M, vecm);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = t + 128 * u;
+            pb[u] = load4(y, j0 + (e >> 3), M, d0 + (e & 7) * 4, D, vecd);
+        }
+    };
+    fetch(0);
+    for (int j0 = 0; j0 < M; j0 += CG_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = t + 128 * u;
+            *reinterpret_cast<float4*>(&as[(e >> 4) * CG_LDA + (e & 15) * 4]) = pa[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = t + 128 * u;
+            *reinterpret_cast<float4*>(&bs[(e >> 3) * CG_LDB + (e & 7) * 4]) = pb[u];
+        }
+        __syncthreads();
+        if (j0 + CG_KC < M) fetch(j0 + CG_KC);
+#pragma unroll
+        for (int kk = 0; kk < CG_KC; kk += 16) {
+            const float4 av = *reinterpret_cast<const float4*>(&as[(lane & 15) * CG_LDA + kk + 4 * (lane >> 4)]);
+            const float* bp = &bs[(kk + 4 * (lane >> 4)) * CG_LDB + w * 16 + (lane & 15)];
+            rs += (av.x + av.y) + (av.z + av.w);
+            acc = mfma16(av.x, bp[0], acc);
+            acc = mfma16(av.y, bp[CG_LDB], acc);
+            acc = mfma16(av.z, bp[2 * CG_LDB], acc);
+            acc = mfma16(av.w, bp[3 * CG_LDB], acc);
+        }
+    }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);  // every lane: the row sum of row (lane & 15)
+    float gs = 0.f;  // sum of the upstream gradients of the cost's replicas: lanes take every 64th, fixed shuffle tree
+    for (int q = lane; q < ng; q += 64) gs += g[q];
+    gs = wave_sum(gs);
+    const float two_g = 2.f * scale * gs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int li = (lane >> 4) * 4 + r;
+        const float rsi = __shfl(rs, li, 64);
+        const int i = i0 + li, d = d0 + w * 16 + (lane & 15);
+        if (i < N && d < D) gz[(size_t)i * D + d] = two_g * (rsi * z[(size_t)i * D + d] - acc[r]);
+    }
+}
+
+extern "C" int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int ng, double scale, int N,
+                                  int M, int D, void* gz, void* stream) {
+    OTVAE_REQUIRE(z && y && pi && g && gz && ng > 0 && N > 0 && M > 0 && D > 0, "otvae_ot_cost_grad: bad argument");
     OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_ot_cost_grad: dtype must be 0 or 1");
     const dim3 grid(cdiv(D, 32), cdiv(N, 32));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0)
-        ot_cost_grad_kernel<float><<<grid, 256, 0, st>>>((const float*)z, (const float*)y, (const float*)pi, (const float*)g, N, M, D,
-                                                         (float*)gz);
+    if (dtype == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)pi % 16 == 0)
+        ot_cost_grad_mfma_kernel<<<dim3(cdiv(D, 32), cdiv(N, 16)), 128, 0, st>>>((const float*)z, (const float*)y, (const float*)pi,
+                                                                                 (const float*)g, ng, (float)scale, N, M, D, (float*)gz);
+    else if (dtype == 0)
+        ot_cost_grad_kernel<float><<<grid, 256, 0, st>>>((const float*)z, (const float*)y, (const float*)pi, (const float*)g, ng,
+                                                         (float)scale, N, M, D, (float*)gz);
     else
-        ot_cost_grad_kernel<double><<<grid, 256, 0, st>>>((const double*)z, (const double*)y, (const double*)pi, (const double*)g, N,
-                                                          M, D, (double*)gz);
+        ot_cost_grad_kernel<double><<<grid, 256, 0, st>>>((const double*)z, (const double*)y, (const double*)pi, (const double*)g, ng,
+                                                          scale, N, M, D, (double*)gz);
     OTVAE_CHECK_LAUNCH("otvae_ot_cost_grad");
+    return OTVAE_OK;
+}
+
+// ---- the minibatch-OT prior's forward in one call: C = |z_i - y_j|^2 (+ tile maxima), Cr = -C / (reg max C), the solve with
+// uniform marginals, cost = sum C * pi.  5 launches (cost tiles, init, solve, finish, read-out x 2), nothing in between.
+extern "C" int64_t otvae_sinkhorn_prior_ws(int dtype, int N, int M) {
+    const int64_t base = otvae_sinkhorn_ws(dtype, 1, N, M);
+    if (base < 0) return -1;
+    const size_t es = dtype ? 8 : 4;
+    return base + (int64_t)align256((size_t)otvae_sqdist_max_parts(dtype, N, M) * es) + (int64_t)align256(COST_PARTS * sizeof(double));
+}
+
+extern "C" int otvae_sinkhorn_prior_fwd(int dtype, const void* z, const void* y, int N, int M, int D, double reg, int max_iter,
+                                        double threshold, double loss_scale, int cost_rep, void* ws, void* C, void* pi, void* u,
+                                        void* v, void* cost, void* cmax, int32_t* iters_done, void* stream) {
+    OTVAE_REQUIRE(z && y && ws && C && pi && u && v && cost, "otvae_sinkhorn_prior_fwd: NULL argument");
+    OTVAE_REQUIRE(N > 0 && M > 0 && D > 0 && max_iter >= 0 && reg > 0.0 && cost_rep > 0, "otvae_sinkhorn_prior_fwd: bad sizes");
+    OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_sinkhorn_prior_fwd: dtype must be 0 (fp32) or 1 (fp64)");
+    OTVAE_REQUIRE(dtype == 1 || ((uintptr_t)z % 16 == 0 && (uintptr_t)y % 16 == 0), "otvae_sinkhorn_prior_fwd: fp32 inputs must be 16-byte aligned");
+    const size_t es = dtype ? 8 : 4;
+    const int P = otvae_sqdist_max_parts(dtype, N, M);
+    char* w = (char*)ws;
+    void* pmax = w;
+    w += align256((size_t)P * es);
+    double* cws = (double*)w;
+    w += align256(COST_PARTS * sizeof(double));
+    hipStream_t st = (hipStream_t)stream;
+    sqdist_launch(dtype, z, y, 1, N, M, D, C, pmax, st);
+    OTVAE_CHECK_LAUNCH("otvae_sinkhorn_prior_fwd(cost matrix)");
+    int rc;
+    if (dtype == 0)
+        rc = sinkhorn_impl<float>(nullptr, nullptr, (const float*)C, 1, N, M, reg, max_iter, threshold, (const float*)pmax, P, (float*)cmax, w,
+                                  (float*)pi, (float*)u, (float*)v, iters_done, st);
+    else
+        rc = sinkhorn_impl<double>(nullptr, nullptr, (const double*)C, 1, N, M, reg, max_iter, threshold, (const double*)pmax, P,
+                                   (double*)cmax, w, (double*)pi, (double*)u, (double*)v, iters_done, st);
+    if (rc) return rc;
+    ot_cost_launch(dtype, C, pi, 1, N, M, cws, cost, loss_scale, cost_rep, st);
+    OTVAE_CHECK_LAUNCH("otvae_sinkhorn_prior_fwd(read-out)");
     return OTVAE_OK;
 }

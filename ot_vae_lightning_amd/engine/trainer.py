@@ -68,7 +68,7 @@ class HipTrainer:
 
     def __init__(self, model, batch_shape, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, use_graph: bool = True, latent_stats=None, dp_overlap: Optional[bool] = None,
-                 batch_kwargs: Optional[Dict[str, Tensor]] = None):
+                 batch_kwargs: Optional[Dict[str, Tensor]] = None, gradient_clip_val: Optional[float] = None):
         self.lib = _lib.load()
         self.model = model
         self.params = list(model.optim_parameters())
@@ -84,6 +84,11 @@ class HipTrainer:
         self.v = torch.zeros_like(self.pflat)
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps], device=dev, dtype=torch.float32)
         self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
+        # global-norm clipping of the (rank-averaged) gradient, the reference's DDP overlay (configs/ddp.yaml:4); the two
+        # floats are {scale Adam applies to the summed gradient, norm of the averaged gradient} of the last step
+        self.gradient_clip_val = None if not gradient_clip_val else float(gradient_clip_val)
+        self.clip_out = torch.zeros(2, device=dev, dtype=torch.float32)
+        self._clip_ws = torch.empty(self.lib.otvae_grad_clip_ws(), device=dev, dtype=torch.float64)
         for p, off in zip(self.params, self.offsets):
             p._otvae_grad_view = (lambda off=off, p=p: _dense_view(self.gflat, off, p.data))
         # dgrad-layout ([T][Cout][Cin]) copies of every conv weight, refreshed by ONE launch at the start of each step
@@ -126,7 +131,16 @@ class HipTrainer:
         # further per-batch keyword tensors of ``model.nelbo`` (e.g. ``labels`` of a conditional model): resident copies of the
         # examples given here, refreshed by ``step(..., name=tensor)``
         self.batch_kwargs = {k: v.to(dev).clone() for k, v in (batch_kwargs or {}).items()}
+        self._rng_key = None
         self.latent_stats = latent_stats  # optional TransportOperator fed with the step's latents (LatentTransport)
+        if latent_stats is not None and self.world > 1 and use_graph:
+            # reduce_on_update=True would all-reduce the batch statistics inside the captured step; the statistics are
+            # additive, so the captured step accumulates rank-locally and ``fit`` reduces once
+            for mod in latent_stats.modules():
+                if getattr(mod, "reduce_on_update", False):
+                    raise ValueError("HipTrainer(latent_stats=...) with more than one rank captures the statistics update into "
+                                     "the step's hipGraph: build the operator's models with reduce_on_update=False (they are "
+                                     "reduced once, in fit())")
         # [1, 0, 0]: the gradient of the loss with respect to the nelbo kernel's output vector (resident: see _backward)
         self._seed = torch.tensor([1.0, 0.0, 0.0], device=self.device, dtype=torch.float32)
         self.out: Optional[Tensor] = None
@@ -156,6 +170,11 @@ class HipTrainer:
             p.grad = None
         loss, logs, art = self.model.nelbo(self._batch(), 0)
         self._backward(loss)
+        # the model's handle on the encoder output would keep this step's autograd graph -- and with it the parameters'
+        # AccumulateGrad nodes, bound to the stream they were created on -- alive into the next step (and from the
+        # warm-up stream into the capture: "AccumulateGrad node's stream does not match ...")
+        if hasattr(self.model, "_last_cut"):
+            self.model._last_cut = None
         from ..functional import _PendingReduce
         _PendingReduce.flush(self.device)  # normally already done by the autograd-engine callback at the end of backward
         self._collect_loose_grads()
@@ -169,12 +188,14 @@ class HipTrainer:
     def _batch(self):
         return {"samples": self.x, "target": self.x, "kwargs": {"eps": self.eps, **self.batch_kwargs}}
 
-    def _collect_loose_grads(self) -> None:
+    def _collect_loose_grads(self, params=None) -> None:
         """Gradients that reached a parameter through plain autograd (p.grad) instead of being written into the flat
         buffer by a kernel (embeddings, learned tokens, LayerNorm weights of the ViT ...): copied into their slot.  The
-        convolution / BatchNorm kernels write their slots directly (then p.grad IS the slot): nothing to do for them."""
+        convolution / BatchNorm kernels write their slots directly (then p.grad IS the slot): nothing to do for them.
+        ``params``: the parameters whose backward has just run (two-phase backward: a slot of the other phase may already
+        be under its all-reduce and must not be written)."""
         loose = self.__dict__.setdefault("_loose_params", set())
-        for p in self.params:
+        for p in (self.params if params is None else params):
             g = p.grad
             if g is None:
                 if id(p) in loose:  # took no part in this step: its slot must not keep the previous step's gradient
@@ -230,7 +251,8 @@ class HipTrainer:
         self._cut = h
         from ..functional import _PendingReduce
         _PendingReduce.flush(self.device)  # the decoder's weight gradients are complete before their all-reduce starts
-        self._collect_loose_grads()
+        # with a cut only the downstream parameters have their gradient now; the encoder's slots are filled by phase 2
+        self._collect_loose_grads(self._post_params if h is not None else None)
         self._logs = {k: v.detach() for k, v in logs.items()}
         self.latents = art["latents"].detach()
         return self._logs
@@ -243,7 +265,9 @@ class HipTrainer:
             h.grad = None
             from ..functional import _PendingReduce
             _PendingReduce.flush(self.device)
-            self._collect_loose_grads()
+            # ONLY the encoder's: the decoder's range is under its all-reduce on the side stream right now, and its
+            # p.grad (still set from phase 1) holds the rank-local value
+            self._collect_loose_grads(self._enc_params)
         self._cut = None
         self.model._last_cut = None
         if self.latent_stats is not None:
@@ -256,6 +280,14 @@ class HipTrainer:
         self.reducer.join()
 
     def _adam(self):
+        if self.gradient_clip_val is not None:
+            lib = self.lib
+            check(lib.otvae_grad_clip_coef(ptr(self.gflat), self.gflat.numel(), self.reducer.grad_scale, self.gradient_clip_val,
+                                           ptr(self._clip_ws), ptr(self.clip_out), stream()), "otvae_grad_clip_coef")
+            check(lib.otvae_adam_step_dev(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
+                                          ptr(self.hyper), ptr(self.step_count), ptr(self.clip_out), stream()),
+                  "otvae_adam_step_dev")
+            return
         check(self.lib.otvae_adam_step(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
                                        ptr(self.hyper), ptr(self.step_count), self.reducer.grad_scale, stream()),
               "otvae_adam_step")
@@ -288,7 +320,15 @@ class HipTrainer:
         if self._captured or not self.use_graph:
             return
         snap = (self.pflat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone())
-        bn_state = {k: v.clone() for k, v in self.model.state_dict().items() if "running_" in k or "num_batches" in k}
+        # everything else a step mutates: every buffer of the model (BatchNorm running statistics, EMA embeddings of a
+        # ConditionalGaussianPrior ...), parameters outside the flat buffer (frozen ones an EMA rewrites), the dropout
+        # key counters, and the running statistics of the latent operator (which may hold earlier eager steps' samples)
+        flat_ids = {id(p) for p in self.params}
+        state = [t for t in self.model.buffers()] + [p.data for p in self.model.parameters() if id(p) not in flat_ids]
+        state += [mod.__dict__["_dropout_key"] for mod in self.model.modules() if isinstance(mod.__dict__.get("_dropout_key"), Tensor)]
+        if self.latent_stats is not None:
+            state += [t for t in self.latent_stats.buffers()] + [p.data for p in self.latent_stats.parameters()]
+        state_snap = [t.clone() for t in state]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -300,7 +340,7 @@ class HipTrainer:
         # "thread_local": only this thread's calls are policed while the stream captures.  Under the default ("global")
         # an event query from another thread -- the RCCL watchdog polling the collectives of earlier steps -- is an
         # illegal call that kills the capture, and the process with it, whenever the poll happens to land inside it
-        mode = dict(capture_error_mode="thread_local")
+        mode = dict(capture_error_mode=os.environ.get("OTVAE_CAPTURE_ERROR_MODE", "thread_local"))
         if self.dp_overlap:
             with torch.cuda.graph(self._graph_fb, **mode):
                 logs = self._phase1()
@@ -326,11 +366,8 @@ class HipTrainer:
         # the warm-up/capture must not count as training: restore parameters, moments, step and BN buffers
         with torch.no_grad():
             self.pflat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self.step_count.copy_(snap[3])
-            sd = self.model.state_dict()
-            for k, v in bn_state.items():
-                sd[k].copy_(v)
-            if self.latent_stats is not None:
-                self.latent_stats.reset()
+            for t, v in zip(state, state_snap):
+                t.copy_(v)
         torch.cuda.synchronize()
         self._captured = True
 
@@ -341,14 +378,21 @@ class HipTrainer:
         if eps is not None:
             self.eps.copy_(eps.reshape(self.eps.shape), non_blocking=True)
         else:
-            self.eps.normal_()
+            self._draw_eps()
+
+    def _draw_eps(self) -> None:
+        """re-parametrisation noise of the next step from the device-side generator (one launch of this library)"""
+        from .. import functional as HF
+        if self._rng_key is None:
+            self._rng_key = HF.new_rng_key(self.device)
+        HF.normal_fill_(self.eps, self._rng_key)
 
     def step(self, x: Optional[Tensor] = None, eps: Optional[Tensor] = None, **batch_kwargs) -> Tensor:
         """One optimisation step.  Returns a device tensor [total, recon, prior] (valid until the next step)."""
         if x is not None:
             self.load_batch(x, eps)
         elif eps is None:
-            self.eps.normal_()
+            self._draw_eps()
         for k, v in batch_kwargs.items():
             if k not in self.batch_kwargs:
                 raise KeyError(f"`{k}` was not declared in HipTrainer(batch_kwargs=...)")
@@ -376,6 +420,30 @@ class HipTrainer:
         except AttributeError:  # Lightning owns global_step
             pass
         return out
+
+    def close(self) -> None:
+        """Releases what the step holds on the device in the order a communicator teardown needs: wait for the
+        reducer's stream and the device, drop the captured graphs (their private pool and the kernels' baked-in
+        addresses), drop the cut tensors.  After ``close()`` the process group may be destroyed; the trainer must not be
+        stepped again.  (the abort seen in round 1 was the RCCL watchdog's event poll landing inside
+        a global-mode stream capture, not the teardown order; this method exists so that callers need not rely on that.)"""
+        if self.reducer.stream is not None:
+            self.reducer.stream.synchronize()
+        torch.cuda.synchronize(self.device)
+        self._graph_fb = self._graph_b2 = self._graph_opt = None
+        self._out_static = None
+        self._cut = None
+        self._logs = None
+        self.latents = None
+        if hasattr(self.model, "_last_cut"):
+            self.model._last_cut = None
+            self.model._last_nelbo = None
+        self._captured = False
+        self.use_graph = False
+        torch.cuda.synchronize(self.device)
+        check_solver = getattr(getattr(self.model, "prior", None), "raise_if_starved", None)
+        if check_solver is not None:
+            check_solver()
 
     def set_lr(self, lr: float):
         self.hyper[0] = lr

@@ -682,6 +682,30 @@ def mha_attention_tokens(qkv: Tensor, n_heads: int, dropout_p: float = 0.0, drop
     return nhwc_as_tokens(out)
 
 
+def new_rng_key(device, seed: Optional[int] = None) -> Tensor:
+    """device int64[3] {seed, call counter, block ticket} for ``normal_like``; the seed comes from torch's default generator
+    unless given, so ``torch.manual_seed`` governs the draws"""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)
+
+
+@torch.no_grad()
+def normal_fill_(out: Tensor, key: Tensor, stream_id: int = 0, advance: bool = True) -> Tensor:
+    """out ~ N(0, 1) in place from the device-side counter-based generator (``otvae_normal_fill``): capturable, and every
+    replay of a captured call draws fresh values (the counter advances on the device)."""
+    _lib.require_cuda(out, "out")
+    if out.dtype != torch.float32 or not out.is_contiguous():
+        raise TypeError("normal_fill_ fills contiguous float32 tensors")
+    check(_lib.load().otvae_normal_fill(ptr(out), out.numel(), ptr(key), int(stream_id), int(advance), stream()),
+          "otvae_normal_fill")
+    return out
+
+
+def normal_like(like: Tensor, key: Tensor, stream_id: int = 0) -> Tensor:
+    return normal_fill_(torch.empty(like.shape, device=like.device, dtype=torch.float32), key, stream_id)
+
+
 class _GaussianPriorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, eps, coeff):

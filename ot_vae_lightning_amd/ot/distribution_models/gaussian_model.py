@@ -96,20 +96,32 @@ class GaussianModel(DistributionModel, W2Mixin):
         self._validate_samples(samples)
         if self.reduce_on_update and self._will_reduce():
             n, sx, sxx = self._batch_stats(samples, accumulate=False)
-            n, sx, sxx = self.reduce(n), self.reduce(sx), self.reduce(sxx)
-            self._n_obs = self.ema_update(self._n_obs, n)
-            self._running_sum = self.ema_update(self._running_sum, sx)
-            self._running_sum_cov = self.ema_update(self._running_sum_cov, sxx)
+            self._accumulate(self.reduce(n), self.reduce(sx), self.reduce(sxx))
         else:
             self._batch_stats(samples, accumulate=True)
+
+    @torch.no_grad()
+    def _accumulate(self, n: Tensor, sx: Tensor, sxx: Tensor) -> None:
+        """running <- ema(running, batch) IN PLACE (reference gaussian_model.py:106-108 rebinds the attributes; here the
+        buffers keep their addresses: a captured training step has them baked into its kernel arguments)."""
+        self._n_obs.copy_(self.ema_update(self._n_obs, n.reshape(self._n_obs.shape)))
+        self._running_sum.copy_(self.ema_update(self._running_sum, sx))
+        self._running_sum_cov.copy_(self.ema_update(self._running_sum_cov, sxx))
+
+    @torch.no_grad()
+    def _reduce_running(self) -> None:
+        """all-reduce(SUM) of the running statistics over the ranks, written back IN PLACE (reference
+        gaussian_model.py:123 with ``_stats(None, reduce=True)``): same values, stable addresses."""
+        for buf in (self._n_obs, self._running_sum, self._running_sum_cov):
+            red = self.reduce(buf)
+            if red is not buf:
+                buf.copy_(red)
 
     @torch.no_grad()
     def fit(self, samples: Optional[Tensor] = None) -> None:
         if samples is not None:
             self.update(samples)
-        self._n_obs = self.reduce(self._n_obs)
-        self._running_sum = self.reduce(self._running_sum)
-        self._running_sum_cov = self.reduce(self._running_sum_cov)
+        self._reduce_running()
         n = self._n_obs
         if bool((n == 0).all()):
             return

@@ -30,8 +30,24 @@ def _dt(t: Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ Sinkhorn
+class SinkhornSolverStarved(RuntimeError):
+    """the single-launch Sinkhorn solver gave up waiting for its other workgroups; its outputs are NaN"""
+
+
+def raise_if_solver_starved(iters: Tensor) -> None:
+    """``iters`` is the device int32 a solve left (-1: a bounded wait of the persistent kernel ran out and the outputs were
+    poisoned with NaN).  Looked at only when that costs no capture: while a stream is capturing the host cannot read device
+    memory, and the NaN loss is then the signal."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    if int(iters.item()) < 0:
+        raise SinkhornSolverStarved(
+            "sinkhorn_log: the persistent solver's workgroups were not co-resident within its wait budget "
+            "(OTVAE_SK_SPIN_LIMIT); outputs are NaN.  OTVAE_SK_MULTILAUNCH=1 selects the one-launch-per-half-iteration path.")
+
+
 def sinkhorn_log_potentials(a: Tensor, b: Tensor, C: Tensor, reg: float = 1e-5, max_iter: int = 1000,
-                            threshold: float = STABILITY_CONST):
+                            threshold: float = STABILITY_CONST, check_starved: bool = True):
     """Returns (pi, u, v, iters_done[device int32]).  See ``sinkhorn_log``."""
     lib = _lib.load()
     _lib.require_cuda(C, "C")
@@ -51,6 +67,8 @@ def sinkhorn_log_potentials(a: Tensor, b: Tensor, C: Tensor, reg: float = 1e-5, 
     iters = torch.zeros(1, device=C.device, dtype=torch.int32)
     check(lib.otvae_sinkhorn_log(dt, ptr(a2), ptr(b2), ptr(c3), nb, n, m, float(reg), int(max_iter), float(threshold),
                                  ptr(ws), ptr(pi), ptr(u), ptr(v), ptr(iters), stream()), "otvae_sinkhorn_log")
+    if check_starved:
+        raise_if_solver_starved(iters)
     return pi.reshape(*lead, n, m), u.reshape(*lead, n), v.reshape(*lead, m), iters
 
 

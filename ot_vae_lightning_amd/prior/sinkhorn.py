@@ -17,33 +17,43 @@ __all__ = ["SinkhornPrior"]
 
 class _SinkhornLossFn(torch.autograd.Function):
     """loss = sum_ij C_ij pi_ij with C_ij = |z_i - y_j|^2 and pi the (detached) entropic plan: by the envelope
-    argument the plan is treated as a constant, so d loss / d z_i = 2 sum_j pi_ij (z_i - y_j)."""
+    argument the plan is treated as a constant, so d loss / d z_i = 2 sum_j pi_ij (z_i - y_j).
+    Forward = ``otvae_sinkhorn_prior_fwd`` (cost tiles + tile maxima on the matrix cores, the solve on C / max C with uniform
+    marginals, the read-out), backward = ``otvae_ot_cost_grad`` (plan x samples on the matrix cores): no library GEMM and no
+    ATen kernel on either side."""
 
     @staticmethod
-    def forward(ctx, z, y, reg, max_iter, threshold):
-        C = W.sq_euclidean_cost(z, y)
-        n, m = C.shape
-        a = torch.full((n,), 1.0 / n, device=z.device, dtype=z.dtype)
-        b = torch.full((m,), 1.0 / m, device=z.device, dtype=z.dtype)
-        cmax = C.max()
-        pi = W.sinkhorn_log(a, b, C / cmax, reg=reg, max_iter=max_iter, threshold=threshold)
+    def forward(ctx, z, y, reg, max_iter, threshold, scale):
+        lib = _lib.load()
+        _lib.require_cuda(z, "latents")
+        if z.dtype not in (torch.float32, torch.float64):
+            raise TypeError("SinkhornPrior computes in float32 or float64")
+        z, y = z.contiguous(), y.to(z.dtype).contiguous()
+        (n, d), m = z.shape, y.shape[0]
+        if y.shape[1] != d:
+            raise ValueError(f"prior samples have {y.shape[1]} dimensions, latents {d}")
+        dt = 0 if z.dtype == torch.float32 else 1
+        new = lambda *shape: torch.empty(shape, device=z.device, dtype=z.dtype)  # noqa: E731
+        C, pi, u, v, cost, cmax = new(n, m), new(n, m), new(n), new(m), new(n), new(1)   # cost: one entry per sample
+        ws = torch.empty(lib.otvae_sinkhorn_prior_ws(dt, n, m), device=z.device, dtype=torch.uint8)
+        iters = torch.empty(1, device=z.device, dtype=torch.int32)
+        check(lib.otvae_sinkhorn_prior_fwd(dt, ptr(z), ptr(y), n, m, d, float(reg), int(max_iter), float(threshold), float(scale), n, ptr(ws), ptr(C),
+                                           ptr(pi), ptr(u), ptr(v), ptr(cost), ptr(cmax), ptr(iters), stream()),
+              "otvae_sinkhorn_prior_fwd")
         ctx.save_for_backward(z, y, pi)
-        return W.ot_cost(C, pi)
+        ctx.scale = float(scale)
+        ctx.mark_non_differentiable(iters)
+        ctx.set_materialize_grads(False)  # no zeros tensor for the iteration count's "gradient"
+        return cost, iters
 
     @staticmethod
-    def backward(ctx, g):
-        z, y, pi = (t.contiguous() for t in ctx.saved_tensors)
+    def backward(ctx, g, _giters):
+        z, y, pi = ctx.saved_tensors
         n, d = z.shape
-        if n * y.shape[0] * d >= (1 << 26):
-            # a real GEMM ([1024 x 1024] x [1024 x 128] at the bench size): the library's tiles beat the small fused kernel
-            gz = 2.0 * (pi.sum(1, keepdim=True) * z - pi @ y) * g
-        else:
-            # per-GPU batches of a few hundred: one fused launch instead of six (the library picks a 256 x 256 macro-tile
-            # for the 256 x 256 x 256 product: 67 us)
-            gz = torch.empty_like(z)
-            check(_lib.load().otvae_ot_cost_grad(0 if z.dtype == torch.float32 else 1, ptr(z), ptr(y), ptr(pi), ptr(g.contiguous()),
-                                                 n, y.shape[0], d, ptr(gz), stream()), "otvae_ot_cost_grad")
-        return gz, None, None, None, None
+        gz = torch.empty_like(z)
+        check(_lib.load().otvae_ot_cost_grad(0 if z.dtype == torch.float32 else 1, ptr(z), ptr(y), ptr(pi), ptr(g.contiguous()),
+                                             g.numel(), ctx.scale, n, y.shape[0], d, ptr(gz), stream()), "otvae_ot_cost_grad")
+        return gz, None, None, None, None, None
 
 
 class SinkhornPrior(Prior):
@@ -52,9 +62,11 @@ class SinkhornPrior(Prior):
     ``prior_loss.mean()`` equals it)."""
 
     def __init__(self, reg: float = 0.05, max_iter: int = 50, threshold: float = 0., loss_coeff: float = 1.,
-                 annealing_steps: int = 0):
+                 annealing_steps: int = 0, seed: int = None):
         super().__init__(loss_coeff, annealing_steps)
         self.reg, self.max_iter, self.threshold = reg, max_iter, threshold
+        self.seed = seed
+        self.last_iters = None  # device int32: iterations of the last solve (-1: the solver was starved, loss is NaN)
 
     def out_size(self, size):
         return size
@@ -62,13 +74,31 @@ class SinkhornPrior(Prior):
     def sample(self, shape, device) -> Tensor:
         return torch.randn(*shape, device=device)
 
-    def forward(self, x: Tensor, step: int, prior_samples: Optional[Tensor] = None) -> Prior.EncodingResults:
-        return super().forward(x, step, prior_samples=prior_samples)
+    def raise_if_starved(self) -> None:
+        """Host check of the last solve (one device read): raises ``SinkhornSolverStarved`` if the single-launch solver gave up
+        waiting for its other workgroups.  The training step itself never synchronises for this: a starved solve makes the
+        loss NaN (every entry of the plan is), which is what a captured step can show; ``HipTrainer.close`` and callers that
+        log losses call this."""
+        if self.last_iters is not None:
+            W.raise_if_solver_starved(self.last_iters)
 
-    def encode(self, x: Tensor, prior_samples: Optional[Tensor] = None) -> Prior.EncodingResults:
+    def _draw(self, like: Tensor) -> Tensor:
+        """prior samples N(0, I) from the device-side counter-based generator: inside a captured step every replay draws
+        fresh samples (the call counter lives in device memory and advances in the kernel)"""
+        from .. import functional as HF
+        key = self.__dict__.get("_rng_key")
+        if key is None or key.device != like.device:
+            key = self.__dict__["_rng_key"] = HF.new_rng_key(like.device, self.seed)
+        return HF.normal_like(like, key, stream_id=1)
+
+    def forward(self, x: Tensor, step: int, prior_samples: Optional[Tensor] = None) -> Prior.EncodingResults:
+        # loss_coeff x annealing is folded into the read-out kernel (and the backward's scale): no separate multiply
+        return self.encode(x, prior_samples=prior_samples, _scale=float(self.loss_coeff * self.annealing(step)))
+
+    def encode(self, x: Tensor, prior_samples: Optional[Tensor] = None, _scale: float = 1.0) -> Prior.EncodingResults:
         z = x
         zf = z.flatten(1)
         if prior_samples is None:
-            prior_samples = torch.randn_like(zf)
-        cost = _SinkhornLossFn.apply(zf, prior_samples.flatten(1), self.reg, self.max_iter, self.threshold)
-        return z, cost.expand(z.shape[0]), {"prior_samples": prior_samples}
+            prior_samples = self._draw(zf) if zf.dtype == torch.float32 else torch.randn_like(zf)
+        loss, self.last_iters = _SinkhornLossFn.apply(zf, prior_samples.flatten(1), self.reg, self.max_iter, self.threshold, _scale)
+        return z, loss, {"prior_samples": prior_samples}

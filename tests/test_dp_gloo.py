@@ -96,6 +96,36 @@ def _worker(rank, world, port, q):
         assert torch.allclose(n, n_all) and torch.allclose(sx, sx_all) and torch.allclose(sxx, sxx_all)
         parts = utils.ddp_gather_all(z[rank * 32:(rank + 1) * 32])
         assert torch.equal(torch.cat(parts), z)
+
+        # -- GaussianModel's running statistics keep their ADDRESSES through update (reduce_on_update branch), fit's
+        # reduction and reset: a captured training step has them baked into its kernel arguments (step, fit, reset, step)
+        gm = A.GaussianModel(6, dtype=torch.double, reduce_on_update=True)
+        bufs = (gm._n_obs, gm._running_sum, gm._running_sum_cov)
+        addr = [b.data_ptr() for b in bufs]
+        mine_z = z[rank * 32:(rank + 1) * 32]
+        st = O.gaussian_stats(mine_z)
+        gm._accumulate(gm.reduce(st[0]), gm.reduce(st[1]), gm.reduce(st[2]))        # what update() does after the kernel
+        assert [b.data_ptr() for b in bufs] == addr and (gm._n_obs, gm._running_sum, gm._running_sum_cov)[0] is bufs[0]
+        assert float(gm._n_obs) == 64 and torch.allclose(gm._running_sum, sx_all) and torch.allclose(gm._running_sum_cov, sxx_all)
+        gm.reset()
+        assert [b.data_ptr() for b in (gm._n_obs, gm._running_sum, gm._running_sum_cov)] == addr and float(gm._n_obs) == 0
+        gm._n_obs.fill_(32.0); gm._running_sum.copy_(st[1]); gm._running_sum_cov.copy_(st[2])   # rank-local (reduce_on_update=False)
+        gm._reduce_running()                                                                       # fit()'s first statement
+        assert [b.data_ptr() for b in (gm._n_obs, gm._running_sum, gm._running_sum_cov)] == addr
+        assert float(gm._n_obs) == 64 and torch.allclose(gm._running_sum, sx_all) and torch.allclose(gm._running_sum_cov, sxx_all)
+
+        # -- global-norm clipping of the DP step (configs/ddp.yaml:4): DDP clips the rank-AVERAGED gradient; the engine
+        # holds the SUM in the flat buffer and hands Adam grad_scale * min(1, c / (|sum| * grad_scale + 1e-6))
+        # (otvae_grad_clip_coef); both must give the same clipped gradient
+        max_norm = 0.5 * float(torch.sqrt(sum((wg.double() ** 2).sum() for wg in want)))
+        ref_params = [wg.clone().requires_grad_(True) for wg in want]
+        for rp, wg in zip(ref_params, want):
+            rp.grad = wg.clone()
+        torch.nn.utils.clip_grad_norm_(ref_params, max_norm)
+        total = float(gflat.double().norm()) * red.grad_scale
+        coef = red.grad_scale * min(1.0, max_norm / (total + 1e-6))
+        for p, off, rp in zip(params, offs, ref_params):
+            assert torch.allclose(_dense_view(gflat, off, p.data) * coef, rp.grad, rtol=1e-5, atol=1e-9)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
