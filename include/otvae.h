@@ -292,7 +292,7 @@ int64_t otvae_sinkhorn_prior_ws(int dtype, int N, int M);
 int otvae_sinkhorn_prior_fwd(int dtype, const void* z, const void* y, int N, int M, int D, double reg, int max_iter,
                              double threshold, double loss_scale, int cost_rep, void* ws, void* C, void* pi, void* u, void* v,
                              void* cost, void* cmax, int32_t* iters_done, void* stream);
-/* cost[nb] = sum_ij C*pi (fp64 accumulate, fixed order), out dtype = dtype; ws: double[nb*64] */
+/* cost[nb] = sum_ij C*pi (fp64 accumulate, fixed order), out dtype = dtype; ws: double[nb*256] */
 int otvae_ot_cost(int dtype, const void* C, const void* pi, int nb, int N, int M, double* ws, void* cost, void* stream);
 /* pairwise squared euclidean cost C[nb][N][M] = |x_i - y_j|^2, x[nb][N][D], y[nb][M][D] */
 int otvae_sqdist(int dtype, const void* x, const void* y, int nb, int N, int M, int D, void* C, void* stream);
@@ -301,10 +301,11 @@ int otvae_sqdist_max_parts(int dtype, int N, int M);
 int otvae_sqdist_max(int dtype, const void* x, const void* y, int nb, int N, int M, int D, void* C, void* pmax, void* stream);
 /* Gradient of scale * sum_ij C_ij pi_ij with respect to z for C_ij = |z_i - y_j|^2 and a fixed plan (the minibatch OT prior's
  * backward, SinkhornPrior): gz[i][d] = 2 scale (sum_q g[q]) sum_j pi_ij (z_id - y_jd); z [N][D], y [M][D], pi [N][M]; g[ng] =
- * the upstream gradients of the ng replicas of the cost that the forward handed out (device memory).  fp32 runs on the
+ * the upstream gradients of the ng replicas of the cost that the forward handed out (device memory); gadd[N][D] (may be
+ * NULL) is added to the result (the gradient reaching z through its other consumer, the decoder).  fp32 runs on the
  * matrix cores (16 x 16 x 4 MFMA tiles, fixed summation order). */
-int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int ng, double scale, int N,
-                       int M, int D, void* gz, void* stream);
+int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int ng, double scale,
+                       const void* gadd, int N, int M, int D, void* gz, void* stream);
 
 /* ---- GaussianModel statistics (ot/distribution_models/gaussian_model.py:99-108,144-157) ------------------- */
 /* samples [nb][B][D] (in_dtype 0=fp32,1=fp64) -> fp64 sum_x[nb][D], sum_xx[nb][D][D] (diag: [nb][D]),

@@ -98,7 +98,7 @@ SIGNATURES = {
     "otvae_normal_fill": (i32, [vp, i64, vp, i32, i32, vp]),
     "otvae_ot_cost": (i32, [i32, vp, vp, i32, i32, i32, vp, vp, vp]),
     "otvae_sqdist": (i32, [i32, vp, vp, i32, i32, i32, i32, vp, vp]),
-    "otvae_ot_cost_grad": (i32, [i32, vp, vp, vp, vp, i32, f64, i32, i32, i32, vp, vp]),
+    "otvae_ot_cost_grad": (i32, [i32, vp, vp, vp, vp, i32, f64, vp, i32, i32, i32, vp, vp]),
     "otvae_gauss_stats_ws": (i64, [i32, i32, i32, i32]),
     "otvae_gauss_stats": (i32, [i32, vp, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp]),
     "otvae_mean_cov": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),

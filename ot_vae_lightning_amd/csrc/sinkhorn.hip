@@ -531,8 +531,10 @@ __global__ void sk_copy_iters(const SkCtl* ctl, int32_t* out) {
 // become NaN (so does every loss computed from them) and iters reports -1; the host wrapper raises when it can look.
 template <typename T>
 __global__ __launch_bounds__(256) void sk_finish(SkCtl* ctl, T* __restrict__ pi, size_t total, T* __restrict__ u, size_t nu,
-                                                 T* __restrict__ v, size_t nv) {
-    if (!__hip_atomic_load(&ctl->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+                                                 T* __restrict__ v, size_t nv, int32_t* __restrict__ iters_out) {
+    const bool starved = __hip_atomic_load(&ctl->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (iters_out && blockIdx.x == 0 && threadIdx.x == 0) *iters_out = starved ? -1 : ctl->iters;
+    if (!starved) return;
     const T nan = (T)NAN;
     for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) pi[e] = nan;
     for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < nu; e += (size_t)gridDim.x * 256) u[e] = nan;
@@ -659,8 +661,9 @@ static int sinkhorn_impl(const T* a, const T* b, const T* Cm, int nb, int N, int
             sk_persistent<T, true, RPWMAX, 512, true><<<G, 512, pot_bytes, st>>>(pi, crt, loga, logb, u, v, adu, adv, nb, N, M, max_iter, threshold, ctl);
         }
         OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(persistent)");
-        sk_finish<T><<<64, 256, 0, st>>>(ctl, pi, (size_t)nb * N * M, u, (size_t)nb * N, v, (size_t)nb * M);
+        sk_finish<T><<<64, 256, 0, st>>>(ctl, pi, (size_t)nb * N * M, u, (size_t)nb * N, v, (size_t)nb * M, iters_done);
         OTVAE_CHECK_LAUNCH("otvae_sinkhorn_log(finish)");
+        iters_done = nullptr;  // written by sk_finish
     } else {
         for (int it = 0; it < max_iter; ++it) {
             // v_j = log b_j - LSE_i(Cr_ij + u_i): rows of CrT
@@ -713,7 +716,7 @@ extern "C" int otvae_sinkhorn_log_normalized(int dtype, const void* a, const voi
 }
 
 // ---- sum_ij C*pi ---------------------------------------------------------------------------------------------
-#define COST_PARTS 64
+#define COST_PARTS 256
 template <typename T>
 __global__ __launch_bounds__(256) void ot_cost_partial(const T* __restrict__ Cm, const T* __restrict__ pi, size_t total,
                                                        double* __restrict__ ws) {
@@ -951,8 +954,8 @@ extern "C" int otvae_sqdist_max(int dtype, const void* x, const void* y, int nb,
 // plan's row sums.  32 x 32 output tiles, the plan and y staged through LDS in 32-wide slices of j, 2 x 2 outputs per lane.
 template <typename T>
 __global__ __launch_bounds__(256) void ot_cost_grad_kernel(const T* __restrict__ z, const T* __restrict__ y, const T* __restrict__ pi,
-                                                           const T* __restrict__ g, int ng, T scale, int N, int M, int D,
-                                                           T* __restrict__ gz) {
+                                                           const T* __restrict__ g, int ng, T scale, const T* __restrict__ gadd,
+                                                           int N, int M, int D, T* __restrict__ gz) {
     __shared__ T ps[32][33], ys[32][33];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
@@ -997,75 +1000,78 @@ __global__ __launch_bounds__(256) void ot_cost_grad_kernel(const T* __restrict__
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int i = i0 + ty + 16 * a, d = d0 + tx + 16 * c;
-            if (i < N && d < D) gz[(size_t)i * D + d] = two_g * (rs[a] * z[(size_t)i * D + d] - acc[a][c]);
+            if (i < N && d < D) {
+                const T val = two_g * (rs[a] * z[(size_t)i * D + d] - acc[a][c]);
+                gz[(size_t)i * D + d] = gadd ? gadd[(size_t)i * D + d] + val : val;
+            }
         }
 }
 
-// fp32 on the matrix cores.  A workgroup of 2 waves owns 16 rows of gz and 32 of its columns (a 16 x 16 MFMA tile per
-// wave), K = M walked in chunks of 64: the plan's 16 x 64 slice and y's 64 x 32 slice staged through LDS (coalesced float4
-// rows, next chunk in registers while this one is multiplied).  A-operands of four consecutive MFMA steps are one
-// ds_read_b128 along k (see sqdist_mfma_kernel); the plan's row sums fall out of the same A values.  The sums run in a
-// fixed order: bit-identical from run to run.
-#define CG_KC 64
-#define CG_LDA 68  // floats per LDS row of the plan slice (16-byte aligned, 4 banks apart)
-#define CG_LDB 36  // floats per LDS row of the y slice
-__global__ __launch_bounds__(128) void ot_cost_grad_mfma_kernel(const float* __restrict__ z, const float* __restrict__ y,
+// fp32 on the matrix cores.  A workgroup owns one 16 x 16 tile of gz; its 4 waves split K = M into 4 contiguous ranges and
+// each accumulates its own MFMA 16x16x4 tile straight from global memory (the plan and y are L2 resident: 4 MiB + 0.5 MiB):
+// per 16 k one 16-byte load of the plan (4 consecutive k of a row: the A operands of four MFMA steps) and four dword loads
+// of y, four such groups in flight per wave, no barrier inside the loop.  The plan's row sums fall out of the same A
+// values.  The 4 partial tiles are combined through LDS in wave order: a fixed summation order, bit-identical from run to run.
+__global__ __launch_bounds__(256) void ot_cost_grad_mfma_kernel(const float* __restrict__ z, const float* __restrict__ y,
                                                                 const float* __restrict__ pi, const float* __restrict__ g, int ng,
-                                                                float scale, int N, int M, int D, float* __restrict__ gz) {
-    __shared__ __align__(16) float as[16 * CG_LDA], bs[CG_KC * CG_LDB];
+                                                                float scale, const float* __restrict__ gadd, int N, int M, int D,
+                                                                float* __restrict__ gz) {
+    __shared__ float part[3][5][64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int i0 = blockIdx.y * 16, d0 = blockIdx.x * 32;
-    const bool vecm = (M & 3) == 0, vecd = (D & 3) == 0;
+    const int i0 = blockIdx.y * 16, d0 = blockIdx.x * 16;
+    const int row = i0 + (lane & 15), col = d0 + (lane & 15), kq = 4 * (lane >> 4);
+    const bool vecm = (M & 3) == 0;
+    const int span = ((M + 63) / 64) * 16;  // k per wave, a multiple of 16
+    const int k_lo = w * span, k_hi = min(M, k_lo + span);
+    const float* prow = pi + (size_t)min(row, N - 1) * M;
+    const bool row_ok = row < N, col_ok = col < D;
+    const float* ycol = y + min(col, D - 1);
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     float rs = 0.f;
-    auto load4 = [&](const float* base, int row, int rows, int col, int cols, bool vec) -> float4 {
-        if (row >= rows) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* p = base + (size_t)row * cols + col;
-        if (vec && col + 3 < cols) return *reinterpret_cast<const float4*>(p);
-        return make_float4(col < cols ? p[0] : 0.f, col + 1 < cols ? p[1] : 0.f, col + 2 < cols ? p[2] : 0.f, col + 3 < cols ? p[3] : 0.f);
+    auto loadA = [&](int k) -> float4 {
+        const int kk = k + kq;
+        if (!row_ok || kk >= k_hi) return make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vecm && kk + 3 < k_hi) return *reinterpret_cast<const float4*>(prow + kk);
+        return make_float4(prow[kk], kk + 1 < k_hi ? prow[kk + 1] : 0.f, kk + 2 < k_hi ? prow[kk + 2] : 0.f,
+                           kk + 3 < k_hi ? prow[kk + 3] : 0.f);
     };
-    // staging: plan slice 16 x 64 = 256 float4 (2 per thread), y slice 64 x 32 = 512 float4 (4 per thread)
-    float4 pa[2], pb[4];
-    auto fetch = [&](int j0) {
+    auto loadB = [&](int k, int s_) -> float {
+        const int kk = k + kq + s_;
+        return (col_ok && kk < k_hi) ? ycol[(size_t)kk * D] : 0.f;
+    };
+    for (int k = k_lo; k < k_hi; k += 64) {
+        float4 av[4];
+        float bv[4][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = t + 128 * u;
-            pa[u] = load4(pi, i0 + (e >> 4), N, j0 + (e & 15) * 4, M, vecm);
+        for (int u = 0; u < 4; ++u) {
+            av[u] = loadA(k + 16 * u);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) bv[u][s_] = loadB(k + 16 * u, s_);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = t + 128 * u;
-            pb[u] = load4(y, j0 + (e >> 3), M, d0 + (e & 7) * 4, D, vecd);
-        }
-    };
-    fetch(0);
-    for (int j0 = 0; j0 < M; j0 += CG_KC) {
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = t + 128 * u;
-            *reinterpret_cast<float4*>(&as[(e >> 4) * CG_LDA + (e & 15) * 4]) = pa[u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = t + 128 * u;
-            *reinterpret_cast<float4*>(&bs[(e >> 3) * CG_LDB + (e & 7) * 4]) = pb[u];
-        }
-        __syncthreads();
-        if (j0 + CG_KC < M) fetch(j0 + CG_KC);
-#pragma unroll
-        for (int kk = 0; kk < CG_KC; kk += 16) {
-            const float4 av = *reinterpret_cast<const float4*>(&as[(lane & 15) * CG_LDA + kk + 4 * (lane >> 4)]);
-            const float* bp = &bs[(kk + 4 * (lane >> 4)) * CG_LDB + w * 16 + (lane & 15)];
-            rs += (av.x + av.y) + (av.z + av.w);
-            acc = mfma16(av.x, bp[0], acc);
-            acc = mfma16(av.y, bp[CG_LDB], acc);
-            acc = mfma16(av.z, bp[2 * CG_LDB], acc);
-            acc = mfma16(av.w, bp[3 * CG_LDB], acc);
+            rs += (av[u].x + av[u].y) + (av[u].z + av[u].w);
+            acc = mfma16(av[u].x, bv[u][0], acc);
+            acc = mfma16(av[u].y, bv[u][1], acc);
+            acc = mfma16(av[u].z, bv[u][2], acc);
+            acc = mfma16(av[u].w, bv[u][3], acc);
         }
     }
     rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);  // every lane: the row sum of row (lane & 15)
+    rs += __shfl_xor(rs, 32, 64);  // every lane: this wave's share of the row sum of row (lane & 15)
+    if (w > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[w - 1][r][lane] = acc[r];
+        part[w - 1][4][lane] = rs;
+    }
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += part[q][r][lane];
+        rs += part[q][4][lane];
+    }
     float gs = 0.f;  // sum of the upstream gradients of the cost's replicas: lanes take every 64th, fixed shuffle tree
     for (int q = lane; q < ng; q += 64) gs += g[q];
     gs = wave_sum(gs);
@@ -1074,26 +1080,31 @@ __global__ __launch_bounds__(128) void ot_cost_grad_mfma_kernel(const float* __r
     for (int r = 0; r < 4; ++r) {
         const int li = (lane >> 4) * 4 + r;
         const float rsi = __shfl(rs, li, 64);
-        const int i = i0 + li, d = d0 + w * 16 + (lane & 15);
-        if (i < N && d < D) gz[(size_t)i * D + d] = two_g * (rsi * z[(size_t)i * D + d] - acc[r]);
+        const int i = i0 + li;
+        if (i < N && col_ok) {
+            const size_t e = (size_t)i * D + col;
+            const float v = two_g * (rsi * z[e] - acc[r]);
+            gz[e] = gadd ? gadd[e] + v : v;
+        }
     }
 }
 
-extern "C" int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int ng, double scale, int N,
-                                  int M, int D, void* gz, void* stream) {
+extern "C" int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int ng, double scale,
+                                  const void* gadd, int N, int M, int D, void* gz, void* stream) {
     OTVAE_REQUIRE(z && y && pi && g && gz && ng > 0 && N > 0 && M > 0 && D > 0, "otvae_ot_cost_grad: bad argument");
     OTVAE_REQUIRE(dtype == 0 || dtype == 1, "otvae_ot_cost_grad: dtype must be 0 or 1");
     const dim3 grid(cdiv(D, 32), cdiv(N, 32));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)pi % 16 == 0)
-        ot_cost_grad_mfma_kernel<<<dim3(cdiv(D, 32), cdiv(N, 16)), 128, 0, st>>>((const float*)z, (const float*)y, (const float*)pi,
-                                                                                 (const float*)g, ng, (float)scale, N, M, D, (float*)gz);
+    if (dtype == 0 && (uintptr_t)pi % 16 == 0 && !getenv("OTVAE_OT_GRAD_VALU"))
+        ot_cost_grad_mfma_kernel<<<dim3(cdiv(D, 16), cdiv(N, 16)), 256, 0, st>>>((const float*)z, (const float*)y, (const float*)pi,
+                                                                                 (const float*)g, ng, (float)scale, (const float*)gadd, N,
+                                                                                 M, D, (float*)gz);
     else if (dtype == 0)
         ot_cost_grad_kernel<float><<<grid, 256, 0, st>>>((const float*)z, (const float*)y, (const float*)pi, (const float*)g, ng,
-                                                         (float)scale, N, M, D, (float*)gz);
+                                                         (float)scale, (const float*)gadd, N, M, D, (float*)gz);
     else
         ot_cost_grad_kernel<double><<<grid, 256, 0, st>>>((const double*)z, (const double*)y, (const double*)pi, (const double*)g, ng,
-                                                          scale, N, M, D, (double*)gz);
+                                                          scale, (const double*)gadd, N, M, D, (double*)gz);
     OTVAE_CHECK_LAUNCH("otvae_ot_cost_grad");
     return OTVAE_OK;
 }

@@ -383,9 +383,13 @@ class HipTrainer:
     def _draw_eps(self) -> None:
         """re-parametrisation noise of the next step from the device-side generator (one launch of this library)"""
         from .. import functional as HF
+        from ..utils import hasarg
         if self._rng_key is None:
             self._rng_key = HF.new_rng_key(self.device)
-        HF.normal_fill_(self.eps, self._rng_key)
+            prior = getattr(self.model, "prior", None)
+            self._wants_eps = prior is not None and hasarg(prior, "eps")
+        if self._wants_eps:
+            HF.normal_fill_(self.eps, self._rng_key)
 
     def step(self, x: Optional[Tensor] = None, eps: Optional[Tensor] = None, **batch_kwargs) -> Tensor:
         """One optimisation step.  Returns a device tensor [total, recon, prior] (valid until the next step)."""

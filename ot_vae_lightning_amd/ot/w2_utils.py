@@ -99,7 +99,7 @@ def ot_cost(C: Tensor, pi: Tensor) -> Tensor:
     lead, n, m = C.shape[:-2], C.shape[-2], C.shape[-1]
     c3, p3 = C.reshape(-1, n, m).contiguous(), pi.to(C.dtype).reshape(-1, n, m).contiguous()
     nb = c3.shape[0]
-    ws = torch.empty(nb * 64, device=C.device, dtype=torch.float64)
+    ws = torch.empty(nb * 256, device=C.device, dtype=torch.float64)
     out = torch.empty(nb, device=C.device, dtype=C.dtype)
     check(lib.otvae_ot_cost(_dt(C), ptr(c3), ptr(p3), nb, n, m, ptr(ws), ptr(out), stream()), "otvae_ot_cost")
     return out.reshape(lead)

@@ -44,15 +44,21 @@ class _SinkhornLossFn(torch.autograd.Function):
         ctx.scale = float(scale)
         ctx.mark_non_differentiable(iters)
         ctx.set_materialize_grads(False)  # no zeros tensor for the iteration count's "gradient"
-        return cost, iters
+        # the latents leave through this node too (an alias of z): the gradient the decoder sends back and the OT term's
+        # own gradient are then summed inside otvae_ot_cost_grad instead of by an autograd accumulation kernel
+        return z.view_as(z), cost, iters
 
     @staticmethod
-    def backward(ctx, g, _giters):
+    def backward(ctx, gz_out, g, _giters):
         z, y, pi = ctx.saved_tensors
         n, d = z.shape
+        if g is None:  # only the latents were used downstream
+            return gz_out, None, None, None, None, None
         gz = torch.empty_like(z)
+        gadd = gz_out.contiguous() if gz_out is not None else None
         check(_lib.load().otvae_ot_cost_grad(0 if z.dtype == torch.float32 else 1, ptr(z), ptr(y), ptr(pi), ptr(g.contiguous()),
-                                             g.numel(), ctx.scale, n, y.shape[0], d, ptr(gz), stream()), "otvae_ot_cost_grad")
+                                             g.numel(), ctx.scale, ptr(gadd), n, y.shape[0], d, ptr(gz), stream()),
+              "otvae_ot_cost_grad")
         return gz, None, None, None, None, None
 
 
@@ -100,5 +106,6 @@ class SinkhornPrior(Prior):
         zf = z.flatten(1)
         if prior_samples is None:
             prior_samples = self._draw(zf) if zf.dtype == torch.float32 else torch.randn_like(zf)
-        loss, self.last_iters = _SinkhornLossFn.apply(zf, prior_samples.flatten(1), self.reg, self.max_iter, self.threshold, _scale)
-        return z, loss, {"prior_samples": prior_samples}
+        z_out, loss, self.last_iters = _SinkhornLossFn.apply(zf, prior_samples.flatten(1), self.reg, self.max_iter, self.threshold,
+                                                             _scale)
+        return z_out.view(z.shape), loss, {"prior_samples": prior_samples}

@@ -90,6 +90,39 @@ def pmc(src, tag):
     print("wrote", out)
 
 
+def pmc_sq(src, tag):
+    """Instruction-issue evidence per kernel from one SQ pass (--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS
+    SQ_WAIT_INST_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES).  Units (MI355X_MICROARCH.md, PMC table):
+    SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_INSTS_* count wave-instructions."""
+    f = glob.glob(os.path.join(src, "*", "*_counter_collection.csv"))[0]
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(int)
+    meta = {}
+    for x in csv.DictReader(open(f)):
+        k = x["Kernel_Name"].split("(")[0]
+        acc[k][x["Counter_Name"]] += float(x["Counter_Value"])
+        if x["Counter_Name"] == "SQ_WAVES":
+            cnt[k] += 1
+            acc[k]["dur_ns"] += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
+            meta[k] = (x["VGPR_Count"], x["Accum_VGPR_Count"], x["LDS_Block_Size"], x["Workgroup_Size"])
+    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_per_kernel.csv")
+    with open(out, "w") as w:
+        w.write("# per launch averages; valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's life spent issuing\n"
+                "# vector instructions), wait_any_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked on s_waitcnt / barrier),\n"
+                "# lds_wait_frac = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES, valu_per_wave = SQ_INSTS_VALU / SQ_WAVES,\n"
+                "# occupancy_waves_per_simd = SQ_WAVE_CYCLES / SQ_BUSY_CYCLES-normalised estimate (wave-quad-cycles per busy SE cycle / SIMDs)\n")
+        w.write("kernel,launches,avg_us_under_pmc,vgpr,agpr,lds_bytes,wg_size,waves,valu_insts_per_wave,lds_insts_per_wave,"
+                "valu_active_frac,wait_any_frac,lds_wait_frac\n")
+        for k in sorted(acc, key=lambda k: -acc[k]["dur_ns"]):
+            a, n = acc[k], max(cnt[k], 1)
+            wc = a["SQ_WAVE_CYCLES"] or 1.0
+            wv = a["SQ_WAVES"] or 1.0
+            w.write('"%s",%d,%.2f,%s,%s,%s,%s,%.0f,%.1f,%.1f,%.3f,%.3f,%.3f\n' % (
+                k, n, a["dur_ns"] / n / 1e3, *meta.get(k, ("", "", "", "")), wv / n, a["SQ_INSTS_VALU"] / wv, a["SQ_INSTS_LDS"] / wv,
+                a["SQ_ACTIVE_INST_VALU"] / wc, a["SQ_WAIT_ANY"] / wc, a["SQ_WAIT_INST_LDS"] / wc))
+    print("wrote", out)
+
+
 def roofline(tag):
     """Joins <tag>_final_replay_kernel_stats.csv and <tag>_pmc_per_kernel.csv into <tag>_kernel_roofline.csv."""
     rep = {r["kernel"]: r for r in csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", f"{tag}_final_replay_kernel_stats.csv"))
@@ -120,7 +153,9 @@ if __name__ == "__main__":
     if sys.argv[1] == "--roofline":
         roofline(sys.argv[2])
         sys.exit(0)
-    if sys.argv[1] == "--pmc":
+    if sys.argv[1] == "--pmc-sq":
+        pmc_sq(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "--pmc":
         pmc(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "--replay":
         replay_stats(sys.argv[2], sys.argv[3])
