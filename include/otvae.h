@@ -307,6 +307,20 @@ int otvae_sqdist_max(int dtype, const void* x, const void* y, int nb, int N, int
 int otvae_ot_cost_grad(int dtype, const void* z, const void* y, const void* pi, const void* g, int ng, double scale,
                        const void* gadd, int N, int M, int D, void* gz, void* stream);
 
+/* ---- Gaussian W2 with empirical covariance as a loss term (GaussianW2Prior; BASELINE north_star) ------------ */
+/* Forward tail of L = w2_gaussian(mean_cov(_stats(z)), N(mut, covt)) (ot/w2_utils.py:40-80, ot/matrix_utils.py:145-158,
+ * gaussian_model.py:144-157): lam[D], vt[D][D] = eigenvalues / eigenvector rows of M = covt^1/2 cov covt^1/2 (otvae_eigh_fn,
+ * fn 3).  mut == NULL: zero mean; covt == NULL: identity (then M = cov and the make_pd shift of the 'spd' validation,
+ * w2_utils.py:661-669, is applied to cov and its spectrum alike).  loss[rep] = scale * L (fp32, the same value rep times: one
+ * entry per sample, prior/base.py:74-78);  q[D][D] = diag(lam^-1/4) vt, so that M^-1/2 = q^T q. */
+int otvae_w2_prior_tail(const double* mu, const double* mut, const double* cov, const double* covt, const double* lam,
+                        const double* vt, int D, double scale, int rep, float* loss, double* q, void* stream);
+/* Backward: gz[i][:] = gadd[i][:] + (2 scale sum(g) / B) [ (mu - mut) + (z_i - mu) - W (z_i - mu) ], W[D][D] = covt^1/2 M^-1/2
+ * covt^1/2 (symmetric) -- the closed form of the reference's autograd through eigh-based sqrtm.  z, gadd (may be NULL), gz:
+ * [B][D] fp32 (dtype 0) or fp64 (1); g[ng] fp32 upstream gradients of the loss replicas. */
+int otvae_w2_prior_bwd(int dtype, const void* z, int B, int D, const double* mu, const double* mut, const double* W,
+                       const float* g, int ng, double scale, const void* gadd, void* gz, void* stream);
+
 /* ---- GaussianModel statistics (ot/distribution_models/gaussian_model.py:99-108,144-157) ------------------- */
 /* samples [nb][B][D] (in_dtype 0=fp32,1=fp64) -> fp64 sum_x[nb][D], sum_xx[nb][D][D] (diag: [nb][D]),
  * accumulated into the running buffers:  run = decay<0 ? run + new : run*decay + new*(1-decay)

@@ -22,6 +22,7 @@ Fixtures:
   discrete.npz       CodebookModel in 'mean' mode, DiscreteTransport.compute/transport, CodebookPrior.forward
   gmm.npz            GaussianMixtureModel (diagonal) update/fit/energy/w2, GMMTransport.compute/transport
   vit.npz            ViT encoder / decoder (reference networks/vit.py) fwd + input and parameter gradients, dropout 0
+  w2_prior.npz       GaussianModel._stats + mean_cov + w2_gaussian under torch.autograd: loss and dL/dz (GaussianW2Prior)
   vit_vae.npz        ConditionalGaussianPrior fwd/bwd (+ EMA variant) and VAE.nelbo of the conditional ViT VAE
 """
 import math
@@ -762,8 +763,47 @@ def gen_gmm_recovery():
     print("gmm_recovery", out["w2_fit"], out["w2_update"])
 
 
+def gen_w2_prior():
+    """Gaussian W2 with empirical covariance as a differentiable loss term (the reference's pieces are
+    GaussianModel._stats + mean_cov + w2_gaussian; here they are composed under torch.autograd exactly as
+    DistributionModel's update_with_autograd path composes them, ot/distribution_models/base.py:82-89): loss and dL/dz."""
+    mu_ = R.ref("ot.matrix_utils")
+    w2 = R.ref("ot.w2_utils")
+    gm = R.ref("ot.distribution_models.gaussian_model")
+    out = {}
+    for D, B in ((16, 64), (128, 256), (128, 1024)):
+        g = torch.Generator().manual_seed(900 + D + B)
+        mix = torch.randn(D, D, generator=g) / math.sqrt(D)
+        z = (torch.randn(B, D, generator=g) @ (0.6 * mix + 0.7 * torch.eye(D)) + 0.3 * torch.randn(D, generator=g)).float()
+        tm = 0.2 * torch.randn(D, generator=g, dtype=torch.double)
+        tq = torch.randn(D, D, generator=g, dtype=torch.double) / math.sqrt(D)
+        tc = tq @ tq.T + 0.5 * torch.eye(D, dtype=torch.double)
+        model = gm.GaussianModel(D, dtype=torch.double)
+        for tag, tmean, tcov in (("std", torch.zeros(D, dtype=torch.double), torch.eye(D, dtype=torch.double)), ("gen", tm, tc)):
+            zz = z.clone().requires_grad_(True)
+            n, sx, sxx = model._stats(zz.double(), reduce=False)
+            mean, cov = mu_.mean_cov(sx, sxx, n)
+            loss = w2.w2_gaussian(mean, tmean, cov, tcov, make_pd=True)
+            loss.backward()
+            k = f"D{D}_B{B}/{tag}"
+            out[f"{k}/loss"] = npy(loss)
+            if B <= 256:
+                out[f"{k}/gz"] = npy(zz.grad)
+            else:  # benchmark-sized batch: the first rows, every row's sum and every column's sum of the gradient
+                out[f"{k}/gz_head"], out[f"{k}/gz_rowsum"], out[f"{k}/gz_colsum"] = \
+                    npy(zz.grad[:8]), npy(zz.grad.double().sum(1)), npy(zz.grad.double().sum(0))
+            out[f"{k}/mean"], out[f"{k}/cov_trace"] = npy(mean), npy(torch.diagonal(cov).sum())
+        kk = f"D{D}_B{B}"
+        if B <= 256:
+            out[f"{kk}/z"] = npy(z)
+        else:  # the benchmark-sized case is regenerated from its seed by the test (detfill-free: plain torch generator calls)
+            out[f"{kk}/z_checksum"] = np.array([z.double().sum().item(), z.double().square().sum().item()])
+        out[f"{kk}/target_mean"], out[f"{kk}/target_cov"] = npy(tm), npy(tc)
+    save("w2_prior.npz", out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior"]
     for w in which:
         globals()["gen_" + w]()

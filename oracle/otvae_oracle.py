@@ -345,6 +345,19 @@ def w2_gaussian(mean_s: Tensor, mean_t: Tensor, cov_s: Tensor, cov_t: Tensor, ma
     return shift + tr
 
 
+def w2_prior_loss(z: Tensor, target_mean: Optional[Tensor] = None, target_cov: Optional[Tensor] = None) -> Tensor:
+    """Gaussian W2 with empirical covariance as a loss term (BASELINE north_star): the batch statistics of
+    ``GaussianModel._stats`` (gaussian_model.py:144-151) -> ``mean_cov`` (matrix_utils.py:145-158) -> ``w2_gaussian``
+    (w2_utils.py:40-80, make_pd=True) against N(target_mean, target_cov) (default N(0, I)); differentiable in z with
+    torch.autograd through eigh, like the reference's update_with_autograd path (distribution_models/base.py:82-89)."""
+    d = z.shape[-1]
+    n, sx, sxx = gaussian_stats(z)
+    mean, cov = mean_cov(sx, sxx, n)
+    tm = torch.zeros(d, dtype=torch.double) if target_mean is None else target_mean.double()
+    tc = torch.eye(d, dtype=torch.double) if target_cov is None else target_cov.double()
+    return w2_gaussian(mean, tm, cov, tc, make_pd=True)
+
+
 def transport_operator_full(cov_s: Tensor, cov_t: Tensor, pg_star: float = 0.0) -> Tensor:
     """``_compute_transport_full_mat`` (ot/w2_utils.py:756-769), eq. 17:
     T = (1-pg) S_s^-1/2 (S_s^1/2 S_t S_s^1/2)^1/2 S_s^-1/2 + pg I, with invsqrtm of S_s + 1e-8 I."""

@@ -99,6 +99,8 @@ SIGNATURES = {
     "otvae_ot_cost": (i32, [i32, vp, vp, i32, i32, i32, vp, vp, vp]),
     "otvae_sqdist": (i32, [i32, vp, vp, i32, i32, i32, i32, vp, vp]),
     "otvae_ot_cost_grad": (i32, [i32, vp, vp, vp, vp, i32, f64, vp, i32, i32, i32, vp, vp]),
+    "otvae_w2_prior_tail": (i32, [vp, vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp]),
+    "otvae_w2_prior_bwd": (i32, [i32, vp, i32, i32, vp, vp, vp, vp, i32, f64, vp, vp, vp]),
     "otvae_gauss_stats_ws": (i64, [i32, i32, i32, i32]),
     "otvae_gauss_stats": (i32, [i32, vp, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp]),
     "otvae_mean_cov": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -1,0 +1,126 @@
+"""``GaussianW2Prior``: squared 2-Wasserstein (Gelbrich) distance between the minibatch's empirical Gaussian and a target
+Gaussian as the prior term of the VAE loss -- "Gaussian W2 with empirical covariance" of BASELINE.json's north_star.  The
+reference has no such class: this is a new ``Prior`` subclass on the reference's plug-in contract
+(prior/base.py:42-78) whose arithmetic is the reference's own pieces composed under autograd,
+
+    n, sum_x, sum_xx = GaussianModel._stats(z)          ot/distribution_models/gaussian_model.py:144-151   (fp64)
+    mean, cov        = mean_cov(sum_x, sum_xx, n)        ot/matrix_utils.py:145-158
+    loss             = w2_gaussian(mean, mean_t, cov, cov_t, make_pd=True)                 ot/w2_utils.py:40-80
+
+with a hand-written backward (csrc/w2_prior.hip) instead of autograd through ``eigh``.  Golden vectors: the three reference
+functions run under torch.autograd (tests/golden/w2_prior.npz)."""
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from .. import _lib
+from .._lib import check, ptr, stream
+from ..ot import matrix_utils as MU
+from .base import Prior
+
+__all__ = ["GaussianW2Prior"]
+
+
+class _W2PriorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, mut, covt, rt, scale):
+        lib = _lib.load()
+        _lib.require_cuda(z, "latents")
+        if z.dtype not in (torch.float32, torch.float64):
+            raise TypeError("GaussianW2Prior takes float32 or float64 latents")
+        z = z.contiguous()
+        b, d = z.shape
+        dev = z.device
+        f64 = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float64)  # noqa: E731
+        # batch statistics (fp64 sums) -> mean, covariance
+        n, sx, sxx = f64(1), f64(1, d), f64(1, d, d)
+        ws = torch.empty(max(8, lib.otvae_gauss_stats_ws(1, b, d, 0)), device=dev, dtype=torch.uint8)
+        check(lib.otvae_gauss_stats(0 if z.dtype == torch.float32 else 1, ptr(z), 1, b, d, 0, 0, -1.0, ptr(ws), ptr(n), ptr(sx),
+                                    ptr(sxx), stream()), "otvae_gauss_stats")
+        mu, cov = f64(1, d), f64(1, d, d)
+        check(lib.otvae_mean_cov(ptr(n), ptr(sx), ptr(sxx), 1, d, 0, ptr(mu), ptr(cov), stream()), "otvae_mean_cov")
+        # M = covt^1/2 cov covt^1/2 (M = cov for the standard-normal target), its spectrum
+        m = cov if rt is None else MU.matmul64(MU.matmul64(rt, cov), rt)
+        lam, vt = f64(1, d), f64(1, d, d)
+        ews = torch.empty(lib.otvae_eigh_ws(1, d), device=dev, dtype=torch.uint8)
+        check(lib.otvae_eigh_fn(ptr(m), 1, d, 3, ptr(vt), ptr(lam), ptr(ews), stream()), "otvae_eigh_fn")
+        loss = torch.empty(b, device=dev, dtype=torch.float32)
+        q = f64(d, d)
+        check(lib.otvae_w2_prior_tail(ptr(mu), ptr(mut), ptr(cov), ptr(covt), ptr(lam), ptr(vt), d, float(scale), b, ptr(loss),
+                                      ptr(q), stream()), "otvae_w2_prior_tail")
+        ctx.save_for_backward(z, mu, q)
+        ctx.target = (mut, rt)
+        ctx.scale = float(scale)
+        # the latents leave through this node too (see prior/sinkhorn.py): the decoder's gradient is added inside the backward kernel
+        return z.view_as(z), loss
+
+    @staticmethod
+    def backward(ctx, gz_out, g):
+        lib = _lib.load()
+        z, mu, q = ctx.saved_tensors
+        mut, rt = ctx.target
+        if g is None:
+            return gz_out, None, None, None, None
+        b, d = z.shape
+        w = MU.matmul64(q, q, trans_a=True)                          # M^-1/2
+        if rt is not None:
+            w = MU.matmul64(MU.matmul64(rt, w), rt)                  # covt^1/2 M^-1/2 covt^1/2
+        gz = torch.empty_like(z)
+        gadd = gz_out.contiguous() if gz_out is not None else None
+        check(lib.otvae_w2_prior_bwd(0 if z.dtype == torch.float32 else 1, ptr(z), b, d, ptr(mu), ptr(mut), ptr(w),
+                                     ptr(g.float().contiguous()), g.numel(), ctx.scale, ptr(gadd), ptr(gz), stream()),
+              "otvae_w2_prior_bwd")
+        return gz, None, None, None, None
+
+
+class GaussianW2Prior(Prior):
+    """Deterministic encoder + W2^2( N(mean_B, cov_B), N(target_mean, target_cov) ) of the minibatch of latents (flattened to
+    [B, D]); ``target_mean`` / ``target_cov`` default to the standard normal.  ``forward`` returns (z, loss[B], artifacts) with
+    every loss entry equal to the distance, so the VAE's ``prior_loss.mean()`` is the distance.  The batch must hold more
+    samples than latent dimensions for the empirical covariance to be positive definite (otherwise the reference's
+    ``make_pd`` shift of 1e-8 applies and the gradient of the square root is ill-conditioned, exactly as under autograd)."""
+
+    def __init__(self, loss_coeff: float = 1., annealing_steps: int = 0, target_mean: Optional[Tensor] = None,
+                 target_cov: Optional[Tensor] = None):
+        super().__init__(loss_coeff, annealing_steps)
+        if target_cov is not None and (target_cov.dim() != 2 or target_cov.shape[0] != target_cov.shape[1]):
+            raise ValueError("`target_cov` should be a 2-dim square matrix")
+        if target_mean is not None and target_cov is not None and target_mean.shape[-1] != target_cov.shape[-1]:
+            raise ValueError(f"All the inputs dimensionalities should match, got {[target_mean.shape[-1], target_cov.shape[-1]]}")
+        self.register_buffer("target_mean", None if target_mean is None else target_mean.detach().double().clone())
+        self.register_buffer("target_cov", None if target_cov is None else target_cov.detach().double().clone())
+        self._root = None  # (validated target covariance, its square root), made on first use on the device
+
+    def out_size(self, size):
+        return size
+
+    def sample(self, shape, device) -> Tensor:
+        x = torch.randn(*shape, device=device)
+        if self.target_cov is None and self.target_mean is None:
+            return x
+        flat = x.flatten(1).double()
+        if self.target_cov is not None:
+            flat = flat @ self._target_root()[1][0].to(device)
+        if self.target_mean is not None:
+            flat = flat + self.target_mean.to(device)
+        return flat.to(x.dtype).reshape(x.shape)
+
+    def _target_root(self):
+        if self._root is None or self._root[0].device != self.target_cov.device:
+            from ..ot.w2_utils import _spd_and_roots
+            cov, root, _ = _spd_and_roots(self.target_cov.reshape(1, *self.target_cov.shape).contiguous(), "target_cov", True)
+            self._root = (cov.contiguous(), root.contiguous())
+        return self._root
+
+    def forward(self, x: Tensor, step: int) -> Prior.EncodingResults:
+        # loss_coeff x annealing is folded into the tail kernel (and the backward's scale): no separate multiply
+        return self.encode(x, _scale=float(self.loss_coeff * self.annealing(step)))
+
+    def encode(self, x: Tensor, _scale: float = 1.0) -> Prior.EncodingResults:
+        zf = x.flatten(1)
+        if self.target_cov is not None and self.target_cov.shape[-1] != zf.shape[1]:
+            raise ValueError(f"All the inputs dimensionalities should match, got {[zf.shape[1], self.target_cov.shape[-1]]}")
+        covt, rt = self._target_root() if self.target_cov is not None else (None, None)
+        z_out, loss = _W2PriorFn.apply(zf, self.target_mean, covt, rt, _scale)
+        return z_out.view(x.shape), loss, {}

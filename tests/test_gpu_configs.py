@@ -193,6 +193,96 @@ def test_sinkhorn_starved_solver_cannot_pass_for_a_result(A, monkeypatch):
     assert torch.equal(multi, good)
 
 
+def _w2_prior_case(G, D, B):
+    import math
+    kk = f"D{D}_B{B}"
+    if B <= 256:
+        return torch.from_numpy(G[f"{kk}/z"])
+    g = torch.Generator().manual_seed(900 + D + B)   # the generator calls of oracle/gen_golden.py:gen_w2_prior
+    mix = torch.randn(D, D, generator=g) / math.sqrt(D)
+    return (torch.randn(B, D, generator=g) @ (0.6 * mix + 0.7 * torch.eye(D)) + 0.3 * torch.randn(D, generator=g)).float()
+
+
+@pytest.mark.parametrize("shape", [(16, 64), (128, 256), (128, 1024)])
+def test_gaussian_w2_prior_vs_reference_autograd(A, shape):
+    """GaussianW2Prior (W2^2 between the batch's empirical Gaussian and a target Gaussian, HIP forward + closed-form HIP
+    backward) against the reference's own ``GaussianModel._stats -> mean_cov -> w2_gaussian`` run under torch.autograd
+    (tests/golden/w2_prior.npz): loss and dL/dz at 1e-4 (north_star), measured ~1e-7.  Standard-normal and general targets;
+    loss coefficient and the decoder-side gradient folded into the kernels."""
+    from conftest import load_golden
+    G = load_golden("w2_prior.npz")
+    D, B = shape
+    rep = Report(f"GaussianW2Prior D={D} B={B} vs the reference under torch.autograd")
+    z0 = _w2_prior_case(G, D, B)
+    for tag in ("std", "gen"):
+        k = f"D{D}_B{B}/{tag}"
+        tm = None if tag == "std" else torch.from_numpy(G[f"D{D}_B{B}/target_mean"])
+        tc = None if tag == "std" else torch.from_numpy(G[f"D{D}_B{B}/target_cov"])
+        prior = A.GaussianW2Prior(loss_coeff=0.25, target_mean=tm, target_cov=tc).cuda()
+        z = z0.clone().cuda().reshape(B, D, 1, 1).requires_grad_(True)
+        zz, loss, _ = prior(z, step=0)
+        assert zz.shape == z.shape and loss.shape == (B,)
+        extra = torch.sin(torch.arange(B * D, dtype=torch.float32).reshape(B, D, 1, 1)).cuda()     # a decoder-side gradient
+        (loss.mean() + (zz * extra).sum()).backward()
+        rep.check(f"{tag}: loss", loss[0] / 0.25, torch.from_numpy(G[f"{k}/loss"]).float(), tol=1e-4)
+        gz = (z.grad - extra).flatten(1).cpu() / 0.25
+        if B <= 256:
+            rep.check(f"{tag}: dL/dz", gz, torch.from_numpy(G[f"{k}/gz"]), tol=1e-4)
+        else:
+            rep.check(f"{tag}: dL/dz (head)", gz[:8], torch.from_numpy(G[f"{k}/gz_head"]), tol=1e-4)
+            rep.check(f"{tag}: dL/dz (row sums)", gz.double().sum(1), torch.from_numpy(G[f"{k}/gz_rowsum"]), tol=1e-4)
+            rep.check(f"{tag}: dL/dz (column sums)", gz.double().sum(0), torch.from_numpy(G[f"{k}/gz_colsum"]), tol=1e-4)
+        # the oracle on the same inputs (the chain the other parity tests use)
+        zo = z0.clone().requires_grad_(True)
+        lo = O.w2_prior_loss(zo, tm, tc)
+        lo.backward()
+        rep.check(f"{tag}: loss vs oracle", loss[0] / 0.25, lo.detach().float(), tol=1e-4)
+        rep.check(f"{tag}: dL/dz vs oracle", gz, zo.grad, tol=1e-4)
+        s = prior.sample((4, D, 1, 1), "cuda")
+        assert s.shape == (4, D, 1, 1) and torch.isfinite(s).all()
+    with pytest.raises(ValueError):
+        A.GaussianW2Prior(target_mean=torch.zeros(3), target_cov=torch.eye(4))
+    rep.finish()
+
+
+def test_gaussian_w2_prior_in_vae_training_step(A):
+    """The W2 prior inside VAE.nelbo through HipTrainer (eager and captured: same bits), against the oracle's step."""
+    rep = Report("VAE + GaussianW2Prior training step vs CPU oracle")
+    B, lat = 256, 128
+    x = mnist_like(B, 35)
+
+    def make():
+        torch.manual_seed(9)
+        enc = A.CNN(1, lat, 32, 1, capacity=8, down_sample=True, residual="add")
+        dec = A.CNN(lat, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+        return A.VAE(encoder=enc, decoder=dec, prior=A.GaussianW2Prior(loss_coeff=0.5))
+
+    model = make()
+    ea = O.cnn_arch(1, lat, 32, 1, capacity=8, down_sample=True, residual="add")
+    da = O.cnn_arch(lat, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    pe = {k: v.detach().clone().contiguous() for k, v in model.encoder.state_dict().items()}
+    pd = {k: v.detach().clone().contiguous() for k, v in model.decoder.state_dict().items()}
+    leaves = [v.requires_grad_(True) for d in (pe, pd) for k, v in d.items() if v.is_floating_point() and "running" not in k]
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    h = O.cnn_forward(x, pe, ea)
+    w2 = O.w2_prior_loss(h.flatten(1))
+    recon = torch.nn.functional.mse_loss(O.cnn_forward(h, pd, da), x)
+    loss = recon + 0.5 * w2.float() / x[0].numel()
+    loss.backward()
+    outs = []
+    for graph in (False, True):
+        tr = A.HipTrainer(make().cuda().train(), batch_shape=(B, 1, 32, 32), use_graph=graph)
+        out = tr.step(x.cuda()).clone()
+        outs.append((out, tr.gflat.clone(), tr.pflat.clone()))
+        if not graph:
+            rep.check("loss[total,recon,prior]", out, torch.stack([loss, recon, 0.5 * w2.float() / x[0].numel()]).detach())
+            params = [p for net in (tr.model.encoder, tr.model.decoder) for p in net.parameters()]
+            rep.check("grad_l2 (all parameters)", torch.tensor([p.grad.double().norm().item() for p in params]),
+                      torch.tensor([v.grad.double().norm().item() for v in leaves]), tol=5e-4)
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    rep.finish()
+
+
 def test_device_normal_generator(A):
     """``otvae_normal_fill``: standard-normal moments, a fresh draw per call (the counter advances on the device, also inside a
     replayed graph), the same values for the same (seed, counter) whatever the launch, independent streams."""

@@ -552,3 +552,33 @@ def test_conditional_vit_vae_nelbo():
     names = [str(n) for n in load_golden("vit_vae.npz")["vae/param_names"]]
     l2 = torch.tensor([grads[n].double().norm().item() if grads[n] is not None else 0.0 for n in names])
     assert rel_err(l2, g["grad_l2"]) < 5e-4
+
+
+def test_w2_prior_loss_and_gradient_vs_reference_autograd():
+    """Gaussian W2 with empirical covariance as a loss: the oracle's composition against the reference's own functions
+    (GaussianModel._stats -> mean_cov -> w2_gaussian) run under torch.autograd (tests/golden/w2_prior.npz)."""
+    import math
+    G = load_golden("w2_prior.npz")
+    for D, B in ((16, 64), (128, 256), (128, 1024)):
+        kk = f"D{D}_B{B}"
+        if B <= 256:
+            z = torch.from_numpy(G[f"{kk}/z"])
+        else:  # regenerated from its seed (the generator calls of oracle/gen_golden.py:gen_w2_prior)
+            g = torch.Generator().manual_seed(900 + D + B)
+            mix = torch.randn(D, D, generator=g) / math.sqrt(D)
+            z = (torch.randn(B, D, generator=g) @ (0.6 * mix + 0.7 * torch.eye(D)) + 0.3 * torch.randn(D, generator=g)).float()
+            chk = G[f"{kk}/z_checksum"]
+            assert abs(z.double().sum().item() - chk[0]) < 1e-6 * abs(chk[0]) + 1e-9
+        for tag in ("std", "gen"):
+            tm = None if tag == "std" else torch.from_numpy(G[f"{kk}/target_mean"])
+            tc = None if tag == "std" else torch.from_numpy(G[f"{kk}/target_cov"])
+            zz = z.clone().requires_grad_(True)
+            loss = O.w2_prior_loss(zz, tm, tc)
+            loss.backward()
+            k = f"{kk}/{tag}"
+            assert rel_err(loss.detach(), torch.from_numpy(G[f"{k}/loss"])) < 1e-10
+            if B <= 256:
+                assert rel_err(zz.grad, torch.from_numpy(G[f"{k}/gz"])) < 2e-6
+            else:
+                assert rel_err(zz.grad[:8], torch.from_numpy(G[f"{k}/gz_head"])) < 2e-6
+                assert rel_err(zz.grad.double().sum(1), torch.from_numpy(G[f"{k}/gz_rowsum"])) < 2e-6
