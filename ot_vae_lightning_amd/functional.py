@@ -17,6 +17,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
+from . import ops as _ops  # noqa: F401  (registers torch.ops.otvae.*)
 from ._lib import ConvGeom, check, ptr, ptr_array, stream
 
 BN_EPS = 1e-5
@@ -192,159 +193,170 @@ class _ConvBNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, specs, stats, params_ref, stats_out, *tensors):
-        lib = _lib.load()
-        nbr = len(specs)
         ctx.specs, ctx.stats, ctx.params_ref = specs, stats, params_ref
-        mean, invstd, scales, shifts, training = stats
-        outs = []
-        geoms = []
-        ctx.out_stats = []
-        jobs = (_lib.ConvJob * nbr)()
-        keep = []
-        for b, sp in enumerate(specs):
-            w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
-            g, ho, wo = _geom(x, w, sp.stride, sp.pad, sp.up)
-            y = empty_nhwc(x.shape[0], w.shape[0], ho, wo, x)
-            part, st = None, None
-            if sp.out_stats:
-                p_s, ld = C.c_int(0), C.c_int(0)
-                check(lib.otvae_conv_fwd_stats_ws(C.byref(g), C.byref(p_s), C.byref(ld)), "otvae_conv_fwd_stats_ws")
-                part = torch.empty((p_s.value, 2, ld.value), device=x.device, dtype=torch.float64)
-                st = (part, p_s.value, ld.value)
-            jb = jobs[b]
-            jb.kind, jb.relu, jb.geom = _lib.JOB_FWD, int(sp.relu), g
-            jb.x = ptr(x)
-            jb.scale = ptr(scales[b]) if sp.has_norm else None
-            jb.shift = ptr(shifts[b]) if sp.has_norm else None
-            jb.w, jb.bias, jb.residual, jb.y, jb.stat_partial = ptr(w), ptr(bias), ptr(res), ptr(y), ptr(part)
-            keep.append(part)
-            outs.append(y)
-            geoms.append(g)
-            ctx.out_stats.append(st)
-        # both branches of a ConvBlock read the same x and are independent: one launch (otvae_conv_multi)
-        check(lib.otvae_conv_multi(nbr, jobs, stream()), "otvae_conv_multi(forward)")
-        ctx.geoms = geoms
-        stats_out.extend(ctx.out_stats)
-        ctx.out_stats = None
+        outs, ctx.geoms, out_stats = conv_forward_launch(x, specs, stats, tensors)
+        stats_out.extend(out_stats)
         ctx.save_for_backward(x, *tensors)
-        return outs[0] if nbr == 1 else tuple(outs)
+        return outs[0] if len(specs) == 1 else tuple(outs)
 
     @staticmethod
     def backward(ctx, *gys):
-        lib = _lib.load()
-        specs, geoms = ctx.specs, ctx.geoms
-        mean, invstd, scales, shifts, training = ctx.stats
         saved = ctx.saved_tensors
-        x, tensors = saved[0], saved[1:]
-        nbr = len(specs)
-        n, cs, hs, ws = x.shape
-        m_in = n * hs * ws
-        need_dx = ctx.needs_input_grad[0]
-        grads: List[Optional[Tensor]] = []
-        gvs, partials, ps = [], [], []
-        cspad = 0
-        per_branch = []
-        # Weight- and data-gradient of every branch are independent of each other: all of them go into ONE launch
-        # (otvae_conv_multi).  When the weight gradient lands in a trainer-owned flat buffer (persistent memory, read by
-        # the optimizer and not through autograd's accumulation) its partial -> gradient reduction is deferred so that
-        # all layers of the backward pass reduce in one launch; otherwise it runs right after the multi launch:
-        # autograd may clone / accumulate the returned tensor before a deferred kernel would have filled it.
-        jobs = (_lib.ConvJob * (2 * nbr))()
-        njobs = 0
-        keep = []
-        for b, sp in enumerate(specs):
-            w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
-            pw, pb, pgam, pbet = ctx.params_ref[b]
-            gy = gys[b]
-            if gy is None:
-                gy = torch.zeros_like(empty_nhwc(n, w.shape[0], geoms[b].Ho, geoms[b].Wo, x))
-            gy = as_nhwc(gy)
-            g = geoms[b]
-            # --- weight / bias gradient
-            p_w = C.c_int(0)
-            check(lib.otvae_conv_bwd_weight_ws(C.byref(g), int(sp.has_bias), C.byref(p_w)), "otvae_conv_bwd_weight_ws")
-            kk = g.KH * g.KW * g.Cs + (1 if sp.has_bias else 0)
-            wpart = torch.empty((p_w.value, kk, g.Cn), device=x.device, dtype=torch.float32)
-            gw = _grad_buffer(pw, w)
-            gb = _grad_buffer(pb, bias) if sp.has_bias else None
-            defer = (pw is not None and getattr(pw, "_otvae_grad_view", None) is not None and
-                     (not sp.has_bias or getattr(pb, "_otvae_grad_view", None) is not None))
+        dx, per = conv_backward_launch(saved[0], saved[1:], ctx.specs, ctx.geoms, ctx.stats, ctx.params_ref, gys,
+                                       ctx.needs_input_grad[0])
+        out: List[Optional[Tensor]] = [dx, None, None, None, None]
+        for gw, gb, dgam, dbet, gres in per:
+            out += [gw, gb, dgam, dbet, gres]
+        return tuple(out)
+
+
+def conv_forward_launch(x, specs, stats, tensors):
+    """The launches of 1 or 2 ConvLayer branches reading the same x (one ``otvae_conv_multi`` call).  ``tensors`` holds
+    (weight, bias, gamma, beta, residual) per branch.  Returns (outputs, geometries, per-output statistics partials)."""
+    lib = _lib.load()
+    nbr = len(specs)
+    mean, invstd, scales, shifts, training = stats
+    outs, geoms, out_stats = [], [], []
+    jobs = (_lib.ConvJob * nbr)()
+    keep = []
+    for b, sp in enumerate(specs):
+        w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
+        g, ho, wo = _geom(x, w, sp.stride, sp.pad, sp.up)
+        y = empty_nhwc(x.shape[0], w.shape[0], ho, wo, x)
+        part, st = None, None
+        if sp.out_stats:
+            p_s, ld = C.c_int(0), C.c_int(0)
+            check(lib.otvae_conv_fwd_stats_ws(C.byref(g), C.byref(p_s), C.byref(ld)), "otvae_conv_fwd_stats_ws")
+            part = torch.empty((p_s.value, 2, ld.value), device=x.device, dtype=torch.float64)
+            st = (part, p_s.value, ld.value)
+        jb = jobs[b]
+        jb.kind, jb.relu, jb.geom = _lib.JOB_FWD, int(sp.relu), g
+        jb.x = ptr(x)
+        jb.scale = ptr(scales[b]) if sp.has_norm else None
+        jb.shift = ptr(shifts[b]) if sp.has_norm else None
+        jb.w, jb.bias, jb.residual, jb.y, jb.stat_partial = ptr(w), ptr(bias), ptr(res), ptr(y), ptr(part)
+        keep.append(part)
+        outs.append(y)
+        geoms.append(g)
+        out_stats.append(st)
+    # both branches of a ConvBlock read the same x and are independent: one launch (otvae_conv_multi)
+    check(lib.otvae_conv_multi(nbr, jobs, stream()), "otvae_conv_multi(forward)")
+    return outs, geoms, out_stats
+
+
+def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_dx):
+    """Weight / bias / BatchNorm / data gradients of 1 or 2 ConvLayer branches (one ``otvae_conv_multi`` call + the BatchNorm
+    backward pair).  Returns (dx | None, [(gw, gb, dgamma, dbeta, gresidual) per branch])."""
+    lib = _lib.load()
+    mean, invstd, scales, shifts, training = stats
+    nbr = len(specs)
+    n, cs, hs, ws = x.shape
+    m_in = n * hs * ws
+    grads: List[Optional[Tensor]] = []
+    gvs, partials, ps = [], [], []
+    cspad = 0
+    per_branch = []
+    # Weight- and data-gradient of every branch are independent of each other: all of them go into ONE launch
+    # (otvae_conv_multi).  When the weight gradient lands in a trainer-owned flat buffer (persistent memory, read by
+    # the optimizer and not through autograd's accumulation) its partial -> gradient reduction is deferred so that
+    # all layers of the backward pass reduce in one launch; otherwise it runs right after the multi launch:
+    # autograd may clone / accumulate the returned tensor before a deferred kernel would have filled it.
+    jobs = (_lib.ConvJob * (2 * nbr))()
+    njobs = 0
+    keep = []
+    for b, sp in enumerate(specs):
+        w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
+        pw, pb, pgam, pbet = params_ref[b]
+        gy = gys[b]
+        if gy is None:
+            gy = torch.zeros_like(empty_nhwc(n, w.shape[0], geoms[b].Ho, geoms[b].Wo, x))
+        gy = as_nhwc(gy)
+        g = geoms[b]
+        # --- weight / bias gradient
+        p_w = C.c_int(0)
+        check(lib.otvae_conv_bwd_weight_ws(C.byref(g), int(sp.has_bias), C.byref(p_w)), "otvae_conv_bwd_weight_ws")
+        kk = g.KH * g.KW * g.Cs + (1 if sp.has_bias else 0)
+        wpart = torch.empty((p_w.value, kk, g.Cn), device=x.device, dtype=torch.float32)
+        gw = _grad_buffer(pw, w)
+        gb = _grad_buffer(pb, bias) if sp.has_bias else None
+        defer = (pw is not None and getattr(pw, "_otvae_grad_view", None) is not None and
+                 (not sp.has_bias or getattr(pb, "_otvae_grad_view", None) is not None))
+        jb = jobs[njobs]
+        njobs += 1
+        # deferred reductions know the taps that never touch the image (1x1 / 2x2 maps): their partial rows may stay unwritten
+        jb.kind, jb.relu, jb.has_bias, jb.geom = _lib.JOB_BWD_WEIGHT, int(sp.relu), int(sp.has_bias), g
+        jb.defer_reduce = (_lib.DEFER_DENSE if _DENSE_REDUCE else _lib.DEFER_SPARSE) if defer else 0
+        jb.x, jb.gy = ptr(x), ptr(gy)
+        jb.scale = ptr(scales[b]) if sp.has_norm else None
+        jb.shift = ptr(shifts[b]) if sp.has_norm else None
+        jb.wpartial, jb.gw, jb.gb = ptr(wpart), ptr(gw), ptr(gb)
+        keep += [wpart, gy]
+        if defer:
+            dead = C.c_uint32(0)
+            if not _DENSE_REDUCE:
+                check(lib.otvae_conv_dead_taps(C.byref(g), C.byref(dead)), "otvae_conv_dead_taps")
+            _PendingReduce.add(x.device, wpart, p_w.value, kk - (1 if sp.has_bias else 0), kk, g.Cn,
+                               gw.data_ptr(), gb.data_ptr() if gb is not None else None, g.Cs, dead.value)
+        # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
+        gv = None
+        part = None
+        if need_dx or sp.has_norm:
+            wd = getattr(pw, "_otvae_wd", None) if pw is not None else None
+            if wd is None:
+                wd = torch.empty(g.KH * g.KW * g.Cn * g.Cs, device=x.device, dtype=torch.float32)
+                check(lib.otvae_weight_transpose(ptr(w), ptr(wd), g.KH * g.KW, g.Cs, g.Cn, stream()),
+                      "otvae_weight_transpose")
+            p_d, cp = C.c_int(0), C.c_int(0)
+            check(lib.otvae_conv_bwd_data_ws(C.byref(g), C.byref(p_d), C.byref(cp)), "otvae_conv_bwd_data_ws")
+            gv = empty_nhwc(n, cs, hs, ws, x)
+            if sp.has_norm:
+                part = torch.empty((p_d.value, 2, cp.value), device=x.device, dtype=torch.float64)
+                cspad = cp.value
+                ps.append(p_d.value)
             jb = jobs[njobs]
             njobs += 1
-            # deferred reductions know the taps that never touch the image (1x1 / 2x2 maps): their partial rows may stay unwritten
-            jb.kind, jb.relu, jb.has_bias, jb.geom = _lib.JOB_BWD_WEIGHT, int(sp.relu), int(sp.has_bias), g
-            jb.defer_reduce = (_lib.DEFER_DENSE if _DENSE_REDUCE else _lib.DEFER_SPARSE) if defer else 0
-            jb.x, jb.gy = ptr(x), ptr(gy)
+            jb.kind, jb.relu, jb.geom = _lib.JOB_BWD_DATA, int(sp.relu), g
+            jb.gy, jb.w, jb.x = ptr(gy), ptr(wd), ptr(x)
             jb.scale = ptr(scales[b]) if sp.has_norm else None
             jb.shift = ptr(shifts[b]) if sp.has_norm else None
-            jb.wpartial, jb.gw, jb.gb = ptr(wpart), ptr(gw), ptr(gb)
-            keep += [wpart, gy]
-            if defer:
-                dead = C.c_uint32(0)
-                if not _DENSE_REDUCE:
-                    check(lib.otvae_conv_dead_taps(C.byref(g), C.byref(dead)), "otvae_conv_dead_taps")
-                _PendingReduce.add(x.device, wpart, p_w.value, kk - (1 if sp.has_bias else 0), kk, g.Cn,
-                                   gw.data_ptr(), gb.data_ptr() if gb is not None else None, g.Cs, dead.value)
-            # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
-            gv = None
-            part = None
-            if need_dx or sp.has_norm:
-                wd = getattr(pw, "_otvae_wd", None) if pw is not None else None
-                if wd is None:
-                    wd = torch.empty(g.KH * g.KW * g.Cn * g.Cs, device=x.device, dtype=torch.float32)
-                    check(lib.otvae_weight_transpose(ptr(w), ptr(wd), g.KH * g.KW, g.Cs, g.Cn, stream()),
-                          "otvae_weight_transpose")
-                p_d, cp = C.c_int(0), C.c_int(0)
-                check(lib.otvae_conv_bwd_data_ws(C.byref(g), C.byref(p_d), C.byref(cp)), "otvae_conv_bwd_data_ws")
-                gv = empty_nhwc(n, cs, hs, ws, x)
-                if sp.has_norm:
-                    part = torch.empty((p_d.value, 2, cp.value), device=x.device, dtype=torch.float64)
-                    cspad = cp.value
-                    ps.append(p_d.value)
-                jb = jobs[njobs]
-                njobs += 1
-                jb.kind, jb.relu, jb.geom = _lib.JOB_BWD_DATA, int(sp.relu), g
-                jb.gy, jb.w, jb.x = ptr(gy), ptr(wd), ptr(x)
-                jb.scale = ptr(scales[b]) if sp.has_norm else None
-                jb.shift = ptr(shifts[b]) if sp.has_norm else None
-                jb.mean = ptr(mean) if sp.has_norm else None
-                jb.invstd = ptr(invstd) if sp.has_norm else None
-                jb.gv, jb.bn_partial = ptr(gv), ptr(part)
-                keep.append(wd)
-            per_branch.append((gw, gb, gv, part, gy if sp.has_residual else None))
-        check(lib.otvae_conv_multi(njobs, jobs, stream()), "otvae_conv_multi(backward)")
-        # --- BatchNorm backward over the branches that have one
-        bn_idx = [b for b, sp in enumerate(specs) if sp.has_norm]
-        dgam = {b: None for b in range(nbr)}
-        dbet = {b: None for b in range(nbr)}
-        dx = None
-        if bn_idx:
-            nbn = len(bn_idx)
-            coef = torch.empty((2 + nbn, cs), device=x.device, dtype=torch.float32)
-            gam_t = [tensors[5 * b + 2] for b in bn_idx]
-            for b in bn_idx:
-                dgam[b] = _grad_buffer(ctx.params_ref[b][2], tensors[5 * b + 2])
-                dbet[b] = _grad_buffer(ctx.params_ref[b][3], tensors[5 * b + 3])
-            parr = (C.c_int * nbn)(*ps)
-            check(lib.otvae_bn_bwd_finalize(nbn, ptr_array([per_branch[b][3] for b in bn_idx]), parr, cspad, m_in, cs,
-                                            ptr(mean), ptr(invstd), ptr_array(gam_t),
-                                            ptr_array([dgam[b] for b in bn_idx]), ptr_array([dbet[b] for b in bn_idx]),
-                                            ptr(coef), stream()), "otvae_bn_bwd_finalize")
-            if need_dx:
-                if not training:
-                    coef[:2].zero_()  # eval mode: BatchNorm is a fixed affine, no batch-statistics terms
-                dx = empty_nhwc(n, cs, hs, ws, x)
-                check(lib.otvae_bn_bwd_apply(nbn, ptr_array([per_branch[b][2] for b in bn_idx]), ptr(x), ptr(coef),
-                                             m_in, cs, ptr(dx), stream()), "otvae_bn_bwd_apply")
+            jb.mean = ptr(mean) if sp.has_norm else None
+            jb.invstd = ptr(invstd) if sp.has_norm else None
+            jb.gv, jb.bn_partial = ptr(gv), ptr(part)
+            keep.append(wd)
+        per_branch.append((gw, gb, gv, part, gy if sp.has_residual else None))
+    check(lib.otvae_conv_multi(njobs, jobs, stream()), "otvae_conv_multi(backward)")
+    # --- BatchNorm backward over the branches that have one
+    bn_idx = [b for b, sp in enumerate(specs) if sp.has_norm]
+    dgam = {b: None for b in range(nbr)}
+    dbet = {b: None for b in range(nbr)}
+    dx = None
+    if bn_idx:
+        nbn = len(bn_idx)
+        coef = torch.empty((2 + nbn, cs), device=x.device, dtype=torch.float32)
+        gam_t = [tensors[5 * b + 2] for b in bn_idx]
+        for b in bn_idx:
+            dgam[b] = _grad_buffer(params_ref[b][2], tensors[5 * b + 2])
+            dbet[b] = _grad_buffer(params_ref[b][3], tensors[5 * b + 3])
+        parr = (C.c_int * nbn)(*ps)
+        check(lib.otvae_bn_bwd_finalize(nbn, ptr_array([per_branch[b][3] for b in bn_idx]), parr, cspad, m_in, cs,
+                                        ptr(mean), ptr(invstd), ptr_array(gam_t),
+                                        ptr_array([dgam[b] for b in bn_idx]), ptr_array([dbet[b] for b in bn_idx]),
+                                        ptr(coef), stream()), "otvae_bn_bwd_finalize")
         if need_dx:
-            for b, sp in enumerate(specs):
-                if not sp.has_norm:
-                    dx = per_branch[b][2] if dx is None else dx + per_branch[b][2]
-        out: List[Optional[Tensor]] = [dx if need_dx else None, None, None, None, None]
-        for b in range(nbr):
-            gw, gb, gv, part, gres = per_branch[b]
-            out += [gw, gb, dgam[b], dbet[b], gres]
-        return tuple(out)
+            if not training:
+                coef[:2].zero_()  # eval mode: BatchNorm is a fixed affine, no batch-statistics terms
+            dx = empty_nhwc(n, cs, hs, ws, x)
+            check(lib.otvae_bn_bwd_apply(nbn, ptr_array([per_branch[b][2] for b in bn_idx]), ptr(x), ptr(coef),
+                                         m_in, cs, ptr(dx), stream()), "otvae_bn_bwd_apply")
+    if need_dx:
+        for b, sp in enumerate(specs):
+            if not sp.has_norm:
+                dx = per_branch[b][2] if dx is None else dx + per_branch[b][2]
+    per = []
+    for b_ in range(nbr):
+        gw, gb, gv, part, gres = per_branch[b_]
+        per.append((gw, gb, dgam[b_], dbet[b_], gres))
+    return (dx if need_dx else None), per
 
 
 def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
@@ -399,40 +411,18 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-class _AttentionFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, qkv, heads, scale=None):
-        lib = _lib.load()
-        n, width, h, w = qkv.shape
-        t = h * w
-        if width % (3 * heads) != 0:
-            raise ValueError(f"tensor width: {width} must be divisible by (3 * n_heads): {3 * heads}")
-        c = width // (3 * heads)
-        out = empty_nhwc(n, heads * c, h, w, qkv)
-        lse = torch.empty((n, heads, t), device=qkv.device, dtype=torch.float32)
-        # head widths 1 and 2 (the 32x32 and 16x16 blocks, 83 % of the attention time): the forward pass also emits the
-        # per-query key moments from which the backward pass forms dq without another pass over the keys
-        aux = None
-        if c <= 2 and ctx.needs_input_grad[0]:
-            aux = torch.empty((n, heads, t, c * c), device=qkv.device, dtype=torch.float32)
-        scale = 1.0 / c if scale is None else float(scale)  # 1/C = the two C^-1/2 factors of QKVAttention
-        check(lib.otvae_attn_fwd_scaled(ptr(qkv), n, t, heads, c, scale, ptr(out), ptr(lse), ptr(aux), stream()), "otvae_attn_fwd")
-        ctx.save_for_backward(qkv, out, lse, aux) if aux is not None else ctx.save_for_backward(qkv, out, lse)
-        ctx.dims = (n, t, heads, c, scale)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        lib = _lib.load()
-        saved = ctx.saved_tensors
-        qkv, out, lse = saved[:3]
-        aux = saved[3] if len(saved) > 3 else None
-        n, t, heads, c, scale = ctx.dims
-        gout = as_nhwc(gout)
-        gqkv = torch.empty_strided(qkv.shape, qkv.stride(), device=qkv.device, dtype=qkv.dtype)
-        check(lib.otvae_attn_bwd_scaled(ptr(qkv), ptr(out), ptr(lse), ptr(gout), ptr(aux), n, t, heads, c, scale, ptr(gqkv),
-                                        stream()), "otvae_attn_bwd")
-        return gqkv, None, None
+def _attention_op(qkv4: Tensor, heads: int, scale: Optional[float]) -> Tensor:
+    """``torch.ops.otvae.qkv_attention`` (ops.py) on a [N, 3*H*C, H, W] NHWC tensor: fused attention forward, its backward
+    registered with ``torch.library.register_autograd``.  Head widths 1 and 2 (the 32x32 and 16x16 blocks, 83 % of the
+    attention time): the forward pass also emits the per-query key moments from which the backward pass forms dq without
+    another pass over the keys."""
+    n, width, h, w = qkv4.shape
+    if width % (3 * heads) != 0:
+        raise ValueError(f"tensor width: {width} must be divisible by (3 * n_heads): {3 * heads}")
+    c = width // (3 * heads)
+    scale = 1.0 / c if scale is None else float(scale)  # 1/C = the two C^-1/2 factors of QKVAttention
+    need_aux = qkv4.requires_grad and torch.is_grad_enabled()
+    return torch.ops.otvae.qkv_attention(qkv4, heads, scale, need_aux)[0]
 
 
 def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:
@@ -442,8 +432,8 @@ def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:
     if qkv.dim() == 3:
         n, width, t = qkv.shape
         q4 = as_nhwc(qkv.unsqueeze(-1))
-        return _AttentionFn.apply(q4, n_heads, None).squeeze(-1)
-    return _AttentionFn.apply(as_nhwc(qkv), n_heads, None)
+        return _attention_op(q4, n_heads, None).squeeze(-1)
+    return _attention_op(as_nhwc(qkv), n_heads, None)
 
 
 # ------------------------------------------------------------------------------------------------ prior / loss
@@ -678,7 +668,7 @@ def mha_attention_tokens(qkv: Tensor, n_heads: int, dropout_p: float = 0.0, drop
         out, used = _AttentionDropoutFn.apply(tokens_as_nhwc(qkv), n_heads, 1.0 / math.sqrt(c), dropout_p, dropout_key, stream_id,
                                               causal)
         return (nhwc_as_tokens(out), used) if return_used else nhwc_as_tokens(out)
-    out = _AttentionFn.apply(tokens_as_nhwc(qkv), n_heads, 1.0 / math.sqrt(c))
+    out = _attention_op(as_nhwc(tokens_as_nhwc(qkv)), n_heads, 1.0 / math.sqrt(c))
     return nhwc_as_tokens(out)
 
 
@@ -704,33 +694,6 @@ def normal_fill_(out: Tensor, key: Tensor, stream_id: int = 0, advance: bool = T
 
 def normal_like(like: Tensor, key: Tensor, stream_id: int = 0) -> Tensor:
     return normal_fill_(torch.empty(like.shape, device=like.device, dtype=torch.float32), key, stream_id)
-
-
-class _GaussianPriorFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, h, eps, coeff):
-        lib = _lib.load()
-        b, c2, hh, ww = h.shape
-        d, s = c2 // 2, hh * ww
-        z = empty_nhwc(b, d, hh, ww, h)
-        loss = torch.empty(b, device=h.device, dtype=torch.float32)
-        check(lib.otvae_gaussian_prior_fwd(ptr(h), ptr(eps), b, s, d, float(coeff), ptr(z), ptr(loss), stream()),
-              "otvae_gaussian_prior_fwd")
-        ctx.save_for_backward(h, eps)
-        ctx.cfg = (b, s, d, float(coeff))
-        return z, loss
-
-    @staticmethod
-    def backward(ctx, gz, gloss):
-        lib = _lib.load()
-        h, eps = ctx.saved_tensors
-        b, s, d, coeff = ctx.cfg
-        gz = as_nhwc(gz) if gz is not None else None
-        gloss = gloss.contiguous() if gloss is not None else None
-        gh = torch.empty_strided(h.shape, h.stride(), device=h.device, dtype=h.dtype)
-        check(lib.otvae_gaussian_prior_bwd(ptr(h), ptr(eps), ptr(gz), ptr(gloss), b, s, d, coeff, ptr(gh), stream()),
-              "otvae_gaussian_prior_bwd")
-        return gh, None, None
 
 
 class _CondGaussianPriorFn(torch.autograd.Function):
@@ -777,7 +740,7 @@ def gaussian_prior(h: Tensor, eps: Tensor, coeff: float) -> Tuple[Tensor, Tensor
     """(z, coeff*KL[B]) for the re-parametrised diagonal Gaussian (reference prior/gaussian.py:63-96)."""
     _lib.require_cuda(h, "prior input")
     if h.dim() == 2:
-        z, loss = _GaussianPriorFn.apply(as_nhwc(h[:, :, None, None]), as_nhwc(eps[:, :, None, None]), coeff)
+        z, loss = torch.ops.otvae.gaussian_prior(as_nhwc(h[:, :, None, None]), as_nhwc(eps[:, :, None, None]), float(coeff))
         return z[:, :, 0, 0], loss
     if h.dim() == 3:  # tokens [B, 2S, D] (the ViT's embed tokens): mu = the first S tokens, log_var = the last S
         b, s2, d = h.shape
@@ -785,34 +748,7 @@ def gaussian_prior(h: Tensor, eps: Tensor, coeff: float) -> Tuple[Tensor, Tensor
         return z.reshape(b, s2 // 2, d), loss
     if h.dim() != 4:
         raise ValueError("GaussianPrior on the MI355X path expects [B, 2D], [B, 2S, D] or [B, 2D, H, W] with reparam_dim=1")
-    return _GaussianPriorFn.apply(as_nhwc(h), as_nhwc(eps), coeff)
-
-
-class _NelboFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, pred, target, prior_loss, chw):
-        lib = _lib.load()
-        b = pred.shape[0]
-        numel = pred.numel()
-        ws = torch.empty(lib.otvae_nelbo_ws(), device=pred.device, dtype=torch.float64)
-        out = torch.empty(3, device=pred.device, dtype=torch.float32)
-        check(lib.otvae_nelbo_fwd(ptr(pred), ptr(target), numel, ptr(prior_loss), b, float(chw), ptr(ws), ptr(out),
-                                  stream()), "otvae_nelbo_fwd")
-        ctx.save_for_backward(pred, target)
-        ctx.cfg = (b, numel, float(chw), prior_loss is not None)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        lib = _lib.load()
-        pred, target = ctx.saved_tensors
-        b, numel, chw, has_prior = ctx.cfg
-        gout = gout.contiguous()
-        gpred = torch.empty_strided(pred.shape, pred.stride(), device=pred.device, dtype=pred.dtype)
-        gprior = torch.empty(b, device=pred.device, dtype=torch.float32) if has_prior else None
-        check(lib.otvae_nelbo_bwd(ptr(pred), ptr(target), numel, b, chw, ptr(gout), ptr(gpred), ptr(gprior), stream()),
-              "otvae_nelbo_bwd")
-        return gpred, None, gprior, None
+    return torch.ops.otvae.gaussian_prior(as_nhwc(h), as_nhwc(eps), float(coeff))
 
 
 def nelbo_loss(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor]) -> Tensor:
@@ -824,4 +760,19 @@ def nelbo_loss(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor]) -> Te
     chw = 1
     for s in target.shape[1:]:
         chw *= s
-    return _NelboFn.apply(pred, target, prior_loss.contiguous() if prior_loss is not None else None, chw)
+    return torch.ops.otvae.nelbo_loss(pred, target, prior_loss.contiguous() if prior_loss is not None else None, float(chw))
+
+
+def conv_bn_act(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
+                beta: Optional[Tensor] = None, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
+                num_batches_tracked: Optional[Tensor] = None, residual: Optional[Tensor] = None, stride: int = 1, pad: int = 0,
+                up: int = 1, relu: bool = True, training: bool = True) -> Tensor:
+    """One ConvLayer (reference networks/cnn.py:183-192: BatchNorm -> ReLU -> nearest x``up`` -> conv (+ bias, + residual)) through
+    the registered custom operators ``torch.ops.otvae.bn_batch_stats`` + ``torch.ops.otvae.conv_bn_act`` (ops.py)."""
+    mean = invstd = scale = shift = None
+    if gamma is not None:
+        with torch.no_grad():
+            mean, invstd, scale, shift = torch.ops.otvae.bn_batch_stats(x, gamma, beta, running_mean, running_var,
+                                                                        num_batches_tracked, training)
+    return torch.ops.otvae.conv_bn_act(x, weight, bias, gamma, beta, mean, invstd, scale, shift, residual, stride, pad, up, relu,
+                                       training)

@@ -14,64 +14,31 @@ from typing import Optional
 import torch
 from torch import Tensor
 
-from .. import _lib
-from .._lib import check, ptr, stream
-from ..ot import matrix_utils as MU
+from .. import ops as _ops  # noqa: F401  (registers torch.ops.otvae.*)
 from .base import Prior
 
 __all__ = ["GaussianW2Prior"]
 
 
 class _W2PriorFn(torch.autograd.Function):
+    """``torch.ops.otvae.gaussian_w2_prior`` / ``..._backward`` (ops.py) plus one thing an operator cannot do: the latents leave
+    through this node too (an alias of z, see prior/sinkhorn.py), so the decoder's gradient is added inside the backward kernel."""
+
     @staticmethod
     def forward(ctx, z, mut, covt, rt, scale):
-        lib = _lib.load()
-        _lib.require_cuda(z, "latents")
-        if z.dtype not in (torch.float32, torch.float64):
-            raise TypeError("GaussianW2Prior takes float32 or float64 latents")
-        z = z.contiguous()
-        b, d = z.shape
-        dev = z.device
-        f64 = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float64)  # noqa: E731
-        # batch statistics (fp64 sums) -> mean, covariance
-        n, sx, sxx = f64(1), f64(1, d), f64(1, d, d)
-        ws = torch.empty(max(8, lib.otvae_gauss_stats_ws(1, b, d, 0)), device=dev, dtype=torch.uint8)
-        check(lib.otvae_gauss_stats(0 if z.dtype == torch.float32 else 1, ptr(z), 1, b, d, 0, 0, -1.0, ptr(ws), ptr(n), ptr(sx),
-                                    ptr(sxx), stream()), "otvae_gauss_stats")
-        mu, cov = f64(1, d), f64(1, d, d)
-        check(lib.otvae_mean_cov(ptr(n), ptr(sx), ptr(sxx), 1, d, 0, ptr(mu), ptr(cov), stream()), "otvae_mean_cov")
-        # M = covt^1/2 cov covt^1/2 (M = cov for the standard-normal target), its spectrum
-        m = cov if rt is None else MU.matmul64(MU.matmul64(rt, cov), rt)
-        lam, vt = f64(1, d), f64(1, d, d)
-        ews = torch.empty(lib.otvae_eigh_ws(1, d), device=dev, dtype=torch.uint8)
-        check(lib.otvae_eigh_fn(ptr(m), 1, d, 3, ptr(vt), ptr(lam), ptr(ews), stream()), "otvae_eigh_fn")
-        loss = torch.empty(b, device=dev, dtype=torch.float32)
-        q = f64(d, d)
-        check(lib.otvae_w2_prior_tail(ptr(mu), ptr(mut), ptr(cov), ptr(covt), ptr(lam), ptr(vt), d, float(scale), b, ptr(loss),
-                                      ptr(q), stream()), "otvae_w2_prior_tail")
+        loss, mu, q = torch.ops.otvae.gaussian_w2_prior(z, mut, covt, rt, float(scale))
         ctx.save_for_backward(z, mu, q)
         ctx.target = (mut, rt)
         ctx.scale = float(scale)
-        # the latents leave through this node too (see prior/sinkhorn.py): the decoder's gradient is added inside the backward kernel
         return z.view_as(z), loss
 
     @staticmethod
     def backward(ctx, gz_out, g):
-        lib = _lib.load()
         z, mu, q = ctx.saved_tensors
         mut, rt = ctx.target
         if g is None:
             return gz_out, None, None, None, None
-        b, d = z.shape
-        w = MU.matmul64(q, q, trans_a=True)                          # M^-1/2
-        if rt is not None:
-            w = MU.matmul64(MU.matmul64(rt, w), rt)                  # covt^1/2 M^-1/2 covt^1/2
-        gz = torch.empty_like(z)
-        gadd = gz_out.contiguous() if gz_out is not None else None
-        check(lib.otvae_w2_prior_bwd(0 if z.dtype == torch.float32 else 1, ptr(z), b, d, ptr(mu), ptr(mut), ptr(w),
-                                     ptr(g.float().contiguous()), g.numel(), ctx.scale, ptr(gadd), ptr(gz), stream()),
-              "otvae_w2_prior_bwd")
-        return gz, None, None, None, None
+        return torch.ops.otvae.gaussian_w2_prior_backward(g, gz_out, z, mu, q, mut, rt, ctx.scale), None, None, None, None
 
 
 class GaussianW2Prior(Prior):

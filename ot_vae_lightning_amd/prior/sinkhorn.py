@@ -18,28 +18,13 @@ __all__ = ["SinkhornPrior"]
 class _SinkhornLossFn(torch.autograd.Function):
     """loss = sum_ij C_ij pi_ij with C_ij = |z_i - y_j|^2 and pi the (detached) entropic plan: by the envelope
     argument the plan is treated as a constant, so d loss / d z_i = 2 sum_j pi_ij (z_i - y_j).
-    Forward = ``otvae_sinkhorn_prior_fwd`` (cost tiles + tile maxima on the matrix cores, the solve on C / max C with uniform
+    Forward = ``torch.ops.otvae.sinkhorn_prior`` -> ``otvae_sinkhorn_prior_fwd`` (cost tiles + tile maxima on the matrix cores, the solve on C / max C with uniform
     marginals, the read-out), backward = ``otvae_ot_cost_grad`` (plan x samples on the matrix cores): no library GEMM and no
     ATen kernel on either side."""
 
     @staticmethod
     def forward(ctx, z, y, reg, max_iter, threshold, scale):
-        lib = _lib.load()
-        _lib.require_cuda(z, "latents")
-        if z.dtype not in (torch.float32, torch.float64):
-            raise TypeError("SinkhornPrior computes in float32 or float64")
-        z, y = z.contiguous(), y.to(z.dtype).contiguous()
-        (n, d), m = z.shape, y.shape[0]
-        if y.shape[1] != d:
-            raise ValueError(f"prior samples have {y.shape[1]} dimensions, latents {d}")
-        dt = 0 if z.dtype == torch.float32 else 1
-        new = lambda *shape: torch.empty(shape, device=z.device, dtype=z.dtype)  # noqa: E731
-        C, pi, u, v, cost, cmax = new(n, m), new(n, m), new(n), new(m), new(n), new(1)   # cost: one entry per sample
-        ws = torch.empty(lib.otvae_sinkhorn_prior_ws(dt, n, m), device=z.device, dtype=torch.uint8)
-        iters = torch.empty(1, device=z.device, dtype=torch.int32)
-        check(lib.otvae_sinkhorn_prior_fwd(dt, ptr(z), ptr(y), n, m, d, float(reg), int(max_iter), float(threshold), float(scale), n, ptr(ws), ptr(C),
-                                           ptr(pi), ptr(u), ptr(v), ptr(cost), ptr(cmax), ptr(iters), stream()),
-              "otvae_sinkhorn_prior_fwd")
+        cost, pi, iters = torch.ops.otvae.sinkhorn_prior(z, y, float(reg), int(max_iter), float(threshold), float(scale))
         ctx.save_for_backward(z, y, pi)
         ctx.scale = float(scale)
         ctx.mark_non_differentiable(iters)
@@ -51,15 +36,9 @@ class _SinkhornLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gz_out, g, _giters):
         z, y, pi = ctx.saved_tensors
-        n, d = z.shape
         if g is None:  # only the latents were used downstream
             return gz_out, None, None, None, None, None
-        gz = torch.empty_like(z)
-        gadd = gz_out.contiguous() if gz_out is not None else None
-        check(_lib.load().otvae_ot_cost_grad(0 if z.dtype == torch.float32 else 1, ptr(z), ptr(y), ptr(pi), ptr(g.contiguous()),
-                                             g.numel(), ctx.scale, ptr(gadd), n, y.shape[0], d, ptr(gz), stream()),
-              "otvae_ot_cost_grad")
-        return gz, None, None, None, None, None
+        return torch.ops.otvae.sinkhorn_prior_backward(g, gz_out, z, y, pi, ctx.scale), None, None, None, None, None
 
 
 class SinkhornPrior(Prior):

@@ -222,10 +222,15 @@ def test_gaussian_w2_prior_vs_reference_autograd(A, shape):
         z = z0.clone().cuda().reshape(B, D, 1, 1).requires_grad_(True)
         zz, loss, _ = prior(z, step=0)
         assert zz.shape == z.shape and loss.shape == (B,)
-        extra = torch.sin(torch.arange(B * D, dtype=torch.float32).reshape(B, D, 1, 1)).cuda()     # a decoder-side gradient
+        loss.mean().backward(retain_graph=True)
+        gz = z.grad.flatten(1).cpu() / 0.25
+        # a decoder-side gradient reaching z through the prior's identity output is added inside the backward kernel
+        extra = 1e-3 * torch.sin(torch.arange(B * D, dtype=torch.float32).reshape(B, D, 1, 1)).cuda()
+        pure = z.grad.clone()
+        z.grad = None
         (loss.mean() + (zz * extra).sum()).backward()
+        rep.check(f"{tag}: decoder-side gradient folded in", z.grad - pure, extra, tol=1e-5)
         rep.check(f"{tag}: loss", loss[0] / 0.25, torch.from_numpy(G[f"{k}/loss"]).float(), tol=1e-4)
-        gz = (z.grad - extra).flatten(1).cpu() / 0.25
         if B <= 256:
             rep.check(f"{tag}: dL/dz", gz, torch.from_numpy(G[f"{k}/gz"]), tol=1e-4)
         else:
