@@ -88,7 +88,22 @@ def time_sinkhorn(A, n=1024, d=128, iters=50, reps=20):
             "l2_resident_read_gbytes_per_s": round(2.0 * n * n * 4 * iters / (ms * 1e-3) / 1e9, 1), "ot_cost": float(cost)}
 
 
-def cpu_baseline(A, batch=250, steps=3, warmup=1):
+def time_eager_route(A, workload, pool, steps=20, warmup=5):
+    """The same step WITHOUT the hipGraph: every operator launched from Python through torch.ops.otvae / the C ABI (what a
+    Lightning loop that calls ``training_step`` + ``loss.backward()`` + the fused Adam pays per step).  Host-bound."""
+    model = build_model(A, seed=1, workload=workload).cuda().train()
+    tr = A.HipTrainer(model, batch_shape=tuple(pool[0].shape), use_graph=False)
+    for i in range(warmup):
+        tr.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def cpu_baseline(A, batch=250, steps=5, warmup=2):
     """The oracle on the host cores: same step definition (fwd + bwd + Adam), bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import otvae_oracle as O
@@ -120,9 +135,9 @@ def cpu_baseline(A, batch=250, steps=3, warmup=1):
                       f"{torch.__version__} CPU ops, oracle/otvae_oracle.py"}
 
 
-def parity_check(A, batch=64):
-    """GPU step vs oracle on identical weights / batch / eps: relative error of [total, recon, prior(KL)] and of the
-    Sinkhorn OT loss (256x256, eps 0.05, 50 iterations)."""
+def parity_check(A, batch=PER_GPU_BATCH):
+    """GPU step vs oracle on identical weights / batch / eps AT THE BENCHED BATCH: relative error of [total, recon, prior(KL)],
+    of the reconstructions, and of the Sinkhorn OT loss (1024 x 1024 plan, eps 0.05, 50 iterations)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import otvae_oracle as O
     from detfill import mnist_like, normal
@@ -141,7 +156,7 @@ def parity_check(A, batch=64):
     got = model._last_out3.cpu()
     rel = ((got - want).abs() / want.abs()).tolist()
     rec = ((art["preds"].cpu() - r["preds"]).abs().max() / r["preds"].abs().max()).item()
-    z, p = normal((256, 128), 11), normal((256, 128), 12)
+    z, p = normal((batch, 128), 11), normal((batch, 128), 12)
     ot_cpu = O.sinkhorn_ot_loss(z, p, reg=0.05, max_iter=50, threshold=0.0).item()
     with torch.no_grad():
         ot_gpu = A.SinkhornPrior(reg=0.05, max_iter=50, threshold=0.0)(z.cuda(), step=0, prior_samples=p.cuda())[1][0].item()
@@ -201,18 +216,137 @@ def time_dominant_kernel(A, trainer, iters=30):
             "pmc_traffic_bytes": pmc_traffic("attn_bwd_kernel<1, 4, true>")}
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA peak == fp32 vector peak
+GEOM_FIELDS = ("N", "Hs", "Ws", "Cs", "up", "Ho", "Wo", "Cn", "KH", "KW", "stride", "pad")
+
+
+def _job_algorithmic(job):
+    """(bytes, flops) one conv job must move / compute at least (fp32; every operand read once, every result written once;
+    the weight-gradient's split-K partials and the BatchNorm partial sums are NOT algorithmic traffic)."""
+    g = dict(zip(GEOM_FIELDS, job["geom"]))
+    x = g["N"] * g["Hs"] * g["Ws"] * g["Cs"]
+    y = g["N"] * g["Ho"] * g["Wo"] * g["Cn"]
+    w = g["KH"] * g["KW"] * g["Cs"] * g["Cn"]
+    flops = 2 * y * g["KH"] * g["KW"] * g["Cs"]
+    if job["kind"] == 0:      # forward: x, w -> y
+        return 4 * (x + w + y), flops
+    if job["kind"] == 1:      # data gradient: gy, w (, x for the ReLU mask / BatchNorm sums) -> gv
+        return 4 * (y + w + x + (x if (job["relu"] or job["bn_sums"]) else 0)), flops
+    return 4 * (x + y + w), flops   # weight gradient: x, gy -> gw
+
+
+def time_largest_aggregate_kernel(A, workload, iters=10):
+    """The kernel with the largest aggregate share of the step (profiles/: ``conv_jobs_kernel<true>``, the packed data- and
+    weight-gradient launches of the deep layers, 24 launches = 16 % of the step): the step's own otvae_conv_multi calls that
+    end in that kernel are recorded from one eager step (functional.JOB_TRACE + otvae_conv_multi_last), re-issued on tensors
+    of the same shapes through the C ABI into one hipGraph, and timed with HIP events on the launch stream."""
+    import ctypes as C
+    from ot_vae_lightning_amd import functional as HF
+    from ot_vae_lightning_amd import _lib as L
+    from ot_vae_lightning_amd.utils.synthetic import mnist_like
+    lib = L.load()
+    model = build_model(A, seed=2, workload=workload).cuda().train()
+    tr = A.HipTrainer(model, batch_shape=(PER_GPU_BATCH, 1, 32, 32), use_graph=False)
+    x = mnist_like(PER_GPU_BATCH, seed=77).cuda()
+    tr.step(x)
+    HF.JOB_TRACE = []
+    tr.step(x)
+    torch.cuda.synchronize()
+    trace, HF.JOB_TRACE = HF.JOB_TRACE, None
+    calls = [c for c in trace if c["uniform_tap"] == 1 and c["packed_mask"]]
+    if not calls:
+        return None
+    dev = "cuda"
+    keep, launches = [], []
+    tot_bytes = tot_flops = 0
+    for c in calls:
+        jobs = [j for i, j in enumerate(c["jobs"]) if c["packed_mask"] >> i & 1]
+        arr = (L.ConvJob * len(jobs))()
+        for jb, j in zip(arr, jobs):
+            g = L.ConvGeom(*j["geom"])
+            gd = dict(zip(GEOM_FIELDS, j["geom"]))
+            t_x = torch.randn(gd["N"], gd["Hs"], gd["Ws"], gd["Cs"], device=dev)
+            t_y = torch.randn(gd["N"], gd["Ho"], gd["Wo"], gd["Cn"], device=dev)
+            t_w = torch.randn(gd["KH"] * gd["KW"] * gd["Cs"] * gd["Cn"], device=dev) * 0.05
+            vec = lambda: torch.rand(gd["Cs"], device=dev) + 0.5  # noqa: E731
+            jb.kind, jb.relu, jb.has_bias, jb.geom = j["kind"], j["relu"], j["has_bias"], g
+            held = [t_x, t_y, t_w]
+            if j["has_norm"]:
+                sc, sh = vec(), vec()
+                jb.scale, jb.shift = L.ptr(sc), L.ptr(sh)
+                held += [sc, sh]
+            if j["kind"] == L.JOB_FWD:
+                jb.x, jb.w, jb.y = L.ptr(t_x), L.ptr(t_w), L.ptr(t_y)
+            elif j["kind"] == L.JOB_BWD_DATA:
+                gv = torch.empty_like(t_x)
+                jb.gy, jb.w, jb.x, jb.gv = L.ptr(t_y), L.ptr(t_w), L.ptr(t_x), L.ptr(gv)
+                held.append(gv)
+                if j["bn_sums"]:
+                    p_d, cp = C.c_int(0), C.c_int(0)
+                    L.check(lib.otvae_conv_bwd_data_ws(C.byref(g), C.byref(p_d), C.byref(cp)), "otvae_conv_bwd_data_ws")
+                    mean, invstd = vec(), vec()
+                    part = torch.empty((p_d.value, 2, cp.value), device=dev, dtype=torch.float64)
+                    jb.mean, jb.invstd, jb.bn_partial = L.ptr(mean), L.ptr(invstd), L.ptr(part)
+                    held += [mean, invstd, part]
+            else:
+                p_w = C.c_int(0)
+                L.check(lib.otvae_conv_bwd_weight_ws(C.byref(g), j["has_bias"], C.byref(p_w)), "otvae_conv_bwd_weight_ws")
+                kk = gd["KH"] * gd["KW"] * gd["Cs"] + (1 if j["has_bias"] else 0)
+                wpart = torch.empty((p_w.value, kk, gd["Cn"]), device=dev)
+                gw, gb = torch.empty_like(t_w), torch.empty(gd["Cn"], device=dev)
+                jb.x, jb.gy, jb.wpartial, jb.gw, jb.gb = L.ptr(t_x), L.ptr(t_y), L.ptr(wpart), L.ptr(gw), L.ptr(gb)
+                jb.defer_reduce = L.DEFER_SPARSE  # as in the step: the partials are reduced by the step's batched reduction
+                held += [wpart, gw, gb]
+            keep.append(held)
+            by, fl = _job_algorithmic(j)
+            tot_bytes += by
+            tot_flops += fl
+        launches.append((arr, len(jobs)))
+    mask, ut = C.c_uint32(0), C.c_int(0)
+
+    def issue(verify=False):
+        for arr, n in launches:
+            L.check(lib.otvae_conv_multi(n, arr, L.stream()), "otvae_conv_multi")
+            if verify:  # every re-issued call must end in exactly the kernel being measured
+                L.check(lib.otvae_conv_multi_last(C.byref(mask), C.byref(ut)), "otvae_conv_multi_last")
+                assert ut.value == 1 and bin(mask.value).count("1") == n, (ut.value, mask.value, n)
+
+    issue(verify=True)
+    issue()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        for _ in range(iters):
+            issue()
+    for _ in range(5):
+        graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    n_launch = len(launches)
+    ms = e0.elapsed_time(e1) / (4 * iters * n_launch)
+    return {"kernel": "conv_jobs_kernel<true> (packed data + weight gradients of one ConvBlock stage, implicit GEMM, fp32 MFMA 16x16x4)",
+            "launches_per_step": n_launch, "ms": ms, "alg_bytes": tot_bytes / n_launch, "alg_flops": tot_flops / n_launch,
+            "pmc_traffic_bytes": pmc_traffic("conv_jobs_kernel<true>")}
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/r01_pmc_per_kernel.csv, written by
-    tools/summarize_profiles.py --pmc from three separate rocprofv3 --pmc passes of this same command: FETCH_SIZE with
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/r02_pmc_per_kernel.csv, else round 1's;
+    written by tools/summarize_profiles.py --pmc from separate rocprofv3 --pmc passes of this same command: FETCH_SIZE with
     the x2 gfx950 correction + WRITE_SIZE, KiB -> bytes, as MI355X_MICROARCH.md prescribes); None if not collected."""
     import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_per_kernel.csv")
-    try:
-        for row in csv.reader(open(path)):
-            if row and row[0].strip().endswith(kernel):
-                return (2.0 * float(row[2]) + float(row[4])) * 1024.0
-    except OSError:
-        pass
+    for tag in ("r02", "r01"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{tag}_pmc_per_kernel.csv")
+        try:
+            for row in csv.reader(open(path)):
+                if row and row[0].strip().endswith(kernel):
+                    return (2.0 * float(row[2]) + float(row[4])) * 1024.0
+        except OSError:
+            continue
     return None
 
 
@@ -286,8 +420,8 @@ def main():
 
     if rank == 0:
         ips = world * B * args.steps / dt
-        dom = time_dominant_kernel(A, trainer)
-        achieved = dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9
+        agg = time_largest_aggregate_kernel(A, args.workload)
+        longest = time_dominant_kernel(A, trainer)
         line = {
             "metric": "training images/sec (whole node) + OT-loss rel-err vs CPU ref",
             "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -309,23 +443,36 @@ def main():
                               "frac_of_hbm_peak": round(ips / world * ALG_BYTES_PER_IMAGE_FWD_BWD / 1e9 / HBM_PEAK_GBS, 5),
                               "alg_tflops": round(ips / world * ALG_FLOP_PER_IMAGE_FWD_BWD / 1e12, 3),
                               "frac_of_fp32_peak": round(ips / world * ALG_FLOP_PER_IMAGE_FWD_BWD / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)},
-            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": dom["pmc_traffic_bytes"], "avg_launch_ms": round(dom["ms"], 4),
-                         "note": "dominant kernel of the step is exp/VALU-issue bound, not HBM/MFMA bound: "
-                                 "%.2f T (query,key) pair evaluations/s of %.2f T/s the vector issue port allows "
-                                 "(per 2 pairs: 2 v_exp_f32 at 8 cycles + 5 packed FMA/MUL at 4..5, tools/probe/mfma4x4.hip)"
-                                 % (dom["pair_evals"] / dom["ms"] / 1e9, ISSUE_BOUND_TPAIRS)},
         }
-        # the same kernel against the bound that actually holds it: vector-instruction issue (2 v_exp_f32 at 8 cycles + 5
-        # packed FMA/MUL at 4 per 2 (query, key) pairs; 1024 SIMDs at the 2.4 GHz peak clock)
-        tp = dom["pair_evals"] / dom["ms"] / 1e9
-        line["roofline_issue"] = {"bound": "valu_issue", "kernel": dom["kernel"], "achieved": round(tp, 3),
+        if agg is not None:
+            gbs = agg["alg_bytes"] / (agg["ms"] * 1e-3) / 1e9
+            tfl = agg["alg_flops"] / (agg["ms"] * 1e-3) / 1e12
+            # The kernel with the largest aggregate share of the step.  Its launches average ~10 MB and ~0.7 GFLOP of
+            # algorithmic work: ~67 FLOP/B against a ridge at 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B, so the fp32 MFMA roof is the
+            # one that bounds it (at that peak a launch would take ~4.5 us, at the HBM peak ~1.3 us); the HBM figures ride along.
+            t_mfma, t_hbm = agg["alg_flops"] / (FP32_MFMA_PEAK_TFLOPS * 1e12), agg["alg_bytes"] / (HBM_PEAK_GBS * 1e9)
+            hbm = {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)}
+            mfma = {"achieved": round(tfl, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / FP32_MFMA_PEAK_TFLOPS, 5)}
+            main_roof, other = (("mfma", mfma), ("hbm", hbm)) if t_mfma >= t_hbm else (("hbm", hbm), ("mfma", mfma))
+            line["roofline"] = {"bound": main_roof[0], "kernel": agg["kernel"], **main_roof[1], "traffic": agg["pmc_traffic_bytes"],
+                                "avg_launch_ms": round(agg["ms"], 5), "launches_per_step": agg["launches_per_step"],
+                                "alg_bytes_per_launch": round(agg["alg_bytes"]), "alg_flops_per_launch": round(agg["alg_flops"]),
+                                other[0]: other[1]}
+        # the longest single launch of the step (attention backward of the decoder's last block) against HBM and against the
+        # bound that actually holds it: vector-instruction issue (2 v_exp_f32 at 8 cycles + 5 packed FMA/MUL at 4 per 2
+        # (query, key) pairs; 1024 SIMDs at the 2.4 GHz peak clock)
+        achieved = longest["alg_bytes"] / (longest["ms"] * 1e-3) / 1e9
+        tp = longest["pair_evals"] / longest["ms"] / 1e9
+        line["roofline_longest_launch"] = {"bound": "hbm", "kernel": longest["kernel"], "achieved": round(achieved, 2),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                           "traffic": longest["pmc_traffic_bytes"], "avg_launch_ms": round(longest["ms"], 4)}
+        line["roofline_issue"] = {"bound": "valu_issue", "kernel": longest["kernel"], "achieved": round(tp, 3),
                                   "peak": round(ISSUE_BOUND_TPAIRS, 3), "unit": "T (query,key) pairs/s",
                                   "frac": round(tp / ISSUE_BOUND_TPAIRS, 4)}
         if args.workload == "sinkhorn":
             line["sinkhorn"] = time_sinkhorn(A)
         if world == 1:
+            line["eager_ms_per_step"] = round(time_eager_route(A, args.workload, pool), 4)
             try:
                 line["parity"] = parity_check(A)
             except Exception as e:  # noqa: BLE001

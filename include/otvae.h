@@ -145,6 +145,10 @@ typedef struct otvae_conv_job {
     float* gb;
 } otvae_conv_job;
 int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream);
+/* Introspection for measurement (bench.py's per-kernel roofline): what the calling thread's last otvae_conv_multi did --
+ * bit i of packed_mask: job i ran inside one packed conv_jobs_kernel launch; uniform_tap: that launch's template flavour
+ * (1 = conv_jobs_kernel<true>), -1 if nothing was packed. */
+int otvae_conv_multi_last(unsigned* packed_mask, int* uniform_tap);
 
 /* ---- QKVAttention (networks/nets_utils.py:63-82) ---------------------------------------------------------- */
 /* qkv [N][T][3*H*C] (channel = which*H*C + h*C + c) -> out [N][T][H*C]; lse [N][H][T] saved for backward.

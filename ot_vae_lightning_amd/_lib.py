@@ -61,6 +61,7 @@ SIGNATURES = {
     "otvae_conv_dead_taps": (i32, [pg, pu32]),
     "otvae_gmm_diag_energy": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "otvae_conv_multi": (i32, [i32, pj, vp]),
+    "otvae_conv_multi_last": (i32, [pu32, pi32]),
     "otvae_attn_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "otvae_attn_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "otvae_attn_fwd_scaled": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),

@@ -1576,9 +1576,22 @@ static int run_single_job(const otvae_conv_job& jb, void* stream) {
     }
 }
 
+// what the calling thread's last otvae_conv_multi did with its jobs (bit i: job i ran inside a packed conv_jobs_kernel launch)
+static thread_local unsigned g_multi_packed_mask = 0;
+static thread_local int g_multi_packed_ut = -1;
+
+extern "C" int otvae_conv_multi_last(unsigned* packed_mask, int* uniform_tap) {
+    OTVAE_REQUIRE(packed_mask && uniform_tap, "otvae_conv_multi_last: NULL argument");
+    *packed_mask = g_multi_packed_mask;
+    *uniform_tap = g_multi_packed_ut;
+    return OTVAE_OK;
+}
+
 extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream) {
     OTVAE_REQUIRE(n > 0 && jobs, "otvae_conv_multi: no jobs");
     hipStream_t st = (hipStream_t)stream;
+    g_multi_packed_mask = 0;
+    g_multi_packed_ut = -1;
     DevJobs pack = {};
     size_t smem = 0;
     int nblocks = 0;
@@ -1599,6 +1612,8 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
         else
             conv_jobs_kernel<false><<<nblocks, 256, smem, st>>>(pack);
         OTVAE_CHECK_LAUNCH("otvae_conv_multi");
+        for (int i = 0; i < pack.n; ++i) g_multi_packed_mask |= 1u << packed_idx[i];
+        g_multi_packed_ut = pack_ut == 1 ? 1 : 0;
         for (int i = 0; i < pack.n; ++i) {  // immediate reductions of the packed weight-gradient jobs
             const otvae_conv_job& jb = jobs[packed_idx[i]];
             if (jb.kind != OTVAE_JOB_BWD_WEIGHT || jb.defer_reduce) continue;

@@ -210,6 +210,22 @@ class _ConvBNFn(torch.autograd.Function):
         return tuple(out)
 
 
+JOB_TRACE: Optional[list] = None  # measurement hook (bench.py): when a list, every otvae_conv_multi call appends its jobs here
+
+
+def _trace_jobs(jobs, njobs):
+    lib = _lib.load()
+    mask, ut = C.c_uint32(0), C.c_int(0)
+    check(lib.otvae_conv_multi_last(C.byref(mask), C.byref(ut)), "otvae_conv_multi_last")
+    desc = []
+    for i in range(njobs):
+        jb = jobs[i]
+        g = jb.geom
+        desc.append(dict(kind=int(jb.kind), relu=int(jb.relu), has_bias=int(jb.has_bias), has_norm=bool(jb.scale), bn_sums=bool(jb.mean),
+                         geom=tuple(int(getattr(g, f)) for f, _ in ConvGeom._fields_)))
+    JOB_TRACE.append(dict(jobs=desc, packed_mask=int(mask.value), uniform_tap=int(ut.value)))
+
+
 def conv_forward_launch(x, specs, stats, tensors):
     """The launches of 1 or 2 ConvLayer branches reading the same x (one ``otvae_conv_multi`` call).  ``tensors`` holds
     (weight, bias, gamma, beta, residual) per branch.  Returns (outputs, geometries, per-output statistics partials)."""
@@ -241,6 +257,8 @@ def conv_forward_launch(x, specs, stats, tensors):
         out_stats.append(st)
     # both branches of a ConvBlock read the same x and are independent: one launch (otvae_conv_multi)
     check(lib.otvae_conv_multi(nbr, jobs, stream()), "otvae_conv_multi(forward)")
+    if JOB_TRACE is not None:
+        _trace_jobs(jobs, nbr)
     return outs, geoms, out_stats
 
 
@@ -325,6 +343,8 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
             keep.append(wd)
         per_branch.append((gw, gb, gv, part, gy if sp.has_residual else None))
     check(lib.otvae_conv_multi(njobs, jobs, stream()), "otvae_conv_multi(backward)")
+    if JOB_TRACE is not None:
+        _trace_jobs(jobs, njobs)
     # --- BatchNorm backward over the branches that have one
     bn_idx = [b for b, sp in enumerate(specs) if sp.has_norm]
     dgam = {b: None for b in range(nbr)}
