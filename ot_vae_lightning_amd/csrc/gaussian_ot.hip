@@ -169,9 +169,15 @@ extern "C" int otvae_mean_cov(const double* n_obs, const double* sum_x, const do
 
 static int eigb_dp(int D) { return (D + 2 * EIGB - 1) / (2 * EIGB) * (2 * EIGB); }
 
+extern "C" int64_t otvae_eigh_onesided_ws(int nb, int D);
+int eigh_onesided(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, hipStream_t st);  // eigh_onesided.hip
+
 extern "C" int64_t otvae_eigh_ws(int nb, int D) {
     if (nb <= 0 || D <= 0) return -1;
-    if (D <= EIGH_MAX_D) return (int64_t)nb * D * D * (int64_t)sizeof(double);
+    if (D <= EIGH_MAX_D) {  // whichever of the two small-matrix solvers runs (OTVAE_EIGH_TWOSIDED=1 selects the first generation)
+        const int64_t two_sided = (int64_t)nb * D * D * (int64_t)sizeof(double), one_sided = otvae_eigh_onesided_ws(nb, D);
+        return two_sided > one_sided ? two_sided : one_sided;
+    }
     // block driver (one matrix at a time): Aw[Dp][Dp], Vt[Dp][Dp], S and U [Dp/32][32][32], sub-eigenvalues, dense
     // D x D copies for the f(A) product, convergence flag
     const int64_t Dp = eigb_dp(D), np = Dp / (2 * EIGB);
@@ -466,6 +472,7 @@ extern "C" int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out
     OTVAE_REQUIRE(fn >= 0 && fn <= 3, "otvae_eigh_fn: fn must be 0, 1, 2 or 3");
     OTVAE_REQUIRE(fn == 0 || out, "otvae_eigh_fn: out missing");
     if (D > EIGH_MAX_D) return eigh_block(A, nb, D, fn, out, eigvals, (double*)ws, (hipStream_t)stream);
+    if (!getenv("OTVAE_EIGH_TWOSIDED")) return eigh_onesided(A, nb, D, fn, out, eigvals, ws, (hipStream_t)stream);
     const size_t lds = eigh_lds_bytes(D);
     if (lds > 65536 && lds > g_eigh_lds_set) {
         if (hipFuncSetAttribute((const void*)eigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {

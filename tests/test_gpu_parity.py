@@ -481,6 +481,43 @@ def test_block_jacobi_eigh_large_D(A, D):
     rep.finish()
 
 
+@pytest.mark.parametrize("solver", ["one_sided", "two_sided"])
+def test_small_eigh_solvers_vs_lapack(A, solver, monkeypatch):
+    """The D <= 128 eigensolvers (one-sided Hestenes Jacobi with replayed rotations, the default; the first-generation two-sided
+    Jacobi behind OTVAE_EIGH_TWOSIDED=1) against torch.linalg.eigh on the CPU: covariance-like, indefinite, rank-deficient,
+    diagonal, identity and 1 x 1 matrices, odd sizes, batches, garbage in the strict upper triangle."""
+    from ot_vae_lightning_amd.ot import matrix_utils as MU
+    if solver == "two_sided":
+        monkeypatch.setenv("OTVAE_EIGH_TWOSIDED", "1")
+    rep = Report(f"small eigh ({solver}) vs torch.linalg.eigh (CPU, fp64)")
+    g = torch.Generator().manual_seed(77)
+    for D in (1, 2, 3, 8, 17, 33, 64, 100, 127, 128):
+        x = torch.randn(4, 3 * D + 2, D, generator=g, dtype=torch.float64) * torch.linspace(0.2, 3.0, D, dtype=torch.float64)
+        cov = x.transpose(-1, -2) @ x / x.shape[-2]
+        sym = torch.randn(4, D, D, generator=g, dtype=torch.float64)
+        sym = sym + sym.transpose(-1, -2)                                       # indefinite
+        low = x[:, : max(1, D // 2)].transpose(-1, -2) @ x[:, : max(1, D // 2)]      # rank-deficient (zero eigenvalues)
+        for name, m in (("cov", cov), ("indefinite", sym), ("rank-deficient", low), ("identity", torch.eye(D, dtype=torch.float64).expand(2, D, D)),
+                        ("diagonal", torch.diag_embed(torch.linspace(-1.0, 2.0, D, dtype=torch.float64)).expand(2, D, D))):
+            lam, vec = torch.linalg.eigh(m)
+            ev, vt = MU.eigh_vectors(m.cuda())
+            ev, vt = ev.cpu(), vt.cpu()
+            scale = lam.abs().max().clamp(min=1e-300)
+            assert float((torch.sort(ev, dim=-1)[0] - lam).abs().max() / scale) < 1e-11, (D, name)
+            recon = vt.transpose(-1, -2) @ (ev.unsqueeze(-1) * vt)               # V diag(lambda) V^T
+            assert float((recon - m).abs().max() / scale) < 1e-11, (D, name, "reconstruction")
+            eye = torch.eye(D, dtype=torch.float64)
+            assert float((vt @ vt.transpose(-1, -2) - eye).abs().max()) < 1e-11, (D, name, "orthonormality")
+        want = (vec_ := torch.linalg.eigh(cov))[1] @ torch.diag_embed(vec_[0].sqrt()) @ vec_[1].transpose(-1, -2)
+        rep.check(f"D={D}: sqrtm", MU.sqrtm(cov.cuda()), want, tol=1e-11)
+        rep.check(f"D={D}: invsqrtm", MU.invsqrtm(cov.cuda()), torch.linalg.inv(want), tol=1e-9)
+        rep.check(f"D={D}: min_eig (indefinite)", MU.min_eig(sym.cuda()), torch.linalg.eigh(sym)[0][..., 0], tol=1e-11)
+        junk = cov.clone()
+        junk[:, torch.triu(torch.ones(D, D, dtype=torch.bool), 1)] = 7.0
+        rep.check(f"D={D}: UPLO='L'", MU.sqrtm(junk.cuda()), want, tol=1e-11)
+    rep.finish()
+
+
 def test_gaussian_transport_1024_dims_vs_oracle(A):
     """W2 + transport operator at the reference's latent-transport test size (D = 1024, transport_dims (1,2,3))."""
     import otvae_oracle as O
