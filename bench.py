@@ -92,7 +92,7 @@ def time_eager_route(A, workload, pool, steps=20, warmup=5):
     """The same step WITHOUT the hipGraph: every operator launched from Python through torch.ops.otvae / the C ABI (what a
     Lightning loop that calls ``training_step`` + ``loss.backward()`` + the fused Adam pays per step).  Host-bound."""
     model = build_model(A, seed=1, workload=workload).cuda().train()
-    tr = A.HipTrainer(model, batch_shape=tuple(pool[0].shape), use_graph=False)
+    tr = A.HipTrainer(model, batch_shape=tuple(pool[0].shape), use_graph=False, data_parallel=False)
     for i in range(warmup):
         tr.step(pool[i % len(pool)])
     torch.cuda.synchronize()
@@ -246,7 +246,7 @@ def time_largest_aggregate_kernel(A, workload, iters=10):
     from ot_vae_lightning_amd.utils.synthetic import mnist_like
     lib = L.load()
     model = build_model(A, seed=2, workload=workload).cuda().train()
-    tr = A.HipTrainer(model, batch_shape=(PER_GPU_BATCH, 1, 32, 32), use_graph=False)
+    tr = A.HipTrainer(model, batch_shape=(PER_GPU_BATCH, 1, 32, 32), use_graph=False, data_parallel=False)  # rank-local
     x = mnist_like(PER_GPU_BATCH, seed=77).cuda()
     tr.step(x)
     HF.JOB_TRACE = []

@@ -22,11 +22,12 @@ class FlatGradReducer:
     """all-reduce(SUM) of a flat gradient buffer.  On GPU tensors the collective runs on its own stream so that it can
     overlap with whatever the main stream still has queued (the latent-statistics kernels at the end of backward)."""
 
-    def __init__(self, flat: Tensor, group=None):
+    def __init__(self, flat: Tensor, group=None, enabled: bool = True):
         self.flat, self.group = flat, group
-        self.world = world_size(group)
+        # enabled=False: a rank-local engine inside a distributed job (measurement helpers of bench.py): no collective at all
+        self.world = world_size(group) if enabled else 1
         # a 1-rank process group still runs the collective (used to rehearse the multi-GPU call sequence on one GPU)
-        self.active = dist.is_available() and dist.is_initialized()
+        self.active = enabled and dist.is_available() and dist.is_initialized()
         self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and self.active) else None
 
     @property

@@ -68,7 +68,8 @@ class HipTrainer:
 
     def __init__(self, model, batch_shape, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, use_graph: bool = True, latent_stats=None, dp_overlap: Optional[bool] = None,
-                 batch_kwargs: Optional[Dict[str, Tensor]] = None, gradient_clip_val: Optional[float] = None):
+                 batch_kwargs: Optional[Dict[str, Tensor]] = None, gradient_clip_val: Optional[float] = None,
+                 data_parallel: bool = True):
         self.lib = _lib.load()
         self.model = model
         self.params = list(model.optim_parameters())
@@ -112,7 +113,8 @@ class HipTrainer:
         self._wd_max = max((t[2] * t[3] * t[4] for t in table), default=0)
         # distributed
         self.group = process_group
-        self.reducer = FlatGradReducer(self.gflat, process_group)
+        # data_parallel=False: this engine is rank-local even when a process group exists (no gradient exchange)
+        self.reducer = FlatGradReducer(self.gflat, process_group, enabled=data_parallel)
         self.world = self.reducer.world
         # Data-parallel overlap: backward runs in two phases cut at the encoder's output (loss, decoder and prior side
         # first); the decoder's gradient range is all-reduced on the reducer's stream WHILE the encoder's backward runs,

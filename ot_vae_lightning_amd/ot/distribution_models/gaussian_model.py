@@ -156,6 +156,23 @@ class GaussianModel(DistributionModel, W2Mixin):
         shift = psd_shift(lam, strict=True, only_if_needed=False)
         return sym + shift[..., None, None] * eye_like(sym), lam + shift[..., None], vt
 
+    @staticmethod
+    def cov_spectra(*models):
+        """``cov_spectrum`` of several models of one shape from ONE batched eigendecomposition (the matrices are independent: the
+        solver runs a workgroup per matrix side by side)."""
+        if any(m.diag for m in models):
+            raise ValueError("cov_spectra is for full covariance matrices")
+        syms = []
+        for m in models:
+            raw = m.parametrizations.cov.original
+            syms.append((raw.triu() + raw.triu(1).transpose(-1, -2)).double())
+        lam, vt = eigh_vectors(torch.stack(syms))
+        out = []
+        for i, sym in enumerate(syms):
+            shift = psd_shift(lam[i], strict=True, only_if_needed=False)
+            out.append((sym + shift[..., None, None] * eye_like(sym), lam[i] + shift[..., None], vt[i]))
+        return out
+
     def w2(self, other) -> Tensor:
         return self.w2_gaussian(self.mean, other.mean, self.variances, self.get_var_normal(other))
 

@@ -48,8 +48,9 @@ class GaussianTransport(TransportOperator, W2Mixin):
             # full matrices: distance and operator share the eigendecompositions of the two covariances (4 Jacobi runs
             # instead of the 10 that `.cov` + w2_gaussian + compute_transport_operators make between them)
             s, t = self.source_model, self.target_model
+            spec_s, spec_t = type(s).cov_spectra(s, t)   # both covariances decomposed by one batched launch
             distance, operator, noise_cov = w2_and_transport_operator(
-                s.mean, t.mean, s.cov_spectrum(), t.cov_spectrum(), pg_star=self.pg_star, make_pd=self.make_pd, dtype=self.dtype)
+                s.mean, t.mean, spec_s, spec_t, pg_star=self.pg_star, make_pd=self.make_pd, dtype=self.dtype)
             self._set_operators(operator, noise_cov)
             return distance
         mean_s, mean_t, cov_s, cov_t = self._moments()

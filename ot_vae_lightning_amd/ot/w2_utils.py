@@ -277,16 +277,19 @@ def w2_and_transport_operator(mean_source: Tensor, mean_target: Tensor, spec_sou
     mix = matmul64(matmul64(rt, flat(cs_v)), rt)
     if not bool(is_symmetric(mix).all()):
         raise ValueError("`cov_target_sqrt @ cov_source @ cov_target_sqrt` should be symmetric.")
-    sq = eigvals_and_fn(mix, 1)[1]
+    # eq. 17: T = (1 - pg) Cs^-1/2 (Cs^1/2 Ct Cs^1/2)^1/2 Cs^-1/2 + pg I, with Ct as given (only Cs is validated there)
+    rs = flat(spectral_fn(lam_sv.sqrt(), vt_s))
+    irs = flat(spectral_fn((lam_sv + STABILITY_CONST).rsqrt(), vt_s))
+    inner_arg = matmul64(matmul64(rs, flat(ct)), rs)
+    # the two inner square roots do not depend on each other: one batched launch (a workgroup per matrix, side by side)
+    nbm = mix.shape[0]
+    roots = eigvals_and_fn(torch.cat([mix, inner_arg]), 1)[1]
+    sq, inner = roots[:nbm].contiguous(), roots[nbm:].contiguous()
     ms = mean_source.double().expand(*lead, d).reshape(-1, d).contiguous()
     mt = mean_target.double().expand(*lead, d).reshape(-1, d).contiguous()
     w2 = torch.empty(ms.shape[0], device=ms.device, dtype=torch.float64)
     check(lib.otvae_w2_tail(ptr(ms), ptr(mt), ptr(flat(cs_v)), ptr(flat(ct_v)), ptr(sq), ms.shape[0], d, ptr(w2), stream()),
           "otvae_w2_tail")
-    # eq. 17: T = (1 - pg) Cs^-1/2 (Cs^1/2 Ct Cs^1/2)^1/2 Cs^-1/2 + pg I, with Ct as given (only Cs is validated there)
-    rs = flat(spectral_fn(lam_sv.sqrt(), vt_s))
-    irs = flat(spectral_fn((lam_sv + STABILITY_CONST).rsqrt(), vt_s))
-    inner = eigvals_and_fn(matmul64(matmul64(rs, flat(ct)), rs), 1)[1]
     T = (1 - pg_star) * matmul64(matmul64(irs, inner), irs) + pg_star * flat(eye)
     T = T.reshape(*lead, d, d).to(dtype)
     return w2.reshape(lead), T, torch.zeros_like(T)

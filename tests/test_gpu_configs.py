@@ -758,7 +758,7 @@ def test_bench_two_rank_call_sequence_on_one_gpu():
     port = 29700 + os.getpid() % 200
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
-                        "--warmup", "3"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+                        "--warmup", "3"], capture_output=True, text=True, timeout=240, env=env, cwd=root)
     assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
