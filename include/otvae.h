@@ -369,6 +369,11 @@ int otvae_codebook_assign(const float* x, const float* codebook, int nb, int B, 
  * (nullable) entropy[nb][B] = -sum_k p log p, which the CodebookPrior 'kl' loss uses (prior/codebook.py:81-82). */
 int otvae_codebook_probs(const float* x, const float* codebook, int nb, int B, int K, int d, float temperature,
                          float* probs, float* entropy, void* stream);
+/* its backward with respect to the samples (the reference's codebook is a frozen parameter unless update_with_autograd,
+ * codebook_model.py:84-86): gprobs[nb][B][K] / gentropy[nb][B] are the upstream gradients (either may be NULL), probs the
+ * forward's output; gx[nb][B][d].  K <= 4096. */
+int otvae_codebook_probs_bwd(const float* x, const float* codebook, const float* probs, const float* gprobs,
+                             const float* gentropy, int nb, int B, int K, int d, float temperature, float* gx, void* stream);
 /* k-means sufficient statistics for one-hot ('argmax') assignments (MixtureMixin.kmean_iteration, base.py:241-252):
  * counts[nb][K] = number of samples per atom, sums[nb][K][d] = their sum, members added in increasing sample order. */
 int otvae_codebook_kmeans(const float* x, const int64_t* idx, int nb, int B, int K, int d, float* counts, float* sums,

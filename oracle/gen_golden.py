@@ -22,6 +22,8 @@ Fixtures:
   discrete.npz       CodebookModel in 'mean' mode, DiscreteTransport.compute/transport, CodebookPrior.forward
   gmm.npz            GaussianMixtureModel (diagonal) update/fit/energy/w2, GMMTransport.compute/transport
   vit.npz            ViT encoder / decoder (reference networks/vit.py) fwd + input and parameter gradients, dropout 0
+  mixture_modes.npz  CodebookPrior in the soft 'mean' mode with the entropy loss (values + encoder gradient); Gumbel assignment modes
+  nelbo_b32.npz      VAE.nelbo at batch 32 with torch's default initialisation (seeded): the well-conditioned whole-network pin
   w2_prior.npz       GaussianModel._stats + mean_cov + w2_gaussian under torch.autograd: loss and dL/dz (GaussianW2Prior)
   vit_vae.npz        ConditionalGaussianPrior fwd/bwd (+ EMA variant) and VAE.nelbo of the conditional ViT VAE
 """
@@ -763,6 +765,123 @@ def gen_gmm_recovery():
     print("gmm_recovery", out["w2_fit"], out["w2_update"])
 
 
+def gen_mixture_modes():
+    """SURVEY 8f-2, the assignment modes beyond one-hot: (a) CodebookPrior in the soft 'mean' training mode with the 'kl' entropy
+    loss (prior/codebook.py:80-105): values and the gradient that reaches the encoder through the assignment probabilities;
+    (b) 'gumbel-softmax' / 'gumbel-hardmax' assignments (distribution_models/base.py:234-235) of a CodebookModel and of a
+    diagonal GaussianMixtureModel, with the Gumbel draws the reference made recorded next to the results."""
+    import torch.nn.functional as F
+    cm = R.ref("ot.distribution_models.codebook_model")
+    gm = R.ref("ot.distribution_models.gassian_mixture_model")
+    pr = R.ref("prior.codebook")
+    out = {}
+    # ---- (a) soft prior
+    size, K, Bp = (6, 2, 2), 8, 16
+    prior = pr.CodebookPrior(size, (1, 2, 3), loss="kl", loss_coeff=0.7,
+                             mixture_cfg=dict(n_components=K, training_mode="mean", inference_mode="mean", temperature=0.5))
+    prior.train()
+    g = torch.Generator().manual_seed(141)
+    w = torch.randn(Bp, *size, generator=g)
+    for step in range(2):
+        x = (torch.randn(Bp, *size, generator=g) * 1.5).requires_grad_(True)
+        if step == 0:
+            torch.manual_seed(179)
+        z, loss, art = prior(x, step=step)
+        ((z * w).sum() + loss.sum()).backward()
+        out[f"soft_prior/step{step}/x"], out[f"soft_prior/step{step}/z"], out[f"soft_prior/step{step}/loss"] = npy(x), npy(z), npy(loss)
+        out[f"soft_prior/step{step}/gx"], out[f"soft_prior/step{step}/probs"] = npy(x.grad), npy(art["distribution"].probs)
+        out[f"soft_prior/step{step}/codebook"] = npy(prior.codebook_model.codebook).copy()
+    out["soft_prior/w"] = npy(w)
+    # ---- (b) Gumbel modes: torch's own F.gumbel_softmax arithmetic with the draws recorded
+    rec = {}
+    orig = F.gumbel_softmax
+
+    def recording(logits, tau=1, hard=False, eps=1e-10, dim=-1):
+        gum = -torch.empty_like(logits).exponential_().log()
+        rec["g"] = gum.clone()
+        y = ((logits + gum) / tau).softmax(dim)
+        if hard:
+            idx = y.max(dim, keepdim=True)[1]
+            return torch.zeros_like(logits).scatter_(dim, idx, 1.0) - y.detach() + y
+        return y
+
+    F.gumbel_softmax = recording
+    try:
+        for mode in ("gumbel-softmax", "gumbel-hardmax"):
+            torch.manual_seed(7)
+            m = cm.CodebookModel(5, mixture_cfg=dict(n_components=6, training_mode=mode, temperature=0.7))
+            with torch.no_grad():
+                m.codebook.copy_(det_input((6, 5), phase=0.4, amp=1.2))
+            m.train()
+            x = det_input((24, 5), phase=1.1, amp=1.5).requires_grad_(True)
+            wgt = det_input((24, 6), phase=2.0)
+            weights, _, _ = m.assign(x)
+            (weights * wgt).sum().backward()
+            k = f"codebook/{mode}"
+            out[f"{k}/x"], out[f"{k}/codebook"], out[f"{k}/gumbel"] = npy(x), npy(m.codebook), npy(rec["g"])
+            out[f"{k}/weights"], out[f"{k}/gx"], out[f"{k}/w"] = npy(weights), npy(x.grad), npy(wgt)
+            torch.manual_seed(8)
+            mm = gm.GaussianMixtureModel(5, w2_cfg={"diag": True}, dtype=torch.double,
+                                         mixture_cfg=dict(n_components=4, training_mode=mode, temperature=1.3))
+            with torch.no_grad():
+                mm.mean.copy_(det_input((4, 5), phase=0.2, amp=1.0, dtype=torch.double))
+                mm.cov = det_input((4, 5), phase=0.9, amp=0.3, dtype=torch.double).abs() + 0.5
+                mm._weights = torch.tensor([0.1, 0.4, 0.3, 0.2], dtype=torch.double)
+            mm.train()
+            xs = det_input((20, 5), phase=0.6, amp=1.4, dtype=torch.double)
+            weights, _, _ = mm.assign(xs)
+            k = f"gmm/{mode}"
+            out[f"{k}/x"], out[f"{k}/mean"], out[f"{k}/var"] = npy(xs), npy(mm.mean), npy(mm.cov)
+            out[f"{k}/gumbel"], out[f"{k}/weights"] = npy(rec["g"]), npy(weights)
+    finally:
+        F.gumbel_softmax = orig
+    save("mixture_modes.npz", out)
+
+
+def gen_nelbo_b32():
+    """A WELL-CONDITIONED whole-network pin straight from the reference: the MNIST test configuration with torch's default
+    initialisation under manual_seed(1234) (encoder built first, then decoder -- the product's classes make the same RNG
+    draws), batch 32 (BatchNorm over >= 32 positions everywhere), explicit eps.  Losses, every parameter's gradient norm and
+    sum, a few full gradients, the reference's own fp64 evaluation beside them."""
+    cnn, pg, vae = R.ref("networks.cnn"), R.ref("prior.gaussian"), R.ref("model.vae")
+    out = {}
+    for residual in ("add", None):
+        tag = str(residual)
+
+        def make():
+            torch.manual_seed(1234)
+            enc = cnn.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual=residual)
+            dec = cnn.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual=residual)
+            m = vae.VAE(metrics=R._MetricCollection(), encoder=enc, decoder=dec, prior=pg.GaussianPrior(loss_coeff=0.1))
+            return m.train()
+
+        B = 32
+        m = make()
+        x, eps = mnist_like(B, seed=52), normal((B, 128, 1, 1), seed=53)
+        with _FixedEps(eps):
+            loss, logs, art = m.nelbo({"samples": x, "target": x, "kwargs": {}}, 0)
+        loss.backward()
+        params = [(pre + k, p) for pre, net in (("encoder.", m.encoder), ("decoder.", m.decoder)) for k, p in net.named_parameters()]
+        out[f"{tag}/loss"] = npy(torch.stack([logs["train/loss/total"], logs["train/loss/recon"], logs["train/loss/prior"]]))
+        out[f"{tag}/preds"] = npy(art["preds"][:2])
+        out[f"{tag}/param_names"] = np.array([k for k, _ in params])
+        out[f"{tag}/param_sum"] = np.array([p.detach().double().sum().item() for _, p in params])
+        out[f"{tag}/param_l2"] = np.array([p.detach().double().norm().item() for _, p in params])
+        out[f"{tag}/grad_l2"] = np.array([p.grad.double().norm().item() for _, p in params])
+        out[f"{tag}/grad_sum"] = np.array([p.grad.double().sum().item() for _, p in params])
+        names = [k for k, _ in params]
+        for k in ("encoder.0.block.0.weight", "encoder.2.block.1.weight", "encoder.4.block.2.qkv.weight", "decoder.4.block.2.qkv.weight",
+                  "decoder.0.skip.weight", "decoder.2.block.0._normalization.weight"):
+            if k in names:
+                out[f"{tag}/grad_full/{k}"] = npy(params[names.index(k)][1].grad)
+        m64 = make().double()
+        with _FixedEps(eps.double()):
+            loss64, _, _ = m64.nelbo({"samples": x.double(), "target": x.double(), "kwargs": {}}, 0)
+        loss64.backward()
+        out[f"{tag}/grad_l2_f64"] = np.array([p.grad.norm().item() for net in (m64.encoder, m64.decoder) for _, p in net.named_parameters()])
+    save("nelbo_b32.npz", out)
+
+
 def gen_w2_prior():
     """Gaussian W2 with empirical covariance as a differentiable loss term (the reference's pieces are
     GaussianModel._stats + mean_cov + w2_gaussian; here they are composed under torch.autograd exactly as
@@ -804,6 +923,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes"]
     for w in which:
         globals()["gen_" + w]()

@@ -502,6 +502,32 @@ def codebook_prior_encode(x: Tensor, codebook: Tensor, temperature: float = 1.0,
     return z, val * coeff, probs
 
 
+def codebook_prior_encode_soft(x: Tensor, codebook: Tensor, temperature: float = 1.0, loss: Optional[str] = "kl",
+                               coeff: float = 1.0, commitment: float = 0.1):
+    """``CodebookPrior.encode`` in the soft 'mean' training mode (prior/codebook.py:75-105): encodings = softmax weights @
+    codebook (differentiable in x), entropy loss, + commitment * mse(encodings, sg[x])."""
+    probs = codebook_probs(x, codebook, temperature)                             # [1, B, K]
+    enc = probs @ codebook
+    if loss is None:
+        val = torch.zeros(x.size(-2)).type_as(x)
+    elif loss == "l2":
+        val = F.mse_loss(x.expand_as(enc), enc.detach(), reduction="none").mean(-1).sum(0)
+    else:
+        gap = math.log(codebook.shape[-2]) - torch.distributions.Categorical(probs).entropy()
+        val = gap.sum(0) if loss == "kl" else gap[0]
+    val = val + commitment * F.mse_loss(enc, x.detach().expand_as(enc), reduction="none").mean(-1).sum(0)
+    return enc, val * coeff, probs
+
+
+def gumbel_assign(energy: Tensor, gumbel: Tensor, temperature: float, hard: bool) -> Tensor:
+    """``MixtureMixin.assign`` in the Gumbel modes (base.py:234-235, F.gumbel_softmax) for given Gumbel draws."""
+    soft = torch.softmax((energy + gumbel) / temperature, dim=-1)
+    if not hard:
+        return soft
+    idx = soft.max(-1, keepdim=True)[1]
+    return torch.zeros_like(soft).scatter_(-1, idx, 1.0) - soft.detach() + soft
+
+
 # ------------------------------------------------------------------------------------------------ Gaussian mixtures (diag)
 def gmm_diag_energy(x: Tensor, mean: Tensor, var: Tensor, weights: Tensor) -> Tensor:
     """``GaussianMixtureModel.energy`` (ot/distribution_models/gassian_mixture_model.py:91-99) for diagonal covariances:

@@ -749,6 +749,71 @@ extern "C" int otvae_codebook_probs(const float* x, const float* codebook, int n
     return OTVAE_OK;
 }
 
+// Backward of codebook_probs with respect to the samples (the codebook is a frozen parameter in the reference unless
+// update_with_autograd, codebook_model.py:84-86): upstream gradients gp[b][r][k] of the probabilities and gh[b][r] of the
+// entropy (either may be NULL).  With e_k = inv_temp / (dist_k + 1e-8), p = softmax(e), H = -sum p log p:
+//   g_k   = gp_k - gh (log p_k + 1)
+//   de_k  = p_k (g_k - sum_j g_j p_j)
+//   gx    = sum_k de_k * (-inv_temp / (dist_k + 1e-8)^2) * (x - c_k) / dist_k
+// One wave per sample; the per-atom coefficients of a sample live in LDS (K floats per wave).
+__global__ __launch_bounds__(256) void codebook_probs_bwd_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                                 const float* __restrict__ probs, const float* __restrict__ gp,
+                                                                 const float* __restrict__ gh, int B, int K, int d, float inv_temp,
+                                                                 float* __restrict__ gx) {
+    extern __shared__ float coef_lds[];  // [4][K]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    const int b = blockIdx.y;
+    if (r >= B) return;
+    float* coef = coef_lds + (size_t)wv * K;
+    const size_t row = (size_t)b * B + r;
+    const float* xr = x + row * d;
+    const float* cbb = cb + (size_t)b * K * d;
+    const float* pr = probs + row * K;
+    const float ghr = gh ? gh[row] : 0.f;
+    float dot = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float p = pr[k];
+        float g = gp ? gp[row * K + k] : 0.f;
+        if (gh) g -= ghr * (__logf(fmaxf(p, 1e-38f)) + 1.f);
+        coef[k] = g;
+        dot = fmaf(g, p, dot);
+    }
+    dot = wave_sum(dot);
+    for (int k = lane; k < K; k += 64) {
+        float s = 0.f;
+        for (int j = 0; j < d; ++j) {
+            const float t = xr[j] - cbb[(size_t)k * d + j];
+            s = fmaf(t, t, s);
+        }
+        const float dist = sqrtf(s), den = dist + 1e-8f;
+        const float de = pr[k] * (coef[k] - dot);
+        coef[k] = dist > 0.f ? de * (-inv_temp / (den * den)) / dist : 0.f;
+    }
+    // the wave's LDS writes above are read by other lanes below: LDS operations of one wave execute in order
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < d; ++j) {
+        float acc = 0.f;
+        const float xj = xr[j];
+        for (int k = lane; k < K; k += 64) acc = fmaf(coef[k], xj - cbb[(size_t)k * d + j], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) gx[row * d + j] = acc;
+    }
+}
+
+extern "C" int otvae_codebook_probs_bwd(const float* x, const float* codebook, const float* probs, const float* gprobs,
+                                        const float* gentropy, int nb, int B, int K, int d, float temperature, float* gx, void* stream) {
+    OTVAE_REQUIRE(x && codebook && probs && gx && (gprobs || gentropy) && nb > 0 && B > 0 && K > 0 && d > 0,
+                  "otvae_codebook_probs_bwd: bad argument");
+    OTVAE_REQUIRE(temperature > 0.f, "otvae_codebook_probs_bwd: temperature must be positive");
+    OTVAE_REQUIRE((size_t)K * 16 <= 64 * 1024, "otvae_codebook_probs_bwd: K = %d atoms exceed the LDS budget (4096)", K);
+    codebook_probs_bwd_kernel<<<dim3(cdiv(B, 4), nb), 256, (size_t)K * 16, (hipStream_t)stream>>>(x, codebook, probs, gprobs, gentropy,
+                                                                                                B, K, d, 1.f / temperature, gx);
+    OTVAE_CHECK_LAUNCH("otvae_codebook_probs_bwd");
+    return OTVAE_OK;
+}
+
 // One-hot k-means accumulation (MixtureMixin.kmean_iteration with 'argmax' weights, base.py:241-252):
 // counts[b][k] = #{r : idx_r = k}, sums[b][k][:] = sum_{r : idx_r = k} x_r, members added in increasing r (fixed order).
 // One block per (atom, problem): the block scans the index vector once, then its threads own the d coordinates.

@@ -12,7 +12,23 @@ from torch import Tensor
 
 from ... import utils
 
-__all__ = ["DistributionModel"]
+__all__ = ["DistributionModel", "gumbel_weights", "MIXTURE_MODES"]
+
+MIXTURE_MODES = ("argmax", "sample", "mean", "gumbel-softmax", "gumbel-hardmax")   # MixtureMixin.Mode, base.py:166
+
+
+def gumbel_weights(energy: Tensor, temperature: float, hard: bool, noise: Optional[Tensor] = None) -> Tensor:
+    """The 'gumbel-softmax' / 'gumbel-hardmax' assignment weights of ``MixtureMixin.assign`` (reference base.py:234-235:
+    ``F.gumbel_softmax(energy, tau=temperature, hard='hard' in mode)``): softmax((energy + g) / T) with g ~ Gumbel(0, 1), and for
+    the hard variant its one-hot argmax with the soft value's gradient (straight-through).  ``noise``: the Gumbel draws to use
+    (parity tests inject the reference's); otherwise they are drawn on the device, -log(Exponential(1))."""
+    g = noise.to(energy) if noise is not None else -torch.empty_like(energy).exponential_().log()
+    soft = torch.softmax((energy + g) / temperature, dim=-1)
+    if not hard:
+        return soft
+    index = soft.argmax(-1, keepdim=True)
+    one_hot = torch.zeros_like(soft).scatter_(-1, index, 1.0)
+    return one_hot - soft.detach() + soft
 
 
 class DistributionModel(nn.Module, utils.DDPMixin, ABC):

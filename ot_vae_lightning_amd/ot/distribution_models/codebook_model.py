@@ -24,7 +24,7 @@ from torch import Tensor
 from ... import _lib, utils
 from ..._lib import check, ptr, stream
 from ..w2_utils import sinkhorn_log
-from .base import DistributionModel
+from .base import MIXTURE_MODES, DistributionModel, gumbel_weights
 
 __all__ = ["CodebookModel", "CategoricalEmbeddings"]
 
@@ -56,7 +56,39 @@ class CategoricalEmbeddings(D.Categorical):
         return self._select_one_hot(super().sample(sample_shape))
 
 
-_MODES = ("argmax", "sample", "mean")
+
+
+class _AssignmentProbsFn(torch.autograd.Function):
+    """softmax((1 / (|x - c_k| + 1e-8)) / T) (+ its entropy) with a backward pass to the samples (``otvae_codebook_probs_bwd``):
+    what lets CodebookPrior's soft 'mean' mode and its entropy losses train.  The codebook gets no gradient: it is a frozen
+    parameter in the reference (requires_grad = update_with_autograd, codebook_model.py:84-86)."""
+
+    @staticmethod
+    def forward(ctx, x3, c3, temperature, with_entropy):
+        lib = _lib.load()
+        nb, bsz, d = x3.shape
+        K = c3.shape[1]
+        probs = torch.empty((nb, bsz, K), device=x3.device, dtype=torch.float32)
+        ent = torch.empty((nb, bsz), device=x3.device, dtype=torch.float32) if with_entropy else None
+        check(lib.otvae_codebook_probs(ptr(x3), ptr(c3), nb, bsz, K, d, float(temperature), ptr(probs), ptr(ent), stream()),
+              "otvae_codebook_probs")
+        ctx.save_for_backward(x3, c3, probs)
+        ctx.temperature = float(temperature)
+        ctx.set_materialize_grads(False)
+        return (probs, ent) if with_entropy else probs
+
+    @staticmethod
+    def backward(ctx, gprobs, gent=None):
+        x3, c3, probs = ctx.saved_tensors
+        if gprobs is None and gent is None:
+            return None, None, None, None
+        nb, bsz, d = x3.shape
+        gx = torch.empty_like(x3)
+        gp = gprobs.contiguous().float() if gprobs is not None else None
+        ge = gent.contiguous().float() if gent is not None else None
+        check(_lib.load().otvae_codebook_probs_bwd(ptr(x3), ptr(c3), ptr(probs), ptr(gp), ptr(ge), nb, bsz, c3.shape[1], d,
+                                                  ctx.temperature, ptr(gx), stream()), "otvae_codebook_probs_bwd")
+        return gx, None, None, None
 
 
 class CodebookModel(DistributionModel):
@@ -74,8 +106,8 @@ class CodebookModel(DistributionModel):
         if cfg["metric"] != "euclidean" or float(cfg["p"]) != 2.0 or cfg["topk"] not in (None, 0):
             raise NotImplementedError("the MI355X CodebookModel implements metric='euclidean', p=2, topk=None")
         for m in (cfg["training_mode"], cfg["inference_mode"]):
-            if m not in _MODES:
-                raise NotImplementedError(f"assignment mode {m!r}: only {_MODES} run on the MI355X path")
+            if m not in MIXTURE_MODES:
+                raise NotImplementedError(f"assignment mode {m!r}: expected one of {MIXTURE_MODES}")
         if kwargs.get("update_with_autograd", False):
             raise NotImplementedError("update_with_autograd=True is not implemented on the MI355X path")
         self.n_components = int(cfg["n_components"])
@@ -138,16 +170,13 @@ class CodebookModel(DistributionModel):
         return enc.reshape(*lead, bsz, self.dim), idx.reshape(*lead, bsz)
 
     def assignment_probs(self, samples: Tensor, with_entropy: bool = False):
-        """softmax(energy / temperature) [*, B, K] (and its entropy [*, B])"""
-        lib = _lib.load()
+        """softmax(energy / temperature) [*, B, K] (and its entropy [*, B]); differentiable with respect to ``samples``"""
         x3, c3, lead = self._flat(samples)
-        nb, bsz = x3.shape[0], x3.shape[1]
-        probs = torch.empty((nb, bsz, self.n_components), device=x3.device, dtype=torch.float32)
-        ent = torch.empty((nb, bsz), device=x3.device, dtype=torch.float32) if with_entropy else None
-        check(lib.otvae_codebook_probs(ptr(x3), ptr(c3), nb, bsz, self.n_components, self.dim, self.temperature, ptr(probs),
-                                       ptr(ent), stream()), "otvae_codebook_probs")
-        probs = probs.reshape(*lead, bsz, self.n_components)
-        return (probs, ent.reshape(*lead, bsz)) if with_entropy else probs
+        bsz = x3.shape[1]
+        out = _AssignmentProbsFn.apply(x3, c3, self.temperature, with_entropy)
+        if with_entropy:
+            return out[0].reshape(*lead, bsz, self.n_components), out[1].reshape(*lead, bsz)
+        return out.reshape(*lead, bsz, self.n_components)
 
     def energy(self, samples: Tensor) -> Tensor:
         """1 / (|x - c_k|_2 + 1e-8) [*, B, K] (codebook_model.py:150-156); only the tiny atoms-vs-atoms case of ``w2``
@@ -173,6 +202,9 @@ class CodebookModel(DistributionModel):
             weights = probs
         elif mode == "sample":
             weights = F.one_hot(indices, self.n_components).type_as(probs)
+        elif "gumbel" in mode:
+            noise, self.gumbel_noise = getattr(self, "gumbel_noise", None), None   # injected draws are used once
+            weights = gumbel_weights(self.energy(samples), self.temperature, "hard" in mode, noise).type_as(probs)
         else:
             _, idx = self._argmax(samples)
             weights = F.one_hot(idx, self.n_components).type_as(probs)

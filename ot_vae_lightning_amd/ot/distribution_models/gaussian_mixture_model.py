@@ -21,12 +21,11 @@ from torch import Tensor
 from ... import _lib, utils
 from ..._lib import check, ptr, stream
 from ..w2_utils import W2Mixin, batch_ot_gmm
-from .base import DistributionModel
+from .base import MIXTURE_MODES, DistributionModel, gumbel_weights
 from .gaussian_model import MakePositiveDefinite
 
 __all__ = ["GaussianMixtureModel"]
 
-_MODES = ("argmax", "sample", "mean")
 
 
 class NormSum(nn.Module):
@@ -58,8 +57,8 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         if cfg["topk"] not in (None, 0):
             raise NotImplementedError("topk assignment is not implemented on the MI355X path")
         for m in (cfg["training_mode"], cfg["inference_mode"]):
-            if m not in _MODES:
-                raise NotImplementedError(f"assignment mode {m!r}: only {_MODES} run on the MI355X path")
+            if m not in MIXTURE_MODES:
+                raise NotImplementedError(f"assignment mode {m!r}: expected one of {MIXTURE_MODES}")
         if kwargs.get("update_with_autograd", False):
             raise NotImplementedError("update_with_autograd=True is not implemented on the MI355X path")
         self.n_components = int(cfg["n_components"])
@@ -158,6 +157,9 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
             weights = F.one_hot(indices, self.n_components).type_as(weights)
         elif mode == "argmax":
             weights = F.one_hot(weights.argmax(-1), self.n_components).type_as(weights)
+        elif "gumbel" in mode:
+            noise, self.gumbel_noise = getattr(self, "gumbel_noise", None), None   # injected draws are used once
+            weights = gumbel_weights(energy, self.temperature, "hard" in mode, noise)
         return weights, indices, distribution
 
     def predict_mean_var(self, assignments: Tensor) -> Tuple[Tensor, Tensor]:

@@ -14,9 +14,9 @@ Regularisers, all per sample ([B]):
     loss='first_kl'  the same for position 0 only
     + 0.1 * sum_positions mean_dim (sg[x] - e)^2   in the soft training mode    (commitment of the atoms)
 
-Differentiable on this path: the straight-through estimator and the two squared-error terms, i.e. all a one-hot mode
-trains with.  The assignment probabilities come out of a kernel that has no backward pass, so the entropy terms and
-the soft 'mean' mode serve evaluation only; asking them for an input gradient raises ``NotImplementedError``.
+Differentiable on this path: the straight-through estimator, the two squared-error terms, and -- through
+``otvae_codebook_probs_bwd`` -- the assignment probabilities, so the soft 'mean' mode and the entropy losses train the
+encoder as in the reference (the codebook itself moves by its streaming k-means update, not by gradient).
 """
 import math
 from typing import Optional, Sequence
@@ -90,17 +90,14 @@ class CodebookPrior(Prior):
             total = total + self.commitment_cost * _sq_err(encodings, x)
         return total
 
-    def _refuse_untrainable(self, x: Tensor) -> None:
-        wants_grad = x.requires_grad and torch.is_grad_enabled()
-        if wants_grad and (self.codebook_model.mode not in _ONE_HOT_MODES or self._loss_kind() in _ENTROPY_LOSSES):
-            raise NotImplementedError("the assignment probabilities have no backward pass on the MI355X path: the 'mean' mode "
-                                      "and the 'kl' / 'first_kl' losses are evaluation-only (use a one-hot mode with "
-                                      "loss=None or 'l2' for training)")
-
     def encode(self, x: Tensor) -> Prior.EncodingResults:
-        self._refuse_untrainable(x)
         vectors = self.layout.split(x)                                           # [positions, B, dim]
-        atoms, indices, dist = self.codebook_model(vectors.detach())             # training: k-means update, then predict
+        model = self.codebook_model
+        if model.training and not model.update_with_autograd:
+            model.update(vectors.detach())                                       # streaming k-means, no gradient
+        # the probabilities carry a gradient to the encoder where something differentiable is made of them
+        soft = model.mode not in _ONE_HOT_MODES or self._loss_kind() in _ENTROPY_LOSSES
+        atoms, indices, dist = model.predict(vectors if soft else vectors.detach())
         atoms = atoms.type_as(vectors)
         prior_loss = self._compute_loss(vectors, atoms, dist)
         if self.codebook_model.training_mode in _ONE_HOT_MODES:

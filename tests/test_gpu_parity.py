@@ -253,6 +253,40 @@ def test_nelbo_and_adam_vs_reference_golden(A, residual):
 
 
 # ------------------------------------------------------------------------------------------------ G5 prior
+@pytest.mark.parametrize("residual", ["add", None])
+def test_whole_network_step_batch32_vs_reference_golden(A, residual):
+    """The HIP path held to the REFERENCE directly on a well-conditioned whole-network case (tests/golden/nelbo_b32.npz: the
+    reference's VAE.nelbo + backward, torch default initialisation under manual_seed(1234), batch 32, explicit eps): losses,
+    reconstructions, every parameter's gradient norm and sum and six full gradients at 3e-4."""
+    from conftest import load_golden
+    G = load_golden("nelbo_b32.npz")
+    tag = str(residual)
+    rep = Report(f"whole network, batch 32, default init (residual={residual}) vs the reference")
+    torch.manual_seed(1234)
+    enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual=residual)
+    dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual=residual)
+    model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+    named = [(pre + k, p) for pre, net in (("encoder.", model.encoder), ("decoder.", model.decoder)) for k, p in net.named_parameters()]
+    assert [k for k, _ in named] == list(G[f"{tag}/param_names"])
+    rep.check("initialisation (parameter sums)", torch.tensor([p.detach().double().sum().item() for _, p in named]),
+              torch.from_numpy(G[f"{tag}/param_sum"]), tol=1e-6)
+    x, eps = mnist_like(32, seed=52).cuda(), normal((32, 128, 1, 1), seed=53).cuda()
+    loss, logs, art = model.nelbo({"samples": x, "target": x, "kwargs": {"eps": eps}}, 0)
+    loss.backward()
+    rep.check("loss[total,recon,prior]", model._last_out3, torch.from_numpy(G[f"{tag}/loss"]))
+    rep.check("preds[:2]", art["preds"][:2], torch.from_numpy(G[f"{tag}/preds"]))
+    rep.check("grad_l2 (all parameters)", torch.tensor([p.grad.double().norm().item() for _, p in named]),
+              torch.from_numpy(G[f"{tag}/grad_l2"]), tol=3e-4)
+    rep.check("grad_sum (all parameters)", torch.tensor([p.grad.double().sum().item() for _, p in named]),
+              torch.from_numpy(G[f"{tag}/grad_sum"]), tol=3e-4)
+    lookup = dict(named)
+    for k in G.files:
+        if k.startswith(f"{tag}/grad_full/"):
+            name = k.split("grad_full/")[1]
+            rep.check(f"grad {name}", lookup[name].grad, torch.from_numpy(G[k]), tol=3e-4)
+    rep.finish()
+
+
 @pytest.mark.parametrize("tag", ["plain", "anneal"])
 def test_gaussian_prior_vs_reference_golden(A, tag):
     g = group(load_golden("prior.npz"), tag)
@@ -878,11 +912,63 @@ def test_codebook_prior_vs_reference_golden(A):
         # log K - entropy of softmax(1 / distance): inherits the rounding of the reference's cdist (see the k-means test)
         rep.check(f"eval/loss_{kind}", loss, g[f"eval/loss_{kind}"], 2e-3)
     rep.check("eval/z", z, g["eval/z"], 1e-6)
-    with pytest.raises(NotImplementedError):
-        prior(xe.clone().requires_grad_(True), step=100)       # entropy losses have no backward pass here
+    xg = xe.clone().requires_grad_(True)                      # the entropy losses are differentiable (otvae_codebook_probs_bwd)
+    prior(xg, step=100)[1].sum().backward()
+    assert torch.isfinite(xg.grad).all() and float(xg.grad.abs().max()) > 0
     assert prior.sample((4, *size), "cuda").shape == (4, *size)
     with pytest.raises(ValueError):
         A.CodebookPrior(size, (4,), mixture_cfg=dict(n_components=K))
+    rep.finish()
+
+
+def test_soft_codebook_prior_and_gumbel_modes_vs_reference_golden(A):
+    """SURVEY 8f-2, beyond one-hot assignments: CodebookPrior in the soft 'mean' training mode with the 'kl' entropy loss -- the
+    gradient reaches the encoder through ``otvae_codebook_probs_bwd`` -- and the 'gumbel-softmax' / 'gumbel-hardmax' assignment
+    modes of CodebookModel / GaussianMixtureModel with the reference's own Gumbel draws injected (tests/golden/mixture_modes.npz)."""
+    G = load_golden("mixture_modes.npz")
+    rep = Report("soft CodebookPrior + Gumbel assignment modes vs reference golden")
+    sp = group(G, "soft_prior")
+    size, K = tuple(sp["step0/x"].shape[1:]), sp["step0/codebook"].shape[-2]
+    prior = A.CodebookPrior(size, (1, 2, 3), loss="kl", loss_coeff=0.7,
+                            mixture_cfg=dict(n_components=K, training_mode="mean", inference_mode="mean", temperature=0.5))
+    _zero_init(prior.codebook_model)
+    prior = prior.cuda().train()
+    w = sp["w"].cuda()
+    for step in range(2):
+        x = sp[f"step{step}/x"].cuda().requires_grad_(True)
+        if step == 0:
+            torch.manual_seed(179)
+        z, loss, art = prior(x, step=step)
+        ((z * w).sum() + loss.sum()).backward()
+        rep.check(f"soft prior step{step}/codebook", prior.codebook_model.codebook, sp[f"step{step}/codebook"], 1e-5)
+        rep.check(f"soft prior step{step}/z", z, sp[f"step{step}/z"], 1e-4)
+        rep.check(f"soft prior step{step}/loss", loss, sp[f"step{step}/loss"], 1e-4)
+        rep.check(f"soft prior step{step}/dx", x.grad, sp[f"step{step}/gx"], 1e-4)
+        rep.check(f"soft prior step{step}/probs", art["distribution"].probs, sp[f"step{step}/probs"], 5e-4)
+    for mode in ("gumbel-softmax", "gumbel-hardmax"):
+        g = group(G, f"codebook/{mode}")
+        m = A.CodebookModel(5, mixture_cfg=dict(n_components=6, training_mode=mode, temperature=0.7)).cuda().train()
+        with torch.no_grad():
+            m.codebook.copy_(g["codebook"].cuda())
+        x = g["x"].cuda().requires_grad_(True)
+        m.gumbel_noise = g["gumbel"].cuda()
+        wts, _, _ = m.assign(x)
+        (wts * g["w"].cuda()).sum().backward()
+        rep.check(f"codebook {mode}: weights", wts, g["weights"], 1e-5)
+        rep.check(f"codebook {mode}: dx", x.grad, g["gx"], 1e-4)
+        assert m.gumbel_noise is None
+        free, _, _ = m.assign(x.detach())                    # drawn on the device: a valid assignment
+        assert torch.allclose(free.sum(-1), torch.ones_like(free.sum(-1)), atol=1e-5)
+        g = group(G, f"gmm/{mode}")
+        mm = A.GaussianMixtureModel(5, w2_cfg={"diag": True}, dtype=torch.double,
+                                    mixture_cfg=dict(n_components=4, training_mode=mode, temperature=1.3)).cuda().train()
+        with torch.no_grad():
+            mm.mean.copy_(g["mean"].cuda())
+            mm.cov = g["var"].cuda()
+            mm._weights = torch.tensor([0.1, 0.4, 0.3, 0.2], dtype=torch.double).cuda()
+        mm.gumbel_noise = g["gumbel"].cuda()
+        # 1e-7: the variances read back through the strictly-positive parametrisation (+1e-8) on both sides
+        rep.check(f"gmm {mode}: weights", mm.assign(g["x"].cuda())[0], g["weights"], 1e-7)
     rep.finish()
 
 
