@@ -22,6 +22,7 @@ Fixtures:
   discrete.npz       CodebookModel in 'mean' mode, DiscreteTransport.compute/transport, CodebookPrior.forward
   gmm.npz            GaussianMixtureModel (diagonal) update/fit/energy/w2, GMMTransport.compute/transport
   vit.npz            ViT encoder / decoder (reference networks/vit.py) fwd + input and parameter gradients, dropout 0
+  gmm_full.npz       full covariances: batch_w2_dissimilarity_gaussian, batch_ot_gmm, gaussian_barycenter, GaussianMixtureModel
   mixture_modes.npz  CodebookPrior in the soft 'mean' mode with the entropy loss (values + encoder gradient); Gumbel assignment modes
   nelbo_b32.npz      VAE.nelbo at batch 32 with torch's default initialisation (seeded): the well-conditioned whole-network pin
   w2_prior.npz       GaussianModel._stats + mean_cov + w2_gaussian under torch.autograd: loss and dL/dz (GaussianW2Prior)
@@ -604,6 +605,75 @@ def gen_gmm():
     save("gmm.npz", out)
 
 
+def gen_gmm_full():
+    """SURVEY 8f-2, full covariances: ``batch_w2_dissimilarity_gaussian`` / ``batch_ot_gmm(diag=False)`` (ot/w2_utils.py:138-270),
+    ``gaussian_barycenter`` diagonal and full (w2_utils.py:325-385; the index its fixed point starts from is the one the reference
+    draws under the recorded seed), and GaussianMixtureModel with full covariances: update x 3 -> fit -> energy / assign /
+    predict_mean_var / w2 (gassian_mixture_model.py)."""
+    w2 = R.ref("ot.w2_utils")
+    gm = R.ref("ot.distribution_models.gassian_mixture_model")
+    out = {}
+    g = torch.Generator().manual_seed(71)
+
+    def spd(*shape):
+        d = shape[-1]
+        a = torch.randn(*shape, d, generator=g, dtype=torch.double) / math.sqrt(d)
+        return a @ a.transpose(-1, -2) + 0.3 * torch.eye(d, dtype=torch.double)
+
+    lead, N, M, d = (2,), 3, 4, 5
+    ms, mt = torch.randn(*lead, N, d, generator=g, dtype=torch.double), torch.randn(*lead, M, d, generator=g, dtype=torch.double) + 0.5
+    cs, ct = spd(*lead, N, d), spd(*lead, M, d)
+    ws = torch.softmax(torch.randn(*lead, N, generator=g, dtype=torch.double), -1)
+    wt = torch.softmax(torch.randn(*lead, M, generator=g, dtype=torch.double), -1)
+    out["fn/ms"], out["fn/mt"], out["fn/cs"], out["fn/ct"], out["fn/ws"], out["fn/wt"] = npy(ms), npy(mt), npy(cs), npy(ct), npy(ws), npy(wt)
+    out["fn/dissimilarity"] = npy(w2.batch_w2_dissimilarity_gaussian(ms, mt, cs, ct, make_pd=True))
+    total, coupling = w2.batch_ot_gmm(ms, mt, cs, ct, diag=False, weight_source=ws, weight_target=wt, max_iter=100)
+    out["fn/ot_total"], out["fn/ot_coupling"] = npy(total), npy(coupling)
+    mb, cb = w2.gaussian_barycenter(ms, torch.diagonal(cs, dim1=-2, dim2=-1), ws, diag=True)
+    out["fn/bary_diag_mean"], out["fn/bary_diag_var"] = npy(mb), npy(cb)
+    torch.manual_seed(5)
+    out["fn/bary_init_index"] = np.array(int(torch.randint(size=(1,), high=N).item()))
+    torch.manual_seed(5)
+    mb, cb = w2.gaussian_barycenter(ms, cs, ws, diag=False, n_iter=100)
+    out["fn/bary_full_mean"], out["fn/bary_full_cov"] = npy(mb), npy(cb)
+    # ---- the model with full covariances
+    w2_cfg = dict(diag=False, stochastic=False, pg_star=0., make_pd=True, verbose=False, dtype=torch.double)
+    mix = dict(metric="euclidean", p=2., topk=None, temperature=1., training_mode="argmax", inference_mode="argmax")
+    for tag, lead, K, d, B, decay in (("sum", (2,), 3, 3, 96, None), ("ema", (), 4, 2, 128, 0.8)):
+        g = torch.Generator().manual_seed(52)
+        centres = torch.randn(*lead, K, d, generator=g, dtype=torch.double) * 3.0
+        shape_mat = torch.randn(d, d, generator=g) * 0.5 + torch.eye(d)
+        model = gm.GaussianMixtureModel(*lead, d, mixture_cfg={**mix, "n_components": K}, w2_cfg=w2_cfg, update_decay=decay,
+                                        dtype=torch.double)
+        model.train()
+        out[f"{tag}/cfg"] = np.array([K, d, B, -1.0 if decay is None else decay])
+        out[f"{tag}/vec_init"] = npy(model.vec_init)
+        xs = [(_clusters(g, lead, K, d, B, centres.float(), noise=1.0) - centres.float().mean(-2, keepdim=True)).double() @ shape_mat.double()
+              + centres.mean(-2, keepdim=True) for _ in range(3)]
+        out[f"{tag}/batches"] = npy(torch.stack(xs))
+        for i, x in enumerate(xs):
+            if i == 0:
+                torch.manual_seed(83)
+            model.update(x)
+            out[f"{tag}/step{i}/mean"], out[f"{tag}/step{i}/cov"] = npy(model.mean).copy(), npy(model.cov).copy()
+            out[f"{tag}/step{i}/weights"], out[f"{tag}/step{i}/n_obs"] = npy(model.weights).copy(), npy(model._n_obs).copy()
+        model.fit()
+        out[f"{tag}/fit/mean"], out[f"{tag}/fit/cov"], out[f"{tag}/fit/weights"] = npy(model.mean), npy(model.cov), npy(model.weights)
+        model.eval()
+        energy = model.energy(xs[-1])
+        weights, _, dist = model.assign(xs[-1])
+        pm, pv = model.predict_mean_var(weights)
+        out[f"{tag}/energy"], out[f"{tag}/assign_onehot"], out[f"{tag}/assign_probs"] = npy(energy), npy(weights), npy(dist.probs)
+        out[f"{tag}/pred_mean"], out[f"{tag}/pred_cov"] = npy(pm), npy(pv)
+        oc = spd(*lead, K, d)
+        other = torch.distributions.MixtureSameFamily(
+            torch.distributions.Categorical(torch.ones(*lead, K, dtype=torch.double) / K),
+            torch.distributions.MultivariateNormal(centres, covariance_matrix=oc))
+        out[f"{tag}/centres"], out[f"{tag}/other_cov"] = npy(centres), npy(oc)
+        out[f"{tag}/w2"] = npy(model.w2(other))
+    save("gmm_full.npz", out)
+
+
 VIT_CASES = [
     # tag, common cfg, batch
     ("d32", dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, dropout=0.0, emb_dropout=0.,
@@ -923,6 +993,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full"]
     for w in which:
         globals()["gen_" + w]()

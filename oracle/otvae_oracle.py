@@ -345,6 +345,43 @@ def w2_gaussian(mean_s: Tensor, mean_t: Tensor, cov_s: Tensor, cov_t: Tensor, ma
     return shift + tr
 
 
+def batch_w2_dissimilarity_gaussian(mean_s: Tensor, mean_t: Tensor, cov_s: Tensor, cov_t: Tensor) -> Tensor:
+    """``batch_w2_dissimilarity_gaussian`` (ot/w2_utils.py:138-189): D[*, i, j] = W2^2 between full-covariance components."""
+    n, m = mean_s.size(-2), mean_t.size(-2)
+    ones = [1] * (mean_s.dim() - 2)
+    dis = w2_gaussian(mean_s.repeat_interleave(m, -2), mean_t.repeat(*ones, n, 1), cov_s.repeat_interleave(m, -3),
+                      cov_t.repeat(*ones, n, 1, 1), make_pd=True)
+    return dis.view(*mean_s.shape[:-2], n, m)
+
+
+def batch_ot_gmm_full(mean_s: Tensor, mean_t: Tensor, cov_s: Tensor, cov_t: Tensor, w_s: Tensor, w_t: Tensor, **sinkhorn_kwargs):
+    """``batch_ot_gmm(diag=False)`` (ot/w2_utils.py:197-270)."""
+    cost = batch_w2_dissimilarity_gaussian(mean_s, mean_t, cov_s, cov_t)
+    cmax = cost.max(-2, keepdim=True)[0].max(-1, keepdim=True)[0]
+    plan = sinkhorn_log(w_s, w_t, cost / cmax, **sinkhorn_kwargs)
+    return torch.sum(cost * plan, dim=(-2, -1)), plan
+
+
+def gaussian_barycenter(mean: Tensor, cov: Tensor, weights: Tensor, diag: bool, n_iter: int = 100, init_index: int = 0):
+    """``gaussian_barycenter`` (ot/w2_utils.py:325-385) with the start of the fixed point given (the reference draws it)."""
+    w_row = weights.unsqueeze(-2)
+    mean_b = (w_row @ mean).squeeze(-2)
+    if diag:
+        return mean_b, ((w_row @ torch.sqrt(cov)) ** 2).squeeze(-2)
+    w4 = weights.unsqueeze(-1).unsqueeze(-1)
+    cov_b = cov.select(dim=-3, index=init_index).unsqueeze(-3)
+    for _ in range(n_iter):
+        root = sqrtm(cov_b)
+        cov_b = (w4 * sqrtm(root @ cov @ root)).sum(-3, keepdim=True)
+    return mean_b, cov_b.squeeze(-3)
+
+
+def gmm_full_energy(x: Tensor, mean: Tensor, cov: Tensor, weights: Tensor) -> Tensor:
+    """``GaussianMixtureModel.energy`` with full covariances (gassian_mixture_model.py:91-99): log N(x; mu_k, C_k) + log w_k."""
+    comp = torch.distributions.MultivariateNormal(mean.unsqueeze(-3), covariance_matrix=cov.unsqueeze(-4))
+    return comp.log_prob(x.unsqueeze(-2)) + torch.log_softmax(torch.log(weights), -1).unsqueeze(-2)
+
+
 def w2_prior_loss(z: Tensor, target_mean: Optional[Tensor] = None, target_cov: Optional[Tensor] = None) -> Tensor:
     """Gaussian W2 with empirical covariance as a loss term (BASELINE north_star): the batch statistics of
     ``GaussianModel._stats`` (gaussian_model.py:144-151) -> ``mean_cov`` (matrix_utils.py:145-158) -> ``w2_gaussian``

@@ -8,6 +8,7 @@ MI355X path: the O(B K d) energies come from ``otvae_gmm_diag_energy``; the [B, 
 weighted sums (``weights^T @ x``: plain library GEMMs) are small tensor expressions kept in the reference's order, and
 ``w2`` composes ``batch_ot_gmm`` (HIP pairwise-distance + Sinkhorn kernels).  Full covariance mixtures are not
 implemented (the reference marks its own full-covariance GMM cost as producing NaN, ot/w2_utils.py:262)."""
+import math
 from functools import partial
 from typing import Optional, Tuple
 
@@ -22,7 +23,8 @@ from ... import _lib, utils
 from ..._lib import check, ptr, stream
 from ..w2_utils import W2Mixin, batch_ot_gmm
 from .base import MIXTURE_MODES, DistributionModel, gumbel_weights
-from .gaussian_model import MakePositiveDefinite
+from .gaussian_model import MakePositiveDefinite, Symmetric
+from ..matrix_utils import eigh_vectors, eye_like, matmul64
 
 __all__ = ["GaussianMixtureModel"]
 
@@ -68,10 +70,8 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         self.laplace_smoothing = partial(utils.laplace_smoothing, n_categories=self.n_components, eps=cfg["laplace_eps"])
         DistributionModel.__init__(self, *size, **kwargs)
         W2Mixin.__init__(self, **dict(w2_cfg))
-        if not self.diag:
-            raise NotImplementedError("GaussianMixtureModel on the MI355X path needs diagonal covariances (w2_cfg diag=True)")
         self.batch_dim = -3
-        self.register_buffer("cov_init", torch.ones_like(self.vec_init))
+        self.register_buffer("cov_init", torch.ones_like(self.vec_init) if self.diag else eye_like(self.mat_init).clone())
         w = torch.ones(*self.leading_shape, self.n_components)
         self.register_buffer("weight_init", (w / w.sum(-1, keepdim=True)).type_as(self.vec_init))
         self.mean = nn.Parameter(self.vec_init.clone(), requires_grad=False)
@@ -80,7 +80,9 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         self.register_buffer("_running_sum", torch.zeros_like(self.mean.data))
         self.register_buffer("_running_sum_cov", torch.zeros_like(self.cov.data))
         self.register_buffer("_n_obs", torch.zeros(self.vec_shape[:-1], dtype=self.vec_init.dtype))
-        P.register_parametrization(self, "cov", MakePositiveDefinite(diag=True, strict=True))
+        if not self.diag:  # as GaussianModel: mirror the upper triangle, then shift to strictly positive definite
+            P.register_parametrization(self, "cov", Symmetric(diag=False))
+        P.register_parametrization(self, "cov", MakePositiveDefinite(diag=self.diag, strict=True))
         P.register_parametrization(self, "_weights", NormSum(1.))
 
     # ---- shapes / distributions
@@ -98,15 +100,19 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
 
     @property
     def batched_variances(self) -> Tensor:
-        return self.cov.unsqueeze(-3)
+        return self.cov.unsqueeze(-3 if self.diag else -4)
 
     @property
     def mode(self) -> str:
         return self.training_mode if self.training else self.inference_mode
 
     def _components(self, batched: bool):
-        mean, cov = (self.mean.unsqueeze(-3), self.cov.unsqueeze(-3)) if batched else (self.mean, self.cov)
-        return D.Independent(D.Normal(mean, cov ** 0.5), 1)
+        cov = self.cov
+        if self.diag:
+            mean, cov = (self.mean.unsqueeze(-3), cov.unsqueeze(-3)) if batched else (self.mean, cov)
+            return D.Independent(D.Normal(mean, cov ** 0.5), 1)
+        mean, cov = (self.mean.unsqueeze(-3), cov.unsqueeze(-4)) if batched else (self.mean, cov)
+        return D.MultivariateNormal(mean, covariance_matrix=cov)
 
     @property
     def distribution(self) -> D.MixtureSameFamily:
@@ -139,12 +145,29 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         x3 = samples.to(dt).expand(*lead, bsz, d).reshape(-1, bsz, d).contiguous()
         nb = x3.shape[0]
         flat = lambda t, tail: t.detach().to(dt).expand(*lead, *tail).reshape(nb, *tail).contiguous()  # noqa: E731
-        mean, var = flat(self.mean, (K, d)), flat(self.cov, (K, d))
         logw = flat(torch.log_softmax(torch.log(self.weights), dim=-1), (K,))
+        if not self.diag:
+            return self._energy_full(x3, flat(self.mean, (K, d)), flat(self.cov, (K, d, d)), logw).reshape(*lead, bsz, K) \
+                .type_as(samples if samples.is_floating_point() else x3)
+        mean, var = flat(self.mean, (K, d)), flat(self.cov, (K, d))
         out = torch.empty((nb, bsz, K), device=x3.device, dtype=dt)
         check(lib.otvae_gmm_diag_energy(0 if dt == torch.float32 else 1, ptr(x3), ptr(mean), ptr(var), ptr(logw), nb, bsz, K, d,
                                         ptr(out), stream()), "otvae_gmm_diag_energy")
         return out.reshape(*lead, bsz, K).type_as(samples if samples.is_floating_point() else out)
+
+    def _energy_full(self, x3: Tensor, mean: Tensor, cov: Tensor, logw: Tensor) -> Tensor:
+        """log N(x; mean_k, C_k) + log w_k for full covariances, [nb, B, K]: from ONE batched eigendecomposition of the nb*K
+        covariances (C = V L V^T): Mahalanobis = |L^-1/2 V^T (x - mean)|^2 (one fp64 product per component), log det = sum log L.
+        The reference goes through MultivariateNormal's Cholesky factor (gassian_mixture_model.py:91-99); same value."""
+        nb, bsz, d = x3.shape
+        K = mean.shape[1]
+        lam, vt = eigh_vectors(cov.double().reshape(nb * K, d, d))                  # vt[k] rows = eigenvectors
+        whiten = lam.rsqrt().unsqueeze(-1) * vt                                     # L^-1/2 V^T
+        centred = (x3.double().unsqueeze(1) - mean.double().unsqueeze(2)).reshape(nb * K, bsz, d)   # [nb*K, B, d]
+        y = matmul64(centred, whiten, trans_b=True)                                 # [nb*K, B, d]
+        maha = y.square().sum(-1).reshape(nb, K, bsz).transpose(1, 2)               # [nb, B, K]
+        logdet = lam.log().sum(-1).reshape(nb, 1, K)
+        return (-0.5 * (maha + logdet + d * math.log(2 * math.pi)) + logw.double().unsqueeze(1)).to(x3.dtype)
 
     def assign(self, samples: Tensor):
         """(assignment weights [*, B, K], sampled indices [*, B], Categorical(softmax weights)) -- base.py:206-239"""
@@ -165,7 +188,11 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
     def predict_mean_var(self, assignments: Tensor) -> Tuple[Tensor, Tensor]:
         """per-sample mean and variance of the assigned component(s): assignments [*, B, K] -> [*, B, d] each"""
         mean = assignments.type_as(self.mean) @ self.mean
-        var = assignments.type_as(self.cov) @ self.cov
+        cov = self.cov
+        if self.diag:
+            var = assignments.type_as(cov) @ cov
+        else:  # [*, B, K] x [*, K, d*d] -> [*, B, d, d]
+            var = (assignments.type_as(cov) @ cov.flatten(-2)).unflatten(-1, (self.dim, self.dim))
         return mean.type_as(assignments), var.type_as(assignments)
 
     def predict(self, samples: Tensor):
@@ -178,7 +205,10 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
             return self._n_obs, self._running_sum, self._running_sum_cov
         weights, _, _ = self.assign(samples)                               # [*, B, K]
         wt = weights.transpose(-1, -2).type_as(samples)
-        return weights.sum(-2).type_as(samples), wt @ samples, wt @ (samples ** 2)
+        if self.diag:
+            return weights.sum(-2).type_as(samples), wt @ samples, wt @ (samples ** 2)
+        outer = (samples.unsqueeze(-1) @ samples.unsqueeze(-2)).flatten(-2)   # [*, B, d*d]
+        return weights.sum(-2).type_as(samples), wt @ samples, (wt @ outer).unflatten(-1, (self.dim, self.dim))
 
     def _init_parameters(self, samples: Tensor) -> None:
         if torch.allclose(self.mean, self.vec_init):
@@ -243,7 +273,7 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
 
     def w2(self, other: D.MixtureSameFamily) -> Tensor:
         total, _ = batch_ot_gmm(self.mean, other.component_distribution.mean, self.variances,
-                                other.component_distribution.variance, diag=True, weight_source=self.weights,
+                                self.get_var_normal(other.component_distribution), diag=self.diag, weight_source=self.weights,
                                 weight_target=other.mixture_distribution.probs, dtype=self.dtype, max_iter=100)
         return total
 

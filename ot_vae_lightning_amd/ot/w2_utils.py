@@ -17,7 +17,7 @@ from .matrix_utils import *  # noqa: F401,F403
 from .matrix_utils import (STABILITY_CONST, eigh_vectors, eigvals_and_fn, eye_like, is_symmetric, matmul64, mean_cov, psd_shift,
                            spectral_fn)
 
-__all__ = ["w2_gaussian", "batch_w2_dissimilarity_gaussian_diag", "batch_ot_gmm", "sinkhorn_log", "sinkhorn_log_potentials",
+__all__ = ["w2_gaussian", "batch_w2_dissimilarity_gaussian_diag", "batch_w2_dissimilarity_gaussian", "gaussian_barycenter", "batch_ot_gmm", "sinkhorn_log", "sinkhorn_log_potentials",
            "sq_euclidean_cost", "ot_cost", "compute_transport_operators", "apply_transport", "W2Mixin"]
 
 _DT = {torch.float32: 0, torch.float64: 1}
@@ -181,6 +181,54 @@ def batch_w2_dissimilarity_gaussian_diag(mean_source: Tensor, mean_target: Tenso
         sq_euclidean_cost(var_source.to(dtype).sqrt(), var_target.to(dtype).sqrt())
 
 
+def batch_w2_dissimilarity_gaussian(mean_source: Tensor, mean_target: Tensor, cov_source: Tensor, cov_target: Tensor,
+                                    make_pd: bool = False, verbose: bool = False, dtype=torch.double) -> Tensor:
+    """D[*, i, j] = W2^2(N(ms_i, Cs_i), N(mt_j, Ct_j)) for full covariances: means [*, N, D] / [*, M, D], covariances
+    [*, N, D, D] / [*, M, D, D] (reference ot/w2_utils.py:138-189).  The N x M pairs go through ONE batched ``w2_gaussian``
+    (the eigensolver runs a workgroup per matrix); as in the reference each side must be symmetric positive definite."""
+    for cov, name in ((cov_source, "cov_source"), (cov_target, "cov_target")):
+        _require_spd(cov.double().reshape(-1, cov.shape[-1], cov.shape[-1]).contiguous(), name, False, True, verbose)
+    n, m = mean_source.size(-2), mean_target.size(-2)
+    ones = [1] * (mean_source.dim() - 2)
+    dis = w2_gaussian(mean_source.repeat_interleave(m, -2), mean_target.repeat(*ones, n, 1),
+                      cov_source.repeat_interleave(m, -3), cov_target.repeat(*ones, n, 1, 1),
+                      make_pd=make_pd, verbose=verbose, dtype=dtype)
+    return dis.view(*mean_source.shape[:-2], n, m)
+
+
+def gaussian_barycenter(mean: Tensor, cov: Tensor, weights: Tensor, diag: bool, n_iter: int = 100, dtype=torch.double,
+                        init_index: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    """W2 barycentre of the Gaussians N(mean_i, cov_i) with weights w_i (reference ot/w2_utils.py:325-385, the fixed point of
+    Alvarez-Esteban et al.): mean [*, N, D], cov [*, N, D, D] ([*, N, D] if diag), weights [*, N] -> ([*, D], [*, D, D] | [*, D]).
+    diag: mean_b = sum w mu, var_b = (sum w sigma)^2.  Full: S <- sum_i w_i (S^1/2 C_i S^1/2)^1/2 iterated ``n_iter`` times from
+    one of the C_i -- the reference draws its index with torch.randint; ``init_index`` fixes it (parity tests)."""
+    mean, cov, weights = mean.to(dtype), cov.to(dtype), weights.to(dtype)
+    if mean.dim() < 2 or weights.dim() < 1 or mean.size(-2) != weights.size(-1) or cov.size(-2 if diag else -3) != mean.size(-2):
+        raise ValueError("All the inputs component dimension should match")
+    total = weights.sum(-1)
+    if bool((weights < -1e-5).any()) or bool((total < 1 - 1e-5).any()) or bool((total > 1 + 1e-5).any()):
+        raise ValueError("`weights` is expected to be a valid probability vector with positive entries that sum up to 1.")
+    w_row = weights.unsqueeze(-2)                                            # [*, 1, N]
+    mean_b = (w_row @ mean).squeeze(-2)
+    if diag:
+        if bool((cov < 0).any()):
+            raise ValueError("`cov` is expected to be a valid variance vector with positive entries.")
+        return mean_b, ((w_row @ torch.sqrt(cov)) ** 2).squeeze(-2)
+    _require_spd(cov.reshape(-1, cov.shape[-1], cov.shape[-1]).contiguous(), "cov", False, True, False)
+    n, d = cov.size(-3), cov.size(-1)
+    lead = torch.broadcast_shapes(cov.shape[:-3], weights.shape[:-1])
+    cflat = cov.expand(*lead, n, d, d).reshape(-1, d, d).contiguous()          # [L*N, D, D]
+    w4 = weights.expand(*lead, n).reshape(-1, n, 1, 1)
+    if init_index is None:
+        init_index = int(torch.randint(size=(1,), high=n).item())
+    cov_b = cflat.reshape(-1, n, d, d)[:, init_index].contiguous()            # [L, D, D]
+    for _ in range(n_iter):
+        root = sqrtm(cov_b).unsqueeze(1).expand(-1, n, d, d).reshape(-1, d, d)
+        mix = matmul64(matmul64(root, cflat), root)
+        cov_b = (w4 * sqrtm(mix).reshape(-1, n, d, d)).sum(1)
+    return mean_b, cov_b.reshape(*lead, d, d)
+
+
 def _check_mixture(mean: Tensor, var: Tensor, weight: Tensor, side: str, tol: float = 1e-5):
     """the argument checks of the reference's ``_validate_args`` for ('vec', 'var', 'prob') triples (w2_utils.py:605-708)"""
     for t, name in ((mean, f"mean_{side}"), (var, f"cov_{side}"), (weight, f"weight_{side}")):
@@ -204,19 +252,27 @@ def batch_ot_gmm(mean_source: Tensor, mean_target: Tensor, cov_source: Tensor, c
                  dtype=torch.double, **sinkhorn_kwargs) -> Tuple[Tensor, Tensor]:
     """Entropy-regularised W2^2 upper bound between two Gaussian mixtures (reference ot/w2_utils.py:197-270): the
     component-to-component Gaussian W2^2 as ground cost, the coupling of the mixture weights from ``sinkhorn_log`` on the
-    cost scaled by its maximum, total = <cost, coupling>.  means [*, N, D] / [*, M, D], variances alike (diag=True; full
-    covariances are not implemented -- the reference flags its own full-covariance cost as producing NaN)."""
-    if not diag:
-        raise NotImplementedError("batch_ot_gmm on the MI355X path takes diagonal covariances (diag=True)")
+    cost scaled by its maximum, total = <cost, coupling>.  means [*, N, D] / [*, M, D]; diag=True: variances alike;
+    diag=False: covariances [*, N, D, D] / [*, M, D, D] and the ground cost of ``batch_w2_dissimilarity_gaussian(make_pd=True)``."""
     if weight_source is None:
         weight_source = torch.ones_like(mean_source.select(dim=-1, index=0)) / mean_source.size(-2)
     if weight_target is None:
         weight_target = torch.ones_like(mean_target.select(dim=-1, index=0)) / mean_target.size(-2)
-    _check_mixture(mean_source, cov_source, weight_source, "source")
-    _check_mixture(mean_target, cov_target, weight_target, "target")
     if mean_source.size(-1) != mean_target.size(-1):
         raise ValueError("All the inputs dimensionalities should match")
-    cost = batch_w2_dissimilarity_gaussian_diag(mean_source, mean_target, cov_source, cov_target, dtype=dtype)
+    if diag:
+        _check_mixture(mean_source, cov_source, weight_source, "source")
+        _check_mixture(mean_target, cov_target, weight_target, "target")
+        cost = batch_w2_dissimilarity_gaussian_diag(mean_source, mean_target, cov_source, cov_target, dtype=dtype)
+    else:
+        for mu, cv, wt in ((mean_source, cov_source, weight_source), (mean_target, cov_target, weight_target)):
+            tot = wt.sum(-1)
+            if bool((wt < -1e-5).any()) or bool((tot < 1 - 1e-5).any()) or bool((tot > 1 + 1e-5).any()):
+                raise ValueError("mixture weights are expected to be valid probability vectors with positive entries that sum up to 1.")
+            if not (mu.size(-2) == cv.size(-3) == wt.size(-1)) or cv.size(-1) != mu.size(-1) or cv.size(-2) != mu.size(-1):
+                raise ValueError("All the inputs component / dimensionality sizes should match")
+        cost = batch_w2_dissimilarity_gaussian(mean_source, mean_target, cov_source, cov_target, make_pd=True, verbose=verbose,
+                                               dtype=dtype)
     max_per_mat = cost.max(-2, keepdim=True)[0].max(-1, keepdim=True)[0]
     coupling = sinkhorn_log(weight_source.to(dtype), weight_target.to(dtype), cost / max_per_mat, **sinkhorn_kwargs)
     return torch.sum(cost * coupling, dim=(-2, -1)), coupling
@@ -349,6 +405,10 @@ class W2Mixin(object):
         self.dtype = kwargs.pop("dtype", torch.double)
         self.mean_cov = partial(mean_cov, diag=self.diag)
         self.batch_w2_dissimilarity_gaussian_diag = partial(batch_w2_dissimilarity_gaussian_diag, dtype=self.dtype)
+        self.batch_w2_dissimilarity_gaussian = partial(batch_w2_dissimilarity_gaussian, make_pd=self.make_pd,
+                                                       verbose=self.verbose, dtype=self.dtype)
+        self.gaussian_barycenter = partial(gaussian_barycenter, diag=self.diag, dtype=self.dtype)
+        self.batch_ot_gmm = partial(batch_ot_gmm, diag=self.diag, verbose=self.verbose, dtype=self.dtype)
         self.compute_transport_operators = partial(compute_transport_operators, diag=self.diag,
                                                    stochastic=self.stochastic, pg_star=self.pg_star,
                                                    make_pd=self.make_pd, verbose=self.verbose, dtype=self.dtype)

@@ -1020,6 +1020,119 @@ def test_gaussian_mixture_model_vs_reference_golden(A, tag):
     rep.finish()
 
 
+_GMM_W2_FULL = dict(diag=False, stochastic=False, pg_star=0., make_pd=True, verbose=False, dtype=torch.double)
+
+
+def test_full_covariance_mixture_functions_vs_reference_golden(A):
+    """SURVEY 8f-2, full covariances: ``batch_w2_dissimilarity_gaussian`` (N x M Gaussian W2 through one batched eigensolver
+    call), ``batch_ot_gmm(diag=False)`` and ``gaussian_barycenter`` (diagonal closed form; full fixed point from the index the
+    reference drew) against the reference's outputs (tests/golden/gmm_full.npz)."""
+    from ot_vae_lightning_amd.ot import w2_utils as W
+    f = group(load_golden("gmm_full.npz"), "fn")
+    rep = Report("full-covariance mixture functions vs reference golden")
+    c = {k: v.cuda() for k, v in f.items() if hasattr(v, "cuda")}
+    rep.check("batch_w2_dissimilarity_gaussian", W.batch_w2_dissimilarity_gaussian(c["ms"], c["mt"], c["cs"], c["ct"], make_pd=True),
+              f["dissimilarity"], 1e-9)
+    total, plan = W.batch_ot_gmm(c["ms"], c["mt"], c["cs"], c["ct"], diag=False, weight_source=c["ws"], weight_target=c["wt"],
+                                 max_iter=100)
+    rep.check("batch_ot_gmm total", total, f["ot_total"], 1e-8)
+    rep.check("batch_ot_gmm coupling", plan, f["ot_coupling"], 1e-7)
+    mb, vb = W.gaussian_barycenter(c["ms"], torch.diagonal(c["cs"], dim1=-2, dim2=-1), c["ws"], diag=True)
+    rep.check("barycenter (diag) mean", mb, f["bary_diag_mean"], 1e-12)
+    rep.check("barycenter (diag) var", vb, f["bary_diag_var"], 1e-12)
+    mb, cb = W.gaussian_barycenter(c["ms"], c["cs"], c["ws"], diag=False, n_iter=100, init_index=int(f["bary_init_index"]))
+    rep.check("barycenter (full) mean", mb, f["bary_full_mean"], 1e-12)
+    rep.check("barycenter (full) cov", cb, f["bary_full_cov"], 1e-8)
+    with pytest.raises(ValueError):
+        W.gaussian_barycenter(c["ms"], c["cs"], c["ws"] * 2, diag=False)
+    rep.finish()
+
+
+@pytest.mark.parametrize("tag", ["sum", "ema"])
+def test_full_covariance_gaussian_mixture_model_vs_reference_golden(A, tag):
+    """GaussianMixtureModel with FULL covariances (reference gassian_mixture_model.py with w2_cfg diag=False): streaming updates,
+    fit, energy (one batched eigendecomposition instead of MultivariateNormal's Cholesky), assignment, predict_mean_var and
+    w2 against another full-covariance mixture."""
+    g = group(load_golden("gmm_full.npz"), tag)
+    rep = Report(f"GaussianMixtureModel, full covariances ({tag}) vs reference golden")
+    K, d, B, decay = g["cfg"].tolist()
+    K, d = int(K), int(d)
+    decay = None if decay < 0 else float(decay)
+    batches = g["batches"]
+    lead = tuple(batches.shape[1:-2])
+    model = A.GaussianMixtureModel(*lead, d, mixture_cfg={**_GMM_MIX, "n_components": K}, w2_cfg=_GMM_W2_FULL, update_decay=decay,
+                                   dtype=torch.double).cuda().train()
+    assert model.cov.shape == (*lead, K, d, d)
+    for step in range(batches.shape[0]):
+        if step == 0:
+            torch.manual_seed(83)
+        model.update(batches[step].cuda())
+        rep.check(f"step{step}/n_obs", model._n_obs, g[f"step{step}/n_obs"], 1e-12)
+        rep.check(f"step{step}/mean", model.mean, g[f"step{step}/mean"], 1e-11)
+        rep.check(f"step{step}/cov", model.cov, g[f"step{step}/cov"], 1e-9)
+        rep.check(f"step{step}/weights", model.weights, g[f"step{step}/weights"], 1e-12)
+    model.fit()
+    rep.check("fit/mean", model.mean, g["fit/mean"], 1e-11)
+    rep.check("fit/cov", model.cov, g["fit/cov"], 1e-9)
+    rep.check("fit/weights", model.weights, g["fit/weights"], 1e-12)
+    model.eval()
+    x = batches[-1].cuda()
+    rep.check("energy", model.energy(x), g["energy"], 1e-8)
+    weights, sampled, dist = model.assign(x)
+    rep.check("assignment one-hot", weights, g["assign_onehot"], exact=True)
+    rep.check("assignment probabilities", dist.probs, g["assign_probs"], 1e-7)
+    pm, pv = model.predict_mean_var(weights)
+    rep.check("predict_mean_var: mean", pm, g["pred_mean"], 1e-11)
+    rep.check("predict_mean_var: cov", pv, g["pred_cov"], 1e-9)
+    centres, oc = g["centres"].cuda(), g["other_cov"].cuda()
+    other = torch.distributions.MixtureSameFamily(
+        torch.distributions.Categorical((torch.ones(*lead, K, dtype=torch.double) / K).cuda()),
+        torch.distributions.MultivariateNormal(centres, covariance_matrix=oc))
+    rep.check("w2", model.w2(other), g["w2"], 1e-7)
+    rep.finish()
+
+
+def test_gmm_transport_barycenter_and_full_covariances(A):
+    """GMMTransport beyond the reference's tested configuration: transport_type='barycenter' (the reference hands the coupled
+    assignment to gaussian_barycenter un-normalised, which its own validation rejects; here it is normalised) and full
+    covariances.  Invariants: finite outputs of the input's shape; for a one-component target the barycentre IS that
+    component, so 'barycenter' and 'argmax' transport agree; the full-covariance map pushes the source's component mean to
+    the target's."""
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(91)
+    mix = {**_GMM_MIX}
+    for diag in (True, False):
+        w2_cfg = dict(_GMM_W2, diag=diag)
+        cfg = lambda k: dict(update_decay=None, update_with_autograd=False, dtype=torch.double, mixture_cfg={**mix, "n_components": k})  # noqa: E731
+        d = 3
+        src = torch.randn(400, d, generator=g, dtype=torch.double) * torch.tensor([1.0, 0.5, 2.0], dtype=torch.double)
+        tgt = torch.randn(400, d, generator=g, dtype=torch.double) * 0.7 + 2.0
+        outs = {}
+        for ttype in ("barycenter", "argmax"):
+            torch.manual_seed(11)
+            op = A.GMMTransport(d, transport_type=ttype, transport_cfg=w2_cfg, source_cfg=cfg(2), target_cfg=cfg(1)).cuda().train()
+            op.update(source_samples=src.cuda())
+            op.update(target_samples=tgt.cuda())
+            cost = op.compute()
+            assert torch.isfinite(cost).all()
+            op.eval()
+            op.barycenter_init = 0
+            outs[ttype] = op.transport(src[:64].cuda())
+            assert outs[ttype].shape == (64, d) and torch.isfinite(outs[ttype]).all()
+        assert rel_err(outs["barycenter"], outs["argmax"]) < 1e-7, diag
+        moved_mean = outs["argmax"].mean(0).cpu()
+        assert float((moved_mean - tgt.mean(0)).abs().max()) < 0.35, (diag, moved_mean)
+        op3 = A.GMMTransport(d, transport_type="barycenter", transport_cfg=w2_cfg, source_cfg=cfg(2), target_cfg=cfg(3)).cuda().train()
+        torch.manual_seed(12)
+        op3.update(source_samples=src.cuda())
+        op3.update(target_samples=torch.cat([tgt, tgt * 0.5 - 3.0]).cuda())
+        op3.compute()
+        op3.eval()
+        op3.barycenter_init = 1
+        moved = op3.transport(src[:16].cuda())
+        assert moved.shape == (16, d) and torch.isfinite(moved).all()
+
+
 def test_gmm_transport_vs_reference_golden(A):
     """GMMTransport (reference ot/transport/gmm_transport.py, configured as tests/test_latent_transport.py:80-91): three
     updates per side, compute (component coupling from the HIP Sinkhorn solver on the diagonal-Gaussian W2 cost),
@@ -1052,9 +1165,7 @@ def test_gmm_transport_vs_reference_golden(A):
     with pytest.raises(RuntimeError):
         op.transport(g["probe"].cuda())
     with pytest.raises(NotImplementedError):
-        A.GMMTransport(d, transport_type="barycenter", transport_cfg=_GMM_W2, source_cfg=cfg, target_cfg=cfg)
-    with pytest.raises(NotImplementedError):
-        A.GMMTransport(d, transport_type="argmax", transport_cfg={**_GMM_W2, "diag": False}, source_cfg=cfg, target_cfg=cfg)
+        A.GMMTransport(d, transport_type="nearest", transport_cfg=_GMM_W2, source_cfg=cfg, target_cfg=cfg)
     rep.finish()
 
 
@@ -1391,5 +1502,5 @@ def test_gaussian_mixture_model_on_the_references_recovery_experiment(A):
     rep.check("update: component means", streamed.mean, torch.from_numpy(g["update_mean"]), 1e-9)
     rep.check("update: W2 to the sampling mixture", streamed.w2(truth_gpu), torch.from_numpy(g["w2_update"]), 1e-6)
     with pytest.raises(NotImplementedError):
-        A.GaussianMixtureModel(*lead, dim, **{**cfg, "w2_cfg": {"diag": False}})
+        A.GaussianMixtureModel(*lead, dim, **{**cfg, "mixture_cfg": {**cfg["mixture_cfg"], "topk": 2}})
     rep.finish()
