@@ -350,6 +350,10 @@ int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out, double* e
  * (|min(lambda_min_b,0)| + (strict ? 1e-8 : 0)), A_b += shift_b * I.  cond_any: 1 = apply only if some matrix of
  * the batch fails the test (w2_utils.py:667-669), 0 = always (gaussian_model.py:204-214). */
 int otvae_make_psd(double* A, const double* eigvals, int nb, int D, int strict, int cond_any, void* stream);
+/* Lower Cholesky factor L[nb][D][D] of A[nb][D][D] (fp64, lower triangle read): the factor torch.distributions.MultivariateNormal
+ * samples with (the reference's stochastic apply_transport, ot/w2_utils.py:521-525).  info[nb] (may be NULL): 0, or 1 + the index
+ * of the first non-positive pivot (then L holds NaN from that column on).  L must not alias A. */
+int otvae_cholesky(const double* A, int nb, int D, double* L, int* info, void* stream);
 /* C[nb][m][n] = alpha * op(A) op(B) + beta*C, fp64, row-major; transX: 0 = N, 1 = T. bcast flags: operand has
  * batch stride 0 */
 int otvae_gemm_f64(int transA, int transB, int nb, int m, int n, int k, double alpha, const double* A, int a_bcast,

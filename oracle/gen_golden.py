@@ -22,6 +22,7 @@ Fixtures:
   discrete.npz       CodebookModel in 'mean' mode, DiscreteTransport.compute/transport, CodebookPrior.forward
   gmm.npz            GaussianMixtureModel (diagonal) update/fit/energy/w2, GMMTransport.compute/transport
   vit.npz            ViT encoder / decoder (reference networks/vit.py) fwd + input and parameter gradients, dropout 0
+  stochastic.npz     compute_transport_operators(stochastic=True) (eq. 19) for degenerate sources + apply_transport with noise
   gmm_full.npz       full covariances: batch_w2_dissimilarity_gaussian, batch_ot_gmm, gaussian_barycenter, GaussianMixtureModel
   mixture_modes.npz  CodebookPrior in the soft 'mean' mode with the entropy loss (values + encoder gradient); Gumbel assignment modes
   nelbo_b32.npz      VAE.nelbo at batch 32 with torch's default initialisation (seeded): the well-conditioned whole-network pin
@@ -605,6 +606,45 @@ def gen_gmm():
     save("gmm.npz", out)
 
 
+def gen_stochastic():
+    """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
+    (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
+    difference to the noiseless transport)."""
+    w2 = R.ref("ot.w2_utils")
+    out = {}
+    g = torch.Generator().manual_seed(91)
+    # diagonal: two entries of every source variance vector vanish
+    cs = torch.rand(2, 6, generator=g, dtype=torch.double) + 0.2
+    cs[:, [1, 4]] = 0.0
+    ct = torch.rand(2, 6, generator=g, dtype=torch.double) + 0.3
+    T, Cw = w2.compute_transport_operators(cs.clone(), ct, stochastic=True, diag=True, pg_star=0.2, make_pd=True)
+    out["diag/cs"], out["diag/ct"], out["diag/T"], out["diag/Cw"] = npy(cs), npy(ct), npy(T), npy(Cw)
+    x = torch.randn(2, 9, 6, generator=g, dtype=torch.double)
+    ms, mt = torch.randn(2, 6, generator=g, dtype=torch.double), torch.randn(2, 6, generator=g, dtype=torch.double)
+    quiet = w2.apply_transport(x, ms.unsqueeze(-2), mt.unsqueeze(-2), T.unsqueeze(-2), torch.zeros_like(T).unsqueeze(-2), diag=True)
+    torch.manual_seed(31)
+    noisy = w2.apply_transport(x, ms.unsqueeze(-2), mt.unsqueeze(-2), T.unsqueeze(-2), Cw.unsqueeze(-2).abs() + 0.05, diag=True)
+    out["diag/x"], out["diag/ms"], out["diag/mt"] = npy(x), npy(ms), npy(mt)
+    out["diag/moved"], out["diag/moved_noisy"], out["diag/Cw_used"] = npy(quiet), npy(noisy), npy(Cw.abs() + 0.05)
+    # full: nearly rank-deficient source (rank 3 of 6 plus 1e-6 I; exactly singular sources make the reference's own sqrtm return
+    # NaN: the zero eigenvalues of Ct^1/2 Cs Ct^1/2 come out slightly negative), positive definite target
+    d = 6
+    a = torch.randn(2, d, 3, generator=g, dtype=torch.double)
+    cs = a @ a.transpose(-1, -2) + 1e-6 * torch.eye(d, dtype=torch.double)
+    b = torch.randn(2, d, d, generator=g, dtype=torch.double) / math.sqrt(d)
+    ct = b @ b.transpose(-1, -2) + 0.4 * torch.eye(d, dtype=torch.double)
+    T, Cw = w2.compute_transport_operators(cs, ct, stochastic=True, diag=False, pg_star=0.1, make_pd=True)
+    out["full/cs"], out["full/ct"], out["full/T"], out["full/Cw"] = npy(cs), npy(ct), npy(T), npy(Cw)
+    out["full/Cw_min_eig"] = npy(torch.linalg.eigvalsh(Cw)[..., 0])
+    x = torch.randn(2, 9, d, generator=g, dtype=torch.double)
+    quiet = w2.apply_transport(x, ms.unsqueeze(-2), mt.unsqueeze(-2), T.unsqueeze(-3), torch.zeros_like(T).unsqueeze(-3), diag=False)
+    cw_used = Cw + 0.05 * torch.eye(d, dtype=torch.double)          # strictly positive definite, as the sampler requires
+    torch.manual_seed(32)
+    noisy = w2.apply_transport(x, ms.unsqueeze(-2), mt.unsqueeze(-2), T.unsqueeze(-3), cw_used.unsqueeze(-3), diag=False, make_pd=True)
+    out["full/x"], out["full/moved"], out["full/moved_noisy"], out["full/Cw_used"] = npy(x), npy(quiet), npy(noisy), npy(cw_used)
+    save("stochastic.npz", out)
+
+
 def gen_gmm_full():
     """SURVEY 8f-2, full covariances: ``batch_w2_dissimilarity_gaussian`` / ``batch_ot_gmm(diag=False)`` (ot/w2_utils.py:138-270),
     ``gaussian_barycenter`` diagonal and full (w2_utils.py:325-385; the index its fixed point starts from is the one the reference
@@ -993,6 +1033,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic"]
     for w in which:
         globals()["gen_" + w]()

@@ -405,6 +405,24 @@ def transport_operator_full(cov_s: Tensor, cov_t: Tensor, pg_star: float = 0.0) 
     return (1 - pg_star) * (irs @ sqrtm(rs @ cov_t @ rs) @ irs) + pg_star * eye
 
 
+def transport_operator_stochastic(cov_s: Tensor, cov_t: Tensor, pg_star: float = 0.0, diag: bool = False):
+    """``_compute_transport_diag_stochastic`` / ``_compute_transport_full_mat_stochastic`` (ot/w2_utils.py:732-751,771-786),
+    eq. 19: (T, Cw) for a possibly degenerate source."""
+    cov_s, cov_t = cov_s.double(), cov_t.double()
+    if diag:
+        cov_s = torch.where(cov_s < STABILITY_CONST, torch.zeros_like(cov_s), cov_s)
+        t_star = torch.sqrt(cov_s / cov_t + STABILITY_CONST)
+        pinv = torch.where(cov_s > STABILITY_CONST, 1 / cov_s.clamp(min=1e-300), torch.zeros_like(cov_s))
+        T = (1 - pg_star) * torch.sqrt(cov_t * cov_s) * pinv + pg_star
+        return T, math.sqrt(1 - pg_star) * cov_t * (1 - cov_t * pinv * t_star ** 2)
+    eye = torch.eye(cov_s.shape[-1], dtype=cov_s.dtype).expand_as(cov_s)
+    pinv = torch.linalg.pinv(cov_s)
+    rt, irt = sqrtm(cov_t), invsqrtm(cov_t + STABILITY_CONST * eye)
+    t_star = transport_operator_full(cov_t, cov_s, 0.0)
+    T = (1 - pg_star) * (rt @ sqrtm(rt @ cov_s @ rt) @ irt @ pinv) + pg_star * eye
+    return T, math.sqrt(1 - pg_star) * rt @ (eye - rt @ t_star @ pinv @ t_star @ rt) @ rt
+
+
 def apply_transport(x: Tensor, mean_s: Tensor, mean_t: Tensor, T: Tensor) -> Tensor:
     """``apply_transport`` without noise (ot/w2_utils.py:517-520), fp64: T (x - mu_s) + mu_t."""
     x, mean_s, mean_t, T = (t.double() for t in (x, mean_s, mean_t, T))

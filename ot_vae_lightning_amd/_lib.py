@@ -109,6 +109,7 @@ SIGNATURES = {
     "otvae_eigh_onesided_ws": (i64, [i32, i32]),
     "otvae_eigh_fn": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "otvae_make_psd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "otvae_cholesky": (i32, [vp, i32, i32, vp, vp, vp]),
     "otvae_gemm_f64": (i32, [i32, i32, i32, i32, i32, i32, f64, vp, i32, vp, i32, f64, vp, vp]),
     "otvae_w2_tail": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "otvae_apply_transport": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),

@@ -519,6 +519,59 @@ extern "C" int otvae_make_psd(double* A, const double* eigvals, int nb, int D, i
     return OTVAE_OK;
 }
 
+// Lower Cholesky factor A = L L^T (fp64), one workgroup per matrix, left-looking by columns: what MultivariateNormal's sampler
+// factors the noise covariance with (torch.distributions, used by the reference's stochastic apply_transport, ot/w2_utils.py:
+// 521-525).  Column j: L[j][j] = sqrt(A[j][j] - |L[j][:j]|^2), L[i][j] = (A[i][j] - L[i][:j] . L[j][:j]) / L[j][j]; row j of L is
+// staged in LDS for the column's dot products.  info[b] = 1 + index of the first non-positive pivot (0 = success).
+__global__ __launch_bounds__(256) void cholesky_kernel(const double* __restrict__ A, int D, double* __restrict__ L,
+                                                       int* __restrict__ info) {
+    extern __shared__ double chol_row[];  // [D]
+    __shared__ double red[4];
+    __shared__ double s_piv;
+    const double* Ab = A + (size_t)blockIdx.x * D * D;
+    double* Lb = L + (size_t)blockIdx.x * D * D;
+    int bad = 0;
+    for (int j = 0; j < D; ++j) {
+        double s = 0.0;
+        for (int k = threadIdx.x; k < j; k += 256) {
+            const double v = Lb[(size_t)j * D + k];
+            chol_row[k] = v;
+            s = fma(v, v, s);
+        }
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double piv = Ab[(size_t)j * D + j] - ((red[0] + red[1]) + (red[2] + red[3]));
+            s_piv = piv > 0.0 ? sqrt(piv) : NAN;
+        }
+        __syncthreads();
+        const double ljj = s_piv;
+        if (!(ljj > 0.0) && !bad) bad = j + 1;
+        for (int i = j + threadIdx.x; i < D; i += 256) {
+            if (i == j) {
+                Lb[(size_t)j * D + j] = ljj;
+                continue;
+            }
+            double acc = Ab[(size_t)i * D + j];  // lower triangle of A
+            const double* li = Lb + (size_t)i * D;
+            for (int k = 0; k < j; ++k) acc = fma(-li[k], chol_row[k], acc);
+            Lb[(size_t)i * D + j] = acc / ljj;
+        }
+        for (int i = threadIdx.x; i < j; i += 256) Lb[(size_t)i * D + j] = 0.0;  // strict upper triangle
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && info) info[blockIdx.x] = bad;
+}
+
+extern "C" int otvae_cholesky(const double* A, int nb, int D, double* L, int* info, void* stream) {
+    OTVAE_REQUIRE(A && L && nb > 0 && D > 0 && A != L, "otvae_cholesky: bad argument");
+    OTVAE_REQUIRE((size_t)D * 8 <= 64 * 1024, "otvae_cholesky: D = %d exceeds the LDS row buffer (8192)", D);
+    cholesky_kernel<<<nb, 256, (size_t)D * sizeof(double), (hipStream_t)stream>>>(A, D, L, info);
+    OTVAE_CHECK_LAUNCH("otvae_cholesky");
+    return OTVAE_OK;
+}
+
 // ================================================================================================ dense helpers
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int transA, int transB, int m, int n, int k, double alpha,
                                                        const double* __restrict__ A, size_t sA, const double* __restrict__ B,

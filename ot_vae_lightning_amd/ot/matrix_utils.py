@@ -10,7 +10,7 @@ from .. import _lib
 from .._lib import check, ptr, stream
 
 __all__ = ["eye_like", "sqrtm", "invsqrtm", "is_spd", "is_pd", "is_symmetric", "min_eig", "make_psd", "mean_cov",
-           "STABILITY_CONST", "eigvals_and_fn", "matmul64", "eigh_vectors", "spectral_fn", "psd_shift"]
+           "STABILITY_CONST", "eigvals_and_fn", "matmul64", "eigh_vectors", "spectral_fn", "psd_shift", "pinv_sym", "cholesky"]
 
 STABILITY_CONST = 1e-8
 
@@ -63,6 +63,26 @@ def psd_shift(eigvals: Tensor, strict: bool, only_if_needed: bool) -> Tensor:
         bad = ~(lo > 0) if strict else ~(lo >= 0)
         shift = shift * bad.any().to(shift.dtype)
     return shift
+
+
+def pinv_sym(matrices: Tensor) -> Tensor:
+    """Moore-Penrose inverse of symmetric matrices from the eigendecomposition: V diag(1/lambda or 0) V^T with torch.linalg.pinv's
+    default cut-off (|lambda| <= D eps max|lambda| -> 0), which the reference's stochastic operator applies to the source
+    covariance (ot/w2_utils.py:779)."""
+    lam, vt = eigh_vectors(matrices)
+    d = matrices.shape[-1]
+    cut = d * torch.finfo(torch.float64).eps * lam.abs().max(-1, keepdim=True)[0]
+    inv = torch.where(lam.abs() > cut, 1.0 / lam, torch.zeros_like(lam))
+    return spectral_fn(inv, vt).to(matrices.dtype)
+
+
+def cholesky(matrices: Tensor) -> Tensor:
+    """lower Cholesky factor [*, D, D] (fp64 on the device; NaN where a matrix is not positive definite)"""
+    lib = _lib.load()
+    a, lead = _as_batch(matrices)
+    out = torch.empty_like(a)
+    check(lib.otvae_cholesky(ptr(a), a.shape[0], a.shape[-1], ptr(out), None, stream()), "otvae_cholesky")
+    return out.reshape(*lead, a.shape[-1], a.shape[-1])
 
 
 def eye_like(matrices: Tensor) -> Tensor:

@@ -3,6 +3,7 @@
 ``apply_transport`` (:464-527), ``batch_w2_dissimilarity_gaussian_diag`` (:86-134), ``W2Mixin`` (:533-600).
 Out of scope for this path: GMM transport (``batch_ot_gmm``), barycenters, the stochastic
 (eq. 19) operators -- they raise ``NotImplementedError``."""
+import math
 import warnings
 from functools import partial
 from typing import Optional, Tuple, Union
@@ -14,7 +15,7 @@ from torch import Tensor
 from .. import _lib
 from .._lib import check, ptr, stream
 from .matrix_utils import *  # noqa: F401,F403
-from .matrix_utils import (STABILITY_CONST, eigh_vectors, eigvals_and_fn, eye_like, is_symmetric, matmul64, mean_cov, psd_shift,
+from .matrix_utils import (STABILITY_CONST, cholesky, pinv_sym, spectral_fn, eigh_vectors, eigvals_and_fn, eye_like, is_symmetric, matmul64, mean_cov, psd_shift,
                            spectral_fn)
 
 __all__ = ["w2_gaussian", "batch_w2_dissimilarity_gaussian_diag", "batch_w2_dissimilarity_gaussian", "gaussian_barycenter", "batch_ot_gmm", "sinkhorn_log", "sinkhorn_log_potentials",
@@ -278,12 +279,60 @@ def batch_ot_gmm(mean_source: Tensor, mean_target: Tensor, cov_source: Tensor, c
     return torch.sum(cost * coupling, dim=(-2, -1)), coupling
 
 
+def _stochastic_operators_diag(cs: Tensor, ct: Tensor, pg_star: float) -> Tuple[Tensor, Tensor]:
+    """eq. 19 for diagonal covariances (reference ot/w2_utils.py:732-751)"""
+    t_star = torch.sqrt(cs / ct + STABILITY_CONST)
+    big = cs > STABILITY_CONST
+    pinv = torch.where(big, 1.0 / torch.where(big, cs, torch.ones_like(cs)), torch.zeros_like(cs))
+    T = (1 - pg_star) * torch.sqrt(ct * cs) * pinv + pg_star
+    return T, math.sqrt(1 - pg_star) * ct * (1 - ct * pinv * t_star ** 2)
+
+
+def _stochastic_operators_full(cs: Tensor, ct: Tensor, pg_star: float) -> Tuple[Tensor, Tensor]:
+    """eq. 19 for full matrices [nb, D, D] (reference ot/w2_utils.py:771-786): the source may be rank deficient (pseudo-inverse),
+    T = (1-pg) Ct^1/2 (Ct^1/2 Cs Ct^1/2)^1/2 Ct^-1/2 Cs^+ + pg I;  Cw = sqrt(1-pg) Ct^1/2 (I - Ct^1/2 T* Cs^+ T* Ct^1/2) Ct^1/2 with
+    T* the eq. 17 operator from the target to the source.  One decomposition of Ct serves its three functions."""
+    eye = eye_like(cs)
+    pinv_s = pinv_sym(cs)
+    lam_t, vt_t = eigh_vectors(ct)
+    rt = spectral_fn(lam_t.sqrt(), vt_t)
+    irt = spectral_fn((lam_t + STABILITY_CONST).rsqrt(), vt_t)
+    inner = eigvals_and_fn(matmul64(matmul64(rt, cs), rt), 1)[1]
+    t_star = matmul64(matmul64(irt, inner), irt)
+    T = (1 - pg_star) * matmul64(matmul64(matmul64(rt, inner), irt), pinv_s) + pg_star * eye
+    core = eye - matmul64(matmul64(matmul64(matmul64(rt, t_star), pinv_s), t_star), rt)
+    return T, math.sqrt(1 - pg_star) * matmul64(matmul64(rt, core), rt)
+
+
 def compute_transport_operators(cov_source: Tensor, cov_target: Tensor, stochastic: bool, diag: bool,
                                 pg_star: float = 0, make_pd: bool = False, verbose: bool = False,
                                 dtype=torch.double) -> Tuple[Tensor, Tensor]:
-    """Eq. 17 of Freirich et al.: T = (1-pg) Cs^-1/2 (Cs^1/2 Ct Cs^1/2)^1/2 Cs^-1/2 + pg I  (and Cw = 0)."""
+    """Eq. 17 / eq. 19 of Freirich et al. (reference ot/w2_utils.py:391-458): (T, Cw).  Non-stochastic:
+    T = (1-pg) Cs^-1/2 (Cs^1/2 Ct Cs^1/2)^1/2 Cs^-1/2 + pg I, Cw = 0.  Stochastic: the operator that also handles a degenerate
+    source, with the noise covariance Cw; as in the reference, a noise covariance that is not positive definite falls back to
+    eq. 17 only when ``verbose`` is set (the fallback sits behind the same condition as its warning)."""
     if stochastic:
-        raise NotImplementedError("stochastic transport operators (eq. 19) are outside the MI355X hot path")
+        if diag:
+            cs, ct = cov_source.to(dtype).clone(), cov_target.to(dtype)
+            cs[cs < STABILITY_CONST] = 0
+            if (cs < 0).any() or (ct < 0).any():
+                raise ValueError("variances are expected to have positive entries.")
+            T, Cw = _stochastic_operators_diag(cs, ct, pg_star)
+            if bool((Cw <= 0).any()) and verbose:
+                warnings.warn("The noise covariance matrix is not positive definite. Falling back to the non-stochastic implementation")
+                return compute_transport_operators(cs, ct, False, True, pg_star, make_pd, verbose, dtype)
+            return T, Cw
+        d = cov_source.shape[-1]
+        lead = torch.broadcast_shapes(cov_source.shape[:-2], cov_target.shape[:-2])
+        flat = lambda m: m.double().expand(*lead, d, d).reshape(-1, d, d).contiguous()  # noqa: E731
+        cs = _require_spd(flat(cov_source), "cov_source", make_pd, False, verbose)           # 'spsd'
+        ct = _require_spd(flat(cov_target), "cov_target", make_pd, True, verbose)            # 'spd'
+        T, Cw = _stochastic_operators_full(cs, ct, pg_star)
+        if verbose and not bool(torch.logical_and(is_symmetric(Cw), eigvals_and_fn(Cw, 0)[0].min(-1)[0] > 0).all()):
+            warnings.warn("The noise covariance matrix is not positive definite. Falling back to the non-stochastic implementation")
+            return compute_transport_operators(cs.reshape(*lead, d, d), ct.reshape(*lead, d, d), False, False, pg_star, make_pd,
+                                               verbose, dtype)
+        return T.reshape(*lead, d, d).to(dtype), Cw.reshape(*lead, d, d).to(dtype)
     if diag:
         cs, ct = cov_source.to(dtype), cov_target.to(dtype)
         if (cs < 0).any() or (ct < 0).any():
@@ -351,12 +400,32 @@ def w2_and_transport_operator(mean_source: Tensor, mean_target: Tensor, spec_sou
     return w2.reshape(lead), T, torch.zeros_like(T)
 
 
+def _transport_noise(shape, Cw: Tensor, diag: bool, make_pd: bool, noise_eps: Optional[Tensor], dtype) -> Tensor:
+    """W ~ N(0, Cw) as the reference draws it (ot/w2_utils.py:521-525): diagonal: ``Normal(0, Cw)`` -- Cw is handed over as the
+    SCALE --, full: ``MultivariateNormal(0, Cw)`` = chol(Cw) eps.  ``noise_eps``: the standard-normal draws to use (parity
+    tests); otherwise drawn on the device."""
+    Cw = Cw.to(dtype)
+    if diag:
+        if bool((Cw < 0).any()):
+            raise ValueError("`Cw` is expected to be a valid variance vector with positive entries.")
+        eps = noise_eps.to(Cw) if noise_eps is not None else torch.randn(shape, device=Cw.device, dtype=dtype)
+        return Cw * eps
+    d = Cw.shape[-1]
+    cw = _require_spd(Cw.double().reshape(-1, d, d).contiguous(), "Cw", make_pd, True, False).reshape(Cw.shape)
+    L = cholesky(cw)
+    eps = noise_eps.to(L) if noise_eps is not None else torch.randn(shape, device=Cw.device, dtype=torch.double)
+    return (L @ eps.unsqueeze(-1)).squeeze(-1).to(dtype)
+
+
 def apply_transport(input: Tensor, mean_source: Tensor, mean_target: Tensor, T: Tensor, Cw: Optional[Tensor] = None,
-                    diag: bool = False, make_pd: bool = False, verbose: bool = False, dtype=torch.double) -> Tensor:
-    """T (x - mean_source) + mean_target, computed in fp64; returns ``dtype``.  input [*, B, D] against
-    [*, D]/[*, D, D] operators (already unsqueezed by the caller like the reference) or matching shapes."""
+                    diag: bool = False, make_pd: bool = False, verbose: bool = False, dtype=torch.double,
+                    noise_eps: Optional[Tensor] = None) -> Tensor:
+    """T (x - mean_source) + mean_target (+ W, W ~ N(0, Cw), when a non-zero noise covariance comes with a stochastic operator),
+    computed in fp64; returns ``dtype``.  input [*, B, D] against [*, D]/[*, D, D] operators (already unsqueezed by the caller
+    like the reference) or matching shapes."""
     if Cw is not None and bool((Cw != 0).any()):
-        raise NotImplementedError("stochastic transport (non-zero Cw) is outside the MI355X hot path")
+        moved = apply_transport(input, mean_source, mean_target, T, None, diag, make_pd, verbose, dtype)
+        return moved + _transport_noise(moved.shape, Cw, diag, make_pd, noise_eps, dtype)
     if diag:
         return (T.to(dtype) * (input.to(dtype) - mean_source.to(dtype)) + mean_target.to(dtype))
     lib = _lib.load()
@@ -431,14 +500,14 @@ class W2Mixin(object):
                            make_pd=self.make_pd, verbose=self.verbose, dtype=self.dtype)
 
     def apply_transport(self, inputs: Tensor, mean_source: Tensor, mean_target: Tensor, T: Tensor, Cw: Tensor,
-                        batch_dim: Optional[int] = None) -> Tensor:
+                        batch_dim: Optional[int] = None, noise_eps: Optional[Tensor] = None) -> Tensor:
         return apply_transport(
             inputs,
             mean_source.unsqueeze(batch_dim) if batch_dim is not None else mean_source,
             mean_target.unsqueeze(batch_dim) if batch_dim is not None else mean_target,
             T.unsqueeze(batch_dim - bool(not self.diag)) if batch_dim is not None else T,
             Cw.unsqueeze(batch_dim - bool(not self.diag)) if (batch_dim is not None and Cw is not None) else Cw,
-            diag=self.diag, make_pd=self.make_pd, verbose=self.verbose, dtype=self.dtype)
+            diag=self.diag, make_pd=self.make_pd, verbose=self.verbose, dtype=self.dtype, noise_eps=noise_eps)
 
     def __repr__(self):
         return ", ".join(f"{k}={v}" for k, v in self._orig_kwargs.items())

@@ -515,6 +515,51 @@ def test_block_jacobi_eigh_large_D(A, D):
     rep.finish()
 
 
+def test_stochastic_transport_operator_vs_reference_golden(A):
+    """eq. 19 of Freirich et al. (reference ot/w2_utils.py:391-458,732-786): the stochastic operator (T, Cw) for degenerate /
+    nearly degenerate sources, diagonal and full (pseudo-inverse and the three functions of the target covariance from
+    eigendecompositions), and ``apply_transport`` with noise: the reference's draw is recovered from its noisy output
+    (eps = chol(Cw)^-1 noise, resp. noise / Cw) and injected, so the device Cholesky factor is what is being compared."""
+    from ot_vae_lightning_amd.ot import w2_utils as W
+    from ot_vae_lightning_amd.ot import matrix_utils as MU
+    G = load_golden("stochastic.npz")
+    rep = Report("stochastic transport operator (eq. 19) vs reference golden")
+    d_, f_ = group(G, "diag"), group(G, "full")
+    T, Cw = W.compute_transport_operators(d_["cs"].cuda(), d_["ct"].cuda(), stochastic=True, diag=True, pg_star=0.2, make_pd=True)
+    rep.check("diag: T", T, d_["T"], 1e-12)
+    rep.check("diag: Cw", Cw, d_["Cw"], 1e-9)
+    ms, mt = d_["ms"].cuda(), d_["mt"].cuda()
+    eps = (d_["moved_noisy"] - d_["moved"]) / d_["Cw_used"].unsqueeze(-2)
+    moved = W.apply_transport(d_["x"].cuda(), ms.unsqueeze(-2), mt.unsqueeze(-2), T.unsqueeze(-2), d_["Cw_used"].cuda().unsqueeze(-2),
+                              diag=True, noise_eps=eps.cuda())
+    rep.check("diag: noisy transport", moved, d_["moved_noisy"], 1e-12)
+    T, Cw = W.compute_transport_operators(f_["cs"].cuda(), f_["ct"].cuda(), stochastic=True, diag=False, pg_star=0.1, make_pd=True)
+    rep.check("full: T", T, f_["T"], 1e-7)
+    # Cw = Ct^1/2 (I - Ct^1/2 T* Cs^+ T* Ct^1/2) Ct^1/2 cancels to O(1) from terms of size 1e6 at this nearly singular source: a 1e-15
+    # relative perturbation of Cs moves the REFERENCE's own Cw by 1.4e-4 ... 3.6e-4 (measured with the oracle on the CPU)
+    rep.check("full: Cw", Cw, f_["Cw"], 1e-3)
+    L_ref = torch.linalg.cholesky(f_["Cw_used"])
+    rep.check("cholesky kernel", MU.cholesky(f_["Cw_used"].cuda()), L_ref, 1e-13)
+    noise = f_["moved_noisy"] - f_["moved"]                                        # [2, 9, 6]
+    eps = torch.linalg.solve_triangular(L_ref.unsqueeze(-3), noise.unsqueeze(-1), upper=False).squeeze(-1)
+    moved = W.apply_transport(f_["x"].cuda(), ms.unsqueeze(-2), mt.unsqueeze(-2), f_["T"].cuda().unsqueeze(-3),
+                              f_["Cw_used"].cuda().unsqueeze(-3), diag=False, make_pd=True, noise_eps=eps.cuda())
+    rep.check("full: noisy transport", moved, f_["moved_noisy"], 1e-11)
+    free = W.apply_transport(f_["x"].cuda(), ms.unsqueeze(-2), mt.unsqueeze(-2), f_["T"].cuda().unsqueeze(-3),
+                             f_["Cw_used"].cuda().unsqueeze(-3), diag=False, make_pd=True)       # drawn on the device
+    assert free.shape == moved.shape and torch.isfinite(free).all() and not torch.equal(free, moved)
+    # through the operator class: a stochastic GaussianTransport computes and transports
+    op = A.GaussianTransport(6, source_cfg=dict(dtype=torch.double), target_cfg=dict(dtype=torch.double),
+                             transport_cfg=dict(diag=False, stochastic=True, pg_star=0.1, make_pd=True, verbose=False, dtype=torch.double)).cuda()
+    g = torch.Generator().manual_seed(5)
+    op.update(source_samples=(torch.randn(400, 6, generator=g, dtype=torch.double) * torch.tensor([1, 1, 1, 1e-3, 1e-3, 1e-3])).cuda(),
+              target_samples=torch.randn(400, 6, generator=g, dtype=torch.double).cuda() + 1.0)
+    assert torch.isfinite(op.compute()).all() and op.cov_stochastic_noise is not None
+    out = op.transport(torch.randn(16, 6, generator=g, dtype=torch.double).cuda())
+    assert out.shape == (16, 6) and torch.isfinite(out).all()
+    rep.finish()
+
+
 @pytest.mark.parametrize("solver", ["one_sided", "two_sided"])
 def test_small_eigh_solvers_vs_lapack(A, solver, monkeypatch):
     """The D <= 128 eigensolvers (one-sided Hestenes Jacobi with replayed rotations, the default; the first-generation two-sided

@@ -655,3 +655,13 @@ def test_full_covariance_mixture_functions_vs_reference():
         g = group(G, tag)
         e = O.gmm_full_energy(g["batches"][-1], g["fit/mean"], g["fit/cov"], g["fit/weights"])
         assert rel_err(e, g["energy"]) < 1e-7    # the stored covariance is read back + 1e-8 by the model's parametrisation
+
+
+def test_stochastic_transport_operator_vs_reference():
+    """tests/golden/stochastic.npz: eq. 19 operators for (nearly) degenerate sources, diagonal and full."""
+    G = load_golden("stochastic.npz")
+    d_, f_ = group(G, "diag"), group(G, "full")
+    T, Cw = O.transport_operator_stochastic(d_["cs"], d_["ct"], 0.2, diag=True)
+    assert rel_err(T, d_["T"]) < 1e-12 and rel_err(Cw, d_["Cw"]) < 1e-10
+    T, Cw = O.transport_operator_stochastic(f_["cs"], f_["ct"], 0.1, diag=False)
+    assert rel_err(T, f_["T"]) < 1e-8 and rel_err(Cw, f_["Cw"]) < 1e-7
