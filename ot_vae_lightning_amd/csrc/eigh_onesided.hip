@@ -2,21 +2,32 @@
 // Replaces torch.linalg.eigh inside the reference's sqrtm / invsqrtm / min_eig (ot/matrix_utils.py:37-46,91-109).
 //
 // Why one-sided: the two-sided form (gaussian_ot.hip: eigh_kernel) rotates rows AND columns of A in LDS and the rows of V^T in
-// global memory every step -- three barriers and a dependent global round trip per step, 8.6 us per step, 11 ms per
-// 128 x 128 matrix.  Here G = A V is the only matrix the iteration touches: a step orthogonalises De/2 disjoint column
-// pairs of G (round-robin tournament), one barrier per step, everything in LDS (G is 128 KB at D = 128).  The rotations are
-// NOT applied to V inside the loop: they are logged (16 bytes per pair and step), and a second kernel replays the log on
-// the rows of V = I, which are independent of each other -- D waves, each with its row in LDS, 64 disjoint rotations per
-// step handled by the 64 lanes.  Eigenvalues are lambda_k = v_k . g_k (signed: indefinite and singular matrices are fine),
-// f(A) = V f(Lambda) V^T is one product.  Arithmetic is fp64 throughout; the iteration ends after the first sweep without a
-// rotation.  A matrix with a negative diagonal entry (certainly indefinite) is solved as A + |A|_inf I and the shift taken
-// off the eigenvalues: one-sided Jacobi sees A^2, in which +lambda and -lambda of equal magnitude are a double eigenvalue.
+// global memory every step -- three barriers and a dependent global round trip per step, 8.6 us per step, 10 ms per
+// 128 x 128 matrix.  Here G = A V is the only matrix the iteration touches, one barrier per step, everything on chip:
+//   * odd-even ordering with unconditional swaps: the n = 2 ceil(D/2) columns sit at positions 0..n-1; even steps orthogonalise
+//     the position pairs (0,1)(2,3)..., odd steps (1,2)(3,4)...; after its rotation a pair's two columns trade places, so
+//     that n steps reverse the order and every two columns have met exactly once (a sweep);
+//   * a group of L lanes owns pair slot i and KEEPS the column at position 2i+1 in registers across steps; the other column
+//     of its pair comes from LDS and one result goes back to LDS for the neighbouring slot: one column read + one written
+//     per slot and step -- half the LDS traffic of a scheme that keeps both columns in LDS, and LDS bandwidth is what
+//     bounds the iteration (fp64, 128 KB per pass at D = 128);
+//   * the rotations are NOT applied to V inside the loop: they are logged (16 bytes per pair and step) and a second kernel
+//     replays the log on the rows of V = I, which are independent of each other -- D waves, each with its row in LDS, the
+//     64 lanes take the 64 disjoint pairs of a step;
+//   * eigenvalues are lambda_k = v_k . g_k (signed: indefinite and singular matrices are fine), f(A) = V f(Lambda) V^T is
+//     one product.  A matrix with a negative diagonal entry (certainly indefinite) is solved as A + |A|_inf I and the shift
+//     taken off the eigenvalues: one-sided Jacobi sees A^2, in which +lambda and -lambda of equal size are a double eigenvalue.
+// Arithmetic is fp64 throughout; the iteration ends after the first sweep without a rotation.
+#include <type_traits>
 #include "common.h"
 
 #define HJ_MAX_SWEEPS 24
-// a pair is rotated while |g_p . g_q| > tol |g_p| |g_q| with tol = 2e-14 (LAPACK's one-sided Jacobi, dgesvj, uses sqrt(M) eps =
-// 2.5e-15 at M = 128; at 1e-15 rounding noise re-triggers rotations sweep after sweep and the solver never sees a quiet sweep)
-#define HJ_TOL2 4e-28
+// A pair is rotated whenever |g_p . g_q| > 1e-15 |g_p| |g_q| (every rotation refines), but only a pair above 1e-13 keeps the
+// iteration going: the computed inner product of two 128-vectors carries rounding noise of up to D eps = 3e-14 of
+// |g_p| |g_q|, so a threshold at that level is re-triggered sweep after sweep and the solver never sees a quiet sweep
+// (LAPACK's dgesvj stops at M eps = 1.4e-14 of its own arithmetic; the stop level here leaves eigenvectors good to ~1e-13).
+#define HJ_TOL2 1e-30
+#define HJ_STOP2 1e-26
 
 struct HjCtl {
     int steps;   // steps whose rotations are in the log
@@ -24,58 +35,31 @@ struct HjCtl {
     double shift;  // added to the diagonal before the iteration (0 unless some diagonal entry was negative)
 };
 
-// seats (unordered) of slot k at `step`: slot 0 keeps player De - 1 and meets step % m; slot k > 0 holds (step + k) % m and
-// (step - k) % m.  From one step to the next every moving seat advances by one (mod m).
-__device__ __forceinline__ void hj_seats(int step, int k, int De, int& a, int& b) {
-    const int m = De - 1;
-    if (k == 0) {
-        a = m;
-        b = step % m;
-    } else {
-        a = (step + k) % m;
-        b = (step - k + m) % m;
-    }
-}
-
-__device__ __forceinline__ void hj_pair(int step, int k, int De, int& p, int& q) {
-    const int m = De - 1;
-    if (k == 0) {
-        p = m;
-        q = step % m;
-    } else {
-        p = (step + k) % m;
-        q = (step - k + m) % m;
-    }
-    if (p > q) {
-        const int t = p;
-        p = q;
-        q = t;
-    }
+static __host__ __device__ inline size_t hj_per_matrix(int D) {
+    const size_t n = (size_t)((D + 1) & ~1), half = n / 2;
+    return ((4 * n * n * 8 + (size_t)HJ_MAX_SWEEPS * n * half * 16 + 256) + 255) & ~(size_t)255;
 }
 
 extern "C" int64_t otvae_eigh_onesided_ws(int nb, int D) {
-    const int De = (D + 1) & ~1, half = De / 2;
-    const int64_t per = 4 * (int64_t)D * D * 8 + (int64_t)HJ_MAX_SWEEPS * (De - 1) * half * 16 + 256;
     if (nb <= 0 || D <= 0) return -1;
-    return (int64_t)nb * ((per + 255) & ~(int64_t)255);
+    return (int64_t)nb * (int64_t)hj_per_matrix(D);
 }
 
 struct HjWs {
-    double *G, *V, *W, *T;
+    double *G, *V, *W, *T;  // G[pos][D] (n x D), V[i][pos] and W[i][pos] (D x n), T[k][D]
     double2* log;
     HjCtl* ctl;
 };
 __host__ __device__ static inline HjWs hj_ws(void* ws, int b, int D) {
-    const int De = (D + 1) & ~1, half = De / 2;
-    const size_t per = ((4 * (size_t)D * D * 8 + (size_t)HJ_MAX_SWEEPS * (De - 1) * half * 16 + 256) + 255) & ~(size_t)255;
-    char* w = (char*)ws + (size_t)b * per;
+    const size_t n = (size_t)((D + 1) & ~1), half = n / 2;
+    char* w = (char*)ws + (size_t)b * hj_per_matrix(D);
     HjWs r;
     r.G = (double*)w;
-    r.V = r.G + (size_t)D * D;
-    r.W = r.V + (size_t)D * D;
-    r.T = r.W + (size_t)D * D;
-    r.log = (double2*)(r.T + (size_t)D * D);
-    r.ctl = (HjCtl*)((char*)r.log + (size_t)HJ_MAX_SWEEPS * (De - 1) * half * 16);
+    r.V = r.G + n * n;
+    r.W = r.V + n * n;
+    r.T = r.W + n * n;
+    r.log = (double2*)(r.T + n * n);
+    r.ctl = (HjCtl*)((char*)r.log + (size_t)HJ_MAX_SWEEPS * n * half * 16);
     return r;
 }
 
@@ -112,25 +96,25 @@ __device__ __forceinline__ double nr_rsq(double x) {
     return y * fma(-h * y, y, 1.5);
 }
 
-// one workgroup of 512 threads per matrix: L lanes per column pair (8 for D > 64: 64 pairs; 16 below), rows strided by L
+// one workgroup of 512 threads per matrix: L lanes per pair slot (8 for D > 64: 64 slots; 16 below), rows strided by L
 template <int L>
 __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict__ Ain, int D, void* __restrict__ ws) {
     extern __shared__ __align__(16) double hj_lds[];
     __shared__ int s_rot;
-    constexpr int R = 128 / L;  // rows per lane at most (D <= 128 for L = 8, D <= 64 for L = 16 -> R = 16 / 4 used)
-    const int De = (D + 1) & ~1, half = De / 2, LD = D + 1;
+    __shared__ double s_red[8], s_shift;
+    constexpr int R = 128 / L;  // rows per lane at most (D <= 128 for L = 8; D <= 64 for L = 16 uses 4 of its 8)
+    const int n = (D + 1) & ~1, half = n / 2, LD = D + 1;
     const HjWs w = hj_ws(ws, blockIdx.x, D);
     const double* Ab = Ain + (size_t)blockIdx.x * D * D;
-    double* G = hj_lds;  // column major: G[col * LD + row]
+    double* G = hj_lds;  // published columns by POSITION: G[pos * LD + row]
     const int tid = threadIdx.x, grp = tid / L, r = tid % L;
-    for (int e = tid; e < D * D; e += 512) {
-        const int i = e / D, j = e - i * D;  // reads the lower triangle, like torch.linalg.eigh(UPLO='L')
-        G[j * LD + i] = (i >= j) ? Ab[(size_t)i * D + j] : Ab[(size_t)j * D + i];
+    for (int e = tid; e < n * D; e += 512) {
+        const int j = e / D, i = e - j * D;  // position j (= column j at the start), row i; lower triangle, like eigh(UPLO='L')
+        G[j * LD + i] = j < D ? ((i >= j) ? Ab[(size_t)i * D + j] : Ab[(size_t)j * D + i]) : 0.0;  // odd D: a zero dummy column
     }
     if (tid == 0) s_rot = 0;
     __syncthreads();
     // certainly indefinite (a negative diagonal entry): shift by the infinity norm, so that the spectrum becomes non-negative
-    __shared__ double s_red[8], s_shift;
     {
         double mind = INFINITY, rsum = 0.0;
         for (int i = tid; i < D; i += 512) {
@@ -160,63 +144,77 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
         __syncthreads();
     }
     const int nrow = (D + L - 1) / L;
+    const bool active = grp < half;
+    const int kpos = 2 * grp + 1;  // the position whose column this slot keeps in registers
+    double keep[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int i = r + L * u;
+        keep[u] = (active && u < nrow && i < D) ? G[kpos * LD + i] : 0.0;
+    }
     int gstep = 0, sweep = 0;
-    // round-robin seats of this slot without a modulo per step: both move one seat forward (mod De - 1) every step
-    const int m = De - 1;
-    int sp, sq;
-    hj_seats(0, grp < half ? grp : 0, De, sp, sq);
-    for (; sweep < HJ_MAX_SWEEPS; ++sweep) {
-        for (int step = 0; step < De - 1; ++step, ++gstep) {
-            const int p = sp < sq ? sp : sq, q = sp < sq ? sq : sp;
-            if (grp != 0) sp = sp + 1 == m ? 0 : sp + 1;
-            sq = sq + 1 == m ? 0 : sq + 1;
-            if (grp < half) {
-                double c = 1.0, s = 0.0;
-                if (q < D) {
-                    double a[R], b[R], alpha = 0.0, beta = 0.0, gamma = 0.0;
-                    double* gp = G + p * LD;
-                    double* gq = G + q * LD;
+    // one step; ODD is a compile-time constant so that the roles of the kept / fetched column cost no selects:
+    // even step: pair (2g, 2g+1): the kept column is the UPPER one (q), the lower (p) comes from LDS position 2g;
+    // odd step:  pair (2g+1, 2g+2): the kept column is the LOWER one (p), the upper (q) comes from LDS position 2g+2.
+    // p' = c p - s q, q' = s p + c q, then the two trade places: position j <- q', position j + 1 <- p'.
+    // even: the kept position 2g+1 = j+1 takes p', q' is published at 2g;  odd: the kept position 2g+1 = j takes q', p' at 2g+2.
+    auto step = [&](auto odd_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value;
+        const int opos = ODD ? kpos + 1 : kpos - 1;
+        if (active && opos < n) {
+            double other[R], kk = 0.0, oo = 0.0, gamma = 0.0;
+            double* go = G + opos * LD;
 #pragma unroll
-                    for (int u = 0; u < R; ++u) {
-                        const int i = r + L * u;
-                        const bool ok = u < nrow && i < D;
-                        a[u] = ok ? gp[i] : 0.0;
-                        b[u] = ok ? gq[i] : 0.0;
-                        alpha = fma(a[u], a[u], alpha);
-                        beta = fma(b[u], b[u], beta);
-                        gamma = fma(a[u], b[u], gamma);
-                    }
-                    alpha = group_sum<L>(alpha);
-                    beta = group_sum<L>(beta);
-                    gamma = group_sum<L>(gamma);
-                    const double ab = alpha * beta;
-                    if (gamma * gamma > HJ_TOL2 * ab && ab > 1e-280) {
-                        const double zeta = (beta - alpha) * 0.5 * nr_rcp(gamma);
-                        const double az = fabs(zeta);
-                        double t;
-                        if (az > 1e8) {
-                            t = 0.5 * nr_rcp(zeta);  // |zeta| + sqrt(1 + zeta^2) = 2 |zeta| to rounding
-                        } else {
-                            const double q2 = fma(zeta, zeta, 1.0);
-                            t = nr_rcp(az + q2 * nr_rsq(q2));
-                            t = zeta >= 0.0 ? t : -t;
-                        }
-                        c = nr_rsq(fma(t, t, 1.0));
-                        s = c * t;
-#pragma unroll
-                        for (int u = 0; u < R; ++u) {
-                            const int i = r + L * u;
-                            if (u < nrow && i < D) {
-                                gp[i] = c * a[u] - s * b[u];
-                                gq[i] = s * a[u] + c * b[u];
-                            }
-                        }
-                        if (r == 0) s_rot = 1;  // benign race: every writer stores 1
-                    }
-                }
-                if (r == 0) w.log[(size_t)gstep * half + grp] = make_double2(c, s);
+            for (int u = 0; u < R; ++u) {
+                const int i = r + L * u;
+                other[u] = (u < nrow && i < D) ? go[i] : 0.0;
+                kk = fma(keep[u], keep[u], kk);
+                oo = fma(other[u], other[u], oo);
+                gamma = fma(keep[u], other[u], gamma);
             }
-            __syncthreads();
+            kk = group_sum<L>(kk);
+            oo = group_sum<L>(oo);
+            gamma = group_sum<L>(gamma);
+            const double alpha = ODD ? kk : oo, beta = ODD ? oo : kk;  // |p|^2 (lower position), |q|^2 (upper)
+            double c = 1.0, s = 0.0;
+            const double ab = alpha * beta;
+            if (gamma * gamma > HJ_TOL2 * ab && ab > 1e-280) {
+                const double zeta = (beta - alpha) * 0.5 * nr_rcp(gamma);
+                const double az = fabs(zeta);
+                double tt;
+                if (az > 1e8) {
+                    tt = 0.5 * nr_rcp(zeta);  // |zeta| + sqrt(1 + zeta^2) = 2 |zeta| to rounding
+                } else {
+                    const double q2 = fma(zeta, zeta, 1.0);
+                    tt = nr_rcp(az + q2 * nr_rsq(q2));
+                    tt = zeta >= 0.0 ? tt : -tt;
+                }
+                c = nr_rsq(fma(tt, tt, 1.0));
+                s = c * tt;
+                if (r == 0 && gamma * gamma > HJ_STOP2 * ab) s_rot = 1;  // benign race: every writer stores 1
+            }
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int i = r + L * u;
+                double pub;
+                if (ODD) {  // p = keep, q = other
+                    pub = c * keep[u] - s * other[u];      // p' -> position 2g+2
+                    keep[u] = s * keep[u] + c * other[u];  // q' -> kept position
+                } else {    // p = other, q = keep
+                    pub = s * other[u] + c * keep[u];      // q' -> position 2g
+                    keep[u] = c * other[u] - s * keep[u];  // p' -> kept position
+                }
+                if (u < nrow && i < D) go[i] = pub;
+            }
+            if (r == 0) w.log[(size_t)gstep * half + grp] = make_double2(c, s);
+        }
+        __syncthreads();
+        ++gstep;
+    };
+    for (; sweep < HJ_MAX_SWEEPS; ++sweep) {
+        for (int t = 0; t < n; t += 2) {
+            step(std::false_type{});
+            step(std::true_type{});
         }
         const int rotated = s_rot;  // read by every thread after the step's barrier
         __syncthreads();
@@ -227,9 +225,17 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
         if (tid == 0) s_rot = 0;
         __syncthreads();
     }
-    for (int e = tid; e < D * D; e += 512) {
+    // odd positions live in the slots' registers, even positions in LDS
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int i = r + L * u;
+            if (u < nrow && i < D) w.G[(size_t)kpos * D + i] = keep[u];
+        }
+    }
+    for (int e = tid; e < half * D; e += 512) {
         const int k = e / D, i = e - k * D;
-        w.G[e] = G[k * LD + i];  // column k contiguous
+        w.G[(size_t)(2 * k) * D + i] = G[(2 * k) * LD + i];
     }
     if (tid == 0) {
         w.ctl->steps = gstep;
@@ -238,63 +244,82 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
     }
 }
 
-// V = J_1 J_2 ... applied to the rows of the identity: a wave per row, its row in LDS, lane k replays pair slot k
+// V = J_1 J_2 ... applied to the rows of the identity: a wave per row, its row (by position) in LDS, lane k replays slot k:
+// the same rotation and the same exchange of places as the columns of G underwent
 __global__ __launch_bounds__(256) void hj_vectors_kernel(int D, void* __restrict__ ws) {
     __shared__ double rows[4][130];
-    const int De = (D + 1) & ~1, half = De / 2;
+    const int n = (D + 1) & ~1, half = n / 2;
     const HjWs w = hj_ws(ws, blockIdx.y, D);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wv;
     double* row = rows[wv];
-    for (int k = lane; k < De; k += 64) row[k] = (k == i) ? 1.0 : 0.0;
+    for (int k = lane; k < n; k += 64) row[k] = (k == i) ? 1.0 : 0.0;
     const int steps = w.ctl->steps;
     __syncthreads();
     double2 cs = (lane < half && steps > 0) ? w.log[lane] : make_double2(1.0, 0.0);
-    const int m = De - 1;
-    int sp, sq;
-    hj_seats(0, lane < half ? lane : 0, De, sp, sq);
     volatile double* vrow = row;  // the wave's own row: LDS operations of one wave execute in order, no workgroup barrier
     for (int st = 0; st < steps; ++st) {
         const double2 cur = cs;
         if (lane < half && st + 1 < steps) cs = w.log[(size_t)(st + 1) * half + lane];  // next step's pair, in flight
-        const int p = sp < sq ? sp : sq, q = sp < sq ? sq : sp;
-        if (lane != 0) sp = sp + 1 == m ? 0 : sp + 1;
-        sq = sq + 1 == m ? 0 : sq + 1;
-        if (lane < half && cur.y != 0.0) {
-            const double vp = vrow[p], vq = vrow[q];
-            vrow[p] = cur.x * vp - cur.y * vq;
-            vrow[q] = cur.y * vp + cur.x * vq;
+        const int j = 2 * lane + (st & 1);  // n is even: the parity of the step within its sweep is the parity of st
+        if (lane < half && j + 1 < n) {
+            const double vp = vrow[j], vq = vrow[j + 1];
+            vrow[j] = cur.y * vp + cur.x * vq;      // q' moves down
+            vrow[j + 1] = cur.x * vp - cur.y * vq;  // p' moves up
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     if (i < D)
-        for (int k = lane; k < D; k += 64) {
+        for (int k = lane; k < n; k += 64) {
             const double v = row[k];
-            w.V[(size_t)i * D + k] = v;
-            w.W[(size_t)i * D + k] = v * w.G[(size_t)k * D + i];  // summed over i by hj_finish_kernel: lambda_k = v_k . g_k
+            w.V[(size_t)i * n + k] = v;
+            w.W[(size_t)i * n + k] = v * w.G[(size_t)k * D + i];  // summed over i by hj_finish_kernel: lambda = v . g
         }
 }
 
-// eigenvalues; fn 3: out[k][:] = v_k; fn 1 / 2: T[k][:] = f(lambda_k) v_k for the product out = V T
+// eigenvalues; fn 3: out[k][:] = v_k; fn 1 / 2: T[k][:] = f(lambda_k) v_k for the product out = V T.  Eigenpair k sits at position
+// k, or k + 1 when D is odd and the zero dummy column has ended at position 0 (every sweep reverses the order of the positions)
 __global__ __launch_bounds__(256) void hj_finish_kernel(int D, int fn, void* __restrict__ ws, double* __restrict__ eigvals,
                                                         double* __restrict__ out) {
     __shared__ double lam[128];
+    __shared__ double s_max[4];
+    const int n = (D + 1) & ~1;
     const HjWs w = hj_ws(ws, blockIdx.x, D);
+    const int off = ((D & 1) && (w.ctl->sweeps & 1)) ? 1 : 0;
+    // lambda_k = +-|g_k|: at convergence the column g_k = lambda_k v_k, and its norm carries the eigenvalue with RELATIVE
+    // accuracy, which v_k . g_k (absolute accuracy eps |A|) does not -- for a covariance with condition 1e17 the dot product of
+    // the smallest pair comes out as -3e-12 and its square root as NaN.  The sign comes from the dot product; a dot product
+    // within rounding noise of zero (64 D eps of the largest) counts as non-negative.
+    double mx = 0.0;
     for (int k = threadIdx.x; k < D; k += 256) {
-        double s = 0.0;
-        for (int i = 0; i < D; ++i) s += w.W[(size_t)i * D + k];
-        s -= w.ctl->shift;
-        lam[k] = s;
-        eigvals[(size_t)blockIdx.x * D + k] = s;
+        double dot = 0.0, nrm = 0.0;
+        for (int i = 0; i < D; ++i) {
+            dot += w.W[(size_t)i * n + k + off];
+            const double gki = w.G[(size_t)(k + off) * D + i];
+            nrm = fma(gki, gki, nrm);
+        }
+        lam[k] = dot;                 // signed, absolute accuracy
+        w.T[k] = sqrt(nrm);           // scratch: |lambda_k|, relative accuracy
+        mx = fmax(mx, fabs(dot));
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const double lmax = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+    const double noise = 64.0 * D * 2.220446049250313e-16 * lmax;
+    for (int k = threadIdx.x; k < D; k += 256) {
+        const double v = (lam[k] < -noise ? -w.T[k] : w.T[k]) - w.ctl->shift;
+        lam[k] = v;
+        eigvals[(size_t)blockIdx.x * D + k] = v;
     }
     __syncthreads();
     if (fn == 0) return;
     double* dst = fn == 3 ? out + (size_t)blockIdx.x * D * D : w.T;
     for (int e = threadIdx.x; e < D * D; e += 256) {
         const int k = e / D, i = e - k * D;
-        const double v = w.V[(size_t)i * D + k];
+        const double v = w.V[(size_t)i * n + k + off];
         dst[e] = fn == 3 ? v : (fn == 1 ? sqrt(lam[k]) : 1.0 / sqrt(lam[k])) * v;
     }
 }
@@ -303,12 +328,13 @@ __global__ __launch_bounds__(256) void hj_finish_kernel(int D, int fn, void* __r
 __global__ __launch_bounds__(256) void hj_product_kernel(int D, void* __restrict__ ws, double* __restrict__ out) {
     __shared__ double as[16][17], bs[16][17];
     const HjWs w = hj_ws(ws, blockIdx.z, D);
+    const int n = (D + 1) & ~1, off = ((D & 1) && (w.ctl->sweeps & 1)) ? 1 : 0;
     double* ob = out + (size_t)blockIdx.z * D * D;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
     double acc = 0.0;
     for (int k0 = 0; k0 < D; k0 += 16) {
-        as[ty][tx] = (i < D && k0 + tx < D) ? w.V[(size_t)i * D + k0 + tx] : 0.0;
+        as[ty][tx] = (i < D && k0 + tx < D) ? w.V[(size_t)i * n + k0 + tx + off] : 0.0;
         bs[ty][tx] = (k0 + ty < D && j < D) ? w.T[(size_t)(k0 + ty) * D + j] : 0.0;
         __syncthreads();
 #pragma unroll
@@ -321,7 +347,7 @@ __global__ __launch_bounds__(256) void hj_product_kernel(int D, void* __restrict
 static bool g_hj_lds_set = false;
 
 int eigh_onesided(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, hipStream_t st) {
-    const size_t lds = (size_t)D * (D + 1) * sizeof(double);
+    const size_t lds = (size_t)((D + 1) & ~1) * (D + 1) * sizeof(double);  // n positions x (D + 1) rows
     if (lds > 65536 && !g_hj_lds_set) {
         // the kernel also holds 4 bytes of static LDS: ask for what D = 128 needs, not for the whole 160 KiB
         if (hipFuncSetAttribute((const void*)hj_sweep_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8) != hipSuccess) {
