@@ -345,6 +345,7 @@ int otvae_mean_cov(const double* n_obs, const double* sum_x, const double* sum_x
  * ws: bytes from otvae_eigh_ws. */
 int64_t otvae_eigh_ws(int nb, int D);
 int64_t otvae_eigh_onesided_ws(int nb, int D); /* part of otvae_eigh_ws for D <= 128: the one-sided solver's share */
+int64_t otvae_eigh_block_onesided_ws(int nb, int D); /* part of otvae_eigh_ws for 128 < D <= 1024 */
 int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, void* stream);
 /* make_psd (ot/matrix_utils.py:123-142) without host sync: shift_b = (any_b lambda_min_b <= thr ? 1 : 0) *
  * (|min(lambda_min_b,0)| + (strict ? 1e-8 : 0)), A_b += shift_b * I.  cond_any: 1 = apply only if some matrix of

@@ -107,6 +107,7 @@ SIGNATURES = {
     "otvae_mean_cov": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "otvae_eigh_ws": (i64, [i32, i32]),
     "otvae_eigh_onesided_ws": (i64, [i32, i32]),
+    "otvae_eigh_block_onesided_ws": (i64, [i32, i32]),
     "otvae_eigh_fn": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "otvae_make_psd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "otvae_cholesky": (i32, [vp, i32, i32, vp, vp, vp]),

@@ -81,6 +81,21 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// all-reduce over the whole wave without the LDS crossbar (the 64-bit __shfl_xor tree is twelve ds_bpermute round trips):
+// the four DPP stages leave every lane of a 16-lane row with its row's sum, four v_readlane pairs fetch the row sums
+__device__ __forceinline__ double wave_allsum_dpp(double v) {
+    v = group_sum<16>(v);
+    double tot = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * rr);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * rr);
+        tot += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return tot;
+}
+
 // 1/x and 1/sqrt(x) from the hardware seeds + two Newton steps each (the compiler's IEEE division / square root expand to
 // ~30 instructions apiece; a rotation angle need not be exact -- only c^2 + s^2 = 1 must hold to rounding, and it does
 // because s = c t and c = rsqrt(1 + t^2) is refined to full precision)
@@ -369,5 +384,329 @@ int eigh_onesided(const double* A, int nb, int D, int fn, double* out, double* e
         hj_product_kernel<<<dim3(cdiv(D, 16), cdiv(D, 16), nb), 256, 0, st>>>(D, ws, out);
         OTVAE_CHECK_LAUNCH("otvae_eigh_fn(product)");
     }
+    return OTVAE_OK;
+}
+
+// ================================================================================================ 128 < D <= 1024
+// The same iteration across workgroups (the reference's tests/test_latent_transport.py transports 64x4x4 = 1024-dimensional
+// latents).  G and V live in global memory (8 MiB each at D = 1024: L2 / Infinity-Cache resident), column by column.  The
+// columns are cut into blocks of 8; a ROUND pairs the blocks round-robin and one workgroup per block pair
+//   * loads its 16 columns of G into LDS (131 KB at D = 1024), runs the odd-even sweep of hj_sweep_kernel over the 16
+//     positions (a wave per pair slot, the kept column in registers, 16 steps), logging the rotations in LDS;
+//   * writes the columns back to their HOME slots (16 steps reverse the order of the positions, so position p goes home to
+//     15 - p): a column of G never changes its slot, the round-robin over blocks therefore meets every pair of columns;
+//   * loads the same 16 columns of V and replays the logged rotations on them.
+// Positive definite input (the covariances this path exists for) is first factored, A = L L^T (otvae_cholesky), and the
+// iteration runs on the columns of X = L^T (= the rows of L, contiguous): X V = U S gives A = X^T X = V S^2 V^T, the same
+// eigenvectors, eigenvalues |x_k|^2 -- but the iteration now sees cond(A)^1/2 instead of the cond(A)^2 that working on the
+// columns of A itself implies (the Gram matrix of A's columns is A^2), which is what its convergence speed depends on: an
+// ill-conditioned 1024 x 1024 latent covariance needed > 16 sweeps on A and needs ~10 on its factor.  When the factorisation
+// meets a non-positive pivot (device flag) the columns of A are iterated as in the small solver.
+// One launch per round (nblk - 1 rounds per sweep); the stop test is a device flag: a round that rotated above the stop level
+// marks the sweep, a tiny kernel after each sweep turns the remaining launches into no-ops once a sweep stayed quiet.
+#define HJB_B 8
+#define HJB_MAX_SWEEPS 24
+#define HJB_MAX_D 1024
+
+struct HjbCtl {
+    int done, rotated, sweeps;
+    int chol_info;  // 0: the iteration runs on the Cholesky factor; else on A itself (written by otvae_cholesky before the init kernel)
+};
+
+static __host__ __device__ inline int hjb_dp(int D) { return (D + 2 * HJB_B - 1) / (2 * HJB_B) * (2 * HJB_B); }
+
+extern "C" int64_t otvae_eigh_block_onesided_ws(int nb, int D) {
+    if (nb <= 0 || D <= 0) return -1;
+    const int64_t Dp = hjb_dp(D);
+    // G[Dp][D], V[Dp][D] (column-major: a column is contiguous), lam[Dp], sign dots [Dp], T[D][D] for f(A), ctl
+    return (int64_t)nb * ((2 * Dp * (int64_t)D + 2 * Dp + (int64_t)D * D) * 8 + 256);
+}
+
+struct HjbWs {
+    double *G, *V, *nrm, *dot, *T;
+    HjbCtl* ctl;
+};
+__host__ __device__ static inline HjbWs hjb_ws(void* ws, int b, int D) {
+    const size_t Dp = (size_t)hjb_dp(D);
+    const size_t per = (2 * Dp * D + 2 * Dp + (size_t)D * D) * 8 + 256;
+    char* w = (char*)ws + (size_t)b * per;
+    HjbWs r;
+    r.G = (double*)w;
+    r.V = r.G + Dp * D;
+    r.nrm = r.V + Dp * D;
+    r.dot = r.nrm + Dp;
+    r.T = r.dot + Dp;
+    r.ctl = (HjbCtl*)(r.T + (size_t)D * D);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void hjb_init_kernel(const double* __restrict__ Ain, int D, void* __restrict__ ws) {
+    const HjbWs w = hjb_ws(ws, blockIdx.y, D);
+    const double* Ab = Ain + (size_t)blockIdx.y * D * D;
+    const size_t total = (size_t)hjb_dp(D) * D;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e / D), i = (int)(e - (size_t)c * D);
+        double v = 0.0;  // zero dummy columns
+        if (c < D) v = w.ctl->chol_info == 0 ? w.T[e]   // column c of X = L^T is row c of L (its strict upper part is zero)
+                                             : ((i >= c) ? Ab[(size_t)i * D + c] : Ab[(size_t)c * D + i]);  // lower triangle of A
+        w.G[e] = v;
+        w.V[e] = (c == i) ? 1.0 : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        w.ctl->done = 0;
+        w.ctl->rotated = 0;
+        w.ctl->sweeps = 0;
+    }
+}
+
+// round-robin pairing of nblk (even) blocks: pair k of `round`
+__device__ __forceinline__ void hjb_pair(int round, int k, int nblk, int& I, int& J) {
+    const int m = nblk - 1;
+    if (k == 0) {
+        I = m;
+        J = round % m;
+    } else {
+        I = (round + k) % m;
+        J = (round - k + m) % m;
+    }
+    if (I > J) {
+        const int t = I;
+        I = J;
+        J = t;
+    }
+}
+
+template <int R>  // rows per lane: D <= 64 R
+__global__ __launch_bounds__(512) void hjb_round_kernel(int D, int round, void* __restrict__ ws) {
+    extern __shared__ __align__(16) double hj_lds[];
+    __shared__ double2 s_log[2 * HJB_B][HJB_B];
+    __shared__ int s_rot;
+    const HjbWs w = hjb_ws(ws, blockIdx.y, D);
+    if (w.ctl->done) return;
+    constexpr int NP = 2 * HJB_B;  // positions
+    const int LD = D + 1;
+    const int nblk = hjb_dp(D) / HJB_B;
+    int I, J;
+    hjb_pair(round, blockIdx.x, nblk, I, J);
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;  // wave g = pair slot g
+    const int kpos = 2 * g + 1;
+    auto home = [&](int pos) { return pos < HJB_B ? I * HJB_B + pos : J * HJB_B + (pos - HJB_B); };
+    double* P = hj_lds;  // P[pos * LD + row]
+    if (tid == 0) s_rot = 0;
+
+    auto sweep16 = [&](double* __restrict__ M, bool replay) {
+        // load the 16 columns (a wave per column, two columns each)
+        for (int pos = g; pos < NP; pos += 8) {
+            const double* src = M + (size_t)home(pos) * D;
+            for (int i = lane; i < D; i += 64) P[pos * LD + i] = src[i];
+        }
+        __syncthreads();
+        double keep[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int i = lane + 64 * u;
+            keep[u] = i < D ? P[kpos * LD + i] : 0.0;
+        }
+        auto step = [&](auto odd_tag, int t) {
+            constexpr bool ODD = decltype(odd_tag)::value;
+            const int opos = ODD ? kpos + 1 : kpos - 1;
+            if (opos < NP) {
+                double other[R];
+                double* go = P + opos * LD;
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const int i = lane + 64 * u;
+                    other[u] = i < D ? go[i] : 0.0;
+                }
+                double c = 1.0, s = 0.0;
+                if (replay) {
+                    const double2 cs = s_log[t][g];
+                    c = cs.x;
+                    s = cs.y;
+                } else {
+                    double kk = 0.0, oo = 0.0, gamma = 0.0;
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        kk = fma(keep[u], keep[u], kk);
+                        oo = fma(other[u], other[u], oo);
+                        gamma = fma(keep[u], other[u], gamma);
+                    }
+                    kk = wave_allsum_dpp(kk);
+                    oo = wave_allsum_dpp(oo);
+                    gamma = wave_allsum_dpp(gamma);
+                    const double alpha = ODD ? kk : oo, beta = ODD ? oo : kk;
+                    const double ab = alpha * beta;
+                    if (gamma * gamma > HJ_TOL2 * ab && ab > 1e-280) {
+                        const double zeta = (beta - alpha) * 0.5 * nr_rcp(gamma);
+                        const double az = fabs(zeta);
+                        double tt;
+                        if (az > 1e8) {
+                            tt = 0.5 * nr_rcp(zeta);
+                        } else {
+                            const double q2 = fma(zeta, zeta, 1.0);
+                            tt = nr_rcp(az + q2 * nr_rsq(q2));
+                            tt = zeta >= 0.0 ? tt : -tt;
+                        }
+                        c = nr_rsq(fma(tt, tt, 1.0));
+                        s = c * tt;
+                        if (lane == 0 && gamma * gamma > HJ_STOP2 * ab) s_rot = 1;
+                    }
+                    if (lane == 0) s_log[t][g] = make_double2(c, s);
+                }
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const int i = lane + 64 * u;
+                    double pub;
+                    if (ODD) {
+                        pub = c * keep[u] - s * other[u];
+                        keep[u] = s * keep[u] + c * other[u];
+                    } else {
+                        pub = s * other[u] + c * keep[u];
+                        keep[u] = c * other[u] - s * keep[u];
+                    }
+                    if (i < D) go[i] = pub;
+                }
+            }
+            __syncthreads();
+        };
+        for (int t = 0; t < NP; t += 2) {
+            step(std::false_type{}, t);
+            step(std::true_type{}, t + 1);
+        }
+        // 16 steps reversed the order: position p holds what started at 15 - p and goes back there
+        {
+            double* dst = M + (size_t)home(NP - 1 - kpos) * D;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int i = lane + 64 * u;
+                if (i < D) dst[i] = keep[u];
+            }
+        }
+        for (int pos = 2 * g; pos < NP; pos += 16) {  // the even positions: wave g writes position 2g
+            double* dst = M + (size_t)home(NP - 1 - pos) * D;
+            for (int i = lane; i < D; i += 64) dst[i] = P[pos * LD + i];
+        }
+        __syncthreads();
+    };
+    sweep16(w.G, false);
+    sweep16(w.V, true);
+    if (tid == 0 && s_rot) w.ctl->rotated = 1;  // benign race: every writer stores 1
+}
+
+__global__ void hjb_check_kernel(int D, void* __restrict__ ws) {
+    const HjbWs w = hjb_ws(ws, blockIdx.x, D);
+    if (threadIdx.x != 0 || w.ctl->done) return;
+    w.ctl->sweeps += 1;
+    if (!w.ctl->rotated) w.ctl->done = 1;
+    w.ctl->rotated = 0;
+}
+
+// |lambda_k| = |g_k| and the sign's dot product v_k . g_k: a wave per column
+__global__ __launch_bounds__(256) void hjb_norms_kernel(int D, void* __restrict__ ws) {
+    const HjbWs w = hjb_ws(ws, blockIdx.y, D);
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= D) return;
+    const double* gk = w.G + (size_t)k * D;
+    const double* vk = w.V + (size_t)k * D;
+    double nn = 0.0, dd = 0.0;
+    for (int i = lane; i < D; i += 64) {
+        nn = fma(gk[i], gk[i], nn);
+        dd = fma(gk[i], vk[i], dd);
+    }
+    nn = wave_sum(nn);
+    dd = wave_sum(dd);
+    if (lane == 0) {
+        w.nrm[k] = sqrt(nn);
+        w.dot[k] = dd;
+    }
+}
+
+// eigenvalues; fn 3: out[k][:] = v_k (a copy: V is stored one eigenvector per row already); fn 1 / 2: T[k][:] = f(lambda_k) v_k
+__global__ __launch_bounds__(256) void hjb_finish_kernel(int D, int fn, void* __restrict__ ws, double* __restrict__ eigvals,
+                                                         double* __restrict__ out) {
+    __shared__ double s_max[4];
+    __shared__ double s_noise;
+    const HjbWs w = hjb_ws(ws, blockIdx.y, D);
+    double mx = 0.0;
+    for (int k = threadIdx.x; k < D; k += 256) mx = fmax(mx, fabs(w.dot[k]));
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) s_noise = 64.0 * D * 2.220446049250313e-16 * fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+    __syncthreads();
+    const double noise = s_noise;
+    const bool chol = w.ctl->chol_info == 0;
+    auto lam = [&](int k) { return chol ? w.nrm[k] * w.nrm[k] : (w.dot[k] < -noise ? -w.nrm[k] : w.nrm[k]); };
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < D; k += 256) eigvals[(size_t)blockIdx.y * D + k] = lam(k);
+    if (fn == 0) return;
+    double* dst = fn == 3 ? out + (size_t)blockIdx.y * D * D : w.T;
+    const size_t total = (size_t)D * D;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int k = (int)(e / D);
+        const double v = w.V[e];
+        if (fn == 3) {
+            dst[e] = v;
+        } else {
+            const double l = lam(k);
+            dst[e] = (fn == 1 ? sqrt(l) : 1.0 / sqrt(l)) * v;
+        }
+    }
+}
+
+// out[i][j] = sum_k V[k][i] T[k][j]
+__global__ __launch_bounds__(256) void hjb_product_kernel(int D, void* __restrict__ ws, double* __restrict__ out) {
+    __shared__ double as[16][17], bs[16][17];
+    const HjbWs w = hjb_ws(ws, blockIdx.z, D);
+    double* ob = out + (size_t)blockIdx.z * D * D;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < D; k0 += 16) {
+        as[ty][tx] = (blockIdx.y * 16 + tx < D && k0 + ty < D) ? w.V[(size_t)(k0 + ty) * D + blockIdx.y * 16 + tx] : 0.0;  // as[k][i]
+        bs[ty][tx] = (k0 + ty < D && j < D) ? w.T[(size_t)(k0 + ty) * D + j] : 0.0;                                      // bs[k][j]
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = fma(as[kk][ty], bs[kk][tx], acc);
+        __syncthreads();
+    }
+    if (i < D && j < D) ob[(size_t)i * D + j] = acc;
+}
+
+static bool g_hjb_lds_set[2] = {false, false};
+
+int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, hipStream_t st) {
+    const size_t lds = (size_t)2 * HJB_B * (D + 1) * sizeof(double);
+    const bool big = D > 512;
+    if (lds > 65536 && !g_hjb_lds_set[big]) {
+        const hipError_t e = big ? hipFuncSetAttribute((const void*)hjb_round_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * HJB_B * (HJB_MAX_D + 1) * 8))
+                                 : hipFuncSetAttribute((const void*)hjb_round_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * HJB_B * 513 * 8));
+        if (e != hipSuccess) {
+            otvae_set_error("otvae_eigh_fn: cannot raise dynamic LDS limit");
+            return OTVAE_ELAUNCH;
+        }
+        g_hjb_lds_set[big] = true;
+    }
+    const int Dp = hjb_dp(D), nblk = Dp / HJB_B;
+    for (int b = 0; b < nb; ++b) {  // L into the T area (free until the end), the pivot flag into the control block
+        const HjbWs w = hjb_ws(ws, b, D);
+        const int rc = otvae_cholesky(A + (size_t)b * D * D, 1, D, w.T, &w.ctl->chol_info, (void*)st);
+        if (rc) return rc;
+    }
+    hjb_init_kernel<<<dim3(imin(cdiv((size_t)Dp * D, 256), 1024), nb), 256, 0, st>>>(A, D, ws);
+    for (int sweep = 0; sweep < HJB_MAX_SWEEPS; ++sweep) {
+        for (int round = 0; round < nblk - 1; ++round) {
+            if (big)
+                hjb_round_kernel<16><<<dim3(nblk / 2, nb), 512, lds, st>>>(D, round, ws);
+            else
+                hjb_round_kernel<8><<<dim3(nblk / 2, nb), 512, lds, st>>>(D, round, ws);
+        }
+        hjb_check_kernel<<<nb, 64, 0, st>>>(D, ws);
+    }
+    OTVAE_CHECK_LAUNCH("otvae_eigh_fn(block rounds)");
+    hjb_norms_kernel<<<dim3(cdiv(D, 4), nb), 256, 0, st>>>(D, ws);
+    hjb_finish_kernel<<<dim3(imin(cdiv((size_t)D * D, 2048), 256), nb), 256, 0, st>>>(D, fn, ws, eigvals, out);
+    if (fn == 1 || fn == 2) hjb_product_kernel<<<dim3(cdiv(D, 16), cdiv(D, 16), nb), 256, 0, st>>>(D, ws, out);
+    OTVAE_CHECK_LAUNCH("otvae_eigh_fn(block finish)");
     return OTVAE_OK;
 }

@@ -171,6 +171,8 @@ static int eigb_dp(int D) { return (D + 2 * EIGB - 1) / (2 * EIGB) * (2 * EIGB);
 
 extern "C" int64_t otvae_eigh_onesided_ws(int nb, int D);
 int eigh_onesided(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, hipStream_t st);  // eigh_onesided.hip
+extern "C" int64_t otvae_eigh_block_onesided_ws(int nb, int D);
+int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, hipStream_t st);
 
 extern "C" int64_t otvae_eigh_ws(int nb, int D) {
     if (nb <= 0 || D <= 0) return -1;
@@ -179,9 +181,11 @@ extern "C" int64_t otvae_eigh_ws(int nb, int D) {
         return two_sided > one_sided ? two_sided : one_sided;
     }
     // block driver (one matrix at a time): Aw[Dp][Dp], Vt[Dp][Dp], S and U [Dp/32][32][32], sub-eigenvalues, dense
-    // D x D copies for the f(A) product, convergence flag
+    // D x D copies for the f(A) product, convergence flag -- or the one-sided multi-workgroup solver's share (D <= 1024)
     const int64_t Dp = eigb_dp(D), np = Dp / (2 * EIGB);
-    return (2 * Dp * Dp + 2 * np * 4 * EIGB * EIGB + np * 2 * EIGB + 2 * (int64_t)D * D + 8) * (int64_t)sizeof(double);
+    const int64_t two_sided = (2 * Dp * Dp + 2 * np * 4 * EIGB * EIGB + np * 2 * EIGB + 2 * (int64_t)D * D + 8) * (int64_t)sizeof(double);
+    const int64_t one_sided = D <= 1024 ? otvae_eigh_block_onesided_ws(nb, D) : 0;
+    return two_sided > one_sided ? two_sided : one_sided;
 }
 
 __global__ __launch_bounds__(EIGH_THREADS) void eigh_kernel(const double* __restrict__ Ain, int D, int fn,
@@ -471,6 +475,8 @@ extern "C" int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out
     OTVAE_REQUIRE(A && eigvals && ws && nb > 0 && D > 0, "otvae_eigh_fn: bad argument");
     OTVAE_REQUIRE(fn >= 0 && fn <= 3, "otvae_eigh_fn: fn must be 0, 1, 2 or 3");
     OTVAE_REQUIRE(fn == 0 || out, "otvae_eigh_fn: out missing");
+    if (D > EIGH_MAX_D && D <= 1024 && !getenv("OTVAE_EIGH_TWOSIDED"))
+        return eigh_block_onesided(A, nb, D, fn, out, eigvals, ws, (hipStream_t)stream);
     if (D > EIGH_MAX_D) return eigh_block(A, nb, D, fn, out, eigvals, (double*)ws, (hipStream_t)stream);
     if (!getenv("OTVAE_EIGH_TWOSIDED")) return eigh_onesided(A, nb, D, fn, out, eigvals, ws, (hipStream_t)stream);
     const size_t lds = eigh_lds_bytes(D);
@@ -564,8 +570,132 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const double* __restrict_
     if (threadIdx.x == 0 && info) info[blockIdx.x] = bad;
 }
 
+// Blocked right-looking variant for D > 128 (one workgroup reads the whole trailing matrix through one CU otherwise: 90 ms at
+// D = 1024): panels of 64 columns; per panel (i) the 64 x 64 diagonal block is factored in LDS by one workgroup, (ii) the rows
+// below solve X L11^T = A21 (a thread per row, L11 in LDS), (iii) the trailing matrix takes A22 -= L21 L21^T in 64 x 64 tiles
+// (lower triangle only).  L is built in place in its output buffer, which starts as a copy of A's lower triangle.
+#define CHB 64
+__global__ __launch_bounds__(256) void chol_copy_lower_kernel(const double* __restrict__ A, int D, double* __restrict__ L,
+                                                              int* __restrict__ info) {
+    const size_t boff = (size_t)blockIdx.y * D * D;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < (size_t)D * D; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / D), j = (int)(e - (size_t)i * D);
+        L[boff + e] = j <= i ? A[boff + e] : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && info) info[blockIdx.y] = 0;
+}
+
+// (i) + (ii): every workgroup factors the diagonal block [k0, k0+nbk) in its own LDS (64^3 / 3 flops: cheaper than handing it
+// over) and solves its 256 rows below against it; WRITE_DIAG: the launch of one workgroup per matrix that stores the factored
+// diagonal block afterwards (no workgroup of the solve launch may see it half written).
+template <bool WRITE_DIAG>
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ L, int D, int k0, int* __restrict__ info) {
+    __shared__ double d[CHB][CHB + 1];
+    __shared__ int s_bad;
+    double* Lb = L + (size_t)blockIdx.y * D * D;
+    const int nbk = min(CHB, D - k0);
+    for (int e = threadIdx.x; e < nbk * nbk; e += 256) {
+        const int i = e / nbk, j = e - i * nbk;
+        d[i][j] = j <= i ? Lb[(size_t)(k0 + i) * D + k0 + j] : 0.0;
+    }
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    for (int j = 0; j < nbk; ++j) {  // unblocked factorisation of the diagonal block, column by column
+        if (threadIdx.x == 0) {
+            const double piv = d[j][j];
+            if (!(piv > 0.0) && !s_bad) s_bad = k0 + j + 1;
+            d[j][j] = piv > 0.0 ? sqrt(piv) : NAN;
+        }
+        __syncthreads();
+        const double ljj = d[j][j];
+        for (int i = j + 1 + threadIdx.x; i < nbk; i += 256) d[i][j] /= ljj;
+        __syncthreads();
+        for (int e = threadIdx.x; e < (nbk - j - 1) * (nbk - j - 1); e += 256) {  // trailing update inside the block (lower part)
+            const int i = j + 1 + e / (nbk - j - 1), c = j + 1 + e % (nbk - j - 1);
+            if (c <= i) d[i][c] = fma(-d[i][j], d[c][j], d[i][c]);
+        }
+        __syncthreads();
+    }
+    if (WRITE_DIAG) {
+        for (int e = threadIdx.x; e < nbk * nbk; e += 256) {
+            const int i = e / nbk, j = e - i * nbk;
+            if (j <= i) Lb[(size_t)(k0 + i) * D + k0 + j] = d[i][j];
+        }
+        if (threadIdx.x == 0 && s_bad && info && info[blockIdx.y] == 0) info[blockIdx.y] = s_bad;
+        return;
+    }
+    // rows below the panel: row r of A21 <- solve x L11^T = a  (forward substitution along the row, in place: a thread re-reads
+    // its own earlier results)
+    const int r = k0 + nbk + blockIdx.x * 256 + threadIdx.x;
+    if (r < D) {
+        double* row = Lb + (size_t)r * D + k0;
+        for (int j = 0; j < nbk; ++j) {
+            double acc = row[j];
+            for (int c = 0; c < j; ++c) acc = fma(-row[c], d[j][c], acc);
+            row[j] = acc / d[j][j];
+        }
+    }
+}
+
+// (iii) A22[i][j] -= sum_c L21[i][c] L21[j][c] for the 64 x 64 tile (ti, tj), tj <= ti, of the trailing matrix
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ L, int D, int k0) {
+    __shared__ double a[CHB][17], b[CHB][17];
+    double* Lb = L + (size_t)blockIdx.z * D * D;
+    const int t0 = k0 + CHB;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int i0 = t0 + ti * CHB, j0 = t0 + tj * CHB;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
+    double acc[4][4] = {};
+    for (int c0 = 0; c0 < CHB; c0 += 16) {
+        for (int e = threadIdx.x; e < CHB * 16; e += 256) {
+            const int rr = e >> 4, cc = e & 15;
+            a[rr][cc] = (i0 + rr < D) ? Lb[(size_t)(i0 + rr) * D + k0 + c0 + cc] : 0.0;
+            b[rr][cc] = (j0 + rr < D) ? Lb[(size_t)(j0 + rr) * D + k0 + c0 + cc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                av[u] = a[ty + 16 * u][c];
+                bv[u] = b[tx + 16 * u][c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fma(av[u], bv[v], acc[u][v]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = i0 + ty + 16 * u, j = j0 + tx + 16 * v;
+            if (i < D && j <= i) Lb[(size_t)i * D + j] -= acc[u][v];
+        }
+}
+
 extern "C" int otvae_cholesky(const double* A, int nb, int D, double* L, int* info, void* stream) {
     OTVAE_REQUIRE(A && L && nb > 0 && D > 0 && A != L, "otvae_cholesky: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (D > 128) {
+        chol_copy_lower_kernel<<<dim3(imin(cdiv((size_t)D * D, 256), 1024), nb), 256, 0, st>>>(A, D, L, info);
+        for (int k0 = 0; k0 < D; k0 += CHB) {
+            const int below = D - k0 - CHB;
+            if (below > 0) chol_panel_kernel<false><<<dim3(cdiv(below, 256), nb), 256, 0, st>>>(L, D, k0, info);
+            chol_panel_kernel<true><<<dim3(1, nb), 256, 0, st>>>(L, D, k0, info);
+            if (below > 0) {
+                const int nt = cdiv(below, CHB);
+                chol_syrk_kernel<<<dim3(nt, nt, nb), 256, 0, st>>>(L, D, k0);
+            }
+        }
+        OTVAE_CHECK_LAUNCH("otvae_cholesky(blocked)");
+        return OTVAE_OK;
+    }
+
     OTVAE_REQUIRE((size_t)D * 8 <= 64 * 1024, "otvae_cholesky: D = %d exceeds the LDS row buffer (8192)", D);
     cholesky_kernel<<<nb, 256, (size_t)D * sizeof(double), (hipStream_t)stream>>>(A, D, L, info);
     OTVAE_CHECK_LAUNCH("otvae_cholesky");
