@@ -4,6 +4,7 @@
     python tools/summarize_profiles.py --replay <kernel-trace dir> <tag> # replayed (timed) steps only
     python tools/summarize_profiles.py --pmc gpurun_out <tag>           # pmc_fetch / pmc_write / pmc_mfma passes
     python tools/summarize_profiles.py --roofline <tag>                 # joins the replay and PMC summaries
+    python tools/summarize_profiles.py --pmc-sq <pmc_sq dir> <tag>      # SQ issue / wait counters per kernel
 
 HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
 the bytes of wide coalesced reads, so reads = 2 * FETCH_SIZE KiB; the two counters need separate passes (TCC slots).
@@ -15,6 +16,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# where the summaries go: profiles/ of the repo, or (on the GPU box, whose repo copy does not travel back) a directory under
+# gpurun_out/ named by OTVAE_PROFILES_OUT
+OUT = os.environ.get("OTVAE_PROFILES_OUT") or os.path.join(ROOT, "profiles")
 
 
 def kernel_stats(src, tag):
@@ -22,7 +26,7 @@ def kernel_stats(src, tag):
     dominant-kernel timing loop of bench.py together): calls, average and total duration per kernel."""
     f = max(glob.glob(os.path.join(src, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
-    out = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
+    out = os.path.join(OUT, f"{tag}_kernel_stats.csv")
     with open(out, "w") as w:
         w.write("kernel,calls,avg_us,total_ms,percent\n")
         tot = sum(int(r["TotalDurationNs"]) for r in rows)
@@ -33,14 +37,18 @@ def kernel_stats(src, tag):
 
 
 def replay_stats(src, tag, steps=20):
-    """Per-kernel statistics over the last `steps` hipGraph replays only (the timed region of bench.py), cut out of the
+    """Per-kernel statistics over `steps` consecutive hipGraph replays only (the timed region of bench.py), cut out of the
     kernel trace at the adam_kernel launches: the stats file of the same run also contains the eager warm-up, the
     capture warm-up, the parity check and the dominant-kernel timing loop."""
     f = max(glob.glob(os.path.join(src, "*", "*_kernel_trace.csv")), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
-    lo, hi = ends[-steps - 1] + 1, ends[-1] + 1
+    # the timed region = the `steps` consecutive steps with the smallest wall time (graph replays run back to back; the eager
+    # warm-up, the eager-route timing and the parity step of the same process are slower per step)
+    t_end = [int(rows[i]["End_Timestamp"]) for i in ends]
+    best = min(range(len(ends) - steps), key=lambda a: t_end[a + steps] - t_end[a])
+    lo, hi = ends[best] + 1, ends[best + steps] + 1
     seg = rows[lo:hi]
     acc = collections.defaultdict(lambda: [0, 0])
     for r in seg:
@@ -49,9 +57,9 @@ def replay_stats(src, tag, steps=20):
         acc[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     tot = sum(v[1] for v in acc.values())
     wall = int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])
-    out = os.path.join(ROOT, "profiles", f"{tag}_replay_kernel_stats.csv")
+    out = os.path.join(OUT, f"{tag}_replay_kernel_stats.csv")
     with open(out, "w") as w:
-        w.write("# last %d graph replays: %d launches/step, kernel-busy %.3f ms/step, wall %.3f ms/step\n" %
+        w.write("# %d consecutive graph replays: %d launches/step, kernel-busy %.3f ms/step, wall %.3f ms/step\n" %
                 (steps, len(seg) // steps, tot / 1e6 / steps, wall / 1e6 / steps))
         w.write("kernel,calls_per_step,avg_us,ms_per_step,percent\n")
         for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
@@ -72,7 +80,7 @@ def pmc(src, tag):
         return a
     F, W = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
     MF, GA = load("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), load("pmc_mfma", "GRBM_GUI_ACTIVE")
-    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.csv")
+    out = os.path.join(OUT, f"{tag}_pmc_per_kernel.csv")
     with open(out, "w") as w:
         w.write("kernel,launches,FETCH_SIZE_KiB_per_launch,read_MB_per_launch(2x_gfx950_correction),WRITE_SIZE_KiB_per_launch,"
                 "hbm_MB_per_launch,SQ_VALU_MFMA_BUSY_CYCLES_per_launch,GRBM_GUI_ACTIVE_per_launch,"
@@ -105,7 +113,7 @@ def pmc_sq(src, tag):
             cnt[k] += 1
             acc[k]["dur_ns"] += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
             meta[k] = (x["VGPR_Count"], x["Accum_VGPR_Count"], x["LDS_Block_Size"], x["Workgroup_Size"])
-    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_per_kernel.csv")
+    out = os.path.join(OUT, f"{tag}_pmc_sq_per_kernel.csv")
     with open(out, "w") as w:
         w.write("# per launch averages; valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's life spent issuing\n"
                 "# vector instructions), wait_any_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked on s_waitcnt / barrier),\n"
@@ -125,9 +133,9 @@ def pmc_sq(src, tag):
 
 def roofline(tag):
     """Joins <tag>_final_replay_kernel_stats.csv and <tag>_pmc_per_kernel.csv into <tag>_kernel_roofline.csv."""
-    rep = {r["kernel"]: r for r in csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", f"{tag}_final_replay_kernel_stats.csv"))
+    rep = {r["kernel"]: r for r in csv.DictReader(l for l in open(os.path.join(OUT, f"{tag}_final_replay_kernel_stats.csv"))
                                                   if not l.startswith("#"))}
-    pm = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.csv"))))
+    pm = list(csv.DictReader(open(os.path.join(OUT, f"{tag}_pmc_per_kernel.csv"))))
     busy_key = [k for k in pm[0] if k.startswith("mfma_busy_frac")][0]
     pm = {r["kernel"]: r for r in pm}
     rows = []
@@ -137,7 +145,7 @@ def roofline(tag):
             rows.append((float(r["ms_per_step"]), k, float(r["calls_per_step"]), us, mib, mib * 1.048576 / us if us else 0.0,
                          float(pm[k][busy_key])))
     rows.sort(reverse=True)
-    out = os.path.join(ROOT, "profiles", f"{tag}_kernel_roofline.csv")
+    out = os.path.join(OUT, f"{tag}_kernel_roofline.csv")
     with open(out, "w") as w:
         w.write("# per kernel of the timed step: average duration (kernel trace, timed replays), HBM MiB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE),\n"
                 "# (the x2 read correction is calibrated for 16-byte-per-lane loads; kernels reading 4 bytes per lane, e.g. the reductions, are\n"
