@@ -249,10 +249,12 @@ def time_largest_aggregate_kernel(A, workload, iters=10):
     tr = A.HipTrainer(model, batch_shape=(PER_GPU_BATCH, 1, 32, 32), use_graph=False, data_parallel=False)  # rank-local
     x = mnist_like(PER_GPU_BATCH, seed=77).cuda()
     tr.step(x)
+    side, HF.WGRAD_SIDE_STREAM = HF.WGRAD_SIDE_STREAM, 2 if HF.WGRAD_SIDE_STREAM else 0  # the launches of the CAPTURED step
     HF.JOB_TRACE = []
     tr.step(x)
     torch.cuda.synchronize()
     trace, HF.JOB_TRACE = HF.JOB_TRACE, None
+    HF.WGRAD_SIDE_STREAM = side
     calls = [c for c in trace if c["uniform_tap"] == 1 and c["packed_mask"]]
     if not calls:
         return None

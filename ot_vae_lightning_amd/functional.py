@@ -141,11 +141,81 @@ def bn_eval_affine(branch: BNBranch):
 _DENSE_REDUCE = os.environ.get("OTVAE_DENSE_REDUCE", "0") == "1"  # A/B switch: ignore the dead-tap information
 
 
+# OTVAE_WGRAD_STREAM: 1 (default) = weight-gradient jobs go to the side stream while a step is being captured (a replayed step
+# is device-bound; an eagerly issued one is host-bound and would only pay for the extra events); 2 = always; 0 = never (the
+# jobs share the data-gradient jobs' launch) -- A/B switch
+WGRAD_SIDE_STREAM = int(os.environ.get("OTVAE_WGRAD_STREAM", "1"))
+# backward calls (ConvBlock stages) whose weight-gradient jobs share one fork: every fork costs the launch stream ~4.5 us
+WGRAD_GROUP = max(1, int(os.environ.get("OTVAE_WGRAD_GROUP", "1")))
+WGRAD_REDUCE_GROUP = max(1, int(os.environ.get("OTVAE_WGRAD_REDUCE_GROUP", "16")))  # layers per side-stream partial reduction
+WGRAD_STREAMS = max(1, int(os.environ.get("OTVAE_WGRAD_STREAMS", "1")))  # side streams taking the forks in turn
+
+
 class _PendingReduce:
     """Weight-gradient partials of the current backward pass whose destination is a trainer-owned flat gradient
     buffer, reduced together by ``flush`` (queued as an autograd-engine callback and called by the trainer before the
-    optimizer).  Destinations are kept as raw addresses: holding the tensors would make autograd clone them."""
+    optimizer).  Destinations are kept as raw addresses: holding the tensors would make autograd clone them.
+
+    Nothing downstream of a layer's weight-gradient job reads its output before ``flush``, so those jobs are off the backward
+    pass's critical path (data gradient -> BatchNorm backward -> next layer): they are issued on a second HIP stream
+    (``side_stream``), forked from the launch stream where the layer's output gradient is complete and joined in ``flush``.  The
+    kernels of a step are latency-bound at 1-3 waves per SIMD, so the two streams share the chip almost for
+    free; in a captured step the fork / join become edges of the hipGraph.  Every tensor a side-stream job reads is held
+    here until the join (the caching allocator would otherwise hand its memory to a later launch-stream kernel)."""
     _state = {}
+    _side = {}
+    _held = {}
+    _wq = {}       # device -> [queued weight-gradient jobs, backward calls they came from]
+    _forked = {}   # device -> the side stream has work of this backward pass
+    _reduced = {}  # device -> leading entries of _state whose partials the side stream has already reduced
+
+    @staticmethod
+    def side_stream(device) -> "torch.cuda.Stream":
+        """Next side stream of the device's pool (round robin: successive forks may run beside each other, too)."""
+        pool = _PendingReduce._side.get(device)
+        if pool is None:
+            pool = _PendingReduce._side[device] = [[torch.cuda.Stream(device=device) for _ in range(WGRAD_STREAMS)], 0]
+        pool[1] = (pool[1] + 1) % len(pool[0])
+        return pool[0][pool[1]]
+
+    @staticmethod
+    def queue_weight_jobs(device, jobs, n, tensors) -> bool:
+        """Defers the weight-gradient jobs of one backward call; ``tensors`` (everything the jobs read or write) stay alive until
+        flush.  True when WGRAD_GROUP calls have accumulated and the caller should fork (``fork_point``) and ``issue``."""
+        q = _PendingReduce._wq.setdefault(device, [[], 0])
+        q[0].extend(_lib.ConvJob.from_buffer_copy(jobs[i]) for i in range(n))
+        q[1] += 1
+        _PendingReduce._held.setdefault(device, []).extend(t for t in tensors if t is not None)
+        return q[1] >= WGRAD_GROUP
+
+    @staticmethod
+    def fork_point(device):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        return ev
+
+    @staticmethod
+    def issue(device, ev):
+        """Launches the queued weight-gradient jobs on the side stream, ordered after the launch stream's work up to ``ev``."""
+        q = _PendingReduce._wq.get(device)
+        if not q or not q[0]:
+            return
+        side = _PendingReduce.side_stream(device)
+        side.wait_event(ev)
+        n = len(q[0])
+        arr = (_lib.ConvJob * n)(*q[0])
+        check(_lib.load().otvae_conv_multi(n, arr, C.c_void_p(side.cuda_stream)), "otvae_conv_multi(backward, weights)")
+        if JOB_TRACE is not None:
+            _trace_jobs(arr, n)
+        q[0].clear()
+        q[1] = 0
+        _PendingReduce._forked[device] = True
+        # every queued layer's job is now in the side stream: reduce the finished layers there as the pass goes, so that only
+        # the last few layers' partials are left for the launch stream after the join
+        st, done = _PendingReduce._state.get(device, []), _PendingReduce._reduced.get(device, 0)
+        if len(st) - done >= WGRAD_REDUCE_GROUP:
+            _PendingReduce._reduce(st[done:], C.c_void_p(side.cuda_stream))
+            _PendingReduce._reduced[device] = len(st)
 
     @staticmethod
     def add(device, partial, p, k, kp, cn, gw, gb, cs, dead):
@@ -155,24 +225,41 @@ class _PendingReduce:
         st.append((partial, p, k, kp, cn, gw, gb, cs, dead))
 
     @staticmethod
-    def flush(device):
-        st = _PendingReduce._state.get(device)
-        if not st:
-            return
+    def _reduce(entries, stream_ptr):
         lib = _lib.load()
-        n = len(st)
-        ia = lambda i: (C.c_int * n)(*[e[i] for e in st])  # noqa: E731
+        n = len(entries)
+        ia = lambda i: (C.c_int * n)(*[e[i] for e in entries])  # noqa: E731
         def raw(vals):  # host array of raw device addresses (gradient slots live in the trainer's flat buffer)
             arr = (C.c_void_p * n)()
             for i, v in enumerate(vals):
                 arr[i] = v
             return arr
 
-        check(lib.otvae_wgrad_reduce_batched(n, ptr_array([e[0] for e in st]), ia(1), ia(2), ia(3), ia(4),
-                                             raw([e[5] for e in st]), raw([e[6] for e in st]), ia(7),
-                                             (C.c_uint32 * n)(*[e[8] for e in st]), stream()),
+        check(lib.otvae_wgrad_reduce_batched(n, ptr_array([e[0] for e in entries]), ia(1), ia(2), ia(3), ia(4),
+                                             raw([e[5] for e in entries]), raw([e[6] for e in entries]), ia(7),
+                                             (C.c_uint32 * n)(*[e[8] for e in entries]), stream_ptr),
               "otvae_wgrad_reduce_batched")
+
+    @staticmethod
+    def flush(device):
+        st = _PendingReduce._state.get(device)
+        if not st:
+            return
+        held = _PendingReduce._held.get(device)
+        q = _PendingReduce._wq.get(device)
+        if q and q[0]:  # the tail of the backward pass
+            _PendingReduce.issue(device, _PendingReduce.fork_point(device))
+        if _PendingReduce._forked.get(device):  # join: the partials below are complete once the side stream's jobs are
+            for side in _PendingReduce._side[device][0]:
+                torch.cuda.current_stream(device).wait_stream(side)
+            _PendingReduce._forked[device] = False
+        done = _PendingReduce._reduced.get(device, 0)
+        if done < len(st):
+            _PendingReduce._reduce(st[done:], stream())
+        _PendingReduce._reduced[device] = 0
         st.clear()
+        if held:
+            held.clear()
 
 
 # ------------------------------------------------------------------------------------------------ fused ConvLayer(s)
@@ -279,8 +366,10 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
     # the optimizer and not through autograd's accumulation) its partial -> gradient reduction is deferred so that
     # all layers of the backward pass reduce in one launch; otherwise it runs right after the multi launch:
     # autograd may clone / accumulate the returned tensor before a deferred kernel would have filled it.
-    jobs = (_lib.ConvJob * (2 * nbr))()
-    njobs = 0
+    wjobs, djobs = (_lib.ConvJob * nbr)(), (_lib.ConvJob * nbr)()
+    nw = nd = 0
+    order = []       # (is_weight_job, index) in issue order of the single-launch variant
+    all_deferred = True
     keep = []
     for b, sp in enumerate(specs):
         w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
@@ -299,8 +388,10 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
         gb = _grad_buffer(pb, bias) if sp.has_bias else None
         defer = (pw is not None and getattr(pw, "_otvae_grad_view", None) is not None and
                  (not sp.has_bias or getattr(pb, "_otvae_grad_view", None) is not None))
-        jb = jobs[njobs]
-        njobs += 1
+        all_deferred = all_deferred and defer
+        jb = wjobs[nw]
+        order.append((True, nw))
+        nw += 1
         # deferred reductions know the taps that never touch the image (1x1 / 2x2 maps): their partial rows may stay unwritten
         jb.kind, jb.relu, jb.has_bias, jb.geom = _lib.JOB_BWD_WEIGHT, int(sp.relu), int(sp.has_bias), g
         jb.defer_reduce = (_lib.DEFER_DENSE if _DENSE_REDUCE else _lib.DEFER_SPARSE) if defer else 0
@@ -308,7 +399,7 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
         jb.scale = ptr(scales[b]) if sp.has_norm else None
         jb.shift = ptr(shifts[b]) if sp.has_norm else None
         jb.wpartial, jb.gw, jb.gb = ptr(wpart), ptr(gw), ptr(gb)
-        keep += [wpart, gy]
+        keep += [wpart, gy, scales[b] if sp.has_norm else None, shifts[b] if sp.has_norm else None]
         if defer:
             dead = C.c_uint32(0)
             if not _DENSE_REDUCE:
@@ -331,8 +422,9 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
                 part = torch.empty((p_d.value, 2, cp.value), device=x.device, dtype=torch.float64)
                 cspad = cp.value
                 ps.append(p_d.value)
-            jb = jobs[njobs]
-            njobs += 1
+            jb = djobs[nd]
+            order.append((False, nd))
+            nd += 1
             jb.kind, jb.relu, jb.geom = _lib.JOB_BWD_DATA, int(sp.relu), g
             jb.gy, jb.w, jb.x = ptr(gy), ptr(wd), ptr(x)
             jb.scale = ptr(scales[b]) if sp.has_norm else None
@@ -342,9 +434,25 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
             jb.gv, jb.bn_partial = ptr(gv), ptr(part)
             keep.append(wd)
         per_branch.append((gw, gb, gv, part, gy if sp.has_residual else None))
-    check(lib.otvae_conv_multi(njobs, jobs, stream()), "otvae_conv_multi(backward)")
-    if JOB_TRACE is not None:
-        _trace_jobs(jobs, njobs)
+    if all_deferred and (WGRAD_SIDE_STREAM == 2 or (WGRAD_SIDE_STREAM == 1 and torch.cuda.is_current_stream_capturing())):
+        # weight-gradient jobs on the side stream (see _PendingReduce), data-gradient jobs on the launch stream.  The data
+        # job is issued FIRST: in a captured step the graph executor keeps the first child of a node on its parent's queue, so
+        # the critical chain stays on one queue and only the side branch pays the cross-queue dependency (~12 us each)
+        ev = _PendingReduce.fork_point(x.device) if _PendingReduce.queue_weight_jobs(x.device, wjobs, nw, [x] + keep) else None
+        if nd:
+            check(lib.otvae_conv_multi(nd, djobs, stream()), "otvae_conv_multi(backward, data)")
+            if JOB_TRACE is not None:
+                _trace_jobs(djobs, nd)
+        if ev is not None:
+            _PendingReduce.issue(x.device, ev)
+    else:
+        njobs = nw + nd
+        jobs = (_lib.ConvJob * njobs)()
+        for i, (is_w, k) in enumerate(order):
+            jobs[i] = wjobs[k] if is_w else djobs[k]
+        check(lib.otvae_conv_multi(njobs, jobs, stream()), "otvae_conv_multi(backward)")
+        if JOB_TRACE is not None:
+            _trace_jobs(jobs, njobs)
     # --- BatchNorm backward over the branches that have one
     bn_idx = [b for b, sp in enumerate(specs) if sp.has_norm]
     dgam = {b: None for b in range(nbr)}

@@ -88,9 +88,12 @@ def _attn_setup(ctx, inputs, output):
     out, lse, aux = output
     ctx.save_for_backward(qkv, out, lse, aux)
     ctx.cfg = (heads, scale)
+    ctx.set_materialize_grads(False)  # lse / aux never carry a gradient: no zero-fill launches for them in every backward pass
 
 
 def _attn_backward(ctx, gout, _glse, _gaux):
+    if gout is None:
+        return None, None, None, None
     qkv, out, lse, aux = ctx.saved_tensors
     return torch.ops.otvae.qkv_attention_backward(gout, qkv, out, lse, aux, *ctx.cfg), None, None, None
 
@@ -232,9 +235,12 @@ def _gp_setup(ctx, inputs, output):
     h, eps, coeff = inputs
     ctx.save_for_backward(h, eps)
     ctx.coeff = coeff
+    ctx.set_materialize_grads(False)  # gz / gloss are optional arguments of the backward kernel
 
 
 def _gp_backward(ctx, gz, gloss):
+    if gz is None and gloss is None:
+        return None, None, None
     h, eps = ctx.saved_tensors
     return torch.ops.otvae.gaussian_prior_backward(h, eps, gz, gloss, ctx.coeff), None, None
 

@@ -711,6 +711,40 @@ def test_dp_overlap_two_phase_backward_equals_single_phase(A):
     assert not dist.is_initialized()
 
 
+def test_side_stream_weight_gradients_equal_single_stream(A, monkeypatch):
+    """The weight-gradient jobs of the backward pass run on a second HIP stream (functional._PendingReduce: forked per backward
+    call, partial reductions on the side stream, joined before the optimizer).  Same bits as the single-stream order -- eagerly
+    issued with the side stream forced on, captured (where it is on by default), and with every fork shared by three calls."""
+    from ot_vae_lightning_amd import functional as HF
+    x = [mnist_like(64, 40 + i).cuda() for i in range(3)]
+    eps = [normal((64, 128, 1, 1), 45 + i).cuda() for i in range(3)]
+
+    def run(mode, graph, group=1, reduce_group=16):
+        monkeypatch.setattr(HF, "WGRAD_SIDE_STREAM", mode)
+        monkeypatch.setattr(HF, "WGRAD_GROUP", group)
+        monkeypatch.setattr(HF, "WGRAD_REDUCE_GROUP", reduce_group)
+        torch.manual_seed(11)
+        enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+        dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+        model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+        tr = A.HipTrainer(model, batch_shape=(64, 1, 32, 32), use_graph=graph, data_parallel=False)
+        losses = [tr.step(x[i], eps[i]).clone() for i in range(3)]
+        torch.cuda.synchronize()
+        out = tr.pflat.clone(), tr.m.clone(), tr.v.clone(), torch.stack(losses)
+        tr.close()
+        return out
+
+    ref = run(0, False)
+    HF._PendingReduce._side.clear()
+    for mode, graph, group, rg in ((2, False, 1, 16), (2, False, 3, 4), (1, True, 1, 16), (2, True, 2, 1000), (0, True, 1, 16)):
+        got = run(mode, graph, group, rg)
+        for g, r, name in zip(got, ref, ("params", "m", "v", "losses")):
+            assert torch.equal(g, r), (mode, graph, group, rg, name, float((g - r).abs().max()))
+    assert HF._PendingReduce._side, "the side stream was never used"
+    dev = next(iter(HF._PendingReduce._state))
+    assert not HF._PendingReduce._state[dev] and not HF._PendingReduce._held.get(dev) and not HF._PendingReduce._wq[dev][0]
+
+
 def test_gradient_clipping_matches_clip_grad_norm(A):
     """Global-norm clipping of the step (reference configs/ddp.yaml:4 -> Lightning -> torch.nn.utils.clip_grad_norm_): the
     norm the kernel reports, the coefficient and the clipped Adam update against torch arithmetic on the same gradient."""

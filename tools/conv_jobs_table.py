@@ -23,6 +23,7 @@ def main(all_calls=False):
     tr = A.HipTrainer(model, batch_shape=(1024, 1, 32, 32), use_graph=False)
     x = mnist_like(1024, seed=77).cuda()
     tr.step(x)
+    HF.WGRAD_SIDE_STREAM = 2 if HF.WGRAD_SIDE_STREAM else 0  # the launches of the captured step (weight gradients on the side stream)
     HF.JOB_TRACE = []
     tr.step(x)
     torch.cuda.synchronize()
