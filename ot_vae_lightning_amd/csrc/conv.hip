@@ -1236,10 +1236,16 @@ static void wgrad_plan(const Geom& g, int has_bias, int& NT, int& P, unsigned& c
         conv_small_wgrad_plan(g, P, chunk);
         return;
     }
-    // ~1024 workgroups (4 per CU; measured on MI355X: 384..3072 are within 1 % of each other for the whole step, fewer
-    // partials mean less workspace traffic), pixel chunks of >= 128 pixels, workspace <= 16 MiB, P <= 2048
+    // ~256 workgroups (1 per CU).  Measured on MI355X: 192..2048 are within 0.5 % of each other for the whole step -- the jobs run
+    // beside the data-gradient chain on their own stream -- and the split-K partial traffic (written here, read by the batched
+    // reduction) is proportional to the number of pixel chunks; pixel chunks of >= 128 pixels, workspace <= 16 MiB, P <= 2048
     const unsigned ws_cap = 4u << 20;
-    int want = cdiv(1024, nkb * nnb);
+    static const int target_wgs = [] {
+        const char* e = getenv("OTVAE_WGRAD_WGS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 64 && v <= 8192 ? v : 256;
+    }();
+    int want = cdiv(target_wgs, nkb * nnb);
     int maxp_pix = imax(1, (int)(M / 128));
     int maxp_ws = imax(1, (int)(ws_cap / ((unsigned)Kp * g.Cn)));
     P = imax(1, imin(imin(want, maxp_pix), imin(maxp_ws, 2048)));

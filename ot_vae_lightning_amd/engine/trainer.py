@@ -90,8 +90,10 @@ class HipTrainer:
         self.gradient_clip_val = None if not gradient_clip_val else float(gradient_clip_val)
         self.clip_out = torch.zeros(2, device=dev, dtype=torch.float32)
         self._clip_ws = torch.empty(self.lib.otvae_grad_clip_ws(), device=dev, dtype=torch.float64)
+        # a FRESH tensor object per call (autograd steals a gradient it holds the only reference to and clones it otherwise),
+        # made from a slot view built once: detach() is one shallow copy instead of slice + view + permute
         for p, off in zip(self.params, self.offsets):
-            p._otvae_grad_view = (lambda off=off, p=p: _dense_view(self.gflat, off, p.data))
+            p._otvae_grad_view = _dense_view(self.gflat, off, p.data).detach
         # dgrad-layout ([T][Cout][Cin]) copies of every conv weight, refreshed by ONE launch at the start of each step
         # (the ViT's Linear weights are 1x1 layers on the same kernels: [out, in] = [Cn, Cs], one tap)
         self.conv_weights = [mod.weight for mod in model.modules() if isinstance(mod, ConvLayer)]

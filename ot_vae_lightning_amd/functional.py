@@ -85,6 +85,28 @@ def _geom(x: Tensor, weight: Tensor, stride: int, pad: int, up: int) -> Tuple[Co
     return ConvGeom(n, hs, ws, cs, up, ho, wo, cn, kh, kw, stride, pad), ho, wo
 
 
+_PLAN_CACHE: dict = {}
+
+
+def _conv_plan(g: ConvGeom, has_bias: bool):
+    """Workspace shapes the library wants for this geometry -- (forward statistics partials, their row length, weight-gradient
+    partials, data-gradient BatchNorm partials, their row length, dead-tap mask) -- asked once per geometry: four C calls per
+    layer and pass otherwise, on a host-bound eagerly issued step."""
+    env = os.environ  # the kernel-selection switches (DESIGN.md section 4) are read per call by the library and change the plan
+    key = (g.N, g.Hs, g.Ws, g.Cs, g.up, g.Ho, g.Wo, g.Cn, g.KH, g.KW, g.stride, g.pad, has_bias,
+           "OTVAE_NO_TILE" in env, "OTVAE_NO_WTILE" in env, "OTVAE_TILE_ALL" in env, "OTVAE_WTILE_ALL" in env)
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        lib = _lib.load()
+        p_s, ld, p_w, p_d, cp, dead = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_uint32(0)
+        check(lib.otvae_conv_fwd_stats_ws(C.byref(g), C.byref(p_s), C.byref(ld)), "otvae_conv_fwd_stats_ws")
+        check(lib.otvae_conv_bwd_weight_ws(C.byref(g), int(has_bias), C.byref(p_w)), "otvae_conv_bwd_weight_ws")
+        check(lib.otvae_conv_bwd_data_ws(C.byref(g), C.byref(p_d), C.byref(cp)), "otvae_conv_bwd_data_ws")
+        check(lib.otvae_conv_dead_taps(C.byref(g), C.byref(dead)), "otvae_conv_dead_taps")
+        plan = _PLAN_CACHE[key] = (p_s.value, ld.value, p_w.value, p_d.value, cp.value, dead.value)
+    return plan
+
+
 # ------------------------------------------------------------------------------------------------ BatchNorm stats
 class BNBranch:
     """What one ConvLayer contributes to a (possibly shared) BatchNorm statistics pass."""
@@ -328,10 +350,9 @@ def conv_forward_launch(x, specs, stats, tensors):
         y = empty_nhwc(x.shape[0], w.shape[0], ho, wo, x)
         part, st = None, None
         if sp.out_stats:
-            p_s, ld = C.c_int(0), C.c_int(0)
-            check(lib.otvae_conv_fwd_stats_ws(C.byref(g), C.byref(p_s), C.byref(ld)), "otvae_conv_fwd_stats_ws")
-            part = torch.empty((p_s.value, 2, ld.value), device=x.device, dtype=torch.float64)
-            st = (part, p_s.value, ld.value)
+            p_s, ld = _conv_plan(g, bias is not None)[:2]
+            part = torch.empty((p_s, 2, ld), device=x.device, dtype=torch.float64)
+            st = (part, p_s, ld)
         jb = jobs[b]
         jb.kind, jb.relu, jb.geom = _lib.JOB_FWD, int(sp.relu), g
         jb.x = ptr(x)
@@ -380,10 +401,9 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
         gy = as_nhwc(gy)
         g = geoms[b]
         # --- weight / bias gradient
-        p_w = C.c_int(0)
-        check(lib.otvae_conv_bwd_weight_ws(C.byref(g), int(sp.has_bias), C.byref(p_w)), "otvae_conv_bwd_weight_ws")
+        _, _, p_w, p_d, cp, dead_taps = _conv_plan(g, sp.has_bias)
         kk = g.KH * g.KW * g.Cs + (1 if sp.has_bias else 0)
-        wpart = torch.empty((p_w.value, kk, g.Cn), device=x.device, dtype=torch.float32)
+        wpart = torch.empty((p_w, kk, g.Cn), device=x.device, dtype=torch.float32)
         gw = _grad_buffer(pw, w)
         gb = _grad_buffer(pb, bias) if sp.has_bias else None
         defer = (pw is not None and getattr(pw, "_otvae_grad_view", None) is not None and
@@ -401,11 +421,8 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
         jb.wpartial, jb.gw, jb.gb = ptr(wpart), ptr(gw), ptr(gb)
         keep += [wpart, gy, scales[b] if sp.has_norm else None, shifts[b] if sp.has_norm else None]
         if defer:
-            dead = C.c_uint32(0)
-            if not _DENSE_REDUCE:
-                check(lib.otvae_conv_dead_taps(C.byref(g), C.byref(dead)), "otvae_conv_dead_taps")
-            _PendingReduce.add(x.device, wpart, p_w.value, kk - (1 if sp.has_bias else 0), kk, g.Cn,
-                               gw.data_ptr(), gb.data_ptr() if gb is not None else None, g.Cs, dead.value)
+            _PendingReduce.add(x.device, wpart, p_w, kk - (1 if sp.has_bias else 0), kk, g.Cn,
+                               gw.data_ptr(), gb.data_ptr() if gb is not None else None, g.Cs, 0 if _DENSE_REDUCE else dead_taps)
         # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
         gv = None
         part = None
@@ -415,13 +432,11 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
                 wd = torch.empty(g.KH * g.KW * g.Cn * g.Cs, device=x.device, dtype=torch.float32)
                 check(lib.otvae_weight_transpose(ptr(w), ptr(wd), g.KH * g.KW, g.Cs, g.Cn, stream()),
                       "otvae_weight_transpose")
-            p_d, cp = C.c_int(0), C.c_int(0)
-            check(lib.otvae_conv_bwd_data_ws(C.byref(g), C.byref(p_d), C.byref(cp)), "otvae_conv_bwd_data_ws")
             gv = empty_nhwc(n, cs, hs, ws, x)
             if sp.has_norm:
-                part = torch.empty((p_d.value, 2, cp.value), device=x.device, dtype=torch.float64)
-                cspad = cp.value
-                ps.append(p_d.value)
+                part = torch.empty((p_d, 2, cp), device=x.device, dtype=torch.float64)
+                cspad = cp
+                ps.append(p_d)
             jb = djobs[nd]
             order.append((False, nd))
             nd += 1
