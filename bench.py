@@ -236,10 +236,12 @@ def _job_algorithmic(job):
 
 
 def time_largest_aggregate_kernel(A, workload, iters=10):
-    """The kernel with the largest aggregate share of the step (profiles/: ``conv_jobs_kernel<true>``, the packed data- and
-    weight-gradient launches of the deep layers, 24 launches = 16 % of the step): the step's own otvae_conv_multi calls that
-    end in that kernel are recorded from one eager step (functional.JOB_TRACE + otvae_conv_multi_last), re-issued on tensors
-    of the same shapes through the C ABI into one hipGraph, and timed with HIP events on the launch stream."""
+    """The MFMA kernel with the largest aggregate share of the step (profiles/r02_final_replay_kernel_stats.csv:
+    ``conv_jobs_kernel<true>``, the packed launches of a ConvBlock's two branches -- forward and data gradient; 9 launches = 5.7 %
+    of the step now that the weight-gradient jobs run on their own stream, 24 launches = 16 % before): the step's own
+    otvae_conv_multi calls that end in that kernel are recorded from one step issued as the captured step issues it
+    (functional.JOB_TRACE + otvae_conv_multi_last), re-issued on tensors of the same shapes through the C ABI into one hipGraph,
+    and timed with HIP events on the launch stream."""
     import ctypes as C
     from ot_vae_lightning_amd import functional as HF
     from ot_vae_lightning_amd import _lib as L
@@ -331,7 +333,7 @@ def time_largest_aggregate_kernel(A, workload, iters=10):
     torch.cuda.synchronize()
     n_launch = len(launches)
     ms = e0.elapsed_time(e1) / (4 * iters * n_launch)
-    return {"kernel": "conv_jobs_kernel<true> (packed data + weight gradients of one ConvBlock stage, implicit GEMM, fp32 MFMA 16x16x4)",
+    return {"kernel": "conv_jobs_kernel<true> (the packed forward / data-gradient jobs of a ConvBlock's two branches, implicit GEMM, fp32 MFMA 16x16x4)",
             "launches_per_step": n_launch, "ms": ms, "alg_bytes": tot_bytes / n_launch, "alg_flops": tot_flops / n_launch,
             "pmc_traffic_bytes": pmc_traffic("conv_jobs_kernel<true>")}
 
