@@ -191,6 +191,22 @@ int otvae_attn_dropout_fwd(const float* qkv, int N, int T, int H, int C, float s
 int otvae_attn_dropout_bwd(const float* qkv, const float* out, const float* lse, const float* gout, int N, int T, int H,
                            int C, float scale, float p, int causal, const int64_t* used, float* gqkv, void* stream);
 int otvae_attn_dropout_mask(int N, int T, int H, float p, const int64_t* used, uint8_t* keep, void* stream);
+/* Cross-attention: nn.MultiheadAttention(query, memory, memory) inside the nn.TransformerDecoderLayer of the ViT's
+ * `preprocess_depth` variant (networks/vit.py:171-181, 240-244): Tq queries of one token set against Tk keys / values of another,
+ * scores = scale * q.k, the same dropout on the probabilities as above (p may be 0: key / used may then be NULL).  q, k and v
+ * are addressed as ptr[n * img_stride + t * row_stride + h * C + c] (strides in floats), so thirds of one in-projected
+ * tensor or three separate tensors both fit; out [N][Tq][H*C], lse [N][H][Tq]; the backward writes gq / gk / gv through their
+ * own strides and touches nothing else.  max(Tq, Tk) <= 256 and max(Tq, Tk)*(2C+3) <= 16384; C in {1,2,4,8,16,32}. */
+int otvae_attn_cross_fwd(const float* q, int64_t q_img_stride, int q_row_stride, const float* k, const float* v,
+                         int64_t kv_img_stride, int kv_row_stride, int N, int Tq, int Tk, int H, int C, float scale, float p,
+                         const int64_t* key, int stream_id, float* out, float* lse, int64_t* used, void* stream);
+int otvae_attn_cross_bwd(const float* q, int64_t q_img_stride, int q_row_stride, const float* k, const float* v,
+                         int64_t kv_img_stride, int kv_row_stride, const float* out, const float* lse, const float* gout, int N,
+                         int Tq, int Tk, int H, int C, float scale, float p, const int64_t* used, float* gq,
+                         int64_t gq_img_stride, int gq_row_stride, float* gk, float* gv, int64_t gkv_img_stride,
+                         int gkv_row_stride, void* stream);
+/* keep as uint8 [N][H][Tq][Tk] of the cross-attention call whose forward left `used` (test / debugging aid) */
+int otvae_attn_cross_mask(int N, int Tq, int Tk, int H, float p, const int64_t* used, uint8_t* keep, void* stream);
 
 /* ---- LayerNorm over the last dimension (the token streams of the ViT: networks/vit.py:38,54 and the two norms of each
  * nn.TransformerEncoderLayer, :169-172; torch.nn.functional.layer_norm arithmetic) ---------------------------------------

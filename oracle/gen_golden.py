@@ -781,6 +781,70 @@ def gen_vit_causal():
     save("vit_causal.npz", out)
 
 
+VIT_CROSS_CASES = {
+    # role, preprocess_depth, causal_mask
+    "enc_p1": ("enc", 1, False),          # 2 embed tokens attend to 16 patches + class token after one encoder layer
+    "dec_p0_causal": ("dec", 0, True),    # 16 patch tokens (causal self-attention) attend to latent + class token, no preprocessing
+}
+
+
+def gen_vit_cross():
+    """G17 (the last open item): the reference's cross-attention ViT -- ``preprocess_depth`` makes the output
+    tokens the target of an nn.TransformerDecoder whose memory is the other tokens (networks/vit.py:171-181,240-244) -- in the
+    d32 configuration of G12 for both roles: outputs, input gradient, every parameter gradient."""
+    vit = R.ref("networks.vit")
+    out = {}
+    _, cfg, B = VIT_CASES[0]
+    roles = {"enc": dict(n_embed_tokens=2, n_input_tokens=None, patch_to_embed=True, embed_to_patch=False),
+             "dec": dict(n_embed_tokens=None, n_input_tokens=1, patch_to_embed=False, embed_to_patch=True)}
+    labels = torch.arange(B) % 10
+    for tag, (role, pre, causal) in VIT_CROSS_CASES.items():
+        net = vit.ViT(output_tokens="embed", preprocess_depth=pre, causal_mask=causal, **roles[role], **cfg)
+        net.train()
+        fill_vit_state_dict(net.state_dict())
+        shape = (B, cfg["channels"], cfg["image_size"], cfg["image_size"]) if role == "enc" else (B, 1, cfg["dim"])
+        x = det_input(shape, 0.3 if role == "enc" else 0.8).clone().requires_grad_(True)
+        y = net(x, labels=labels)
+        g = det_input(tuple(y.shape), 1.1, 0.5)
+        y.backward(g)
+        out[f"{tag}/x"], out[f"{tag}/y"], out[f"{tag}/gy"], out[f"{tag}/gx"] = npy(x), npy(y), npy(g), npy(x.grad)
+        out[f"{tag}/param_names"] = np.array(list(net.state_dict().keys()))
+        for k, p in net.named_parameters():
+            if p.numel() <= 4096:
+                out[f"{tag}/grad/{k}"] = npy(p.grad)
+            else:
+                gd = p.grad.double().flatten()
+                out[f"{tag}/gradsum/{k}"] = np.concatenate([[gd.sum().item(), gd.norm().item()], gd[:16].numpy()])
+    out["labels"] = npy(labels)
+    save("vit_cross.npz", out)
+
+
+AR_CFG = dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, dropout=0.0, emb_dropout=0.,
+              num_classes=10, n_input_tokens=7, n_embed_tokens=0, output_tokens="input", patch_to_embed=False, embed_to_patch=False,
+              causal_mask=True)
+
+
+def gen_vit_autoregressive():
+    """G18: ``AutoRegressive`` (networks/vit.py:249-260) -- 7 token ids of a 13-word vocabulary, causal self-attention, class token
+    -> logits: output, parameter gradients (the ids carry none)."""
+    vit = R.ref("networks.vit")
+    out = {}
+    B, V = 4, 13
+    net = vit.AutoRegressive(vocab_size=V, **AR_CFG)
+    net.train()
+    fill_vit_state_dict(net.state_dict())
+    ids = (torch.arange(B * 7).reshape(B, 7) * 5 + 3) % V
+    labels = torch.arange(B) % 10
+    y = net(ids, labels=labels)
+    g = det_input(tuple(y.shape), 1.1, 0.5)
+    y.backward(g)
+    out["ids"], out["labels"], out["y"], out["gy"] = npy(ids), npy(labels), npy(y), npy(g)
+    out["param_names"] = np.array(list(net.state_dict().keys()))
+    for k, p in net.named_parameters():
+        out[f"grad/{k}"] = npy(p.grad)
+    save("vit_autoregressive.npz", out)
+
+
 def gen_vit_vae():
     """G13: ConditionalGaussianPrior alone (learned embeddings: z, loss, gradients of x and of the two
     embeddings; EMA embeddings: the buffers after two training steps) and VAE.nelbo of the conditional ViT VAE of
@@ -1033,6 +1097,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive"]
     for w in which:
         globals()["gen_" + w]()

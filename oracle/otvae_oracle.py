@@ -681,28 +681,54 @@ def gmm_transport_apply(x: Tensor, src: Dict[str, Tensor], tgt: Dict[str, Tensor
 
 
 # ------------------------------------------------------------------------------------------------ ViT
-def transformer_encoder_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int) -> Tensor:
+def transformer_encoder_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, causal: bool = False) -> Tensor:
     """One post-norm ``nn.TransformerEncoderLayer(dim, heads, mlp_dim, dropout=0, batch_first=True)`` as the reference's ViT
     builds them (networks/vit.py:169-172): x = LN1(x + out_proj(MHA(x))); x = LN2(x + linear2(relu(linear1(x)))), with
     ``nn.MultiheadAttention``'s packed in-projection (q | k | v, head-major channels) and 1/sqrt(head width) scores."""
-    n, t, d = x.shape
-    hd = d // heads
-    qkv = F.linear(x, p[prefix + "self_attn.in_proj_weight"], p[prefix + "self_attn.in_proj_bias"])
-    q, k, v = (z.reshape(n, t, heads, hd).transpose(1, 2) for z in qkv.chunk(3, dim=-1))
-    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ v
-    sa = F.linear(att.transpose(1, 2).reshape(n, t, d), p[prefix + "self_attn.out_proj.weight"], p[prefix + "self_attn.out_proj.bias"])
-    x = F.layer_norm(x + sa, (d,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], 1e-5)
+    d = x.shape[-1]
+    x = F.layer_norm(x + _mha(x, x, p, prefix + "self_attn.", heads, causal), (d,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], 1e-5)
     ff = F.linear(torch.relu(F.linear(x, p[prefix + "linear1.weight"], p[prefix + "linear1.bias"])),
                   p[prefix + "linear2.weight"], p[prefix + "linear2.bias"])
     return F.layer_norm(x + ff, (d,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], 1e-5)
 
 
+def _mha(xq: Tensor, xkv: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, causal: bool = False) -> Tensor:
+    """``nn.MultiheadAttention(xq, xkv, xkv)`` with the packed in-projection: q from the first third of in_proj on xq, k | v from
+    the other two thirds on xkv; ``causal``: the -inf upper triangle of nn.Transformer.generate_square_subsequent_mask."""
+    n, tq, d = xq.shape
+    tk, hd = xkv.shape[1], d // heads
+    w, b = p[prefix + "in_proj_weight"], p[prefix + "in_proj_bias"]
+    q = F.linear(xq, w[:d], b[:d]).reshape(n, tq, heads, hd).transpose(1, 2)
+    k = F.linear(xkv, w[d:2 * d], b[d:2 * d]).reshape(n, tk, heads, hd).transpose(1, 2)
+    v = F.linear(xkv, w[2 * d:], b[2 * d:]).reshape(n, tk, heads, hd).transpose(1, 2)
+    sc = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    if causal:
+        sc = sc + torch.full((tq, tk), float("-inf"), dtype=sc.dtype).triu(1)
+    att = torch.softmax(sc, dim=-1) @ v
+    return F.linear(att.transpose(1, 2).reshape(n, tq, d), p[prefix + "out_proj.weight"], p[prefix + "out_proj.bias"])
+
+
+def transformer_decoder_layer(x: Tensor, memory: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, causal: bool = False) -> Tensor:
+    """One post-norm ``nn.TransformerDecoderLayer(dim, heads, mlp_dim, dropout=0, batch_first=True)`` of the reference's
+    cross-attention ViT (networks/vit.py:176-181): x = LN1(x + self_attn(x)); x = LN2(x + multihead_attn(x, memory, memory));
+    x = LN3(x + linear2(relu(linear1(x))))."""
+    d = x.shape[-1]
+    x = F.layer_norm(x + _mha(x, x, p, prefix + "self_attn.", heads, causal), (d,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], 1e-5)
+    x = F.layer_norm(x + _mha(x, memory, p, prefix + "multihead_attn.", heads), (d,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], 1e-5)
+    ff = F.linear(torch.relu(F.linear(x, p[prefix + "linear1.weight"], p[prefix + "linear1.bias"])),
+                  p[prefix + "linear2.weight"], p[prefix + "linear2.bias"])
+    return F.layer_norm(x + ff, (d,), p[prefix + "norm3.weight"], p[prefix + "norm3.bias"], 1e-5)
+
+
 def vit_forward(x: Tensor, p: Dict[str, Tensor], *, image_size: int, patch_size: int, dim: int, depth: int, heads: int,
                 channels: int, n_embed_tokens: Optional[int], n_input_tokens: Optional[int], patch_to_embed: bool,
-                embed_to_patch: bool, labels: Optional[Tensor] = None) -> Tensor:
-    """``ViT.forward`` (networks/vit.py:225-246) for output_tokens='embed', no time token, no causal mask, dropout 0:
+                embed_to_patch: bool, labels: Optional[Tensor] = None, preprocess_depth: Optional[int] = None,
+                causal_mask: bool = False, output_tokens: str = "embed") -> Tensor:
+    """``ViT.forward`` (networks/vit.py:225-246) for output_tokens='embed', no time token, dropout 0:
     [patchify + Linear] -> append the learned embed tokens (and the class token) -> + positions, LayerNorm
-    (PositionalEmbedding :41-58) -> the encoder layers -> the embed tokens -> [Linear + un-patchify]."""
+    (PositionalEmbedding :41-58) -> the encoder layers -> the embed tokens -> [Linear + un-patchify].
+    ``preprocess_depth`` (:171-181, 240-244): the embed tokens are the target of decoder layers whose memory is the other tokens
+    after ``preprocess_depth`` encoder layers (state_dict prefix ``prepocess.``, the reference's spelling)."""
     ps = patch_size
     nh = image_size // ps
     num_patches = nh * nh
@@ -718,15 +744,30 @@ def vit_forward(x: Tensor, p: Dict[str, Tensor], *, image_size: int, patch_size:
         x = torch.cat((x, p["class_token.weight"][labels].unsqueeze(1)), dim=1)
     x = x + p["positional_embed.position_embeddings.weight"][:x.size(1)].unsqueeze(0)
     x = F.layer_norm(x, (dim,), p["positional_embed.LayerNorm.weight"], p["positional_embed.LayerNorm.bias"], 1e-5)
-    for i in range(depth):
-        x = transformer_encoder_layer(x, p, f"transformer.layers.{i}.", heads)
-    out = x[:, n_in:n_in + n_emb]
+    lo, hi = (n_in, n_in + n_emb) if output_tokens == "embed" else (0, n_in)   # token order: input, embed, class
+    if preprocess_depth is None:
+        for i in range(depth):
+            x = transformer_encoder_layer(x, p, f"transformer.layers.{i}.", heads, causal_mask)
+        out = x[:, lo:hi]
+    else:
+        out = x[:, lo:hi]
+        memory = torch.cat((x[:, :lo], x[:, hi:]), dim=1)
+        for i in range(preprocess_depth):
+            memory = transformer_encoder_layer(memory, p, f"prepocess.layers.{i}.", heads)
+        for i in range(depth):
+            out = transformer_decoder_layer(out, memory, p, f"transformer.layers.{i}.", heads, causal_mask)
     if embed_to_patch:
         out = out[:, -num_patches:]
         out = F.linear(out, p["embed_to_patch.0.weight"], p["embed_to_patch.0.bias"])
         b = out.size(0)
         out = out.reshape(b, nh, nh, ps, ps, channels).permute(0, 5, 1, 3, 2, 4).reshape(b, channels, nh * ps, nh * ps)
     return out
+
+
+def autoregressive_forward(tokens: Tensor, p: Dict[str, Tensor], **vit_kwargs) -> Tensor:
+    """``AutoRegressive.forward`` (networks/vit.py:249-260): vocabulary embedding -> the ViT on the embedded tokens -> Linear head"""
+    hs = vit_forward(p["vocab_embed.weight"][tokens], p, **vit_kwargs)
+    return F.linear(hs, p["head.weight"], p["head.bias"])
 
 
 # ------------------------------------------------------------------------------------------------ conditional prior, ViT VAE

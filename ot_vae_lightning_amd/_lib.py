@@ -69,6 +69,10 @@ SIGNATURES = {
     "otvae_attn_dropout_fwd": (i32, [vp, i32, i32, i32, i32, f32, f32, i32, vp, i32, vp, vp, vp, vp]),
     "otvae_attn_dropout_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, vp]),
     "otvae_attn_dropout_mask": (i32, [i32, i32, i32, f32, vp, vp, vp]),
+    "otvae_attn_cross_fwd": (i32, [vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, f32, vp, i32, vp, vp, vp, vp]),
+    "otvae_attn_cross_mask": (i32, [i32, i32, i32, i32, f32, vp, vp, vp]),
+    "otvae_attn_cross_bwd": (i32, [vp, i64, i32, vp, vp, i64, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp, vp, i64, i32,
+                                   vp, vp, i64, i32, vp]),
     "otvae_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]),
     "otvae_layernorm_bwd_ws": (i32, [i32, i32]),
     "otvae_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),

@@ -780,6 +780,68 @@ class _AttentionDropoutFn(torch.autograd.Function):
         return gqkv, None, None, None, None, None, None
 
 
+class _CrossAttentionFn(torch.autograd.Function):
+    """Tq queries against the keys / values of the Tk memory tokens, all three taken from ONE in-projected tensor
+    ``qkv`` [N, Tq + Tk, 3 H C] (rows 0..Tq-1: the queries' projection, rows Tq..: the memory's; q | k | v head-major): q from
+    the first third of the query rows, k / v from the other thirds of the memory rows.  The unused thirds get zero gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, tq, heads, scale, p, key, stream_id):
+        lib = _lib.load()
+        n, tall, w3 = qkv.shape
+        tk, hc = tall - tq, w3 // 3
+        c = hc // heads
+        out = torch.empty((n, tq, hc), device=qkv.device, dtype=torch.float32)
+        lse = torch.empty((n, heads, tq), device=qkv.device, dtype=torch.float32)
+        used = torch.empty(1, device=qkv.device, dtype=torch.int64) if p > 0 else None
+        base = qkv.data_ptr()
+        kv0 = base + 4 * tq * w3  # first memory row
+        check(lib.otvae_attn_cross_fwd(base, tall * w3, w3, kv0 + 4 * hc, kv0 + 8 * hc, tall * w3, w3, n, tq, tk, heads, c, float(scale),
+                                       float(p), ptr(key) if p > 0 else None, int(stream_id), ptr(out), ptr(lse), ptr(used), stream()),
+              "otvae_attn_cross_fwd")
+        ctx.save_for_backward(qkv, out, lse, used)
+        ctx.dims = (n, tq, tk, heads, c, float(scale), float(p))
+        _CrossAttentionFn.last_used = used  # test aid: the call key of the latest forward (attention_cross_mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        qkv, out, lse, used = ctx.saved_tensors
+        n, tq, tk, heads, c, scale, p = ctx.dims
+        hc, w3, tall = heads * c, 3 * heads * c, tq + tk
+        gout = gout.contiguous()
+        gqkv = torch.zeros_like(qkv)  # the memory rows' q third and the query rows' k | v thirds took no part
+        base, gbase = qkv.data_ptr(), gqkv.data_ptr()
+        kv0, gkv0 = base + 4 * tq * w3, gbase + 4 * tq * w3
+        check(lib.otvae_attn_cross_bwd(base, tall * w3, w3, kv0 + 4 * hc, kv0 + 8 * hc, tall * w3, w3, ptr(out), ptr(lse), ptr(gout),
+                                       n, tq, tk, heads, c, scale, p, ptr(used), gbase, tall * w3, w3, gkv0 + 4 * hc, gkv0 + 8 * hc,
+                                       tall * w3, w3, stream()), "otvae_attn_cross_bwd")
+        return gqkv, None, None, None, None, None, None
+
+
+def attention_cross_mask(used: Tensor, n: int, tq: int, tk: int, heads: int, p: float) -> Tensor:
+    """the keep mask [N, H, Tq, Tk] (bool) of the cross-attention call whose forward left ``used`` -- for tests"""
+    keep = torch.empty((n, heads, tq, tk), device=used.device, dtype=torch.uint8)
+    check(_lib.load().otvae_attn_cross_mask(n, tq, tk, heads, float(p), ptr(used), ptr(keep), stream()), "otvae_attn_cross_mask")
+    return keep.bool()
+
+
+def cross_attention_tokens(x: Tensor, memory: Tensor, in_proj_weight: Tensor, in_proj_bias: Optional[Tensor], n_heads: int,
+                           dropout_p: float = 0.0, dropout_key: Optional[Tensor] = None, stream_id: int = 0) -> Tensor:
+    """The attention part of ``nn.MultiheadAttention(x, memory, memory)`` (before out_proj): softmax(q k^T / sqrt(C)) v with
+    q = in_proj(x)[..., :D], k | v = in_proj(memory)[..., D:].  Both token sets go through ONE in-projection launch
+    (concatenated along the token axis: a parameter enters the step once, so its gradient slot is written once), the
+    attention kernel reads the thirds it needs through strides."""
+    _lib.require_cuda(x, "x")
+    if dropout_p > 0 and dropout_key is None:
+        raise ValueError("`dropout_p` > 0 needs a `dropout_key` (functional.new_dropout_key)")
+    tq = x.shape[1]
+    qkv = linear_tokens(torch.cat((x, memory), dim=1), in_proj_weight, in_proj_bias).contiguous()
+    c = qkv.shape[-1] // (3 * n_heads)
+    return _CrossAttentionFn.apply(qkv, tq, n_heads, 1.0 / math.sqrt(c), float(dropout_p), dropout_key, stream_id)
+
+
 def new_dropout_key(device, seed: Optional[int] = None) -> Tensor:
     """device int64[2] {seed, call counter} for ``mha_attention_tokens(dropout_p > 0)``; the seed comes from torch's default
     generator unless given, so ``torch.manual_seed`` governs the masks"""

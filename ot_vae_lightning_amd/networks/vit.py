@@ -9,8 +9,12 @@ The transformer is the reference's ``nn.TransformerEncoder`` of post-norm ``nn.T
 drawn by constructing the very torch modules the reference constructs, in its order, so a seeded construction gives the
 reference's initial weights (note that ``nn.TransformerEncoder`` deep-copies ONE layer: all layers start identical).
 
-Not implemented (they raise): the cross-attention variant (``preprocess_depth``) and ``time_dependant``.  ``causal_mask``
-runs on the generic attention kernels of ``attention_dropout.hip`` (softmax over tokens <= t).
+``preprocess_depth`` (networks/vit.py:171-181,240-244): the output tokens become the target of an ``nn.TransformerDecoder``
+(post-norm layers: self-attention, cross-attention over the memory, feed-forward) whose memory is the remaining tokens, run
+through ``preprocess_depth`` encoder layers first; the cross-attention kernel (``otvae_attn_cross_*``) reads queries and
+keys / values of different token counts.  Not implemented (raises): ``time_dependant`` (the reference's own time token cannot
+be constructed).  ``causal_mask`` runs on the generic attention kernels of ``attention_dropout.hip``
+(softmax over tokens <= t).
 Dropout > 0 in training mode: the three dropouts of a layer that act on token tensors are applied with
 ``torch.nn.functional.dropout`` between the kernels; the fourth, nn.MultiheadAttention's dropout on the attention
 probabilities, happens inside the attention kernel (``otvae_attn_dropout_*``: the mask is a hash recomputed by the
@@ -26,7 +30,7 @@ from torch import Tensor
 
 from .. import functional as HF
 
-__all__ = ["PositionalEmbedding", "ViT", "TokenLinear", "TokenLayerNorm", "TokenEncoderLayer"]
+__all__ = ["PositionalEmbedding", "ViT", "AutoRegressive", "TokenLinear", "TokenLayerNorm", "TokenEncoderLayer", "TokenDecoderLayer"]
 
 
 def pair(t):
@@ -136,6 +140,78 @@ class _Encoder(nn.Module):
         return x
 
 
+class _CrossAttention(nn.Module):
+    """``nn.MultiheadAttention(x, memory, memory)`` with its parameter names; q from x, k | v from the memory tokens"""
+
+    def __init__(self, like: nn.MultiheadAttention):
+        super().__init__()
+        self.embed_dim, self.num_heads = like.embed_dim, like.num_heads
+        self.in_proj_weight = _adopt(like.in_proj_weight.data)
+        self.in_proj_bias = nn.Parameter(like.in_proj_bias.data.clone())
+        self.out_proj = TokenLinear(like.embed_dim, like.embed_dim, like=like.out_proj)
+
+    def forward(self, x: Tensor, memory: Tensor, dropout_p: float = 0.0, dropout_key: Optional[Tensor] = None,
+                stream_id: int = 0) -> Tensor:
+        return self.out_proj(HF.cross_attention_tokens(x, memory, self.in_proj_weight, self.in_proj_bias, self.num_heads,
+                                                       dropout_p, dropout_key, stream_id))
+
+
+class TokenDecoderLayer(nn.Module):
+    """post-norm ``nn.TransformerDecoderLayer(dim, heads, mlp_dim, dropout, batch_first=True)``:
+    x = norm1(x + self_attn(x)); x = norm2(x + multihead_attn(x, memory, memory)); x = norm3(x + linear2(relu(linear1(x))))"""
+
+    def __init__(self, like: nn.TransformerDecoderLayer):
+        super().__init__()
+        if getattr(like, "norm_first", False):
+            raise NotImplementedError("norm_first transformer layers are not implemented on the MI355X path")
+        self.self_attn = _SelfAttention(like.self_attn)
+        self.multihead_attn = _CrossAttention(like.multihead_attn)
+        self.linear1 = TokenLinear(like.linear1.in_features, like.linear1.out_features, like=like.linear1)
+        self.linear2 = TokenLinear(like.linear2.in_features, like.linear2.out_features, like=like.linear2)
+        self.norm1 = TokenLayerNorm(like.norm1.normalized_shape[0], like.norm1.eps)
+        self.norm2 = TokenLayerNorm(like.norm2.normalized_shape[0], like.norm2.eps)
+        self.norm3 = TokenLayerNorm(like.norm3.normalized_shape[0], like.norm3.eps)
+        self.p = float(like.dropout.p)
+
+    def _drop(self, x: Tensor) -> Tensor:
+        return F.dropout(x, self.p, True) if (self.training and self.p > 0) else x
+
+    def forward(self, x: Tensor, memory: Tensor, dropout_key: Optional[Tensor] = None, index: int = 0, causal: bool = False) -> Tensor:
+        """Dropout call sites of layer i under one key (the encoder layers of ``prepocess`` own 0.., 1024.., 2048..): 256 + i
+        self-attention, 512 + i cross-attention, 3072 + 3 i + {0, 1, 2} the three norms, 2304 + i the feed-forward pair."""
+        fused = self.training and self.p > 0 and dropout_key is not None
+        p, i = (self.p if fused else 0.0), index
+        a = self.self_attn(x, p, dropout_key, 256 + i, causal)
+        x = self.norm1(a, x, p, dropout_key, 3072 + 3 * i) if fused else self.norm1(self._drop(a), residual=x)
+        c = self.multihead_attn(x, memory, p, dropout_key, 512 + i)
+        x = self.norm2(c, x, p, dropout_key, 3073 + 3 * i) if fused else self.norm2(self._drop(c), residual=x)
+        h = self.linear1(x)
+        if fused and h.shape[-1] % 4 == 0:
+            f = self.linear2(HF.dropout_tokens(h, p, dropout_key, 2304 + i, relu=True))
+        elif self.training and self.p > 0:
+            f = self.linear2(self._drop(torch.relu(h)))
+        else:
+            f = self.linear2(h, relu_input=True)
+        return self.norm3(f, x, p, dropout_key, 3074 + 3 * i) if fused else self.norm3(self._drop(f), residual=x)
+
+
+class _Decoder(nn.Module):
+    """``nn.TransformerDecoder``: keys ``layers.{i}.*``"""
+
+    def __init__(self, like: nn.TransformerDecoder):
+        super().__init__()
+        self.layers = nn.ModuleList([TokenDecoderLayer(layer) for layer in like.layers])
+        if like.norm is not None:
+            raise NotImplementedError("a final norm on the TransformerDecoder is not part of the reference's ViT")
+        if len(self.layers) > 256:
+            raise NotImplementedError("more than 256 decoder layers share dropout call-site ids with other layers")
+
+    def forward(self, x: Tensor, memory: Tensor, dropout_key: Optional[Tensor] = None, causal: bool = False) -> Tensor:
+        for i, layer in enumerate(self.layers):
+            x = layer(x, memory, dropout_key, i, causal)
+        return x
+
+
 class PositionalEmbedding(nn.Module):
     """learned positions added to the tokens, then LayerNorm (+ dropout): reference networks/vit.py:33-58"""
 
@@ -197,8 +273,6 @@ class ViT(nn.Module):
                  patch_to_embed: bool = True, embed_to_patch: bool = False, num_classes: Optional[int] = None,
                  time_dependant: bool = False, causal_mask: bool = False):
         super().__init__()
-        if preprocess_depth is not None:
-            raise NotImplementedError("the cross-attention ViT (`preprocess_depth`) is not implemented on the MI355X path")
         if time_dependant:
             raise NotImplementedError("`time_dependant` (Fourier time token) is not implemented on the MI355X path")
         self.dim, self.causal_mask = dim, causal_mask
@@ -237,19 +311,33 @@ class ViT(nn.Module):
         self.class_token = nn.Embedding(num_classes, dim) if self.n_tokens["class"] > 0 else None
         self.time_token = None
         self.positional_embed = PositionalEmbedding(self.total_num_tokens, dim, emb_dropout, True)
-        self.prepocess = None
-        self.transformer = _Encoder(nn.TransformerEncoder(
-            encoder_layer=nn.TransformerEncoderLayer(dim, heads, mlp_dim, dropout, batch_first=True), num_layers=depth,
-            enable_nested_tensor=False))
+        if preprocess_depth is None:
+            self.prepocess = None   # (sic: the reference's attribute and state_dict name)
+            self.transformer = _Encoder(nn.TransformerEncoder(
+                encoder_layer=nn.TransformerEncoderLayer(dim, heads, mlp_dim, dropout, batch_first=True), num_layers=depth,
+                enable_nested_tensor=False))
+        else:
+            if not self.cross_tokens_indices:
+                raise ValueError("the cross-attention ViT needs tokens outside `output_tokens` to attend to")
+            self.prepocess = _Encoder(nn.TransformerEncoder(
+                encoder_layer=nn.TransformerEncoderLayer(dim, heads, mlp_dim, dropout, batch_first=True),
+                num_layers=preprocess_depth, enable_nested_tensor=False)) if preprocess_depth > 0 else nn.Identity()
+            self.transformer = _Decoder(nn.TransformerDecoder(
+                decoder_layer=nn.TransformerDecoderLayer(dim, heads, mlp_dim, dropout, batch_first=True), num_layers=depth))
         self.out_size = torch.Size([channels, image_height, image_width]) if embed_to_patch else \
             torch.Size([len(self.output_tokens_indices), dim])
 
-    def _out_index(self, device) -> Tensor:
-        cached = self.__dict__.get("_out_index_cache")
-        if cached is None or cached.device != device:
-            cached = torch.tensor(self.output_tokens_indices, device=device)
-            self.__dict__["_out_index_cache"] = cached
-        return cached
+    def _select(self, tokens: Tensor, which: str) -> Tensor:
+        """tokens[:, indices]: a slice when the indices are one run (an index LIST would be uploaded from the host on every
+        call, which a graph capture cannot hold), else through a device-resident index tensor"""
+        idx = self.output_tokens_indices if which == "output" else self.cross_tokens_indices
+        if idx == list(range(idx[0], idx[0] + len(idx))):
+            return tokens[:, idx[0]:idx[0] + len(idx)]
+        cache = self.__dict__.setdefault("_index_cache", {})
+        cached = cache.get(which)
+        if cached is None or cached.device != tokens.device:
+            cached = cache[which] = torch.tensor(idx, device=tokens.device)
+        return tokens[:, cached]
 
     def _next_dropout_key(self, device) -> Optional[Tensor]:
         """{seed, call counter} for the attention-probability dropout of this forward pass, or None when nothing is
@@ -290,12 +378,26 @@ class ViT(nn.Module):
         x = self._add_time_token(x, time)
         key = self._next_dropout_key(x.device)
         x = self.positional_embed(x, key)
-        idx = self.output_tokens_indices
-        tokens = self.transformer(x, key, causal=self.causal_mask)
-        if idx == list(range(idx[0], idx[0] + len(idx))):  # one run of tokens: a slice (an index LIST would be uploaded from
-            out = tokens[:, idx[0]:idx[0] + len(idx)]      # the host on every call, which a graph capture cannot hold)
+        if self.prepocess is None:
+            out = self._select(self.transformer(x, key, causal=self.causal_mask), "output")
         else:
-            out = tokens[:, self._out_index(x.device)]
+            memory = self._select(x, "cross")
+            if not isinstance(self.prepocess, nn.Identity):
+                memory = self.prepocess(memory, key)
+            out = self.transformer(self._select(x, "output"), memory, key, causal=self.causal_mask)
         if not isinstance(self.embed_to_patch, nn.Identity):
             out = out[:, -self.num_patches:]
         return self.embed_to_patch(out)
+
+
+class AutoRegressive(ViT):
+    """``AutoRegressive(vocab_size, **vit_kwargs)`` (reference networks/vit.py:249-260): token ids -> vocabulary embedding -> the
+    ViT on the embedded tokens -> Linear head over the vocabulary (keys ``vocab_embed.weight``, ``head.{weight,bias}``)."""
+
+    def __init__(self, vocab_size: int, **vit_kwargs):
+        super().__init__(**vit_kwargs)
+        self.vocab_embed = nn.Embedding(vocab_size, self.dim)
+        self.head = TokenLinear(self.dim, vocab_size)
+
+    def forward(self, x: Tensor, labels: Optional[Tensor] = None, time: Optional[Tensor] = None) -> Tensor:
+        return self.head(super().forward(self.vocab_embed(x), labels, time))

@@ -639,6 +639,40 @@ def test_vit_vae_with_dropout_draws_fresh_masks_in_a_captured_step(A):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_cross_attention_vit_vae_trains_through_hip_trainer(A, dropout):
+    """A ViT VAE whose encoder and decoder are the cross-attention variant (``preprocess_depth``: nn.TransformerDecoder layers,
+    reference networks/vit.py:171-181) through the engine: the captured step equals the eagerly issued one bit for bit (dropout
+    0), the loss goes down, and with the reference's training dropout the replays draw fresh masks."""
+    vcfg = dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, dropout=dropout, emb_dropout=0.)
+    x = normal((64, 3, 16, 16), 61).cuda()
+    eps = normal((64, 1, 32), 62).cuda()
+
+    def run(graph, steps, lr=1e-3):
+        torch.manual_seed(3)
+        enc = A.ViT(n_embed_tokens=2, n_input_tokens=None, output_tokens="embed", patch_to_embed=True, embed_to_patch=False,
+                    preprocess_depth=1, **vcfg)
+        dec = A.ViT(n_embed_tokens=None, n_input_tokens=1, output_tokens="embed", patch_to_embed=False, embed_to_patch=True,
+                    preprocess_depth=0, **vcfg)
+        model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+        tr = A.HipTrainer(model, batch_shape=(64, 3, 16, 16), use_graph=graph, data_parallel=False, lr=lr)
+        losses = torch.stack([tr.step(x, eps).clone() for _ in range(steps)])
+        torch.cuda.synchronize()
+        out = tr.pflat.clone(), losses
+        tr.close()
+        return out
+
+    if dropout == 0.0:
+        pe, le = run(False, 6)
+        pg, lg = run(True, 6)
+        assert torch.equal(pe, pg) and torch.equal(le, lg)
+        assert torch.isfinite(le).all() and float(le[-1, 0]) < float(le[0, 0])
+    else:
+        _, losses = run(True, 5, lr=0.0)
+        rec = losses[:, 1]
+        assert torch.isfinite(rec).all() and len({float(v) for v in rec}) == 5, rec     # five replays, five masks
+
+
 def test_dp_overlap_two_phase_backward_equals_single_phase(A):
     """Data-parallel overlap path (backward cut at the encoder output, decoder gradients all-reduced under the encoder's
     backward, three captured graphs) rehearsed on ONE GPU with a 1-rank RCCL process group: parameters, moments and

@@ -1272,6 +1272,101 @@ def test_vit_with_causal_mask_vs_reference_golden(A, role):
     rep.finish()
 
 
+@pytest.mark.parametrize("tag", ["enc_p1", "dec_p0_causal"])
+def test_vit_cross_attention_variant_vs_reference_golden(A, tag):
+    """``ViT(preprocess_depth=...)`` (reference networks/vit.py:171-181,240-244): the output tokens are the target of
+    nn.TransformerDecoder layers (self-attention, cross-attention over the other tokens as memory -- pre-processed by encoder layers
+    or not -- feed-forward).  d32 configuration: 2 embed tokens over 17 memory tokens after one encoder layer; 16 patch tokens with the
+    causal mask over 2 memory tokens.  Output, input gradient and every parameter gradient against the reference class."""
+    from detfill import fill_vit_state_dict
+    from test_oracle_vs_golden import VIT_CASES, VIT_CROSS_CASES, VIT_ROLES, check_vit_grads, vit_param_shapes
+    g = load_golden("vit_cross.npz")
+    names = [str(n) for n in g[f"{tag}/param_names"]]
+    labels = torch.from_numpy(g["labels"]).cuda()
+    g = {k[len(tag) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "/") and not k.endswith("param_names")}
+    role, pre, causal = VIT_CROSS_CASES[tag]
+    cfg = VIT_CASES["d32"]
+    rep = Report(f"cross-attention ViT {tag} vs reference golden")
+    net = A.ViT(output_tokens="embed", dropout=0.0, emb_dropout=0., preprocess_depth=pre, causal_mask=causal, **cfg, **VIT_ROLES[role])
+    want = vit_param_shapes(cfg, role, preprocess_depth=pre)
+    sd = net.state_dict()
+    assert list(want) == names and set(sd.keys()) == set(names) and all(tuple(sd[k].shape) == tuple(s) for k, s in want.items())
+    ordered = {k: torch.zeros(s) for k, s in want.items()}          # the reference's key order decides the fill phases
+    fill_vit_state_dict(ordered)
+    net.load_state_dict(ordered)
+    net = net.cuda().train()
+    x = g["x"].cuda().requires_grad_(True)
+    y = net(x, labels=labels)
+    y.backward(g["gy"].cuda())
+    rep.check("output", y, g["y"], 1e-5)
+    rep.check("input gradient", x.grad, g["gx"], 1e-4)
+    rep.finish()
+    check_vit_grads(g, "", {k: p.grad for k, p in net.named_parameters()}, 5e-4, sep="")
+    assert tuple(net.out_size) == tuple(y.shape[1:])
+    # the same network trains through the captured engine: two steps, finite and moving
+    from ot_vae_lightning_amd.networks.vit import TokenDecoderLayer
+    assert any(isinstance(m, TokenDecoderLayer) for m in net.modules())
+
+
+def test_autoregressive_vit_vs_reference_golden(A):
+    """``AutoRegressive(vocab_size, **vit_kwargs)`` (reference networks/vit.py:249-260): 7 token ids -> vocabulary embedding -> causal
+    ViT over the input tokens (class-conditioned) -> logits; output and every parameter gradient against the reference class."""
+    from test_oracle_vs_golden import AR_CFG, AR_ROLE, autoregressive_state
+    g = load_golden("vit_autoregressive.npz")
+    rep = Report("AutoRegressive ViT vs reference golden")
+    net = A.AutoRegressive(vocab_size=13, output_tokens="input", causal_mask=True, dropout=0.0, emb_dropout=0., **AR_CFG, **AR_ROLE)
+    state = autoregressive_state(g)
+    sd = net.state_dict()
+    assert set(sd.keys()) == set(state.keys()) and all(tuple(sd[k].shape) == tuple(v.shape) for k, v in state.items())
+    net.load_state_dict(state)
+    net = net.cuda().train()
+    y = net(torch.from_numpy(g["ids"]).cuda(), labels=torch.from_numpy(g["labels"]).cuda())
+    y.backward(torch.from_numpy(g["gy"]).cuda())
+    rep.check("logits", y, torch.from_numpy(g["y"]), 1e-5)
+    for k, p in net.named_parameters():
+        rep.check("grad " + k, p.grad, torch.from_numpy(g[f"grad/{k}"]), 5e-4)
+    rep.finish()
+
+
+@pytest.mark.parametrize("n,tq,tk,heads,c,p", [(3, 2, 17, 4, 8, 0.0), (4, 16, 2, 4, 8, 0.0), (2, 40, 100, 2, 16, 0.2), (5, 7, 7, 1, 32, 0.5),
+                                                (2, 200, 31, 3, 4, 0.1), (3, 1, 1, 2, 2, 0.0)])
+def test_cross_attention_kernels_vs_float64(n, tq, tk, heads, c, p):
+    """``otvae_attn_cross_fwd/_bwd`` through ``functional.cross_attention_tokens``: nn.MultiheadAttention(x, memory, memory) up to
+    out_proj, queries and keys of different token counts, with and without dropout on the probabilities (the reference is
+    handed the kernel's own mask), against float64 torch arithmetic -- output and the gradients of x, memory, weight, bias."""
+    import ot_vae_lightning_amd.functional as HF
+    d = heads * c
+    rep = Report(f"cross attention N={n} Tq={tq} Tk={tk} H={heads} C={c} p={p}")
+    x = normal((n, tq, d), 810 + tq).cuda().requires_grad_(True)
+    mem = normal((n, tk, d), 811 + tk).cuda().requires_grad_(True)
+    w = HF.new_linear_weight(3 * d, d, device="cuda")
+    with torch.no_grad():
+        w.copy_(normal((3 * d, d), 812).cuda() / d ** 0.5)
+    w.requires_grad_(True)
+    b = (normal((3 * d,), 813).cuda() * 0.1).requires_grad_(True)
+    gout = normal((n, tq, d), 814).cuda()
+    key = HF.new_dropout_key(x.device, seed=77) if p > 0 else None
+    out = HF.cross_attention_tokens(x, mem, w, b, heads, p, key, stream_id=5)
+    gx, gm, gw, gb = torch.autograd.grad(out, (x, mem, w, b), gout)
+    keep = HF.attention_cross_mask(HF._CrossAttentionFn.last_used, n, tq, tk, heads, p).double() if p > 0 else 1.0
+    if p > 0:
+        frac = float(keep.mean())
+        assert abs(frac - (1 - p)) < 6 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-3, (frac, 1 - p)
+    xr, mr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, mem, w, b))
+    q = torch.nn.functional.linear(xr, wr[:d], br[:d]).reshape(n, tq, heads, c).transpose(1, 2)
+    k = torch.nn.functional.linear(mr, wr[d:2 * d], br[d:2 * d]).reshape(n, tk, heads, c).transpose(1, 2)
+    v = torch.nn.functional.linear(mr, wr[2 * d:], br[2 * d:]).reshape(n, tk, heads, c).transpose(1, 2)
+    prob = torch.softmax(q @ k.transpose(-1, -2) / c ** 0.5, dim=-1)
+    ref = ((prob * keep / (1 - p)) @ v).transpose(1, 2).reshape(n, tq, d)
+    rx, rm, rw, rb = torch.autograd.grad(ref, (xr, mr, wr, br), gout.double())
+    rep.check("out", out, ref.detach(), tol=2e-5)
+    rep.check("dx", gx, rx, tol=5e-5)
+    rep.check("dmemory", gm, rm, tol=5e-5)
+    rep.check("dweight", gw, rw, tol=5e-5)
+    rep.check("dbias", gb, rb, tol=5e-5)
+    rep.finish()
+
+
 # ------------------------------------------------------------------------------------------------ G13 conditional prior, ViT VAE
 def test_conditional_gaussian_prior_vs_reference_golden(A):
     """ConditionalGaussianPrior (reference prior/conditional_gaussian.py): learned class embeddings (z, loss with cosine

@@ -443,7 +443,25 @@ VIT_ROLES = {"enc": dict(n_embed_tokens=2, n_input_tokens=None, patch_to_embed=T
              "dec": dict(n_embed_tokens=None, n_input_tokens=1, patch_to_embed=False, embed_to_patch=True)}
 
 
-def vit_param_shapes(cfg, role):
+def _encoder_layer_shapes(pre, d, m):
+    return {pre + "self_attn.in_proj_weight": (3 * d, d), pre + "self_attn.in_proj_bias": (3 * d,),
+            pre + "self_attn.out_proj.weight": (d, d), pre + "self_attn.out_proj.bias": (d,),
+            pre + "linear1.weight": (m, d), pre + "linear1.bias": (m,), pre + "linear2.weight": (d, m),
+            pre + "linear2.bias": (d,), pre + "norm1.weight": (d,), pre + "norm1.bias": (d,),
+            pre + "norm2.weight": (d,), pre + "norm2.bias": (d,)}
+
+
+def _decoder_layer_shapes(pre, d, m):
+    return {pre + "self_attn.in_proj_weight": (3 * d, d), pre + "self_attn.in_proj_bias": (3 * d,),
+            pre + "self_attn.out_proj.weight": (d, d), pre + "self_attn.out_proj.bias": (d,),
+            pre + "multihead_attn.in_proj_weight": (3 * d, d), pre + "multihead_attn.in_proj_bias": (3 * d,),
+            pre + "multihead_attn.out_proj.weight": (d, d), pre + "multihead_attn.out_proj.bias": (d,),
+            pre + "linear1.weight": (m, d), pre + "linear1.bias": (m,), pre + "linear2.weight": (d, m),
+            pre + "linear2.bias": (d,), pre + "norm1.weight": (d,), pre + "norm1.bias": (d,),
+            pre + "norm2.weight": (d,), pre + "norm2.bias": (d,), pre + "norm3.weight": (d,), pre + "norm3.bias": (d,)}
+
+
+def vit_param_shapes(cfg, role, preprocess_depth=None):
     """state_dict key -> shape of the reference's ViT for this configuration (insertion order = the reference's)"""
     d, m, ps, c = cfg["dim"], cfg["mlp_dim"], cfg["patch_size"], cfg["channels"]
     npatch = (cfg["image_size"] // ps) ** 2
@@ -460,30 +478,112 @@ def vit_param_shapes(cfg, role):
         shapes["class_token.weight"] = (cfg["num_classes"], d)
     shapes.update({"positional_embed.position_embeddings.weight": (total, d), "positional_embed.LayerNorm.weight": (d,),
                    "positional_embed.LayerNorm.bias": (d,)})
-    for i in range(cfg["depth"]):
-        pre = f"transformer.layers.{i}."
-        shapes.update({pre + "self_attn.in_proj_weight": (3 * d, d), pre + "self_attn.in_proj_bias": (3 * d,),
-                       pre + "self_attn.out_proj.weight": (d, d), pre + "self_attn.out_proj.bias": (d,),
-                       pre + "linear1.weight": (m, d), pre + "linear1.bias": (m,), pre + "linear2.weight": (d, m),
-                       pre + "linear2.bias": (d,), pre + "norm1.weight": (d,), pre + "norm1.bias": (d,),
-                       pre + "norm2.weight": (d,), pre + "norm2.bias": (d,)})
+    if preprocess_depth is None:
+        for i in range(cfg["depth"]):
+            shapes.update(_encoder_layer_shapes(f"transformer.layers.{i}.", d, m))
+    else:  # the cross-attention variant: `prepocess` (sic) encoder layers, then decoder layers
+        for i in range(preprocess_depth):
+            shapes.update(_encoder_layer_shapes(f"prepocess.layers.{i}.", d, m))
+        for i in range(cfg["depth"]):
+            shapes.update(_decoder_layer_shapes(f"transformer.layers.{i}.", d, m))
     return shapes
 
 
-def check_vit_grads(g, prefix, grads, tol):
+def check_vit_grads(g, prefix, grads, tol, sep="/"):
     """full gradients where the fixture holds them, (sum, L2, first 16 entries) for the large matrices"""
     seen = 0
+    prefix = prefix + sep
     for k, gr in grads.items():
-        if f"{prefix}/grad/{k}" in g:
-            assert rel_err(gr, g[f"{prefix}/grad/{k}"]) < tol, k
+        if f"{prefix}grad/{k}" in g:
+            assert rel_err(gr, g[f"{prefix}grad/{k}"]) < tol, k
         else:
-            want = g[f"{prefix}/gradsum/{k}"].double()
+            want = g[f"{prefix}gradsum/{k}"].double()
             gd = gr.double().flatten().cpu()
             got = torch.cat([torch.stack([gd.sum(), gd.norm()]), gd[:16]])
             scale = float(want[1]) + 1e-30
             assert float((got - want).abs().max()) / scale < tol, (k, got[:3], want[:3])
         seen += 1
     assert seen == len(grads)
+
+
+VIT_CROSS_CASES = {"enc_p1": ("enc", 1, False), "dec_p0_causal": ("dec", 0, True)}
+
+
+@pytest.mark.parametrize("tag", list(VIT_CROSS_CASES))
+def test_vit_cross_attention_forward_backward(tag):
+    """The cross-attention ViT (``preprocess_depth``, reference networks/vit.py:171-181,240-244): decoder layers over the output
+    tokens with the other tokens as memory; key order and shapes are the reference's recorded ``param_names``."""
+    from detfill import fill_vit_state_dict
+    g = load_golden("vit_cross.npz")
+    names = [str(n) for n in g[f"{tag}/param_names"]]
+    labels = torch.from_numpy(g["labels"])
+    g = {k[len(tag) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "/") and not k.endswith("param_names")}
+    role, pre, causal = VIT_CROSS_CASES[tag]
+    cfg = VIT_CASES["d32"]
+    shapes = vit_param_shapes(cfg, role, preprocess_depth=pre)
+    assert list(shapes) == names
+    p = {k: torch.zeros(s) for k, s in shapes.items()}
+    fill_vit_state_dict(p)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    x = g["x"].clone().requires_grad_(True)
+    y = O.vit_forward(x, p, image_size=cfg["image_size"], patch_size=cfg["patch_size"], dim=cfg["dim"], depth=cfg["depth"],
+                      heads=cfg["heads"], channels=cfg["channels"], labels=labels, preprocess_depth=pre, causal_mask=causal,
+                      **VIT_ROLES[role])
+    y.backward(g["gy"])
+    assert rel_err(y, g["y"]) < 1e-5
+    assert rel_err(x.grad, g["gx"]) < 1e-4
+    # the self-attention q / k thirds of a decoder whose first target token sees only itself etc. are exercised by the causal case
+    check_vit_grads(g, "", {k: v.grad for k, v in p.items() if v.grad is not None}, 5e-4, sep="")
+
+
+AR_CFG = dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, num_classes=10)
+AR_ROLE = dict(n_input_tokens=7, n_embed_tokens=0, patch_to_embed=False, embed_to_patch=False)
+
+
+def autoregressive_state(g):
+    """the reference's recorded key order with the shapes of its AutoRegressive(vocab 13, AR_CFG), filled in that order"""
+    from detfill import fill_vit_state_dict
+    d, m, vocab = AR_CFG["dim"], AR_CFG["mlp_dim"], 13
+    shapes = {"class_token.weight": (10, d), "positional_embed.position_embeddings.weight": (8, d),
+              "positional_embed.LayerNorm.weight": (d,), "positional_embed.LayerNorm.bias": (d,)}
+    for i in range(AR_CFG["depth"]):
+        shapes.update(_encoder_layer_shapes(f"transformer.layers.{i}.", d, m))
+    shapes.update({"vocab_embed.weight": (vocab, d), "head.weight": (vocab, d), "head.bias": (vocab,)})
+    assert list(shapes) == [str(n) for n in g["param_names"]]
+    p = {k: torch.zeros(s) for k, s in shapes.items()}
+    fill_vit_state_dict(p)
+    return p
+
+
+def test_autoregressive_vit_forward_backward():
+    """``AutoRegressive`` (reference networks/vit.py:249-260): ids -> vocabulary embedding -> causal ViT over the input tokens -> head"""
+    g = load_golden("vit_autoregressive.npz")
+    p = {k: v.requires_grad_(True) for k, v in autoregressive_state(g).items()}
+    y = O.autoregressive_forward(torch.from_numpy(g["ids"]), p, image_size=16, patch_size=4, dim=32, depth=2, heads=4, channels=3,
+                                 labels=torch.from_numpy(g["labels"]), causal_mask=True, output_tokens="input", **AR_ROLE)
+    y.backward(torch.from_numpy(g["gy"]))
+    assert rel_err(y, torch.from_numpy(g["y"])) < 1e-5
+    for k, v in p.items():
+        assert rel_err(v.grad, torch.from_numpy(g[f"grad/{k}"])) < 5e-4, k
+
+
+@pytest.mark.parametrize("role", ["enc", "dec"])
+def test_vit_causal_mask_forward_backward(role):
+    """the d32 ViT with ``causal_mask=True`` (networks/vit.py:215-217,225) against ``vit_causal.npz``"""
+    from detfill import fill_vit_state_dict
+    g = {k: torch.from_numpy(v) for k, v in load_golden("vit_causal.npz").items()}
+    cfg = VIT_CASES["d32"]
+    p = {k: torch.zeros(s) for k, s in vit_param_shapes(cfg, role).items()}
+    fill_vit_state_dict(p)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    x = g[f"{role}/x"].clone().requires_grad_(True)
+    y = O.vit_forward(x, p, image_size=cfg["image_size"], patch_size=cfg["patch_size"], dim=cfg["dim"], depth=cfg["depth"],
+                      heads=cfg["heads"], channels=cfg["channels"], labels=g["labels"], causal_mask=True, **VIT_ROLES[role])
+    y.backward(g[f"{role}/gy"])
+    assert rel_err(y, g[f"{role}/y"]) < 1e-5
+    assert rel_err(x.grad, g[f"{role}/gx"]) < 1e-4
+    l2 = torch.tensor([v.grad.double().norm().item() for v in p.values() if v.grad is not None])
+    assert rel_err(l2, g[f"{role}/grad_l2"]) < 5e-4
 
 
 @pytest.mark.parametrize("tag", ["d32", "d128"])
