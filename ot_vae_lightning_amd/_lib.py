@@ -165,10 +165,18 @@ def check(rc: int, what: str) -> None:
     raise RuntimeError(msg)
 
 
+def _host_tensor(t):
+    raise RuntimeError(f"a {tuple(t.shape)} {t.dtype} tensor on {t.device} was about to be handed to an MI355X kernel: move the "
+                       "module / tensor to the GPU first (.cuda()); there is no CPU path")
+
+
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
+    """Device pointer of a tensor (None -> NULL).  A host tensor is refused here, at the last gate before a kernel: its address
+    would fault the GPU (and may take the node's other GPUs with it)."""
     if t is None:
         return None
+    if not t.is_cuda:
+        _host_tensor(t)
     return t.data_ptr()
 
 
@@ -176,7 +184,10 @@ def ptr_array(tensors):
     """Host array of device pointers for the `const float* const*` style arguments."""
     arr = (C.c_void_p * max(1, len(tensors)))()
     for i, t in enumerate(tensors):
-        arr[i] = None if t is None else t.data_ptr()
+        if t is not None:
+            if not t.is_cuda:
+                _host_tensor(t)
+            arr[i] = t.data_ptr()
     return arr
 
 

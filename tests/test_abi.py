@@ -109,3 +109,16 @@ def test_cpu_tensors_are_refused():
     layer = A.ConvLayer(2, 4, normalization="batchnorm", activation="relu")
     with pytest.raises(RuntimeError):
         layer(torch.zeros(1, 2, 4, 4))
+
+
+def test_host_pointers_never_reach_a_kernel():
+    """The last gate before every kernel call (``_lib.ptr`` / ``ptr_array``) refuses host tensors: a module left on the CPU whose
+    buffers meet GPU samples (``GaussianTransport(...)`` without ``.cuda()``) must raise, not fault the GPU."""
+    import torch
+    from ot_vae_lightning_amd import _lib
+    assert _lib.ptr(None) is None
+    with pytest.raises(RuntimeError, match="MI355X kernel"):
+        _lib.ptr(torch.zeros(3))
+    with pytest.raises(RuntimeError, match="MI355X kernel"):
+        _lib.ptr_array([None, torch.zeros(2, dtype=torch.float64)])
+    assert _lib.ptr_array([None, None])[0] is None

@@ -416,6 +416,13 @@ def test_error_behaviour(A):
     w = A.w2_gaussian(torch.zeros(200, device="cuda"), torch.ones(200, device="cuda"),
                       torch.eye(200, device="cuda"), torch.eye(200, device="cuda"))   # block-Jacobi path
     assert abs(float(w) - 200.0) < 1e-9
+    # a module left on the host meeting GPU samples: refused at the pointer gate, never a GPU fault
+    op = A.GaussianTransport(16, source_cfg=dict(dtype=torch.double), target_cfg=dict(dtype=torch.double))
+    with pytest.raises(RuntimeError, match="MI355X kernel"):
+        op.update(source_samples=torch.randn(32, 16, device="cuda"), target_samples=torch.randn(32, 16, device="cuda"))
+    conv = A.ConvLayer(4, 4, normalization="batchnorm", activation="relu")   # parameters on the host
+    with pytest.raises(RuntimeError):
+        conv(torch.zeros(2, 4, 8, 8, device="cuda"))
 
 
 @pytest.mark.parametrize("D", [128, 256])
