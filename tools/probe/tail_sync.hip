@@ -1,0 +1,166 @@
+// probe: what does a "last-arriver" reduction at the end of a producing kernel cost on gfx950, against the kernel boundary of a
+// separate finalize launch?  Chain of L dependent layers inside one hipGraph:
+//   unfused: producer (P blocks, one statistics partial each) -> finalize (C channels) -> producer -> ...
+//   fused:   producer + tail (agent-scope stores of the partial, ticket, last arriver reduces the P partials) -> producer (prologue
+//            turns the sums into a table) -> ...
+// hipcc --offload-arch=gfx950 -O3 tools/probe/tail_sync.hip -o tools/probe/tail_sync && tools/probe/tail_sync
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+constexpr int C = 32;
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// MODE 0: partial only; 1: + threadfence/ticket/last-arriver; 2: + agent-scope atomic stores (no fence)/ticket/last-arriver with agent loads
+template <int MODE>
+__global__ __launch_bounds__(256) void producer(const float4* __restrict__ in, float4* __restrict__ out, int per_block,
+                                                const float* __restrict__ table, const double* __restrict__ sums_in, double* partial,
+                                                int P, unsigned* ticket, double* sums_out) {
+    __shared__ float tab[2 * C];
+    __shared__ double red[4][2][C];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (sums_in) {  // fused consumer prologue: finalize per channel
+        if (tid < C) {
+            const double mu = sums_in[tid] / 1e6, var = sums_in[C + tid] / 1e6 - mu * mu;
+            const float is = (float)(1.0 / sqrt(fabs(var) + 1e-5));
+            tab[tid] = is;
+            tab[C + tid] = (float)(-mu) * is;
+        }
+    } else if (tid < 2 * C) tab[tid] = table[tid];
+    __syncthreads();
+    double s = 0.0, q = 0.0;
+    const int c4 = (tid * 4) % C;
+    for (int i = 0; i < per_block; ++i) {
+        const size_t e = ((size_t)blockIdx.x * per_block + i) * 256 + tid;
+        float4 v = in[e];
+        v.x = fmaf(v.x, tab[c4], tab[C + c4]) * 0.5f;
+        v.y = fmaf(v.y, tab[c4 + 1], tab[C + c4 + 1]) * 0.5f;
+        v.z = fmaf(v.z, tab[c4 + 2], tab[C + c4 + 2]) * 0.5f;
+        v.w = fmaf(v.w, tab[c4 + 3], tab[C + c4 + 3]) * 0.5f;
+        out[e] = v;
+        s += (double)v.x + (double)v.y;
+        q += (double)v.x * v.x + (double)v.w;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane < C) {
+        red[wave][0][lane] = s + lane;
+        red[wave][1][lane] = q + lane;
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+        const int which = tid / C, c = tid % C;
+        const double t = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        double* dst = partial + ((size_t)which * C + c) * P + blockIdx.x;
+        if (MODE == 2) __hip_atomic_store(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = t;
+    }
+    if (MODE == 0) return;
+    if (MODE == 1) __threadfence();
+    else __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t + 1 == (unsigned)P);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (MODE == 1) __threadfence();
+    for (int i = wave; i < 2 * C; i += 4) {
+        const double* ps = partial + (size_t)i * P;
+        double a = 0.0;
+        for (int p = lane; p < P; p += 64)
+            a += MODE == 2 ? __hip_atomic_load(ps + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ps[p];
+        a = wave_sum(a);
+        if (lane == 0) sums_out[i] = a;
+    }
+    if (tid == 0) *ticket = 0;
+}
+
+__global__ __launch_bounds__(256) void finalize(const double* __restrict__ partial, int P, float* __restrict__ table) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int p = lane; p < P; p += 64) {
+        s += partial[(size_t)c * P + p];
+        q += partial[((size_t)C + c) * P + p];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) {
+        const double mu = s / 1e6, var = q / 1e6 - mu * mu;
+        const float is = (float)(1.0 / sqrt(fabs(var) + 1e-5));
+        table[c] = is;
+        table[C + c] = (float)(-mu) * is;
+    }
+}
+
+int main() {
+    const int L = 40;
+    for (int P : {64, 256, 1024}) {
+        for (int per_block : {1, 4, 16}) {
+            const size_t n4 = (size_t)P * per_block * 256;
+            float4 *a, *b;
+            float* table;
+            double *partial, *sums;
+            unsigned* ticket;
+            CK(hipMalloc(&a, n4 * 16));
+            CK(hipMalloc(&b, n4 * 16));
+            CK(hipMalloc(&table, 2 * C * 4));
+            CK(hipMalloc(&partial, (size_t)2 * C * P * 8));
+            CK(hipMalloc(&sums, 2 * C * 8));
+            CK(hipMalloc(&ticket, 4));
+            CK(hipMemset(a, 0, n4 * 16));
+            CK(hipMemset(table, 0, 2 * C * 4));
+            CK(hipMemset(sums, 0, 2 * C * 8));
+            CK(hipMemset(ticket, 0, 4));
+            hipStream_t st;
+            CK(hipStreamCreate(&st));
+            double res[4];
+            for (int variant = 0; variant < 4; ++variant) {  // 0 unfused, 1 fused fence, 2 fused agent atomics, 3 producers only
+                hipGraph_t g;
+                hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                for (int l = 0; l < L; ++l) {
+                    float4 *src = l & 1 ? b : a, *dst = l & 1 ? a : b;
+                    if (variant == 0) {
+                        producer<0><<<P, 256, 0, st>>>(src, dst, per_block, table, nullptr, partial, P, ticket, sums);
+                        finalize<<<C / 4, 256, 0, st>>>(partial, P, table);
+                    } else if (variant == 1)
+                        producer<1><<<P, 256, 0, st>>>(src, dst, per_block, table, sums, partial, P, ticket, sums);
+                    else if (variant == 2)
+                        producer<2><<<P, 256, 0, st>>>(src, dst, per_block, table, sums, partial, P, ticket, sums);
+                    else
+                        producer<0><<<P, 256, 0, st>>>(src, dst, per_block, table, nullptr, partial, P, ticket, sums);
+                }
+                CK(hipStreamEndCapture(st, &g));
+                CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0));
+                CK(hipEventCreate(&e1));
+                for (int w = 0; w < 3; ++w) CK(hipGraphLaunch(ge, st));
+                CK(hipEventRecord(e0, st));
+                for (int w = 0; w < 10; ++w) CK(hipGraphLaunch(ge, st));
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                res[variant] = ms * 1e3 / (10 * L);
+                CK(hipGraphExecDestroy(ge));
+                CK(hipGraphDestroy(g));
+            }
+            unsigned tk;
+            CK(hipMemcpy(&tk, ticket, 4, hipMemcpyDeviceToHost));
+            printf("P=%4d blocks x %2d KB each: per layer  unfused %6.2f us | fused(fence) %6.2f | fused(agent atomics) %6.2f | producer alone %6.2f   (ticket %u)\n",
+                   P, per_block * 4, res[0], res[1], res[2], res[3], tk);
+            hipFree(a); hipFree(b); hipFree(table); hipFree(partial); hipFree(sums); hipFree(ticket);
+        }
+    }
+    return 0;
+}
