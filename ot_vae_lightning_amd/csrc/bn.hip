@@ -83,6 +83,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = WPC == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     const int sub = WPC == 4 ? wave : 0;
+    const bool writer = c < C && lane == 0 && sub == 0;
+    // what the writing lane needs besides the sums is requested first: these loads fly together with the partials' instead of
+    // forming a second, dependent round trip behind the reduction (the kernel is nothing but memory latency)
+    float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f}, rm[2] = {0.f, 0.f}, rv[2] = {0.f, 0.f};
+    if (writer)
+        for (int b = 0; b < n_bn; ++b) {
+            gam[b] = f.gamma[b][c];
+            bet[b] = f.beta[b][c];
+            if (f.rmean[b]) rm[b] = f.rmean[b][c];
+            if (f.rvar[b]) rv[b] = f.rvar[b][c];
+        }
     double s = 0.0, q = 0.0;
     if (c < C) {
         const double* ps = partial + ((size_t)0 * ld + c) * P;  // [2][ld][P]: lanes read consecutive p
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
         s = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         q = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
-    if (c < C && lane == 0 && sub == 0) {
+    if (writer) {
         const double mu = s / (double)M;
         double var = q / (double)M - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -113,11 +124,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
         invstd[c] = fis;
         const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
         for (int b = 0; b < n_bn; ++b) {
-            const float sc = f.gamma[b][c] * fis;
+            const float sc = gam[b] * fis;
             f.scale[b][c] = sc;
-            f.shift[b][c] = fmaf(-fmu, sc, f.beta[b][c]);
-            if (f.rmean[b]) f.rmean[b][c] = (1.f - momentum) * f.rmean[b][c] + momentum * fmu;
-            if (f.rvar[b]) f.rvar[b][c] = (1.f - momentum) * f.rvar[b][c] + momentum * (float)unbiased;
+            f.shift[b][c] = fmaf(-fmu, sc, bet[b]);
+            if (f.rmean[b]) f.rmean[b][c] = (1.f - momentum) * rm[b] + momentum * fmu;
+            if (f.rvar[b]) f.rvar[b][c] = (1.f - momentum) * rv[b] + momentum * (float)unbiased;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -173,6 +184,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int nb, BnBwdFin f
     const int c = WPC == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     const int sub = WPC == 4 ? wave : 0;
     const bool in = c < C;
+    const bool writer = in && lane == 0 && sub == 0;
+    // the writing lane's per-channel operands are requested before the reduction (one memory round trip instead of two)
+    double is = 0.0, mu = 0.0, gam[2] = {0.0, 0.0};
+    if (writer) {
+        is = (double)invstd[c];
+        mu = (double)mean[c];
+        for (int b = 0; b < nb; ++b) gam[b] = (double)f.gamma[b][c];
+    }
     double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
     for (int b = 0; b < nb; ++b) {
         if (in) {
@@ -199,11 +218,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int nb, BnBwdFin f
             s2[b] = (red[b][0][1] + red[b][1][1]) + (red[b][2][1] + red[b][3][1]);
         }
     }
-    if (!in || lane != 0 || sub != 0) return;
-    const double is = (double)invstd[c], mu = (double)mean[c];
+    if (!writer) return;
     double A = 0.0, B = 0.0;
     for (int b = 0; b < nb; ++b) {
-        const double k = (double)f.gamma[b][c] * is;
+        const double k = gam[b] * is;
         if (f.dbeta[b]) f.dbeta[b][c] = (float)s1[b];
         if (f.dgamma[b]) f.dgamma[b][c] = (float)s2[b];
         coef[(size_t)(2 + b) * C + c] = (float)k;

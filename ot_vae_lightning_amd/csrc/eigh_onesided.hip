@@ -411,24 +411,28 @@ int eigh_onesided(const double* A, int nb, int D, int fn, double* out, double* e
 struct HjbCtl {
     int done, rotated, sweeps;
     int chol_info;  // 0: the iteration runs on the Cholesky factor; else on A itself (written by otvae_cholesky before the init kernel)
+    int log_stamp[2];  // id of the launch whose column rotations fill rotation log 0 / 1 (-1: none)
 };
+#define HJB_VSLABS 2  // row slabs the eigenvector update of a block pair is split over (when the launch still fits the chip)
 
 static __host__ __device__ inline int hjb_dp(int D) { return (D + 2 * HJB_B - 1) / (2 * HJB_B) * (2 * HJB_B); }
 
 extern "C" int64_t otvae_eigh_block_onesided_ws(int nb, int D) {
     if (nb <= 0 || D <= 0) return -1;
     const int64_t Dp = hjb_dp(D);
-    // G[Dp][D], V[Dp][D] (column-major: a column is contiguous), lam[Dp], sign dots [Dp], T[D][D] for f(A), ctl
-    return (int64_t)nb * ((2 * Dp * (int64_t)D + 2 * Dp + (int64_t)D * D) * 8 + 256);
+    // G[Dp][D], V[Dp][D] (column-major: a column is contiguous), lam[Dp], sign dots [Dp], T[D][D] for f(A), two rotation logs
+    // (one (c, s) pair per column pair and step of a round: Dp * HJB_B of them), ctl
+    return (int64_t)nb * ((2 * Dp * (int64_t)D + 2 * Dp + (int64_t)D * D) * 8 + 2 * Dp * HJB_B * 16 + 256);
 }
 
 struct HjbWs {
     double *G, *V, *nrm, *dot, *T;
+    double2* log;  // [2][pairs = Dp / (2 HJB_B)][2 HJB_B steps][HJB_B pair slots]
     HjbCtl* ctl;
 };
 __host__ __device__ static inline HjbWs hjb_ws(void* ws, int b, int D) {
     const size_t Dp = (size_t)hjb_dp(D);
-    const size_t per = (2 * Dp * D + 2 * Dp + (size_t)D * D) * 8 + 256;
+    const size_t per = (2 * Dp * D + 2 * Dp + (size_t)D * D) * 8 + 2 * Dp * HJB_B * 16 + 256;
     char* w = (char*)ws + (size_t)b * per;
     HjbWs r;
     r.G = (double*)w;
@@ -436,7 +440,8 @@ __host__ __device__ static inline HjbWs hjb_ws(void* ws, int b, int D) {
     r.nrm = r.V + Dp * D;
     r.dot = r.nrm + Dp;
     r.T = r.dot + Dp;
-    r.ctl = (HjbCtl*)(r.T + (size_t)D * D);
+    r.log = (double2*)(r.T + (size_t)D * D);
+    r.ctl = (HjbCtl*)(r.log + 2 * Dp * HJB_B);
     return r;
 }
 
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(256) void hjb_init_kernel(const double* __restrict_
         w.ctl->done = 0;
         w.ctl->rotated = 0;
         w.ctl->sweeps = 0;
+        w.ctl->log_stamp[0] = w.ctl->log_stamp[1] = -1;
     }
 }
 
@@ -476,36 +482,78 @@ __device__ __forceinline__ void hjb_pair(int round, int k, int nblk, int& I, int
     }
 }
 
+// One launch = the column rotations of round `launch % nrounds` (blocks 0 .. pairs-1, one block pair each) AND the eigenvector update
+// of the PREVIOUS launch's round (blocks pairs .., HJB_VSLABS row slabs per block pair): the update only replays logged rotations
+// on the rows of V, so it neither feeds the next round's rotations nor needs whole columns -- it runs beside them on otherwise idle
+// CUs instead of behind them in the same workgroup (70 -> 45 us per round at D = 1024).  The log is double-buffered in the
+// workspace and stamped with the launch that filled it: a rotation role that found the solver converged leaves no stamp, and the
+// update role of the next launch has nothing to replay.
 template <int R>  // rows per lane: D <= 64 R
-__global__ __launch_bounds__(512) void hjb_round_kernel(int D, int round, void* __restrict__ ws) {
+__global__ __launch_bounds__(512) void hjb_round_kernel(int D, int launch, int nrounds, int rotate, int vslabs, void* __restrict__ ws) {
     extern __shared__ __align__(16) double hj_lds[];
     __shared__ double2 s_log[2 * HJB_B][HJB_B];
+    __shared__ double s_nrm[2 * HJB_B];  // squared norms of the columns in the even positions (the kept columns' live in registers)
     __shared__ int s_rot;
     const HjbWs w = hjb_ws(ws, blockIdx.y, D);
-    if (w.ctl->done) return;
     constexpr int NP = 2 * HJB_B;  // positions
-    const int LD = D + 1;
-    const int nblk = hjb_dp(D) / HJB_B;
+    const int nblk = hjb_dp(D) / HJB_B, npairs = nblk / 2;
+    const bool vrole = (int)blockIdx.x >= npairs;
+    int pair_idx, row0, nrows, my_launch;
+    if (!vrole) {
+        if (!rotate || w.ctl->done) return;
+        pair_idx = blockIdx.x;
+        row0 = 0;
+        nrows = D;
+        my_launch = launch;
+    } else {
+        my_launch = launch - 1;
+        if (my_launch < 0 || w.ctl->log_stamp[my_launch & 1] != my_launch) return;
+        const int v = blockIdx.x - npairs;
+        pair_idx = v / vslabs;
+        const int per = ((D + vslabs - 1) / vslabs + 63) / 64 * 64;  // rows per slab, whole lanes
+        row0 = (v % vslabs) * per;
+        nrows = min(per, D - row0);
+        if (nrows <= 0) return;
+    }
+    const int LD = nrows + 1;
     int I, J;
-    hjb_pair(round, blockIdx.x, nblk, I, J);
+    hjb_pair(my_launch % nrounds, pair_idx, nblk, I, J);
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;  // wave g = pair slot g
     const int kpos = 2 * g + 1;
     auto home = [&](int pos) { return pos < HJB_B ? I * HJB_B + pos : J * HJB_B + (pos - HJB_B); };
-    double* P = hj_lds;  // P[pos * LD + row]
+    double* P = hj_lds;  // P[pos * LD + row - row0]
+    double2* glog = w.log + ((size_t)(my_launch & 1) * npairs + pair_idx) * NP * HJB_B;
     if (tid == 0) s_rot = 0;
+    if (vrole)
+        for (int e = tid; e < NP * HJB_B; e += 512) s_log[e / HJB_B][e % HJB_B] = glog[e];
 
     auto sweep16 = [&](double* __restrict__ M, bool replay) {
         // load the 16 columns (a wave per column, two columns each)
         for (int pos = g; pos < NP; pos += 8) {
-            const double* src = M + (size_t)home(pos) * D;
-            for (int i = lane; i < D; i += 64) P[pos * LD + i] = src[i];
+            const double* src = M + (size_t)home(pos) * D + row0;
+            for (int i = lane; i < nrows; i += 64) P[pos * LD + i] = src[i];
         }
         __syncthreads();
         double keep[R];
+        double nk = 0.0;  // |kept column|^2, tracked through the round: a step then needs ONE dot product (the pair's) instead of three
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const int i = lane + 64 * u;
-            keep[u] = i < D ? P[kpos * LD + i] : 0.0;
+            keep[u] = i < nrows ? P[kpos * LD + i] : 0.0;
+        }
+        if (!replay) {
+            double ne = 0.0;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int i = lane + 64 * u;
+                const double e = i < nrows ? P[(kpos - 1) * LD + i] : 0.0;
+                nk = fma(keep[u], keep[u], nk);
+                ne = fma(e, e, ne);
+            }
+            nk = wave_allsum_dpp(nk);
+            ne = wave_allsum_dpp(ne);
+            if (lane == 0) s_nrm[kpos - 1] = ne;
+            __syncthreads();
         }
         auto step = [&](auto odd_tag, int t) {
             constexpr bool ODD = decltype(odd_tag)::value;
@@ -516,26 +564,37 @@ __global__ __launch_bounds__(512) void hjb_round_kernel(int D, int round, void* 
 #pragma unroll
                 for (int u = 0; u < R; ++u) {
                     const int i = lane + 64 * u;
-                    other[u] = i < D ? go[i] : 0.0;
+                    other[u] = i < nrows ? go[i] : 0.0;
                 }
                 double c = 1.0, s = 0.0;
                 if (replay) {
                     const double2 cs = s_log[t][g];
                     c = cs.x;
                     s = cs.y;
-                } else {
-                    double kk = 0.0, oo = 0.0, gamma = 0.0;
 #pragma unroll
                     for (int u = 0; u < R; ++u) {
-                        kk = fma(keep[u], keep[u], kk);
-                        oo = fma(other[u], other[u], oo);
-                        gamma = fma(keep[u], other[u], gamma);
+                        const int i = lane + 64 * u;
+                        double pub;
+                        if (ODD) {
+                            pub = c * keep[u] - s * other[u];
+                            keep[u] = s * keep[u] + c * other[u];
+                        } else {
+                            pub = s * other[u] + c * keep[u];
+                            keep[u] = c * other[u] - s * keep[u];
+                        }
+                        if (i < nrows) go[i] = pub;
                     }
-                    kk = wave_allsum_dpp(kk);
-                    oo = wave_allsum_dpp(oo);
+                } else {
+                    double gamma = 0.0;
+#pragma unroll
+                    for (int u = 0; u < R; ++u) gamma = fma(keep[u], other[u], gamma);
                     gamma = wave_allsum_dpp(gamma);
-                    const double alpha = ODD ? kk : oo, beta = ODD ? oo : kk;
+                    const double no = s_nrm[opos];
+                    // the pair is (a, b) = (keep, other) in an odd step, (other, keep) in an even one; it becomes
+                    // (c a - s b, s a + c b) with squared norms alpha - t gamma and beta + t gamma
+                    const double alpha = ODD ? nk : no, beta = ODD ? no : nk;
                     const double ab = alpha * beta;
+                    double tg = 0.0;
                     if (gamma * gamma > HJ_TOL2 * ab && ab > 1e-280) {
                         const double zeta = (beta - alpha) * 0.5 * nr_rcp(gamma);
                         const double az = fabs(zeta);
@@ -549,23 +608,40 @@ __global__ __launch_bounds__(512) void hjb_round_kernel(int D, int round, void* 
                         }
                         c = nr_rsq(fma(tt, tt, 1.0));
                         s = c * tt;
+                        tg = tt * gamma;
                         if (lane == 0 && gamma * gamma > HJ_STOP2 * ab) s_rot = 1;
                     }
                     if (lane == 0) s_log[t][g] = make_double2(c, s);
-                }
+                    // tracked norms of the two new columns; the shrinking one (alpha - t gamma) is recomputed below when the
+                    // subtraction cancelled more than two digits (rank-deficient input: a column on its way to zero)
+                    const double n_x = alpha - tg, n_y = beta + tg;
+                    const bool recount = !(n_x > 0.01 * alpha) && tg != 0.0;
+                    double n_pub = ODD ? n_x : n_y;
+                    nk = ODD ? n_y : n_x;
+                    double acc2 = 0.0;
 #pragma unroll
-                for (int u = 0; u < R; ++u) {
-                    const int i = lane + 64 * u;
-                    double pub;
-                    if (ODD) {
-                        pub = c * keep[u] - s * other[u];
-                        keep[u] = s * keep[u] + c * other[u];
-                    } else {
-                        pub = s * other[u] + c * keep[u];
-                        keep[u] = c * other[u] - s * keep[u];
+                    for (int u = 0; u < R; ++u) {
+                        const int i = lane + 64 * u;
+                        double pub;
+                        if (ODD) {
+                            pub = c * keep[u] - s * other[u];
+                            keep[u] = s * keep[u] + c * other[u];
+                        } else {
+                            pub = s * other[u] + c * keep[u];
+                            keep[u] = c * other[u] - s * keep[u];
+                        }
+                        if (i < nrows) go[i] = pub;
+                        if (recount) acc2 = ODD ? fma(pub, pub, acc2) : fma(keep[u], keep[u], acc2);
                     }
-                    if (i < D) go[i] = pub;
+                    if (recount) {  // wave-uniform
+                        acc2 = wave_allsum_dpp(acc2);
+                        if (ODD) n_pub = acc2;
+                        else nk = acc2;
+                    }
+                    if (lane == 0) s_nrm[opos] = n_pub;
                 }
+            } else if (!replay && lane == 0) {
+                s_log[t][g] = make_double2(1.0, 0.0);  // the idle slot of an odd step: its log entry is never read, but it is copied
             }
             __syncthreads();
         };
@@ -575,22 +651,29 @@ __global__ __launch_bounds__(512) void hjb_round_kernel(int D, int round, void* 
         }
         // 16 steps reversed the order: position p holds what started at 15 - p and goes back there
         {
-            double* dst = M + (size_t)home(NP - 1 - kpos) * D;
+            double* dst = M + (size_t)home(NP - 1 - kpos) * D + row0;
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const int i = lane + 64 * u;
-                if (i < D) dst[i] = keep[u];
+                if (i < nrows) dst[i] = keep[u];
             }
         }
         for (int pos = 2 * g; pos < NP; pos += 16) {  // the even positions: wave g writes position 2g
-            double* dst = M + (size_t)home(NP - 1 - pos) * D;
-            for (int i = lane; i < D; i += 64) dst[i] = P[pos * LD + i];
+            double* dst = M + (size_t)home(NP - 1 - pos) * D + row0;
+            for (int i = lane; i < nrows; i += 64) dst[i] = P[pos * LD + i];
         }
         __syncthreads();
     };
+    if (vrole) {
+        sweep16(w.V, true);
+        return;
+    }
     sweep16(w.G, false);
-    sweep16(w.V, true);
-    if (tid == 0 && s_rot) w.ctl->rotated = 1;  // benign race: every writer stores 1
+    for (int e = tid; e < NP * HJB_B; e += 512) glog[e] = s_log[e / HJB_B][e % HJB_B];
+    if (tid == 0) {
+        if (s_rot) w.ctl->rotated = 1;  // benign race: every writer stores 1
+        if (blockIdx.x == 0) w.ctl->log_stamp[launch & 1] = launch;
+    }
 }
 
 __global__ void hjb_check_kernel(int D, void* __restrict__ ws) {
@@ -654,24 +737,8 @@ __global__ __launch_bounds__(256) void hjb_finish_kernel(int D, int fn, void* __
     }
 }
 
-// out[i][j] = sum_k V[k][i] T[k][j]
-__global__ __launch_bounds__(256) void hjb_product_kernel(int D, void* __restrict__ ws, double* __restrict__ out) {
-    __shared__ double as[16][17], bs[16][17];
-    const HjbWs w = hjb_ws(ws, blockIdx.z, D);
-    double* ob = out + (size_t)blockIdx.z * D * D;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
-    double acc = 0.0;
-    for (int k0 = 0; k0 < D; k0 += 16) {
-        as[ty][tx] = (blockIdx.y * 16 + tx < D && k0 + ty < D) ? w.V[(size_t)(k0 + ty) * D + blockIdx.y * 16 + tx] : 0.0;  // as[k][i]
-        bs[ty][tx] = (k0 + ty < D && j < D) ? w.T[(size_t)(k0 + ty) * D + j] : 0.0;                                      // bs[k][j]
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) acc = fma(as[kk][ty], bs[kk][tx], acc);
-        __syncthreads();
-    }
-    if (i < D && j < D) ob[(size_t)i * D + j] = acc;
-}
+void gemm_f64_launch(int transA, int transB, int nb, int m, int n, int k, double alpha, const double* A, size_t sA, const double* B,
+                     size_t sB, double beta, double* C, hipStream_t st);  // gaussian_ot.hip
 
 static bool g_hjb_lds_set[2] = {false, false};
 
@@ -694,19 +761,30 @@ int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, dou
         if (rc) return rc;
     }
     hjb_init_kernel<<<dim3(imin(cdiv((size_t)Dp * D, 256), 1024), nb), 256, 0, st>>>(A, D, ws);
+    const int nrounds = nblk - 1;
+    // one workgroup per CU at these LDS sizes: split the eigenvector update over row slabs only while every block of a launch is
+    // still resident at once (two matrices of D = 1024 side by side are 128 rotation + 128 update blocks already)
+    const int vslabs = (nblk / 2 * (1 + HJB_VSLABS) * nb <= 256) ? HJB_VSLABS : 1;
+    const dim3 grid(nblk / 2 * (1 + vslabs), nb);  // rotation blocks, then the eigenvector-update blocks of the launch before
+    auto round_launch = [&](int launch, int rotate) {
+        if (big)
+            hjb_round_kernel<16><<<grid, 512, lds, st>>>(D, launch, nrounds, rotate, vslabs, ws);
+        else
+            hjb_round_kernel<8><<<grid, 512, lds, st>>>(D, launch, nrounds, rotate, vslabs, ws);
+    };
     for (int sweep = 0; sweep < HJB_MAX_SWEEPS; ++sweep) {
-        for (int round = 0; round < nblk - 1; ++round) {
-            if (big)
-                hjb_round_kernel<16><<<dim3(nblk / 2, nb), 512, lds, st>>>(D, round, ws);
-            else
-                hjb_round_kernel<8><<<dim3(nblk / 2, nb), 512, lds, st>>>(D, round, ws);
-        }
+        for (int round = 0; round < nrounds; ++round) round_launch(sweep * nrounds + round, 1);
         hjb_check_kernel<<<nb, 64, 0, st>>>(D, ws);
     }
+    round_launch(HJB_MAX_SWEEPS * nrounds, 0);  // the eigenvector update of the very last round, if the sweep limit was reached
     OTVAE_CHECK_LAUNCH("otvae_eigh_fn(block rounds)");
     hjb_norms_kernel<<<dim3(cdiv(D, 4), nb), 256, 0, st>>>(D, ws);
     hjb_finish_kernel<<<dim3(imin(cdiv((size_t)D * D, 2048), 256), nb), 256, 0, st>>>(D, fn, ws, eigvals, out);
-    if (fn == 1 || fn == 2) hjb_product_kernel<<<dim3(cdiv(D, 16), cdiv(D, 16), nb), 256, 0, st>>>(D, ws, out);
+    if (fn == 1 || fn == 2)  // out = V^T T (V holds one eigenvector per row): the fp64 matrix-core product of gaussian_ot.hip
+        for (int b = 0; b < nb; ++b) {
+            const HjbWs w = hjb_ws(ws, b, D);
+            gemm_f64_launch(1, 0, 1, D, D, D, 1.0, w.V, 0, w.T, 0, 0.0, out + (size_t)b * D * D, st);
+        }
     OTVAE_CHECK_LAUNCH("otvae_eigh_fn(block finish)");
     return OTVAE_OK;
 }

@@ -730,12 +730,84 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int transA, int transB, i
     }
 }
 
+// The same product on the fp64 matrix cores for the large operands (D = 1024 latent transport: the products around the
+// eigendecompositions were 2-4 ms each on the kernel above).  64 x 64 output tile per workgroup, 4 waves x (16 rows x 64 columns) =
+// 4 v_mfma_f64_16x16x4_f64 accumulators per wave, K in chunks of 16 through LDS (k-major for both operands, so that lane
+// (i | j = l % 16, k = l / 16) reads its A / B element with one ds_read_b64).  Accumulator layout (probed on gfx950,
+// tools/probe/mfma_f64.hip): register r of lane l holds D[4 r + l / 16][l % 16].
+typedef double double4v __attribute__((ext_vector_type(4)));
+#define GM_T 64
+#define GM_KC 16
+#define GM_LD (GM_T + 4)
+
+__global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(int transA, int transB, int m, int n, int k, double alpha,
+                                                            const double* __restrict__ A, size_t sA, const double* __restrict__ B,
+                                                            size_t sB, double beta, double* __restrict__ Cm) {
+    __shared__ double as[GM_KC][GM_LD], bs[GM_KC][GM_LD];
+    const int b = blockIdx.z;
+    const double* Ab = A + (size_t)b * sA;
+    const double* Bb = B + (size_t)b * sB;
+    double* Cb = Cm + (size_t)b * m * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_T;
+    const int l16 = lane & 15, lk = lane >> 4;
+    double4v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = double4v{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < k; k0 += GM_KC) {
+        // stage: each operand along its contiguous direction
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (transA) {  // stored [k][m]
+                const int kk = (tid >> 6) + 4 * u, i = tid & 63;
+                as[kk][i] = (k0 + kk < k && i0 + i < m) ? Ab[(size_t)(k0 + kk) * m + i0 + i] : 0.0;
+            } else {       // stored [m][k]
+                const int i = (tid >> 4) + 16 * u, kk = tid & 15;
+                as[kk][i] = (k0 + kk < k && i0 + i < m) ? Ab[(size_t)(i0 + i) * k + k0 + kk] : 0.0;
+            }
+            if (transB) {  // stored [n][k]
+                const int j = (tid >> 4) + 16 * u, kk = tid & 15;
+                bs[kk][j] = (k0 + kk < k && j0 + j < n) ? Bb[(size_t)(j0 + j) * k + k0 + kk] : 0.0;
+            } else {       // stored [k][n]
+                const int kk = (tid >> 6) + 4 * u, j = tid & 63;
+                bs[kk][j] = (k0 + kk < k && j0 + j < n) ? Bb[(size_t)(k0 + kk) * n + j0 + j] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GM_KC / 4; ++ks) {
+            const double av = as[ks * 4 + lk][wave * 16 + l16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bs[ks * 4 + lk][t * 16 + l16], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wave * 16 + 4 * r + lk, j = j0 + t * 16 + l16;
+            if (i < m && j < n) {
+                const size_t o = (size_t)i * n + j;
+                Cb[o] = alpha * acc[t][r] + (beta != 0.0 ? beta * Cb[o] : 0.0);
+            }
+        }
+}
+
+void gemm_f64_launch(int transA, int transB, int nb, int m, int n, int k, double alpha, const double* A, size_t sA, const double* B,
+                     size_t sB, double beta, double* C, hipStream_t st) {
+    if (imax(m, n) >= 256 && k >= 64) {  // enough tiles to matter: the matrix cores
+        gemm_f64_mfma_kernel<<<dim3(cdiv(n, GM_T), cdiv(m, GM_T), nb), 256, 0, st>>>(transA, transB, m, n, k, alpha, A, sA, B, sB, beta, C);
+    } else {
+        gemm_f64_kernel<<<dim3(cdiv(n, 16), cdiv(m, 16), nb), 256, 0, st>>>(transA, transB, m, n, k, alpha, A, sA, B, sB, beta, C);
+    }
+}
+
 extern "C" int otvae_gemm_f64(int transA, int transB, int nb, int m, int n, int k, double alpha, const double* A, int a_bcast,
                               const double* B, int b_bcast, double beta, double* C, void* stream) {
     OTVAE_REQUIRE(A && B && C && nb > 0 && m > 0 && n > 0 && k > 0, "otvae_gemm_f64: bad argument");
-    dim3 grid(cdiv(n, 16), cdiv(m, 16), nb);
-    gemm_f64_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(transA, transB, m, n, k, alpha, A, a_bcast ? 0 : (size_t)m * k, B,
-                                                          b_bcast ? 0 : (size_t)k * n, beta, C);
+    gemm_f64_launch(transA, transB, nb, m, n, k, alpha, A, a_bcast ? 0 : (size_t)m * k, B, b_bcast ? 0 : (size_t)k * n, beta, C,
+                    (hipStream_t)stream);
     OTVAE_CHECK_LAUNCH("otvae_gemm_f64");
     return OTVAE_OK;
 }
@@ -771,8 +843,7 @@ static int eigh_block(const double* A, int nb, int D, int fn, double* out, doubl
         eb_finish_kernel<<<imin(cdiv((size_t)D * D, 256), 2048), 256, 0, st>>>(Aw, Vt, D, Dp, fn, eigvals + (size_t)b * D,
                                                                               fn == 3 ? out + (size_t)b * D * D : Vd, Td);
         if (fn == 1 || fn == 2)  // out = Vd^T * Td
-            gemm_f64_kernel<<<dim3(cdiv(D, 16), cdiv(D, 16), 1), 256, 0, st>>>(1, 0, D, D, D, 1.0, Vd, 0, Td, 0, 0.0,
-                                                                             out + (size_t)b * D * D);
+            gemm_f64_launch(1, 0, 1, D, D, D, 1.0, Vd, 0, Td, 0, 0.0, out + (size_t)b * D * D, st);
         OTVAE_CHECK_LAUNCH("otvae_eigh_fn(block)");
     }
     return OTVAE_OK;
