@@ -117,6 +117,7 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
     extern __shared__ __align__(16) double hj_lds[];
     __shared__ int s_rot;
     __shared__ double s_red[8], s_shift;
+    __shared__ double s_nrm[130];  // squared norms of the columns in the even positions (the kept columns' live in registers)
     constexpr int R = 128 / L;  // rows per lane at most (D <= 128 for L = 8; D <= 64 for L = 16 uses 4 of its 8)
     const int n = (D + 1) & ~1, half = n / 2, LD = D + 1;
     const HjWs w = hj_ws(ws, blockIdx.x, D);
@@ -168,6 +169,26 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
         keep[u] = (active && u < nrow && i < D) ? G[kpos * LD + i] : 0.0;
     }
     int gstep = 0, sweep = 0;
+    // squared norms are carried from step to step (|p'|^2 = |p|^2 - t gamma, |q'|^2 = |q|^2 + t gamma) and recounted at the start of
+    // every sweep: a step needs ONE dot product (p . q) instead of three
+    double nk = 0.0;
+    auto recount_norms = [&]() {
+        if (active) {
+            double a = 0.0, e2 = 0.0;
+            const double* ge = G + (kpos - 1) * LD;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int i = r + L * u;
+                const double ev = (u < nrow && i < D) ? ge[i] : 0.0;
+                a = fma(keep[u], keep[u], a);
+                e2 = fma(ev, ev, e2);
+            }
+            nk = group_sum<L>(a);
+            e2 = group_sum<L>(e2);
+            if (r == 0) s_nrm[kpos - 1] = e2;
+        }
+        __syncthreads();
+    };
     // one step; ODD is a compile-time constant so that the roles of the kept / fetched column cost no selects:
     // even step: pair (2g, 2g+1): the kept column is the UPPER one (q), the lower (p) comes from LDS position 2g;
     // odd step:  pair (2g+1, 2g+2): the kept column is the LOWER one (p), the upper (q) comes from LDS position 2g+2.
@@ -177,21 +198,18 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
         constexpr bool ODD = decltype(odd_tag)::value;
         const int opos = ODD ? kpos + 1 : kpos - 1;
         if (active && opos < n) {
-            double other[R], kk = 0.0, oo = 0.0, gamma = 0.0;
+            double other[R], gamma = 0.0;
             double* go = G + opos * LD;
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const int i = r + L * u;
                 other[u] = (u < nrow && i < D) ? go[i] : 0.0;
-                kk = fma(keep[u], keep[u], kk);
-                oo = fma(other[u], other[u], oo);
                 gamma = fma(keep[u], other[u], gamma);
             }
-            kk = group_sum<L>(kk);
-            oo = group_sum<L>(oo);
             gamma = group_sum<L>(gamma);
-            const double alpha = ODD ? kk : oo, beta = ODD ? oo : kk;  // |p|^2 (lower position), |q|^2 (upper)
-            double c = 1.0, s = 0.0;
+            const double no = s_nrm[opos];
+            const double alpha = ODD ? nk : no, beta = ODD ? no : nk;  // |p|^2 (lower position), |q|^2 (upper)
+            double c = 1.0, s = 0.0, tg = 0.0;
             const double ab = alpha * beta;
             if (gamma * gamma > HJ_TOL2 * ab && ab > 1e-280) {
                 const double zeta = (beta - alpha) * 0.5 * nr_rcp(gamma);
@@ -206,8 +224,15 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
                 }
                 c = nr_rsq(fma(tt, tt, 1.0));
                 s = c * tt;
+                tg = tt * gamma;
                 if (r == 0 && gamma * gamma > HJ_STOP2 * ab) s_rot = 1;  // benign race: every writer stores 1
             }
+            // p' shrinks to |p|^2 - t gamma: recounted when the subtraction cancelled more than two digits (a column on its way to
+            // zero in a rank-deficient matrix); p' is the published column in an odd step, the kept one in an even step
+            const double n_p = alpha - tg, n_q = beta + tg;
+            const bool recount = !(n_p > 0.01 * alpha) && tg != 0.0;  // uniform over the slot's lanes
+            double n_pub = ODD ? n_p : n_q, acc2 = 0.0;
+            nk = ODD ? n_q : n_p;
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const int i = r + L * u;
@@ -220,13 +245,23 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
                     keep[u] = c * other[u] - s * keep[u];  // p' -> kept position
                 }
                 if (u < nrow && i < D) go[i] = pub;
+                if (recount) acc2 = ODD ? fma(pub, pub, acc2) : fma(keep[u], keep[u], acc2);
             }
-            if (r == 0) w.log[(size_t)gstep * half + grp] = make_double2(c, s);
+            if (recount) {
+                acc2 = group_sum<L>(acc2);
+                if (ODD) n_pub = acc2;
+                else nk = acc2;
+            }
+            if (r == 0) {
+                s_nrm[opos] = n_pub;
+                w.log[(size_t)gstep * half + grp] = make_double2(c, s);
+            }
         }
         __syncthreads();
         ++gstep;
     };
     for (; sweep < HJ_MAX_SWEEPS; ++sweep) {
+        recount_norms();
         for (int t = 0; t < n; t += 2) {
             step(std::false_type{});
             step(std::true_type{});
@@ -261,8 +296,10 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
 
 // V = J_1 J_2 ... applied to the rows of the identity: a wave per row, its row (by position) in LDS, lane k replays slot k:
 // the same rotation and the same exchange of places as the columns of G underwent
+#define HJV_CHUNK 32  // steps of the rotation log staged in LDS at a time (32 KB): a step then costs an LDS round trip, not an L2 one
 __global__ __launch_bounds__(256) void hj_vectors_kernel(int D, void* __restrict__ ws) {
     __shared__ double rows[4][130];
+    __shared__ double2 slog[HJV_CHUNK][64];
     const int n = (D + 1) & ~1, half = n / 2;
     const HjWs w = hj_ws(ws, blockIdx.y, D);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -270,20 +307,24 @@ __global__ __launch_bounds__(256) void hj_vectors_kernel(int D, void* __restrict
     double* row = rows[wv];
     for (int k = lane; k < n; k += 64) row[k] = (k == i) ? 1.0 : 0.0;
     const int steps = w.ctl->steps;
-    __syncthreads();
-    double2 cs = (lane < half && steps > 0) ? w.log[lane] : make_double2(1.0, 0.0);
     volatile double* vrow = row;  // the wave's own row: LDS operations of one wave execute in order, no workgroup barrier
-    for (int st = 0; st < steps; ++st) {
-        const double2 cur = cs;
-        if (lane < half && st + 1 < steps) cs = w.log[(size_t)(st + 1) * half + lane];  // next step's pair, in flight
-        const int j = 2 * lane + (st & 1);  // n is even: the parity of the step within its sweep is the parity of st
-        if (lane < half && j + 1 < n) {
-            const double vp = vrow[j], vq = vrow[j + 1];
-            vrow[j] = cur.y * vp + cur.x * vq;      // q' moves down
-            vrow[j + 1] = cur.x * vp - cur.y * vq;  // p' moves up
+    for (int st0 = 0; st0 < steps; st0 += HJV_CHUNK) {
+        __syncthreads();  // the previous chunk is consumed (first pass: the rows are initialised)
+        const int cnt = min(HJV_CHUNK, steps - st0);
+        for (int e = threadIdx.x; e < cnt * half; e += 256) slog[e / half][e % half] = w.log[(size_t)st0 * half + e];
+        __syncthreads();
+        for (int s_ = 0; s_ < cnt; ++s_) {
+            const int st = st0 + s_;
+            const int j = 2 * lane + (st & 1);  // n is even: the parity of the step within its sweep is the parity of st
+            if (lane < half && j + 1 < n) {
+                const double2 cur = slog[s_][lane];
+                const double vp = vrow[j], vq = vrow[j + 1];
+                vrow[j] = cur.y * vp + cur.x * vq;      // q' moves down
+                vrow[j + 1] = cur.x * vp - cur.y * vq;  // p' moves up
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     if (i < D)
