@@ -314,7 +314,12 @@ bool conv_wtile_plan(const Geom& g, int has_bias, WTilePlan& pl, int& nblocks, s
     pl.vfloats = ipb * pl.Hv * pl.Wv * pl.CKp;
     pl.gfloats = ipb * pl.rowsPIp * pl.CnP;
     const int ngroups = cdiv(g.N, ipb);
-    nblocks = imin(ngroups, 512);
+    static const int max_blocks = [] {  // one weight-gradient partial per block: fewer blocks = less split-K traffic (A/B switch)
+        const char* e = getenv("OTVAE_WTILE_BLOCKS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 32 && v <= 2048 ? v : 512;
+    }();
+    nblocks = imin(ngroups, max_blocks);
     smem = ((size_t)pl.vfloats + 4 + pl.gfloats) * sizeof(float) + (size_t)pl.rowsPIp * sizeof(int);
     if (smem < 21 * 1024) smem = 21 * 1024;  // cross-wave reduction area: <= 20 accumulator tiles of 1 KiB
     return true;
