@@ -214,11 +214,19 @@ class HipTrainer:
         """``loss.backward()`` seeded at the nelbo kernel's [total, recon, prior] vector with a resident [1, 0, 0]: the
         select / ones_like / zeros that autograd would build between the forward and the backward pass are three launches."""
         out3 = getattr(self.model, "_last_nelbo", None)
-        if out3 is None:
-            torch.autograd.backward(loss, **kw)
-            return
-        torch.autograd.backward(out3, grad_tensors=[self._seed], **kw)
-        self.model._last_nelbo = None
+        try:
+            if out3 is None:
+                torch.autograd.backward(loss, **kw)
+            else:
+                torch.autograd.backward(out3, grad_tensors=[self._seed], **kw)
+        except BaseException:
+            # the deferred weight-gradient jobs / reductions of the interrupted pass must not leak into the next one
+            from ..functional import _PendingReduce
+            _PendingReduce.reset(self.device)
+            raise
+        finally:
+            if out3 is not None:
+                self.model._last_nelbo = None
 
     def _decoder_range(self):
         """(lo, hi) of the decoder's gradients in the flat buffer, or None when they are not one contiguous range"""

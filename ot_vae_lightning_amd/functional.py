@@ -247,6 +247,24 @@ class _PendingReduce:
         st.append((partial, p, k, kp, cn, gw, gb, cs, dead))
 
     @staticmethod
+    def reset(device) -> None:
+        """Forgets whatever an interrupted backward pass left behind (an exception between ``add`` and ``flush``): the queued jobs
+        hold raw addresses of tensors that the next pass no longer owns.  Joins the side streams first."""
+        pool = _PendingReduce._side.get(device)
+        if pool is not None and _PendingReduce._forked.get(device):
+            for side in pool[0]:
+                torch.cuda.current_stream(device).wait_stream(side)
+        _PendingReduce._forked[device] = False
+        for table in (_PendingReduce._state, _PendingReduce._held):
+            if table.get(device):
+                table[device].clear()
+        q = _PendingReduce._wq.get(device)
+        if q:
+            q[0].clear()
+            q[1] = 0
+        _PendingReduce._reduced[device] = 0
+
+    @staticmethod
     def _reduce(entries, stream_ptr):
         lib = _lib.load()
         n = len(entries)

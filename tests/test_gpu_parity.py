@@ -515,6 +515,30 @@ def test_block_jacobi_eigh_large_D(A, D):
     rep.finish()
 
 
+@pytest.mark.parametrize("D,nb", [(136, 3), (200, 2), (320, 3), (520, 1)])
+def test_block_jacobi_eigh_batches_and_hard_spectra(A, D, nb):
+    """The multi-workgroup solver (128 < D <= 1024) on batches (the eigenvector update then takes one row slab per block pair),
+    indefinite input (no Cholesky factor: the columns of A itself are iterated) and rank-deficient input (columns shrinking to
+    zero: the tracked squared norms are recounted): eigenvalues, V diag(lambda) V^T and V V^T = I against torch.linalg.eigh."""
+    from ot_vae_lightning_amd.ot import matrix_utils as MU
+    g = torch.Generator().manual_seed(300 + D)
+    x = torch.randn(nb, 2 * D, D, generator=g, dtype=torch.float64) * torch.linspace(0.1, 4.0, D, dtype=torch.float64)
+    cov = x.transpose(-1, -2) @ x / x.shape[-2]
+    sym = torch.randn(nb, D, D, generator=g, dtype=torch.float64)
+    sym = sym + sym.transpose(-1, -2)
+    low = x[:, : D // 3].transpose(-1, -2) @ x[:, : D // 3] / D
+    eye = torch.eye(D, dtype=torch.float64)
+    for name, m, tol in (("cov", cov, 1e-10), ("indefinite", sym, 1e-10), ("rank-deficient", low, 1e-10)):
+        lam = torch.linalg.eigvalsh(m)
+        ev, vt = MU.eigh_vectors(m.cuda())
+        ev, vt = ev.cpu(), vt.cpu()
+        scale = lam.abs().max()
+        assert float((torch.sort(ev, dim=-1)[0] - lam).abs().max() / scale) < tol, (name, "eigenvalues")
+        recon = vt.transpose(-1, -2) @ (ev.unsqueeze(-1) * vt)
+        assert float((recon - m).abs().max() / scale) < tol, (name, "reconstruction")
+        assert float((vt @ vt.transpose(-1, -2) - eye).abs().max()) < tol, (name, "orthonormality")
+
+
 def test_stochastic_transport_operator_vs_reference_golden(A):
     """eq. 19 of Freirich et al. (reference ot/w2_utils.py:391-458,732-786): the stochastic operator (T, Cw) for degenerate /
     nearly degenerate sources, diagonal and full (pseudo-inverse and the three functions of the target covariance from
