@@ -375,6 +375,14 @@ int otvae_cholesky(const double* A, int nb, int D, double* L, int* info, void* s
  * batch stride 0 */
 int otvae_gemm_f64(int transA, int transB, int nb, int m, int n, int k, double alpha, const double* A, int a_bcast,
                    const double* B, int b_bcast, double beta, double* C, void* stream);
+/* the same in fp32: the small weighted sums of the mixture / codebook models (weights @ atoms, probs^T @ samples:
+ * ot/distribution_models/base.py:241-251, codebook_model.py:145-148, ot/transport/discrete_transport.py:70-76) */
+int otvae_gemm_f32(int transA, int transB, int nb, int m, int n, int k, float alpha, const float* A, int a_bcast,
+                   const float* B, int b_bcast, float beta, float* C, void* stream);
+/* y[rows][K] = softmax_k(scale * x) and its backward gx = scale * y o (gy - sum_k y gy): the assignment distributions
+ * softmax(energy / temperature) (base.py:216-224) and F.gumbel_softmax (:234-235); dtype 0 = fp32, 1 = fp64 */
+int otvae_softmax_rows(int dtype, const void* x, int64_t rows, int K, double scale, void* y, void* stream);
+int otvae_softmax_rows_bwd(int dtype, const void* y, const void* gy, int64_t rows, int K, double scale, void* gx, void* stream);
 /* w2_gaussian tail (ot/w2_utils.py:78-80): out[nb] = |ms-mt|^2 + tr(cs + ct - 2*sqrt_mix) */
 int otvae_w2_tail(const double* ms, const double* mt, const double* cs, const double* ct, const double* sqrt_mix,
                   int nb, int D, double* out, void* stream);

@@ -116,6 +116,9 @@ SIGNATURES = {
     "otvae_make_psd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "otvae_cholesky": (i32, [vp, i32, i32, vp, vp, vp]),
     "otvae_gemm_f64": (i32, [i32, i32, i32, i32, i32, i32, f64, vp, i32, vp, i32, f64, vp, vp]),
+    "otvae_gemm_f32": (i32, [i32, i32, i32, i32, i32, i32, f32, vp, i32, vp, i32, f32, vp, vp]),
+    "otvae_softmax_rows": (i32, [i32, vp, i64, i32, f64, vp, vp]),
+    "otvae_softmax_rows_bwd": (i32, [i32, vp, vp, i64, i32, f64, vp, vp]),
     "otvae_w2_tail": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "otvae_apply_transport": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "otvae_codebook_assign": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),

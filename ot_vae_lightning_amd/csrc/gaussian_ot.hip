@@ -703,22 +703,23 @@ extern "C" int otvae_cholesky(const double* A, int nb, int D, double* L, int* in
 }
 
 // ================================================================================================ dense helpers
-__global__ __launch_bounds__(256) void gemm_f64_kernel(int transA, int transB, int m, int n, int k, double alpha,
-                                                       const double* __restrict__ A, size_t sA, const double* __restrict__ B,
-                                                       size_t sB, double beta, double* __restrict__ Cm) {
-    __shared__ double as[16][17], bs[16][17];
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(int transA, int transB, int m, int n, int k, T alpha,
+                                                        const T* __restrict__ A, size_t sA, const T* __restrict__ B,
+                                                        size_t sB, T beta, T* __restrict__ Cm) {
+    __shared__ T as[16][17], bs[16][17];
     const int b = blockIdx.z;
-    const double* Ab = A + (size_t)b * sA;
-    const double* Bb = B + (size_t)b * sB;
-    double* Cb = Cm + (size_t)b * m * n;
+    const T* Ab = A + (size_t)b * sA;
+    const T* Bb = B + (size_t)b * sB;
+    T* Cb = Cm + (size_t)b * m * n;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
-    double acc = 0.0;
+    T acc = (T)0;
     for (int k0 = 0; k0 < k; k0 += 16) {
         const int ka = k0 + tx;  // A tile: rows i (ty), cols k (tx)
-        as[ty][tx] = (i < m && ka < k) ? (transA ? Ab[(size_t)ka * m + i] : Ab[(size_t)i * k + ka]) : 0.0;
+        as[ty][tx] = (i < m && ka < k) ? (transA ? Ab[(size_t)ka * m + i] : Ab[(size_t)i * k + ka]) : (T)0;
         const int kb = k0 + ty;  // B tile: rows k (ty), cols j (tx)
-        bs[ty][tx] = (kb < k && j < n) ? (transB ? Bb[(size_t)j * k + kb] : Bb[(size_t)kb * n + j]) : 0.0;
+        bs[ty][tx] = (kb < k && j < n) ? (transB ? Bb[(size_t)j * k + kb] : Bb[(size_t)kb * n + j]) : (T)0;
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) acc = fma(as[ty][kk], bs[kk][tx], acc);
@@ -726,8 +727,78 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int transA, int transB, i
     }
     if (i < m && j < n) {
         const size_t o = (size_t)i * n + j;
-        Cb[o] = alpha * acc + (beta != 0.0 ? beta * Cb[o] : 0.0);
+        Cb[o] = alpha * acc + (beta != (T)0 ? beta * Cb[o] : (T)0);
     }
+}
+#define gemm_f64_kernel gemm_tile_kernel<double>
+
+// fp32 twin for the small weighted sums of the mixture / codebook models ([B, K] x [K, d], reference base.py:241-251,
+// codebook_model.py:145-148): a plain tiled product, the operands are a few hundred KB at most
+extern "C" int otvae_gemm_f32(int transA, int transB, int nb, int m, int n, int k, float alpha, const float* A, int a_bcast,
+                              const float* B, int b_bcast, float beta, float* C, void* stream) {
+    OTVAE_REQUIRE(A && B && C && nb > 0 && m > 0 && n > 0 && k > 0, "otvae_gemm_f32: bad argument");
+    gemm_tile_kernel<float><<<dim3(cdiv(n, 16), cdiv(m, 16), nb), 256, 0, (hipStream_t)stream>>>(
+        transA, transB, m, n, k, alpha, A, a_bcast ? 0 : (size_t)m * k, B, b_bcast ? 0 : (size_t)k * n, beta, C);
+    OTVAE_CHECK_LAUNCH("otvae_gemm_f32");
+    return OTVAE_OK;
+}
+
+// y[r][:] = softmax(scale * x[r][:]) over the last dimension and its backward gx = scale * y o (gy - sum_k y gy): the assignment
+// distributions of the mixture models (softmax(energy / temperature), base.py:216-224; F.gumbel_softmax, :234-235).  A wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, long rows, int K, T scale, T* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const T* xr = x + r * K;
+    T* yr = y + r * K;
+    T mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmax(mx, scale * xr[k]);
+    mx = wave_max(mx);
+    T sum = (T)0;
+    for (int k = lane; k < K; k += 64) sum += exp(scale * xr[k] - mx);
+    sum = wave_sum(sum);
+    const T inv = (T)1 / sum;
+    for (int k = lane; k < K; k += 64) yr[k] = exp(scale * xr[k] - mx) * inv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restrict__ y, const T* __restrict__ gy, long rows, int K, T scale,
+                                                               T* __restrict__ gx) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const T* yr = y + r * K;
+    const T* gr = gy + r * K;
+    T dot = (T)0;
+    for (int k = lane; k < K; k += 64) dot = fma(yr[k], gr[k], dot);
+    dot = wave_sum(dot);
+    for (int k = lane; k < K; k += 64) gx[r * K + k] = scale * yr[k] * (gr[k] - dot);
+}
+
+extern "C" int otvae_softmax_rows(int dtype, const void* x, int64_t rows, int K, double scale, void* y, void* stream) {
+    OTVAE_REQUIRE(x && y && rows > 0 && K > 0 && (dtype == 0 || dtype == 1), "otvae_softmax_rows: bad argument");
+    const int grid = cdiv(rows, 4);
+    if (dtype == 0)
+        softmax_rows_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, rows, K, (float)scale, (float*)y);
+    else
+        softmax_rows_kernel<double><<<grid, 256, 0, (hipStream_t)stream>>>((const double*)x, rows, K, scale, (double*)y);
+    OTVAE_CHECK_LAUNCH("otvae_softmax_rows");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_softmax_rows_bwd(int dtype, const void* y, const void* gy, int64_t rows, int K, double scale, void* gx,
+                                      void* stream) {
+    OTVAE_REQUIRE(y && gy && gx && rows > 0 && K > 0 && (dtype == 0 || dtype == 1), "otvae_softmax_rows_bwd: bad argument");
+    const int grid = cdiv(rows, 4);
+    if (dtype == 0)
+        softmax_rows_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)y, (const float*)gy, rows, K, (float)scale,
+                                                                               (float*)gx);
+    else
+        softmax_rows_bwd_kernel<double><<<grid, 256, 0, (hipStream_t)stream>>>((const double*)y, (const double*)gy, rows, K, scale,
+                                                                                (double*)gx);
+    OTVAE_CHECK_LAUNCH("otvae_softmax_rows_bwd");
+    return OTVAE_OK;
 }
 
 // The same product on the fp64 matrix cores for the large operands (D = 1024 latent transport: the products around the

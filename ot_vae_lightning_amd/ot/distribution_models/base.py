@@ -11,6 +11,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ... import utils
+from ..matrix_utils import softmax_rows
 
 __all__ = ["DistributionModel", "gumbel_weights", "MIXTURE_MODES"]
 
@@ -23,7 +24,7 @@ def gumbel_weights(energy: Tensor, temperature: float, hard: bool, noise: Option
     the hard variant its one-hot argmax with the soft value's gradient (straight-through).  ``noise``: the Gumbel draws to use
     (parity tests inject the reference's); otherwise they are drawn on the device, -log(Exponential(1))."""
     g = noise.to(energy) if noise is not None else -torch.empty_like(energy).exponential_().log()
-    soft = torch.softmax((energy + g) / temperature, dim=-1)
+    soft = softmax_rows(energy + g, 1.0 / temperature)
     if not hard:
         return soft
     index = soft.argmax(-1, keepdim=True)

@@ -23,6 +23,7 @@ from torch import Tensor
 
 from ... import _lib, utils
 from ..._lib import check, ptr, stream
+from ..matrix_utils import mm
 from ..w2_utils import sinkhorn_log
 from .base import MIXTURE_MODES, DistributionModel, gumbel_weights
 
@@ -39,7 +40,7 @@ class CategoricalEmbeddings(D.Categorical):
             raise ValueError("`probs` and `embeddings` should have the same leading dimensions")
 
     def _select(self, weights: Tensor) -> Tensor:
-        return (weights.unsqueeze(-2).type_as(self.embeddings) @ self.embeddings).squeeze(-2)
+        return mm(weights.unsqueeze(-2).type_as(self.embeddings), self.embeddings).squeeze(-2)
 
     def _select_one_hot(self, index_list: Tensor) -> Tensor:
         return self._select(F.one_hot(index_list, self._num_events).type_as(index_list))
@@ -219,7 +220,7 @@ class CodebookModel(DistributionModel):
             distribution = D.Categorical(self.assignment_probs(features))
             return preds.type_as(self.codebook), distribution.sample(), distribution
         weights, indices, distribution = self.assign(features)
-        return (weights.type_as(self.codebook) @ self.codebook), indices, distribution
+        return mm(weights.type_as(self.codebook), self.codebook), indices, distribution
 
     def nearest(self, features: Tensor) -> Tuple[Tensor, Tensor]:
         """(codebook[argmax], argmax indices): the deterministic part of ``predict``"""
@@ -234,7 +235,7 @@ class CodebookModel(DistributionModel):
         mode = self.mode
         if mode == "mean":  # soft assignment: sums of the probabilities and probs^T @ samples (base.py:241-251)
             probs = self.assignment_probs(samples).reshape(nb, bsz, self.n_components)
-            counts, sums = probs.sum(-2), probs.transpose(-1, -2) @ x3
+            counts, sums = probs.sum(-2), mm(probs.transpose(-1, -2).contiguous(), x3)
             return (counts.reshape(*lead, self.n_components).type_as(self._n_obs),
                     sums.reshape(*lead, self.n_components, self.dim).type_as(self._running_sum))
         if mode == "sample":

@@ -24,7 +24,7 @@ from ..._lib import check, ptr, stream
 from ..w2_utils import W2Mixin, batch_ot_gmm
 from .base import MIXTURE_MODES, DistributionModel, gumbel_weights
 from .gaussian_model import MakePositiveDefinite, Symmetric
-from ..matrix_utils import eigh_vectors, eye_like, matmul64
+from ..matrix_utils import eigh_vectors, eye_like, matmul64, mm, softmax_rows
 
 __all__ = ["GaussianMixtureModel"]
 
@@ -172,7 +172,7 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
     def assign(self, samples: Tensor):
         """(assignment weights [*, B, K], sampled indices [*, B], Categorical(softmax weights)) -- base.py:206-239"""
         energy = self.energy(samples)
-        weights = torch.softmax(energy / self.temperature, dim=-1)
+        weights = softmax_rows(energy, 1.0 / self.temperature)
         distribution = D.Categorical(weights)
         indices = distribution.sample()
         mode = self.mode
@@ -187,17 +187,17 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
 
     def predict_mean_var(self, assignments: Tensor) -> Tuple[Tensor, Tensor]:
         """per-sample mean and variance of the assigned component(s): assignments [*, B, K] -> [*, B, d] each"""
-        mean = assignments.type_as(self.mean) @ self.mean
+        mean = mm(assignments.type_as(self.mean), self.mean)
         cov = self.cov
         if self.diag:
-            var = assignments.type_as(cov) @ cov
+            var = mm(assignments.type_as(cov), cov)
         else:  # [*, B, K] x [*, K, d*d] -> [*, B, d, d]
-            var = (assignments.type_as(cov) @ cov.flatten(-2)).unflatten(-1, (self.dim, self.dim))
+            var = mm(assignments.type_as(cov), cov.flatten(-2)).unflatten(-1, (self.dim, self.dim))
         return mean.type_as(assignments), var.type_as(assignments)
 
     def predict(self, samples: Tensor):
         weights, indices, distribution = self.assign(samples)
-        return weights.type_as(self.mean) @ self.mean, indices, distribution
+        return mm(weights.type_as(self.mean), self.mean), indices, distribution
 
     # ---- fitting (codebook_model.py:121-143 driving gassian_mixture_model.py:108-170)
     def kmean_iteration(self, samples: Optional[Tensor]):
@@ -206,9 +206,9 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         weights, _, _ = self.assign(samples)                               # [*, B, K]
         wt = weights.transpose(-1, -2).type_as(samples)
         if self.diag:
-            return weights.sum(-2).type_as(samples), wt @ samples, wt @ (samples ** 2)
-        outer = (samples.unsqueeze(-1) @ samples.unsqueeze(-2)).flatten(-2)   # [*, B, d*d]
-        return weights.sum(-2).type_as(samples), wt @ samples, (wt @ outer).unflatten(-1, (self.dim, self.dim))
+            return weights.sum(-2).type_as(samples), mm(wt, samples), mm(wt, samples ** 2)
+        outer = (samples.unsqueeze(-1) * samples.unsqueeze(-2)).flatten(-2)   # [*, B, d*d]: the outer products x x^T
+        return weights.sum(-2).type_as(samples), mm(wt, samples), mm(wt, outer).unflatten(-1, (self.dim, self.dim))
 
     def _init_parameters(self, samples: Tensor) -> None:
         if torch.allclose(self.mean, self.vec_init):

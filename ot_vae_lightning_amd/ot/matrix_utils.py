@@ -10,7 +10,7 @@ from .. import _lib
 from .._lib import check, ptr, stream
 
 __all__ = ["eye_like", "sqrtm", "invsqrtm", "is_spd", "is_pd", "is_symmetric", "min_eig", "make_psd", "mean_cov",
-           "STABILITY_CONST", "eigvals_and_fn", "matmul64", "eigh_vectors", "spectral_fn", "psd_shift", "pinv_sym", "cholesky"]
+           "STABILITY_CONST", "eigvals_and_fn", "matmul64", "eigh_vectors", "spectral_fn", "psd_shift", "pinv_sym", "cholesky", "mm", "softmax_rows"]
 
 STABILITY_CONST = 1e-8
 
@@ -175,3 +175,94 @@ def matmul64(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False)
     check(lib.otvae_gemm_f64(int(trans_a), int(trans_b), nb, m, n, k, 1.0, ptr(a3), int(a3.shape[0] == 1 and nb > 1),
                              ptr(b3), int(b3.shape[0] == 1 and nb > 1), 0.0, ptr(out), stream()), "otvae_gemm_f64")
     return out
+
+
+def _mm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False) -> Tensor:
+    """[nb, m, k] x [nb, k, n] (a 2-D operand is broadcast over the batch) in the operands' dtype (fp32 / fp64) on our kernels"""
+    if a.dtype == torch.float64:
+        return matmul64(a, b, trans_a, trans_b)
+    lib = _lib.load()
+    a_b, b_b = a.dim() == 2, b.dim() == 2
+    a3 = a.contiguous() if not a_b else a.contiguous().unsqueeze(0)
+    b3 = b.contiguous() if not b_b else b.contiguous().unsqueeze(0)
+    nb = max(a3.shape[0], b3.shape[0])
+    m, k = (a3.shape[2], a3.shape[1]) if trans_a else (a3.shape[1], a3.shape[2])
+    n = b3.shape[1] if trans_b else b3.shape[2]
+    out = torch.empty((nb, m, n), device=a.device, dtype=torch.float32)
+    check(lib.otvae_gemm_f32(int(trans_a), int(trans_b), nb, m, n, k, 1.0, ptr(a3), int(a3.shape[0] == 1 and nb > 1),
+                             ptr(b3), int(b3.shape[0] == 1 and nb > 1), 0.0, ptr(out), stream()), "otvae_gemm_f32")
+    return out
+
+
+class _MatmulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _mm_raw(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = _mm_raw(g, b, trans_b=True)                  # [nb, m, n] x [nb, k, n]^T
+            if a.dim() == 2:
+                ga = ga.sum(0)
+        if ctx.needs_input_grad[1]:
+            gb = _mm_raw(a, g, trans_a=True)                  # [nb, m, k]^T x [nb, m, n]
+            if b.dim() == 2:
+                gb = gb.sum(0)
+        return ga, gb
+
+
+def mm(a: Tensor, b: Tensor) -> Tensor:
+    """``a @ b`` for [*, m, k] x [*, k, n] (equal leading shapes, or a 2-D operand shared by the batch) on the library's own GEMM
+    kernels, differentiable; the dtype is ``a``'s (fp32 or fp64)."""
+    _lib.require_cuda(a, "a")
+    if a.dtype not in (torch.float32, torch.float64):
+        raise TypeError("mm computes in fp32 or fp64")
+    b = b.to(a.dtype)
+    lead = a.shape[:-2] if a.dim() > 2 else b.shape[:-2]
+    a3 = a if a.dim() == 2 else a.reshape(-1, *a.shape[-2:])
+    b3 = b if b.dim() == 2 else b.reshape(-1, *b.shape[-2:])
+    if a3.dim() == 3 and b3.dim() == 3 and a3.shape[0] != b3.shape[0]:
+        if a.shape[:-2] != b.shape[:-2]:   # general broadcasting of the leading dimensions: materialise it
+            lead = torch.broadcast_shapes(a.shape[:-2], b.shape[:-2])
+            a3 = a.expand(*lead, *a.shape[-2:]).reshape(-1, *a.shape[-2:])
+            b3 = b.expand(*lead, *b.shape[-2:]).reshape(-1, *b.shape[-2:])
+    out = _MatmulFn.apply(a3, b3)
+    if a.dim() == 2 and b.dim() == 2:
+        return out[0]
+    return out.reshape(*lead, out.shape[-2], out.shape[-1])
+
+
+class _SoftmaxRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        lib = _lib.load()
+        x2 = x.contiguous()
+        y = torch.empty_like(x2)
+        rows, k = x2.numel() // x2.shape[-1], x2.shape[-1]
+        check(lib.otvae_softmax_rows(int(x2.dtype == torch.float64), ptr(x2), rows, k, float(scale), ptr(y), stream()), "otvae_softmax_rows")
+        ctx.save_for_backward(y)
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(y)
+        rows, k = y.numel() // y.shape[-1], y.shape[-1]
+        check(_lib.load().otvae_softmax_rows_bwd(int(y.dtype == torch.float64), ptr(y), ptr(gy), rows, k, ctx.scale, ptr(gx), stream()),
+              "otvae_softmax_rows_bwd")
+        return gx, None
+
+
+def softmax_rows(x: Tensor, scale: float = 1.0) -> Tensor:
+    """softmax(scale * x, dim=-1) on the library's kernel (fp32 / fp64), differentiable: the assignment distributions of the mixture models"""
+    _lib.require_cuda(x, "x")
+    if x.dtype not in (torch.float32, torch.float64):
+        raise TypeError("softmax_rows computes in fp32 or fp64")
+    return _SoftmaxRowsFn.apply(x, scale)

@@ -17,6 +17,7 @@ from torch import Tensor
 from torch.distributions import Categorical
 
 from ..distribution_models.codebook_model import CodebookModel
+from ..matrix_utils import mm
 from ..w2_utils import sinkhorn_log
 from .base import TransportOperator
 
@@ -70,10 +71,10 @@ class DiscreteTransport(TransportOperator):
             raise RuntimeError("call `compute()` before `transport()`")
         with self._inference_mode():
             assignment = self.source_model.assign(inputs)[0]                    # [*, B, K_source]
-        pushed = assignment.type_as(plan) @ plan                                # [*, B, K_target]
+        pushed = mm(assignment.type_as(plan), plan)                                # [*, B, K_target]
         atoms = self.target_model.codebook
         if self.transport_type == "mean":
-            moved = pushed.type_as(atoms) @ atoms
+            moved = mm(pushed.type_as(atoms), atoms)
         else:
             chosen = pushed.argmax(-1) if self.transport_type == "argmax" else Categorical(pushed).sample()
             moved = _rows(atoms, chosen)

@@ -210,11 +210,11 @@ def gaussian_barycenter(mean: Tensor, cov: Tensor, weights: Tensor, diag: bool, 
     if bool((weights < -1e-5).any()) or bool((total < 1 - 1e-5).any()) or bool((total > 1 + 1e-5).any()):
         raise ValueError("`weights` is expected to be a valid probability vector with positive entries that sum up to 1.")
     w_row = weights.unsqueeze(-2)                                            # [*, 1, N]
-    mean_b = (w_row @ mean).squeeze(-2)
+    mean_b = mm(w_row, mean).squeeze(-2)
     if diag:
         if bool((cov < 0).any()):
             raise ValueError("`cov` is expected to be a valid variance vector with positive entries.")
-        return mean_b, ((w_row @ torch.sqrt(cov)) ** 2).squeeze(-2)
+        return mean_b, (mm(w_row, torch.sqrt(cov)) ** 2).squeeze(-2)
     _require_spd(cov.reshape(-1, cov.shape[-1], cov.shape[-1]).contiguous(), "cov", False, True, False)
     n, d = cov.size(-3), cov.size(-1)
     lead = torch.broadcast_shapes(cov.shape[:-3], weights.shape[:-1])
@@ -414,7 +414,12 @@ def _transport_noise(shape, Cw: Tensor, diag: bool, make_pd: bool, noise_eps: Op
     cw = _require_spd(Cw.double().reshape(-1, d, d).contiguous(), "Cw", make_pd, True, False).reshape(Cw.shape)
     L = cholesky(cw)
     eps = noise_eps.to(L) if noise_eps is not None else torch.randn(shape, device=Cw.device, dtype=torch.double)
-    return (L @ eps.unsqueeze(-1)).squeeze(-1).to(dtype)
+    # L eps per sample = eps L^T per batch: one [B, D] x [D, D] product per operator instead of B matrix-vector products
+    if L.dim() == eps.dim() + 1 and L.shape[-3] == 1:
+        return mm(eps, L.squeeze(-3).transpose(-1, -2)).to(dtype)
+    if L.dim() == eps.dim():
+        return mm(eps, L.transpose(-1, -2)).to(dtype)
+    return mm(L, eps.unsqueeze(-1)).squeeze(-1).to(dtype)
 
 
 def apply_transport(input: Tensor, mean_source: Tensor, mean_target: Tensor, T: Tensor, Cw: Optional[Tensor] = None,

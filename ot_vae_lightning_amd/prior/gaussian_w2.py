@@ -68,7 +68,8 @@ class GaussianW2Prior(Prior):
             return x
         flat = x.flatten(1).double()
         if self.target_cov is not None:
-            flat = flat @ self._target_root()[1][0].to(device)
+            from ..ot.matrix_utils import mm
+            flat = mm(flat, self._target_root()[1][0].to(device))
         if self.target_mean is not None:
             flat = flat + self.target_mean.to(device)
         return flat.to(x.dtype).reshape(x.shape)

@@ -539,6 +539,45 @@ def test_block_jacobi_eigh_batches_and_hard_spectra(A, D, nb):
         assert float((vt @ vt.transpose(-1, -2) - eye).abs().max()) < tol, (name, "orthonormality")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_library_matmul_and_row_softmax_vs_float64(A, dtype):
+    """``matrix_utils.mm`` / ``softmax_rows``: the weighted sums (weights @ atoms, probs^T @ samples) and assignment distributions
+    (softmax(energy / T), F.gumbel_softmax) of the mixture / codebook models on the library's own kernels, values and gradients
+    against float64 torch arithmetic; batched, a 2-D operand shared by the batch, broadcast leading dimensions."""
+    from ot_vae_lightning_amd.ot import matrix_utils as MU
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    rep = Report(f"mm / softmax_rows ({dtype}) vs float64")
+    g = torch.Generator().manual_seed(12)
+    cases = [((3, 37, 50), (3, 50, 19)), ((37, 50), (50, 19)), ((2, 4, 9, 33), (33, 5)), ((5, 1, 64), (5, 64, 300)),
+             ((2, 1, 7, 16), (1, 3, 16, 8)), ((300, 1024), (1024, 16))]
+    for sa, sb in cases:
+        a = torch.randn(*sa, generator=g, dtype=torch.float64).to(dtype).cuda().requires_grad_(True)
+        b = torch.randn(*sb, generator=g, dtype=torch.float64).to(dtype).cuda().requires_grad_(True)
+        out = MU.mm(a, b)
+        ar, br = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+        ref = ar @ br
+        assert out.shape == ref.shape and out.dtype == dtype
+        go = torch.randn(ref.shape, generator=g, dtype=torch.float64).cuda()
+        ga, gb = torch.autograd.grad(out, (a, b), go.to(dtype))
+        ra, rb = torch.autograd.grad(ref, (ar, br), go)
+        rep.check(f"mm {sa} x {sb}", out, ref.detach(), tol)
+        rep.check(f"mm {sa} x {sb}: da", ga, ra, tol)
+        rep.check(f"mm {sa} x {sb}: db", gb, rb, tol)
+    for shape, scale in (((4, 33, 10), 1.0), ((700, 1024), 1 / 0.3), ((5, 1), 2.0), ((2, 3, 4, 130), 0.05)):
+        x = (torch.randn(*shape, generator=g, dtype=torch.float64) * 3).to(dtype).cuda().requires_grad_(True)
+        y = MU.softmax_rows(x, scale)
+        xr = x.detach().double().requires_grad_(True)
+        ref = torch.softmax(xr * scale, dim=-1)
+        go = torch.randn(shape, generator=g, dtype=torch.float64).cuda()
+        (gx,) = torch.autograd.grad(y, x, go.to(dtype))
+        (rx,) = torch.autograd.grad(ref, xr, go)
+        rep.check(f"softmax {shape}", y, ref.detach(), tol)
+        rep.check(f"softmax {shape}: dx", gx, rx, 5 * tol)
+    with pytest.raises(RuntimeError):
+        MU.mm(torch.zeros(2, 2), torch.zeros(2, 2))
+    rep.finish()
+
+
 def test_stochastic_transport_operator_vs_reference_golden(A):
     """eq. 19 of Freirich et al. (reference ot/w2_utils.py:391-458,732-786): the stochastic operator (T, Cw) for degenerate /
     nearly degenerate sources, diagonal and full (pseudo-inverse and the three functions of the target covariance from
