@@ -9,9 +9,10 @@ smoothing over the observed atoms), and ``w2`` composes the HIP Sinkhorn solver 
 
 Supported: ``metric='euclidean'``, ``p=2``, ``topk=None``, the assignment modes ``'argmax'``, ``'sample'`` (one-hot) and
 ``'mean'`` (soft: the assignment distribution itself, as ``DiscreteTransport`` uses it in the reference's
-tests/test_latent_transport.py:92-101; its weighted sums are ``probs^T @ samples``, a plain library GEMM on the HIP
-kernel's probabilities), ``update_with_autograd=False``.  The Gumbel modes of the reference's DAD models (out
-of scope) raise ``NotImplementedError``."""
+tests/test_latent_transport.py:92-101; its weighted sums ``probs^T @ samples`` go through ``matrix_utils.mm`` =
+``otvae_gemm_f32``), the Gumbel modes (``gumbel_weights``: ``otvae_softmax_rows`` with injectable draws),
+``update_with_autograd=False``.  ``energy`` (atoms against atoms, K x K, inside ``w2`` only) keeps ``torch.cdist``: its exact
+zero diagonal is what the reference's 1 / (dist + 1e-8) cost sees, which the |x|^2 + |y|^2 - 2 x.y kernel does not reproduce."""
 from functools import partial
 from typing import Optional, Tuple
 

@@ -1,13 +1,13 @@
-"""``GaussianMixtureModel`` with diagonal covariances (reference ot/distribution_models/gassian_mixture_model.py:28-177,
+"""``GaussianMixtureModel``, diagonal and full covariances (reference ot/distribution_models/gassian_mixture_model.py:28-177,
 mixture behaviour from base.py:165-262, fitting loop from codebook_model.py:121-143): K Gaussians per leading index
 fitted by (EMA) k-means style updates on streaming batches -- every sample is assigned to components by its
 log-likelihood + log-weight, the assignment weights accumulate (count, sum x, sum x^2) per component, and mean /
 variance / mixture weight of the OBSERVED components follow from the Laplace-smoothed counts.
 
-MI355X path: the O(B K d) energies come from ``otvae_gmm_diag_energy``; the [B, K] soft-max / arg-max and the three
-weighted sums (``weights^T @ x``: plain library GEMMs) are small tensor expressions kept in the reference's order, and
-``w2`` composes ``batch_ot_gmm`` (HIP pairwise-distance + Sinkhorn kernels).  Full covariance mixtures are not
-implemented (the reference marks its own full-covariance GMM cost as producing NaN, ot/w2_utils.py:262)."""
+MI355X path: the O(B K d) energies come from ``otvae_gmm_diag_energy`` (diagonal) or one batched eigendecomposition of the
+component covariances + fp64 products (full); the assignment soft-max (``otvae_softmax_rows``) and the weighted sums
+``weights^T @ x`` (``matrix_utils.mm``: ``otvae_gemm_f32 / _f64``) run on the library's own kernels in the reference's order;
+``w2`` composes ``batch_ot_gmm`` (HIP pairwise Gaussian W2 costs + Sinkhorn kernels)."""
 import math
 from functools import partial
 from typing import Optional, Tuple
