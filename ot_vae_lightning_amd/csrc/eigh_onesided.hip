@@ -22,12 +22,15 @@
 #include "common.h"
 
 #define HJ_MAX_SWEEPS 24
-// A pair is rotated whenever |g_p . g_q| > 1e-15 |g_p| |g_q| (every rotation refines), but only a pair above 1e-13 keeps the
-// iteration going: the computed inner product of two 128-vectors carries rounding noise of up to D eps = 3e-14 of
-// |g_p| |g_q|, so a threshold at that level is re-triggered sweep after sweep and the solver never sees a quiet sweep
-// (LAPACK's dgesvj stops at M eps = 1.4e-14 of its own arithmetic; the stop level here leaves eigenvectors good to ~1e-13).
+// A pair is rotated whenever |g_p . g_q| > 1e-15 |g_p| |g_q| (every rotation refines), but only a pair whose cosine is above
+// 1e-8 BEFORE its rotation keeps the iteration going.  Jacobi converges quadratically: a sweep that met no cosine above
+// 1e-8 has rotated all of them away and leaves ~1e-16 behind, so it is the last one -- a level of 1e-13 (round 2's first
+// setting) only confirmed that with one more, quiet sweep (measured on a numpy restatement of this ordering: one sweep fewer on
+// covariance-like, graded, clustered and rank-deficient spectra alike, the same final cosines of 1e-15).  The computed inner
+// product of two 128-vectors carries rounding noise of up to D eps = 3e-14 of |g_p| |g_q|: a stop level down there is
+// re-triggered sweep after sweep and the solver never sees a quiet sweep.
 #define HJ_TOL2 1e-30
-#define HJ_STOP2 1e-26
+#define HJ_STOP2 1e-16
 
 struct HjCtl {
     int steps;   // steps whose rotations are in the log
