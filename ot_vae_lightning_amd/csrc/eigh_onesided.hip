@@ -783,6 +783,7 @@ __global__ __launch_bounds__(256) void hjb_finish_kernel(int D, int fn, void* __
 
 void gemm_f64_launch(int transA, int transB, int nb, int m, int n, int k, double alpha, const double* A, size_t sA, const double* B,
                      size_t sB, double beta, double* C, hipStream_t st);  // gaussian_ot.hip
+int cholesky_blocked(const double* A, int nb, int D, double* L, size_t ls, int* info, size_t is, hipStream_t st);  // gaussian_ot.hip
 
 static bool g_hjb_lds_set[2] = {false, false};
 
@@ -799,9 +800,10 @@ int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, dou
         g_hjb_lds_set[big] = true;
     }
     const int Dp = hjb_dp(D), nblk = Dp / HJB_B;
-    for (int b = 0; b < nb; ++b) {  // L into the T area (free until the end), the pivot flag into the control block
-        const HjbWs w = hjb_ws(ws, b, D);
-        const int rc = otvae_cholesky(A + (size_t)b * D * D, 1, D, w.T, &w.ctl->chol_info, (void*)st);
+    {  // L into the T area (free until the end), the pivot flag into the control block: the whole batch in the same launches
+        const HjbWs w0 = hjb_ws(ws, 0, D);
+        const size_t per = (size_t)((char*)hjb_ws(ws, 1, D).G - (char*)w0.G);  // workspace pitch per matrix (a multiple of 8 bytes)
+        const int rc = cholesky_blocked(A, nb, D, w0.T, per / sizeof(double), &w0.ctl->chol_info, per / sizeof(int), st);
         if (rc) return rc;
     }
     hjb_init_kernel<<<dim3(imin(cdiv((size_t)Dp * D, 256), 1024), nb), 256, 0, st>>>(A, D, ws);

@@ -575,24 +575,28 @@ __global__ __launch_bounds__(256) void cholesky_kernel(const double* __restrict_
 // below solve X L11^T = A21 (a thread per row, L11 in LDS), (iii) the trailing matrix takes A22 -= L21 L21^T in 64 x 64 tiles
 // (lower triangle only).  L is built in place in its output buffer, which starts as a copy of A's lower triangle.
 #define CHB 64
-__global__ __launch_bounds__(256) void chol_copy_lower_kernel(const double* __restrict__ A, int D, double* __restrict__ L,
-                                                              int* __restrict__ info) {
+// ls / is: distance between consecutive matrices' factors (doubles) and info words (ints): D * D and 1 for the C entry point, the
+// per-matrix workspace pitch when the eigensolver factors a whole batch into its own buffers
+__global__ __launch_bounds__(256) void chol_copy_lower_kernel(const double* __restrict__ A, int D, double* __restrict__ L, size_t ls,
+                                                              int* __restrict__ info, size_t is) {
     const size_t boff = (size_t)blockIdx.y * D * D;
+    double* Lb = L + (size_t)blockIdx.y * ls;
     for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < (size_t)D * D; e += (size_t)gridDim.x * 256) {
         const int i = (int)(e / D), j = (int)(e - (size_t)i * D);
-        L[boff + e] = j <= i ? A[boff + e] : 0.0;
+        Lb[e] = j <= i ? A[boff + e] : 0.0;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && info) info[blockIdx.y] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && info) info[blockIdx.y * is] = 0;
 }
 
 // (i) + (ii): every workgroup factors the diagonal block [k0, k0+nbk) in its own LDS (64^3 / 3 flops: cheaper than handing it
 // over) and solves its 256 rows below against it; WRITE_DIAG: the launch of one workgroup per matrix that stores the factored
 // diagonal block afterwards (no workgroup of the solve launch may see it half written).
 template <bool WRITE_DIAG>
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ L, int D, int k0, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ L, size_t ls, int D, int k0, int* __restrict__ info,
+                                                         size_t is) {
     __shared__ double d[CHB][CHB + 1];
     __shared__ int s_bad;
-    double* Lb = L + (size_t)blockIdx.y * D * D;
+    double* Lb = L + (size_t)blockIdx.y * ls;
     const int nbk = min(CHB, D - k0);
     for (int e = threadIdx.x; e < nbk * nbk; e += 256) {
         const int i = e / nbk, j = e - i * nbk;
@@ -621,26 +625,36 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ L,
             const int i = e / nbk, j = e - i * nbk;
             if (j <= i) Lb[(size_t)(k0 + i) * D + k0 + j] = d[i][j];
         }
-        if (threadIdx.x == 0 && s_bad && info && info[blockIdx.y] == 0) info[blockIdx.y] = s_bad;
+        if (threadIdx.x == 0 && s_bad && info && info[blockIdx.y * is] == 0) info[blockIdx.y * is] = s_bad;
         return;
     }
-    // rows below the panel: row r of A21 <- solve x L11^T = a  (forward substitution along the row, in place: a thread re-reads
-    // its own earlier results)
+    // rows below the panel: row r of A21 <- solve x L11^T = a  (forward substitution along the row; the row's 64 entries live in
+    // registers -- re-reading its own earlier results from global memory made this launch 218 us at D = 1024)
     const int r = k0 + nbk + blockIdx.x * 256 + threadIdx.x;
     if (r < D) {
         double* row = Lb + (size_t)r * D + k0;
-        for (int j = 0; j < nbk; ++j) {
-            double acc = row[j];
-            for (int c = 0; c < j; ++c) acc = fma(-row[c], d[j][c], acc);
-            row[j] = acc / d[j][j];
+        double x[CHB];
+#pragma unroll
+        for (int j = 0; j < CHB; ++j) x[j] = j < nbk ? row[j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < CHB; ++j) {
+            if (j < nbk) {
+                double acc = x[j];
+#pragma unroll
+                for (int c = 0; c < j; ++c) acc = fma(-x[c], d[j][c], acc);
+                x[j] = acc / d[j][j];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < CHB; ++j)
+            if (j < nbk) row[j] = x[j];
     }
 }
 
 // (iii) A22[i][j] -= sum_c L21[i][c] L21[j][c] for the 64 x 64 tile (ti, tj), tj <= ti, of the trailing matrix
-__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ L, int D, int k0) {
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ L, size_t ls, int D, int k0) {
     __shared__ double a[CHB][17], b[CHB][17];
-    double* Lb = L + (size_t)blockIdx.z * D * D;
+    double* Lb = L + (size_t)blockIdx.z * ls;
     const int t0 = k0 + CHB;
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti) return;
@@ -678,23 +692,26 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ L, 
         }
 }
 
+// the blocked factorisation of nb matrices side by side; L / info of matrix b at L + b * ls, info + b * is
+int cholesky_blocked(const double* A, int nb, int D, double* L, size_t ls, int* info, size_t is, hipStream_t st) {
+    chol_copy_lower_kernel<<<dim3(imin(cdiv((size_t)D * D, 256), 1024), nb), 256, 0, st>>>(A, D, L, ls, info, is);
+    for (int k0 = 0; k0 < D; k0 += CHB) {
+        const int below = D - k0 - CHB;
+        if (below > 0) chol_panel_kernel<false><<<dim3(cdiv(below, 256), nb), 256, 0, st>>>(L, ls, D, k0, info, is);
+        chol_panel_kernel<true><<<dim3(1, nb), 256, 0, st>>>(L, ls, D, k0, info, is);
+        if (below > 0) {
+            const int nt = cdiv(below, CHB);
+            chol_syrk_kernel<<<dim3(nt, nt, nb), 256, 0, st>>>(L, ls, D, k0);
+        }
+    }
+    OTVAE_CHECK_LAUNCH("otvae_cholesky(blocked)");
+    return OTVAE_OK;
+}
+
 extern "C" int otvae_cholesky(const double* A, int nb, int D, double* L, int* info, void* stream) {
     OTVAE_REQUIRE(A && L && nb > 0 && D > 0 && A != L, "otvae_cholesky: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (D > 128) {
-        chol_copy_lower_kernel<<<dim3(imin(cdiv((size_t)D * D, 256), 1024), nb), 256, 0, st>>>(A, D, L, info);
-        for (int k0 = 0; k0 < D; k0 += CHB) {
-            const int below = D - k0 - CHB;
-            if (below > 0) chol_panel_kernel<false><<<dim3(cdiv(below, 256), nb), 256, 0, st>>>(L, D, k0, info);
-            chol_panel_kernel<true><<<dim3(1, nb), 256, 0, st>>>(L, D, k0, info);
-            if (below > 0) {
-                const int nt = cdiv(below, CHB);
-                chol_syrk_kernel<<<dim3(nt, nt, nb), 256, 0, st>>>(L, D, k0);
-            }
-        }
-        OTVAE_CHECK_LAUNCH("otvae_cholesky(blocked)");
-        return OTVAE_OK;
-    }
+    if (D > 128) return cholesky_blocked(A, nb, D, L, (size_t)D * D, info, 1, st);
 
     OTVAE_REQUIRE((size_t)D * 8 <= 64 * 1024, "otvae_cholesky: D = %d exceeds the LDS row buffer (8192)", D);
     cholesky_kernel<<<nb, 256, (size_t)D * sizeof(double), (hipStream_t)stream>>>(A, D, L, info);
