@@ -720,6 +720,220 @@ __global__ __launch_bounds__(512) void hjb_round_kernel(int D, int launch, int n
     }
 }
 
+// ---- the same round from the block pair's GRAM matrix ----------------------------------------------------------------------
+// The 16 sequential column steps above each reduce over all D rows; here the rotation workgroup forms W = B^T B (16 x 16, the
+// 16 columns B of the block pair; one v_mfma_f64_16x16x4_f64 per 4 rows: a lane's element of B is both operands), runs ONE
+// cyclic sweep of two-sided Jacobi on W in LDS (15 steps of 8 disjoint rotations on 16-vectors, accumulated in Q) and applies
+// B <- B Q as a product; the update role applies the same Q to the rows of V.  A numpy restatement (block pairs of 16 columns,
+// one inner sweep, the Cholesky factor of covariance-like and graded matrices) needs the same number of outer sweeps as the
+// column steps and ends at the same cosines (1e-15).  Measured at D = 1024 (phases switched off one at a time): a launch is
+// ~31 us instead of ~40 -- ~15 us of it the launch itself plus streaming the 16 columns in, 2.6 us the Gram matrix, ~6 us the 8
+// rotation steps, ~7 us writing the rotated columns back: every round moves the whole of X and V (33 MB) through HBM.
+// Columns keep their slots (no exchange of places): the log is the 16 x 16 matrix Q of the block pair.
+typedef double double4v_hj __attribute__((ext_vector_type(4)));
+
+// B <- B Q for the 16 columns of a block pair, as out^T = Q^T B^T on the matrix cores: one 16-row tile per wave and MFMA group;
+// lane (i = l % 16, k = l / 16) feeds A[i][k] = Q[4 ks + k][i] and B[k][j] = x[row 16 T + j][column 4 ks + k], and ends up with
+// out[row 16 T + l % 16][column 4 r + l / 16] in accumulator register r (layout probed on gfx950, tools/probe/mfma_f64.hip): its four
+// stores run along the rows.  From the LDS copy of the columns (rotation role), or in place on M (update role: a wave reads a
+// tile's 16 x 16 entries before the MFMAs and writes them after, tiles of different waves share no row).
+__device__ __forceinline__ void hjg_apply_lds(const double* __restrict__ P, int LD, double* __restrict__ M, int D, int I, int J,
+                                              const double (*Qs)[17]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, lk = lane >> 4;
+    auto home = [&](int pos) { return pos < HJB_B ? I * HJB_B + pos : J * HJB_B + (pos - HJB_B); };
+    double qa[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qa[ks] = Qs[4 * ks + lk][l16];
+    const int ntiles = (D + 15) / 16;
+    for (int T = wave; T < ntiles; T += 8) {
+        double4v_hj acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ks], P[(4 * ks + lk) * LD + 16 * T + l16], acc, 0, 0, 0);
+        const int row = 16 * T + l16;
+        if (row < D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[(size_t)home(4 * r + lk) * D + row] = acc[r];
+        }
+    }
+}
+
+__device__ __forceinline__ void hjg_apply_inplace(double* __restrict__ M, int D, int row0, int nrows, int I, int J, const double (*Qs)[17]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, lk = lane >> 4;
+    auto home = [&](int pos) { return pos < HJB_B ? I * HJB_B + pos : J * HJB_B + (pos - HJB_B); };
+    double qa[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qa[ks] = Qs[4 * ks + lk][l16];
+    const int ntiles = (nrows + 15) / 16;
+    for (int T = wave; T < ntiles; T += 8) {
+        const int row = 16 * T + l16;
+        double b[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b[ks] = row < nrows ? M[(size_t)home(4 * ks + lk) * D + row0 + row] : 0.0;
+        double4v_hj acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ks], b[ks], acc, 0, 0, 0);
+        if (row < nrows) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[(size_t)home(4 * r + lk) * D + row0 + row] = acc[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void hjg_round_kernel(int D, int launch, int nrounds, int rotate, int vslabs, void* __restrict__ ws) {
+    extern __shared__ __align__(16) double hj_lds[];
+    __shared__ double s_W[16][17], s_Q[16][17], s_part[8][16][16];
+    __shared__ double2 s_cs[8];
+    __shared__ int s_pq[8][2];
+    __shared__ int s_rot;
+    const HjbWs w = hjb_ws(ws, blockIdx.y, D);
+    constexpr int NP = 2 * HJB_B;
+    const int nblk = hjb_dp(D) / HJB_B, npairs = nblk / 2;
+    const bool vrole = (int)blockIdx.x >= npairs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int pair_idx, my_launch;
+    if (!vrole) {
+        if (!rotate || w.ctl->done) return;
+        pair_idx = blockIdx.x;
+        my_launch = launch;
+    } else {
+        my_launch = launch - 1;
+        if (my_launch < 0 || w.ctl->log_stamp[my_launch & 1] != my_launch) return;
+        pair_idx = (blockIdx.x - npairs) / vslabs;
+    }
+    int I, J;
+    hjb_pair(my_launch % nrounds, pair_idx, nblk, I, J);
+    auto home = [&](int pos) { return pos < HJB_B ? I * HJB_B + pos : J * HJB_B + (pos - HJB_B); };
+    double* glog = (double*)(w.log + ((size_t)(my_launch & 1) * npairs + pair_idx) * NP * HJB_B);  // 256 doubles: Q row-major
+    if (vrole) {
+        const int v = blockIdx.x - npairs;
+        const int per = ((D + vslabs - 1) / vslabs + 63) / 64 * 64;
+        const int row0 = (v % vslabs) * per, nrows = min(per, D - row0);
+        if (nrows <= 0) return;
+        if (tid < 256) s_Q[tid >> 4][tid & 15] = glog[tid];
+        __syncthreads();
+        hjg_apply_inplace(w.V, D, row0, nrows, I, J, s_Q);
+        return;
+    }
+    // ---- rotation role
+    const int Dr = (D + 15) & ~15, LD = Dr + 1;
+    double* P = hj_lds;  // P[pos * LD + row], rows D .. Dr zero (whole 16-row tiles for the products)
+    for (int pos = wave; pos < NP; pos += 8) {
+        const double* src = w.G + (size_t)home(pos) * D;
+        for (int i = lane; i < Dr; i += 64) P[pos * LD + i] = i < D ? src[i] : 0.0;
+    }
+    if (tid == 0) s_rot = 0;
+    __syncthreads();
+    {   // W = B^T B on the matrix cores: row group rg covers rows 4 rg .. 4 rg + 3; lane (c = l % 16, k = l / 16) holds B[4 rg + k][c]
+        double4v_hj acc = {0.0, 0.0, 0.0, 0.0};
+        const int c = lane & 15, k = lane >> 4;
+        for (int rg = wave; rg < Dr / 4; rg += 8) {
+            const double a = P[c * LD + 4 * rg + k];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_part[wave][4 * r + k][c] = acc[r];  // D[4 r + l / 16][l % 16]
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int i = tid >> 4, j = tid & 15;
+        double t = 0.0;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) t += s_part[g8][i][j];
+        s_W[i][j] = t;
+        s_Q[i][j] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (tid < 256) {  // does this pair still hold a cosine above the stop level?
+        const int i = tid >> 4, j = tid & 15;
+        const double gij = s_W[i][j], ab = s_W[i][i] * s_W[j][j];
+        if (i < j && gij * gij > HJ_STOP2 * ab && ab > 1e-280) s_rot = 1;  // benign race
+    }
+    __syncthreads();  // the sweep below rewrites W
+    if (wave == 0) {  // two-sided Jacobi on W in LDS, 8 disjoint rotations per step, accumulated in Q
+        volatile double(*W)[17] = s_W;
+        volatile double(*Q)[17] = s_Q;
+        // Every round rotates the 64 pairs ACROSS the two blocks (8 steps: column i against column 8 + (i + t) % 8); the pairs inside
+        // a block, which every round of a sweep would meet again, are only rotated by the first round of a sweep (a full round-robin
+        // of 15 steps).  Same final cosines, at most one outer sweep more (numpy restatement), half the steps per round.
+        const bool full = (my_launch % nrounds) == 0;
+        const int nsteps = full ? NP - 1 : HJB_B;
+        for (int t = 0; t < nsteps; ++t) {
+            if (lane < 8) {
+                int p, q;
+                if (full) {
+                    hjb_pair(t, lane, NP, p, q);
+                } else {
+                    p = lane;
+                    q = HJB_B + ((lane + t) & (HJB_B - 1));
+                }
+                const double alpha = W[p][p], beta = W[q][q], gamma = W[p][q];
+                double c = 1.0, s_ = 0.0;
+                const double ab = alpha * beta;
+                if (gamma * gamma > HJ_TOL2 * ab && ab > 1e-280) {
+                    // the tangent need not be exact (an inexact angle only leaves a little more for the next visit): hardware
+                    // seeds + one Newton step; c and s are made orthonormal to rounding below
+                    double y = __builtin_amdgcn_rcp(gamma);
+                    y = fma(fma(-gamma, y, 1.0), y, y);
+                    const double zeta = (beta - alpha) * 0.5 * y;
+                    const double az = fabs(zeta);
+                    double tt;
+                    if (az > 1e8) {
+                        tt = 0.5 * __builtin_amdgcn_rcp(zeta);
+                    } else {
+                        const double q2 = fma(zeta, zeta, 1.0);
+                        double rq = __builtin_amdgcn_rsq(q2);
+                        rq = rq * fma(-0.5 * q2 * rq, rq, 1.5);
+                        const double den = az + q2 * rq;
+                        double rd = __builtin_amdgcn_rcp(den);
+                        rd = fma(fma(-den, rd, 1.0), rd, rd);
+                        tt = zeta >= 0.0 ? rd : -rd;
+                    }
+                    c = nr_rsq(fma(tt, tt, 1.0));
+                    s_ = c * tt;
+                }
+                s_cs[lane] = make_double2(c, s_);
+                s_pq[lane][0] = p;
+                s_pq[lane][1] = q;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // columns: (W J) and (Q J): item (pair kk, row r), two items per lane
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int item = lane + 64 * it, kk = item >> 4, r = item & 15;
+                const int p = s_pq[kk][0], q = s_pq[kk][1];
+                const double c = s_cs[kk].x, s_ = s_cs[kk].y;
+                const double wp = W[r][p], wq = W[r][q], qp = Q[r][p], qq = Q[r][q];
+                W[r][p] = c * wp - s_ * wq;
+                W[r][q] = s_ * wp + c * wq;
+                Q[r][p] = c * qp - s_ * qq;
+                Q[r][q] = s_ * qp + c * qq;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // rows: J^T (W J): item (pair kk, column col)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int item = lane + 64 * it, kk = item >> 4, col = item & 15;
+                const int p = s_pq[kk][0], q = s_pq[kk][1];
+                const double c = s_cs[kk].x, s_ = s_cs[kk].y;
+                const double wp = W[p][col], wq = W[q][col];
+                W[p][col] = c * wp - s_ * wq;
+                W[q][col] = s_ * wp + c * wq;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    if (tid < 256) glog[tid] = s_Q[tid >> 4][tid & 15];
+    hjg_apply_lds(P, LD, w.G, D, I, J, s_Q);
+    if (tid == 0) {
+        if (s_rot) w.ctl->rotated = 1;
+        if (blockIdx.x == 0) w.ctl->log_stamp[launch & 1] = launch;
+    }
+}
+
 __global__ void hjb_check_kernel(int D, void* __restrict__ ws) {
     const HjbWs w = hjb_ws(ws, blockIdx.x, D);
     if (threadIdx.x != 0 || w.ctl->done) return;
@@ -786,6 +1000,7 @@ void gemm_f64_launch(int transA, int transB, int nb, int m, int n, int k, double
 int cholesky_blocked(const double* A, int nb, int D, double* L, size_t ls, int* info, size_t is, hipStream_t st);  // gaussian_ot.hip
 
 static bool g_hjb_lds_set[2] = {false, false};
+static bool g_hjg_lds_set = false;
 
 int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, hipStream_t st) {
     const size_t lds = (size_t)2 * HJB_B * (D + 1) * sizeof(double);
@@ -798,6 +1013,14 @@ int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, dou
             return OTVAE_ELAUNCH;
         }
         g_hjb_lds_set[big] = true;
+    }
+    if (!g_hjg_lds_set) {
+        if (hipFuncSetAttribute((const void*)hjg_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(2 * HJB_B * (HJB_MAX_D + 1) * 8)) != hipSuccess) {
+            otvae_set_error("otvae_eigh_fn: cannot raise dynamic LDS limit");
+            return OTVAE_ELAUNCH;
+        }
+        g_hjg_lds_set = true;
     }
     const int Dp = hjb_dp(D), nblk = Dp / HJB_B;
     {  // L into the T area (free until the end), the pivot flag into the control block: the whole batch in the same launches
@@ -812,8 +1035,12 @@ int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, dou
     // still resident at once (two matrices of D = 1024 side by side are 128 rotation + 128 update blocks already)
     const int vslabs = (nblk / 2 * (1 + HJB_VSLABS) * nb <= 256) ? HJB_VSLABS : 1;
     const dim3 grid(nblk / 2 * (1 + vslabs), nb);  // rotation blocks, then the eigenvector-update blocks of the launch before
+    static const bool column_steps = getenv("OTVAE_EIGH_COLUMN_STEPS") != nullptr;  // A/B switch: the first-generation rounds
+    const size_t lds_g = (size_t)2 * HJB_B * (((D + 15) & ~15) + 1) * sizeof(double);
     auto round_launch = [&](int launch, int rotate) {
-        if (big)
+        if (!column_steps)
+            hjg_round_kernel<<<grid, 512, lds_g, st>>>(D, launch, nrounds, rotate, vslabs, ws);
+        else if (big)
             hjb_round_kernel<16><<<grid, 512, lds, st>>>(D, launch, nrounds, rotate, vslabs, ws);
         else
             hjb_round_kernel<8><<<grid, 512, lds, st>>>(D, launch, nrounds, rotate, vslabs, ws);
