@@ -363,6 +363,13 @@ int64_t otvae_eigh_ws(int nb, int D);
 int64_t otvae_eigh_onesided_ws(int nb, int D); /* part of otvae_eigh_ws for D <= 128: the one-sided solver's share */
 int64_t otvae_eigh_block_onesided_ws(int nb, int D); /* part of otvae_eigh_ws for 128 < D <= 1024 */
 int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, void* stream);
+/* otvae_eigh_fn started from an orthonormal basis the caller already has (Vinit[nb][D][D], row k = vector k; e.g. the eigenvectors
+ * of the previous training step's latent covariance, prior/gaussian_w2.py): the iteration begins with the nearly orthogonal columns
+ * A v_k and needs 2-4 sweeps instead of ~9; the result is the same decomposition.  A must be symmetric in both triangles; g0:
+ * scratch of nb*D*D doubles.  warm (nullable): device int read by the kernels, 0 = "Vinit holds nothing yet" (run cold): lets a
+ * captured step decide per replay.  Vinit == NULL, D > 128: the cold solver. */
+int otvae_eigh_fn_warm(const double* A, const double* Vinit, const int* warm, int nb, int D, int fn, double* out, double* eigvals,
+                       void* ws, double* g0, void* stream);
 /* make_psd (ot/matrix_utils.py:123-142) without host sync: shift_b = (any_b lambda_min_b <= thr ? 1 : 0) *
  * (|min(lambda_min_b,0)| + (strict ? 1e-8 : 0)), A_b += shift_b * I.  cond_any: 1 = apply only if some matrix of
  * the batch fails the test (w2_utils.py:667-669), 0 = always (gaussian_model.py:204-214). */

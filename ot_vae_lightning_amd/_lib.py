@@ -113,6 +113,7 @@ SIGNATURES = {
     "otvae_eigh_onesided_ws": (i64, [i32, i32]),
     "otvae_eigh_block_onesided_ws": (i64, [i32, i32]),
     "otvae_eigh_fn": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    "otvae_eigh_fn_warm": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "otvae_make_psd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "otvae_cholesky": (i32, [vp, i32, i32, vp, vp, vp]),
     "otvae_gemm_f64": (i32, [i32, i32, i32, i32, i32, i32, f64, vp, i32, vp, i32, f64, vp, vp]),

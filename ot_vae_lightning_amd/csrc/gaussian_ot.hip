@@ -170,7 +170,8 @@ extern "C" int otvae_mean_cov(const double* n_obs, const double* sum_x, const do
 static int eigb_dp(int D) { return (D + 2 * EIGB - 1) / (2 * EIGB) * (2 * EIGB); }
 
 extern "C" int64_t otvae_eigh_onesided_ws(int nb, int D);
-int eigh_onesided(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, hipStream_t st);  // eigh_onesided.hip
+int eigh_onesided(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, hipStream_t st, const double* Vinit,
+                  double* g0, const int* warm);  // eigh_onesided.hip
 extern "C" int64_t otvae_eigh_block_onesided_ws(int nb, int D);
 int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, double* eigvals, void* ws, hipStream_t st);
 
@@ -478,7 +479,7 @@ extern "C" int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out
     if (D > EIGH_MAX_D && D <= 1024 && !getenv("OTVAE_EIGH_TWOSIDED"))
         return eigh_block_onesided(A, nb, D, fn, out, eigvals, ws, (hipStream_t)stream);
     if (D > EIGH_MAX_D) return eigh_block(A, nb, D, fn, out, eigvals, (double*)ws, (hipStream_t)stream);
-    if (!getenv("OTVAE_EIGH_TWOSIDED")) return eigh_onesided(A, nb, D, fn, out, eigvals, ws, (hipStream_t)stream);
+    if (!getenv("OTVAE_EIGH_TWOSIDED")) return eigh_onesided(A, nb, D, fn, out, eigvals, ws, (hipStream_t)stream, nullptr, nullptr, nullptr);
     const size_t lds = eigh_lds_bytes(D);
     if (lds > 65536 && lds > g_eigh_lds_set) {
         if (hipFuncSetAttribute((const void*)eigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -490,6 +491,22 @@ extern "C" int otvae_eigh_fn(const double* A, int nb, int D, int fn, double* out
     eigh_kernel<<<nb, EIGH_THREADS, lds, (hipStream_t)stream>>>(A, D, fn, out, eigvals, (double*)ws, nullptr);
     OTVAE_CHECK_LAUNCH("otvae_eigh_fn");
     return OTVAE_OK;
+}
+
+// The same decomposition started from an orthonormal basis the caller already has (Vinit[b][k][:] = vector k: the eigenvectors of
+// a nearby matrix, e.g. the previous training step's latent covariance under GaussianW2Prior): the one-sided iteration then
+// begins with the nearly orthogonal columns A v_k and needs 2-4 sweeps instead of ~9.  A must be symmetric in BOTH triangles
+// here (it enters a product); g0: scratch of nb * D * D doubles.  warm (nullable): a device int the kernels read -- 0 means
+// "Vinit holds nothing yet" and the call runs cold, so that a captured training step can make that decision per replay.
+// D > 128 (or the two-sided solver): Vinit is ignored.
+extern "C" int otvae_eigh_fn_warm(const double* A, const double* Vinit, const int* warm, int nb, int D, int fn, double* out,
+                                  double* eigvals, void* ws, double* g0, void* stream) {
+    OTVAE_REQUIRE(A && eigvals && ws && nb > 0 && D > 0, "otvae_eigh_fn_warm: bad argument");
+    OTVAE_REQUIRE(fn >= 0 && fn <= 3, "otvae_eigh_fn_warm: fn must be 0, 1, 2 or 3");
+    OTVAE_REQUIRE(fn == 0 || out, "otvae_eigh_fn_warm: out missing");
+    OTVAE_REQUIRE(!Vinit || g0, "otvae_eigh_fn_warm: scratch for the start columns missing");
+    if (D > EIGH_MAX_D || getenv("OTVAE_EIGH_TWOSIDED") || !Vinit) return otvae_eigh_fn(A, nb, D, fn, out, eigvals, ws, stream);
+    return eigh_onesided(A, nb, D, fn, out, eigvals, ws, (hipStream_t)stream, Vinit, g0, warm);
 }
 
 // make_psd: A_b += shift_b I, shift_b = |min(lmin_b, 0)| (+1e-8 if strict), optionally only if some matrix fails

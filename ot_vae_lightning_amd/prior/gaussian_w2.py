@@ -25,20 +25,22 @@ class _W2PriorFn(torch.autograd.Function):
     through this node too (an alias of z, see prior/sinkhorn.py), so the decoder's gradient is added inside the backward kernel."""
 
     @staticmethod
-    def forward(ctx, z, mut, covt, rt, scale):
-        loss, mu, q = torch.ops.otvae.gaussian_w2_prior(z, mut, covt, rt, float(scale))
+    def forward(ctx, z, mut, covt, rt, v_init, warm, scale):
+        loss, mu, q, vt = torch.ops.otvae.gaussian_w2_prior(z, mut, covt, rt, v_init, warm, float(scale))
         ctx.save_for_backward(z, mu, q)
         ctx.target = (mut, rt)
         ctx.scale = float(scale)
-        return z.view_as(z), loss
+        ctx.mark_non_differentiable(vt)
+        return z.view_as(z), loss, vt
 
     @staticmethod
-    def backward(ctx, gz_out, g):
+    def backward(ctx, gz_out, g, _gvt):
         z, mu, q = ctx.saved_tensors
         mut, rt = ctx.target
         if g is None:
-            return gz_out, None, None, None, None
-        return torch.ops.otvae.gaussian_w2_prior_backward(g, gz_out, z, mu, q, mut, rt, ctx.scale), None, None, None, None
+            return gz_out, None, None, None, None, None, None
+        return (torch.ops.otvae.gaussian_w2_prior_backward(g, gz_out, z, mu, q, mut, rt, ctx.scale), None, None, None, None, None,
+                None)
 
 
 class GaussianW2Prior(Prior):
@@ -58,6 +60,14 @@ class GaussianW2Prior(Prior):
         self.register_buffer("target_mean", None if target_mean is None else target_mean.detach().double().clone())
         self.register_buffer("target_cov", None if target_cov is None else target_cov.detach().double().clone())
         self._root = None  # (validated target covariance, its square root), made on first use on the device
+        # Warm start of the eigendecomposition: the eigenvectors of the previous training step's matrix are the start basis of this
+        # step's solve (consecutive minibatch covariances are close: 2-4 Jacobi sweeps instead of ~9).  `_warm` says whether
+        # `_v_prev` holds a basis yet; it is a BUFFER so that an engine capturing the step snapshots / restores it with the
+        # other buffers and a captured step decides cold / warm per replay exactly as the eagerly issued one does.  The basis is
+        # a product of exactly orthogonal rotations from step to step; its orthogonality error grows like sqrt(rotations) * 1e-16
+        # (1e-12 after 1e8 of them), far below what the loss resolves.
+        self.register_buffer("_warm", torch.zeros(1, dtype=torch.int32), persistent=False)
+        self._v_prev = None
 
     def out_size(self, size):
         return size
@@ -90,5 +100,15 @@ class GaussianW2Prior(Prior):
         if self.target_cov is not None and self.target_cov.shape[-1] != zf.shape[1]:
             raise ValueError(f"All the inputs dimensionalities should match, got {[zf.shape[1], self.target_cov.shape[-1]]}")
         covt, rt = self._target_root() if self.target_cov is not None else (None, None)
-        z_out, loss = _W2PriorFn.apply(zf, self.target_mean, covt, rt, _scale)
+        d = zf.shape[1]
+        warm_ok = self.training and zf.is_cuda and d <= 128
+        if warm_ok and (self._v_prev is None or self._v_prev.shape[-1] != d or self._v_prev.device != zf.device):
+            self._v_prev = torch.zeros((1, d, d), device=zf.device, dtype=torch.float64)
+            self._warm.zero_()
+        z_out, loss, vt = _W2PriorFn.apply(zf, self.target_mean, covt, rt, self._v_prev if warm_ok else None,
+                                           self._warm if warm_ok else None, _scale)
+        if warm_ok:
+            with torch.no_grad():
+                self._v_prev.copy_(vt)
+                self._warm.fill_(1)
         return z_out.view(x.shape), loss, {}

@@ -55,5 +55,5 @@ def test_fake_implementations_give_the_kernels_shapes():
         cost, pi, iters = torch.ops.otvae.sinkhorn_prior(zz, yy, 0.05, 50, 0.0, 1.0)
         assert cost.shape == (64,) and pi.shape == (64, 48) and iters.dtype == torch.int32
         assert torch.ops.otvae.sinkhorn_prior_backward(cost, None, zz, yy, pi, 1.0).shape == zz.shape
-        loss, mu, q = torch.ops.otvae.gaussian_w2_prior(zz, None, None, None, 1.0)
-        assert loss.shape == (64,) and mu.shape == (1, 16) and q.shape == (16, 16) and q.dtype == torch.float64
+        loss, mu, q, vt = torch.ops.otvae.gaussian_w2_prior(zz, None, None, None, None, None, 1.0)
+        assert loss.shape == (64,) and mu.shape == (1, 16) and q.shape == (16, 16) and q.dtype == torch.float64 and vt.shape == (1, 16, 16)

@@ -284,6 +284,10 @@ def test_gaussian_w2_prior_in_vae_training_step(A):
             params = [p for net in (tr.model.encoder, tr.model.decoder) for p in net.parameters()]
             rep.check("grad_l2 (all parameters)", torch.tensor([p.grad.double().norm().item() for p in params]),
                       torch.tensor([v.grad.double().norm().item() for v in leaves]), tol=5e-4)
+        # steps 2-4 start the eigendecomposition from the previous step's eigenvectors (the first one cold, in both modes)
+        later = torch.stack([tr.step(x.cuda()).clone() for _ in range(3)])
+        assert int(tr.model.prior._warm) == 1 and torch.isfinite(later).all()
+        outs[-1] = outs[-1] + (later, tr.pflat.clone())
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     rep.finish()
 

@@ -41,7 +41,10 @@ def test_opcheck_on_every_differentiable_op(A):
             test_utils=utils)
     z = normal((64, 16), 11).cuda().requires_grad_(True)
     opcheck(torch.ops.otvae.sinkhorn_prior, (z, normal((64, 16), 12).cuda(), 0.05, 20, 0.0, 1.0), test_utils=utils)
-    opcheck(torch.ops.otvae.gaussian_w2_prior, (z, None, None, None, 1.0), test_utils=utils)
+    opcheck(torch.ops.otvae.gaussian_w2_prior, (z, None, None, None, None, None, 1.0), test_utils=utils)
+    basis = torch.linalg.qr(normal((16, 16), 13).double())[0].unsqueeze(0).cuda()   # any orthonormal start basis
+    opcheck(torch.ops.otvae.gaussian_w2_prior, (z, None, None, None, basis, torch.ones(1, dtype=torch.int32, device="cuda"), 1.0),
+            test_utils=utils)
 
 
 def test_conv_bn_act_operator_equals_the_module_route_and_torch_autograd(A):

@@ -578,6 +578,47 @@ def test_library_matmul_and_row_softmax_vs_float64(A, dtype):
     rep.finish()
 
 
+@pytest.mark.parametrize("D", [16, 65, 128])
+def test_warm_started_eigensolver_gives_the_same_decomposition(D):
+    """``otvae_eigh_fn_warm``: the one-sided solver started from an orthonormal basis (the eigenvectors of a nearby matrix, or any
+    orthonormal matrix) instead of the identity -- same eigenvalues, a valid eigenbasis of the SAME matrix; with the device flag at
+    0 the call is the cold solver bit for bit."""
+    import ctypes as C
+    from ot_vae_lightning_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(40 + D)
+    x = torch.randn(3 * D, D, generator=g, dtype=torch.float64) * torch.linspace(0.3, 2.0, D, dtype=torch.float64)
+    a0 = (x.T @ x / x.shape[0])
+    pert = torch.randn(D, D, generator=g, dtype=torch.float64) * 0.02
+    a1 = a0 + (pert + pert.T) * 0.5 + 0.1 * torch.eye(D, dtype=torch.float64)
+
+    def solve(a, basis=None, flag=1):
+        ad = a.reshape(1, D, D).contiguous().cuda()
+        ev, vt = torch.empty((1, D), dtype=torch.float64, device="cuda"), torch.empty((1, D, D), dtype=torch.float64, device="cuda")
+        ws = torch.empty(lib.otvae_eigh_ws(1, D), dtype=torch.uint8, device="cuda")
+        if basis is None:
+            L.check(lib.otvae_eigh_fn(L.ptr(ad), 1, D, 3, L.ptr(vt), L.ptr(ev), L.ptr(ws), L.stream()), "otvae_eigh_fn")
+        else:
+            g0 = torch.empty((1, D, D), dtype=torch.float64, device="cuda")
+            warm = torch.full((1,), flag, dtype=torch.int32, device="cuda")
+            L.check(lib.otvae_eigh_fn_warm(L.ptr(ad), L.ptr(basis.contiguous()), L.ptr(warm), 1, D, 3, L.ptr(vt), L.ptr(ev), L.ptr(ws),
+                                           L.ptr(g0), L.stream()), "otvae_eigh_fn_warm")
+        return ev[0].cpu(), vt[0].cpu()
+
+    _, v0 = solve(a0)
+    lam = torch.linalg.eigvalsh(a1)
+    eye = torch.eye(D, dtype=torch.float64)
+    for name, basis in (("previous eigenvectors", v0.unsqueeze(0).cuda()),
+                        ("random orthonormal", torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0].unsqueeze(0).cuda())):
+        ev, vt = solve(a1, basis)
+        assert float((torch.sort(ev)[0] - lam).abs().max() / lam.max()) < 1e-12, name
+        assert float((vt.T @ (ev.unsqueeze(-1) * vt) - a1).abs().max() / lam.max()) < 1e-12, name
+        assert float((vt @ vt.T - eye).abs().max()) < 1e-12, name
+    cold = solve(a1)
+    flagged_off = solve(a1, v0.unsqueeze(0).cuda(), flag=0)
+    assert torch.equal(cold[0], flagged_off[0]) and torch.equal(cold[1], flagged_off[1])
+
+
 def test_stochastic_transport_operator_vs_reference_golden(A):
     """eq. 19 of Freirich et al. (reference ot/w2_utils.py:391-458,732-786): the stochastic operator (T, Cw) for degenerate /
     nearly degenerate sources, diagonal and full (pseudo-inverse and the three functions of the target covariance from
