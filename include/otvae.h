@@ -393,6 +393,18 @@ int otvae_softmax_rows_bwd(int dtype, const void* y, const void* gy, int64_t row
 /* w2_gaussian tail (ot/w2_utils.py:78-80): out[nb] = |ms-mt|^2 + tr(cs + ct - 2*sqrt_mix) */
 int otvae_w2_tail(const double* ms, const double* mt, const double* cs, const double* ct, const double* sqrt_mix,
                   int nb, int D, double* out, void* stream);
+/* w2_gaussian (ot/w2_utils.py:40-80) and the non-stochastic full-matrix operator of eq. 17 (compute_transport_operators ->
+ * _compute_transport_full_mat, :756-769) of the same nb pairs of Gaussians in one call, from the spectra of the two covariances
+ * (lam_x[nb][D], vt_x[nb][D][D] with row k = eigenvector k, as otvae_eigh_fn(fn = 3) returns them), including the reference's
+ * 'spd' argument validation (:661-669: with make_pd a strictly positive shift |min(lambda_min, 0)| + 1e-8 on a side whose batch
+ * holds a matrix that is not positive definite).  w2[nb], T[nb][D][D] = (1 - pg_star) Cs^-1/2 (Cs^1/2 Ct Cs^1/2)^1/2 Cs^-1/2 + pg_star I.
+ * No host synchronisation inside: flags[3] (device ints) = {a source covariance is not positive definite, a target covariance is
+ * not, Ct^1/2 Cs Ct^1/2 is not symmetric} for the caller to turn into the reference's ValueErrors.  ws: otvae_w2_transport_ws(nb, D)
+ * bytes; eigh_ws: otvae_eigh_ws(2 * nb, D) bytes. */
+int64_t otvae_w2_transport_ws(int nb, int D);
+int otvae_w2_transport(const double* ms, const double* mt, const double* cs, const double* ct, const double* lam_s, const double* vt_s,
+                       const double* lam_t, const double* vt_t, int nb, int D, double pg_star, int make_pd, void* ws, void* eigh_ws,
+                       double* w2, double* T, int* flags, void* stream);
 /* apply_transport (ot/w2_utils.py:517-520): y[nb][B][D] = T[nb] (x - ms) + mt ; x dtype 0/1, y same dtype */
 int otvae_apply_transport(int dtype, const void* x, const double* ms, const double* mt, const double* T,
                           int nb, int B, int D, void* y, void* stream);

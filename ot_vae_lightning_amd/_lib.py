@@ -116,6 +116,8 @@ SIGNATURES = {
     "otvae_eigh_fn_warm": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "otvae_make_psd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "otvae_cholesky": (i32, [vp, i32, i32, vp, vp, vp]),
+    "otvae_w2_transport_ws": (i64, [i32, i32]),
+    "otvae_w2_transport": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp]),
     "otvae_gemm_f64": (i32, [i32, i32, i32, i32, i32, i32, f64, vp, i32, vp, i32, f64, vp, vp]),
     "otvae_gemm_f32": (i32, [i32, i32, i32, i32, i32, i32, f32, vp, i32, vp, i32, f32, vp, vp]),
     "otvae_softmax_rows": (i32, [i32, vp, i64, i32, f64, vp, vp]),

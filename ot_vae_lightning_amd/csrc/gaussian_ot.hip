@@ -979,6 +979,113 @@ extern "C" int otvae_w2_tail(const double* ms, const double* mt, const double* c
     return OTVAE_OK;
 }
 
+// ---- w2_gaussian + the eq. 17 operator of the same pair of Gaussians in one call -----------------------------------------------
+// (reference ot/w2_utils.py:40-80 and 756-769 with their 'spd' argument validation, :661-669).  Inputs: means, covariances and the
+// spectra (eigvals, Vt rows = eigenvectors) of both covariances.  Everything between the two rounds of eigendecompositions --
+// definiteness shifts, V f(lambda) V^T for three functions, the two inner products, the symmetry test, the tail, the operator --
+// runs here without a host read: the Python composition of the same steps was ~90 small launches and four synchronisations
+// (2.3 ms of a 6.5 ms call at D = 128).  flags[0..2] = {some source / target covariance is not positive definite, the inner
+// product is not symmetric}: read ONCE by the caller, who raises the reference's errors.
+__global__ __launch_bounds__(256) void w2t_shift_kernel(const double* __restrict__ lam_s, const double* __restrict__ lam_t, int nb, int D,
+                                                        int make_pd, double* __restrict__ shift, int* __restrict__ flags) {
+    __shared__ int s_bad[2];
+    if (threadIdx.x < 2) s_bad[threadIdx.x] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * nb; e += 256) {
+        const double* l = (e < nb ? lam_s : lam_t) + (size_t)(e % nb) * D;
+        double mn = INFINITY;
+        for (int k = 0; k < D; ++k) mn = fmin(mn, l[k]);
+        shift[e] = fabs(fmin(mn, 0.0)) + 1e-8;   // psd_shift(strict=True)
+        if (!(mn > 0.0)) s_bad[e < nb ? 0 : 1] = 1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * nb; e += 256)   // only_if_needed: no shift unless a matrix of that side's batch fails
+        if (!make_pd || !s_bad[e < nb ? 0 : 1]) shift[e] = 0.0;
+    if (threadIdx.x < 2) flags[threadIdx.x] = s_bad[threadIdx.x];
+    if (threadIdx.x == 2) flags[2] = 0;
+}
+
+__global__ __launch_bounds__(256) void w2t_prep_kernel(const double* __restrict__ cs, const double* __restrict__ ct,
+                                                       const double* __restrict__ lam_s, const double* __restrict__ vt_s,
+                                                       const double* __restrict__ lam_t, const double* __restrict__ vt_t, int nb, int D,
+                                                       const double* __restrict__ shift, double* __restrict__ cs_v, double* __restrict__ ct_v,
+                                                       double* __restrict__ f_rt, double* __restrict__ f_rs, double* __restrict__ f_irs) {
+    const size_t total = (size_t)nb * D * D;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int b = (int)(e / ((size_t)D * D));
+        const int r = (int)((e / D) % D), c = (int)(e % D);
+        const double ss = shift[b], st = shift[nb + b];
+        cs_v[e] = cs[e] + (r == c ? ss : 0.0);
+        ct_v[e] = ct[e] + (r == c ? st : 0.0);
+        const double ls = lam_s[(size_t)b * D + r] + ss, lt = lam_t[(size_t)b * D + r] + st;
+        f_rt[e] = sqrt(lt) * vt_t[e];
+        f_rs[e] = sqrt(ls) * vt_s[e];
+        f_irs[e] = vt_s[e] / sqrt(ls + 1e-8);   // (lambda + STABILITY_CONST)^-1/2
+    }
+}
+
+__global__ __launch_bounds__(256) void w2t_sym_kernel(const double* __restrict__ m, int D, int* __restrict__ flags) {
+    __shared__ double red[4];
+    const double* mb = m + (size_t)blockIdx.x * D * D;
+    double s = 0.0;
+    for (size_t e = threadIdx.x; e < (size_t)D * D; e += 256) {
+        const int r = (int)(e / D), c = (int)(e % D);
+        const double d = mb[e] - mb[(size_t)c * D + r];
+        s = fma(d, d, s);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && !(((red[0] + red[1]) + (red[2] + red[3])) < 1e-8)) flags[2] = 1;   // is_symmetric: sum (m - m^T)^2 < 1e-8
+}
+
+__global__ __launch_bounds__(256) void w2t_diag_add_kernel(double* __restrict__ T, int nb, int D, double v) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < nb * D) T[(size_t)(e / D) * D * D + (size_t)(e % D) * (D + 1)] += v;
+}
+
+extern "C" int64_t otvae_w2_transport_ws(int nb, int D) {
+    if (nb <= 0 || D <= 0) return -1;
+    // shifts | cs_v ct_v f_rt f_rs f_irs rt rs irs tmp | mixcat[2 nb] roots[2 nb] | eigenvalue scratch [2 nb][D]
+    return (int64_t)(2 * nb + 64) * 8 + (int64_t)13 * nb * D * D * 8 + (int64_t)2 * nb * D * 8;
+}
+
+extern "C" int otvae_w2_transport(const double* ms, const double* mt, const double* cs, const double* ct, const double* lam_s,
+                                  const double* vt_s, const double* lam_t, const double* vt_t, int nb, int D, double pg_star, int make_pd,
+                                  void* ws, void* eigh_ws, double* w2, double* T, int* flags, void* stream) {
+    OTVAE_REQUIRE(ms && mt && cs && ct && lam_s && vt_s && lam_t && vt_t && ws && eigh_ws && w2 && T && flags && nb > 0 && D > 0,
+                  "otvae_w2_transport: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t mat = (size_t)nb * D * D, one = (size_t)D * D;
+    double* shift = (double*)ws;
+    double* cs_v = shift + 2 * nb + 64;
+    double *ct_v = cs_v + mat, *f_rt = ct_v + mat, *f_rs = f_rt + mat, *f_irs = f_rs + mat, *rt = f_irs + mat, *rs = rt + mat,
+           *irs = rs + mat, *tmp = irs + mat, *mixcat = tmp + mat, *roots = mixcat + 2 * mat, *evs = roots + 2 * mat;
+    w2t_shift_kernel<<<1, 256, 0, st>>>(lam_s, lam_t, nb, D, make_pd, shift, flags);
+    w2t_prep_kernel<<<imin(cdiv(mat, 256), 2048), 256, 0, st>>>(cs, ct, lam_s, vt_s, lam_t, vt_t, nb, D, shift, cs_v, ct_v, f_rt, f_rs, f_irs);
+    OTVAE_CHECK_LAUNCH("otvae_w2_transport(prep)");
+    // V f(lambda) V^T = Vt^T (f Vt)
+    gemm_f64_launch(1, 0, nb, D, D, D, 1.0, vt_t, one, f_rt, one, 0.0, rt, st);
+    gemm_f64_launch(1, 0, nb, D, D, D, 1.0, vt_s, one, f_rs, one, 0.0, rs, st);
+    gemm_f64_launch(1, 0, nb, D, D, D, 1.0, vt_s, one, f_irs, one, 0.0, irs, st);
+    // mix = Ct^1/2 Cs Ct^1/2 (validated covariances); inner = Cs^1/2 Ct Cs^1/2 (Ct as given)
+    gemm_f64_launch(0, 0, nb, D, D, D, 1.0, rt, one, cs_v, one, 0.0, tmp, st);
+    gemm_f64_launch(0, 0, nb, D, D, D, 1.0, tmp, one, rt, one, 0.0, mixcat, st);
+    gemm_f64_launch(0, 0, nb, D, D, D, 1.0, rs, one, ct, one, 0.0, tmp, st);
+    gemm_f64_launch(0, 0, nb, D, D, D, 1.0, tmp, one, rs, one, 0.0, mixcat + mat, st);
+    w2t_sym_kernel<<<nb, 256, 0, st>>>(mixcat, D, flags);
+    OTVAE_CHECK_LAUNCH("otvae_w2_transport(products)");
+    int rc = otvae_eigh_fn(mixcat, 2 * nb, D, 1, roots, evs, eigh_ws, stream);   // both inner square roots side by side
+    if (rc) return rc;
+    w2_tail_kernel<<<nb, 256, 0, st>>>(ms, mt, cs_v, ct_v, roots, D, w2);
+    // T = (1 - pg) Cs^-1/2 inner^1/2 Cs^-1/2 + pg I
+    gemm_f64_launch(0, 0, nb, D, D, D, 1.0, irs, one, roots + mat, one, 0.0, tmp, st);
+    gemm_f64_launch(0, 0, nb, D, D, D, 1.0 - pg_star, tmp, one, irs, one, 0.0, T, st);
+    if (pg_star != 0.0) w2t_diag_add_kernel<<<cdiv((size_t)nb * D, 256), 256, 0, st>>>(T, nb, D, pg_star);
+    OTVAE_CHECK_LAUNCH("otvae_w2_transport(tail)");
+    return OTVAE_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void apply_transport_kernel(const T* __restrict__ x, const double* __restrict__ ms,
                                                               const double* __restrict__ mt, const double* __restrict__ Tm,

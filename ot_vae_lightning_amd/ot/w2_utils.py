@@ -363,39 +363,30 @@ def w2_and_transport_operator(mean_source: Tensor, mean_target: Tensor, spec_sou
     lib = _lib.load()
     (cs, lam_s, vt_s), (ct, lam_t, vt_t) = spec_source, spec_target
     lead, d = cs.shape[:-2], cs.shape[-1]
-    eye = eye_like(cs)
-
-    def validated(cov, lam, name):  # the 'spd' argument validation of both functions, from the known spectrum
-        if make_pd:
-            shift = psd_shift(lam, strict=True, only_if_needed=True)
-            return cov + shift[..., None, None] * eye, lam + shift[..., None]
-        if not bool((lam.min(-1)[0] > 0).all()):
-            raise ValueError(f"`{name}` should be symmetric and positive definite. Use `make_pd=True` to automatically add a "
-                             "small value to the matrix diagonals.")
-        return cov, lam
-
-    cs_v, lam_sv = validated(cs, lam_s, "cov_source")
-    ct_v, lam_tv = validated(ct, lam_t, "cov_target")
-    flat = lambda m: m.reshape(-1, d, d).contiguous()  # noqa: E731
-    # squared W2: |ms - mt|^2 + tr(Cs + Ct - 2 (Ct^1/2 Cs Ct^1/2)^1/2)
-    rt = flat(spectral_fn(lam_tv.sqrt(), vt_t))
-    mix = matmul64(matmul64(rt, flat(cs_v)), rt)
-    if not bool(is_symmetric(mix).all()):
-        raise ValueError("`cov_target_sqrt @ cov_source @ cov_target_sqrt` should be symmetric.")
-    # eq. 17: T = (1 - pg) Cs^-1/2 (Cs^1/2 Ct Cs^1/2)^1/2 Cs^-1/2 + pg I, with Ct as given (only Cs is validated there)
-    rs = flat(spectral_fn(lam_sv.sqrt(), vt_s))
-    irs = flat(spectral_fn((lam_sv + STABILITY_CONST).rsqrt(), vt_s))
-    inner_arg = matmul64(matmul64(rs, flat(ct)), rs)
-    # the two inner square roots do not depend on each other: one batched launch (a workgroup per matrix, side by side)
-    nbm = mix.shape[0]
-    roots = eigvals_and_fn(torch.cat([mix, inner_arg]), 1)[1]
-    sq, inner = roots[:nbm].contiguous(), roots[nbm:].contiguous()
+    f64c = lambda t, *shape: t.double().reshape(*shape).contiguous()  # noqa: E731
+    cs3, ct3 = f64c(cs, -1, d, d), f64c(ct, -1, d, d)
+    nb = cs3.shape[0]
     ms = mean_source.double().expand(*lead, d).reshape(-1, d).contiguous()
     mt = mean_target.double().expand(*lead, d).reshape(-1, d).contiguous()
-    w2 = torch.empty(ms.shape[0], device=ms.device, dtype=torch.float64)
-    check(lib.otvae_w2_tail(ptr(ms), ptr(mt), ptr(flat(cs_v)), ptr(flat(ct_v)), ptr(sq), ms.shape[0], d, ptr(w2), stream()),
-          "otvae_w2_tail")
-    T = (1 - pg_star) * matmul64(matmul64(irs, inner), irs) + pg_star * flat(eye)
+    dev = cs3.device
+    ws = torch.empty(lib.otvae_w2_transport_ws(nb, d), device=dev, dtype=torch.uint8)
+    ews = torch.empty(lib.otvae_eigh_ws(2 * nb, d), device=dev, dtype=torch.uint8)
+    w2 = torch.empty(nb, device=dev, dtype=torch.float64)
+    T = torch.empty((nb, d, d), device=dev, dtype=torch.float64)
+    flags = torch.empty(3, device=dev, dtype=torch.int32)
+    # one native call: shifts, V f(lambda) V^T x 3, the two inner products, their square roots (one batched decomposition), the
+    # tail and the operator -- no host read in between (the step-by-step composition was ~90 launches and four synchronisations)
+    check(lib.otvae_w2_transport(ptr(ms), ptr(mt), ptr(cs3), ptr(ct3), ptr(f64c(lam_s, -1, d)), ptr(f64c(vt_s, -1, d, d)),
+                                 ptr(f64c(lam_t, -1, d)), ptr(f64c(vt_t, -1, d, d)), nb, d, float(pg_star), int(bool(make_pd)),
+                                 ptr(ws), ptr(ews), ptr(w2), ptr(T), ptr(flags), stream()), "otvae_w2_transport")
+    bad_s, bad_t, asym = (int(v) for v in flags.tolist())   # the one host read: the reference's argument errors
+    if not make_pd:
+        for bad, name in ((bad_s, "cov_source"), (bad_t, "cov_target")):
+            if bad:
+                raise ValueError(f"`{name}` should be symmetric and positive definite. Use `make_pd=True` to automatically add a "
+                                 "small value to the matrix diagonals.")
+    if asym:
+        raise ValueError("`cov_target_sqrt @ cov_source @ cov_target_sqrt` should be symmetric.")
     T = T.reshape(*lead, d, d).to(dtype)
     return w2.reshape(lead), T, torch.zeros_like(T)
 
