@@ -313,46 +313,70 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
 
 // V = J_1 J_2 ... applied to the rows of the identity: a wave per row, its row (by position) in LDS, lane k replays slot k:
 // the same rotation and the same exchange of places as the columns of G underwent
-#define HJV_CHUNK 32  // steps of the rotation log staged in LDS at a time (32 KB): a step then costs an LDS round trip, not an L2 one
+#define HJV_CHUNK 32  // steps of the rotation log staged in LDS at a time (32 KB)
+// lane k of a wave holds the row's entries (2k, 2k + 1) in registers.  An even step rotates exactly such a pair: no communication.
+// An odd step rotates (2k + 1, 2k + 2): lane k needs the first entry of lane k + 1 for its new second entry, lane k + 1 the second
+// entry of lane k (and slot k's rotation) for its new first entry -- two whole-wave DPP shifts by one lane (gfx9 wave_shl1 /
+// wave_shr1), no LDS round trip: 0.28 -> ~0.1 ms per 128 x 128 decomposition against the version that kept the row in LDS.
+__device__ __forceinline__ double wave_take_next(double v) {  // lane k <- lane k + 1 (lane 63: 0)
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x130, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x130, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double wave_take_prev(double v) {  // lane k <- lane k - 1 (lane 0: 0)
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x138, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x138, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+
 __global__ __launch_bounds__(256) void hj_vectors_kernel(int D, void* __restrict__ ws, const double* __restrict__ Vin, const int* __restrict__ warm) {
     const double* __restrict__ Vinit = (Vin && (!warm || warm[0])) ? Vin : nullptr;
-    __shared__ double rows[4][130];
     __shared__ double2 slog[HJV_CHUNK][64];
     const int n = (D + 1) & ~1, half = n / 2;
     const HjWs w = hj_ws(ws, blockIdx.y, D);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wv;
-    double* row = rows[wv];
     // row i of V0: the identity, or component i of the caller's start vectors (Vinit[k][:] = vector of position k)
-    for (int k = lane; k < n; k += 64)
-        row[k] = Vinit ? ((k < D && i < D) ? Vinit[((size_t)blockIdx.y * D + k) * D + i] : ((k == i) ? 1.0 : 0.0)) : ((k == i) ? 1.0 : 0.0);
+    auto v0 = [&](int k) -> double {
+        if (k >= n) return 0.0;
+        if (Vinit && k < D && i < D) return Vinit[((size_t)blockIdx.y * D + k) * D + i];
+        return k == i ? 1.0 : 0.0;
+    };
+    double a = v0(2 * lane), b = v0(2 * lane + 1);
     const int steps = w.ctl->steps;
-    volatile double* vrow = row;  // the wave's own row: LDS operations of one wave execute in order, no workgroup barrier
+    const bool slot = lane < half;
     for (int st0 = 0; st0 < steps; st0 += HJV_CHUNK) {
-        __syncthreads();  // the previous chunk is consumed (first pass: the rows are initialised)
+        __syncthreads();  // the previous chunk is consumed
         const int cnt = min(HJV_CHUNK, steps - st0);
         for (int e = threadIdx.x; e < cnt * half; e += 256) slog[e / half][e % half] = w.log[(size_t)st0 * half + e];
         __syncthreads();
         for (int s_ = 0; s_ < cnt; ++s_) {
-            const int st = st0 + s_;
-            const int j = 2 * lane + (st & 1);  // n is even: the parity of the step within its sweep is the parity of st
-            if (lane < half && j + 1 < n) {
-                const double2 cur = slog[s_][lane];
-                const double vp = vrow[j], vq = vrow[j + 1];
-                vrow[j] = cur.y * vp + cur.x * vq;      // q' moves down
-                vrow[j + 1] = cur.x * vp - cur.y * vq;  // p' moves up
+            const double2 cur = slot ? slog[s_][lane] : make_double2(1.0, 0.0);
+            if (!((st0 + s_) & 1)) {  // pair (2k, 2k + 1): (p, q) = (a, b) -> q' moves down, p' moves up
+                if (slot) {
+                    const double na = cur.y * a + cur.x * b, nb2 = cur.x * a - cur.y * b;
+                    a = na;
+                    b = nb2;
+                }
+            } else {                  // pair (2k + 1, 2k + 2) = (b of lane k, a of lane k + 1), slots k < half - 1
+                const double an = wave_take_next(a), bp = wave_take_prev(b);
+                const double2 prv = (lane >= 1 && lane < half) ? slog[s_][lane - 1] : make_double2(1.0, 0.0);
+                const double nb2 = cur.y * b + cur.x * an;       // position 2k + 1 <- q' = s p + c q
+                const double na = prv.x * bp - prv.y * a;        // position 2k     <- p' = c p - s q of slot k - 1
+                if (lane < half - 1) b = nb2;
+                if (lane >= 1 && lane < half) a = na;
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
     }
-    __syncthreads();
-    if (i < D)
-        for (int k = lane; k < n; k += 64) {
-            const double v = row[k];
-            w.V[(size_t)i * n + k] = v;
-            w.W[(size_t)i * n + k] = v * w.G[(size_t)k * D + i];  // summed over i by hj_finish_kernel: lambda = v . g
-        }
+    if (i < D && slot) {
+        const int k0 = 2 * lane;
+        w.V[(size_t)i * n + k0] = a;
+        w.V[(size_t)i * n + k0 + 1] = b;
+        w.W[(size_t)i * n + k0] = a * w.G[(size_t)k0 * D + i];  // summed over i by hj_finish_kernel: lambda = v . g
+        w.W[(size_t)i * n + k0 + 1] = b * w.G[(size_t)(k0 + 1) * D + i];
+    }
 }
 
 // eigenvalues; fn 3: out[k][:] = v_k; fn 1 / 2: T[k][:] = f(lambda_k) v_k for the product out = V T.  Eigenpair k sits at position
