@@ -14,6 +14,26 @@ if os.environ.get("SKIP_WGRAD") == "1":  # lower bound of the launch stream's ch
         q[0].clear()
         q[1] = 0
     HF._PendingReduce.issue = staticmethod(_drop)
+if os.environ.get("EMPTY_FORKS") == "1":  # probe: keep the fork / join edges of the side stream but launch no weight-gradient job on it
+    from ot_vae_lightning_amd import functional as HF
+
+    def _empty(device, ev):
+        q = HF._PendingReduce._wq[device]
+        if not q[0]:
+            return
+        side = HF._PendingReduce.side_stream(device)
+        side.wait_event(ev)
+        if os.environ.get("TINY_SIDE") == "1":  # one trivial kernel per fork: the graph keeps its second branch
+            import ctypes as C
+            from ot_vae_lightning_amd import _lib as L
+            global _dummy
+            if "_dummy" not in globals():
+                _dummy = torch.zeros(1, dtype=torch.int32, device=device)
+            L.check(L.load().otvae_step_begin(L.ptr(_dummy), C.c_void_p(side.cuda_stream)), "otvae_step_begin")
+        q[0].clear()
+        q[1] = 0
+        HF._PendingReduce._forked[device] = True
+    HF._PendingReduce.issue = staticmethod(_empty)
 if os.environ.get("SKIP_RANGE"):  # drop the weight-gradient jobs of backward calls lo <= index < hi (timing probe only)
     from ot_vae_lightning_amd import functional as HF
     lo, hi = map(int, os.environ["SKIP_RANGE"].split(":"))
