@@ -642,6 +642,29 @@ def gen_stochastic():
     torch.manual_seed(32)
     noisy = w2.apply_transport(x, ms.unsqueeze(-2), mt.unsqueeze(-2), T.unsqueeze(-3), cw_used.unsqueeze(-3), diag=False, make_pd=True)
     out["full/x"], out["full/moved"], out["full/moved_noisy"], out["full/Cw_used"] = npy(x), npy(quiet), npy(noisy), npy(cw_used)
+    # well-conditioned FULL-RANK sources with stochastic=True (the common case: unit-scale target, source variances >= 1): Cw is
+    # analytically zero and comes out at rounding / 1e-8 size (negative in the diagonal case), which ``apply_transport`` must treat
+    # as "no noise" like the reference's allclose(Cw, 0) test (ot/w2_utils.py:507) -- the output is deterministic
+    cs = torch.rand(2, 6, generator=g, dtype=torch.double) + 1.0
+    ct = torch.rand(2, 6, generator=g, dtype=torch.double) * 0.5 + 0.3
+    T, Cw = w2.compute_transport_operators(cs.clone(), ct, stochastic=True, diag=True, pg_star=0.2, make_pd=True)
+    x = torch.randn(2, 9, 6, generator=g, dtype=torch.double)
+    moved = w2.apply_transport(x, ms.unsqueeze(-2), mt.unsqueeze(-2), T.unsqueeze(-2), Cw.unsqueeze(-2), diag=True)
+    out["wc_diag/cs"], out["wc_diag/ct"], out["wc_diag/T"], out["wc_diag/Cw"] = npy(cs), npy(ct), npy(T), npy(Cw)
+    out["wc_diag/x"], out["wc_diag/moved"] = npy(x), npy(moved)
+    a = torch.randn(2, d, d, generator=g, dtype=torch.double) / math.sqrt(d)
+    cs = a @ a.transpose(-1, -2) + 1.0 * torch.eye(d, dtype=torch.double)
+    b = torch.randn(2, d, d, generator=g, dtype=torch.double) / math.sqrt(d)
+    ct = 0.3 * (b @ b.transpose(-1, -2)) + 0.2 * torch.eye(d, dtype=torch.double)
+    T, Cw = w2.compute_transport_operators(cs, ct, stochastic=True, diag=False, pg_star=0.1, make_pd=True)
+    # full matrices: the 1e-8 regularisation of the swapped-role operator leaves Cw ~ 1.9e-8 I (positive definite, ABOVE allclose's
+    # 1e-8): the reference does draw noise of standard deviation ~1.4e-4 here, with and without make_pd
+    quiet = w2.apply_transport(x, ms.unsqueeze(-2), mt.unsqueeze(-2), T.unsqueeze(-3), torch.zeros_like(T).unsqueeze(-3), diag=False)
+    torch.manual_seed(33)
+    moved = w2.apply_transport(x, ms.unsqueeze(-2), mt.unsqueeze(-2), T.unsqueeze(-3), Cw.unsqueeze(-3), diag=False, make_pd=False)
+    out["wc_full/cs"], out["wc_full/ct"], out["wc_full/T"], out["wc_full/Cw"] = npy(cs), npy(ct), npy(T), npy(Cw)
+    out["wc_full/x"], out["wc_full/moved_quiet"], out["wc_full/moved"] = npy(x), npy(quiet), npy(moved)
+    out["wc/Cw_absmax"] = np.array([out["wc_diag/Cw"].__abs__().max(), out["wc_full/Cw"].__abs__().max()])
     save("stochastic.npz", out)
 
 

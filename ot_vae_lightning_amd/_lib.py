@@ -10,7 +10,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libotvae_hip.so")
+# OTVAE_LIB (a file name next to this module) selects another build of the same ABI: A/B timing of kernel variants on one box
+LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("OTVAE_LIB", "libotvae_hip.so")))
 
 _lock = threading.Lock()
 _lib = None

@@ -18,6 +18,8 @@ LIB = os.path.join(HERE, "libotvae_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result",
          "-munsafe-fp-atomics", "-DNDEBUG"]
+# per-source additions (none at present; attention.hip was tried with -fno-slp-vectorize, see its header)
+FILE_FLAGS = {}
 
 
 def _sources():
@@ -29,7 +31,7 @@ def _digest(path, headers):
     for p in [path] + headers:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + FILE_FLAGS.get(os.path.basename(path), [])).encode())
     return h.hexdigest()
 
 
@@ -40,7 +42,7 @@ def _compile(src, headers, force):
     dig = _digest(path, headers)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    cmd = ["hipcc", "-x", "hip", *FLAGS, "-c", path, "-o", obj]
+    cmd = ["hipcc", "-x", "hip", *FLAGS, *FILE_FLAGS.get(src, []), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

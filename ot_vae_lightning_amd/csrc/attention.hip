@@ -17,6 +17,16 @@
 #define LN2 0.6931471805599453f
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
 #define ATTN_LDS_FLOATS 16384  // 64 KiB dynamic LDS budget (the default limit: no function attribute needed)
+// OTVAE_ATTN_PACK=0 (compile time, together with -fno-slp-vectorize) spells the pair arithmetic as plain v_fma_f32 instead of
+// v_pk_fma_f32 over two queries.  Measured on the MI355X at 4 waves per SIMD (profiles/r03_attn_ab.txt): plain is 19-29 % SLOWER
+// (C = 1: 153 -> 182 / 154 -> 198 us, C = 2 backward 77 -> 100 us) -- a v_fma_f32 costs ~3.7 issue cycles there, a v_pk_fma_f32
+// ~5.8 for two FMAs; the cycle table's 2-cycle v_fma_f32 was not reproduced in these loops.  Packed stays the default.
+#ifndef OTVAE_ATTN_PACK
+#define OTVAE_ATTN_PACK 1
+#endif
+// largest distance (log2 units) between the Cauchy-Schwarz bound |q| max|k| and the smallest possible row maximum for which
+// the forward pass skips its row-maximum pass over the keys: every p = 2^(score - bound) then lies in [2^-64, 1]
+#define ATTN_BOUND_GAP 64.0f
 
 template <int C>
 __device__ __forceinline__ float dotc(const float (&a)[C], const float* __restrict__ b) {
@@ -47,19 +57,36 @@ __device__ __forceinline__ void stage_kv(float* __restrict__ sm, const float* __
     const int per = T * 2 * C;
     const float inv_per = 1.0f / (float)per, inv_h = 1.0f / (float)H;
     const int n0 = (int)(slice0 / H), h0 = (int)(slice0 - (long)n0 * H);  // once per block
-    for (int e = threadIdx.x; e < nsl * per; e += 256) {
-        const int sl = adiv(e, per, inv_per), r = e - sl * per;
-        const int t = r / (2 * C), j = r - t * 2 * C;  // compile-time divisor
-        const int which = j / C, c = j - which * C;
-        const int hs = h0 + sl;                          // < H + slices per block
-        const int dn = adiv(hs, H, inv_h);
-        const long n = n0 + dn;
-        const int h = hs - dn * H;
-        sm[STRIDE == 2 * C ? e : (sl * T + t) * STRIDE + j] = qkv[(n * T + t) * W3 + (1 + which) * HC + h * C + c];
+    // four elements per thread and trip, the loads issued together (a trip per element exposed one global round trip each:
+    // 16 dependent trips at T = 256, C = 2 -- a fifth of the backward kernel's time)
+    const int total = nsl * per, NT = blockDim.x;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * NT) {
+        float val[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * NT;
+            dst[u] = -1;
+            val[u] = 0.f;
+            if (e < total) {
+                const int sl = adiv(e, per, inv_per), r = e - sl * per;
+                const int t = r / (2 * C), j = r - t * 2 * C;  // compile-time divisor
+                const int which = j / C, c = j - which * C;
+                const int hs = h0 + sl;                          // < H + slices per block
+                const int dn = adiv(hs, H, inv_h);
+                const long n = n0 + dn;
+                const int h = hs - dn * H;
+                dst[u] = STRIDE == 2 * C ? e : (sl * T + t) * STRIDE + j;
+                val[u] = qkv[(n * T + t) * W3 + (1 + which) * HC + h * C + c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) sm[dst[u]] = val[u];
     }
 }
 
-// Combine one value per lane over the TPS consecutive lanes of a slice (OP 0 sum, 1 max, 2 min).  All 256 threads of the
+// Combine one value per lane over the TPS consecutive lanes of a slice (OP 0 sum, 1 max, 2 min).  All threads of the
 // block call it together; TPS must be a multiple of 64 or a power of two below 64 (slice_reduce_ok).
 __device__ __forceinline__ bool slice_reduce_ok(int TPS) { return TPS % 64 == 0 || (TPS < 64 && (TPS & (TPS - 1)) == 0); }
 template <int OP>
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     // shifted-data covariance; kmax / kmin (C == 1) = the extreme keys, which give the row maxima in closed form.
     __shared__ float red[4];
     const bool fast = slice_reduce_ok(TPS);
-    float vbar[C], kmax = -INFINITY, kmin = INFINITY;
+    float vbar[C], kmax = -INFINITY, kmin = INFINITY, knorm = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) vbar[c] = 0.f;
     if (fast) {
@@ -149,8 +176,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             if constexpr (C == 1) {
                 kmax = fmaxf(kmax, r[0]);
                 kmin = fminf(kmin, r[0]);
+            } else {
+                float s2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) s2 = fmaf(r[c], r[c], s2);
+                knorm = fmaxf(knorm, s2);
             }
         }
+        if constexpr (C > 1) knorm = __builtin_sqrtf(slice_reduce<1>(knorm, TPS, red));
         if constexpr (AUX) {
 #pragma unroll
             for (int c = 0; c < C; ++c) vbar[c] = slice_reduce<0>(vbar[c], TPS, red);
@@ -205,16 +238,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     // scores of two queries at a time as one packed FMA (the compiler does not pair them by itself: it folds the
     // subtraction of the maximum into a source-negation modifier, which v_pk_fma_f32 would have to apply to both halves)
     typedef float f2 __attribute__((ext_vector_type(2)));
-    constexpr int QP = QPT / 2;
+    constexpr int QP = OTVAE_ATTN_PACK ? QPT / 2 : 0;
     f2 q2[QP > 0 ? QP : 1][C], nm2[QP > 0 ? QP : 1];
 #pragma unroll
     for (int j = 0; j < QP; ++j)
 #pragma unroll
         for (int c = 0; c < C; ++c) q2[j][c] = (f2){q[2 * j][c], q[2 * j + 1][c]};
+    // C >= 2: |q . k| <= |q| max_s |k_s|.  When twice that bound stays below ATTN_BOUND_GAP for every query of the wave the bound
+    // itself serves as the row "maximum" (any m >= max_s score with sum_s 2^(score - m) > 0 gives the same softmax and the same
+    // LSE) and the pass over the keys that computes the exact one is skipped
+    bool bounded = false;
+    if constexpr (C > 1) {
+        if (fast) {
+            float qn2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) s2 = fmaf(q[i][c], q[i][c], s2);
+                mx[i] = __builtin_sqrtf(s2) * knorm * 1.0001f;
+                qn2 = fmaxf(qn2, mx[i]);
+            }
+            bounded = __all(2.f * qn2 < ATTN_BOUND_GAP);
+        }
+    }
     if constexpr (C == 1) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) mx[i] = fmaxf(q[i][0] * kmax, q[i][0] * kmin);
+    } else if (bounded) {
+        // mx holds the bound
     } else if constexpr (QP > 0) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) mx[i] = -INFINITY;
 #pragma unroll 2
         for (int s = 0; s < T; ++s) {
             const float* r = kv + s * KVS;
@@ -228,6 +283,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             }
         }
     } else {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) mx[i] = -INFINITY;
+#pragma unroll 2
         for (int s = 0; s < T; ++s) {
             const float* r = kv + s * KVS;
 #pragma unroll
@@ -260,10 +318,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                 scs[2 * j + 1] = sc.y;
             }
         } else {
-            float sc = -mx[0];
 #pragma unroll
-            for (int c = 0; c < C; ++c) sc = fmaf(q[0][c], kk[c], sc);
-            scs[0] = sc;
+            for (int i = 0; i < QPT; ++i) {
+                float sc = -mx[i];
+#pragma unroll
+                for (int c = 0; c < C; ++c) sc = fmaf(q[i][c], kk[c], sc);
+                scs[i] = sc;
+            }
         }
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -316,7 +377,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     // query records {q/C, gout, lse, delta = sum_c gout*out}
     const float inv_t = 1.0f / (float)T, inv_hq = 1.0f / (float)H;
     const int qn0 = (int)(slice0 / H), qh0 = (int)(slice0 - (long)qn0 * H);
-    for (int it = threadIdx.x; it < nsl * T; it += 256) {
+#pragma unroll 2
+    for (int it = threadIdx.x; it < nsl * T; it += blockDim.x) {
         const int sl = adiv(it, T, inv_t), t = it - sl * T;
         const int hs = qh0 + sl;
         const int dn = adiv(hs, H, inv_hq);
@@ -371,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 dqv[i][c] = s * inv_c;
             }
         }
-    } else if constexpr (QPT % 2 == 0) {
+    } else if constexpr (OTVAE_ATTN_PACK && QPT % 2 == 0) {
         // two queries at a time in packed registers (as the forward pass and phase B)
         typedef float f2 __attribute__((ext_vector_type(2)));
         constexpr int QP = QPT / 2;
@@ -462,7 +524,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     // ---- phase B: this lane's QPT keys against every query -> dK, dV.  Two keys at a time in packed registers (spelled
     // out: left to itself the compiler folds the "- lse" / "- delta" into source-negation modifiers of scalar FMAs and
     // packs only the accumulations)
-    if constexpr (QPT % 2 == 0) {
+    if constexpr (OTVAE_ATTN_PACK && QPT % 2 == 0) {
         typedef float f2 __attribute__((ext_vector_type(2)));
         constexpr int QP = QPT / 2;
         f2 k2[QP][C], v2[QP][C], dk2[QP][C], dv2[QP][C];
@@ -578,6 +640,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 }
             }
         }
+        if constexpr (C == 1 && QPT == 4) {
+            // one head of one channel, the whole workgroup on one image (T = 1024): see the packed branch above
+            if (H == 1 && T == 1024 && (reinterpret_cast<uintptr_t>(gqkv) & 15) == 0) {
+                __syncthreads();  // every wave is done with the key / query records
+                float* w = sm + (threadIdx.x >> 6) * (64 * 12);
+                float4* wl = reinterpret_cast<float4*>(w + (threadIdx.x & 63) * 12);
+                wl[0] = make_float4(dqv[0][0], dk[0][0], dv[0][0], dqv[1][0]);
+                wl[1] = make_float4(dk[1][0], dv[1][0], dqv[2][0], dk[2][0]);
+                wl[2] = make_float4(dv[2][0], dqv[3][0], dk[3][0], dv[3][0]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float4* o = reinterpret_cast<float4*>(gqkv + (n * T + (t0 - (int)(threadIdx.x & 63) * 4)) * 3);
+                const float4* r4 = reinterpret_cast<const float4*>(w);
+#pragma unroll
+                for (int k4 = 0; k4 < 3; ++k4) o[k4 * 64 + (threadIdx.x & 63)] = r4[k4 * 64 + (threadIdx.x & 63)];
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             float* o = gqkv + (n * T + t0 + i) * W3 + h * C;
@@ -617,15 +698,20 @@ __global__ __launch_bounds__(256) void attn_t1_bwd_kernel(const float* __restric
     gqkv[i] = j >= 2 * HC ? gout[(size_t)n * HC + j - 2 * HC] : 0.f;
 }
 
-// slices per block: as many as 256 threads cover (T/QPT threads each) and as the LDS budget holds
+// slices per block: as many as 256 threads cover (T/QPT threads each) and as the LDS budget holds; OTVAE_ATTN_SPB (A/B switch,
+// read once) caps it -- smaller workgroups of whole waves
 static int pick_qpt(int T, int C) { return (T >= 256 && T % 4 == 0 && C <= 4) ? 4 : 1; }
 static int pick_spb(int T, int qpt, int floats_per_key) {
+    static const int cap_env = getenv("OTVAE_ATTN_SPB") ? atoi(getenv("OTVAE_ATTN_SPB")) : 0;
     int tps = T / qpt;
     int spb = 256 / tps;
     int cap = ATTN_LDS_FLOATS / (T * floats_per_key);
     if (spb > cap) spb = cap;
+    if (cap_env > 0 && spb > cap_env && (cap_env * tps) % 64 == 0) spb = cap_env;
     return spb;
 }
+// threads of a block: its slices' lanes, in whole waves
+static int attn_threads(int spb, int T, int qpt) { return imax(64, (spb * (T / qpt) + 63) / 64 * 64); }
 
 #define ATTN_C_SWITCH(C_, MACRO)                                                                              \
     switch (C_) {                                                                                             \
@@ -680,21 +766,21 @@ extern "C" int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int 
     int rc = attn_check("otvae_attn_fwd", N, T, H, C, rkv, &qpt, &spb);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = cdiv((int64_t)N * H, spb);
+    const int grid = cdiv((int64_t)N * H, spb), nthr = attn_threads(spb, T, qpt);
     const size_t lds = (size_t)spb * T * rkv * sizeof(float);
 #define FWD_K(CC)                                                                                   \
     do {                                                                                            \
         if (qpt == 4) {                                                                             \
             if constexpr (CC <= 2) {                                                                \
-                if (aux) attn_fwd_kernel<CC, 4, true><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, aux, scale); \
-                else attn_fwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
-            } else if constexpr (CC <= 4) attn_fwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
+                if (aux) attn_fwd_kernel<CC, 4, true><<<grid, nthr, lds, st>>>(qkv, N, T, H, spb, out, lse, aux, scale); \
+                else attn_fwd_kernel<CC, 4, false><<<grid, nthr, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
+            } else if constexpr (CC <= 4) attn_fwd_kernel<CC, 4, false><<<grid, nthr, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
             else { otvae_set_error("otvae_attn_fwd: T >= 256 with head width %d > 4 unsupported", CC); return OTVAE_EUNSUPPORTED; } \
         } else {                                                                                    \
             if constexpr (CC <= 2) {                                                                \
-                if (aux) attn_fwd_kernel<CC, 1, true><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, aux, scale); \
-                else attn_fwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
-            } else attn_fwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
+                if (aux) attn_fwd_kernel<CC, 1, true><<<grid, nthr, lds, st>>>(qkv, N, T, H, spb, out, lse, aux, scale); \
+                else attn_fwd_kernel<CC, 1, false><<<grid, nthr, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
+            } else attn_fwd_kernel<CC, 1, false><<<grid, nthr, lds, st>>>(qkv, N, T, H, spb, out, lse, nullptr, scale); \
         }                                                                                           \
     } while (0)
     ATTN_C_SWITCH(C, FWD_K)
@@ -725,21 +811,21 @@ extern "C" int otvae_attn_bwd_scaled(const float* qkv, const float* out, const f
     int rc = attn_check("otvae_attn_bwd", N, T, H, C, 2 * C + rqg, &qpt, &spb);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = cdiv((int64_t)N * H, spb);
+    const int grid = cdiv((int64_t)N * H, spb), nthr = attn_threads(spb, T, qpt);
     const size_t lds = (size_t)spb * T * (2 * C + rqg) * sizeof(float);
 #define BWD_K(CC)                                                                                   \
     do {                                                                                            \
         if (qpt == 4) {                                                                             \
             if constexpr (CC <= 2) {                                                                \
-                if (aux) attn_bwd_kernel<CC, 4, true><<<grid, 256, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv, scale); \
-                else attn_bwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
-            } else if constexpr (CC <= 4) attn_bwd_kernel<CC, 4, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
+                if (aux) attn_bwd_kernel<CC, 4, true><<<grid, nthr, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv, scale); \
+                else attn_bwd_kernel<CC, 4, false><<<grid, nthr, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
+            } else if constexpr (CC <= 4) attn_bwd_kernel<CC, 4, false><<<grid, nthr, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
             else { otvae_set_error("otvae_attn_bwd: T >= 256 with head width %d > 4 unsupported", CC); return OTVAE_EUNSUPPORTED; } \
         } else {                                                                                    \
             if constexpr (CC <= 2) {                                                                \
-                if (aux) attn_bwd_kernel<CC, 1, true><<<grid, 256, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv, scale); \
-                else attn_bwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
-            } else attn_bwd_kernel<CC, 1, false><<<grid, 256, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
+                if (aux) attn_bwd_kernel<CC, 1, true><<<grid, nthr, lds, st>>>(qkv, out, lse, gout, aux, N, T, H, spb, gqkv, scale); \
+                else attn_bwd_kernel<CC, 1, false><<<grid, nthr, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
+            } else attn_bwd_kernel<CC, 1, false><<<grid, nthr, lds, st>>>(qkv, out, lse, gout, nullptr, N, T, H, spb, gqkv, scale); \
         }                                                                                           \
     } while (0)
     ATTN_C_SWITCH(C, BWD_K)

@@ -17,7 +17,12 @@
 //   * eigenvalues are lambda_k = v_k . g_k (signed: indefinite and singular matrices are fine), f(A) = V f(Lambda) V^T is
 //     one product.  A matrix with a negative diagonal entry (certainly indefinite) is solved as A + |A|_inf I and the shift
 //     taken off the eigenvalues: one-sided Jacobi sees A^2, in which +lambda and -lambda of equal size are a double eigenvalue.
-// Arithmetic is fp64 throughout; the iteration ends after the first sweep without a rotation.
+//     An indefinite matrix whose diagonal is non-negative (A = [[0,1],[1,0]], a bipartite adjacency matrix) is caught AFTER the
+//     iteration: within such a +-lambda pair the columns of G are orthogonal for ANY rotation of the two eigenvectors, so the
+//     iteration may stop at mixtures v with |v . A v| < |A v|.  hj_finish_kernel tests every pair for |v_k . g_k| = |g_k| and,
+//     when one fails, the three kernels run a second time on A + |A|_inf I (pass 1; they return at once otherwise).
+// Arithmetic is fp64 throughout; the iteration ends after the first sweep without a rotation.  A matrix that is still rotating
+// after HJ_MAX_SWEEPS sweeps gets NaN eigenvalues (loud, like a starved Sinkhorn solve) instead of an unconverged answer.
 #include <type_traits>
 #include "common.h"
 
@@ -39,7 +44,9 @@ int cholesky_blocked(const double* A, int nb, int D, double* L, size_t ls, int* 
 struct HjCtl {
     int steps;   // steps whose rotations are in the log
     int sweeps;
-    double shift;  // added to the diagonal before the iteration (0 unless some diagonal entry was negative)
+    double shift;  // added to the diagonal before the iteration (0 unless some diagonal entry was negative, or pass 1)
+    int redo;         // written by hj_finish_kernel (pass 0): an eigenpair failed |v . g| = |g|: pass 1 runs on the shifted matrix
+    int unconverged;  // the last sweep of the budget still rotated above the stop level
 };
 
 static __host__ __device__ inline size_t hj_per_matrix(int D) {
@@ -121,8 +128,10 @@ __device__ __forceinline__ double nr_rsq(double x) {
 // one workgroup of 512 threads per matrix: L lanes per pair slot (8 for D > 64: 64 slots; 16 below), rows strided by L
 template <int L>
 __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict__ Ain, int D, void* __restrict__ ws,
-                                                        const double* __restrict__ G0in, const int* __restrict__ warm) {
-    const double* __restrict__ G0 = (G0in && (!warm || warm[0])) ? G0in : nullptr;  // the start basis counts only once the caller's flag says it holds one
+                                                        const double* __restrict__ G0in, const int* __restrict__ warm, int pass) {
+    if (pass == 1 && hj_ws(ws, blockIdx.x, D).ctl->redo == 0) return;  // uniform over the workgroup
+    // the start basis counts only once the caller's flag says it holds one; the second pass starts cold on the shifted matrix
+    const double* __restrict__ G0 = (pass == 0 && G0in && (!warm || warm[0])) ? G0in : nullptr;
     extern __shared__ __align__(16) double hj_lds[];
     __shared__ int s_rot;
     __shared__ double s_red[8], s_shift;
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
         if (tid == 0) {
             double r8 = s_red[0];
             for (int q8 = 1; q8 < 8; ++q8) r8 = fmax(r8, s_red[q8]);
-            s_shift = m8 < 0.0 ? r8 : 0.0;
+            s_shift = (m8 < 0.0 || pass == 1) ? r8 : 0.0;
         }
         __syncthreads();
         const double sh = s_shift;
@@ -277,6 +286,7 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
         __syncthreads();
         ++gstep;
     };
+    bool quiet = false;
     for (; sweep < HJ_MAX_SWEEPS; ++sweep) {
         recount_norms();
         for (int t = 0; t < n; t += 2) {
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
         __syncthreads();
         if (!rotated) {
             ++sweep;
+            quiet = true;
             break;
         }
         if (tid == 0) s_rot = 0;
@@ -308,6 +319,8 @@ __global__ __launch_bounds__(512) void hj_sweep_kernel(const double* __restrict_
         w.ctl->steps = gstep;
         w.ctl->sweeps = sweep;
         w.ctl->shift = s_shift;
+        w.ctl->unconverged = quiet ? 0 : 1;
+        if (pass == 0) w.ctl->redo = 0;
     }
 }
 
@@ -331,8 +344,10 @@ __device__ __forceinline__ double wave_take_prev(double v) {  // lane k <- lane 
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
 }
 
-__global__ __launch_bounds__(256) void hj_vectors_kernel(int D, void* __restrict__ ws, const double* __restrict__ Vin, const int* __restrict__ warm) {
-    const double* __restrict__ Vinit = (Vin && (!warm || warm[0])) ? Vin : nullptr;
+__global__ __launch_bounds__(256) void hj_vectors_kernel(int D, void* __restrict__ ws, const double* __restrict__ Vin, const int* __restrict__ warm,
+                                                         int pass) {
+    if (pass == 1 && hj_ws(ws, blockIdx.y, D).ctl->redo == 0) return;
+    const double* __restrict__ Vinit = (pass == 0 && Vin && (!warm || warm[0])) ? Vin : nullptr;
     __shared__ double2 slog[HJV_CHUNK][64];
     const int n = (D + 1) & ~1, half = n / 2;
     const HjWs w = hj_ws(ws, blockIdx.y, D);
@@ -382,11 +397,14 @@ __global__ __launch_bounds__(256) void hj_vectors_kernel(int D, void* __restrict
 // eigenvalues; fn 3: out[k][:] = v_k; fn 1 / 2: T[k][:] = f(lambda_k) v_k for the product out = V T.  Eigenpair k sits at position
 // k, or k + 1 when D is odd and the zero dummy column has ended at position 0 (every sweep reverses the order of the positions)
 __global__ __launch_bounds__(256) void hj_finish_kernel(int D, int fn, void* __restrict__ ws, double* __restrict__ eigvals,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ out, int pass) {
     __shared__ double lam[128];
     __shared__ double s_max[4];
+    __shared__ int s_bad;
     const int n = (D + 1) & ~1;
     const HjWs w = hj_ws(ws, blockIdx.x, D);
+    if (pass == 1 && w.ctl->redo == 0) return;
+    if (threadIdx.x == 0) s_bad = 0;
     const int off = ((D & 1) && (w.ctl->sweeps & 1)) ? 1 : 0;
     // lambda_k = +-|g_k|: at convergence the column g_k = lambda_k v_k, and its norm carries the eigenvalue with RELATIVE
     // accuracy, which v_k . g_k (absolute accuracy eps |A|) does not -- for a covariance with condition 1e17 the dot product of
@@ -409,12 +427,19 @@ __global__ __launch_bounds__(256) void hj_finish_kernel(int D, int fn, void* __r
     __syncthreads();
     const double lmax = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
     const double noise = 64.0 * D * 2.220446049250313e-16 * lmax;
+    const double shift = w.ctl->shift;
+    const bool unconverged = w.ctl->unconverged != 0;
     for (int k = threadIdx.x; k < D; k += 256) {
-        const double v = (lam[k] < -noise ? -w.T[k] : w.T[k]) - w.ctl->shift;
+        // an eigenpair satisfies |v . g| = |g|; a mixture inside a +-lambda pair (equal columns norms in G, i.e. a double
+        // eigenvalue of A^2) does not.  Testable where the dot product's absolute noise is below 1e-6 of the norm; only unshifted
+        // runs can hold such pairs (the shifted spectrum is non-negative)
+        if (pass == 0 && shift == 0.0 && w.T[k] > 1e6 * noise && fabs(lam[k]) < (1.0 - 1e-6) * w.T[k]) s_bad = 1;
+        const double v = (lam[k] < -noise ? -w.T[k] : w.T[k]) - shift;
         lam[k] = v;
-        eigvals[(size_t)blockIdx.x * D + k] = v;
+        eigvals[(size_t)blockIdx.x * D + k] = unconverged ? __longlong_as_double(0x7ff8000000000000LL) : v;
     }
     __syncthreads();
+    if (pass == 0 && threadIdx.x == 0) w.ctl->redo = s_bad;
     if (fn == 0) return;
     double* dst = fn == 3 ? out + (size_t)blockIdx.x * D * D : w.T;
     for (int e = threadIdx.x; e < D * D; e += 256) {
@@ -462,15 +487,17 @@ int eigh_onesided(const double* A, int nb, int D, int fn, double* out, double* e
         gemm_f64_launch(0, 0, nb, D, D, D, 1.0, Vinit, (size_t)D * D, A, (size_t)D * D, 0.0, g0, st);
         G0 = g0;
     }
-    if (D > 64)
-        hj_sweep_kernel<8><<<nb, 512, lds, st>>>(A, D, ws, G0, warm);
-    else
-        hj_sweep_kernel<16><<<nb, 512, lds, st>>>(A, D, ws, G0, warm);
-    OTVAE_CHECK_LAUNCH("otvae_eigh_fn(sweeps)");
-    hj_vectors_kernel<<<dim3(cdiv(D, 4), nb), 256, 0, st>>>(D, ws, Vinit, warm);
-    OTVAE_CHECK_LAUNCH("otvae_eigh_fn(vectors)");
-    hj_finish_kernel<<<nb, 256, 0, st>>>(D, fn, ws, eigvals, out);
-    OTVAE_CHECK_LAUNCH("otvae_eigh_fn(finish)");
+    for (int pass = 0; pass < 2; ++pass) {  // pass 1: no-ops unless pass 0 met a +-lambda pair (see the header)
+        if (D > 64)
+            hj_sweep_kernel<8><<<nb, 512, lds, st>>>(A, D, ws, G0, warm, pass);
+        else
+            hj_sweep_kernel<16><<<nb, 512, lds, st>>>(A, D, ws, G0, warm, pass);
+        OTVAE_CHECK_LAUNCH("otvae_eigh_fn(sweeps)");
+        hj_vectors_kernel<<<dim3(cdiv(D, 4), nb), 256, 0, st>>>(D, ws, Vinit, warm, pass);
+        OTVAE_CHECK_LAUNCH("otvae_eigh_fn(vectors)");
+        hj_finish_kernel<<<nb, 256, 0, st>>>(D, fn, ws, eigvals, out, pass);
+        OTVAE_CHECK_LAUNCH("otvae_eigh_fn(finish)");
+    }
     if (fn == 1 || fn == 2) {
         hj_product_kernel<<<dim3(cdiv(D, 16), cdiv(D, 16), nb), 256, 0, st>>>(D, ws, out);
         OTVAE_CHECK_LAUNCH("otvae_eigh_fn(product)");
@@ -1024,7 +1051,17 @@ __global__ __launch_bounds__(256) void hjb_finish_kernel(int D, int fn, void* __
     __syncthreads();
     const double noise = s_noise;
     const bool chol = w.ctl->chol_info == 0;
-    auto lam = [&](int k) { return chol ? w.nrm[k] * w.nrm[k] : (w.dot[k] < -noise ? -w.nrm[k] : w.nrm[k]); };
+    // the columns of an indefinite A were iterated unshifted: a +-lambda pair of equal size is a double eigenvalue of A^2 and the
+    // iteration may have stopped at a mixture of its two eigenvectors (|v . g| < |g|, see the header of this file).  The small
+    // solver repeats such a matrix on A + |A|_inf I; here (a hundred launches per sweep) the matrix gets NaN eigenvalues instead
+    // of a silently wrong answer.  Covariances -- what this path exists for -- are never indefinite beyond rounding.
+    int bad = 0;
+    if (!chol)
+        for (int k = threadIdx.x; k < D; k += 256)
+            if (w.nrm[k] > 1e6 * noise && fabs(w.dot[k]) < (1.0 - 1e-6) * w.nrm[k]) bad = 1;
+    bad = __syncthreads_or(bad);
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    auto lam = [&](int k) { return bad ? qnan : chol ? w.nrm[k] * w.nrm[k] : (w.dot[k] < -noise ? -w.nrm[k] : w.nrm[k]); };
     if (blockIdx.x == 0)
         for (int k = threadIdx.x; k < D; k += 256) eigvals[(size_t)blockIdx.y * D + k] = lam(k);
     if (fn == 0) return;

@@ -419,7 +419,9 @@ def apply_transport(input: Tensor, mean_source: Tensor, mean_target: Tensor, T: 
     """T (x - mean_source) + mean_target (+ W, W ~ N(0, Cw), when a non-zero noise covariance comes with a stochastic operator),
     computed in fp64; returns ``dtype``.  input [*, B, D] against [*, D]/[*, D, D] operators (already unsqueezed by the caller
     like the reference) or matching shapes."""
-    if Cw is not None and bool((Cw != 0).any()):
+    # the reference's test is torch.allclose(Cw, 0) (ot/w2_utils.py:507): entries up to 1e-8 count as "no noise" -- a stochastic
+    # operator of a full-rank source carries a Cw of that size (rounding + the 1e-8 regularisation) and is applied without it
+    if Cw is not None and bool((~(Cw.abs() <= 1e-8)).any()):
         moved = apply_transport(input, mean_source, mean_target, T, None, diag, make_pd, verbose, dtype)
         return moved + _transport_noise(moved.shape, Cw, diag, make_pd, noise_eps, dtype)
     if diag:

@@ -765,3 +765,10 @@ def test_stochastic_transport_operator_vs_reference():
     assert rel_err(T, d_["T"]) < 1e-12 and rel_err(Cw, d_["Cw"]) < 1e-10
     T, Cw = O.transport_operator_stochastic(f_["cs"], f_["ct"], 0.1, diag=False)
     assert rel_err(T, f_["T"]) < 1e-8 and rel_err(Cw, f_["Cw"]) < 1e-7
+    # well-conditioned full-rank sources: Cw is rounding / regularisation-sized (diag: negative, <= 1e-8; full: ~1.9e-8 I)
+    wd, wf = group(G, "wc_diag"), group(G, "wc_full")
+    T, Cw = O.transport_operator_stochastic(wd["cs"], wd["ct"], 0.2, diag=True)
+    assert rel_err(T, wd["T"]) < 1e-12 and (Cw - wd["Cw"]).abs().max() < 1e-14 and Cw.abs().max() <= 1e-8
+    T, Cw = O.transport_operator_stochastic(wf["cs"], wf["ct"], 0.1, diag=False)
+    assert rel_err(T, wf["T"]) < 1e-10 and (Cw - wf["Cw"]).abs().max() < 2e-10
+    assert torch.linalg.eigvalsh(wf["Cw"]).min() > 1e-8

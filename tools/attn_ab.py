@@ -21,5 +21,11 @@ def run(n, t, heads, c, tag):
         for _ in range(5): gr.replay()
         e1.record(); torch.cuda.synchronize()
         print(tag, name, (n, t, heads, c), "%.1f us" % (e0.elapsed_time(e1) / 100 * 1e3), flush=True)
-run(1024, 1024, 1, 1, "mnist dec L4")
-run(1024, 256, 4, 2, "mnist enc L0 / dec L3")
+tag = os.environ.get("OTVAE_LIB", "default")
+run(1024, 1024, 1, 1, tag + " mnist dec L4")
+run(1024, 256, 4, 2, tag + " mnist enc L0 / dec L3")
+run(1024, 64, 4, 4, tag + " mnist enc L1 / dec L2")
+run(1024, 16, 8, 4, tag + " mnist enc L2 / dec L1")
+run(1024, 4, 8, 8, tag + " mnist enc L3 / dec L0")
+run(256, 256, 4, 4, tag + " cifar enc L0")
+run(256, 1024, 3, 1, tag + " cifar dec L4")
