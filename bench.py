@@ -103,6 +103,30 @@ def time_eager_route(A, workload, pool, steps=20, warmup=5):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def time_lightning_route(A, workload, pool, steps=30, warmup=8):
+    """The reference's own loop shape -- ``training_step`` -> ``loss.backward()`` -> a stock ``torch.optim.Adam`` (model/base.py:
+    122-129, model/vae.py:148-156) -- with ``model.enable_graphed_step()``: nelbo is one autograd node that replays a captured
+    forward graph and a captured backward graph (engine/graphed.py); the optimizer is torch's, untouched."""
+    model = build_model(A, seed=1, workload=workload).cuda().train().enable_graphed_step()
+    opt = torch.optim.Adam(model.optim_parameters(), lr=1e-3, betas=(0.9, 0.999))
+    labels = torch.zeros(pool[0].shape[0], dtype=torch.long, device="cuda")
+
+    def step(i):
+        opt.zero_grad()
+        out = model.training_step((pool[i % len(pool)], labels), i)
+        out["loss"].backward()
+        opt.step()
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 def cpu_baseline(A, batch=250, steps=5, warmup=2):
     """The oracle on the host cores: same step definition (fwd + bwd + Adam), bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -477,6 +501,10 @@ def main():
             line["sinkhorn"] = time_sinkhorn(A)
         if world == 1:
             line["eager_ms_per_step"] = round(time_eager_route(A, args.workload, pool), 4)
+            try:
+                line["lightning_route_ms_per_step"] = round(time_lightning_route(A, args.workload, pool), 4)
+            except Exception as e:  # noqa: BLE001
+                line["lightning_route_ms_per_step"] = {"error": repr(e)}
             try:
                 line["parity"] = parity_check(A)
             except Exception as e:  # noqa: BLE001

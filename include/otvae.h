@@ -269,6 +269,15 @@ int otvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, con
 /* the same update with the gradient scale read from device memory (what otvae_grad_clip_coef leaves in out[0]) */
 int otvae_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                         const int32_t* step, const float* grad_scale_dev, void* stream);
+/* Guarded update: what makes a bad step survivable inside a captured training step (the reference leans on Lightning's
+ * loop to stop on a NaN loss, configs/ddp.yaml:1-5; a hipGraph replay has no host in the loop).  The update is applied only
+ * when every watched device scalar is finite: watch_loss[0] (the step's loss; a starved Sinkhorn solve poisons it with
+ * NaN), and grad_scale_dev[0..1] = {scale, |g|} when given (what otvae_grad_clip_coef leaves; with max_norm <= 0 it only
+ * reports the norm).  grad_scale_dev NULL: the host value grad_scale is used.  A skipped step leaves p, m, v unchanged, takes
+ * *step back by one, and counts itself: guard[0] += 1, guard[1] = the step number that was skipped (device int32[2]). */
+int otvae_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step,
+                            float grad_scale, const float* grad_scale_dev, const float* watch_loss, int32_t* guard,
+                            void* stream);
 
 /* ---- global-norm gradient clipping (configs/ddp.yaml:4 `gradient_clip_val: 1.0`, applied by Lightning through
  * torch.nn.utils.clip_grad_norm_) over the flat gradient buffer -------------------------------------------------- */

@@ -127,8 +127,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
             const float sc = gam[b] * fis;
             f.scale[b][c] = sc;
             f.shift[b][c] = fmaf(-fmu, sc, bet[b]);
-            if (f.rmean[b]) f.rmean[b][c] = (1.f - momentum) * rm[b] + momentum * fmu;
-            if (f.rvar[b]) f.rvar[b][c] = (1.f - momentum) * rv[b] + momentum * (float)unbiased;
+            // step guard: a non-finite batch statistic (a NaN that reached this layer's input) must not enter the running
+            // buffers, where it would stay for good -- the step itself is skipped by the guarded Adam kernel
+            const bool fin = isfinite(fmu) && isfinite((float)unbiased);
+            if (f.rmean[b] && fin) f.rmean[b][c] = (1.f - momentum) * rm[b] + momentum * fmu;
+            if (f.rvar[b] && fin) f.rvar[b][c] = (1.f - momentum) * rv[b] + momentum * (float)unbiased;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)

@@ -219,11 +219,31 @@ extern "C" int otvae_step_begin(int32_t* step, void* stream) {
 
 // torch.optim.Adam (no weight decay / amsgrad): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// Step guard (guard != NULL): the update is applied only when every watched device scalar is finite -- the step's loss
+// (a starved Sinkhorn solve poisons it with NaN, csrc/sinkhorn.hip: sk_finish) and, when the gradient norm was reduced
+// (otvae_grad_clip_coef), that norm.  Every block evaluates the same two scalars, so the decision is uniform without a flag
+// kernel.  A skipped step leaves p, m, v untouched, takes the step counter back (Adam's bias correction must not advance) and
+// counts itself in guard[0]; guard[1] holds the step number of the last skip.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, const float* __restrict__ hyper,
-                                                   const int32_t* __restrict__ step, float grad_scale,
-                                                   const float* __restrict__ scale_dev) {
+                                                   int32_t* __restrict__ step, float grad_scale,
+                                                   const float* __restrict__ scale_dev, int32_t* __restrict__ guard,
+                                                   const float* __restrict__ watch_loss) {
     if (scale_dev) grad_scale = *scale_dev;  // clip coefficient x 1/world, left by grad_clip_final_kernel
+    if (guard) {
+        bool ok = isfinite(grad_scale);
+        if (scale_dev) ok = ok && isfinite(scale_dev[1]);      // the gradient norm
+        if (watch_loss) ok = ok && isfinite(watch_loss[0]);
+        if (!ok) {
+            // every block has read *step-free state only; the counter is taken back by one thread of the grid
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                guard[0] += 1;
+                guard[1] = *step;
+                *step -= 1;
+            }
+            return;
+        }
+    }
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
     const int t = *step;
     const float bc1 = 1.f - powf(b1, (float)t);
@@ -264,7 +284,8 @@ extern "C" int otvae_adam_step(float* p, const float* g, float* m, float* v, int
     OTVAE_REQUIRE(p && g && m && v && hyper && step && n > 0, "otvae_adam_step: bad argument");
     OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                   "otvae_adam_step: buffers must be 16-byte aligned");
-    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, step, grad_scale, nullptr);
+    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, const_cast<int32_t*>(step), grad_scale,
+                                                                            nullptr, nullptr, nullptr);
     OTVAE_CHECK_LAUNCH("otvae_adam_step");
     return OTVAE_OK;
 }
@@ -274,8 +295,21 @@ extern "C" int otvae_adam_step_dev(float* p, const float* g, float* m, float* v,
     OTVAE_REQUIRE(p && g && m && v && hyper && step && grad_scale_dev && n > 0, "otvae_adam_step_dev: bad argument");
     OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                   "otvae_adam_step_dev: buffers must be 16-byte aligned");
-    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, step, 1.f, grad_scale_dev);
+    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, const_cast<int32_t*>(step), 1.f,
+                                                                            grad_scale_dev, nullptr, nullptr);
     OTVAE_CHECK_LAUNCH("otvae_adam_step_dev");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step,
+                                       float grad_scale, const float* grad_scale_dev, const float* watch_loss, int32_t* guard,
+                                       void* stream) {
+    OTVAE_REQUIRE(p && g && m && v && hyper && step && guard && n > 0, "otvae_adam_step_guarded: bad argument");
+    OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                  "otvae_adam_step_guarded: buffers must be 16-byte aligned");
+    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, step, grad_scale, grad_scale_dev, guard,
+                                                                            watch_loss);
+    OTVAE_CHECK_LAUNCH("otvae_adam_step_guarded");
     return OTVAE_OK;
 }
 

@@ -1,0 +1,174 @@
+"""``GraphedNelbo``: the hipGraph speed for an UNMODIFIED training loop.
+
+The reference trains through Lightning: ``training_step`` (model/base.py:122-129) calls ``self.loss`` (= ``VAE.nelbo``,
+model/vae.py:158-189), Lightning calls ``loss.backward()`` and steps whatever optimizer ``configure_optimizers`` returned
+(model/vae.py:148-156).  Issued eagerly that route costs ~250 launches through Python per step (7 ms at batch 1024, host-bound);
+``HipTrainer`` is fast (one replayed graph) but replaces the loop.  This class keeps the loop:
+
+    model.loss = GraphedNelbo(model)            # or model.enable_graphed_step()
+    out = model.training_step(batch, i); out["loss"].backward(); optimizer.step()      # any torch optimizer
+
+``nelbo`` becomes ONE autograd node whose forward replays a captured forward graph and whose backward replays a captured backward
+graph (in the manner of ``torch.cuda.make_graphed_callables``): static input slots, the parameters' gradients written by the
+backward kernels straight into their slots of a flat buffer and handed to autograd as views, so that they land in ``p.grad``
+without a copy and any optimizer can consume them.  Everything a step mutates besides the parameters (BatchNorm running
+statistics, RNG counters) advances inside the replayed graphs exactly as in the eager route.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .trainer import HipTrainer
+
+__all__ = ["GraphedNelbo"]
+
+
+class _Replay(torch.autograd.Function):
+    """forward = replay of the captured forward graph; backward = replay of the captured backward graph.  The parameters are
+    inputs only so that autograd routes their gradients: the graphs read them in place."""
+
+    @staticmethod
+    def forward(ctx, cap, *params):
+        cap.graph_f.replay()
+        ctx.cap = cap
+        ctx.set_materialize_grads(False)
+        return cap.out3.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        cap = ctx.cap
+        if g is None:
+            return (None,) * (1 + len(cap.params))
+        cap.seed.copy_(g)
+        cap.graph_b.replay()
+        # fresh view objects: autograd keeps ("steals") a gradient it holds the only reference to instead of cloning it
+        return (None, *[p._otvae_grad_view() for p in cap.params])
+
+
+class _Capture:
+    __slots__ = ("key", "engine", "graph_f", "graph_b", "out3", "seed", "params", "artifacts", "logs_keys")
+
+
+class GraphedNelbo:
+    """Callable with ``VAE.nelbo``'s signature and return value; see the module docstring.  Falls back to the plain ``nelbo``
+    whenever a replay would not be the same computation: evaluation / no-grad calls, host tensors, a cosine-annealed prior
+    coefficient (a kernel argument that changes per step), a batch whose shapes differ from the captured ones (captured anew)."""
+
+    def __init__(self, model, warmup: int = 2):
+        self.model = model
+        self.warmup = warmup
+        self._cap: Optional[_Capture] = None
+        self._nelbo = model.nelbo  # the bound method, before anything re-points model.loss
+
+    # ---- capture ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _key(batch) -> Tuple:
+        kw = batch["kwargs"]
+        return (tuple(batch["samples"].shape), batch["target"] is batch["samples"],
+                tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in kw.items() if isinstance(v, Tensor))))
+
+    def _capture(self, batch) -> _Capture:
+        from .. import functional as HF
+        model = self.model
+        samples, kwargs = batch["samples"], batch["kwargs"]
+        old = self._cap
+        if old is not None:  # re-capture for a new batch shape: the parameters stay where the first engine put them
+            engine = old.engine
+            old.graph_f = old.graph_b = None
+            if tuple(engine.x.shape) != tuple(samples.shape):
+                engine.x = torch.zeros_like(samples)
+                engine.eps = torch.zeros((samples.shape[0], *model.latent_size), device=samples.device, dtype=torch.float32)
+        else:
+            # the engine's layout (flat parameter / gradient buffers, gradient slots, resident transposed weights, static batch);
+            # its optimizer is never run
+            engine = HipTrainer(model, batch_shape=tuple(samples.shape), use_graph=False, data_parallel=False, step_guard=None)
+        engine.batch_kwargs = {k: v.detach().clone() for k, v in kwargs.items() if isinstance(v, Tensor) and k != "eps"}
+        engine._rng_key = None
+        cap = _Capture()
+        cap.key, cap.engine = self._key(batch), engine
+        cap.params = engine.params
+        cap.seed = torch.tensor([1.0, 0.0, 0.0], device=engine.device)
+        engine._seed = cap.seed
+        explicit_eps = "eps" in kwargs
+
+        def forward():
+            if not explicit_eps:
+                engine._draw_eps()      # device-side generator: every replay draws fresh noise
+            engine._refresh_wd()
+            loss, logs, art = self._nelbo(engine._batch(), 0)
+            return loss, logs, art
+
+        def backward(loss):
+            for p in engine.params:
+                p.grad = None
+            engine._backward(loss)
+            HF._PendingReduce.flush(engine.device)
+            engine._collect_loose_grads()
+            for p in engine.params:    # the captured pass's own p.grad objects must not outlive the capture
+                p.grad = None
+
+        # everything a step mutates besides what the optimizer owns: restored after warm-up + capture
+        flat_ids = {id(p) for p in engine.params}
+        state = [t for t in model.buffers()] + [p.data for p in model.parameters() if id(p) not in flat_ids]
+        state += [m.__dict__["_dropout_key"] for m in model.modules() if isinstance(m.__dict__.get("_dropout_key"), Tensor)]
+        snap = [t.clone() for t in state]
+        s = torch.cuda.Stream(device=engine.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self.warmup):
+                backward(forward()[0])
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        mode = dict(capture_error_mode=os.environ.get("OTVAE_CAPTURE_ERROR_MODE", "thread_local"))
+        cap.graph_f = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cap.graph_f, **mode):
+            loss, logs, art = forward()
+            cap.out3 = model._last_nelbo
+        cap.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cap.graph_b, pool=cap.graph_f.pool(), **mode):
+            backward(loss)
+        cap.out3 = cap.out3.detach()
+        cap.artifacts = {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in art.items()
+                         if k not in ("samples", "target", "kwargs")}
+        model._last_nelbo = None
+        model._last_cut = None
+        with torch.no_grad():
+            for t, v in zip(state, snap):
+                t.copy_(v)
+        torch.cuda.synchronize()
+        return cap
+
+    # ---- call ------------------------------------------------------------------------------------------------
+    def __call__(self, batch, batch_idx: int):
+        model = self.model
+        samples = batch["samples"]
+        prior = getattr(model, "prior", None)
+        annealing = getattr(prior, "annealing_steps", 0) > int(getattr(model, "global_step", 0) or 0)
+        if not (torch.is_grad_enabled() and model.training and samples.is_cuda) or annealing:
+            return self._nelbo(batch, batch_idx)
+        if self._cap is None or self._cap.key != self._key(batch):
+            self._cap = self._capture(batch)
+        cap, eng = self._cap, self._cap.engine
+        for p in cap.params:
+            g = p.grad
+            if g is not None and g.data_ptr() == p._otvae_grad_view().data_ptr():
+                # zero_grad(set_to_none=False) left the slot view in place: the backward graph will overwrite the slot and autograd
+                # would then add the slot to itself
+                p.grad = None
+        eng.x.copy_(samples, non_blocking=True)
+        if batch["target"] is not samples:
+            raise ValueError("GraphedNelbo replays VAE.nelbo with target = samples (what batch_preprocess builds)")
+        for k, v in batch["kwargs"].items():
+            if k == "eps":
+                eng.eps.copy_(v.reshape(eng.eps.shape), non_blocking=True)
+            elif isinstance(v, Tensor):
+                eng.batch_kwargs[k].copy_(v, non_blocking=True)
+        out3 = _Replay.apply(cap, *cap.params)
+        model._last_out3 = out3.detach()
+        loss = out3[0]
+        logs = {"train/loss/total": loss, "train/loss/recon": out3[1], "train/loss/prior": out3[2]}
+        return loss, logs, {**batch, **cap.artifacts}

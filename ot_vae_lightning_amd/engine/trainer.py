@@ -69,7 +69,7 @@ class HipTrainer:
     def __init__(self, model, batch_shape, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, use_graph: bool = True, latent_stats=None, dp_overlap: Optional[bool] = None,
                  batch_kwargs: Optional[Dict[str, Tensor]] = None, gradient_clip_val: Optional[float] = None,
-                 data_parallel: bool = True):
+                 data_parallel: bool = True, step_guard: Optional[str] = "auto"):
         self.lib = _lib.load()
         self.model = model
         self.params = list(model.optim_parameters())
@@ -90,6 +90,16 @@ class HipTrainer:
         self.gradient_clip_val = None if not gradient_clip_val else float(gradient_clip_val)
         self.clip_out = torch.zeros(2, device=dev, dtype=torch.float32)
         self._clip_ws = torch.empty(self.lib.otvae_grad_clip_ws(), device=dev, dtype=torch.float64)
+        # Device-side step guard: a captured step has no host in the loop that could stop on a NaN loss as
+        # Lightning's does, so the Adam kernel itself refuses a bad step (parameters, moments and the step counter stay as they
+        # were; BatchNorm's running buffers refuse non-finite batch statistics on their own) and counts it.
+        #   "loss": the step's loss must be finite (free: Adam reads the loss vector the step produced anyway; covers a starved
+        #           Sinkhorn solve, whose outputs are NaN-poisoned, and NaN / inf inputs);
+        #   "full": also the L2 norm of the (all-reduced) gradient, two small launches unless clipping runs them already --
+        #           identical on every rank, hence the mode for world > 1 (a rank-local loss test would let ranks diverge);
+        #   None:   unguarded (round-2 behaviour).  "auto" = "loss" on one rank, "full" on several.
+        self._guard_arg = step_guard
+        self.guard = torch.zeros(2, device=dev, dtype=torch.int32)  # {skipped steps, step number of the last skip}
         # a FRESH tensor object per call (autograd steals a gradient it holds the only reference to and clones it otherwise),
         # made from a slot view built once: detach() is one shallow copy instead of slice + view + permute
         for p, off in zip(self.params, self.offsets):
@@ -118,6 +128,9 @@ class HipTrainer:
         # data_parallel=False: this engine is rank-local even when a process group exists (no gradient exchange)
         self.reducer = FlatGradReducer(self.gflat, process_group, enabled=data_parallel)
         self.world = self.reducer.world
+        if self._guard_arg not in (None, "auto", "loss", "full"):
+            raise ValueError("step_guard must be None, 'auto', 'loss' or 'full'")
+        self.step_guard = ("full" if self.world > 1 else "loss") if self._guard_arg == "auto" else self._guard_arg
         # Data-parallel overlap: backward runs in two phases cut at the encoder's output (loss, decoder and prior side
         # first); the decoder's gradient range is all-reduced on the reducer's stream WHILE the encoder's backward runs,
         # the rest afterwards.
@@ -172,8 +185,14 @@ class HipTrainer:
         self._refresh_wd()
         for p in self.params:
             p.grad = None
-        loss, logs, art = self.model.nelbo(self._batch(), 0)
-        self._backward(loss)
+        from ..functional import PriorLane
+        PriorLane.enabled = True  # the prior's OT work may run beside the decoder: this method joins it (functional.PriorLane)
+        try:
+            loss, logs, art = self.model.nelbo(self._batch(), 0)
+            self._backward(loss)
+        finally:
+            PriorLane.enabled = False
+            PriorLane.join(self.device)  # (already joined by the prior's backward when it took part in the pass)
         # the model's handle on the encoder output would keep this step's autograd graph -- and with it the parameters'
         # AccumulateGrad nodes, bound to the stream they were created on -- alive into the next step (and from the
         # warm-up stream into the capture: "AccumulateGrad node's stream does not match ...")
@@ -253,13 +272,19 @@ class HipTrainer:
         self._refresh_wd()
         for p in self.params:
             p.grad = None
-        loss, logs, art = self.model.nelbo(self._batch(), 0)
-        h = getattr(self.model, "_last_cut", None)
-        if h is None:  # nothing upstream of the cut needs a gradient: one-phase backward
-            self._backward(loss)
-        else:
-            # retain_graph: without it the engine also releases the saved tensors of the node that produced h
-            self._backward(loss, inputs=self._post_params + [h], retain_graph=True)
+        from ..functional import PriorLane
+        PriorLane.enabled = True
+        try:
+            loss, logs, art = self.model.nelbo(self._batch(), 0)
+            h = getattr(self.model, "_last_cut", None)
+            if h is None:  # nothing upstream of the cut needs a gradient: one-phase backward
+                self._backward(loss)
+            else:
+                # retain_graph: without it the engine also releases the saved tensors of the node that produced h
+                self._backward(loss, inputs=self._post_params + [h], retain_graph=True)
+        finally:
+            PriorLane.enabled = False
+            PriorLane.join(self.device)
         self._cut = h
         from ..functional import _PendingReduce
         _PendingReduce.flush(self.device)  # the decoder's weight gradients are complete before their all-reduce starts
@@ -292,17 +317,31 @@ class HipTrainer:
         self.reducer.join()
 
     def _adam(self):
-        if self.gradient_clip_val is not None:
-            lib = self.lib
-            check(lib.otvae_grad_clip_coef(ptr(self.gflat), self.gflat.numel(), self.reducer.grad_scale, self.gradient_clip_val,
+        lib = self.lib
+        norm = self.gradient_clip_val is not None or self.step_guard == "full"
+        if norm:  # max_norm 0: the norm is only reported (out[0] = grad_scale)
+            check(lib.otvae_grad_clip_coef(ptr(self.gflat), self.gflat.numel(), self.reducer.grad_scale, self.gradient_clip_val or 0.0,
                                            ptr(self._clip_ws), ptr(self.clip_out), stream()), "otvae_grad_clip_coef")
+        if self.step_guard is not None:
+            watch = getattr(self.model, "_last_out3", None)  # [total, recon, prior] of this step (static inside a captured step)
+            self._watch = watch
+            check(lib.otvae_adam_step_guarded(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
+                                              ptr(self.hyper), ptr(self.step_count), self.reducer.grad_scale,
+                                              ptr(self.clip_out) if norm else None, ptr(watch), ptr(self.guard), stream()),
+                  "otvae_adam_step_guarded")
+        elif norm:
             check(lib.otvae_adam_step_dev(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
                                           ptr(self.hyper), ptr(self.step_count), ptr(self.clip_out), stream()),
                   "otvae_adam_step_dev")
-            return
-        check(self.lib.otvae_adam_step(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
-                                       ptr(self.hyper), ptr(self.step_count), self.reducer.grad_scale, stream()),
-              "otvae_adam_step")
+        else:
+            check(lib.otvae_adam_step(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
+                                      ptr(self.hyper), ptr(self.step_count), self.reducer.grad_scale, stream()),
+                  "otvae_adam_step")
+
+    @property
+    def skipped_steps(self) -> int:
+        """steps the device-side guard refused so far (one host read)"""
+        return int(self.guard[0].item())
 
     def _allreduce(self):
         self.reducer.allreduce()
@@ -331,7 +370,7 @@ class HipTrainer:
         """Warm-up eagerly on a side stream (allocator + lazy kernel loading), then capture."""
         if self._captured or not self.use_graph:
             return
-        snap = (self.pflat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone())
+        snap = (self.pflat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone(), self.guard.clone())
         # everything else a step mutates: every buffer of the model (BatchNorm running statistics, EMA embeddings of a
         # ConditionalGaussianPrior ...), parameters outside the flat buffer (frozen ones an EMA rewrites), the dropout
         # key counters, and the running statistics of the latent operator (which may hold earlier eager steps' samples)
@@ -378,6 +417,7 @@ class HipTrainer:
         # the warm-up/capture must not count as training: restore parameters, moments, step and BN buffers
         with torch.no_grad():
             self.pflat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self.step_count.copy_(snap[3])
+            self.guard.copy_(snap[4])
             for t, v in zip(state, state_snap):
                 t.copy_(v)
         torch.cuda.synchronize()

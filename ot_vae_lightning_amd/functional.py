@@ -302,6 +302,80 @@ class _PendingReduce:
             held.clear()
 
 
+# ------------------------------------------------------------------------------------------------ prior lane
+# OTVAE_PRIOR_STREAM: 1 (default) = inside a training engine's CAPTURED step the prior's optimal-transport work (Sinkhorn cost +
+# solve + read-out, or batch statistics + eigendecomposition + W2 tail) and the loss vector run on a stream of their own beside
+# the decoder's forward and backward pass; 2 = also in the engine's eagerly issued steps; 0 = in line on the launch stream (the
+# round-2 order) -- A/B switch.  Nothing in the decoder depends on that work (it needs the latents, which the prior passes
+# through), and the decoder's backward does not need the loss VALUE (nelbo's gradient is 2 (pred - target) / numel and a
+# constant for the prior term), so the launch stream meets the lane again only where the prior's own backward starts.
+PRIOR_SIDE_STREAM = int(os.environ.get("OTVAE_PRIOR_STREAM", "1"))
+
+
+class PriorLane:
+    """Fork / join bookkeeping of the prior's side stream (one per device).  Only a training engine switches it on
+    (``PriorLane.enabled``): it is the engine that guarantees the join (``join`` at the prior's backward and again after the
+    backward pass) before anything reads what the lane produced.
+
+    Memory: work issued inside ``with lane`` allocates from the LANE stream's pool (``torch.cuda.stream``), so a temporary freed
+    when an operator returns can only be handed to a later allocation on the same stream -- ordered behind its last use.  The
+    autograd nodes above were created on the launch stream and run their backward there."""
+    enabled = False          # set by HipTrainer around the step it issues
+    _streams: dict = {}
+    _open: dict = {}         # device -> event after the lane's last piece of work (None: nothing forked)
+
+    @staticmethod
+    def active(device) -> bool:
+        if not PriorLane.enabled or PRIOR_SIDE_STREAM == 0 or device.type != "cuda":
+            return False
+        return PRIOR_SIDE_STREAM == 2 or torch.cuda.is_current_stream_capturing()
+
+    @staticmethod
+    def stream(device) -> "torch.cuda.Stream":
+        st = PriorLane._streams.get(device)
+        if st is None:
+            st = PriorLane._streams[device] = torch.cuda.Stream(device=device)
+        return st
+
+    @staticmethod
+    def is_open(device) -> bool:
+        return PriorLane._open.get(device) is not None
+
+    class _Section:
+        def __init__(self, device):
+            self.device = device
+            self.ctx = None
+
+        def __enter__(self):
+            lane = PriorLane.stream(self.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))   # everything the section reads is complete here
+            lane.wait_event(ev)
+            self.ctx = torch.cuda.stream(lane)
+            self.ctx.__enter__()
+            return lane
+
+        def __exit__(self, *exc):
+            lane = PriorLane.stream(self.device)
+            done = torch.cuda.Event()
+            done.record(lane)
+            PriorLane._open[self.device] = done
+            return self.ctx.__exit__(*exc)
+
+    @staticmethod
+    def section(device) -> "PriorLane._Section":
+        """``with PriorLane.section(dev):`` -- the body is issued on the lane, ordered after the launch stream's work so far"""
+        return PriorLane._Section(device)
+
+    @staticmethod
+    def join(device) -> None:
+        """the launch stream waits for the lane's work (no-op when nothing is outstanding)"""
+        done = PriorLane._open.get(device)
+        if done is not None:
+            torch.cuda.current_stream(device).wait_event(done)
+            PriorLane._open[device] = None
+
+
 # ------------------------------------------------------------------------------------------------ fused ConvLayer(s)
 class ConvSpec:
     """Static description of one ConvLayer branch (everything that is not a tensor)."""

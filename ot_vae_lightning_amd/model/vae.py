@@ -76,6 +76,14 @@ class VAE(VisionModule):
                                                            min_lr=1e-6)
         return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "monitor": self.monitor}}
 
+    def enable_graphed_step(self, warmup: int = 2) -> "VAE":
+        """``training_step`` -> ``loss.backward()`` -> any optimizer at hipGraph speed: ``self.loss`` (what the reference's
+        ``training_step`` calls, model/base.py:122-129) becomes an ``engine.GraphedNelbo`` over ``self.nelbo`` -- one autograd node
+        that replays a captured forward graph and, in ``backward``, a captured backward graph; gradients land in ``p.grad``."""
+        from ..engine.graphed import GraphedNelbo
+        self.loss = GraphedNelbo(self, warmup=warmup)
+        return self
+
     def recon_loss(self, reconstructions: Tensor, target: Tensor, **kwargs) -> Tensor:
         return HF.nelbo_loss(reconstructions, target, None)[1]
 

@@ -250,6 +250,16 @@ torch.library.register_autograd("otvae::gaussian_prior", _gp_backward, setup_con
 
 # ------------------------------------------------------------------------------------------------ nelbo reduction
 def _nelbo_fwd(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor], chw: float):
+    from .functional import PriorLane
+    if PriorLane.is_open(pred.device) and PriorLane.active(pred.device):
+        # the prior term is still being computed on the prior lane (functional.PriorLane): the loss vector is formed there too,
+        # behind it -- the backward pass needs pred and target, not this value
+        with PriorLane.section(pred.device):
+            return _nelbo_fwd_launch(pred, target, prior_loss, chw)
+    return _nelbo_fwd_launch(pred, target, prior_loss, chw)
+
+
+def _nelbo_fwd_launch(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor], chw: float):
     lib = _lib.load()
     b, numel = pred.shape[0], pred.numel()
     ws = torch.empty(lib.otvae_nelbo_ws(), device=pred.device, dtype=torch.float64)

@@ -26,7 +26,16 @@ class _W2PriorFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, mut, covt, rt, v_init, warm, scale):
-        loss, mu, q, vt = torch.ops.otvae.gaussian_w2_prior(z, mut, covt, rt, v_init, warm, float(scale))
+        from ..functional import PriorLane
+        ctx.lane = PriorLane.active(z.device)
+        if ctx.lane:  # beside the decoder, on the prior lane of a training engine's step (functional.PriorLane)
+            with PriorLane.section(z.device):
+                loss, mu, q, vt = torch.ops.otvae.gaussian_w2_prior(z, mut, covt, rt, v_init, warm, float(scale))
+                if v_init is not None:  # the warm-start basis of the next step, behind the solve that produced it
+                    v_init.copy_(vt)
+                    warm.fill_(1)
+        else:
+            loss, mu, q, vt = torch.ops.otvae.gaussian_w2_prior(z, mut, covt, rt, v_init, warm, float(scale))
         ctx.save_for_backward(z, mu, q)
         ctx.target = (mut, rt)
         ctx.scale = float(scale)
@@ -37,6 +46,9 @@ class _W2PriorFn(torch.autograd.Function):
     def backward(ctx, gz_out, g, _gvt):
         z, mu, q = ctx.saved_tensors
         mut, rt = ctx.target
+        if ctx.lane:
+            from ..functional import PriorLane
+            PriorLane.join(z.device)
         if g is None:
             return gz_out, None, None, None, None, None, None
         return (torch.ops.otvae.gaussian_w2_prior_backward(g, gz_out, z, mu, q, mut, rt, ctx.scale), None, None, None, None, None,
@@ -107,7 +119,8 @@ class GaussianW2Prior(Prior):
             self._warm.zero_()
         z_out, loss, vt = _W2PriorFn.apply(zf, self.target_mean, covt, rt, self._v_prev if warm_ok else None,
                                            self._warm if warm_ok else None, _scale)
-        if warm_ok:
+        from ..functional import PriorLane
+        if warm_ok and not PriorLane.active(zf.device):  # (on the prior lane the node itself refreshed the basis, behind its solve)
             with torch.no_grad():
                 self._v_prev.copy_(vt)
                 self._warm.fill_(1)

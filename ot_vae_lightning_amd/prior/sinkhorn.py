@@ -24,7 +24,13 @@ class _SinkhornLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, y, reg, max_iter, threshold, scale):
-        cost, pi, iters = torch.ops.otvae.sinkhorn_prior(z, y, float(reg), int(max_iter), float(threshold), float(scale))
+        from ..functional import PriorLane
+        ctx.lane = PriorLane.active(z.device)
+        if ctx.lane:  # beside the decoder, on the prior lane of a training engine's step (functional.PriorLane)
+            with PriorLane.section(z.device):
+                cost, pi, iters = torch.ops.otvae.sinkhorn_prior(z, y, float(reg), int(max_iter), float(threshold), float(scale))
+        else:
+            cost, pi, iters = torch.ops.otvae.sinkhorn_prior(z, y, float(reg), int(max_iter), float(threshold), float(scale))
         ctx.save_for_backward(z, y, pi)
         ctx.scale = float(scale)
         ctx.mark_non_differentiable(iters)
@@ -36,6 +42,9 @@ class _SinkhornLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gz_out, g, _giters):
         z, y, pi = ctx.saved_tensors
+        if ctx.lane:
+            from ..functional import PriorLane
+            PriorLane.join(z.device)  # the plan (and the loss vector behind it) is complete from here on
         if g is None:  # only the latents were used downstream
             return gz_out, None, None, None, None, None
         return torch.ops.otvae.sinkhorn_prior_backward(g, gz_out, z, y, pi, ctx.scale), None, None, None, None, None

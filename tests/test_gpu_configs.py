@@ -27,6 +27,10 @@ def A():
     return pkg
 
 
+def _pnames(model):
+    return [f"{net}.{k}" for net, m_ in (("encoder", model.encoder), ("decoder", model.decoder)) for k, _ in m_.named_parameters()]
+
+
 def _oracle_step(model, enc_kw, dec_kw, x, eps, loss_coeff):
     ea, da = O.cnn_arch(**enc_kw), O.cnn_arch(**dec_kw)
     pe = {k: v.detach().cpu().clone().contiguous() for k, v in model.encoder.state_dict().items()}
@@ -64,6 +68,7 @@ def test_training_step_other_configs_vs_oracle(A, cfg):
     params = [p for net in (model.encoder, model.decoder) for p in net.parameters()]
     gl2 = torch.tensor([p.grad.double().norm().item() for p in params])
     rep.check("grad_l2 (all parameters)", gl2, torch.tensor([v.grad.double().norm().item() for v in leaves]), tol=5e-4)
+    rep.check_grads(f"gradients [{cfg}]", [p.grad for p in params], [v.grad for v in leaves], _pnames(model))
     # BatchNorm running statistics after the step
     rs_gpu = torch.tensor([b.double().sum().item() for net in (model.encoder, model.decoder)
                            for k, b in net.named_buffers() if "running_" in k])
@@ -72,6 +77,30 @@ def test_training_step_other_configs_vs_oracle(A, cfg):
     with torch.no_grad():
         loss, logs, art = model.nelbo({"samples": x.cuda(), "target": x.cuda(), "kwargs": {"eps": eps.cuda()}}, 0)
     assert art["preds"].shape == x.shape and art["latents"].shape == (B, lat, 1, 1)
+    rep.finish()
+
+
+def test_benchmark_config_batch1024_gradients_elementwise_vs_oracle(A):
+    """BASELINE configs[1] exactly as benched (MNIST-32 CNN VAE + GaussianPrior(0.1), batch 1024, residual="add"): the captured
+    step's loss vector and EVERY parameter gradient element by element against the CPU oracle (VERDICT r2 #4: norms only before)."""
+    rep = Report("configs[1] (benchmark) B=1024: loss + element-wise gradients vs CPU oracle")
+    B = 1024
+    torch.manual_seed(0)
+    enc_kw = dict(in_features=1, out_features=256, in_resolution=32, out_resolution=1, capacity=8, down_sample=True, residual="add")
+    dec_kw = dict(in_features=128, out_features=1, in_resolution=1, out_resolution=32, capacity=8, up_sample=True, residual="add")
+    enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+    dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1))
+    x, eps = mnist_like(B, 41), normal((B, 128, 1, 1), 42)
+    r, leaves, pe, pd = _oracle_step(model, enc_kw, dec_kw, x, eps, 0.1)
+    model = model.cuda().train()
+    tr = A.HipTrainer(model, batch_shape=(B, 1, 32, 32), use_graph=True)
+    out = tr.step(x.cuda(), eps.cuda()).clone()
+    torch.cuda.synchronize()
+    rep.check("loss[total,recon,prior]", out, torch.stack([r["loss"], r["recon"], r["prior"]]).detach())
+    grads = [p._otvae_grad_view() for net in (model.encoder, model.decoder) for p in net.parameters()]  # the flat buffer's slots
+    rep.check_grads("gradients B=1024 (captured step)", grads, [v.grad for v in leaves], _pnames(model))
+    tr.close()
     rep.finish()
 
 
@@ -123,6 +152,7 @@ def test_sinkhorn_prior_in_vae_step_vs_oracle(A, cfg):
     params = [p for net in (model.encoder, model.decoder) for p in net.parameters()]
     rep.check("grad_l2 (all parameters)", torch.tensor([p.grad.double().norm().item() for p in params]),
               torch.tensor([v.grad.double().norm().item() for v in leaves]), tol=5e-4)
+    rep.check_grads(f"gradients [{cfg}]", [p.grad for p in params], [v.grad for v in leaves], _pnames(model))
     rep.finish()
 
 
@@ -284,6 +314,7 @@ def test_gaussian_w2_prior_in_vae_training_step(A):
             params = [p for net in (tr.model.encoder, tr.model.decoder) for p in net.parameters()]
             rep.check("grad_l2 (all parameters)", torch.tensor([p.grad.double().norm().item() for p in params]),
                       torch.tensor([v.grad.double().norm().item() for v in leaves]), tol=5e-4)
+            rep.check_grads("gradients [GaussianW2Prior step]", [p.grad for p in params], [v.grad for v in leaves], _pnames(tr.model))
         # steps 2-4 start the eigendecomposition from the previous step's eigenvectors (the first one cold, in both modes)
         later = torch.stack([tr.step(x.cuda()).clone() for _ in range(3)])
         assert int(tr.model.prior._warm) == 1 and torch.isfinite(later).all()
@@ -807,6 +838,84 @@ def test_side_stream_weight_gradients_equal_single_stream(A, monkeypatch):
     assert not HF._PendingReduce._state[dev] and not HF._PendingReduce._held.get(dev) and not HF._PendingReduce._wq[dev][0]
 
 
+@pytest.mark.parametrize("prior_kind", ["sinkhorn", "gaussian_w2"])
+def test_prior_lane_equals_in_line_order(A, prior_kind, monkeypatch):
+    """inside a captured step the prior's optimal-transport work (Sinkhorn solve / statistics + eigh + W2 tail) and
+    the loss vector run on a stream of their own beside the decoder (functional.PriorLane).  Same kernels, same inputs: losses,
+    gradients and parameters after three replays must be bit-identical to the in-line order (OTVAE_PRIOR_STREAM=0)."""
+    from ot_vae_lightning_amd import functional as HF
+    B = 256
+    xs = [mnist_like(B, 90 + i).cuda() for i in range(3)]
+
+    def run(mode):
+        monkeypatch.setattr(HF, "PRIOR_SIDE_STREAM", mode)
+        torch.manual_seed(11)
+        enc = A.CNN(1, 128, 32, 1, capacity=8, down_sample=True, residual="add")
+        dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+        prior = A.SinkhornPrior(reg=0.05, max_iter=50, threshold=0.0, seed=7) if prior_kind == "sinkhorn" else A.GaussianW2Prior(loss_coeff=0.1)
+        model = A.VAE(encoder=enc, decoder=dec, prior=prior).cuda().train()
+        tr = A.HipTrainer(model, batch_shape=(B, 1, 32, 32), use_graph=True)
+        outs = [tr.step(x).clone() for x in xs]
+        torch.cuda.synchronize()
+        res = (torch.stack(outs), tr.gflat.clone(), tr.pflat.clone())
+        assert tr.skipped_steps == 0 and torch.isfinite(res[0]).all()
+        tr.close()
+        return res
+
+    lane, inline = run(1), run(0)
+    for name, a, b in zip(("losses", "gradients", "parameters"), lane, inline):
+        assert torch.equal(a, b), f"{prior_kind}: {name} differ between the prior lane and the in-line order"
+    assert not HF.PriorLane.is_open(torch.device("cuda", torch.cuda.current_device()))
+
+
+def test_graphed_nelbo_gives_the_unmodified_loop_the_graph_route(A):
+    """``training_step`` -> ``loss.backward()`` -> a stock ``torch.optim.Adam`` (the reference's loop: model/base.py:
+    122-129, model/vae.py:148-156) with ``model.enable_graphed_step()``: the loss vector and every gradient must be BIT-equal
+    to ``HipTrainer``'s for the same weights / batch / eps over several steps, ``p.grad`` must be populated for any optimizer, the
+    parameters after stock Adam agree with the fused Adam kernel to rounding, BatchNorm's running buffers advance alike, and an
+    evaluation call goes through the plain ``nelbo``."""
+    B = 64
+    xs = [mnist_like(B, 110 + i).cuda() for i in range(3)]
+    es = [normal((B, 128, 1, 1), 120 + i).cuda() for i in range(3)]
+
+    def make():
+        torch.manual_seed(21)
+        enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+        dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+        return A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+
+    ref_model = make()
+    tr = A.HipTrainer(ref_model, batch_shape=(B, 1, 32, 32), use_graph=True)
+    model = make().enable_graphed_step()
+    opt = torch.optim.Adam(model.optim_parameters(), lr=1e-3, betas=(0.9, 0.999))
+    for i in range(3):
+        want = tr.step(xs[i], es[i]).clone()
+        want_g = tr.gflat.clone()
+        opt.zero_grad()
+        # the reference's training_step, called the way Lightning does (batch_preprocess builds {samples, target, kwargs})
+        model.batch_preprocess = lambda b: {"samples": b[0], "target": b[0], "kwargs": {"eps": b[1]}}
+        out = model.training_step((xs[i], es[i]), i)
+        out["loss"].backward()
+        got = torch.stack([out["train/loss/total"], out["train/loss/recon"], out["train/loss/prior"]]).detach()
+        assert torch.equal(got, want), (i, got, want)
+        eng = model.loss._cap.engine
+        assert torch.equal(eng.gflat, want_g), f"step {i}: gradients differ from HipTrainer's"
+        assert all(p.grad is not None and p.grad.data_ptr() == p._otvae_grad_view().data_ptr() for p in eng.params)
+        assert out["preds"].shape == xs[i].shape and out["latents"].shape == (B, 128, 1, 1)
+        opt.step()
+        err = float((eng.pflat - tr.pflat).abs().max())
+        assert err < 5e-6, (i, err)     # stock Adam vs the fused kernel: same update to rounding (a step moves a weight by ~1e-3)
+    for (ka, va), (kb, vb) in zip(model.state_dict().items(), ref_model.state_dict().items()):
+        if "running" in ka or "num_batches" in ka:
+            assert torch.allclose(va.float(), vb.float(), rtol=1e-5, atol=1e-6), ka
+    # no graph outside training: evaluation runs the plain nelbo (BatchNorm in inference mode)
+    model.eval()
+    with torch.no_grad():
+        loss, logs, art = model.loss({"samples": xs[0], "target": xs[0], "kwargs": {"eps": es[0]}}, 0)
+    assert torch.isfinite(loss) and art["preds"].shape == xs[0].shape
+    tr.close()
+
+
 def test_gradient_clipping_matches_clip_grad_norm(A):
     """Global-norm clipping of the step (reference configs/ddp.yaml:4 -> Lightning -> torch.nn.utils.clip_grad_norm_): the
     norm the kernel reports, the coefficient and the clipped Adam update against torch arithmetic on the same gradient."""
@@ -839,6 +948,68 @@ def test_gradient_clipping_matches_clip_grad_norm(A):
         err = float((tr.pflat - ref_p.detach()).abs().max())
         assert err < 2e-7, (clip, err)                          # one Adam step moves a weight by <= lr = 1e-3
     assert float((make(0.25 * norm).pflat - p0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", ["loss-graph", "loss-eager", "full-graph"])
+def test_step_guard_skips_a_bad_step_and_leaves_no_trace(A, mode):
+    """VERDICT r2 #5 / ADVICE r2: a bad step must be survivable inside a captured step.  Trainer A sees [good, NaN batch, good],
+    trainer B only the two good batches: parameters, Adam moments, the step counter and every BatchNorm running buffer must be
+    BIT-identical afterwards, and A reports one skipped step.  Without the guard the NaN batch lands in every parameter."""
+    guard, graph = mode.split("-")
+    xs = [mnist_like(32, 71).cuda(), mnist_like(32, 72).cuda()]
+    es = [normal((32, 128, 1, 1), 73).cuda(), normal((32, 128, 1, 1), 74).cuda()]
+    bad = xs[0].clone()
+    bad[3, 0, 5, 7] = float("nan")
+
+    def make(g):
+        torch.manual_seed(5)
+        enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+        dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+        model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+        return A.HipTrainer(model, batch_shape=(32, 1, 32, 32), use_graph=graph == "graph", step_guard=g)
+
+    ta, tb = make(guard), make(guard)
+    ta.step(xs[0], es[0])
+    out_bad = ta.step(bad, es[1]).clone()
+    ta.step(xs[1], es[1])
+    tb.step(xs[0], es[0])
+    tb.step(xs[1], es[1])
+    torch.cuda.synchronize()
+    assert torch.isnan(out_bad[0]), "the bad step's loss is what the host sees"
+    assert ta.skipped_steps == 1 and tb.skipped_steps == 0 and int(ta.guard[1]) == 2
+    assert int(ta.step_count) == int(tb.step_count) == 2
+    for name in ("pflat", "m", "v"):
+        assert torch.equal(getattr(ta, name), getattr(tb, name)), name
+    for (ka, va), (kb, vb) in zip(ta.model.state_dict().items(), tb.model.state_dict().items()):
+        if "num_batches_tracked" in ka:
+            continue  # counts forward passes, like torch's (the skipped step did run its forward pass)
+        assert torch.equal(va, vb), ka
+    # unguarded: the same batch poisons the parameters (what round 2 shipped)
+    tc = make(None)
+    tc.step(bad, es[1])
+    assert torch.isnan(tc.pflat).any()
+    for t in (ta, tb, tc):
+        t.close()
+
+
+def test_step_guard_survives_a_starved_sinkhorn_solve_in_a_captured_step(A, monkeypatch):
+    """The persistent Sinkhorn solver's workgroups wait for each other; starved (poll budget 0, baked into the captured step)
+    every replay ends in NaN-poisoned plan / loss: the guarded Adam must leave the parameters untouched and count the steps."""
+    from ot_vae_lightning_amd.ot import w2_utils as W
+    monkeypatch.setenv("OTVAE_SK_SPIN_LIMIT", "0")
+    torch.manual_seed(6)
+    enc = A.CNN(1, 128, 32, 1, capacity=8, down_sample=True, residual="add")
+    dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+    model = A.VAE(encoder=enc, decoder=dec, prior=A.SinkhornPrior(reg=0.05, max_iter=50, threshold=0.0)).cuda().train()
+    tr = A.HipTrainer(model, batch_shape=(128, 1, 32, 32), use_graph=True)
+    p0 = tr.pflat.clone()
+    for i in range(3):
+        out = tr.step(mnist_like(128, 80 + i).cuda())
+    torch.cuda.synchronize()
+    assert torch.isnan(out[0]) and tr.skipped_steps == 3 and int(tr.step_count) == 0
+    assert torch.equal(tr.pflat, p0) and not torch.isnan(tr.m).any()
+    with pytest.raises(W.SinkhornSolverStarved):
+        tr.close()
 
 
 def test_bench_two_rank_call_sequence_on_one_gpu():

@@ -22,6 +22,11 @@ TOL32 = 1e-4
 REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.txt")
 
 
+# whole-network gradients, tensor by tensor (Report.check_grads): fp32 forward + backward through ~50 convolutions, 40 training-
+# mode BatchNorms and 10 attention blocks against the CPU oracle's fp32 autograd
+GRAD_TOL_L2, GRAD_TOL_MAX = 2e-3, 5e-3
+
+
 class Report:
     def __init__(self, title):
         self.title, self.rows, self.failed = title, [], []
@@ -40,6 +45,33 @@ class Report:
         self.rows.append((name, err, tol, ok))
         if not ok:
             self.failed.append((name, err, tol))
+
+    def check_grads(self, name, got, want, names=None, tol_l2=GRAD_TOL_L2, tol_max=GRAD_TOL_MAX):
+        """Element-wise gradient comparison, tensor by tensor (per-parameter L2 NORMS pass a permuted or
+        sign-flipped gradient).  Per tensor: |got - want|_2 / |want|_2 and max|got - want| / max|want|, each against the
+        tensor's own size but never below 1e-3 of the network's gradient scale (the largest per-tensor value over all
+        parameters): a tensor whose exact gradient is zero -- the bias of a convolution feeding a training-mode BatchNorm --
+        holds only rounding noise on both sides."""
+        got = [g.detach().double().cpu() for g in got]
+        want = [w.detach().double().cpu() for w in want]
+        assert len(got) == len(want) and all(a.shape == b.shape for a, b in zip(got, want)), "gradient lists differ in shape"
+        rms_scale = max(float(b.norm()) / max(b.numel(), 1) ** 0.5 for b in want)
+        max_scale = max(float(b.abs().max()) for b in want)
+        worst = (0.0, 0.0, "")
+        for i, (a, b) in enumerate(zip(got, want)):
+            n = b.numel() ** 0.5
+            e2 = float((a - b).norm()) / max(float(b.norm()), 1e-3 * rms_scale * n, 1e-30)
+            em = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3 * max_scale, 1e-30)
+            tag = f"{name}: {names[i] if names else i}"
+            ok = e2 < tol_l2 and em < tol_max and math.isfinite(e2) and math.isfinite(em)
+            if not ok:
+                self.failed.append((tag, (e2, em), (tol_l2, tol_max)))
+                self.rows.append((tag + " (rel L2)", e2, tol_l2, e2 < tol_l2))
+                self.rows.append((tag + " (max)", em, tol_max, em < tol_max))
+            if max(e2 / tol_l2, em / tol_max) > max(worst[0] / tol_l2, worst[1] / tol_max):
+                worst = (e2, em, tag)
+        self.rows.append((f"{name}: {len(got)} tensors element-wise, worst rel L2 [{worst[2]}]", worst[0], tol_l2, worst[0] < tol_l2))
+        self.rows.append((f"{name}: worst max-norm", worst[1], tol_max, worst[1] < tol_max))
 
     def finish(self):
         os.makedirs(os.path.dirname(REPORT), exist_ok=True)
@@ -434,6 +466,8 @@ def test_training_step_vs_oracle_batch256_and_graph(A):
     params = [p for net in (model.encoder, model.decoder) for p in net.parameters()]
     rep.check("loss", out, want_loss)
     rep.check("grad_l2", torch.tensor([p.grad.double().norm().item() for p in params]), want_gl2, tol=3e-4)
+    pnames = [f"{net}.{k}" for net, m_ in (("encoder", model.encoder), ("decoder", model.decoder)) for k, _ in m_.named_parameters()]
+    rep.check_grads("gradients B=256", [p.grad for p in params], [v.grad for v in leaves], pnames)
     p_eager = tr.pflat.clone()
 
     model_g = make().cuda().train()
