@@ -260,6 +260,22 @@ int otvae_nelbo_fwd(const float* pred, const float* target, int64_t numel, const
 int otvae_nelbo_bwd(const float* pred, const float* target, int64_t numel, int B, float chw,
                     const float* gout, float* gpred, float* gprior, void* stream);
 
+/* ---- ConvLayer activations other than ReLU, and equalized_lr (networks/cnn.py:114-118,128-147,186-188) -----------
+ * kind: 0 identity, 1 ReLU, 2 LeakyReLU(0.2), 3 SELU, 4 GELU (erf form), 5 SiLU.  x, out, ga, gv: [M][C] channels-last.
+ * The fused convolution kernels carry ReLU only; these run unfused around them (csrc/activation.hip). */
+/* out = act(x * scale[c] + shift[c]); scale == shift == NULL: out = act(x) */
+int otvae_bn_act_fwd(const float* x, const float* scale, const float* shift, int kind, int64_t M, int C, float* out,
+                     void* stream);
+/* blocks (= partial sums per channel) otvae_bn_act_bwd uses for M rows */
+int otvae_bn_act_bwd_parts(int64_t M);
+/* gv = ga * act'(x * scale + shift).  With mean / invstd (training-mode BatchNorm in front of the activation) also the
+ * BatchNorm-backward sums per block, partial[2][C][P] (fp64) = {sum gv, sum gv * (x - mean) * invstd}: the layout
+ * otvae_bn_bwd_finalize reads (its CsPad = C). */
+int otvae_bn_act_bwd(const float* ga, const float* x, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, int kind, int64_t M, int C, float* gv, double* partial, void* stream);
+/* dst[i] = alpha * src[i], n contiguous floats (weight * conv_scale * lr_mult, bias * lr_mult and their gradients) */
+int otvae_scale_f32(const float* src, float alpha, int64_t n, float* dst, void* stream);
+
 /* ---- Adam (model/vae.py:148-151; torch.optim.Adam defaults) over one flat buffer --------------------------- */
 /* hyper (device): float[4] = {lr, beta1, beta2, eps}; step (device int32) is the 1-based count of THIS update
  * (incremented by otvae_step_begin). grad_scale multiplies g first (1/world_size for data-parallel means). */

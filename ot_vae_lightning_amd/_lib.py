@@ -89,6 +89,10 @@ SIGNATURES = {
     "otvae_nelbo_ws": (i32, []),
     "otvae_nelbo_fwd": (i32, [vp, vp, i64, vp, i32, f32, vp, vp, vp]),
     "otvae_nelbo_bwd": (i32, [vp, vp, i64, i32, f32, vp, vp, vp, vp]),
+    "otvae_bn_act_fwd": (i32, [vp, vp, vp, i32, i64, i32, vp, vp]),
+    "otvae_bn_act_bwd_parts": (i32, [i64]),
+    "otvae_bn_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, vp]),
+    "otvae_scale_f32": (i32, [vp, f32, i64, vp, vp]),
     "otvae_step_begin": (i32, [vp, vp]),
     "otvae_adam_step": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp]),
     "otvae_adam_step_dev": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),

@@ -110,6 +110,10 @@ class GraphedNelbo:
             engine._collect_loose_grads()
             for p in engine.params:    # the captured pass's own p.grad objects must not outlive the capture
                 p.grad = None
+            # nor may the model's handles keep this pass's autograd graph -- and its AccumulateGrad nodes, bound to the stream
+            # they were created on -- alive into the next one (warm-up stream -> capture stream)
+            model._last_cut = None
+            model._last_nelbo = None
 
         # everything a step mutates besides what the optimizer owns: restored after warm-up + capture
         flat_ids = {id(p) for p in engine.params}

@@ -594,14 +594,117 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
     return (dx if need_dx else None), per
 
 
+# ---- activations other than ReLU, equalized_lr (reference networks/cnn.py:114-118,128-147,186-188): unfused around the kernels
+ACT_KINDS = {None: 0, "relu": 1, "leaky": 2, "selu": 3, "gelu": 4, "silu": 5}
+
+
+class _BnActFn(torch.autograd.Function):
+    """a = act(BatchNorm(x)) (or act(x)) as one element-wise kernel, with the BatchNorm backward of the fused path (the same
+    finalize / apply kernels) behind ``otvae_bn_act_bwd``.  ``stats`` = (mean, invstd, scale, shift, training) or None."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, stats, kind, params_ref):
+        lib = _lib.load()
+        n, c, h, w = x.shape
+        a = empty_nhwc(n, c, h, w, x)
+        scale, shift = (stats[2], stats[3]) if stats is not None else (None, None)
+        check(lib.otvae_bn_act_fwd(ptr(x), ptr(scale), ptr(shift), kind, n * h * w, c, ptr(a), stream()), "otvae_bn_act_fwd")
+        ctx.stats, ctx.kind, ctx.params_ref = stats, kind, params_ref
+        ctx.save_for_backward(x, gamma)
+        return a
+
+    @staticmethod
+    def backward(ctx, ga):
+        lib = _lib.load()
+        x, gamma = ctx.saved_tensors
+        n, c, h, w = x.shape
+        m = n * h * w
+        ga = as_nhwc(ga)
+        gv = empty_nhwc(n, c, h, w, x)
+        stats = ctx.stats
+        if stats is None:
+            check(lib.otvae_bn_act_bwd(ptr(ga), ptr(x), None, None, None, None, ctx.kind, m, c, ptr(gv), None, stream()),
+                  "otvae_bn_act_bwd")
+            return gv, None, None, None, None, None
+        mean, invstd, scale, shift, training = stats
+        p = lib.otvae_bn_act_bwd_parts(m)
+        part = torch.empty((2, c, p), device=x.device, dtype=torch.float64)
+        check(lib.otvae_bn_act_bwd(ptr(ga), ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ctx.kind, m, c, ptr(gv),
+                                   ptr(part), stream()), "otvae_bn_act_bwd")
+        coef = torch.empty((3, c), device=x.device, dtype=torch.float32)
+        dgam = _grad_buffer(ctx.params_ref[0], gamma)
+        dbet = _grad_buffer(ctx.params_ref[1], gamma)
+        check(lib.otvae_bn_bwd_finalize(1, ptr_array([part]), (C.c_int * 1)(p), c, m, c, ptr(mean), ptr(invstd), ptr_array([gamma]),
+                                        ptr_array([dgam]), ptr_array([dbet]), ptr(coef), stream()), "otvae_bn_bwd_finalize")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if not training:
+                coef[:2].zero_()  # eval mode: BatchNorm is a fixed affine
+            dx = empty_nhwc(n, c, h, w, x)
+            check(lib.otvae_bn_bwd_apply(1, ptr_array([gv]), ptr(x), ptr(coef), m, c, ptr(dx), stream()), "otvae_bn_bwd_apply")
+        return dx, dgam, dbet, None, None, None
+
+
+class _ScaleFn(torch.autograd.Function):
+    """alpha * t on t's own memory order (the ``weight * conv_scale * lr_mult`` / ``bias * lr_mult`` of equalized_lr)"""
+
+    @staticmethod
+    def forward(ctx, t, alpha):
+        ctx.alpha = alpha
+        out = torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype)
+        check(_lib.load().otvae_scale_f32(ptr(t), alpha, t.numel(), ptr(out), stream()), "otvae_scale_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g.stride() != tuple(g.stride()) or not g.is_non_overlapping_and_dense():
+            g = g.contiguous()
+        out = torch.empty_strided(g.shape, g.stride(), device=g.device, dtype=g.dtype)
+        check(_lib.load().otvae_scale_f32(ptr(g), ctx.alpha, g.numel(), ptr(out), stream()), "otvae_scale_f32")
+        return out, None
+
+
+def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
+    """One ConvLayer whose activation is not ReLU and / or whose weight and bias carry the equalized_lr multipliers: BatchNorm
+    statistics (the fused path's kernels) -> ``_BnActFn`` -> the fused convolution kernels with neither BatchNorm nor activation."""
+    kind = int(br.get("act", 1 if br["relu"] else 0))
+    has_norm = br.get("gamma") is not None
+    stats = None
+    if has_norm:
+        bn = BNBranch(br["gamma"], br["beta"], br.get("running_mean"), br.get("running_var"), br.get("num_batches_tracked"))
+        if training:
+            mean, invstd, sc, sh = bn_batch_stats(x, [bn])
+        else:
+            mean, invstd, s0, h0 = bn_eval_affine(bn)
+            sc, sh = [s0], [h0]
+        stats = (mean, invstd, sc[0], sh[0], training)
+    a = x
+    if has_norm or kind != 0:
+        a = _BnActFn.apply(x, br.get("gamma"), br.get("beta"), stats, kind, (br.get("gamma"), br.get("beta")))
+    w = br["weight"]
+    w = w if is_hwio(w) else hwio_weight(w)
+    bias = br.get("bias")
+    ws, bs = float(br.get("wscale", 1.0)), float(br.get("bscale", 1.0))
+    if ws != 1.0:
+        w = _ScaleFn.apply(w, ws)
+    if bias is not None and bs != 1.0:
+        bias = _ScaleFn.apply(bias, bs)
+    plain = dict(weight=w, bias=bias, residual=br.get("residual"), stride=br["stride"], pad=br["pad"], up=br["up"], relu=False,
+                 out_stats=br.get("out_stats", False))
+    return conv_layers(a, [plain], training=training)[0]
+
+
 def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
     """Runs 1 or 2 ConvLayer branches on the same input.  Each branch dict has:
     weight (OIHW/HWIO), bias|None, gamma|None, beta|None, running_mean/var/num_batches_tracked|None,
-    residual|None, stride, pad, up, relu.  Returns one tensor per branch (logical NCHW, NHWC memory)."""
+    residual|None, stride, pad, up, relu (+ optionally act: an ACT_KINDS value, wscale, bscale: see ``_conv_layer_general``).
+    Returns one tensor per branch (logical NCHW, NHWC memory)."""
     _lib.require_cuda(x, "conv input")
     x = as_nhwc(x)
     if x.dtype != torch.float32:
         raise TypeError("the MI355X conv path computes in fp32")
+    if any(br.get("act", 0) > 1 or br.get("wscale", 1.0) != 1.0 or br.get("bscale", 1.0) != 1.0 for br in branches):
+        return tuple(_conv_layer_general(x, br, training) for br in branches)
     specs, tensors, params_ref, bns = [], [], [], []
     for br in branches:
         w = br["weight"]

@@ -7,9 +7,10 @@ is execution: a ConvLayer is ONE fused kernel (BatchNorm-apply + ReLU + nearest 
 [+ residual add]) fed by a statistics pass shared between a block's first layer and its skip branch, activations
 stay channels-last between layers, and attention never materialises the TxT matrix.
 
-Options the reference implements but no BASELINE configuration uses (group/instance norm, non-ReLU activations,
-equalised learning rate, FiLM embeddings, dropout, grouped/dilated convolutions) are rejected with
-``NotImplementedError`` rather than silently run on another path.
+Activations other than ReLU (LeakyReLU(0.2), SELU, GELU, SiLU) and ``equalized_lr`` -- what the reference's
+configs/vae/defaults_imagenet.yaml trains with -- run unfused around the same kernels (functional._conv_layer_general,
+csrc/activation.hip).  Options no configuration of the reference uses on this path (group/instance norm, FiLM embeddings,
+dropout, grouped/dilated convolutions) are rejected with ``NotImplementedError`` rather than silently run elsewhere.
 """
 import math
 import warnings
@@ -46,8 +47,6 @@ class ConvLayer(nn.Module):
             raise NotImplementedError("module-valued down_sample/up_sample are not supported on the MI355X path")
         if bool(additional_embed):
             raise NotImplementedError("additional_embed (FiLM conditioning) is not supported on the MI355X path")
-        if equalized_lr:
-            raise NotImplementedError("equalized_lr is not supported on the MI355X path")
         if dropout and dropout > 0:
             raise NotImplementedError("dropout > 0 is not supported on the MI355X path")
         kernel_size = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
@@ -98,16 +97,33 @@ class ConvLayer(nn.Module):
         else:
             raise NotImplementedError(f"normalization={normalization} not supported")
 
+        # activation + its weight initialisation, in the reference's order of tests (cnn.py:128-147)
+        self._act_kind = 0
         if _is_none(activation):
             self._activation = nn.Identity()
-        elif "leaky" in activation.lower() or "selu" in activation.lower() or "gelu" in activation.lower() \
-                or "silu" in activation.lower() or "swish" in activation.lower():
-            raise NotImplementedError(f"activation={activation} is not supported on the MI355X path")
+        elif "leaky" in activation.lower():
+            self._activation, self._act_kind = nn.LeakyReLU(0.2), HF.ACT_KINDS["leaky"]
+            nn.init.kaiming_uniform_(w0, a=0.2, mode="fan_in", nonlinearity="leaky_relu")
         elif "relu" in activation.lower():
-            self._activation = nn.ReLU()
+            self._activation, self._act_kind = nn.ReLU(), HF.ACT_KINDS["relu"]
             nn.init.kaiming_uniform_(w0, mode="fan_out", nonlinearity="relu")
+        elif "selu" in activation.lower():
+            self._activation, self._act_kind = nn.SELU(), HF.ACT_KINDS["selu"]
+            nn.init.xavier_uniform_(w0, gain=nn.init.calculate_gain("selu"))
+        elif "gelu" in activation.lower():
+            self._activation, self._act_kind = nn.GELU(), HF.ACT_KINDS["gelu"]
+            nn.init.xavier_uniform_(w0, gain=nn.init.calculate_gain("linear"))
+        elif "silu" in activation.lower() or "swish" in activation.lower():
+            self._activation, self._act_kind = nn.SiLU(), HF.ACT_KINDS["silu"]
+            nn.init.xavier_uniform_(w0, gain=nn.init.calculate_gain("linear"))
         else:
             raise NotImplementedError(f"activation={activation} not supported")
+        # equalized learning rate (cnn.py:114-118,149-158,186-188): N(0, 1/lr_mult) weights, the forward pass multiplies the
+        # weight by gain / sqrt(fan_in) * lr_mult and the bias by lr_mult
+        self._lr_mult, self._gain = equalized_lr or 1, 1
+        self._conv_scale = self._gain / math.sqrt(in_features * kernel_size * kernel_size) if equalized_lr else 1
+        if equalized_lr:
+            nn.init.normal_(w0, std=1 / self._lr_mult)
         with torch.no_grad():
             self.weight.copy_(w0)
 
@@ -124,7 +140,8 @@ class ConvLayer(nn.Module):
                     running_var=bn.running_var if bn is not None else None,
                     num_batches_tracked=bn.num_batches_tracked if bn is not None else None,
                     residual=residual, stride=self.stride[0], pad=self.padding[0], up=self._up,
-                    relu=isinstance(self._activation, nn.ReLU), out_stats=out_stats)
+                    relu=isinstance(self._activation, nn.ReLU), act=self._act_kind,
+                    wscale=float(self._conv_scale * self._lr_mult), bscale=float(self._lr_mult), out_stats=out_stats)
 
     def forward(self, x: Tensor, embed: Optional[Tensor] = None, *, residual: Optional[Tensor] = None,
                 out_stats: bool = True) -> Tensor:
