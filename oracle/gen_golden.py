@@ -76,6 +76,15 @@ CONV_CASES = [
     ("skip_up", "Conv1x1", 16, 8, 4, dict(up_sample=2, normalization="batchnorm")),
     ("skip_up1", "Conv1x1", 8, 1, 16, dict(up_sample=2, normalization="batchnorm")),
     ("nonorm_relu", "ConvLayer", 4, 8, 8, dict(activation="relu")),
+    # the options configs/vae/defaults_imagenet.yaml:26-27 turns on (activation: leaky, equalized_lr: 1.) and the other
+    # activations of cnn.py:128-147; equalized_lr = 2 / 0.5 so that weight * conv_scale * lr_mult and bias * lr_mult both show
+    ("leaky_eq", "ConvLayer", 8, 8, 8, dict(normalization="batchnorm", activation="leaky", equalized_lr=1.)),
+    ("leaky_down_eq2", "ConvLayer", 3, 8, 16, dict(down_sample=2, normalization="batchnorm", activation="leaky_relu", equalized_lr=2.)),
+    ("selu_down", "ConvLayer", 4, 8, 8, dict(down_sample=2, normalization="batchnorm", activation="selu")),
+    ("gelu_up", "ConvLayer", 8, 4, 4, dict(up_sample=2, normalization="batchnorm", activation="gelu")),
+    ("silu_nonorm", "ConvLayer", 4, 8, 8, dict(activation="silu")),
+    ("swish_bn_1ch", "ConvLayer", 1, 4, 16, dict(normalization="batchnorm", activation="swish")),
+    ("eq_1x1", "Conv1x1", 8, 24, 8, dict(normalization="batchnorm", equalized_lr=0.5)),
 ]
 
 
@@ -155,6 +164,31 @@ def gen_cnn_small():
                 if not k.endswith("num_batches_tracked"):
                     out[f"{tag}/{nm}/buf/{k}"] = npy(b)
     save("cnn_small.npz", out)
+
+
+def gen_cnn_small_opts():
+    """The same small encoder / decoder with the options of the reference's configs/vae/defaults_imagenet.yaml:26-27
+    (``activation: leaky``, ``equalized_lr: 1.``; residual "add"): every ConvLayer, Conv1x1 and AttentionBlock of the network
+    runs the multipliers of cnn.py:114-118,186-188 and LeakyReLU(0.2) in place of ReLU."""
+    cnn = R.ref("networks.cnn")
+    out = {}
+    kw = dict(capacity=2, residual="add", activation="leaky", equalized_lr=1.0)
+    enc = cnn.CNN(1, 16, 16, 1, down_sample=True, **kw)
+    dec = cnn.CNN(8, 1, 1, 16, up_sample=True, **kw)
+    for net, nm, xin in ((enc, "enc", det_input((3, 1, 16, 16), 0.2)), (dec, "dec", det_input((3, 8, 1, 1), 0.9))):
+        net.train()
+        fill_state_dict(net.state_dict())
+        x = xin.clone().requires_grad_(True)
+        y = net(x)
+        g = det_input(tuple(y.shape), 1.7, 0.5)
+        y.backward(g)
+        out[f"{nm}/x"], out[f"{nm}/y"], out[f"{nm}/gy"], out[f"{nm}/gx"] = npy(x), npy(y), npy(g), npy(x.grad)
+        for k, p in net.named_parameters():
+            out[f"{nm}/grad/{k}"] = npy(p.grad)
+        for k, b in net.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                out[f"{nm}/buf/{k}"] = npy(b)
+    save("cnn_small_opts.npz", out)
 
 
 # ------------------------------------------------------------------------------------------------ G4
@@ -1120,6 +1154,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts"]
     for w in which:
         globals()["gen_" + w]()

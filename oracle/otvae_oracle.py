@@ -98,17 +98,26 @@ def cnn_arch(in_features: int, out_features: int, in_resolution: int, out_resolu
 # ------------------------------------------------------------------------------------------------
 # layers
 # ------------------------------------------------------------------------------------------------
+_ACTIVATIONS = {  # cnn.py:128-147 (the reference tests the names in this order: "leaky" before "relu")
+    "leaky": lambda t: F.leaky_relu(t, 0.2), "relu": F.relu, "selu": F.selu, "gelu": F.gelu, "silu": F.silu,
+}
+
+
 def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: bool, relu: bool,
-               norm: bool, ksize: int = 3, training: bool = True) -> Tensor:
+               norm: bool, ksize: int = 3, training: bool = True, act: Optional[str] = None,
+               equalized_lr: Optional[float] = None) -> Tensor:
     """``ConvLayer.forward`` (networks/cnn.py:183-192): BN -> act -> nearest x2 up -> conv (stride-2 4x4 when
     down-sampling, cnn.py:98-101).  ``p[prefix+'_normalization.running_*']`` are updated in place like
-    nn.BatchNorm2d does in training mode."""
+    nn.BatchNorm2d does in training mode.  ``act``: one of leaky / relu / selu / gelu / silu (overrides ``relu``);
+    ``equalized_lr``: weight * (1 / sqrt(fan_in)) * lr_mult, bias * lr_mult (cnn.py:114-118,186-188)."""
     out = x
     if norm:
         out = F.batch_norm(out, p[prefix + "_normalization.running_mean"], p[prefix + "_normalization.running_var"],
                            p[prefix + "_normalization.weight"], p[prefix + "_normalization.bias"],
                            training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
-    if relu:
+    if act is not None:
+        out = _ACTIVATIONS[act](out)
+    elif relu:
         out = F.relu(out)
     if up:
         out = F.interpolate(out, scale_factor=2.0, mode="nearest")
@@ -119,7 +128,11 @@ def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: 
         k, stride, pad = ksize, 1, (1 if ksize == 3 else 0)
     w = p[prefix + "weight"]
     assert w.shape[-1] == k, (prefix, w.shape, k)
-    return F.conv2d(out, w, p.get(prefix + "bias"), stride=stride, padding=pad)
+    bias = p.get(prefix + "bias")
+    if equalized_lr:
+        w = w * (1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])) * equalized_lr
+        bias = bias * equalized_lr if bias is not None else None
+    return F.conv2d(out, w, bias, stride=stride, padding=pad)
 
 
 def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:

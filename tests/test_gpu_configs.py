@@ -431,7 +431,7 @@ def test_error_behaviour(A):
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, normalization="groupnorm")
     with pytest.raises(NotImplementedError):
-        A.ConvLayer(4, 4, activation="gelu")
+        A.ConvLayer(4, 4, activation="tanh")           # not among the reference's activations either (cnn.py:147)
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, normalization="whatever")
     with pytest.raises(ValueError):

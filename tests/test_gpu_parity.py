@@ -136,6 +136,14 @@ CONV_CTOR = {
     "skip_up": ("Conv1x1", dict(up_sample=2, normalization="batchnorm")),
     "skip_up1": ("Conv1x1", dict(up_sample=2, normalization="batchnorm")),
     "nonorm_relu": ("ConvLayer", dict(activation="relu")),
+    # configs/vae/defaults_imagenet.yaml:26-27 (leaky + equalized_lr) and the other activations of cnn.py:128-147
+    "leaky_eq": ("ConvLayer", dict(normalization="batchnorm", activation="leaky", equalized_lr=1.)),
+    "leaky_down_eq2": ("ConvLayer", dict(down_sample=2, normalization="batchnorm", activation="leaky_relu", equalized_lr=2.)),
+    "selu_down": ("ConvLayer", dict(down_sample=2, normalization="batchnorm", activation="selu")),
+    "gelu_up": ("ConvLayer", dict(up_sample=2, normalization="batchnorm", activation="gelu")),
+    "silu_nonorm": ("ConvLayer", dict(activation="silu")),
+    "swish_bn_1ch": ("ConvLayer", dict(normalization="batchnorm", activation="swish")),
+    "eq_1x1": ("Conv1x1", dict(normalization="batchnorm", equalized_lr=0.5)),
 }
 
 
@@ -192,6 +200,32 @@ def test_cnn_small_vs_reference_golden(A, residual):
         nets.append(("dec", lambda: A.CNN(8, 1, 1, 16, capacity=cap, up_sample=True, residual=res)))
     for nm, make in nets:
         g = group(z, f"{residual}/{nm}")
+        net = make()
+        fill_state_dict(net.state_dict())
+        net = net.cuda().train()
+        x = g["x"].cuda().requires_grad_(True)
+        y = net(x)
+        y.backward(g["gy"].cuda())
+        rep.check(f"{nm}/y", y, g["y"])
+        rep.check(f"{nm}/gx", x.grad, g["gx"], tol=2e-4)
+        gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith("grad/"))
+        for k, p in net.named_parameters():
+            rep.check(f"{nm}/grad/{k}", p.grad, g[f"grad/{k}"], tol=5e-4, floor=3e-3 * gscale)
+        for k, b in net.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                rep.check(f"{nm}/buf/{k}", b, g[f"buf/{k}"])
+    rep.finish()
+
+
+def test_cnn_leaky_equalized_lr_vs_reference_golden(A):
+    """a whole encoder / decoder with ``activation="leaky", equalized_lr=1.`` (the reference's
+    configs/vae/defaults_imagenet.yaml:26-27) against the reference's own CNN: outputs, input gradient, every parameter gradient
+    and the BatchNorm running buffers."""
+    z = load_golden("cnn_small_opts.npz")
+    rep = Report("CNN capacity 2, residual=add, activation=leaky, equalized_lr=1 vs reference golden")
+    kw = dict(capacity=2, residual="add", activation="leaky", equalized_lr=1.0)
+    for nm, make in (("enc", lambda: A.CNN(1, 16, 16, 1, down_sample=True, **kw)), ("dec", lambda: A.CNN(8, 1, 1, 16, up_sample=True, **kw))):
+        g = group(z, nm)
         net = make()
         fill_state_dict(net.state_dict())
         net = net.cuda().train()

@@ -24,20 +24,26 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
     "proj": (False, False, False, False, 1), "skip_down": (True, False, False, True, 1),
     "skip_up": (False, True, False, True, 1), "skip_up1": (False, True, False, True, 1),
     "nonorm_relu": (False, False, True, False, 3),
+    # (..., activation, equalized_lr): the non-ReLU activations and equalized_lr of cnn.py:114-118,128-147
+    "leaky_eq": (False, False, False, True, 3, "leaky", 1.0), "leaky_down_eq2": (True, False, False, True, 3, "leaky", 2.0),
+    "selu_down": (True, False, False, True, 3, "selu", None), "gelu_up": (False, True, False, True, 3, "gelu", None),
+    "silu_nonorm": (False, False, False, False, 3, "silu", None), "swish_bn_1ch": (False, False, False, True, 3, "silu", None),
+    "eq_1x1": (False, False, False, True, 1, None, 0.5),
 }
 
 
 @pytest.mark.parametrize("name", sorted(CONV_GEOM))
 def test_conv_layer(name):
     g = group(load_golden("convlayer.npz"), name)
-    down, up, relu, norm, ks = CONV_GEOM[name]
+    down, up, relu, norm, ks, *opt = CONV_GEOM[name]
+    act, eq = opt if opt else (None, None)
     p = {k[len("param/"):]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("param/")}
     if norm:
         c = g["x"].shape[1]
         p["_normalization.running_mean"] = torch.zeros(c)
         p["_normalization.running_var"] = torch.ones(c)
     x = g["x"].clone().requires_grad_(True)
-    y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks)
+    y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks, act=act, equalized_lr=eq)
     y.backward(g["gy"])
     assert rel_err(y, g["y"]) < TIGHT
     assert rel_err(x.grad, g["gx"]) < TIGHT
