@@ -26,8 +26,10 @@ from torch import Tensor
 
 from .. import _lib
 from .._lib import check, ptr, stream
+from .. import functional as HF
 from ..networks.cnn import ConvLayer
 from .dp import FlatGradReducer
+from .segments import SEGMENT_CALLS, SegmentedStep
 
 __all__ = ["HipTrainer", "flatten_parameters"]
 
@@ -165,6 +167,7 @@ class HipTrainer:
         self.use_graph = use_graph
         self._graph_fb = None
         self._graph_opt = None
+        self._segments: Optional[SegmentedStep] = None
         self._captured = False
         self.n_steps = 0
 
@@ -402,6 +405,19 @@ class HipTrainer:
             self._graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_opt, pool=self._graph_fb.pool(), **mode):
                 self._adam()
+        elif self.world == 1 and not self.reducer.active and SEGMENT_CALLS > 0 and HF.WGRAD_SIDE_STREAM == 1:
+            # a chain of linear graphs + side graphs instead of one graph with a fork per layer (engine/segments.py)
+            self._graph_fb = None
+            side = HF._PendingReduce.side_stream(self.device)
+            self._segments = SegmentedStep(self.device, side)
+            HF._PendingReduce.begin_segments(self.device, self._segments, may_cut=lambda: not HF.PriorLane.is_open(self.device))
+            try:
+                with self._segments:
+                    logs = self._forward_backward()   # its backward pass cuts the graph and ends with a joining cut
+                    self._adam()
+                    self._out_static = self._loss_vector(logs)
+            finally:
+                HF._PendingReduce.end_segments(self.device)
         elif self.world == 1 and not self.reducer.active:
             with torch.cuda.graph(self._graph_fb, **mode):
                 logs = self._forward_backward()
@@ -457,7 +473,10 @@ class HipTrainer:
         if self.use_graph and not annealing:  # the annealing coefficient is a kernel argument: not replayable
             if not self._captured:
                 self.capture()
-            self._graph_fb.replay()
+            if self._segments is not None:
+                self._segments.replay()
+            else:
+                self._graph_fb.replay()
             if self.dp_overlap:
                 self.reducer.allreduce_range(*self._dec_range, wait=False)  # side stream, under the encoder's backward
                 self._graph_b2.replay()
@@ -487,6 +506,9 @@ class HipTrainer:
             self.reducer.stream.synchronize()
         torch.cuda.synchronize(self.device)
         self._graph_fb = self._graph_b2 = self._graph_opt = None
+        if self._segments is not None:
+            self._segments.release()
+            self._segments = None
         self._out_static = None
         self._cut = None
         self._logs = None

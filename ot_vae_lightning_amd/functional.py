@@ -212,15 +212,69 @@ class _PendingReduce:
 
     @staticmethod
     def fork_point(device):
+        if device in _PendingReduce._segment:
+            return True  # segmented capture: the order between the streams is set between graph launches, not by an event here
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         return ev
+
+    # Segmented capture (engine/segments.py): while a SegmentedStep is capturing on `device` the queued jobs are not launched from
+    # a fork inside the capture; they accumulate into the segment's side work, and every `segment_calls` backward calls the
+    # launch stream's graph is cut there.  _segment[device] = [SegmentedStep, jobs, reduce entries, backward calls, may_cut()]
+    _segment = {}
+
+    @staticmethod
+    def begin_segments(device, step, may_cut=None) -> None:
+        _PendingReduce._segment[device] = [step, [], [], 0, may_cut]
+
+    @staticmethod
+    def end_segments(device) -> None:
+        _PendingReduce._segment.pop(device, None)
+
+    @staticmethod
+    def _segment_work(jobs, entries):
+        """closure issuing one segment's weight-gradient jobs + the partial reductions of its layers on the current stream"""
+        n = len(jobs)
+        arr = (_lib.ConvJob * n)(*jobs) if n else None
+
+        def work():
+            if n:
+                check(_lib.load().otvae_conv_multi(n, arr, stream()), "otvae_conv_multi(backward, weights, segment)")
+            if entries:
+                _PendingReduce._reduce(entries, stream())
+        return work
+
+    @staticmethod
+    def _segment_close(device, final: bool) -> None:
+        seg = _PendingReduce._segment[device]
+        step, jobs, entries, _, may_cut = seg
+        if not final and may_cut is not None and not may_cut():
+            return  # a forked lane of the capture is still open (the prior's): this graph cannot end here
+        st, done = _PendingReduce._state.get(device, []), _PendingReduce._reduced.get(device, 0)
+        entries = entries + st[done:]
+        _PendingReduce._reduced[device] = len(st)
+        work = _PendingReduce._segment_work(list(jobs), list(entries)) if (jobs or entries) else None
+        seg[1], seg[2], seg[3] = [], [], 0
+        step.cut(work, join=final)
 
     @staticmethod
     def issue(device, ev):
         """Launches the queued weight-gradient jobs on the side stream, ordered after the launch stream's work up to ``ev``."""
         q = _PendingReduce._wq.get(device)
         if not q or not q[0]:
+            return
+        seg = _PendingReduce._segment.get(device)
+        if seg is not None:
+            from .engine.segments import SEGMENT_CALLS
+            seg[1].extend(q[0])
+            seg[3] += q[1]
+            if JOB_TRACE is not None:
+                n_ = len(q[0])
+                _trace_jobs((_lib.ConvJob * n_)(*q[0]), n_)
+            q[0].clear()
+            q[1] = 0
+            if seg[3] >= SEGMENT_CALLS:
+                _PendingReduce._segment_close(device, final=False)
             return
         side = _PendingReduce.side_stream(device)
         side.wait_event(ev)
@@ -289,6 +343,17 @@ class _PendingReduce:
         q = _PendingReduce._wq.get(device)
         if q and q[0]:  # the tail of the backward pass
             _PendingReduce.issue(device, _PendingReduce.fork_point(device))
+        seg = _PendingReduce._segment.get(device)
+        if seg is not None:
+            # the last segment's side work; the launch stream's next graph (the optimizer's) starts behind the side stream.  The
+            # tensors the side graphs touch stay held until the step's capture is over (SegmentedStep.__exit__ captures them)
+            _PendingReduce._segment_close(device, final=True)
+            _PendingReduce._reduced[device] = 0
+            st.clear()
+            seg[0]._held = list(held) if held else []
+            if held:
+                held.clear()
+            return
         if _PendingReduce._forked.get(device):  # join: the partials below are complete once the side stream's jobs are
             for side in _PendingReduce._side[device][0]:
                 torch.cuda.current_stream(device).wait_stream(side)

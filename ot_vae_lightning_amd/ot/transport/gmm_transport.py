@@ -5,6 +5,8 @@ the target component ('argmax' / 'sample') and applies the closed-form Gaussian 
 components to each input; 'barycenter' moves every input to the W2 barycentre of ALL target components weighted by its
 coupled assignment (``gaussian_barycenter``).  Diagonal or full covariances (``transport_cfg['diag']``)."""
 import torch
+
+from ..matrix_utils import mm
 import torch.nn.functional as F
 from torch import Tensor
 from torch.distributions import Categorical
@@ -47,7 +49,7 @@ class GMMTransport(TransportOperator, W2Mixin):
             raise RuntimeError("call `compute()` before `transport()`")
         assignments, _, _ = self.source_model.assign(inputs.to(self.dtype))                 # [*, B, K_s]
         source_means, source_vars = self.source_model.predict_mean_var(assignments)
-        moved = assignments.type_as(self.transport_matrix) @ self.transport_matrix          # [*, B, K_t]
+        moved = mm(assignments.type_as(self.transport_matrix).contiguous(), self.transport_matrix)   # [*, B, K_t], otvae_gemm_*
         if self.transport_type == "barycenter":
             # a smooth interpolation of all the target components, weighted by each input's coupled assignment
             # (gmm_transport.py:103-110); `barycenter_init` fixes the start of the full-covariance fixed point (parity tests)

@@ -70,7 +70,8 @@ class ConditionalGaussianPrior(GaussianPrior, utils.DDPMixin):
         n = q.mean[0].numel()
         rows = torch.cat([q.mean.flatten(1), q.stddev.log().flatten(1), q.mean.new_ones(labels.numel(), 1)], dim=1)
         member = (torch.arange(self.num_classes, device=labels.device).unsqueeze(1) == labels.unsqueeze(0)).type_as(rows)
-        sums = self.reduce(member @ rows)                                             # [classes, 2n+1]
+        from ..ot.matrix_utils import mm
+        sums = self.reduce(mm(member.contiguous(), rows.contiguous()))                # [classes, 2n+1], otvae_gemm_f32
         return sums[:, 2 * n], sums[:, :n], sums[:, n:2 * n]
 
     @torch.no_grad()

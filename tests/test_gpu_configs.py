@@ -916,6 +916,50 @@ def test_graphed_nelbo_gives_the_unmodified_loop_the_graph_route(A):
     tr.close()
 
 
+@pytest.mark.parametrize("prior_kind", ["gaussian", "sinkhorn"])
+def test_segmented_capture_equals_forked_capture(A, prior_kind, monkeypatch):
+    """the captured step as a chain of linear hipGraphs + side graphs ordered by events between graph launches
+    (engine/segments.py) against the single graph with one fork per layer (round 2) and against the eagerly issued step: same
+    kernels, same order per stream -> bit-identical losses, gradients and parameters over several steps (different segment
+    lengths included; with the Sinkhorn prior the first cut has to wait for the prior lane's join)."""
+    from ot_vae_lightning_amd.engine import segments, trainer as trainer_mod
+    B = 128
+    xs = [mnist_like(B, 130 + i).cuda() for i in range(3)]
+    es = [normal((B, 128, 1, 1), 140 + i).cuda() for i in range(3)]
+
+    def run(seg_calls, graph=True):
+        monkeypatch.setattr(segments, "SEGMENT_CALLS", seg_calls)
+        monkeypatch.setattr(trainer_mod, "SEGMENT_CALLS", seg_calls)
+        torch.manual_seed(31)
+        dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+        if prior_kind == "gaussian":
+            enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+            prior = A.GaussianPrior(loss_coeff=0.1)
+        else:
+            enc = A.CNN(1, 128, 32, 1, capacity=8, down_sample=True, residual="add")
+            prior = A.SinkhornPrior(reg=0.05, max_iter=50, threshold=0.0, seed=9)
+        model = A.VAE(encoder=enc, decoder=dec, prior=prior).cuda().train()
+        tr = A.HipTrainer(model, batch_shape=(B, 1, 32, 32), use_graph=graph)
+        outs = [tr.step(x, e).clone() for x, e in zip(xs, es)]
+        torch.cuda.synchronize()
+        if graph:
+            assert (tr._segments is not None) == (seg_calls > 0)
+            if seg_calls > 0:
+                assert len(tr._segments.main) >= 3 and any(g is not None for g in tr._segments.side)
+        res = (torch.stack(outs), tr.gflat.clone(), tr.pflat.clone())
+        tr.close()
+        return res
+
+    forked = run(0)
+    for calls in (6, 2, 50):
+        seg = run(calls)
+        for name, a, b in zip(("losses", "gradients", "parameters"), seg, forked):
+            assert torch.equal(a, b), f"{prior_kind}: {name} differ between {calls}-call segments and the forked graph"
+    eager = run(6, graph=False)
+    for name, a, b in zip(("losses", "gradients", "parameters"), eager, forked):
+        assert torch.equal(a, b), f"{prior_kind}: {name} differ between the eager step and the captured one"
+
+
 def test_gradient_clipping_matches_clip_grad_norm(A):
     """Global-norm clipping of the step (reference configs/ddp.yaml:4 -> Lightning -> torch.nn.utils.clip_grad_norm_): the
     norm the kernel reports, the coefficient and the clipped Adam update against torch arithmetic on the same gradient."""
