@@ -238,6 +238,14 @@ int otvae_gaussian_prior_fwd(const float* h, const float* eps, int B, int S, int
                              float* z, float* loss, void* stream);
 int otvae_gaussian_prior_bwd(const float* h, const float* eps, const float* gz, const float* gloss,
                              int B, int S, int D, float coeff, float* gh, void* stream);
+/* the options of GaussianPrior (prior/gaussian.py:38-41,63-96; prior/base.py:65-68).  mode bit 0: empirical_kl -- the
+ * Monte-Carlo estimate sum log q(z) - log p(z) at the drawn z instead of the closed form; bit 1: fixed_var -- q = N(h, s) with
+ * s = 1, or temp[b] + 1e-8 when a per-sample temperature temp[B] is given (`time` of encode); h is then [B][S][D] (no
+ * log-variance half).  mode 0 = otvae_gaussian_prior_fwd / _bwd. */
+int otvae_gaussian_prior_ex_fwd(const float* h, const float* eps, const float* temp, int B, int S, int D, float coeff, int mode,
+                                float* z, float* loss, void* stream);
+int otvae_gaussian_prior_ex_bwd(const float* h, const float* eps, const float* temp, const float* gz, const float* gloss, int B,
+                                int S, int D, float coeff, int mode, float* gh, void* stream);
 
 /* ---- ConditionalGaussianPrior (prior/conditional_gaussian.py:84-93): the same re-parametrisation against a per-sample
  * diagonal prior N(prior_mean, exp(prior_log_std)^2) (rows of the class embeddings gathered by label).  h [B][2n]
@@ -275,6 +283,18 @@ int otvae_bn_act_bwd(const float* ga, const float* x, const float* scale, const 
                      const float* invstd, int kind, int64_t M, int C, float* gv, double* partial, void* stream);
 /* dst[i] = alpha * src[i], n contiguous floats (weight * conv_scale * lr_mult, bias * lr_mult and their gradients) */
 int otvae_scale_f32(const float* src, float alpha, int64_t n, float* dst, void* stream);
+
+/* ---- GaussianModel(update_with_autograd=True): log-density under N(mean, L L^T) / N(mean, diag(sigma^2))
+ * (ot/distribution_models/gaussian_model.py:52-55,76-93,125-128; torch.distributions.MultivariateNormal(scale_tril=) /
+ * Independent(Normal) in the reference).  fp64, x / y / qg [nb][B][D], mean [nb][D], L [nb][D][D] lower triangular with a
+ * positive diagonal (diag != 0: sigma [nb][D]), D <= 128. */
+/* y = L^-1 (x - mean); lp[nb][B] = -|y|^2 / 2 - sum_i log L_ii - D/2 log(2 pi) */
+int otvae_mvn_logprob_fwd(const double* x, const double* mean, const double* L, int nb, int B, int D, int diag, double* y,
+                          double* lp, void* stream);
+/* qg_b = g_b L^-T y_b (diag: g_b y_b / sigma): d mean = sum_b qg_b, d x_b = -qg_b,
+ * d L = tril(sum_b qg_b y_b^T) - (sum_b g_b) diag(1 / L_ii), formed by the caller with otvae_gemm_f64 */
+int otvae_mvn_logprob_bwd(const double* g, const double* y, const double* L, int nb, int B, int D, int diag, double* qg,
+                          void* stream);
 
 /* ---- Adam (model/vae.py:148-151; torch.optim.Adam defaults) over one flat buffer --------------------------- */
 /* hyper (device): float[4] = {lr, beta1, beta2, eps}; step (device int32) is the 1-based count of THIS update

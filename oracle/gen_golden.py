@@ -324,6 +324,26 @@ def gen_prior():
         out[f"{tag}/x"], out[f"{tag}/eps"], out[f"{tag}/z"], out[f"{tag}/loss"] = npy(x), npy(eps), npy(z), npy(loss)
         out[f"{tag}/gz"], out[f"{tag}/gl"], out[f"{tag}/gx"] = npy(gz), npy(gl), npy(x.grad)
         out[f"{tag}/cfg"] = np.array([kw.get("loss_coeff", 1.0), kw.get("annealing_steps", 0), step], dtype=np.float64)
+    # the options of prior/gaussian.py:38-41 (empirical_kl, fixed_var) and the temperature of encode(time=) (fixed_var only)
+    for tag, kw, use_time in (("empirical", dict(loss_coeff=0.3, empirical_kl=True), False),
+                              ("fixed_var", dict(loss_coeff=0.7, fixed_var=True), False),
+                              ("fixed_var_time", dict(loss_coeff=0.7, fixed_var=True), True),
+                              ("fixed_var_empirical", dict(loss_coeff=1.5, fixed_var=True, empirical_kl=True), True)):
+        prior = pg.GaussianPrior(**kw)
+        fixed = kw.get("fixed_var", False)
+        x = det_input((8, 128 if fixed else 256, 1, 1), 0.4, 0.8).requires_grad_(True)
+        eps = normal((8, 128, 1, 1), seed=8)
+        time = (0.2 + 0.1 * torch.arange(8, dtype=torch.float32)) if use_time else None
+        with _FixedEps(eps):
+            z, loss, art = prior(x, step=0, **({"time": time} if use_time else {}))
+        gz = det_input(tuple(z.shape), 2.2)
+        gl = det_input(tuple(loss.shape), 0.1)
+        (z * gz).sum().add((loss * gl).sum()).backward()
+        out[f"{tag}/x"], out[f"{tag}/eps"], out[f"{tag}/z"], out[f"{tag}/loss"] = npy(x), npy(eps), npy(z), npy(loss)
+        out[f"{tag}/gz"], out[f"{tag}/gl"], out[f"{tag}/gx"] = npy(gz), npy(gl), npy(x.grad)
+        if use_time:
+            out[f"{tag}/time"] = npy(time)
+        out[f"{tag}/cfg"] = np.array([kw.get("loss_coeff", 1.0), float(kw.get("empirical_kl", False)), float(fixed)], dtype=np.float64)
     save("prior.npz", out)
 
 

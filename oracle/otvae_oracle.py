@@ -209,6 +209,28 @@ def gaussian_prior_encode(x: Tensor, eps: Tensor, loss_coeff: float = 1.0, step:
     return z, kl * (loss_coeff * prior_annealing(step, annealing_steps))
 
 
+def gaussian_prior_encode_options(x: Tensor, eps: Tensor, loss_coeff: float = 1.0, empirical_kl: bool = False,
+                                  fixed_var: bool = False, time: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """``GaussianPrior.encode`` with ``empirical_kl`` / ``fixed_var`` (prior/gaussian.py:63-96) and ``Prior.empirical_reverse_kl``
+    (prior/base.py:65-68).  Note that the reference hands the STANDARD DEVIATION to ``Normal`` under the name ``var``."""
+    if fixed_var:
+        mu, sd = x, torch.ones_like(x)
+        if time is not None:
+            sd = sd * time.reshape(-1, *([1] * (x.dim() - 1))) + 1e-8
+    else:
+        mu, log_var = torch.chunk(x, 2, dim=1)
+        sd = (log_var / 2).exp()
+    z = mu + eps * sd
+    dims = list(range(1, mu.dim()))
+    if empirical_kl:
+        q, p = torch.distributions.Normal(mu, sd), torch.distributions.Normal(torch.zeros_like(mu), torch.ones_like(mu))
+        loss = (q.log_prob(z) - p.log_prob(z)).sum(dims)
+    else:
+        var = sd ** 2
+        loss = torch.sum(0.5 * (mu ** 2 + 0.0 - var.log() + var - 1), dim=dims)
+    return z, loss * loss_coeff
+
+
 def vae_nelbo(x: Tensor, eps: Tensor, enc: Dict[str, Tensor], dec: Dict[str, Tensor], enc_arch, dec_arch,
               loss_coeff: float = 1.0, step: int = 0, annealing_steps: int = 0, training: bool = True):
     """``VAE.nelbo`` with expansion=1 (model/vae.py:165-189): loss = mse(decode(z), x) + mean_B(prior)/(C*H*W)."""

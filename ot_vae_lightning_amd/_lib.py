@@ -84,6 +84,8 @@ SIGNATURES = {
     "otvae_dropout_bwd": (i32, [vp, vp, i64, i32, i32, f32, vp, vp, vp]),
     "otvae_gaussian_prior_fwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),
     "otvae_gaussian_prior_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
+    "otvae_gaussian_prior_ex_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp]),
+    "otvae_gaussian_prior_ex_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),
     "otvae_gaussian_prior_cond_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     "otvae_gaussian_prior_cond_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     "otvae_nelbo_ws": (i32, []),
@@ -93,6 +95,8 @@ SIGNATURES = {
     "otvae_bn_act_bwd_parts": (i32, [i64]),
     "otvae_bn_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, vp]),
     "otvae_scale_f32": (i32, [vp, f32, i64, vp, vp]),
+    "otvae_mvn_logprob_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "otvae_mvn_logprob_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "otvae_step_begin": (i32, [vp, vp]),
     "otvae_adam_step": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp]),
     "otvae_adam_step_dev": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),

@@ -64,6 +64,92 @@ extern "C" int otvae_gaussian_prior_bwd(const float* h, const float* eps, const 
     return OTVAE_OK;
 }
 
+// ---- GaussianPrior options (prior/gaussian.py:63-96, prior/base.py:65-68): mode bit 0 = empirical_kl (the Monte-Carlo estimate
+// sum log q(z) - log p(z) at the drawn z instead of the closed form), bit 1 = fixed_var (q = N(h, s), s = 1 or the per-sample
+// temperature + 1e-8; h carries no log-variance half: [B][S][D]).
+//   closed form:  0.5 (mu^2 - log s^2 + s^2 - 1)            empirical:  0.5 z^2 - 0.5 eps^2 - log s,   z = mu + s eps
+__global__ __launch_bounds__(256) void gaussian_prior_ex_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                                                    const float* __restrict__ temp, int S, int D, float coeff, int mode,
+                                                                    float* __restrict__ z, float* __restrict__ loss) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int n = S * D;
+    const bool emp = mode & 1, fixed = mode & 2;
+    const float* hb = h + (size_t)b * S * (fixed ? D : 2 * D);
+    const float sfix = temp ? temp[b] + 1e-8f : 1.f;
+    float kl = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int s = i / D, d = i - s * D;
+        float mu, sd, lsd;  // mean, standard deviation, its logarithm
+        if (fixed) {
+            mu = hb[i];
+            sd = sfix;
+            lsd = logf(sfix);
+        } else {
+            mu = hb[(size_t)s * 2 * D + d];
+            lsd = 0.5f * hb[(size_t)s * 2 * D + D + d];
+            sd = __expf(lsd);
+        }
+        const float e = eps[(size_t)b * n + i];
+        const float zz = fmaf(e, sd, mu);
+        z[(size_t)b * n + i] = zz;
+        kl += emp ? 0.5f * (zz * zz - e * e) - lsd : 0.5f * (mu * mu + sd * sd - 1.f) - lsd;
+    }
+    kl = wave_sum(kl);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kl;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[b] = coeff * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void gaussian_prior_ex_bwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                                                    const float* __restrict__ temp, const float* __restrict__ gz,
+                                                                    const float* __restrict__ gloss, int S, int D, float coeff,
+                                                                    int mode, float* __restrict__ gh) {
+    const int b = blockIdx.x;
+    const int n = S * D;
+    const bool emp = mode & 1, fixed = mode & 2;
+    const size_t row = (size_t)S * (fixed ? D : 2 * D);
+    const float* hb = h + (size_t)b * row;
+    float* gb = gh + (size_t)b * row;
+    const float sfix = temp ? temp[b] + 1e-8f : 1.f;
+    const float gl = (gloss ? gloss[b] : 0.f) * coeff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int s = i / D, d = i - s * D;
+        const float e = eps[(size_t)b * n + i];
+        const float g = gz ? gz[(size_t)b * n + i] : 0.f;
+        if (fixed) {
+            const float mu = hb[i];
+            gb[i] = fmaf(gl, emp ? fmaf(e, sfix, mu) : mu, g);
+        } else {
+            const float mu = hb[(size_t)s * 2 * D + d];
+            const float sd = __expf(0.5f * hb[(size_t)s * 2 * D + D + d]);
+            const float zz = fmaf(e, sd, mu);
+            // d z / d lv = eps sd / 2;  closed form: d KL / d mu = mu, d KL / d lv = (sd^2 - 1) / 2
+            // empirical: d L / d mu = z,  d L / d lv = z eps sd / 2 - 1/2
+            gb[(size_t)s * 2 * D + d] = fmaf(gl, emp ? zz : mu, g);
+            gb[(size_t)s * 2 * D + D + d] = 0.5f * (g * e * sd + gl * (emp ? zz * e * sd - 1.f : sd * sd - 1.f));
+        }
+    }
+}
+
+extern "C" int otvae_gaussian_prior_ex_fwd(const float* h, const float* eps, const float* temp, int B, int S, int D, float coeff,
+                                           int mode, float* z, float* loss, void* stream) {
+    OTVAE_REQUIRE(h && eps && z && loss && B > 0 && S > 0 && D > 0 && mode >= 0 && mode <= 3, "otvae_gaussian_prior_ex_fwd: bad argument");
+    OTVAE_REQUIRE(!temp || (mode & 2), "otvae_gaussian_prior_ex_fwd: a temperature goes with fixed_var (mode bit 1)");
+    gaussian_prior_ex_fwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(h, eps, temp, S, D, coeff, mode, z, loss);
+    OTVAE_CHECK_LAUNCH("otvae_gaussian_prior_ex_fwd");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_gaussian_prior_ex_bwd(const float* h, const float* eps, const float* temp, const float* gz, const float* gloss,
+                                           int B, int S, int D, float coeff, int mode, float* gh, void* stream) {
+    OTVAE_REQUIRE(h && eps && gh && B > 0 && S > 0 && D > 0 && mode >= 0 && mode <= 3, "otvae_gaussian_prior_ex_bwd: bad argument");
+    OTVAE_REQUIRE(!temp || (mode & 2), "otvae_gaussian_prior_ex_bwd: a temperature goes with fixed_var (mode bit 1)");
+    gaussian_prior_ex_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(h, eps, temp, gz, gloss, S, D, coeff, mode, gh);
+    OTVAE_CHECK_LAUNCH("otvae_gaussian_prior_ex_bwd");
+    return OTVAE_OK;
+}
+
 // ---- ConditionalGaussianPrior (prior/conditional_gaussian.py:84-93): KL(q || p_y) against a per-sample diagonal prior ----
 // h [B][2n] (mu | log_var), eps / z [B][n], prior mean pm and log standard deviation pl [B][n] (rows gathered by label):
 //   KL = sum_i  pl_i - lv_i/2 + (exp(lv_i) + (mu_i - pm_i)^2) / (2 exp(2 pl_i)) - 1/2

@@ -1216,6 +1216,62 @@ def gaussian_prior(h: Tensor, eps: Tensor, coeff: float) -> Tuple[Tensor, Tensor
     return torch.ops.otvae.gaussian_prior(as_nhwc(h), as_nhwc(eps), float(coeff))
 
 
+class _GaussianPriorExFn(torch.autograd.Function):
+    """``GaussianPrior`` with ``empirical_kl`` and / or ``fixed_var`` (and the temperature of ``encode(time=)``):
+    ``otvae_gaussian_prior_ex_fwd / _bwd`` on h flattened to [B, S = 1, D (or 2D)]."""
+
+    @staticmethod
+    def forward(ctx, h, eps, temp, coeff, mode):
+        lib = _lib.load()
+        b = h.shape[0]
+        d = h.shape[1] if mode & 2 else h.shape[1] // 2
+        z = torch.empty((b, d), device=h.device, dtype=torch.float32)
+        loss = torch.empty(b, device=h.device, dtype=torch.float32)
+        check(lib.otvae_gaussian_prior_ex_fwd(ptr(h), ptr(eps), ptr(temp), b, 1, d, float(coeff), int(mode), ptr(z), ptr(loss), stream()),
+              "otvae_gaussian_prior_ex_fwd")
+        ctx.save_for_backward(h, eps, temp)
+        ctx.cfg = (float(coeff), int(mode), d)
+        ctx.set_materialize_grads(False)
+        return z, loss
+
+    @staticmethod
+    def backward(ctx, gz, gloss):
+        if gz is None and gloss is None:
+            return None, None, None, None, None
+        h, eps, temp = ctx.saved_tensors
+        coeff, mode, d = ctx.cfg
+        gh = torch.empty_like(h)
+        gz = gz.contiguous() if gz is not None else None
+        gloss = gloss.contiguous() if gloss is not None else None
+        check(_lib.load().otvae_gaussian_prior_ex_bwd(ptr(h), ptr(eps), ptr(temp), ptr(gz), ptr(gloss), h.shape[0], 1, d, coeff, mode,
+                                                      ptr(gh), stream()), "otvae_gaussian_prior_ex_bwd")
+        return gh, None, None, None, None
+
+
+def gaussian_prior_ex(h: Tensor, eps: Tensor, coeff: float, empirical_kl: bool = False, fixed_var: bool = False,
+                      temperature: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """(z, coeff * loss[B]) of ``GaussianPrior(empirical_kl=, fixed_var=)`` (reference prior/gaussian.py:63-96, prior/base.py:65-68)
+    for h [B, 2C, ...] re-parametrised on dim 1 (fixed_var: [B, C, ...], z = h + s eps with s = 1 or temperature[b] + 1e-8)."""
+    _lib.require_cuda(h, "prior input")
+    b = h.shape[0]
+    out_shape = list(h.shape)
+    if not fixed_var:
+        out_shape[1] //= 2
+        # mu | log_var are the two halves of dim 1: flattened per half so that the kernel sees [B, 2 n]
+        mu, lv = h.chunk(2, dim=1)
+        flat = torch.cat([mu.reshape(b, -1), lv.reshape(b, -1)], dim=1)
+    else:
+        flat = h.reshape(b, -1)
+    temp = None
+    if temperature is not None:
+        if not fixed_var:
+            raise ValueError("a temperature (`time`) is only meaningful with fixed_var=True")
+        temp = temperature.reshape(b).float().contiguous()
+    mode = (1 if empirical_kl else 0) | (2 if fixed_var else 0)
+    z, loss = _GaussianPriorExFn.apply(flat.float().contiguous(), eps.reshape(b, -1).float().contiguous(), temp, float(coeff), mode)
+    return z.reshape(out_shape), loss
+
+
 def nelbo_loss(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor]) -> Tensor:
     """[total, recon, prior] of VAE.nelbo (reference model/vae.py:158-176): recon = mse(pred, target),
     prior = mean(prior_loss) / prod(target.shape[1:])."""

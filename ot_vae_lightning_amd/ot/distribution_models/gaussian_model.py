@@ -2,7 +2,9 @@
 (n, sum x, sum x x^T), reference ot/distribution_models/gaussian_model.py.  The statistics kernel accumulates the
 batch straight into the running buffers (or hands raw batch statistics to the all-reduce when running
 data-parallel); ``fit`` and the ``cov`` parametrisations (symmetrise, make strictly positive definite) run on the
-fp64 device kernels.  The autograd-trained variant (``update_with_autograd=True``) is outside the hot path."""
+fp64 device kernels.  ``update_with_autograd=True`` (reference gaussian_model.py:52-55,76-93: mean and the Cholesky factor of the
+covariance as trainable nn.Parameters, fitted through the negative log-likelihood) evaluates the log-density and its gradient
+on the kernels of csrc/mvn.hip + the library GEMM."""
 from typing import Optional
 
 import torch
@@ -13,7 +15,7 @@ from torch import Tensor
 
 from ... import _lib
 from ..._lib import check, ptr, stream
-from ..matrix_utils import eigh_vectors, eye_like, make_psd, psd_shift
+from ..matrix_utils import eigh_vectors, eye_like, make_psd, mm, psd_shift
 from ..w2_utils import W2Mixin
 from .base import DistributionModel
 
@@ -26,13 +28,16 @@ class GaussianModel(DistributionModel, W2Mixin):
     def __init__(self, *size: int, w2_cfg={}, **kwargs):
         DistributionModel.__init__(self, *size, **kwargs)
         W2Mixin.__init__(self, **dict(w2_cfg))
-        if self.update_with_autograd:
-            raise NotImplementedError("update_with_autograd=True is outside the MI355X hot path")
         self.batch_dim = -2
         self.register_buffer("cov_init", torch.ones_like(self.vec_init) if self.diag else
                              eye_like(self.mat_init).clone())
-        self.mean = nn.Parameter(self.vec_init.clone(), requires_grad=False)
-        self.cov = nn.Parameter(self.cov_init.clone(), requires_grad=False)
+        self.mean = nn.Parameter(self.vec_init.clone(), requires_grad=self.update_with_autograd)
+        self.cov = nn.Parameter(self.cov_init.clone(), requires_grad=self.update_with_autograd)
+        if self.update_with_autograd:
+            # `cov` holds the Cholesky factor (diag: the variances) through the exp + tril re-parametrisation, which keeps it a
+            # valid scale while an optimizer moves the raw parameter (reference gaussian_model.py:52-55,186-201)
+            P.register_parametrization(self, "cov", ExpScaleTril(diag=self.diag))
+            return
         self.register_buffer("_running_sum", torch.zeros_like(self.mean.data))
         self.register_buffer("_running_sum_cov", torch.zeros_like(self.cov.data))
         self.register_buffer("_n_obs", torch.zeros(self.vec_shape[:-1], dtype=self.vec_init.dtype))
@@ -44,16 +49,22 @@ class GaussianModel(DistributionModel, W2Mixin):
     def reset(self) -> None:
         self.mean.copy_(self.vec_init)
         self.cov = self.cov_init
+        if self.update_with_autograd:
+            return
         self._running_sum.zero_()
         self._running_sum_cov.zero_()
         self._n_obs.zero_()
 
     @property
     def distribution(self):
+        if self.update_with_autograd:  # cov is the scale (gaussian_model.py:76-83)
+            return self.instantiate_normal(self.mean, scale=self.cov ** 0.5, scale_tril=self.cov)
         return self.instantiate_normal(self.mean, scale=self.cov ** 0.5, covariance_matrix=self.cov)
 
     @property
     def variances(self) -> Tensor:
+        if self.update_with_autograd:  # get_var_normal(distribution): sigma^2, resp. L L^T
+            return self.cov if self.diag else mm(self.cov, self.cov.transpose(-1, -2).contiguous())
         return self.cov
 
     # -- statistics --------------------------------------------------------------------------------------------
@@ -94,6 +105,9 @@ class GaussianModel(DistributionModel, W2Mixin):
     @torch.no_grad()
     def update(self, samples: Tensor) -> None:
         self._validate_samples(samples)
+        if self.update_with_autograd:
+            raise RuntimeError("`update_with_autograd` is True: the parameters are trained with autograd; the running statistics "
+                               "`update` feeds were not created (reference base.py:85-88 warns, then fails on the missing buffers)")
         if self.reduce_on_update and self._will_reduce():
             n, sx, sxx = self._batch_stats(samples, accumulate=False)
             self._accumulate(self.reduce(n), self.reduce(sx), self.reduce(sxx))
@@ -119,6 +133,16 @@ class GaussianModel(DistributionModel, W2Mixin):
 
     @torch.no_grad()
     def fit(self, samples: Optional[Tensor] = None) -> None:
+        if self.update_with_autograd:
+            # gaussian_model.py:111-116: overrides the trained parameters with the moments of `samples`, assigned through the
+            # parametrisation's right inverse exactly as the reference does; nothing to do without samples
+            if samples is None:
+                return
+            n, sx, sxx = self._batch_stats(samples, accumulate=False)
+            mean, cov = self.mean_cov(self.reduce(sx), self.reduce(sxx), self.reduce(n))
+            self.mean.copy_(mean.type_as(self.mean))
+            self.cov = cov.type_as(self.mean)
+            return
         if samples is not None:
             self.update(samples)
         self._reduce_running()
@@ -139,6 +163,8 @@ class GaussianModel(DistributionModel, W2Mixin):
 
     def predict(self, samples: Tensor) -> Tensor:
         self._validate_samples(samples)
+        if self.update_with_autograd:
+            return mvn_log_prob(samples.type_as(self.mean), self.mean, self.cov ** 0.5 if self.diag else self.cov, self.diag)
         dist = self.instantiate_normal(self.mean.unsqueeze(-2), scale=self.cov.unsqueeze(-2) ** 0.5,
                                        covariance_matrix=self.cov.unsqueeze(-3) if not self.diag else None)
         return dist.log_prob(samples.type_as(self.mean))
@@ -178,6 +204,65 @@ class GaussianModel(DistributionModel, W2Mixin):
 
     def extra_repr(self) -> str:
         return super().extra_repr() + W2Mixin.__repr__(self)
+
+
+class _MvnLogProbFn(torch.autograd.Function):
+    """log N(x; mean, L L^T) (diag: N(mean, diag(scale^2))) on csrc/mvn.hip: x [nb, B, D], mean [nb, D], scale [nb, D, D] | [nb, D]"""
+
+    @staticmethod
+    def forward(ctx, x, mean, scale, diag):
+        lib = _lib.load()
+        nb, b, d = x.shape
+        y, lp = torch.empty_like(x), torch.empty((nb, b), device=x.device, dtype=torch.float64)
+        check(lib.otvae_mvn_logprob_fwd(ptr(x), ptr(mean), ptr(scale), nb, b, d, int(diag), ptr(y), ptr(lp), stream()),
+              "otvae_mvn_logprob_fwd")
+        ctx.save_for_backward(y, scale)
+        ctx.diag = diag
+        return lp
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        y, scale = ctx.saved_tensors
+        nb, b, d = y.shape
+        g = g.contiguous()
+        qg = torch.empty_like(y)
+        check(lib.otvae_mvn_logprob_bwd(ptr(g), ptr(y), ptr(scale), nb, b, d, int(ctx.diag), ptr(qg), stream()),
+              "otvae_mvn_logprob_bwd")
+        gsum = g.sum(-1)
+        if ctx.diag:      # d sigma = sum_b qg_b * y_b - (sum_b g_b) / sigma
+            gscale = (qg * y).sum(-2) - gsum[:, None] / scale
+        else:             # d L = tril(sum_b qg_b y_b^T) - (sum_b g_b) diag(1 / L_ii)
+            gscale = mm(qg.transpose(-1, -2).contiguous(), y).tril() - torch.diag_embed(gsum[:, None] / scale.diagonal(dim1=-1, dim2=-2))
+        return -qg, qg.sum(-2), gscale, None
+
+
+def mvn_log_prob(samples: Tensor, mean: Tensor, scale: Tensor, diag: bool) -> Tensor:
+    """log-density of samples [*, B, D] under the Gaussians (mean [*, D], Cholesky factor [*, D, D] or standard deviations
+    [*, D]); differentiable in all three.  fp64."""
+    _lib.require_cuda(samples, "samples")
+    lead, b, d = mean.shape[:-1], samples.shape[-2], samples.shape[-1]
+    x = samples.double().expand(*lead, b, d).reshape(-1, b, d).contiguous()
+    m = mean.double().reshape(-1, d).contiguous()
+    sc = scale.double().reshape(-1, *( (d,) if diag else (d, d))).contiguous()
+    return _MvnLogProbFn.apply(x, m, sc, diag).reshape(*lead, b).type_as(mean)
+
+
+class ExpScaleTril(nn.Module):
+    """cov parametrisation of the autograd-trained model: strictly lower triangle + exp(diagonal) (diag: exp), so that the
+    value is always a valid Cholesky factor / variance vector (reference gaussian_model.py:186-201)."""
+
+    def __init__(self, diag):
+        super().__init__()
+        self.diag = diag
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.diag:
+            return x.exp()
+        return x.tril(-1) + torch.diag_embed(x.diagonal(dim1=-1, dim2=-2).exp())
+
+    def right_inverse(self, x: Tensor) -> Tensor:
+        return x if self.diag else x.tril()
 
 
 class MakePositiveDefinite(nn.Module):

@@ -37,40 +37,53 @@ class GaussianPrior(Prior):
     def __init__(self, loss_coeff: float = 1., empirical_kl: bool = False, reparam_dim: int = 1,
                  annealing_steps: int = 0, fixed_var: bool = False):
         super().__init__(loss_coeff, annealing_steps)
-        if empirical_kl or fixed_var or reparam_dim != 1:
-            raise NotImplementedError("GaussianPrior on the MI355X path implements the closed-form KL with the "
-                                      "re-parametrisation on dim 1 (the configuration every BASELINE config uses)")
+        if reparam_dim != 1:
+            raise NotImplementedError("GaussianPrior on the MI355X path re-parametrises on dim 1 (every configuration of the "
+                                      "reference does)")
         self.empirical_kl, self.reparam_dim, self.fixed_var = empirical_kl, reparam_dim, fixed_var
 
     def out_size(self, size):
+        if self.fixed_var:   # prior/gaussian.py:84: no log-variance half
+            return torch.Size(size)
         out = list(size)
         out[self.reparam_dim - 1 if self.reparam_dim > 0 else self.reparam_dim] //= 2
         return torch.Size(out)
 
     def reparametrization(self, z: Tensor, temperature: Optional[Tensor] = None):
+        if self.fixed_var:   # prior/gaussian.py:74-77: unit scale, or the temperature (+ 1e-8) broadcast over the sample
+            def scale():
+                s = torch.ones_like(z)
+                if temperature is not None:
+                    s = s * temperature.reshape(-1, *([1] * (z.dim() - 1))) + 1e-8
+                return s
+            return _LazyNormal(lambda: z, scale)
         mu, log_var = torch.chunk(z, 2, self.reparam_dim)
         return _LazyNormal(lambda: mu, lambda: (log_var / 2).exp())
 
-    def _encode(self, x: Tensor, coeff: float, eps: Optional[Tensor] = None):
+    def _encode(self, x: Tensor, coeff: float, eps: Optional[Tensor] = None, time: Optional[Tensor] = None):
         shape = list(x.shape)
-        shape[1] //= 2
+        if not self.fixed_var:
+            shape[1] //= 2
         if eps is None:
             eps = torch.randn(shape, device=x.device, dtype=x.dtype)
-        z, loss = HF.gaussian_prior(x, eps, coeff)
+        if self.fixed_var or self.empirical_kl:
+            z, loss = HF.gaussian_prior_ex(x, eps, coeff, self.empirical_kl, self.fixed_var, time)
+        else:
+            z, loss = HF.gaussian_prior(x, eps, coeff)
         artifacts = {"prior": _LazyNormal(lambda: torch.zeros_like(z), lambda: torch.ones_like(z)),
-                     "distribution": self.reparametrization(x.detach())}
+                     "distribution": self.reparametrization(x.detach(), temperature=time)}
         return z, loss, artifacts
 
     def encode(self, x: Tensor, time: Optional[Tensor] = None, eps: Optional[Tensor] = None) -> Prior.EncodingResults:
-        if time is not None:
+        if time is not None and not self.fixed_var:
             raise NotImplementedError("temperature (`time`) is only meaningful with fixed_var=True")
-        return self._encode(x, 1.0, eps)
+        return self._encode(x, 1.0, eps, time)
 
     def sample(self, shape, device) -> Tensor:
         return torch.randn(*shape, device=device)
 
     def forward(self, x: Tensor, step: int, time: Optional[Tensor] = None, eps: Optional[Tensor] = None):
         # loss_coeff * annealing is folded into the kernel (one multiply per sample instead of a separate launch)
-        if time is not None:
+        if time is not None and not self.fixed_var:
             raise NotImplementedError("temperature (`time`) is only meaningful with fixed_var=True")
-        return self._encode(x, float(self.loss_coeff * self.annealing(step)), eps)
+        return self._encode(x, float(self.loss_coeff * self.annealing(step)), eps, time)

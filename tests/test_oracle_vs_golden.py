@@ -188,6 +188,20 @@ def test_gaussian_prior(tag):
     assert rel_err(z, g["z"]) < TIGHT and rel_err(loss, g["loss"]) < TIGHT and rel_err(x.grad, g["gx"]) < TIGHT
 
 
+PRIOR_OPTION_TAGS = ["empirical", "fixed_var", "fixed_var_time", "fixed_var_empirical"]
+
+
+@pytest.mark.parametrize("tag", PRIOR_OPTION_TAGS)
+def test_gaussian_prior_options(tag):
+    """empirical_kl / fixed_var / temperature of the reference's GaussianPrior (prior/gaussian.py:38-41,63-96)"""
+    g = group(load_golden("prior.npz"), tag)
+    coeff, emp, fixed = g["cfg"].tolist()
+    x = g["x"].clone().requires_grad_(True)
+    z, loss = O.gaussian_prior_encode_options(x, g["eps"], coeff, bool(emp), bool(fixed), g.get("time"))
+    ((z * g["gz"]).sum() + (loss * g["gl"]).sum()).backward()
+    assert rel_err(z, g["z"]) < TIGHT and rel_err(loss, g["loss"]) < 1e-5 and rel_err(x.grad, g["gx"]) < 1e-5
+
+
 def _sinkhorn_problem(lead, n, m, dtype, seed):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(*lead, n, 5, generator=g, dtype=torch.float64)
