@@ -240,6 +240,56 @@ def time_dominant_kernel(A, trainer, iters=30):
             "pmc_traffic_bytes": pmc_traffic("attn_bwd_kernel<1, 4, true>")}
 
 
+# Issue model of the head-width-2 attention kernels (T = 256, 4 heads: encoder block 0 / decoder block 3), from the ISA of the
+# inner loops (hipcc -S): per 16 (query, key) pairs of a lane
+#   forward  (moments for dq ride along): 80 v_pk_fma_f32 + 8 v_pk_add_f32 + 8 v_mov_b32 + 16 v_exp_f32
+#   backward (dk, dv; dq from the moments): 64 v_pk_fma_f32 + 8 v_pk_mul_f32 + 4 v_mov_b32 + 16 v_exp_f32
+# at the cycle table's issue costs (MI355X_MICROARCH.md: 4 cycles per vector instruction, 8 per transcendental), 1024 SIMDs,
+# 2.4 GHz, 64 lanes.  (Measured at 4 waves per SIMD a v_pk_fma_f32 costs 5.2-5.8, which is most of the gap.)
+ATTN_C2_CYCLES_PER_16_PAIRS = {"fwd": (80 + 8 + 8) * 4 + 16 * 8, "bwd": (64 + 8 + 4) * 4 + 16 * 8}
+
+
+def time_attention_c2(A, iters=20):
+    """attn_fwd_kernel<2,4,true> / attn_bwd_kernel<2,4,true> at the benchmark's shape through the C ABI, 20 launches per hipGraph,
+    HIP events on the launch stream; against the issue model above."""
+    from ot_vae_lightning_amd import _lib as L
+    lib = L.load()
+    n, t, heads, c = PER_GPU_BATCH, 256, 4, 2
+    qkv = torch.randn(n, t, 3 * heads * c, device="cuda")
+    out = torch.empty(n, t, heads * c, device="cuda")
+    lse = torch.empty(n, heads, t, device="cuda")
+    aux = torch.empty(n, heads, t, c * c, device="cuda")
+    g, gq = torch.randn_like(out), torch.empty_like(qkv)
+    fns = {"fwd": lambda: L.check(lib.otvae_attn_fwd(L.ptr(qkv), n, t, heads, c, L.ptr(out), L.ptr(lse), L.ptr(aux), L.stream()), "f"),
+           "bwd": lambda: L.check(lib.otvae_attn_bwd(L.ptr(qkv), L.ptr(out), L.ptr(lse), L.ptr(g), L.ptr(aux), n, t, heads, c, L.ptr(gq),
+                                                     L.stream()), "b")}
+    res = {}
+    pairs = n * heads * t * t
+    for name, fn in fns.items():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for _ in range(iters):
+                fn()
+        for _ in range(5):
+            graph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / (4 * iters)
+        peak = 1024 * 2.4e9 * 64 * 16 / ATTN_C2_CYCLES_PER_16_PAIRS[name] / 1e12
+        tp = pairs / ms / 1e9
+        res[name] = {"kernel": f"attn_{name}_kernel<2,4,true> (T=256,H=4,C=2)", "avg_launch_ms": round(ms, 5), "launches_per_step": 2,
+                     "achieved": round(tp, 3), "peak": round(peak, 3), "unit": "T (query,key) pairs/s", "frac": round(tp / peak, 4)}
+    return res
+
+
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA peak == fp32 vector peak
 GEOM_FIELDS = ("N", "Hs", "Ws", "Cs", "up", "Ho", "Wo", "Cn", "KH", "KW", "stride", "pad")
 
@@ -362,19 +412,34 @@ def time_largest_aggregate_kernel(A, workload, iters=10):
             "pmc_traffic_bytes": pmc_traffic("conv_jobs_kernel<true>")}
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (the same function as tools/summarize_profiles.py:csrc_digest)"""
+    import hashlib
+    root = os.path.join(ROOT, "ot_vae_lightning_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/r02_pmc_per_kernel.csv, else round 1's;
-    written by tools/summarize_profiles.py --pmc from separate rocprofv3 --pmc passes of this same command: FETCH_SIZE with
-    the x2 gfx950 correction + WRITE_SIZE, KiB -> bytes, as MI355X_MICROARCH.md prescribes); None if not collected."""
+    """HBM bytes per launch of `kernel` from the committed PMC summary of THIS round (profiles/r03_pmc_per_kernel.csv, written by
+    tools/summarize_profiles.py --pmc from separate rocprofv3 --pmc passes of this same command: FETCH_SIZE with the x2 gfx950
+    correction + WRITE_SIZE, KiB -> bytes, as MI355X_MICROARCH.md prescribes).  None -- not a stale number -- when the summary is
+    missing or was collected from other kernel sources than the tree holds now (its first line carries their digest)."""
     import csv
-    for tag in ("r02", "r01"):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{tag}_pmc_per_kernel.csv")
-        try:
-            for row in csv.reader(open(path)):
-                if row and row[0].strip().endswith(kernel):
-                    return (2.0 * float(row[2]) + float(row[4])) * 1024.0
-        except OSError:
-            continue
+    path = os.path.join(ROOT, "profiles", "r03_pmc_per_kernel.csv")
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None
+    if not lines or not lines[0].startswith("# csrc_sha256=") or lines[0].split("=", 1)[1].strip() != csrc_digest():
+        return None
+    for row in csv.reader(lines[1:]):
+        if row and row[0].strip().endswith(kernel):
+            return (2.0 * float(row[2]) + float(row[4])) * 1024.0
     return None
 
 
@@ -497,6 +562,10 @@ def main():
         line["roofline_issue"] = {"bound": "valu_issue", "kernel": longest["kernel"], "achieved": round(tp, 3),
                                   "peak": round(ISSUE_BOUND_TPAIRS, 3), "unit": "T (query,key) pairs/s",
                                   "frac": round(tp / ISSUE_BOUND_TPAIRS, 4)}
+        try:
+            line["roofline_issue_c2"] = {"bound": "valu_issue", **time_attention_c2(A)}
+        except Exception as e:  # noqa: BLE001
+            line["roofline_issue_c2"] = {"error": repr(e)}
         if args.workload == "sinkhorn":
             line["sinkhorn"] = time_sinkhorn(A)
         if world == 1:

@@ -310,10 +310,16 @@ int otvae_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
  * when every watched device scalar is finite: watch_loss[0] (the step's loss; a starved Sinkhorn solve poisons it with
  * NaN), and grad_scale_dev[0..1] = {scale, |g|} when given (what otvae_grad_clip_coef leaves; with max_norm <= 0 it only
  * reports the norm).  grad_scale_dev NULL: the host value grad_scale is used.  A skipped step leaves p, m, v unchanged, takes
- * *step back by one, and counts itself: guard[0] += 1, guard[1] = the step number that was skipped (device int32[2]). */
+ * *step back by one, restores state[n_state] from backup (below), and counts itself: guard[0] += 1, guard[1] = the step number
+ * that was skipped (device int32[2]). */
 int otvae_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step,
                             float grad_scale, const float* grad_scale_dev, const float* watch_loss, int32_t* guard,
-                            void* stream);
+                            float* state, const float* backup, int64_t n_state, void* stream);
+/* The running buffers of a guarded step.  A NaN that reaches a BatchNorm does not stay one (the next ReLU maps the NaN-normalised
+ * tensor to zeros), so later layers would fold finite but meaningless batch statistics into their running buffers:
+ * otvae_step_begin_guarded increments *step like otvae_step_begin AND copies state[n_state] (every running buffer of the model,
+ * one flat fp32 range) to backup; a refused step (otvae_adam_step_guarded) copies it back.  n_state 0: no such buffers. */
+int otvae_step_begin_guarded(int32_t* step, const float* state, float* backup, int64_t n_state, void* stream);
 
 /* ---- global-norm gradient clipping (configs/ddp.yaml:4 `gradient_clip_val: 1.0`, applied by Lightning through
  * torch.nn.utils.clip_grad_norm_) over the flat gradient buffer -------------------------------------------------- */

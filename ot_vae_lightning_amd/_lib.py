@@ -100,7 +100,8 @@ SIGNATURES = {
     "otvae_step_begin": (i32, [vp, vp]),
     "otvae_adam_step": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp]),
     "otvae_adam_step_dev": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),
-    "otvae_adam_step_guarded": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp, vp, vp, vp]),
+    "otvae_adam_step_guarded": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp, vp, vp, vp, vp, i64, vp]),
+    "otvae_step_begin_guarded": (i32, [vp, vp, vp, i64, vp]),
     "otvae_grad_clip_ws": (i32, []),
     "otvae_grad_clip_coef": (i32, [vp, i64, f32, f32, vp, vp, vp]),
     "otvae_sinkhorn_ws": (i64, [i32, i32, i32, i32]),

@@ -305,6 +305,23 @@ extern "C" int otvae_step_begin(int32_t* step, void* stream) {
 
 // torch.optim.Adam (no weight decay / amsgrad): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// Step guard, running buffers.  A NaN that reaches a BatchNorm's input does not stay a NaN: the next layer's ReLU (fmaxf) turns the
+// NaN-normalised tensor into zeros, so later layers see finite -- and meaningless -- batch statistics and would fold them into
+// their running buffers.  The guarded step therefore keeps a copy of all running buffers (one flat fp32 range) from the start
+// of the step (otvae_step_begin_guarded) and the guarded Adam kernel puts it back when it refuses the step.
+__global__ __launch_bounds__(256) void step_begin_guarded_kernel(int32_t* step, const float* __restrict__ state, float* __restrict__ backup,
+                                                                 int64_t n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) backup[i] = state[i];
+}
+
+extern "C" int otvae_step_begin_guarded(int32_t* step, const float* state, float* backup, int64_t n, void* stream) {
+    OTVAE_REQUIRE(step && (n == 0 || (state && backup)) && n >= 0, "otvae_step_begin_guarded: bad argument");
+    step_begin_guarded_kernel<<<imax(1, imin(cdiv(n, 256), 64)), 256, 0, (hipStream_t)stream>>>(step, state, backup, n);
+    OTVAE_CHECK_LAUNCH("otvae_step_begin_guarded");
+    return OTVAE_OK;
+}
+
 // Step guard (guard != NULL): the update is applied only when every watched device scalar is finite -- the step's loss
 // (a starved Sinkhorn solve poisons it with NaN, csrc/sinkhorn.hip: sk_finish) and, when the gradient norm was reduced
 // (otvae_grad_clip_coef), that norm.  Every block evaluates the same two scalars, so the decision is uniform without a flag
@@ -314,7 +331,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ v, int64_t n, const float* __restrict__ hyper,
                                                    int32_t* __restrict__ step, float grad_scale,
                                                    const float* __restrict__ scale_dev, int32_t* __restrict__ guard,
-                                                   const float* __restrict__ watch_loss) {
+                                                   const float* __restrict__ watch_loss, float* __restrict__ state,
+                                                   const float* __restrict__ backup, int64_t n_state) {
     if (scale_dev) grad_scale = *scale_dev;  // clip coefficient x 1/world, left by grad_clip_final_kernel
     if (guard) {
         bool ok = isfinite(grad_scale);
@@ -327,6 +345,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                 guard[1] = *step;
                 *step -= 1;
             }
+            for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n_state; i += (int64_t)gridDim.x * 256) state[i] = backup[i];
             return;
         }
     }
@@ -371,7 +390,7 @@ extern "C" int otvae_adam_step(float* p, const float* g, float* m, float* v, int
     OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                   "otvae_adam_step: buffers must be 16-byte aligned");
     adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, const_cast<int32_t*>(step), grad_scale,
-                                                                            nullptr, nullptr, nullptr);
+                                                                            nullptr, nullptr, nullptr, nullptr, nullptr, 0);
     OTVAE_CHECK_LAUNCH("otvae_adam_step");
     return OTVAE_OK;
 }
@@ -382,19 +401,20 @@ extern "C" int otvae_adam_step_dev(float* p, const float* g, float* m, float* v,
     OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                   "otvae_adam_step_dev: buffers must be 16-byte aligned");
     adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, const_cast<int32_t*>(step), 1.f,
-                                                                            grad_scale_dev, nullptr, nullptr);
+                                                                            grad_scale_dev, nullptr, nullptr, nullptr, nullptr, 0);
     OTVAE_CHECK_LAUNCH("otvae_adam_step_dev");
     return OTVAE_OK;
 }
 
 extern "C" int otvae_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step,
                                        float grad_scale, const float* grad_scale_dev, const float* watch_loss, int32_t* guard,
-                                       void* stream) {
+                                       float* state, const float* backup, int64_t n_state, void* stream) {
     OTVAE_REQUIRE(p && g && m && v && hyper && step && guard && n > 0, "otvae_adam_step_guarded: bad argument");
+    OTVAE_REQUIRE(n_state >= 0 && (n_state == 0 || (state && backup)), "otvae_adam_step_guarded: state / backup missing");
     OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                   "otvae_adam_step_guarded: buffers must be 16-byte aligned");
     adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, step, grad_scale, grad_scale_dev, guard,
-                                                                            watch_loss);
+                                                                            watch_loss, state, backup, n_state);
     OTVAE_CHECK_LAUNCH("otvae_adam_step_guarded");
     return OTVAE_OK;
 }

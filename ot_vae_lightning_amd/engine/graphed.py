@@ -22,6 +22,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
+from .segments import SEGMENT_CALLS, SegmentedStep
 from .trainer import HipTrainer
 
 __all__ = ["GraphedNelbo"]
@@ -132,12 +133,25 @@ class GraphedNelbo:
         with torch.cuda.graph(cap.graph_f, **mode):
             loss, logs, art = forward()
             cap.out3 = model._last_nelbo
-        cap.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cap.graph_b, pool=cap.graph_f.pool(), **mode):
-            backward(loss)
+        if SEGMENT_CALLS > 0 and HF.WGRAD_SIDE_STREAM == 1:
+            # the backward pass as a chain of linear graphs + side graphs (engine/segments.py): ~0.1 ms of host time per replay
+            # instead of ~0.8 ms for one graph with a fork per layer, which matters on this host-bound route
+            cap.graph_b = SegmentedStep(engine.device, HF._PendingReduce.side_stream(engine.device), pool=cap.graph_f.pool())
+            HF._PendingReduce.begin_segments(engine.device, cap.graph_b)
+            try:
+                with cap.graph_b:
+                    backward(loss)
+            finally:
+                HF._PendingReduce.end_segments(engine.device)
+        else:
+            cap.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cap.graph_b, pool=cap.graph_f.pool(), **mode):
+                backward(loss)
         cap.out3 = cap.out3.detach()
-        cap.artifacts = {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in art.items()
-                         if k not in ("samples", "target", "kwargs")}
+        # tensors only (preds, latents, preds_mean ...): a prior's lazily built distribution objects could hold the captured pass's
+        # autograd graph -- and with it AccumulateGrad nodes bound to the capture stream -- alive for good
+        cap.artifacts = {k: v.detach() for k, v in art.items() if isinstance(v, Tensor) and k not in ("samples", "target")}
+        del loss, logs, art
         model._last_nelbo = None
         model._last_cut = None
         with torch.no_grad():

@@ -40,7 +40,7 @@ class SegmentedStep:
         seg.replay()
     """
 
-    def __init__(self, device, side_stream: "torch.cuda.Stream"):
+    def __init__(self, device, side_stream: "torch.cuda.Stream", pool=None):
         self.device = device
         self.side_stream = side_stream
         self.main: List[torch.cuda.CUDAGraph] = []
@@ -49,7 +49,7 @@ class SegmentedStep:
         self._side_work: List[Optional[Callable[[], None]]] = []
         self._pending_join = False
         self._cur: Optional[torch.cuda.CUDAGraph] = None
-        self._pool = None
+        self._pool = pool   # None: the first graph's own pool; else the pool of graphs captured before (their tensors are read here)
         self._ctx = None
         self._events: List[torch.cuda.Event] = []
         self._join_event = torch.cuda.Event()

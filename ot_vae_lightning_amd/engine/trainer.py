@@ -102,6 +102,23 @@ class HipTrainer:
         #   None:   unguarded (round-2 behaviour).  "auto" = "loss" on one rank, "full" on several.
         self._guard_arg = step_guard
         self.guard = torch.zeros(2, device=dev, dtype=torch.int32)  # {skipped steps, step number of the last skip}
+        # every floating-point running buffer of the model (BatchNorm running_mean / running_var) as a view of ONE flat range, so
+        # that a guarded step can keep a copy from its start and a refused step can put it back (csrc/loss_optim.hip: a NaN does
+        # not survive the next ReLU, later layers would average garbage into their buffers)
+        self.rflat = self.rbackup = None
+        if step_guard is not None:
+            bufs = [b for n_, b in model.named_buffers() if b.dtype == torch.float32 and ("running_mean" in n_ or "running_var" in n_)]
+            if bufs:
+                total = sum((b.numel() + 3) // 4 * 4 for b in bufs)
+                self.rflat = torch.zeros(total, device=dev, dtype=torch.float32)
+                off = 0
+                with torch.no_grad():
+                    for b in bufs:
+                        v = self.rflat[off: off + b.numel()].view(b.shape)
+                        v.copy_(b)
+                        b.data = v
+                        off += (b.numel() + 3) // 4 * 4
+                self.rbackup = torch.empty_like(self.rflat)
         # a FRESH tensor object per call (autograd steals a gradient it holds the only reference to and clones it otherwise),
         # made from a slot view built once: detach() is one shallow copy instead of slice + view + permute
         for p, off in zip(self.params, self.offsets):
@@ -183,8 +200,15 @@ class HipTrainer:
             check(lib.otvae_weight_transpose(ptr(w), ptr(w._otvae_wd), kh * kw, cs, cn, stream()),
                   "otvae_weight_transpose")
 
+    def _step_begin(self):
+        if self.step_guard is not None and self.rflat is not None:
+            check(self.lib.otvae_step_begin_guarded(ptr(self.step_count), ptr(self.rflat), ptr(self.rbackup), self.rflat.numel(),
+                                                    stream()), "otvae_step_begin_guarded")
+        else:
+            check(self.lib.otvae_step_begin(ptr(self.step_count), stream()), "otvae_step_begin")
+
     def _forward_backward(self):
-        check(self.lib.otvae_step_begin(ptr(self.step_count), stream()), "otvae_step_begin")
+        self._step_begin()
         self._refresh_wd()
         for p in self.params:
             p.grad = None
@@ -271,7 +295,7 @@ class HipTrainer:
     def _phase1(self):
         """forward + backward of everything downstream of the encoder's output h (loss, decoder, prior): gradients of
         their parameters and dL/dh.  Same kernels in the same order as ``_forward_backward`` up to the cut."""
-        check(self.lib.otvae_step_begin(ptr(self.step_count), stream()), "otvae_step_begin")
+        self._step_begin()
         self._refresh_wd()
         for p in self.params:
             p.grad = None
@@ -330,8 +354,9 @@ class HipTrainer:
             self._watch = watch
             check(lib.otvae_adam_step_guarded(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
                                               ptr(self.hyper), ptr(self.step_count), self.reducer.grad_scale,
-                                              ptr(self.clip_out) if norm else None, ptr(watch), ptr(self.guard), stream()),
-                  "otvae_adam_step_guarded")
+                                              ptr(self.clip_out) if norm else None, ptr(watch), ptr(self.guard),
+                                              ptr(self.rflat), ptr(self.rbackup), 0 if self.rflat is None else self.rflat.numel(),
+                                              stream()), "otvae_adam_step_guarded")
         elif norm:
             check(lib.otvae_adam_step_dev(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
                                           ptr(self.hyper), ptr(self.step_count), ptr(self.clip_out), stream()),

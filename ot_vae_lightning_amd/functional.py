@@ -710,19 +710,33 @@ class _BnActFn(torch.autograd.Function):
         return dx, dgam, dbet, None, None, None
 
 
+def _is_dense(t: Tensor) -> bool:
+    """True if t's elements fill one contiguous block of memory in some dimension order (then an element-wise kernel may walk
+    the memory and an output with the same strides has the same logical layout)"""
+    order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))
+    expect = 1
+    for d in reversed(order):
+        if t.shape[d] != 1 and t.stride(d) != expect:
+            return False
+        expect *= t.shape[d]
+    return True
+
+
 class _ScaleFn(torch.autograd.Function):
     """alpha * t on t's own memory order (the ``weight * conv_scale * lr_mult`` / ``bias * lr_mult`` of equalized_lr)"""
 
     @staticmethod
     def forward(ctx, t, alpha):
         ctx.alpha = alpha
+        if not _is_dense(t):
+            t = t.contiguous()
         out = torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype)
         check(_lib.load().otvae_scale_f32(ptr(t), alpha, t.numel(), ptr(out), stream()), "otvae_scale_f32")
         return out
 
     @staticmethod
     def backward(ctx, g):
-        if g.stride() != tuple(g.stride()) or not g.is_non_overlapping_and_dense():
+        if not _is_dense(g):
             g = g.contiguous()
         out = torch.empty_strided(g.shape, g.stride(), device=g.device, dtype=g.dtype)
         check(_lib.load().otvae_scale_f32(ptr(g), ctx.alpha, g.numel(), ptr(out), stream()), "otvae_scale_f32")

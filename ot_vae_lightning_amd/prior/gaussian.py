@@ -70,7 +70,8 @@ class GaussianPrior(Prior):
             z, loss = HF.gaussian_prior_ex(x, eps, coeff, self.empirical_kl, self.fixed_var, time)
         else:
             z, loss = HF.gaussian_prior(x, eps, coeff)
-        artifacts = {"prior": _LazyNormal(lambda: torch.zeros_like(z), lambda: torch.ones_like(z)),
+        zd = z.detach()  # the lazily built distributions must not keep this step's autograd graph alive
+        artifacts = {"prior": _LazyNormal(lambda: torch.zeros_like(zd), lambda: torch.ones_like(zd)),
                      "distribution": self.reparametrization(x.detach(), temperature=time)}
         return z, loss, artifacts
 

@@ -67,6 +67,18 @@ def replay_stats(src, tag, steps=20):
     print("wrote", out, "launches/step", len(seg) // steps, "busy ms/step %.3f wall %.3f" % (tot / 1e6 / steps, wall / 1e6 / steps))
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, *.cpp, sorted by name): the same function as bench.csrc_digest"""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ot_vae_lightning_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
+
+
 def pmc(src, tag):
     def load(d, counter):
         f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))[0]
@@ -82,6 +94,9 @@ def pmc(src, tag):
     MF, GA = load("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), load("pmc_mfma", "GRBM_GUI_ACTIVE")
     out = os.path.join(OUT, f"{tag}_pmc_per_kernel.csv")
     with open(out, "w") as w:
+        # the kernel sources these counters were collected from: bench.py reports `roofline.traffic` from this file only while
+        # the digest still matches the tree (a changed kernel makes the committed bytes stale)
+        w.write("# csrc_sha256=%s\n" % csrc_digest())
         w.write("kernel,launches,FETCH_SIZE_KiB_per_launch,read_MB_per_launch(2x_gfx950_correction),WRITE_SIZE_KiB_per_launch,"
                 "hbm_MB_per_launch,SQ_VALU_MFMA_BUSY_CYCLES_per_launch,GRBM_GUI_ACTIVE_per_launch,"
                 "mfma_busy_frac(=busy/(gui_active/8*1024 SIMDs))\n")
@@ -135,7 +150,7 @@ def roofline(tag):
     """Joins <tag>_final_replay_kernel_stats.csv and <tag>_pmc_per_kernel.csv into <tag>_kernel_roofline.csv."""
     rep = {r["kernel"]: r for r in csv.DictReader(l for l in open(os.path.join(OUT, f"{tag}_final_replay_kernel_stats.csv"))
                                                   if not l.startswith("#"))}
-    pm = list(csv.DictReader(open(os.path.join(OUT, f"{tag}_pmc_per_kernel.csv"))))
+    pm = list(csv.DictReader(l for l in open(os.path.join(OUT, f"{tag}_pmc_per_kernel.csv")) if not l.startswith("#")))
     busy_key = [k for k in pm[0] if k.startswith("mfma_busy_frac")][0]
     pm = {r["kernel"]: r for r in pm}
     rows = []
