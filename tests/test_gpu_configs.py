@@ -672,6 +672,72 @@ def test_conditional_vit_vae_trains_through_hip_trainer(A):
                            prior=A.GaussianPrior()).cuda(), batch_shape=(4, 1, 16, 16), use_graph=False).step(labels=y)
 
 
+def test_config5_conditional_vit_vae_at_the_yaml_shape_vs_oracle(A):
+    """BASELINE configs[4]'s NETWORK on the HIP path at the size the reference's configs/vae/vit.yaml:12-48 gives it
+    (64 x 64 x 3 images, 8 x 8 patches -> 64 patch tokens, dim 256, 8 heads of width 32, encoder depth 3, decoder depth 2,
+    mlp 4 x dim) with the class conditioning and ConditionalGaussianPrior of tests/test_conditional_vit_vae.py, 64 images per
+    GPU (512 over 8): one captured training step's losses, reconstructions, latents and EVERY parameter gradient element-wise
+    against the CPU oracle on the same weights / batch / eps / labels.  Dropout 0 (the oracle has no mask to share)."""
+    from detfill import fill_vit_state_dict
+    from test_oracle_vs_golden import VIT_ROLES, vit_param_shapes
+    rep = Report("conditional ViT VAE at the vit.yaml shape (64x64, dim 256, heads 8, depth 3/2), B=64, vs CPU oracle")
+    B, ncls = 64, 10
+    base = dict(image_size=64, patch_size=8, dim=256, heads=8, mlp_dim=1024, channels=3, num_classes=ncls)
+    cfgs = {"enc": dict(depth=3, **base), "dec": dict(depth=2, **base)}
+    x = normal((B, 3, 64, 64), 151)
+    eps = normal((B, 1, 256), 152)
+    labels = torch.arange(B) % ncls
+    g = torch.Generator().manual_seed(153)
+    mu_w, ls_w = torch.randn(ncls, 256, generator=g) * 0.3, torch.randn(ncls, 256, generator=g) * 0.1
+    # oracle
+    pcpu = {}
+    for role in ("enc", "dec"):
+        sd = {k: torch.zeros(sh) for k, sh in vit_param_shapes(cfgs[role], role).items()}
+        fill_vit_state_dict(sd)
+        pcpu[role] = {k: v.requires_grad_(True) for k, v in sd.items()}
+    mw, lw = mu_w.clone().requires_grad_(True), ls_w.clone().requires_grad_(True)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    vit = lambda role: dict(image_size=64, patch_size=8, dim=256, depth=cfgs[role]["depth"], heads=8, channels=3, labels=labels,  # noqa: E731
+                            **VIT_ROLES[role])
+    h = O.vit_forward(x, pcpu["enc"], **vit("enc"))
+    z, prior_l = O.cond_gaussian_prior_encode(h, eps, mw, lw, labels, 0.1, 0, 0)
+    preds = O.vit_forward(z, pcpu["dec"], **vit("dec"))
+    prior_loss = prior_l.mean() / float(x[0].numel())
+    recon = torch.nn.functional.mse_loss(preds, x)
+    (recon + prior_loss).backward()
+    # product: the captured step
+    nets = {}
+    for role in ("enc", "dec"):
+        net = A.ViT(output_tokens="embed", dropout=0.0, emb_dropout=0., **cfgs[role], **VIT_ROLES[role])
+        net.load_state_dict({k: v.detach() for k, v in pcpu[role].items()})
+        nets[role] = net
+    prior = A.ConditionalGaussianPrior(dim=(1, 256), num_classes=ncls, loss_coeff=0.1)
+    with torch.no_grad():
+        prior._mu.weight.copy_(mu_w)
+        prior._log_std.weight.copy_(ls_w)
+    model = A.VAE(encoder=nets["enc"], decoder=nets["dec"], prior=prior, conditional=True).cuda().train()
+    tr = A.HipTrainer(model, batch_shape=(B, 3, 64, 64), use_graph=True, batch_kwargs={"labels": labels.cuda()})
+    out = tr.step(x.cuda(), eps.cuda(), labels=labels.cuda()).clone()
+    torch.cuda.synchronize()
+    rep.check("loss [total, recon, prior]", out, torch.stack([recon + prior_loss, recon, prior_loss]).detach(), 1e-5)
+    rep.check("latents", tr.latents, z.detach(), 1e-5)
+    names, got, want = [], [], []
+    for pre, net, ref in (("encoder.", model.encoder, pcpu["enc"]), ("decoder.", model.decoder, pcpu["dec"])):
+        for k, p_ in net.named_parameters():
+            if ref[k].grad is None:
+                continue
+            names.append(pre + k)
+            got.append(p_._otvae_grad_view())
+            want.append(ref[k].grad)
+    for k, p_, ref in (("prior._mu.weight", prior._mu.weight, mw), ("prior._log_std.weight", prior._log_std.weight, lw)):
+        names.append(k)
+        got.append(p_._otvae_grad_view())
+        want.append(ref.grad)
+    rep.check_grads("gradients (captured step)", got, want, names)
+    tr.close()
+    rep.finish()
+
+
 def test_vit_vae_with_dropout_draws_fresh_masks_in_a_captured_step(A):
     """The reference's ViT configuration trains with dropout 0.1 (configs/vae/vit.yaml): token dropouts between the
     kernels, attention-probability dropout inside ``otvae_attn_dropout_*``.  Through the captured HipTrainer step every

@@ -1271,11 +1271,27 @@ def test_codebook_prior_vs_reference_golden(A):
         assert art["indices"].shape == (x.shape[0], 1)
     prior.eval()
     xe = g["eval/x"].cuda()
+    # fp64 TRUTH of the two entropy losses: the same formula -- distances by exact differences, energy =
+    # 1 / (|x - c| + 1e-8), softmax(energy / T), loss_coeff (log K - entropy) -- in float64 on the CPU from the eval batch and the
+    # codebook the golden recorded.  The reference computes the distances in fp32 through cdist's |x|^2 + |c|^2 - 2 x.c expansion,
+    # whose cancellation moves 1 / distance by up to 1e-2 for samples next to an atom; the HIP kernels difference first.
+    with torch.no_grad():   # both sides evaluate on exactly the reference's codebook (the trained one agrees with it to 1e-5)
+        prior.codebook_model.codebook.copy_(g["step1/codebook"].cuda().reshape(prior.codebook_model.codebook.shape))
+    x3 = prior.permute_and_flatten(xe).double().cpu()                                  # [P, B, d]
+    cb = prior.codebook_model.codebook.detach().double().cpu()
+    dist = (x3.unsqueeze(-2) - cb.unsqueeze(-3)).square().sum(-1).sqrt()               # [P, B, K]
+    pr = torch.softmax((1.0 / (dist + 1e-8)) / float(prior.codebook_model.temperature), dim=-1)
+    ent = -(pr * pr.clamp_min(1e-300).log()).sum(-1)                                   # [P, B]
+    truth = {"kl": 0.5 * (math.log(K) - ent).sum(0), "first_kl": 0.5 * (math.log(K) - ent)[0]}
     for kind in ("kl", "first_kl"):
         prior.loss = kind
         z, loss, _ = prior(xe, step=100)
-        # log K - entropy of softmax(1 / distance): inherits the rounding of the reference's cdist (see the k-means test)
-        rep.check(f"eval/loss_{kind}", loss, g[f"eval/loss_{kind}"], 2e-3)
+        # against the truth at north_star's 1e-4, and closer to it than the reference's own fp32 value is
+        rep.check(f"eval/loss_{kind} vs fp64 truth", loss, truth[kind], 1e-4)
+        e_hip, e_ref = rel_err(loss.double().cpu(), truth[kind]), rel_err(g[f"eval/loss_{kind}"].double(), truth[kind])
+        rep.rows.append((f"eval/loss_{kind}: reference fp32 golden vs fp64 truth (for comparison)", e_ref, 2e-3, True))
+        assert e_hip <= e_ref + 1e-7, (kind, e_hip, e_ref)
+        rep.check(f"eval/loss_{kind} vs reference golden (its cdist rounding)", loss, g[f"eval/loss_{kind}"], 2e-3)
     rep.check("eval/z", z, g["eval/z"], 1e-6)
     xg = xe.clone().requires_grad_(True)                      # the entropy losses are differentiable (otvae_codebook_probs_bwd)
     prior(xg, step=100)[1].sum().backward()
