@@ -130,13 +130,15 @@ class GraphedNelbo:
         torch.cuda.synchronize()
         mode = dict(capture_error_mode=os.environ.get("OTVAE_CAPTURE_ERROR_MODE", "thread_local"))
         cap.graph_f = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cap.graph_f, **mode):
+        cstream = torch.cuda.Stream(device=engine.device)   # ONE capture stream for the forward and the backward graphs (segments.py)
+        with torch.cuda.graph(cap.graph_f, stream=cstream, **mode):
             loss, logs, art = forward()
             cap.out3 = model._last_nelbo
         if SEGMENT_CALLS > 0 and HF.WGRAD_SIDE_STREAM == 1:
             # the backward pass as a chain of linear graphs + side graphs (engine/segments.py): ~0.1 ms of host time per replay
             # instead of ~0.8 ms for one graph with a fork per layer, which matters on this host-bound route
-            cap.graph_b = SegmentedStep(engine.device, HF._PendingReduce.side_stream(engine.device), pool=cap.graph_f.pool())
+            cap.graph_b = SegmentedStep(engine.device, HF._PendingReduce.side_stream(engine.device), pool=cap.graph_f.pool(),
+                                        stream=cstream)
             HF._PendingReduce.begin_segments(engine.device, cap.graph_b)
             try:
                 with cap.graph_b:
@@ -145,7 +147,7 @@ class GraphedNelbo:
                 HF._PendingReduce.end_segments(engine.device)
         else:
             cap.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cap.graph_b, pool=cap.graph_f.pool(), **mode):
+            with torch.cuda.graph(cap.graph_b, pool=cap.graph_f.pool(), stream=cstream, **mode):
                 backward(loss)
         cap.out3 = cap.out3.detach()
         # tensors only (preds, latents, preds_mean ...): a prior's lazily built distribution objects could hold the captured pass's

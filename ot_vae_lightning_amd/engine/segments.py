@@ -40,8 +40,12 @@ class SegmentedStep:
         seg.replay()
     """
 
-    def __init__(self, device, side_stream: "torch.cuda.Stream", pool=None):
+    def __init__(self, device, side_stream: "torch.cuda.Stream", pool=None, stream: Optional["torch.cuda.Stream"] = None):
         self.device = device
+        # the capture stream.  Autograd runs a node's backward on the stream its forward ran on: a backward pass that is cut into
+        # segments must be captured on the SAME stream its forward pass was captured on, or the engine's cross-stream hand-over
+        # (a fork of the capture) is still open when a cut ends the graph ("capturing stream has unjoined work")
+        self._stream = stream
         self.side_stream = side_stream
         self.main: List[torch.cuda.CUDAGraph] = []
         self.side: List[Optional[torch.cuda.CUDAGraph]] = []      # side[k] runs behind main[k]
@@ -49,7 +53,9 @@ class SegmentedStep:
         self._side_work: List[Optional[Callable[[], None]]] = []
         self._pending_join = False
         self._cur: Optional[torch.cuda.CUDAGraph] = None
-        self._pool = pool   # None: the first graph's own pool; else the pool of graphs captured before (their tensors are read here)
+        # one private pool for all graphs of the step (None: a fresh one; else the pool of graphs captured before, whose tensors
+        # are read here)
+        self._pool = pool if pool is not None else torch.cuda.graph_pool_handle()
         self._ctx = None
         self._events: List[torch.cuda.Event] = []
         self._join_event = torch.cuda.Event()
@@ -60,18 +66,15 @@ class SegmentedStep:
     def _begin_graph(self):
         g = torch.cuda.CUDAGraph()
         # "relaxed": the autograd engine ends / begins captures from its worker thread (a cut lands inside backward)
-        if self._pool is None:
-            g.capture_begin(capture_error_mode="relaxed")
-            self._pool = g.pool()
-        else:
-            g.capture_begin(pool=self._pool, capture_error_mode="relaxed")
+        g.capture_begin(pool=self._pool, capture_error_mode="relaxed")
         self._cur = g
         self.join_before.append(self._pending_join)
         self._pending_join = False
 
     def __enter__(self):
         torch.cuda.synchronize(self.device)
-        self._stream = torch.cuda.Stream(device=self.device)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
         self._stream.wait_stream(torch.cuda.current_stream(self.device))
         self._ctx = torch.cuda.stream(self._stream)
         self._ctx.__enter__()
@@ -91,7 +94,11 @@ class SegmentedStep:
     def __exit__(self, exc_type, exc, tb):
         try:
             if self._cur is not None:
-                self._cur.capture_end()
+                try:
+                    self._cur.capture_end()
+                except Exception:  # noqa: BLE001
+                    if exc_type is None:
+                        raise      # (an exception already under way is the one to report; the capture is invalid either way)
                 if exc_type is None:
                     self.main.append(self._cur)
                     self._side_work.append(None)
