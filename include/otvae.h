@@ -284,6 +284,20 @@ int otvae_bn_act_bwd(const float* ga, const float* x, const float* scale, const 
 /* dst[i] = alpha * src[i], n contiguous floats (weight * conv_scale * lr_mult, bias * lr_mult and their gradients) */
 int otvae_scale_f32(const float* src, float alpha, int64_t n, float* dst, void* stream);
 
+/* ---- GroupNorm / InstanceNorm2d in front of a ConvLayer's activation (networks/cnn.py:121-125: nn.GroupNorm(div_sqrt(C // groups), C),
+ * nn.InstanceNorm2d(C) = G == C without gamma / beta).  x, out, ga, dx [N][HW][C] channels-last; statistics per (sample, group) over
+ * the group's C / G channels and all HW positions (biased variance, eps inside the root); kind: the activation codes above. */
+/* out = act(xhat * gamma + beta) (gamma == beta == NULL: act(xhat)); mean, rstd [N][G] are kept for the backward */
+int otvae_group_norm_act_fwd(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps, int kind,
+                             float* out, float* mean, float* rstd, void* stream);
+/* dx of the same chain from ga = dL/d out; with gamma also the per-sample parameter partials pgamma, pbeta [N][C]
+ * (d gamma = otvae_colsum_f32(pgamma), d beta likewise) */
+int otvae_group_norm_act_bwd(const float* ga, const float* x, const float* gamma, const float* beta, const float* mean,
+                             const float* rstd, int N, int HW, int C, int G, int kind, float* dx, float* pgamma, float* pbeta,
+                             void* stream);
+/* dst[c] = sum_r src[r][c] in fixed order, src [R][C] */
+int otvae_colsum_f32(const float* src, int R, int C, float* dst, void* stream);
+
 /* ---- GaussianModel(update_with_autograd=True): log-density under N(mean, L L^T) / N(mean, diag(sigma^2))
  * (ot/distribution_models/gaussian_model.py:52-55,76-93,125-128; torch.distributions.MultivariateNormal(scale_tril=) /
  * Independent(Normal) in the reference).  fp64, x / y / qg [nb][B][D], mean [nb][D], L [nb][D][D] lower triangular with a

@@ -85,6 +85,12 @@ CONV_CASES = [
     ("silu_nonorm", "ConvLayer", 4, 8, 8, dict(activation="silu")),
     ("swish_bn_1ch", "ConvLayer", 1, 4, 16, dict(normalization="batchnorm", activation="swish")),
     ("eq_1x1", "Conv1x1", 8, 24, 8, dict(normalization="batchnorm", equalized_lr=0.5)),
+    # GroupNorm(div_sqrt(C), C) / InstanceNorm2d(C) in place of BatchNorm (cnn.py:123-124)
+    ("gn_relu", "ConvLayer", 8, 8, 8, dict(normalization="groupnorm", activation="relu")),
+    ("gn_down_leaky", "ConvLayer", 12, 8, 8, dict(down_sample=2, normalization="groupnorm", activation="leaky")),
+    ("gn_1x1_up", "Conv1x1", 16, 8, 4, dict(up_sample=2, normalization="groupnorm")),
+    ("in_silu", "ConvLayer", 6, 8, 8, dict(normalization="instancenorm", activation="silu")),
+    ("in_relu_up", "ConvLayer", 8, 4, 4, dict(up_sample=2, normalization="instancenorm", activation="relu")),
 ]
 
 

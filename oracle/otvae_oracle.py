@@ -105,7 +105,7 @@ _ACTIVATIONS = {  # cnn.py:128-147 (the reference tests the names in this order:
 
 def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: bool, relu: bool,
                norm: bool, ksize: int = 3, training: bool = True, act: Optional[str] = None,
-               equalized_lr: Optional[float] = None) -> Tensor:
+               equalized_lr: Optional[float] = None, other_norm: Optional[str] = None) -> Tensor:
     """``ConvLayer.forward`` (networks/cnn.py:183-192): BN -> act -> nearest x2 up -> conv (stride-2 4x4 when
     down-sampling, cnn.py:98-101).  ``p[prefix+'_normalization.running_*']`` are updated in place like
     nn.BatchNorm2d does in training mode.  ``act``: one of leaky / relu / selu / gelu / silu (overrides ``relu``);
@@ -115,6 +115,12 @@ def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: 
         out = F.batch_norm(out, p[prefix + "_normalization.running_mean"], p[prefix + "_normalization.running_var"],
                            p[prefix + "_normalization.weight"], p[prefix + "_normalization.bias"],
                            training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
+    if other_norm == "group":      # nn.GroupNorm(div_sqrt(C), C) (cnn.py:123, groups = 1)
+        c = out.shape[1]
+        g = next(d for d in range(1, c + 1) if c % d == 0 and d >= math.sqrt(c))
+        out = F.group_norm(out, g, p[prefix + "_normalization.weight"], p[prefix + "_normalization.bias"], eps=BN_EPS)
+    elif other_norm == "instance":  # nn.InstanceNorm2d(C): no affine, no running statistics (cnn.py:124)
+        out = F.instance_norm(out, eps=BN_EPS)
     if act is not None:
         out = _ACTIVATIONS[act](out)
     elif relu:

@@ -722,6 +722,44 @@ def _is_dense(t: Tensor) -> bool:
     return True
 
 
+class _GroupNormActFn(torch.autograd.Function):
+    """a = act(GroupNorm(x)) / act(InstanceNorm(x)) (``gamma`` None) as one launch per pass (csrc/groupnorm.hip)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, kind, params_ref):
+        lib = _lib.load()
+        n, c, h, w = x.shape
+        a = empty_nhwc(n, c, h, w, x)
+        mean = torch.empty((n, groups), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        check(lib.otvae_group_norm_act_fwd(ptr(x), ptr(gamma), ptr(beta), n, h * w, c, groups, BN_EPS, kind, ptr(a), ptr(mean), ptr(rstd),
+                                           stream()), "otvae_group_norm_act_fwd")
+        ctx.cfg = (groups, kind, params_ref)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return a
+
+    @staticmethod
+    def backward(ctx, ga):
+        lib = _lib.load()
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        groups, kind, params_ref = ctx.cfg
+        n, c, h, w = x.shape
+        ga = as_nhwc(ga)
+        dx = empty_nhwc(n, c, h, w, x)
+        pg = pb = None
+        if gamma is not None:
+            pg = torch.empty((n, c), device=x.device, dtype=torch.float32)
+            pb = torch.empty_like(pg)
+        check(lib.otvae_group_norm_act_bwd(ptr(ga), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), n, h * w, c, groups, kind, ptr(dx),
+                                           ptr(pg), ptr(pb), stream()), "otvae_group_norm_act_bwd")
+        dgam = dbet = None
+        if gamma is not None:
+            dgam, dbet = _grad_buffer(params_ref[0], gamma), _grad_buffer(params_ref[1], beta)
+            check(lib.otvae_colsum_f32(ptr(pg), n, c, ptr(dgam), stream()), "otvae_colsum_f32")
+            check(lib.otvae_colsum_f32(ptr(pb), n, c, ptr(dbet), stream()), "otvae_colsum_f32")
+        return dx, dgam, dbet, None, None, None
+
+
 class _ScaleFn(torch.autograd.Function):
     """alpha * t on t's own memory order (the ``weight * conv_scale * lr_mult`` / ``bias * lr_mult`` of equalized_lr)"""
 
@@ -758,7 +796,10 @@ def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
             sc, sh = [s0], [h0]
         stats = (mean, invstd, sc[0], sh[0], training)
     a = x
-    if has_norm or kind != 0:
+    gn = br.get("group_norm")   # (groups, weight | None, bias | None): GroupNorm / InstanceNorm2d instead of BatchNorm
+    if gn is not None:
+        a = _GroupNormActFn.apply(x, gn[1], gn[2], int(gn[0]), kind, (gn[1], gn[2]))
+    elif has_norm or kind != 0:
         a = _BnActFn.apply(x, br.get("gamma"), br.get("beta"), stats, kind, (br.get("gamma"), br.get("beta")))
     w = br["weight"]
     w = w if is_hwio(w) else hwio_weight(w)
@@ -782,7 +823,8 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
     x = as_nhwc(x)
     if x.dtype != torch.float32:
         raise TypeError("the MI355X conv path computes in fp32")
-    if any(br.get("act", 0) > 1 or br.get("wscale", 1.0) != 1.0 or br.get("bscale", 1.0) != 1.0 for br in branches):
+    if any(br.get("act", 0) > 1 or br.get("wscale", 1.0) != 1.0 or br.get("bscale", 1.0) != 1.0 or br.get("group_norm") is not None
+           for br in branches):
         return tuple(_conv_layer_general(x, br, training) for br in branches)
     specs, tensors, params_ref, bns = [], [], [], []
     for br in branches:

@@ -9,8 +9,9 @@ stay channels-last between layers, and attention never materialises the TxT matr
 
 Activations other than ReLU (LeakyReLU(0.2), SELU, GELU, SiLU) and ``equalized_lr`` -- what the reference's
 configs/vae/defaults_imagenet.yaml trains with -- run unfused around the same kernels (functional._conv_layer_general,
-csrc/activation.hip).  Options no configuration of the reference uses on this path (group/instance norm, FiLM embeddings,
-dropout, grouped/dilated convolutions) are rejected with ``NotImplementedError`` rather than silently run elsewhere.
+csrc/activation.hip), and so do GroupNorm / InstanceNorm2d (csrc/groupnorm.hip).  Options no configuration of the reference uses
+on this path (FiLM embeddings, dropout, grouped/dilated convolutions) are rejected with ``NotImplementedError`` rather than
+silently run elsewhere.
 """
 import math
 import warnings
@@ -92,8 +93,10 @@ class ConvLayer(nn.Module):
             self._normalization = nn.Identity()
         elif "batch" in normalization.lower():
             self._normalization = nn.BatchNorm2d(in_features)  # parameter/buffer container; its forward is never called
-        elif "group" in normalization.lower() or "instance" in normalization.lower():
-            raise NotImplementedError(f"normalization={normalization} is not supported on the MI355X path")
+        elif "group" in normalization.lower():     # cnn.py:123 (groups == 1 here: grouped convolutions are not on this path)
+            self._normalization = nn.GroupNorm(div_sqrt(in_features // groups), in_features)
+        elif "instance" in normalization.lower():  # cnn.py:124: no affine parameters, no running statistics
+            self._normalization = nn.InstanceNorm2d(in_features)
         else:
             raise NotImplementedError(f"normalization={normalization} not supported")
 
@@ -134,7 +137,12 @@ class ConvLayer(nn.Module):
 
     def branch(self, residual: Optional[Tensor] = None, out_stats: bool = True) -> dict:
         bn = self._normalization if self._has_norm else None
-        return dict(weight=self.weight, bias=self.bias,
+        gn = None
+        if isinstance(self._normalization, nn.GroupNorm):
+            gn = (self._normalization.num_groups, self._normalization.weight, self._normalization.bias)
+        elif isinstance(self._normalization, nn.InstanceNorm2d):
+            gn = (self.in_channels, None, None)
+        return dict(group_norm=gn, weight=self.weight, bias=self.bias,
                     gamma=bn.weight if bn is not None else None, beta=bn.bias if bn is not None else None,
                     running_mean=bn.running_mean if bn is not None else None,
                     running_var=bn.running_var if bn is not None else None,

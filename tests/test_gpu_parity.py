@@ -144,6 +144,11 @@ CONV_CTOR = {
     "silu_nonorm": ("ConvLayer", dict(activation="silu")),
     "swish_bn_1ch": ("ConvLayer", dict(normalization="batchnorm", activation="swish")),
     "eq_1x1": ("Conv1x1", dict(normalization="batchnorm", equalized_lr=0.5)),
+    "gn_relu": ("ConvLayer", dict(normalization="groupnorm", activation="relu")),
+    "gn_down_leaky": ("ConvLayer", dict(down_sample=2, normalization="groupnorm", activation="leaky")),
+    "gn_1x1_up": ("Conv1x1", dict(up_sample=2, normalization="groupnorm")),
+    "in_silu": ("ConvLayer", dict(normalization="instancenorm", activation="silu")),
+    "in_relu_up": ("ConvLayer", dict(up_sample=2, normalization="instancenorm", activation="relu")),
 }
 
 

@@ -29,6 +29,10 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
     "selu_down": (True, False, False, True, 3, "selu", None), "gelu_up": (False, True, False, True, 3, "gelu", None),
     "silu_nonorm": (False, False, False, False, 3, "silu", None), "swish_bn_1ch": (False, False, False, True, 3, "silu", None),
     "eq_1x1": (False, False, False, True, 1, None, 0.5),
+    # (..., activation, equalized_lr, normalisation): GroupNorm / InstanceNorm2d instead of BatchNorm (cnn.py:123-124)
+    "gn_relu": (False, False, False, False, 3, "relu", None, "group"), "gn_down_leaky": (True, False, False, False, 3, "leaky", None, "group"),
+    "gn_1x1_up": (False, True, False, False, 1, None, None, "group"), "in_silu": (False, False, False, False, 3, "silu", None, "instance"),
+    "in_relu_up": (False, True, False, False, 3, "relu", None, "instance"),
 }
 
 
@@ -36,14 +40,14 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
 def test_conv_layer(name):
     g = group(load_golden("convlayer.npz"), name)
     down, up, relu, norm, ks, *opt = CONV_GEOM[name]
-    act, eq = opt if opt else (None, None)
+    act, eq, gn = (list(opt) + [None, None, None])[:3]
     p = {k[len("param/"):]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("param/")}
     if norm:
         c = g["x"].shape[1]
         p["_normalization.running_mean"] = torch.zeros(c)
         p["_normalization.running_var"] = torch.ones(c)
     x = g["x"].clone().requires_grad_(True)
-    y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks, act=act, equalized_lr=eq)
+    y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks, act=act, equalized_lr=eq, other_norm=gn)
     y.backward(g["gy"])
     assert rel_err(y, g["y"]) < TIGHT
     assert rel_err(x.grad, g["gx"]) < TIGHT
