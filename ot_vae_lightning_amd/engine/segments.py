@@ -25,8 +25,13 @@ import torch
 
 __all__ = ["SegmentedStep", "SEGMENT_CALLS"]
 
-# backward calls (ConvBlock stages) per launch-stream graph; 0 disables the segmented capture (the forked single graph of round 2)
-SEGMENT_CALLS = int(os.environ.get("OTVAE_SEGMENT_CALLS", "6"))
+# backward calls (ConvBlock stages) per launch-stream graph; 0 (default) = the forked single graph of round 2.
+# MEASURED on the MI355X (profiles/r03_segments_ab.txt, batch 1024, ms per step / host enqueue ms per step):
+#   forked graph 2.81 / 2.32;  12-call segments (3 graphs) 2.96 / 0.26;  6-call (5 graphs) 3.03 / 0.34;  3-call (10 graphs) 3.11 / 0.51.
+# Every graph-to-graph boundary on the launch stream costs the DEVICE ~35 us (more than the ~3 us per fork it removes) even
+# though the launches are enqueued ahead; the host cost per replay does fall 7-9x.  The segmented capture therefore stays an A/B
+# switch (OTVAE_SEGMENT_CALLS=n): it is the better shape only where the host, not the device, bounds the step.
+SEGMENT_CALLS = int(os.environ.get("OTVAE_SEGMENT_CALLS", "0"))
 
 
 class SegmentedStep:

@@ -184,13 +184,8 @@ class CodebookModel(DistributionModel):
         """1 / (|x - c_k|_2 + 1e-8) [*, B, K] (codebook_model.py:150-156); only the tiny atoms-vs-atoms case of ``w2``
         goes through here, the assignment kernels never materialise it."""
         self._validate_samples(samples)
-        if self.p != 2:
-            raise NotImplementedError("CodebookModel on the MI355X path implements the euclidean metric (p = 2)")
-        from ..w2_utils import sq_euclidean_cost
-        x = samples.type_as(self.codebook)
-        cb = self.codebook.expand(*x.shape[:-2], *self.codebook.shape[-2:]) if self.codebook.dim() < x.dim() else self.codebook
-        # |x - c|_2 from otvae_sqdist; clamped: the expanded form can come out at -1e-7 for x == c (torch.cdist clamps alike)
-        return 1 / (sq_euclidean_cost(x.contiguous(), cb.contiguous()).clamp_min(0).sqrt() + 1e-8)
+        # (kept on torch.cdist: the Gumbel assignment modes differentiate through this value, and otvae_sqdist has no backward)
+        return 1 / (torch.cdist(samples.type_as(self.codebook), self.codebook, self.p) + 1e-8)
 
     @property
     def mode(self) -> str:
