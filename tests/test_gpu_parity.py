@@ -1953,8 +1953,11 @@ def test_gaussian_model_recovers_the_sampling_distribution(A, diag):
     streamed.fit()
     assert float(streamed.w2(truth_gpu).max()) < _REF_TOL
     assert torch.allclose(streamed.mean, fitted.mean, atol=1e-9) and torch.allclose(streamed.cov, fitted.cov, atol=1e-9)
-    with pytest.raises(NotImplementedError):
-        A.GaussianModel(*size, **kwargs, update_with_autograd=True)
+    # the third mode of the reference's test, 'autograd' (:150-168), has its own test: test_gaussian_model_update_with_autograd
+    auto = A.GaussianModel(*size, **kwargs, update_with_autograd=True).cuda()
+    assert auto.mean.requires_grad and not hasattr(auto, "_running_sum")
+    with pytest.raises(RuntimeError):
+        auto.update(samples[..., :100, :])
 
 
 def test_gaussian_mixture_model_on_the_references_recovery_experiment(A):
