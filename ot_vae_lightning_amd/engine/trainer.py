@@ -31,8 +31,6 @@ from ..networks.cnn import ConvLayer
 from .dp import FlatGradReducer
 from .segments import SEGMENT_CALLS, SegmentedStep
 
-AUX_LANE = os.environ.get("OTVAE_AUX_LANE", "1") != "0"
-
 __all__ = ["HipTrainer", "flatten_parameters"]
 
 
@@ -215,27 +213,13 @@ class HipTrainer:
             p.grad = None
         from ..functional import PriorLane
         PriorLane.enabled = True  # the prior's OT work may run beside the decoder: this method joins it (functional.PriorLane)
-        # OTVAE_AUX_LANE: small launches that nothing on the forward / backward chain waits for ride on the same lane (captured
-        # steps): the refresh of the transposed weights (read by the data-gradient kernels only), the loss vector (the backward
-        # pass needs pred and target, not its value) and the latent statistics (they need the latents)
-        aux = AUX_LANE and PriorLane.active(self.device)
-        stats_done = False
+        # (Round 3 tried to put the step's small off-chain launches -- the refresh of the transposed weights, the loss vector, the
+        # latent statistics -- on the same lane: 2.80 -> 2.86 ms at batch 1024, the extra graph branches cost more than the ~40 us
+        # of launches they take off the chain; removed.)
         try:
-            wd_ready = None
-            if aux:
-                with PriorLane.section(self.device):
-                    self._refresh_wd()
-                wd_ready = PriorLane._open[self.device]
-            else:
-                self._refresh_wd()
+            self._refresh_wd()
             loss, logs, art = self.model.nelbo(self._batch(), 0)
             self.latents = art["latents"].detach()
-            if aux and self.latent_stats is not None:
-                with PriorLane.section(self.device):
-                    self.latent_stats.update(target_samples=self.latents.flatten(1))
-                stats_done = True
-            if wd_ready is not None:
-                torch.cuda.current_stream(self.device).wait_event(wd_ready)  # long complete: the transposes ran beside the encoder
             self._backward(loss)
         finally:
             PriorLane.enabled = False
@@ -249,7 +233,7 @@ class HipTrainer:
         _PendingReduce.flush(self.device)  # normally already done by the autograd-engine callback at the end of backward
         self._collect_loose_grads()
         self._logs = {k: v.detach() for k, v in logs.items()}  # no reference into the autograd graph survives the step
-        if self.latent_stats is not None and not stats_done:
+        if self.latent_stats is not None:
             lat = self.latents.flatten(1)  # [B, D] with transport_dims = (1, 2, 3)
             self.latent_stats.update(target_samples=lat)
         return self._logs

@@ -1031,6 +1031,32 @@ def test_segmented_capture_equals_forked_capture(A, prior_kind, monkeypatch):
             assert torch.equal(a, b), f"{prior_kind}: {name} differ between the eager step and the captured one"
 
 
+def test_prior_lane_with_a_vit_autoencoder_equals_in_line_order(A, monkeypatch):
+    """the same lane with token networks around it (ViT encoder / decoder, reconstruction re-laid out before the loss kernel):
+    SinkhornPrior on the latent token, captured step, lane vs in-line order bit for bit"""
+    from ot_vae_lightning_amd import functional as HF
+    cfg = dict(image_size=16, patch_size=4, dim=32, depth=2, heads=4, mlp_dim=64, channels=3, dropout=0.0, emb_dropout=0.)
+    xs = [normal((64, 3, 16, 16), 171 + i).cuda() for i in range(3)]
+
+    def run(mode):
+        monkeypatch.setattr(HF, "PRIOR_SIDE_STREAM", mode)
+        torch.manual_seed(15)
+        enc = A.ViT(n_embed_tokens=1, n_input_tokens=None, output_tokens="embed", patch_to_embed=True, embed_to_patch=False, **cfg)
+        dec = A.ViT(n_embed_tokens=None, n_input_tokens=1, output_tokens="embed", patch_to_embed=False, embed_to_patch=True, **cfg)
+        model = A.VAE(encoder=enc, decoder=dec, prior=A.SinkhornPrior(reg=0.05, max_iter=50, threshold=0.0, seed=3)).cuda().train()
+        tr = A.HipTrainer(model, batch_shape=(64, 3, 16, 16), use_graph=True)
+        outs = torch.stack([tr.step(x).clone() for x in xs])
+        torch.cuda.synchronize()
+        res = (outs, tr.gflat.clone(), tr.pflat.clone())
+        tr.close()
+        return res
+
+    lane, inline = run(1), run(0)
+    assert torch.isfinite(lane[0]).all() and float(lane[0][:, 2].min()) > 0
+    for name, a, b in zip(("losses", "gradients", "parameters"), lane, inline):
+        assert torch.equal(a, b), f"{name} differ between the prior lane and the in-line order"
+
+
 def test_gradient_clipping_matches_clip_grad_norm(A):
     """Global-norm clipping of the step (reference configs/ddp.yaml:4 -> Lightning -> torch.nn.utils.clip_grad_norm_): the
     norm the kernel reports, the coefficient and the clipped Adam update against torch arithmetic on the same gradient."""
