@@ -21,33 +21,44 @@ __global__ __launch_bounds__(256) void w2_prior_tail_kernel(const double* __rest
                                                             const double* __restrict__ lam, const double* __restrict__ vt, int D,
                                                             int source_is_m, double scale, int rep_n, float* __restrict__ loss_out,
                                                             double* __restrict__ q) {
-    __shared__ double red[4];
-    __shared__ double s_shift;
+    __shared__ double red[4], red2[4];
+    __shared__ double s_shift, s_floor;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // lambda_min -> shift (every block computes it: D reads)
-    double lo = INFINITY;
-    for (int i = threadIdx.x; i < D; i += 256) lo = fmin(lo, lam[i]);
+    // lambda_min -> shift (every block computes it: D reads); general target: the mean target variance for the floor below
+    double lo = INFINITY, tv = 0.0;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        lo = fmin(lo, lam[i]);
+        if (covt) tv += covt[(size_t)i * D + i];
+    }
     lo = wave_min(lo);
-    if (lane == 0) red[wv] = lo;
+    tv = wave_sum(tv);
+    if (lane == 0) {
+        red[wv] = lo;
+        red2[wv] = tv;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         const double m = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
         s_shift = (source_is_m && !(m > 0.0)) ? fabs(fmin(m, 0.0)) + 1e-8 : 0.0;
+        // General target: lambda are the eigenvalues of covt^1/2 S covt^1/2.  The reference validates S with make_pd (a rank-
+        // deficient batch covariance, B <= D, gets |lambda_min| + 1e-8 on its diagonal), which lifts them by ~1e-8 x the target's
+        // variances; without it lambda^-1/4 below is infinite and the captured step trains to NaN.  Clamped at that size.
+        s_floor = source_is_m ? 0.0 : 1e-8 * ((red2[0] + red2[1]) + (red2[2] + red2[3])) / (double)D;
     }
     __syncthreads();
-    const double shift = s_shift;
+    const double shift = s_shift, floor_ = s_floor;
     // Q[k][:] = (lambda_k + shift)^-1/4 V^T[k][:]
     const size_t total = (size_t)D * D;
     for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int k = (int)(e / D);
-        q[e] = vt[e] / sqrt(sqrt(lam[k] + shift));
+        q[e] = vt[e] / sqrt(sqrt(fmax(lam[k] + shift, floor_)));
     }
     if (blockIdx.x != 0) return;
     double s = 0.0;
     for (int i = threadIdx.x; i < D; i += 256) {
         const double dm = mu[i] - (mut ? mut[i] : 0.0);
         const size_t dd = (size_t)i * D + i;
-        s += dm * dm + (cov[dd] + shift) + (covt ? covt[dd] : 1.0) - 2.0 * sqrt(lam[i] + shift);
+        s += dm * dm + (cov[dd] + shift) + (covt ? covt[dd] : 1.0) - 2.0 * sqrt(fmax(lam[i] + shift, floor_));
     }
     s = wave_sum(s);
     __syncthreads();

@@ -323,6 +323,21 @@ def test_gaussian_w2_prior_in_vae_training_step(A):
     rep.finish()
 
 
+def test_gaussian_w2_prior_rank_deficient_batch_with_a_general_target_stays_finite(A):
+    """B <= D makes the batch covariance rank deficient; with a general ``target_cov`` the eigenvalues of
+    covt^1/2 S covt^1/2 then hold zeros, lambda^-1/4 was infinite and loss / gradient came out inf / NaN (the reference shifts S by
+    1e-8 through make_pd and stays finite).  The tail kernel now clamps at that size."""
+    D, B = 32, 16
+    g = torch.Generator().manual_seed(41)
+    a = torch.randn(D, D, generator=g, dtype=torch.double) / D ** 0.5
+    prior = A.GaussianW2Prior(loss_coeff=1.0, target_mean=torch.zeros(D, dtype=torch.double),
+                              target_cov=a @ a.T + 0.5 * torch.eye(D, dtype=torch.double)).cuda().train()
+    z = torch.randn(B, D, generator=g).cuda().requires_grad_(True)
+    _, loss, _ = prior(z, step=0)
+    loss.mean().backward()
+    assert torch.isfinite(loss).all() and torch.isfinite(z.grad).all() and float(z.grad.abs().max()) > 0
+
+
 def test_device_normal_generator(A):
     """``otvae_normal_fill``: standard-normal moments, a fresh draw per call (the counter advances on the device, also inside a
     replayed graph), the same values for the same (seed, counter) whatever the launch, independent streams."""
