@@ -388,6 +388,15 @@ class PriorLane:
     enabled = False          # set by HipTrainer around the step it issues
     _streams: dict = {}
     _open: dict = {}         # device -> event after the lane's last piece of work (None: nothing forked)
+    _held: dict = {}         # device -> launch-stream tensors a lane kernel reads: kept alive until the join
+
+    @staticmethod
+    def hold(device, *tensors) -> None:
+        """Operands of a lane kernel that were allocated on the LAUNCH stream must outlive that kernel: a temporary (e.g. the
+        channels-last copy of a ViT's reconstruction handed to the loss kernel) that autograd releases when the node's own backward
+        has run would go back to the launch stream's pool and be handed to the next backward tensor while the lane still reads
+        it (found in round 3: recon came out as 2e-9 in a captured ViT + SinkhornPrior step)."""
+        PriorLane._held.setdefault(device, []).extend(t for t in tensors if t is not None)
 
     @staticmethod
     def active(device) -> bool:
@@ -439,6 +448,9 @@ class PriorLane:
         if done is not None:
             torch.cuda.current_stream(device).wait_event(done)
             PriorLane._open[device] = None
+        held = PriorLane._held.get(device)
+        if held:
+            held.clear()
 
 
 # ------------------------------------------------------------------------------------------------ fused ConvLayer(s)

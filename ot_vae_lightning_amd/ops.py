@@ -254,6 +254,7 @@ def _nelbo_fwd(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor], chw: 
     if PriorLane.is_open(pred.device) and PriorLane.active(pred.device):
         # the prior term is still being computed on the prior lane (functional.PriorLane): the loss vector is formed there too,
         # behind it -- the backward pass needs pred and target, not this value
+        PriorLane.hold(pred.device, pred, target, prior_loss)
         with PriorLane.section(pred.device):
             return _nelbo_fwd_launch(pred, target, prior_loss, chw)
     return _nelbo_fwd_launch(pred, target, prior_loss, chw)

@@ -29,6 +29,7 @@ class _W2PriorFn(torch.autograd.Function):
         from ..functional import PriorLane
         ctx.lane = PriorLane.active(z.device)
         if ctx.lane:  # beside the decoder, on the prior lane of a training engine's step (functional.PriorLane)
+            PriorLane.hold(z.device, z, mut, covt, rt)
             with PriorLane.section(z.device):
                 loss, mu, q, vt = torch.ops.otvae.gaussian_w2_prior(z, mut, covt, rt, v_init, warm, float(scale))
                 if v_init is not None:  # the warm-start basis of the next step, behind the solve that produced it

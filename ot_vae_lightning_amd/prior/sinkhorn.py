@@ -27,6 +27,7 @@ class _SinkhornLossFn(torch.autograd.Function):
         from ..functional import PriorLane
         ctx.lane = PriorLane.active(z.device)
         if ctx.lane:  # beside the decoder, on the prior lane of a training engine's step (functional.PriorLane)
+            PriorLane.hold(z.device, z, y)
             with PriorLane.section(z.device):
                 cost, pi, iters = torch.ops.otvae.sinkhorn_prior(z, y, float(reg), int(max_iter), float(threshold), float(scale))
         else:
