@@ -298,6 +298,19 @@ int otvae_group_norm_act_bwd(const float* ga, const float* x, const float* gamma
 /* dst[c] = sum_r src[r][c] in fixed order, src [R][C] */
 int otvae_colsum_f32(const float* src, int R, int C, float* dst, void* stream);
 
+/* ---- FiLM conditioning (`additional_embed`) and Dropout2d of ConvLayer (networks/cnn.py:112-118,160-192); x, out, g [N][HW][C] ------- */
+/* out = x * scale[n][c] + bias[n][c] (scale / bias [N][C]: the two Linear projections of the activated embedding) */
+int otvae_film_fwd(const float* x, const float* scale, const float* bias, int N, int HW, int C, float* out, void* stream);
+/* gx = g * scale; gscale[n][c] = sum_hw g x; gbias[n][c] = sum_hw g */
+int otvae_film_bwd(const float* g, const float* x, const float* scale, int N, int HW, int C, float* gx, float* gscale, float* gbias,
+                   void* stream);
+/* nn.Dropout2d(p): y = keep(n, c) ? x / (1 - p) : 0 with keep = hash(call key, n, c); key = device int64[2] {seed, call counter},
+ * used[0] <- the call key (the backward and otvae_dropout2d_mask recompute the mask from it; no mask tensor) */
+int otvae_dropout2d_fwd(const float* x, int N, int HW, int C, float p, const int64_t* key, int stream_id, float* y, int64_t* used,
+                        void* stream);
+int otvae_dropout2d_bwd(const float* gy, int N, int HW, int C, float p, const int64_t* used, float* gx, void* stream);
+int otvae_dropout2d_mask(int N, int C, float p, const int64_t* used, uint8_t* keep, void* stream);
+
 /* ---- GaussianModel(update_with_autograd=True): log-density under N(mean, L L^T) / N(mean, diag(sigma^2))
  * (ot/distribution_models/gaussian_model.py:52-55,76-93,125-128; torch.distributions.MultivariateNormal(scale_tril=) /
  * Independent(Normal) in the reference).  fp64, x / y / qg [nb][B][D], mean [nb][D], L [nb][D][D] lower triangular with a

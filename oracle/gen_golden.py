@@ -91,6 +91,10 @@ CONV_CASES = [
     ("gn_1x1_up", "Conv1x1", 16, 8, 4, dict(up_sample=2, normalization="groupnorm")),
     ("in_silu", "ConvLayer", 6, 8, 8, dict(normalization="instancenorm", activation="silu")),
     ("in_relu_up", "ConvLayer", 8, 4, 4, dict(up_sample=2, normalization="instancenorm", activation="relu")),
+    # FiLM conditioning (`additional_embed`, cnn.py:114-116,160-181): forward(x, embed) with embed [B, E]
+    ("film_relu", "ConvLayer", 8, 8, 8, dict(normalization="batchnorm", activation="relu", additional_embed=5)),
+    ("film_leaky_eq", "ConvLayer", 4, 8, 8, dict(down_sample=2, normalization="batchnorm", activation="leaky", equalized_lr=2., additional_embed=6)),
+    ("film_1x1_gn", "Conv1x1", 8, 24, 8, dict(normalization="groupnorm", additional_embed=5)),
 ]
 
 
@@ -102,9 +106,14 @@ def gen_convlayer():
         layer.train()
         fill_state_dict(layer.state_dict())
         x = det_input((4, cin, hw, hw), phase=0.3).requires_grad_(True)
-        y = layer(x)
+        emb = None
+        if kw.get("additional_embed"):
+            emb = det_input((4, kw["additional_embed"]), phase=0.8, amp=0.9).requires_grad_(True)
+        y = layer(x, emb) if emb is not None else layer(x)
         g = det_input(tuple(y.shape), phase=1.1, amp=0.7)
         y.backward(g)
+        if emb is not None:
+            out[f"{name}/embed"], out[f"{name}/gembed"] = npy(emb), npy(emb.grad)
         out[f"{name}/x"] = npy(x)
         out[f"{name}/gy"] = npy(g)
         out[f"{name}/y"] = npy(y)

@@ -105,7 +105,7 @@ _ACTIVATIONS = {  # cnn.py:128-147 (the reference tests the names in this order:
 
 def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: bool, relu: bool,
                norm: bool, ksize: int = 3, training: bool = True, act: Optional[str] = None,
-               equalized_lr: Optional[float] = None, other_norm: Optional[str] = None) -> Tensor:
+               equalized_lr: Optional[float] = None, other_norm: Optional[str] = None, embed: Optional[Tensor] = None) -> Tensor:
     """``ConvLayer.forward`` (networks/cnn.py:183-192): BN -> act -> nearest x2 up -> conv (stride-2 4x4 when
     down-sampling, cnn.py:98-101).  ``p[prefix+'_normalization.running_*']`` are updated in place like
     nn.BatchNorm2d does in training mode.  ``act``: one of leaky / relu / selu / gelu / silu (overrides ``relu``);
@@ -121,10 +121,15 @@ def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: 
         out = F.group_norm(out, g, p[prefix + "_normalization.weight"], p[prefix + "_normalization.bias"], eps=BN_EPS)
     elif other_norm == "instance":  # nn.InstanceNorm2d(C): no affine, no running statistics (cnn.py:124)
         out = F.instance_norm(out, eps=BN_EPS)
-    if act is not None:
-        out = _ACTIVATIONS[act](out)
-    elif relu:
-        out = F.relu(out)
+    fn = _ACTIVATIONS[act] if act is not None else (F.relu if relu else (lambda t: t))
+    if embed is not None:  # FiLM (cnn.py:160-181): scale / bias = Linear(act(embed)) with the equalized_lr multipliers
+        lr = equalized_lr or 1.0
+        ls = (1.0 / math.sqrt(x.shape[1])) if equalized_lr else 1.0
+        e = fn(embed)
+        sc = F.linear(e, p[prefix + "_embed_proj_scale.weight"] * ls * lr, p[prefix + "_embed_proj_scale.bias"] * lr)
+        bi = F.linear(e, p[prefix + "_embed_proj_bias.weight"] * ls * lr, p[prefix + "_embed_proj_bias.bias"] * lr)
+        out = out * sc[..., None, None] + bi[..., None, None]
+    out = fn(out)
     if up:
         out = F.interpolate(out, scale_factor=2.0, mode="nearest")
     if down:

@@ -772,6 +772,68 @@ class _GroupNormActFn(torch.autograd.Function):
         return dx, dgam, dbet, None, None, None
 
 
+class _FilmFn(torch.autograd.Function):
+    """x * scale[n, c] + bias[n, c] (FiLM conditioning of ConvLayer, reference cnn.py:160-181) on csrc/film_dropout2d.hip"""
+
+    @staticmethod
+    def forward(ctx, x, scale, bias):
+        n, c, h, w = x.shape
+        out = empty_nhwc(n, c, h, w, x)
+        scale, bias = scale.contiguous(), bias.contiguous()
+        check(_lib.load().otvae_film_fwd(ptr(x), ptr(scale), ptr(bias), n, h * w, c, ptr(out), stream()), "otvae_film_fwd")
+        ctx.save_for_backward(x, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, scale = ctx.saved_tensors
+        n, c, h, w = x.shape
+        g = as_nhwc(g)
+        gx = empty_nhwc(n, c, h, w, x)
+        gs, gb = torch.empty_like(scale), torch.empty_like(scale)
+        check(_lib.load().otvae_film_bwd(ptr(g), ptr(x), ptr(scale), n, h * w, c, ptr(gx), ptr(gs), ptr(gb), stream()), "otvae_film_bwd")
+        return gx, gs, gb
+
+
+class _Dropout2dFn(torch.autograd.Function):
+    """nn.Dropout2d(p) in training mode: whole (sample, channel) maps dropped; mask recomputed from the call key in backward"""
+
+    @staticmethod
+    def forward(ctx, x, p, key, stream_id):
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h, w, x)
+        used = torch.empty(1, device=x.device, dtype=torch.int64)
+        check(_lib.load().otvae_dropout2d_fwd(ptr(x), n, h * w, c, float(p), ptr(key), int(stream_id), ptr(y), ptr(used), stream()),
+              "otvae_dropout2d_fwd")
+        ctx.save_for_backward(used)
+        ctx.p = float(p)
+        ctx.mark_non_differentiable(used)
+        return y, used
+
+    @staticmethod
+    def backward(ctx, gy, _gused):
+        (used,) = ctx.saved_tensors
+        gy = as_nhwc(gy)
+        n, c, h, w = gy.shape
+        gx = empty_nhwc(n, c, h, w, gy)
+        check(_lib.load().otvae_dropout2d_bwd(ptr(gy), n, h * w, c, ctx.p, ptr(used), ptr(gx), stream()), "otvae_dropout2d_bwd")
+        return gx, None, None, None
+
+
+def dropout2d(x: Tensor, p: float, key: Tensor, stream_id: int = 0, return_used: bool = False):
+    """``nn.Dropout2d(p)`` (training mode) on a channels-last [N, C, H, W] tensor; ``key`` = ``new_dropout_key`` (the caller advances
+    its counter); the keep mask [N, C] of a call is ``dropout2d_mask(used, N, C, p)``."""
+    _lib.require_cuda(x, "dropout2d input")
+    y, used = _Dropout2dFn.apply(as_nhwc(x), float(p), key, stream_id)
+    return (y, used) if return_used else y
+
+
+def dropout2d_mask(used: Tensor, n: int, c: int, p: float) -> Tensor:
+    keep = torch.empty((n, c), device=used.device, dtype=torch.uint8)
+    check(_lib.load().otvae_dropout2d_mask(n, c, float(p), ptr(used), ptr(keep), stream()), "otvae_dropout2d_mask")
+    return keep.bool()
+
+
 class _ScaleFn(torch.autograd.Function):
     """alpha * t on t's own memory order (the ``weight * conv_scale * lr_mult`` / ``bias * lr_mult`` of equalized_lr)"""
 
@@ -809,10 +871,16 @@ def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
         stats = (mean, invstd, sc[0], sh[0], training)
     a = x
     gn = br.get("group_norm")   # (groups, weight | None, bias | None): GroupNorm / InstanceNorm2d instead of BatchNorm
+    film = br.get("film")       # (scale [N, C], bias [N, C]): FiLM conditioning sits between the normalisation and the activation
+    norm_kind = 0 if film is not None else kind
     if gn is not None:
-        a = _GroupNormActFn.apply(x, gn[1], gn[2], int(gn[0]), kind, (gn[1], gn[2]))
-    elif has_norm or kind != 0:
-        a = _BnActFn.apply(x, br.get("gamma"), br.get("beta"), stats, kind, (br.get("gamma"), br.get("beta")))
+        a = _GroupNormActFn.apply(x, gn[1], gn[2], int(gn[0]), norm_kind, (gn[1], gn[2]))
+    elif has_norm or norm_kind != 0:
+        a = _BnActFn.apply(x, br.get("gamma"), br.get("beta"), stats, norm_kind, (br.get("gamma"), br.get("beta")))
+    if film is not None:
+        a = _FilmFn.apply(a, film[0], film[1])
+        if kind != 0:
+            a = _BnActFn.apply(a, None, None, None, kind, (None, None))
     w = br["weight"]
     w = w if is_hwio(w) else hwio_weight(w)
     bias = br.get("bias")
@@ -821,9 +889,13 @@ def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
         w = _ScaleFn.apply(w, ws)
     if bias is not None and bs != 1.0:
         bias = _ScaleFn.apply(bias, bs)
+    drop = br.get("dropout2d")  # (p, key): nn.Dropout2d behind the convolution, training mode only
     plain = dict(weight=w, bias=bias, residual=br.get("residual"), stride=br["stride"], pad=br["pad"], up=br["up"], relu=False,
-                 out_stats=br.get("out_stats", False))
-    return conv_layers(a, [plain], training=training)[0]
+                 out_stats=br.get("out_stats", False) and drop is None)
+    y = conv_layers(a, [plain], training=training)[0]
+    if drop is not None and training:
+        y = dropout2d(y, drop[0], drop[1], stream_id=int(drop[2]))
+    return y
 
 
 def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
@@ -836,7 +908,7 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
     if x.dtype != torch.float32:
         raise TypeError("the MI355X conv path computes in fp32")
     if any(br.get("act", 0) > 1 or br.get("wscale", 1.0) != 1.0 or br.get("bscale", 1.0) != 1.0 or br.get("group_norm") is not None
-           for br in branches):
+           or br.get("film") is not None or br.get("dropout2d") is not None for br in branches):
         return tuple(_conv_layer_general(x, br, training) for br in branches)
     specs, tensors, params_ref, bns = [], [], [], []
     for br in branches:

@@ -9,8 +9,8 @@ stay channels-last between layers, and attention never materialises the TxT matr
 
 Activations other than ReLU (LeakyReLU(0.2), SELU, GELU, SiLU) and ``equalized_lr`` -- what the reference's
 configs/vae/defaults_imagenet.yaml trains with -- run unfused around the same kernels (functional._conv_layer_general,
-csrc/activation.hip), and so do GroupNorm / InstanceNorm2d (csrc/groupnorm.hip).  Options no configuration of the reference uses
-on this path (FiLM embeddings, dropout, grouped/dilated convolutions) are rejected with ``NotImplementedError`` rather than
+csrc/activation.hip), and so do GroupNorm / InstanceNorm2d (csrc/groupnorm.hip), FiLM conditioning (`additional_embed`) and
+Dropout2d (csrc/film_dropout2d.hip).  Grouped / dilated convolutions are rejected with ``NotImplementedError`` rather than
 silently run elsewhere.
 """
 import math
@@ -46,10 +46,6 @@ class ConvLayer(nn.Module):
         super().__init__()
         if isinstance(down_sample, nn.Module) or isinstance(up_sample, nn.Module):
             raise NotImplementedError("module-valued down_sample/up_sample are not supported on the MI355X path")
-        if bool(additional_embed):
-            raise NotImplementedError("additional_embed (FiLM conditioning) is not supported on the MI355X path")
-        if dropout and dropout > 0:
-            raise NotImplementedError("dropout > 0 is not supported on the MI355X path")
         kernel_size = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
         stride = stride if isinstance(stride, int) else stride[0]
         padding = padding if isinstance(padding, int) else padding[0]
@@ -87,7 +83,10 @@ class ConvLayer(nn.Module):
             self.register_parameter("bias", None)
         self._down_sample = nn.Identity()
         self._up_sample = nn.Upsample(scale_factor=up) if up > 1 else nn.Identity()
-        self._dropout = nn.Identity()
+        self._dropout = nn.Dropout2d(dropout) if dropout and dropout > 0 else nn.Identity()   # cnn.py:112 (container: p)
+        # FiLM conditioning (cnn.py:114-116): two Linear projections of the (activated) embedding, created in the reference's order
+        self._embed_proj_scale = nn.Linear(additional_embed, in_features) if bool(additional_embed) else None
+        self._embed_proj_bias = nn.Linear(additional_embed, in_features) if bool(additional_embed) else None
 
         if _is_none(normalization):
             self._normalization = nn.Identity()
@@ -125,8 +124,12 @@ class ConvLayer(nn.Module):
         # weight by gain / sqrt(fan_in) * lr_mult and the bias by lr_mult
         self._lr_mult, self._gain = equalized_lr or 1, 1
         self._conv_scale = self._gain / math.sqrt(in_features * kernel_size * kernel_size) if equalized_lr else 1
+        self._linear_scale = self._gain / math.sqrt(in_features) if equalized_lr else 1
         if equalized_lr:
             nn.init.normal_(w0, std=1 / self._lr_mult)
+            if self._embed_proj_scale is not None:   # cnn.py:152-157
+                nn.init.normal_(self._embed_proj_scale.weight, std=1 / self._lr_mult)
+                nn.init.normal_(self._embed_proj_bias.weight, std=1 / self._lr_mult)
         with torch.no_grad():
             self.weight.copy_(w0)
 
@@ -135,14 +138,48 @@ class ConvLayer(nn.Module):
     def _has_norm(self) -> bool:
         return isinstance(self._normalization, nn.BatchNorm2d)
 
-    def branch(self, residual: Optional[Tensor] = None, out_stats: bool = True) -> dict:
+    def _film(self, embed: Optional[Tensor]):
+        """(scale, bias) [N, C] of the FiLM conditioning from ``embed`` [N, E] (cnn.py:160-181), or None"""
+        if self._embed_proj_scale is None:
+            if embed is not None and self.enable_warnings:
+                warnings.warn("given conditional argument `embed` but the layer has no embedding projection")
+            return None
+        if embed is None:
+            raise ValueError("`additional_embed` specified in the ConvLayer constructor but `embed` is None")
+        from ..ot.matrix_utils import mm
+        e = embed.float()
+        if self._act_kind:  # the layer's own activation on the embedding (cnn.py:170,175)
+            e = HF._BnActFn.apply(HF.as_nhwc(e[:, :, None, None]), None, None, None, self._act_kind, (None, None))[:, :, 0, 0]
+        c = float(self._linear_scale * self._lr_mult)
+        lr = float(self._lr_mult)
+        out = []
+        for proj in (self._embed_proj_scale, self._embed_proj_bias):
+            w, b = proj.weight, proj.bias
+            if c != 1.0:
+                w = HF._ScaleFn.apply(w, c)
+            if lr != 1.0:
+                b = HF._ScaleFn.apply(b, lr)
+            out.append(mm(e.contiguous(), w.t().contiguous()) + b)
+        return tuple(out)
+
+    def _dropout2d(self):
+        """(p, device key {seed, counter}, stream id) of the layer's Dropout2d for this training-mode forward, or None"""
+        if not (self.training and isinstance(self._dropout, nn.Dropout2d)):
+            return None
+        key = self.__dict__.get("_dropout_key")
+        if key is None or key.device != self.weight.device:
+            key = self.__dict__["_dropout_key"] = HF.new_dropout_key(self.weight.device)
+        key[1:].add_(1)   # device-side: a captured step draws a fresh mask on every replay
+        return float(self._dropout.p), key, 0
+
+    def branch(self, residual: Optional[Tensor] = None, out_stats: bool = True, embed: Optional[Tensor] = None) -> dict:
         bn = self._normalization if self._has_norm else None
         gn = None
         if isinstance(self._normalization, nn.GroupNorm):
             gn = (self._normalization.num_groups, self._normalization.weight, self._normalization.bias)
         elif isinstance(self._normalization, nn.InstanceNorm2d):
             gn = (self.in_channels, None, None)
-        return dict(group_norm=gn, weight=self.weight, bias=self.bias,
+        return dict(group_norm=gn, film=self._film(embed), dropout2d=self._dropout2d(), weight=self.weight, bias=self.bias,
                     gamma=bn.weight if bn is not None else None, beta=bn.bias if bn is not None else None,
                     running_mean=bn.running_mean if bn is not None else None,
                     running_var=bn.running_var if bn is not None else None,
@@ -155,9 +192,7 @@ class ConvLayer(nn.Module):
                 out_stats: bool = True) -> Tensor:
         """``out_stats``: let the kernel's epilogue also emit the per-channel sums of its output, which the next layer's
         BatchNorm picks up instead of re-reading the tensor (wasted only if the consumer has no BatchNorm)."""
-        if embed is not None and self.enable_warnings:
-            warnings.warn("given conditional argument `embed` but the layer has no embedding projection")
-        return HF.conv_layers(x, [self.branch(residual, out_stats)], training=self.training)[0]
+        return HF.conv_layers(x, [self.branch(residual, out_stats, embed)], training=self.training)[0]
 
     def extra_repr(self) -> str:
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
@@ -192,7 +227,7 @@ class AttentionBlock(nn.Module):
         self.proj_out = Conv1x1(channels, channels, equalized_lr=equalized_lr, groups=groups)
 
     def forward(self, x: Tensor, embed: Optional[Tensor] = None, *, residual: Optional[Tensor] = None) -> Tensor:
-        qkv = self.qkv(x, out_stats=False)                  # [N, 3*C, H, W] channels-last; feeds attention, no BN
+        qkv = self.qkv(x, embed, out_stats=False)           # [N, 3*C, H, W] channels-last; feeds attention, no BN
         h = HF.qkv_attention(qkv, self.attention.n_heads)   # [N, C, H, W]
         return self.proj_out(h, residual=residual)
 
@@ -229,13 +264,13 @@ class ConvBlock(nn.Module):
         if self.skip is not None:
             # block[0] and skip normalise the same tensor: one statistics pass, one fused backward
             # (the skip output is only ever added to the block output: nobody normalises it -> no statistics)
-            out, sk = HF.conv_layers(x, [first.branch(), self.skip.branch(out_stats=False)], training=self.training)
+            out, sk = HF.conv_layers(x, [first.branch(embed=embed), self.skip.branch(out_stats=False)], training=self.training)
         else:
-            out = first(x)
+            out = first(x, embed)
         fuse_add = self.residual == "add" and len(layers) > 1
         for i, layer in enumerate(layers[1:], start=1):
             last = i == len(layers) - 1
-            out = layer(out, residual=sk if (fuse_add and last) else None)
+            out = layer(out, embed, residual=sk if (fuse_add and last) else None)
         if self.residual == "add" and not fuse_add:
             out = out + sk
         elif self.residual == "cat":

@@ -444,7 +444,7 @@ def test_autoencoder_plugin(A):
 
 def test_error_behaviour(A):
     with pytest.raises(NotImplementedError):
-        A.ConvLayer(4, 4, additional_embed=8)          # FiLM conditioning: not on this path
+        A.ConvLayer(4, 4, groups=2)                    # grouped / dilated convolutions: not on this path
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, activation="tanh")           # not among the reference's activations either (cnn.py:147)
     with pytest.raises(NotImplementedError):

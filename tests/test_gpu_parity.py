@@ -149,6 +149,9 @@ CONV_CTOR = {
     "gn_1x1_up": ("Conv1x1", dict(up_sample=2, normalization="groupnorm")),
     "in_silu": ("ConvLayer", dict(normalization="instancenorm", activation="silu")),
     "in_relu_up": ("ConvLayer", dict(up_sample=2, normalization="instancenorm", activation="relu")),
+    "film_relu": ("ConvLayer", dict(normalization="batchnorm", activation="relu", additional_embed=5)),
+    "film_leaky_eq": ("ConvLayer", dict(down_sample=2, normalization="batchnorm", activation="leaky", equalized_lr=2., additional_embed=6)),
+    "film_1x1_gn": ("Conv1x1", dict(normalization="groupnorm", additional_embed=5)),
 }
 
 
@@ -163,10 +166,13 @@ def test_conv_layer_vs_reference_golden(A):
         layer.load_state_dict({k[6:]: v for k, v in g.items() if k.startswith("param/")}, strict=False)
         layer = layer.cuda().train()
         x = g["x"].cuda().requires_grad_(True)
-        y = layer(x)
+        emb = g["embed"].cuda().requires_grad_(True) if "embed" in g else None
+        y = layer(x, emb) if emb is not None else layer(x)
         y.backward(g["gy"].cuda())
         rep.check(f"{name}/y", y, g["y"])
         rep.check(f"{name}/gx", x.grad, g["gx"])
+        if emb is not None:
+            rep.check(f"{name}/gembed", emb.grad, g["gembed"])
         for k, p in layer.named_parameters():
             rep.check(f"{name}/grad/{k}", p.grad, g[f"grad/{k}"])
         for k, b in layer.named_buffers():
@@ -220,6 +226,43 @@ def test_cnn_small_vs_reference_golden(A, residual):
             if not k.endswith("num_batches_tracked"):
                 rep.check(f"{nm}/buf/{k}", b, g[f"buf/{k}"])
     rep.finish()
+
+
+def test_conv_layer_dropout2d_matches_torch_given_its_own_mask(A):
+    """``ConvLayer(dropout=p)`` = nn.Dropout2d behind the convolution (reference cnn.py:112,191): whole (sample, channel) maps are
+    dropped.  The mask is a hash the backward recomputes; parity: the layer's output and gradients against the dropout-free layer
+    multiplied by the kernel's own mask / (1 - p); the drop rate; a fresh mask per call; evaluation mode drops nothing."""
+    from ot_vae_lightning_amd import functional as HF
+    torch.manual_seed(3)
+    p = 0.3
+    layer = A.ConvLayer(8, 16, normalization="batchnorm", activation="relu", dropout=p).cuda().train()
+    plain = A.ConvLayer(8, 16, normalization="batchnorm", activation="relu").cuda().train()
+    plain.load_state_dict(layer.state_dict())
+    x = normal((64, 8, 8, 8), 5).cuda()
+    gy = normal((64, 16, 8, 8), 6).cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = layer(xa)
+    y_ref = plain(xb)
+    # recover the mask from the output itself (kept maps equal y_ref / (1 - p) exactly in fp32 up to one rounding; dropped ones are 0)
+    kept = (ya.detach().abs().sum((2, 3)) > 0)
+    rate = 1.0 - float(kept.float().mean())
+    assert abs(rate - p) < 0.06, rate
+    want = y_ref * kept[:, :, None, None] / (1 - p)
+    assert rel_err(ya.detach().cpu(), want.detach().cpu()) < 1e-6
+    ya.backward(gy)
+    want.backward(gy)
+    assert rel_err(xa.grad.cpu(), xb.grad.cpu()) < 1e-5
+    for (ka, pa), (kb, pb) in zip(layer.named_parameters(), plain.named_parameters()):
+        assert rel_err(pa.grad.cpu(), pb.grad.cpu()) < 1e-5, ka
+    # the exported mask agrees with what the output shows; a second call draws another one
+    y2, used = HF.dropout2d(y_ref.detach(), p, HF.new_dropout_key(x.device, seed=11), return_used=True)
+    m2 = HF.dropout2d_mask(used, 64, 16, p)
+    assert torch.equal(m2, y2.abs().sum((2, 3)) > 0)
+    kept2 = (layer(x).detach().abs().sum((2, 3)) > 0)
+    assert not torch.equal(kept, kept2)
+    layer.eval()
+    plain.eval()
+    assert torch.equal(layer(x), plain(x))
 
 
 def test_cnn_leaky_equalized_lr_vs_reference_golden(A):

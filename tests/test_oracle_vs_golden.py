@@ -33,6 +33,9 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
     "gn_relu": (False, False, False, False, 3, "relu", None, "group"), "gn_down_leaky": (True, False, False, False, 3, "leaky", None, "group"),
     "gn_1x1_up": (False, True, False, False, 1, None, None, "group"), "in_silu": (False, False, False, False, 3, "silu", None, "instance"),
     "in_relu_up": (False, True, False, False, 3, "relu", None, "instance"),
+    # FiLM conditioning: forward(x, embed)
+    "film_relu": (False, False, False, True, 3, "relu", None, None), "film_leaky_eq": (True, False, False, True, 3, "leaky", 2.0, None),
+    "film_1x1_gn": (False, False, False, False, 1, None, None, "group"),
 }
 
 
@@ -47,8 +50,11 @@ def test_conv_layer(name):
         p["_normalization.running_mean"] = torch.zeros(c)
         p["_normalization.running_var"] = torch.ones(c)
     x = g["x"].clone().requires_grad_(True)
-    y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks, act=act, equalized_lr=eq, other_norm=gn)
+    emb = g["embed"].clone().requires_grad_(True) if "embed" in g else None
+    y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks, act=act, equalized_lr=eq, other_norm=gn, embed=emb)
     y.backward(g["gy"])
+    if emb is not None:
+        assert rel_err(emb.grad, g["gembed"]) < TIGHT
     assert rel_err(y, g["y"]) < TIGHT
     assert rel_err(x.grad, g["gx"]) < TIGHT
     for k, v in g.items():
