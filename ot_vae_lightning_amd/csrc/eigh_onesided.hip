@@ -32,6 +32,7 @@
 // after HJ_MAX_SWEEPS sweeps gets NaN eigenvalues (loud, like a starved Sinkhorn solve) instead of an unconverged answer.
 #include <type_traits>
 #include "common.h"
+#include <mutex>
 
 void gemm_f64_launch(int transA, int transB, int nb, int m, int n, int k, double alpha, const double* A, size_t sA, const double* B,
                      size_t sB, double beta, double* C, hipStream_t st);  // gaussian_ot.hip
@@ -581,10 +582,13 @@ int eigh_onesided(const double* A, int nb, int D, int fn, double* out, double* e
 //     15 - p): a column of G never changes its slot, the round-robin over blocks therefore meets every pair of columns;
 //   * loads the same 16 columns of V and replays the logged rotations on them.
 // Positive definite input (the covariances this path exists for) is first factored, A = L L^T (otvae_cholesky), and the
-// iteration runs on the columns of X = L^T (= the rows of L, contiguous): X V = U S gives A = X^T X = V S^2 V^T, the same
-// eigenvectors, eigenvalues |x_k|^2 -- but the iteration now sees cond(A)^1/2 instead of the cond(A)^2 that working on the
-// columns of A itself implies (the Gram matrix of A's columns is A^2), which is what its convergence speed depends on: an
-// ill-conditioned 1024 x 1024 latent covariance needed > 16 sweeps on A and needs ~10 on its factor.  When the factorisation
+// iteration runs on the columns of X = L: X V = Q S gives A = X X^T = Q S^2 Q^T -- eigenvalues |x_k|^2, eigenvectors the
+// NORMALISED FINAL COLUMNS themselves, so V is neither kept nor updated (ctl->qmode; the update role of a launch returns at
+// once).  The iteration sees cond(A)^1/2 instead of the cond(A)^2 that working on the columns of A itself implies (the Gram
+// matrix of A's columns is A^2), which is what its convergence speed depends on: an ill-conditioned 1024 x 1024 latent
+// covariance needed > 16 sweeps on A and needs ~10 on its factor.  Round 2 iterated on the columns of L^T (the rows of L:
+// no transposed copy, but V had to be carried and the sweep count is ~20 % higher: 11 against 9 at D = 128 in a numpy
+// restatement of the ordering); OTVAE_EIGH_BLOCK_LT=1 brings that variant back for an A/B.  When the factorisation
 // meets a non-positive pivot (device flag) the columns of A are iterated as in the small solver.
 // One launch per round (nblk - 1 rounds per sweep); the stop test is a device flag: a round that rotated above the stop level
 // marks the sweep, a tiny kernel after each sweep turns the remaining launches into no-ops once a sweep stayed quiet.
@@ -596,6 +600,7 @@ struct HjbCtl {
     int done, rotated, sweeps;
     int chol_info;  // 0: the iteration runs on the Cholesky factor; else on A itself (written by otvae_cholesky before the init kernel)
     int log_stamp[2];  // id of the launch whose column rotations fill rotation log 0 / 1 (-1: none)
+    int qmode;         // the iteration runs on the columns of L (not of L^T): the eigenvectors are the final columns, V is not kept
 };
 #define HJB_VSLABS 2  // row slabs the eigenvector update of a block pair is split over (when the launch still fits the chip)
 
@@ -629,14 +634,15 @@ __host__ __device__ static inline HjbWs hjb_ws(void* ws, int b, int D) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void hjb_init_kernel(const double* __restrict__ Ain, int D, void* __restrict__ ws) {
+__global__ __launch_bounds__(256) void hjb_init_kernel(const double* __restrict__ Ain, int D, void* __restrict__ ws, int lcols) {
     const HjbWs w = hjb_ws(ws, blockIdx.y, D);
     const double* Ab = Ain + (size_t)blockIdx.y * D * D;
     const size_t total = (size_t)hjb_dp(D) * D;
     for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int c = (int)(e / D), i = (int)(e - (size_t)c * D);
         double v = 0.0;  // zero dummy columns
-        if (c < D) v = w.ctl->chol_info == 0 ? w.T[e]   // column c of X = L^T is row c of L (its strict upper part is zero)
+        if (c < D) v = w.ctl->chol_info == 0 ? (lcols ? w.T[(size_t)i * D + c]   // column c of X = L (zero above the diagonal)
+                                                      : w.T[e])                   // column c of X = L^T is row c of L
                                              : ((i >= c) ? Ab[(size_t)i * D + c] : Ab[(size_t)c * D + i]);  // lower triangle of A
         w.G[e] = v;
         w.V[e] = (c == i) ? 1.0 : 0.0;
@@ -646,6 +652,7 @@ __global__ __launch_bounds__(256) void hjb_init_kernel(const double* __restrict_
         w.ctl->rotated = 0;
         w.ctl->sweeps = 0;
         w.ctl->log_stamp[0] = w.ctl->log_stamp[1] = -1;
+        w.ctl->qmode = (lcols && w.ctl->chol_info == 0) ? 1 : 0;
     }
 }
 
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(512) void hjb_round_kernel(int D, int launch, int n
         my_launch = launch;
     } else {
         my_launch = launch - 1;
-        if (my_launch < 0 || w.ctl->log_stamp[my_launch & 1] != my_launch) return;
+        if (my_launch < 0 || w.ctl->qmode || w.ctl->log_stamp[my_launch & 1] != my_launch) return;
         const int v = blockIdx.x - npairs;
         pair_idx = v / vslabs;
         const int per = ((D + vslabs - 1) / vslabs + 63) / 64 * 64;  // rows per slab, whole lanes
@@ -937,7 +944,7 @@ __global__ __launch_bounds__(512) void hjg_round_kernel(int D, int launch, int n
         my_launch = launch;
     } else {
         my_launch = launch - 1;
-        if (my_launch < 0 || w.ctl->log_stamp[my_launch & 1] != my_launch) return;
+        if (my_launch < 0 || w.ctl->qmode || w.ctl->log_stamp[my_launch & 1] != my_launch) return;
         pair_idx = (blockIdx.x - npairs) / vslabs;
     }
     int I, J;
@@ -1074,12 +1081,24 @@ __global__ __launch_bounds__(512) void hjg_round_kernel(int D, int launch, int n
     }
 }
 
-__global__ void hjb_check_kernel(int D, void* __restrict__ ws) {
-    const HjbWs w = hjb_ws(ws, blockIdx.x, D);
-    if (threadIdx.x != 0 || w.ctl->done) return;
-    w.ctl->sweeps += 1;
-    if (!w.ctl->rotated) w.ctl->done = 1;
-    w.ctl->rotated = 0;
+// after every sweep: one thread closes the sweep of every matrix of the batch; `host_done` (mapped host memory, or NULL) learns
+// whether the whole batch has converged -- the host stops enqueueing rounds two sweeps later (see eigh_block_onesided)
+__global__ void hjb_check_kernel(int D, int nb, void* __restrict__ ws, volatile int* host_done) {
+    if (threadIdx.x != 0) return;
+    int all = 1;
+    for (int b = 0; b < nb; ++b) {
+        const HjbWs w = hjb_ws(ws, b, D);
+        if (!w.ctl->done) {
+            w.ctl->sweeps += 1;
+            if (!w.ctl->rotated) w.ctl->done = 1;
+            w.ctl->rotated = 0;
+        }
+        all &= w.ctl->done;
+    }
+    if (host_done) {
+        *host_done = all;
+        __threadfence_system();
+    }
 }
 
 // |lambda_k| = |g_k| and the sign's dot product v_k . g_k: a wave per column
@@ -1116,7 +1135,7 @@ __global__ __launch_bounds__(256) void hjb_finish_kernel(int D, int fn, void* __
     if (threadIdx.x == 0) s_noise = 64.0 * D * 2.220446049250313e-16 * fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
     __syncthreads();
     const double noise = s_noise;
-    const bool chol = w.ctl->chol_info == 0;
+    const bool chol = w.ctl->chol_info == 0, qmode = w.ctl->qmode != 0;
     // the columns of an indefinite A were iterated unshifted: a +-lambda pair of equal size is a double eigenvalue of A^2 and the
     // iteration may have stopped at a mixture of its two eigenvectors (|v . g| < |g|, see the header of this file).  The small
     // solver repeats such a matrix on A + |A|_inf I; here (a hundred launches per sweep) the matrix gets NaN eigenvalues instead
@@ -1135,7 +1154,13 @@ __global__ __launch_bounds__(256) void hjb_finish_kernel(int D, int fn, void* __
     const size_t total = (size_t)D * D;
     for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int k = (int)(e / D);
-        const double v = w.V[e];
+        double v;
+        if (qmode) {  // the eigenvectors are the normalised final columns; V (one eigenvector per row) is filled for the product below
+            v = w.nrm[k] > 0.0 ? w.G[e] / w.nrm[k] : 0.0;
+            if (fn != 3) w.V[e] = v;
+        } else {
+            v = w.V[e];
+        }
         if (fn == 3) {
             dst[e] = v;
         } else {
@@ -1176,7 +1201,8 @@ int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, dou
         const int rc = cholesky_blocked(A, nb, D, w0.T, per / sizeof(double), &w0.ctl->chol_info, per / sizeof(int), st);
         if (rc) return rc;
     }
-    hjb_init_kernel<<<dim3(imin(cdiv((size_t)Dp * D, 256), 1024), nb), 256, 0, st>>>(A, D, ws);
+    static const int lcols = getenv("OTVAE_EIGH_BLOCK_LT") ? 0 : 1;  // A/B switch: the round-2 iteration on the columns of L^T
+    hjb_init_kernel<<<dim3(imin(cdiv((size_t)Dp * D, 256), 1024), nb), 256, 0, st>>>(A, D, ws, lcols);
     const int nrounds = nblk - 1;
     // one workgroup per CU at these LDS sizes: split the eigenvector update over row slabs only while every block of a launch is
     // still resident at once (two matrices of D = 1024 side by side are 128 rotation + 128 update blocks already)
@@ -1192,11 +1218,51 @@ int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, dou
         else
             hjb_round_kernel<8><<<grid, 512, lds, st>>>(D, launch, nrounds, rotate, vslabs, ws);
     };
-    for (int sweep = 0; sweep < HJB_MAX_SWEEPS; ++sweep) {
-        for (int round = 0; round < nrounds; ++round) round_launch(sweep * nrounds + round, 1);
-        hjb_check_kernel<<<nb, 64, 0, st>>>(D, ws);
+    // The launches of a converged solver are no-ops, but a no-op still costs its ~2 us of queue time and a sweep is 31 ... 127 of
+    // them: the 24-sweep budget, issued blindly, spent 1 ms (D = 256) ... 4 ms (D = 1024) behind the ~10 sweeps that did the
+    // work.  Outside a stream capture the host therefore FOLLOWS the device two sweeps behind: the check kernel of sweep s writes
+    // "all converged" to mapped host memory and an event marks it; before enqueueing sweep s + 2 the host waits for that event (the
+    // device is busy with sweep s + 1 meanwhile: no bubble) and stops when the flag is up -- at most one sweep of no-ops is left.
+    // Under capture (nothing may synchronise) the whole budget is recorded as before.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    static const bool no_follow = getenv("OTVAE_EIGH_NO_FOLLOW") != nullptr;  // A/B switch
+    static std::mutex follow_mutex;
+    static int* follow_flags = nullptr;  // [HJB_MAX_SWEEPS], mapped host memory
+    static hipEvent_t follow_ev[2];
+    std::unique_lock<std::mutex> follow_lock(follow_mutex, std::defer_lock);
+    bool follow = cap == hipStreamCaptureStatusNone && !no_follow;
+    if (follow) {
+        follow_lock.lock();
+        if (!follow_flags) {
+            int* f = nullptr;
+            if (hipHostMalloc((void**)&f, HJB_MAX_SWEEPS * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+                hipEventCreateWithFlags(&follow_ev[0], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&follow_ev[1], hipEventDisableTiming) == hipSuccess)
+                follow_flags = f;
+            else
+                follow = false;  // (no pinned memory: the blind budget still gives the right answer)
+        }
     }
-    round_launch(HJB_MAX_SWEEPS * nrounds, 0);  // the eigenvector update of the very last round, if the sweep limit was reached
+    int issued = 0;
+    for (int sweep = 0; sweep < HJB_MAX_SWEEPS; ++sweep) {
+        if (follow && sweep >= 2) {
+            if (hipEventSynchronize(follow_ev[sweep & 1]) != hipSuccess) {
+                otvae_set_error("otvae_eigh_fn: the device failed while the host followed the sweeps");
+                return OTVAE_ELAUNCH;
+            }
+            if (((volatile int*)follow_flags)[sweep - 2]) break;
+        }
+        for (int round = 0; round < nrounds; ++round) round_launch(sweep * nrounds + round, 1);
+        if (follow) follow_flags[sweep] = 0;
+        hjb_check_kernel<<<1, 64, 0, st>>>(D, nb, ws, follow ? follow_flags + sweep : nullptr);
+        if (follow && hipEventRecord(follow_ev[sweep & 1], st) != hipSuccess) {
+            otvae_set_error("otvae_eigh_fn: hipEventRecord failed");
+            return OTVAE_ELAUNCH;
+        }
+        issued = sweep + 1;
+    }
+    round_launch(issued * nrounds, 0);  // the eigenvector update of the very last round, if the last sweep issued still rotated
     OTVAE_CHECK_LAUNCH("otvae_eigh_fn(block rounds)");
     hjb_norms_kernel<<<dim3(cdiv(D, 4), nb), 256, 0, st>>>(D, ws);
     hjb_finish_kernel<<<dim3(imin(cdiv((size_t)D * D, 2048), 256), nb), 256, 0, st>>>(D, fn, ws, eigvals, out);
