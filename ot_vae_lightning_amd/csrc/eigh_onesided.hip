@@ -964,9 +964,39 @@ __global__ __launch_bounds__(512) void hjg_round_kernel(int D, int launch, int n
     // ---- rotation role
     const int Dr = (D + 15) & ~15, LD = Dr + 1;
     double* P = hj_lds;  // P[pos * LD + row], rows D .. Dr zero (whole 16-row tiles for the products)
-    for (int pos = wave; pos < NP; pos += 8) {
-        const double* src = w.G + (size_t)home(pos) * D;
-        for (int i = lane; i < Dr; i += 64) P[pos * LD + i] = i < D ? src[i] : 0.0;
+    {   // a wave streams in its two columns with every load of a batch in flight before the first LDS store: 8 x 16 bytes per lane
+        // and column cover 1024 rows, so that D = 1024 costs one memory round trip instead of one per 64 rows (D even: the rows of a
+        // column start 16-byte aligned; odd D takes the 8-byte path)
+        const double* src0 = w.G + (size_t)home(wave) * D;
+        const double* src1 = w.G + (size_t)home(wave + 8) * D;
+        double* d0 = P + wave * LD;
+        double* d1 = P + (wave + 8) * LD;
+        if ((D & 1) == 0) {
+            for (int base = 0; base < Dr; base += 1024) {
+                double2 v0[8], v1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + 2 * lane + 128 * u;  // rows i, i + 1 (D even: both inside or both outside)
+                    v0[u] = i < D ? *(const double2*)(src0 + i) : make_double2(0.0, 0.0);
+                    v1[u] = i < D ? *(const double2*)(src1 + i) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + 2 * lane + 128 * u;
+                    if (i < Dr) {
+                        d0[i] = v0[u].x;
+                        d0[i + 1] = v0[u].y;
+                        d1[i] = v1[u].x;
+                        d1[i + 1] = v1[u].y;
+                    }
+                }
+            }
+        } else {
+            for (int i = lane; i < Dr; i += 64) {
+                d0[i] = i < D ? src0[i] : 0.0;
+                d1[i] = i < D ? src1[i] : 0.0;
+            }
+        }
     }
     if (tid == 0) s_rot = 0;
     __syncthreads();
@@ -1044,29 +1074,30 @@ __global__ __launch_bounds__(512) void hjg_round_kernel(int D, int launch, int n
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // columns: (W J) and (Q J): item (pair kk, row r), two items per lane
+            // The 8 pairs of a step cover all 16 indices, so W falls into 8 x 8 blocks of 2 x 2 entries, block (a, b) = rows of pair a x
+            // columns of pair b, and J^T W J maps every block onto itself: W_ab <- J_a^T W_ab J_b.  One lane per block, one pass (the
+            // column update followed by the row update of the first version was two LDS round trips and a barrier more per step).
+            {
+                const int a = lane >> 3, b = lane & 7;
+                const int pa = s_pq[a][0], qa = s_pq[a][1], pb = s_pq[b][0], qb = s_pq[b][1];
+                const double ca = s_cs[a].x, sa = s_cs[a].y, cb = s_cs[b].x, sb = s_cs[b].y;
+                const double w00 = W[pa][pb], w01 = W[pa][qb], w10 = W[qa][pb], w11 = W[qa][qb];
+                // columns: (p, q) <- (c p - s q, s p + c q) with pair b's rotation
+                const double t00 = cb * w00 - sb * w01, t01 = sb * w00 + cb * w01;
+                const double t10 = cb * w10 - sb * w11, t11 = sb * w10 + cb * w11;
+                // rows, with pair a's rotation
+                W[pa][pb] = ca * t00 - sa * t10;
+                W[pa][qb] = ca * t01 - sa * t11;
+                W[qa][pb] = sa * t00 + ca * t10;
+                W[qa][qb] = sa * t01 + ca * t11;
+                // Q <- Q J: rows 2a, 2a + 1 against pair b
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int item = lane + 64 * it, kk = item >> 4, r = item & 15;
-                const int p = s_pq[kk][0], q = s_pq[kk][1];
-                const double c = s_cs[kk].x, s_ = s_cs[kk].y;
-                const double wp = W[r][p], wq = W[r][q], qp = Q[r][p], qq = Q[r][q];
-                W[r][p] = c * wp - s_ * wq;
-                W[r][q] = s_ * wp + c * wq;
-                Q[r][p] = c * qp - s_ * qq;
-                Q[r][q] = s_ * qp + c * qq;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // rows: J^T (W J): item (pair kk, column col)
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int item = lane + 64 * it, kk = item >> 4, col = item & 15;
-                const int p = s_pq[kk][0], q = s_pq[kk][1];
-                const double c = s_cs[kk].x, s_ = s_cs[kk].y;
-                const double wp = W[p][col], wq = W[q][col];
-                W[p][col] = c * wp - s_ * wq;
-                W[q][col] = s_ * wp + c * wq;
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int r = 2 * a + rr;
+                    const double qp = Q[r][pb], qq = Q[r][qb];
+                    Q[r][pb] = cb * qp - sb * qq;
+                    Q[r][qb] = sb * qp + cb * qq;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();

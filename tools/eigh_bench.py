@@ -22,7 +22,10 @@ def t_gpu(fn, reps=5):
 
 def main():
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    for D, nb in ((32, 1), (64, 1), (128, 1), (128, 8), (256, 1), (512, 1), (1024, 1)):
+    cases = ((32, 1), (64, 1), (128, 1), (128, 8), (256, 1), (512, 1), (1024, 1))
+    if len(sys.argv) > 1:  # python tools/eigh_bench.py 1024 [nb]
+        cases = ((int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 1),)
+    for D, nb in cases:
         g = torch.Generator().manual_seed(D)
         x = torch.randn(nb, 3 * D, D, generator=g, dtype=torch.float64)
         cov = x.transpose(-1, -2) @ x / x.shape[-2]
