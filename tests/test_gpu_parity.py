@@ -861,6 +861,40 @@ def test_small_eigh_solvers_vs_lapack(A, solver, monkeypatch):
     rep.finish()
 
 
+def test_eigh_graded_spectra_and_capture(A):
+    """Round 3: positive definite input is factored first and the Jacobi iteration runs on the Cholesky factor's columns (in LDS
+    for D <= 128, on the columns of L for the block solver), eigenvectors = the normalised final columns.  (1) graded spectra up
+    to condition 1e12, which the iteration on A itself could not finish inside its sweep budget at D >= 96 (NaN by contract):
+    residual and orthonormality at fp64 rounding, eigenvalues to the accuracy the matrix defines them (eps * cond).  (2) the block
+    solver's host-following sweep loop (not capturable) against the blind 24-sweep budget recorded under a hipGraph capture: the
+    launches skipped are no-ops, so the two agree bit for bit."""
+    from ot_vae_lightning_amd.ot import matrix_utils as MU
+    g = torch.Generator().manual_seed(5)
+    for D in (8, 31, 64, 96, 128, 200, 256):
+        for cond in (1e1, 1e6, 1e12):
+            q, _ = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))
+            lam = torch.logspace(0, -math.log10(cond), D, dtype=torch.float64)
+            cov = (q * lam) @ q.T
+            cov = 0.5 * (cov + cov.T)
+            ev, vt = MU.eigh_vectors(cov.cuda()[None])
+            ev, v = ev[0].cpu(), vt[0].cpu().T
+            assert bool(torch.isfinite(ev).all()), (D, cond)
+            assert float((cov @ v - v * ev).norm() / cov.norm()) < 1e-13, (D, cond, "residual")
+            assert float((v.T @ v - torch.eye(D, dtype=torch.float64)).abs().max()) < 1e-12, (D, cond, "orthonormality")
+            rel = ((ev.sort().values - lam.sort().values).abs() / lam.sort().values).max()
+            assert float(rel) < 64 * D * 2.3e-16 * cond, (D, cond, float(rel))
+    x = torch.randn(2, 700, 256, generator=g, dtype=torch.float64)
+    cov = (x.transpose(-1, -2) @ x / 700).cuda()
+    ev0, vt0 = MU.eigh_vectors(cov)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ev1, vt1 = MU.eigh_vectors(cov)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ev0, ev1) and torch.equal(vt0, vt1)
+
+
 def test_eigh_plus_minus_lambda_pairs(A):
     """indefinite matrices whose diagonal is NON-negative never triggered the up-front |A|_inf shift of the one-sided
     solver, and inside a +-lambda pair (a double eigenvalue of A^2) the iteration stops at any mixture of the two eigenvectors:
