@@ -500,6 +500,13 @@ int otvae_codebook_probs(const float* x, const float* codebook, int nb, int B, i
  * forward's output; gx[nb][B][d].  K <= 4096. */
 int otvae_codebook_probs_bwd(const float* x, const float* codebook, const float* probs, const float* gprobs,
                              const float* gentropy, int nb, int B, int K, int d, float temperature, float* gx, void* stream);
+
+/* The same with the gradient of the atoms too: CodebookModel(update_with_autograd=True) trains its codebook as a parameter
+ * (reference ot/distribution_models/codebook_model.py:89 `requires_grad=self.update_with_autograd`; energies :158-160 under
+ * torch.autograd).  coef_ws: [nb][B][K] floats of workspace; gc: [nb][K][d], summed over the samples in a fixed order. */
+int otvae_codebook_probs_bwd_atoms(const float* x, const float* codebook, const float* probs, const float* gprobs,
+                                   const float* gentropy, int nb, int B, int K, int d, float temperature, float* gx,
+                                   float* coef_ws, float* gc, void* stream);
 /* k-means sufficient statistics for one-hot ('argmax') assignments (MixtureMixin.kmean_iteration, base.py:241-252):
  * counts[nb][K] = number of samples per atom, sums[nb][K][d] = their sum, members added in increasing sample order. */
 int otvae_codebook_kmeans(const float* x, const int64_t* idx, int nb, int B, int K, int d, float* counts, float* sums,

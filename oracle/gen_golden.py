@@ -675,6 +675,111 @@ def gen_gmm():
     save("gmm.npz", out)
 
 
+def gen_gmm_autograd():
+    """GaussianMixtureModel: (1) `model(samples)` of a fitted model in eval mode (= GaussianModel.predict through the class's MRO:
+    the mixture log-density); (2) `update_with_autograd=True` (gassian_mixture_model.py:53-58, gaussian_model.py:52-93): the
+    log-density and its gradients with respect to the samples, the means, the raw ExpScaleTril parameter and the raw soft-max
+    weight parameter, diagonal and full covariances, with and without a leading dimension."""
+    gm = R.ref("ot.distribution_models.gassian_mixture_model")
+    out = {}
+    mix = dict(metric="euclidean", p=2., topk=None, temperature=1., training_mode="argmax", inference_mode="argmax")
+    # (1)
+    for tag, diag, lead, K, d, B in (("fit_diag", True, (2,), 4, 3, 64), ("fit_full", False, (), 3, 4, 80)):
+        g = torch.Generator().manual_seed(151)
+        w2_cfg = dict(diag=diag, stochastic=False, pg_star=0., make_pd=True, verbose=False, dtype=torch.double)
+        centres = torch.randn(*lead, K, d, generator=g, dtype=torch.double) * 3.0
+        model = gm.GaussianMixtureModel(*lead, d, mixture_cfg={**mix, "n_components": K}, w2_cfg=w2_cfg, update_decay=None, dtype=torch.double)
+        model.train()
+        xs = [_clusters(g, lead, K, d, B, centres.float(), noise=0.4).double() for _ in range(2)]
+        for i, x in enumerate(xs):
+            if i == 0:
+                torch.manual_seed(83)
+            model.update(x)
+        model.fit()
+        model.eval()
+        out[f"{tag}/cfg"] = np.array([K, d, B, int(diag)])
+        out[f"{tag}/mean"], out[f"{tag}/cov"], out[f"{tag}/weights"] = npy(model.mean), npy(model.cov), npy(model.weights)
+        # what is stored behind the parametrisations (reading `cov` adds the positive-definite shift, `_weights` normalises)
+        out[f"{tag}/raw_cov"] = npy(model.parametrizations.cov.original)
+        out[f"{tag}/raw_weights"] = npy(model.parametrizations._weights.original)
+        out[f"{tag}/probe"] = npy(xs[-1])
+        out[f"{tag}/log_prob"] = npy(model(xs[-1]))
+    # (2)
+    for tag, diag, lead, K, d, B in (("auto_diag", True, (), 3, 5, 40), ("auto_diag_lead", True, (2,), 4, 3, 24),
+                                     ("auto_full", False, (), 3, 4, 32), ("auto_full_lead", False, (2,), 2, 6, 20)):
+        g = torch.Generator().manual_seed(161 + d)
+        w2_cfg = dict(diag=diag, stochastic=False, pg_star=0., make_pd=True, verbose=False, dtype=torch.double)
+        model = gm.GaussianMixtureModel(*lead, d, mixture_cfg={**mix, "n_components": K}, w2_cfg=w2_cfg, update_with_autograd=True,
+                                        dtype=torch.double)
+        raw_cov = model.parametrizations.cov.original
+        raw_w = model.parametrizations._weights.original
+        with torch.no_grad():
+            model.mean.copy_(torch.randn(model.mean.shape, generator=g, dtype=torch.double) * 1.5)
+            raw_cov.copy_(torch.randn(raw_cov.shape, generator=g, dtype=torch.double) * 0.3)
+            raw_w.copy_(torch.randn(raw_w.shape, generator=g, dtype=torch.double))
+        x = (torch.randn(*lead, B, d, generator=g, dtype=torch.double) * 2.0).requires_grad_(True)
+        seed = torch.randn(*lead, B, generator=g, dtype=torch.double)
+        model.train()
+        lp = model(x)
+        (lp * seed).sum().backward()
+        out[f"{tag}/cfg"] = np.array([K, d, B, int(diag)])
+        out[f"{tag}/mean"], out[f"{tag}/raw_cov"], out[f"{tag}/raw_weights"] = npy(model.mean), npy(raw_cov), npy(raw_w)
+        out[f"{tag}/x"], out[f"{tag}/seed"], out[f"{tag}/log_prob"] = npy(x), npy(seed), npy(lp)
+        out[f"{tag}/g_x"], out[f"{tag}/g_mean"] = npy(x.grad), npy(model.mean.grad)
+        out[f"{tag}/g_raw_cov"], out[f"{tag}/g_raw_weights"] = npy(raw_cov.grad), npy(raw_w.grad)
+        out[f"{tag}/variances"], out[f"{tag}/weights"] = npy(model.variances), npy(model.weights)
+    save("gmm_autograd.npz", out)
+
+
+def gen_codebook_autograd():
+    """CodebookModel(update_with_autograd=True) (codebook_model.py:89-93): `model(x)` = (weights @ codebook, indices, distribution)
+    with the codebook a trained parameter; gradients of a scalar made of the predictions, the assignment probabilities and their
+    entropy with respect to the samples and the codebook, in the soft 'mean' mode and the one-hot 'argmax' mode; and the same
+    through CodebookPrior (loss='kl', soft mode: commitment term included) on a [B, 8, 2, 2] latent."""
+    cb = R.ref("ot.distribution_models.codebook_model")
+    out = {}
+    for tag, mode, lead, K, d, B, T in (("mean", "mean", (), 6, 4, 32, 0.7), ("mean_lead", "mean", (2,), 5, 3, 24, 1.0),
+                                        ("argmax", "argmax", (), 6, 4, 32, 1.0)):
+        g = torch.Generator().manual_seed(171 + K)
+        mix = dict(n_components=K, metric="euclidean", p=2., topk=None, temperature=T, training_mode=mode, inference_mode=mode)
+        model = cb.CodebookModel(*lead, d, mixture_cfg=mix, update_with_autograd=True)
+        with torch.no_grad():
+            model.codebook.copy_(torch.randn(model.codebook.shape, generator=g) * 1.5)
+        x = (torch.randn(*lead, B, d, generator=g) * 1.5).requires_grad_(True)
+        s_pred = torch.randn(*lead, B, d, generator=g)
+        s_prob = torch.randn(*lead, B, K, generator=g)
+        s_ent = torch.randn(*lead, B, generator=g)
+        model.train()
+        torch.manual_seed(5)
+        preds, _, dist = model(x)
+        scalar = (preds * s_pred).sum() + (dist.probs * s_prob).sum() + (dist.entropy() * s_ent).sum()
+        scalar.backward()
+        out[f"{tag}/cfg"] = np.array([K, d, B, T])
+        out[f"{tag}/codebook"], out[f"{tag}/x"] = npy(model.codebook), npy(x)
+        out[f"{tag}/s_pred"], out[f"{tag}/s_prob"], out[f"{tag}/s_ent"] = npy(s_pred), npy(s_prob), npy(s_ent)
+        out[f"{tag}/preds"], out[f"{tag}/probs"], out[f"{tag}/entropy"] = npy(preds), npy(dist.probs), npy(dist.entropy())
+        out[f"{tag}/g_x"], out[f"{tag}/g_codebook"] = npy(x.grad), npy(model.codebook.grad)
+    # through the prior
+    pr = R.ref("prior.codebook")
+    g = torch.Generator().manual_seed(181)
+    K = 7
+    mix = dict(n_components=K, metric="euclidean", p=2., topk=None, temperature=0.8, training_mode="mean", inference_mode="mean")
+    prior = pr.CodebookPrior((8, 2, 2), embed_dims=(1,), loss="kl", loss_coeff=1.0, mixture_cfg=mix, update_with_autograd=True)
+    with torch.no_grad():
+        prior.codebook_model.codebook.copy_(torch.randn(prior.codebook_model.codebook.shape, generator=g))
+    z = torch.randn(6, 8, 2, 2, generator=g).requires_grad_(True)
+    s_z = torch.randn(6, 8, 2, 2, generator=g)
+    prior.train()
+    torch.manual_seed(6)
+    enc, loss, _ = prior.encode(z)
+    ((enc * s_z).sum() + loss.sum()).backward()
+    out["prior/cfg"] = np.array([K, 0.8])
+    out["prior/codebook"], out["prior/z"], out["prior/s_z"] = npy(prior.codebook_model.codebook), npy(z), npy(s_z)
+    out["prior/enc"], out["prior/loss"] = npy(enc), npy(loss)
+    out["prior/g_z"], out["prior/g_codebook"] = npy(z.grad), npy(prior.codebook_model.codebook.grad)
+    save("codebook_autograd.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1189,6 +1294,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd"]
     for w in which:
         globals()["gen_" + w]()

@@ -428,6 +428,27 @@ def gmm_full_energy(x: Tensor, mean: Tensor, cov: Tensor, weights: Tensor) -> Te
     return comp.log_prob(x.unsqueeze(-2)) + torch.log_softmax(torch.log(weights), -1).unsqueeze(-2)
 
 
+def gmm_log_prob(x: Tensor, mean: Tensor, cov: Tensor, weights: Tensor, diag: bool) -> Tensor:
+    """``GaussianMixtureModel.forward`` / ``predict`` of a fitted model: the class inherits GaussianModel.predict first
+    (gaussian_model.py:129-132), i.e. ``batched_distribution.log_prob`` of the MixtureSameFamily (gassian_mixture_model.py:74-80):
+    logsumexp_k(log N(x; mu_k, C_k) + log w_k), [*, B]."""
+    energy = gmm_diag_energy(x, mean, cov, weights) if diag else gmm_full_energy(x, mean, cov, weights)
+    return torch.logsumexp(energy, dim=-1)
+
+
+def gmm_autograd_log_prob(x: Tensor, mean: Tensor, raw_cov: Tensor, raw_weights: Tensor, diag: bool) -> Tensor:
+    """The same log-density for ``update_with_autograd=True`` (gassian_mixture_model.py:53-58; gaussian_model.py:52-55,76-93,186-201):
+    the raw `cov` parameter passes through ExpScaleTril (diag: variances = exp(raw), scale = variances ** 0.5; full: Cholesky
+    factor = strict lower triangle + exp(diagonal)), the raw weights through a soft-max; differentiable with torch.autograd."""
+    w = torch.softmax(raw_weights, -1)
+    if diag:
+        comp = torch.distributions.Independent(torch.distributions.Normal(mean.unsqueeze(-3), raw_cov.exp().unsqueeze(-3) ** 0.5), 1)
+    else:
+        tril = raw_cov.tril(-1) + torch.diag_embed(raw_cov.diagonal(dim1=-1, dim2=-2).exp())
+        comp = torch.distributions.MultivariateNormal(mean.unsqueeze(-3), scale_tril=tril.unsqueeze(-4))
+    return torch.logsumexp(comp.log_prob(x.unsqueeze(-2)) + torch.log_softmax(torch.log(w), -1).unsqueeze(-2), dim=-1)
+
+
 def w2_prior_loss(z: Tensor, target_mean: Optional[Tensor] = None, target_cov: Optional[Tensor] = None) -> Tensor:
     """Gaussian W2 with empirical covariance as a loss term (BASELINE north_star): the batch statistics of
     ``GaussianModel._stats`` (gaussian_model.py:144-151) -> ``mean_cov`` (matrix_utils.py:145-158) -> ``w2_gaussian``
@@ -499,6 +520,26 @@ def codebook_probs(x: Tensor, codebook: Tensor, temperature: float = 1.0) -> Ten
     softmax_k((1 / (cdist(x, c) + 1e-8)) / T)."""
     energy = 1 / (torch.cdist(x, codebook, 2.0) + 1e-8)
     return torch.softmax(energy / temperature, dim=-1)
+
+
+def codebook_forward(x: Tensor, codebook: Tensor, temperature: float = 1.0, mode: str = "mean"):
+    """``CodebookModel.predict`` (codebook_model.py:145-148) on ``MixtureMixin.assign`` (base.py:206-239) with everything kept in
+    the autograd graph -- what ``update_with_autograd=True`` trains through (codebook_model.py:89): (weights @ codebook, probs,
+    entropy of Categorical(probs)); 'mean': weights = probs, 'argmax': their one-hot arg-max."""
+    probs = codebook_probs(x, codebook, temperature)
+    weights = probs if mode == "mean" else F.one_hot(probs.argmax(-1), probs.size(-1)).type_as(probs)
+    return weights @ codebook, probs, torch.distributions.Categorical(probs).entropy()
+
+
+def codebook_prior_encode_soft_kl(z: Tensor, codebook: Tensor, temperature: float):
+    """``CodebookPrior.encode`` (prior/codebook.py:86-105) for embed_dims=(1,), loss='kl', the soft 'mean' mode (commitment cost
+    0.1), a trained codebook [1, K, C]: z [B, C, H, W] -> vectors [H*W, B, C]; (encodings [B, C, H, W], loss [B])."""
+    b, c, h, w = z.shape
+    x = z.permute(2, 3, 0, 1).reshape(h * w, b, c)
+    preds, probs, ent = codebook_forward(x, codebook, temperature, "mean")
+    loss = (math.log(codebook.shape[-2]) - ent).sum(0)
+    loss = loss + 0.1 * ((preds - x.detach()) ** 2).mean(-1).sum(0)
+    return preds.reshape(h, w, b, c).permute(2, 3, 0, 1), loss
 
 
 def codebook_kmeans_stats(x: Tensor, codebook: Tensor, temperature: float = 1.0, mode: str = "argmax"):

@@ -1225,7 +1225,7 @@ extern "C" int otvae_codebook_probs(const float* x, const float* codebook, int n
 __global__ __launch_bounds__(256) void codebook_probs_bwd_kernel(const float* __restrict__ x, const float* __restrict__ cb,
                                                                  const float* __restrict__ probs, const float* __restrict__ gp,
                                                                  const float* __restrict__ gh, int B, int K, int d, float inv_temp,
-                                                                 float* __restrict__ gx) {
+                                                                 float* __restrict__ gx, float* __restrict__ coef_out) {
     extern __shared__ float coef_lds[];  // [4][K]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wv;
@@ -1255,6 +1255,7 @@ __global__ __launch_bounds__(256) void codebook_probs_bwd_kernel(const float* __
         const float dist = sqrtf(s), den = dist + 1e-8f;
         const float de = pr[k] * (coef[k] - dot);
         coef[k] = dist > 0.f ? de * (-inv_temp / (den * den)) / dist : 0.f;
+        if (coef_out) coef_out[row * K + k] = coef[k];  // for the gradient of the atoms (codebook_probs_bwd_atoms_kernel)
     }
     // the wave's LDS writes above are read by other lanes below: LDS operations of one wave execute in order
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1268,16 +1269,51 @@ __global__ __launch_bounds__(256) void codebook_probs_bwd_kernel(const float* __
     }
 }
 
-extern "C" int otvae_codebook_probs_bwd(const float* x, const float* codebook, const float* probs, const float* gprobs,
-                                        const float* gentropy, int nb, int B, int K, int d, float temperature, float* gx, void* stream) {
+// gc[k][:] = -sum_r coef[r][k] (x_r - c_k): the same per-(sample, atom) coefficients as gx, summed over the samples in increasing r
+// (fixed order).  One block per (atom, problem); thread j owns coordinate j.
+__global__ __launch_bounds__(256) void codebook_probs_bwd_atoms_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                                       const float* __restrict__ coef, int B, int K, int d,
+                                                                       float* __restrict__ gc) {
+    const int k = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (size_t)b * B * d;
+    const float* cf = coef + (size_t)b * B * K + k;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const float ckj = cb[((size_t)b * K + k) * d + j];
+        float acc = 0.f;
+        for (int r = 0; r < B; ++r) acc = fmaf(cf[(size_t)r * K], ckj - xb[(size_t)r * d + j], acc);
+        gc[((size_t)b * K + k) * d + j] = acc;
+    }
+}
+
+static int codebook_probs_bwd_launch(const float* x, const float* codebook, const float* probs, const float* gprobs, const float* gentropy,
+                                     int nb, int B, int K, int d, float temperature, float* gx, float* coef_ws, float* gc, void* stream) {
     OTVAE_REQUIRE(x && codebook && probs && gx && (gprobs || gentropy) && nb > 0 && B > 0 && K > 0 && d > 0,
                   "otvae_codebook_probs_bwd: bad argument");
     OTVAE_REQUIRE(temperature > 0.f, "otvae_codebook_probs_bwd: temperature must be positive");
     OTVAE_REQUIRE((size_t)K * 16 <= 64 * 1024, "otvae_codebook_probs_bwd: K = %d atoms exceed the LDS budget (4096)", K);
+    OTVAE_REQUIRE((gc == nullptr) == (coef_ws == nullptr), "otvae_codebook_probs_bwd_atoms: the coefficient workspace goes with gc");
     codebook_probs_bwd_kernel<<<dim3(cdiv(B, 4), nb), 256, (size_t)K * 16, (hipStream_t)stream>>>(x, codebook, probs, gprobs, gentropy,
-                                                                                                B, K, d, 1.f / temperature, gx);
+                                                                                                B, K, d, 1.f / temperature, gx, coef_ws);
     OTVAE_CHECK_LAUNCH("otvae_codebook_probs_bwd");
+    if (gc) {
+        codebook_probs_bwd_atoms_kernel<<<dim3(K, nb), 256, 0, (hipStream_t)stream>>>(x, codebook, coef_ws, B, K, d, gc);
+        OTVAE_CHECK_LAUNCH("otvae_codebook_probs_bwd_atoms");
+    }
     return OTVAE_OK;
+}
+
+extern "C" int otvae_codebook_probs_bwd(const float* x, const float* codebook, const float* probs, const float* gprobs,
+                                        const float* gentropy, int nb, int B, int K, int d, float temperature, float* gx, void* stream) {
+    return codebook_probs_bwd_launch(x, codebook, probs, gprobs, gentropy, nb, B, K, d, temperature, gx, nullptr, nullptr, stream);
+}
+
+// the same with the gradient of the ATOMS as well (CodebookModel(update_with_autograd=True): the codebook is a trained parameter,
+// reference codebook_model.py:89): coef_ws [nb][B][K] floats of workspace, gc [nb][K][d]
+extern "C" int otvae_codebook_probs_bwd_atoms(const float* x, const float* codebook, const float* probs, const float* gprobs,
+                                              const float* gentropy, int nb, int B, int K, int d, float temperature, float* gx,
+                                              float* coef_ws, float* gc, void* stream) {
+    OTVAE_REQUIRE(coef_ws && gc, "otvae_codebook_probs_bwd_atoms: NULL workspace / output");
+    return codebook_probs_bwd_launch(x, codebook, probs, gprobs, gentropy, nb, B, K, d, temperature, gx, coef_ws, gc, stream);
 }
 
 // One-hot k-means accumulation (MixtureMixin.kmean_iteration with 'argmax' weights, base.py:241-252):

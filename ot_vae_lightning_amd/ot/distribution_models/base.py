@@ -53,8 +53,14 @@ class DistributionModel(nn.Module, utils.DDPMixin, ABC):
         return (*self.leading_shape, self.dim)
 
     def _validate_samples(self, samples: Tensor) -> None:
-        if torch.broadcast_shapes(samples.shape[:-2], self.leading_shape) != self.leading_shape:
-            raise ValueError(f"`samples` leading dimensions are expected to broadcast to {tuple(self.leading_shape)}")
+        # the leading dimensions must be broadcast-compatible with the model's: equal, absent, or -- a codebook shared by all
+        # positions of a latent, CodebookPrior(embed_dims=(1,)) over a (1, dim) model -- larger where the model's are 1.  (The
+        # reference builds this ValueError without raising it, base.py:76-79: whatever broadcasts, runs.)
+        try:
+            torch.broadcast_shapes(samples.shape[:-2], self.leading_shape)
+        except RuntimeError:
+            raise ValueError(f"`samples` leading dimensions {tuple(samples.shape[:-2])} do not broadcast with "
+                             f"{tuple(self.leading_shape)}") from None
         if samples.size(-1) != self.dim:
             raise ValueError(f"`samples` are expected to have dimensionality {self.dim}")
 

@@ -10,8 +10,9 @@ smoothing over the observed atoms), and ``w2`` composes the HIP Sinkhorn solver 
 Supported: ``metric='euclidean'``, ``p=2``, ``topk=None``, the assignment modes ``'argmax'``, ``'sample'`` (one-hot) and
 ``'mean'`` (soft: the assignment distribution itself, as ``DiscreteTransport`` uses it in the reference's
 tests/test_latent_transport.py:92-101; its weighted sums ``probs^T @ samples`` go through ``matrix_utils.mm`` =
-``otvae_gemm_f32``), the Gumbel modes (``gumbel_weights``: ``otvae_softmax_rows`` with injectable draws),
-``update_with_autograd=False``.  ``energy`` (atoms against atoms, K x K, inside ``w2`` only) keeps ``torch.cdist``: its exact
+``otvae_gemm_f32``), the Gumbel modes (``gumbel_weights``: ``otvae_softmax_rows`` with injectable draws), and
+``update_with_autograd=True`` (the codebook as a trained parameter: gradients reach it through ``weights @ codebook`` and,
+in the soft modes and entropy losses, through the assignment probabilities, ``otvae_codebook_probs_bwd_atoms``).  ``energy`` (atoms against atoms, K x K, inside ``w2`` only) keeps ``torch.cdist``: its exact
 zero diagonal is what the reference's 1 / (dist + 1e-8) cost sees, which the |x|^2 + |y|^2 - 2 x.y kernel does not reproduce."""
 from functools import partial
 from typing import Optional, Tuple
@@ -62,8 +63,8 @@ class CategoricalEmbeddings(D.Categorical):
 
 class _AssignmentProbsFn(torch.autograd.Function):
     """softmax((1 / (|x - c_k| + 1e-8)) / T) (+ its entropy) with a backward pass to the samples (``otvae_codebook_probs_bwd``):
-    what lets CodebookPrior's soft 'mean' mode and its entropy losses train.  The codebook gets no gradient: it is a frozen
-    parameter in the reference (requires_grad = update_with_autograd, codebook_model.py:84-86)."""
+    what lets CodebookPrior's soft 'mean' mode and its entropy losses train.  The codebook gets a gradient only when it is a
+    trained parameter (requires_grad = update_with_autograd, reference codebook_model.py:89): ``otvae_codebook_probs_bwd_atoms``."""
 
     @staticmethod
     def forward(ctx, x3, c3, temperature, with_entropy):
@@ -88,6 +89,14 @@ class _AssignmentProbsFn(torch.autograd.Function):
         gx = torch.empty_like(x3)
         gp = gprobs.contiguous().float() if gprobs is not None else None
         ge = gent.contiguous().float() if gent is not None else None
+        if ctx.needs_input_grad[1]:  # update_with_autograd: the atoms are trained too
+            K = c3.shape[1]
+            coef = torch.empty((nb, bsz, K), device=x3.device, dtype=torch.float32)
+            gc = torch.empty_like(c3)
+            check(_lib.load().otvae_codebook_probs_bwd_atoms(ptr(x3), ptr(c3), ptr(probs), ptr(gp), ptr(ge), nb, bsz, K, d,
+                                                            ctx.temperature, ptr(gx), ptr(coef), ptr(gc), stream()),
+                  "otvae_codebook_probs_bwd_atoms")
+            return gx, gc, None, None
         check(_lib.load().otvae_codebook_probs_bwd(ptr(x3), ptr(c3), ptr(probs), ptr(gp), ptr(ge), nb, bsz, c3.shape[1], d,
                                                   ctx.temperature, ptr(gx), stream()), "otvae_codebook_probs_bwd")
         return gx, None, None, None
@@ -110,8 +119,6 @@ class CodebookModel(DistributionModel):
         for m in (cfg["training_mode"], cfg["inference_mode"]):
             if m not in MIXTURE_MODES:
                 raise NotImplementedError(f"assignment mode {m!r}: expected one of {MIXTURE_MODES}")
-        if kwargs.get("update_with_autograd", False):
-            raise NotImplementedError("update_with_autograd=True is not implemented on the MI355X path")
         self.n_components = int(cfg["n_components"])
         self.metric, self.p, self.topk = cfg["metric"], float(cfg["p"]), cfg["topk"]
         self.temperature = float(cfg["temperature"])
@@ -121,9 +128,11 @@ class CodebookModel(DistributionModel):
         DistributionModel.__init__(self, *size, **kwargs)
         w = torch.ones(*self.leading_shape, self.n_components)
         self.register_buffer("weight_init", (w / w.sum(-1, keepdim=True)).type_as(self.vec_init))
-        self.codebook = nn.Parameter(self.vec_init.clone(), requires_grad=False)
-        self.register_buffer("_running_sum", torch.zeros_like(self.vec_init))
-        self.register_buffer("_n_obs", torch.zeros(*self.leading_shape, self.n_components).type_as(self.vec_init))
+        # update_with_autograd: the atoms are a trained parameter and the k-means buffers are not created (codebook_model.py:89-93)
+        self.codebook = nn.Parameter(self.vec_init.clone(), requires_grad=self.update_with_autograd)
+        if not self.update_with_autograd:
+            self.register_buffer("_running_sum", torch.zeros_like(self.vec_init))
+            self.register_buffer("_n_obs", torch.zeros(*self.leading_shape, self.n_components).type_as(self.vec_init))
 
     # ---- shapes / distributions
     @property
@@ -132,7 +141,7 @@ class CodebookModel(DistributionModel):
 
     @property
     def weights(self) -> Tensor:
-        if torch.allclose(self._n_obs, torch.zeros_like(self._n_obs)):
+        if not hasattr(self, "_n_obs") or torch.allclose(self._n_obs, torch.zeros_like(self._n_obs)):
             return self.weight_init.type_as(self.codebook)
         return self._n_obs.type_as(self.codebook) / self._n_obs.sum(-1, keepdim=True)
 
@@ -147,6 +156,8 @@ class CodebookModel(DistributionModel):
     @torch.no_grad()
     def reset(self) -> None:
         self.codebook.copy_(self.vec_init)
+        if self.update_with_autograd:
+            return
         self._running_sum.zero_()
         self._n_obs.zero_()
 
@@ -157,8 +168,8 @@ class CodebookModel(DistributionModel):
         lead = torch.broadcast_shapes(samples.shape[:-2], self.leading_shape)
         bsz = samples.shape[-2]
         x3 = samples.float().expand(*lead, bsz, self.dim).reshape(-1, bsz, self.dim).contiguous()
-        c3 = self.codebook.detach().float().expand(*lead, self.n_components, self.dim) \
-            .reshape(-1, self.n_components, self.dim).contiguous()
+        cb = self.codebook if self.update_with_autograd else self.codebook.detach()   # a trained codebook stays in the graph
+        c3 = cb.float().expand(*lead, self.n_components, self.dim).reshape(-1, self.n_components, self.dim).contiguous()
         return x3, c3, lead
 
     def _argmax(self, samples: Tensor) -> Tuple[Tensor, Tensor]:
@@ -217,7 +228,7 @@ class CodebookModel(DistributionModel):
         """(weights @ codebook, sampled indices, assignment distribution) -- codebook_model.py:145-148.  In 'argmax'
         mode the product with a one-hot matrix is the gather the assignment kernel already did."""
         self._validate_samples(features)
-        if self.mode == "argmax":
+        if self.mode == "argmax" and not self.update_with_autograd:
             preds, _ = self._argmax(features)
             distribution = D.Categorical(self.assignment_probs(features))
             return preds.type_as(self.codebook), distribution.sample(), distribution
@@ -253,9 +264,15 @@ class CodebookModel(DistributionModel):
                 sums.reshape(*lead, self.n_components, self.dim).type_as(self._running_sum))
 
     # ---- fitting (codebook_model.py:121-143, 189-214)
+    def _no_buffers(self, what: str):
+        raise RuntimeError(f"`update_with_autograd` is True: the codebook is trained with autograd; the k-means buffers `{what}` feeds "
+                           "were not created (the reference warns, base.py:82-90, then fails on the missing buffers)")
+
     @torch.no_grad()
     def update(self, samples: Tensor) -> None:
         self._validate_samples(samples)
+        if self.update_with_autograd:
+            self._no_buffers("update")
         samples = samples.detach().type_as(self._running_sum)
         self._init_parameters(samples)
         res = self.kmean_iteration(samples)
@@ -266,6 +283,8 @@ class CodebookModel(DistributionModel):
 
     @torch.no_grad()
     def fit(self, samples: Optional[Tensor] = None) -> None:
+        if self.update_with_autograd:
+            self._no_buffers("fit")
         if samples is not None:
             self._validate_samples(samples)
             samples = samples.detach().type_as(self._running_sum)

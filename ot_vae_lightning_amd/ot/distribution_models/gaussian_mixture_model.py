@@ -23,7 +23,7 @@ from ... import _lib, utils
 from ..._lib import check, ptr, stream
 from ..w2_utils import W2Mixin, batch_ot_gmm
 from .base import MIXTURE_MODES, DistributionModel, gumbel_weights
-from .gaussian_model import MakePositiveDefinite, Symmetric
+from .gaussian_model import ExpScaleTril, MakePositiveDefinite, Symmetric, mvn_log_prob
 from ..matrix_utils import eigh_vectors, eye_like, matmul64, mm, softmax_rows
 
 __all__ = ["GaussianMixtureModel"]
@@ -61,8 +61,6 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         for m in (cfg["training_mode"], cfg["inference_mode"]):
             if m not in MIXTURE_MODES:
                 raise NotImplementedError(f"assignment mode {m!r}: expected one of {MIXTURE_MODES}")
-        if kwargs.get("update_with_autograd", False):
-            raise NotImplementedError("update_with_autograd=True is not implemented on the MI355X path")
         self.n_components = int(cfg["n_components"])
         self.temperature = float(cfg["temperature"])
         self.training_mode, self.inference_mode = cfg["training_mode"], cfg["inference_mode"]
@@ -74,9 +72,17 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         self.register_buffer("cov_init", torch.ones_like(self.vec_init) if self.diag else eye_like(self.mat_init).clone())
         w = torch.ones(*self.leading_shape, self.n_components)
         self.register_buffer("weight_init", (w / w.sum(-1, keepdim=True)).type_as(self.vec_init))
-        self.mean = nn.Parameter(self.vec_init.clone(), requires_grad=False)
-        self.cov = nn.Parameter(self.cov_init.clone(), requires_grad=False)
-        self._weights = nn.Parameter(self.weight_init.clone(), requires_grad=False)
+        auto = self.update_with_autograd
+        self.mean = nn.Parameter(self.vec_init.clone(), requires_grad=auto)
+        self.cov = nn.Parameter(self.cov_init.clone(), requires_grad=auto)
+        self._weights = nn.Parameter(self.weight_init.clone(), requires_grad=auto)
+        if auto:
+            # trained through the mixture log-likelihood (`forward` = `predict`): `cov` holds each component's Cholesky factor
+            # (diag: its variances) behind the exp + tril re-parametrisation, the weights sit behind a soft-max; the k-means
+            # buffers are not created (reference gaussian_model.py:52-72, gassian_mixture_model.py:53-58)
+            P.register_parametrization(self, "cov", ExpScaleTril(diag=self.diag))
+            P.register_parametrization(self, "_weights", nn.Softmax(-1))
+            return
         self.register_buffer("_running_sum", torch.zeros_like(self.mean.data))
         self.register_buffer("_running_sum_cov", torch.zeros_like(self.cov.data))
         self.register_buffer("_n_obs", torch.zeros(self.vec_shape[:-1], dtype=self.vec_init.dtype))
@@ -96,11 +102,13 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
 
     @property
     def variances(self) -> Tensor:
+        if self.update_with_autograd and not self.diag:  # get_var_normal(components): L L^T
+            return mm(self.cov, self.cov.transpose(-1, -2).contiguous())
         return self.cov
 
     @property
     def batched_variances(self) -> Tensor:
-        return self.cov.unsqueeze(-3 if self.diag else -4)
+        return self.variances.unsqueeze(-3 if self.diag else -4)
 
     @property
     def mode(self) -> str:
@@ -108,6 +116,9 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
 
     def _components(self, batched: bool):
         cov = self.cov
+        if self.update_with_autograd and not self.diag:
+            mean, tril = (self.mean.unsqueeze(-3), cov.unsqueeze(-4)) if batched else (self.mean, cov)
+            return D.MultivariateNormal(mean, scale_tril=tril)
         if self.diag:
             mean, cov = (self.mean.unsqueeze(-3), cov.unsqueeze(-3)) if batched else (self.mean, cov)
             return D.Independent(D.Normal(mean, cov ** 0.5), 1)
@@ -127,6 +138,8 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         self.mean.copy_(self.vec_init)
         self.cov = self.cov_init
         self._weights = self.weight_init
+        if self.update_with_autograd:
+            return
         self._running_sum.zero_()
         self._running_sum_cov.zero_()
         self._n_obs.zero_()
@@ -147,7 +160,7 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         flat = lambda t, tail: t.detach().to(dt).expand(*lead, *tail).reshape(nb, *tail).contiguous()  # noqa: E731
         logw = flat(torch.log_softmax(torch.log(self.weights), dim=-1), (K,))
         if not self.diag:
-            return self._energy_full(x3, flat(self.mean, (K, d)), flat(self.cov, (K, d, d)), logw).reshape(*lead, bsz, K) \
+            return self._energy_full(x3, flat(self.mean, (K, d)), flat(self.variances, (K, d, d)), logw).reshape(*lead, bsz, K) \
                 .type_as(samples if samples.is_floating_point() else x3)
         mean, var = flat(self.mean, (K, d)), flat(self.cov, (K, d))
         out = torch.empty((nb, bsz, K), device=x3.device, dtype=dt)
@@ -195,7 +208,24 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
             var = mm(assignments.type_as(cov), cov.flatten(-2)).unflatten(-1, (self.dim, self.dim))
         return mean.type_as(assignments), var.type_as(assignments)
 
-    def predict(self, samples: Tensor):
+    def predict(self, samples: Tensor) -> Tensor:
+        """log-density of the mixture at the samples, [*, B] -- what `model(samples)` returns.  (The reference class inherits
+        from GaussianModel first: its `predict` is GaussianModel.predict on the MixtureSameFamily `batched_distribution`,
+        gaussian_model.py:129-132, not CodebookModel's (encodings, indices, distribution) triple.)  With
+        ``update_with_autograd`` this is the training objective: differentiable in mean, Cholesky factor / variances and weights
+        through ``mvn_log_prob`` (csrc/mvn.hip)."""
+        self._validate_samples(samples)
+        if not self.update_with_autograd:
+            return torch.logsumexp(self.energy(samples), dim=-1)
+        x = samples.type_as(self.mean).unsqueeze(-3)                                  # [*, 1, B, d] against K components
+        scale = self.cov ** 0.5 if self.diag else self.cov
+        comp = mvn_log_prob(x, self.mean, scale, self.diag).transpose(-1, -2)         # [*, K, B] -> [*, B, K]
+        logw = torch.log_softmax(torch.log(self.weights), dim=-1).unsqueeze(-2)
+        return torch.logsumexp(comp + logw, dim=-1)
+
+    def encode(self, samples: Tensor):
+        """(expected component mean per sample, sampled indices, assignment distribution): the triple CodebookModel.predict returns
+        for a codebook (round 1-2 exposed it under the name `predict`, which the reference class resolves differently)"""
         weights, indices, distribution = self.assign(samples)
         return mm(weights.type_as(self.mean), self.mean), indices, distribution
 
@@ -242,9 +272,15 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         tmp[seen] = weights_sum[seen].type_as(tmp)  # ... with the raw counts of the observed components, as the reference
         self._weights = tmp
 
+    def _no_buffers(self, what: str):
+        raise RuntimeError(f"`update_with_autograd` is True: the parameters are trained with autograd; the k-means buffers `{what}` "
+                           "feeds were not created (the reference warns, base.py:82-90, then fails on the missing buffers)")
+
     @torch.no_grad()
     def update(self, samples: Tensor) -> None:
         self._validate_samples(samples)
+        if self.update_with_autograd:
+            self._no_buffers("update")
         samples = samples.detach().type_as(self._running_sum)
         self._init_parameters(samples)
         res = self.kmean_iteration(samples)
@@ -254,6 +290,8 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
 
     @torch.no_grad()
     def fit(self, samples: Optional[Tensor] = None) -> None:
+        if self.update_with_autograd:
+            self._no_buffers("fit")
         if samples is not None:
             self._validate_samples(samples)
             samples = samples.detach().type_as(self._running_sum)

@@ -1002,6 +1002,112 @@ def test_gaussian_model_update_with_autograd(A, diag):
     rep.finish()
 
 
+@pytest.mark.parametrize("tag", ["fit_diag", "fit_full"])
+def test_gmm_forward_is_the_mixture_log_density(A, tag):
+    """`GaussianMixtureModel(...)(samples)` in eval mode: the reference class resolves `predict` to GaussianModel.predict (its first
+    base), the log-density of the MixtureSameFamily -- golden from the reference's own fitted model (gmm_autograd.npz)."""
+    g = group(load_golden("gmm_autograd.npz"), tag)
+    K, d, B, diag = (int(v) for v in g["cfg"])
+    lead = tuple(g["mean"].shape[:-2])
+    model = A.GaussianMixtureModel(*lead, d, mixture_cfg=dict(n_components=K), w2_cfg=dict(diag=bool(diag), make_pd=True),
+                                   dtype=torch.double).cuda()
+    with torch.no_grad():  # the values stored BEHIND the parametrisations (reading `cov` adds the strict positive-definite shift)
+        model.mean.copy_(g["mean"].cuda())
+        model.parametrizations.cov.original.copy_(g["raw_cov"].cuda())
+        model.parametrizations._weights.original.copy_(g["raw_weights"].cuda())
+    model.eval()
+    rep = Report(f"GaussianMixtureModel forward ({tag}) vs the reference class")
+    rep.check("cov as read", model.cov, g["cov"], 1e-12)
+    rep.check("weights as read", model.weights, g["weights"], 1e-12)
+    rep.check("log-density", model(g["probe"].cuda()), g["log_prob"], 1e-10)
+    rep.finish()
+
+
+@pytest.mark.parametrize("tag", ["auto_diag", "auto_diag_lead", "auto_full", "auto_full_lead"])
+def test_gmm_update_with_autograd(A, tag):
+    """`GaussianMixtureModel(update_with_autograd=True)` (gassian_mixture_model.py:53-58): log-density and its gradients with
+    respect to samples, means, the raw ExpScaleTril parameter and the raw soft-max weights against the reference class under
+    torch.autograd (golden gmm_autograd.npz), plus the derived `variances` / `weights` attributes."""
+    g = group(load_golden("gmm_autograd.npz"), tag)
+    K, d, B, diag = (int(v) for v in g["cfg"])
+    lead = tuple(g["mean"].shape[:-2])
+    model = A.GaussianMixtureModel(*lead, d, mixture_cfg=dict(n_components=K), w2_cfg=dict(diag=bool(diag), make_pd=True),
+                                   update_with_autograd=True, dtype=torch.double).cuda()
+    raw_cov, raw_w = model.parametrizations.cov.original, model.parametrizations._weights.original
+    assert model.mean.requires_grad and raw_cov.requires_grad and raw_w.requires_grad
+    with torch.no_grad():
+        model.mean.copy_(g["mean"].cuda())
+        raw_cov.copy_(g["raw_cov"].cuda())
+        raw_w.copy_(g["raw_weights"].cuda())
+    x = g["x"].cuda().requires_grad_(True)
+    model.train()
+    lp = model(x)
+    (lp * g["seed"].cuda()).sum().backward()
+    rep = Report(f"GaussianMixtureModel(update_with_autograd=True) ({tag}) vs the reference class")
+    rep.check("log-density", lp, g["log_prob"], 1e-10)
+    rep.check("d/d samples", x.grad, g["g_x"], 1e-9)
+    rep.check("d/d mean", model.mean.grad, g["g_mean"], 1e-9)
+    rep.check("d/d raw cov parameter", raw_cov.grad, g["g_raw_cov"], 1e-9)
+    rep.check("d/d raw weight parameter", raw_w.grad, g["g_raw_weights"], 1e-9)
+    rep.check("variances", model.variances, g["variances"], 1e-12)
+    rep.check("weights", model.weights, g["weights"], 1e-12)
+    rep.finish()
+    with pytest.raises(RuntimeError):
+        model.update(x.detach())
+
+
+@pytest.mark.parametrize("tag", ["mean", "mean_lead", "argmax"])
+def test_codebook_update_with_autograd(A, tag):
+    """`CodebookModel(update_with_autograd=True)` (codebook_model.py:89-93): predictions, assignment probabilities, entropy and the
+    gradients of a scalar made of all three with respect to the samples AND the codebook (otvae_codebook_probs_bwd_atoms +
+    the library GEMM's backward) against the reference class under torch.autograd (golden codebook_autograd.npz)."""
+    g = group(load_golden("codebook_autograd.npz"), tag)
+    K, d, B = (int(v) for v in g["cfg"][:3])
+    T = float(g["cfg"][3])
+    mode = "argmax" if tag == "argmax" else "mean"
+    lead = tuple(g["codebook"].shape[:-2])
+    model = A.CodebookModel(*lead, d, mixture_cfg=dict(n_components=K, temperature=T, training_mode=mode, inference_mode=mode),
+                            update_with_autograd=True).cuda()
+    assert model.codebook.requires_grad and not hasattr(model, "_n_obs")
+    with torch.no_grad():
+        model.codebook.copy_(g["codebook"].cuda())
+    x = g["x"].cuda().requires_grad_(True)
+    model.train()
+    preds, _, dist = model(x)
+    ent = dist.entropy()
+    ((preds * g["s_pred"].cuda()).sum() + (dist.probs * g["s_prob"].cuda()).sum() + (ent * g["s_ent"].cuda()).sum()).backward()
+    rep = Report(f"CodebookModel(update_with_autograd=True) ({tag}) vs the reference class")
+    rep.check("predictions", preds, g["preds"], 1e-5)
+    rep.check("assignment probabilities", dist.probs, g["probs"], 5e-5)
+    rep.check("entropy", ent, g["entropy"], 5e-5, floor=1e-3)
+    rep.check("d/d samples", x.grad, g["g_x"], 5e-4)
+    rep.check("d/d codebook", model.codebook.grad, g["g_codebook"], 5e-4)
+    rep.finish()
+    with pytest.raises(RuntimeError):
+        model.update(x.detach())
+
+
+def test_codebook_prior_with_trained_codebook(A):
+    """CodebookPrior(loss='kl', soft mode) over a CodebookModel(update_with_autograd=True): encodings, loss and the gradients of
+    (seeded encodings + loss) with respect to the latent and the codebook against the reference classes."""
+    g = group(load_golden("codebook_autograd.npz"), "prior")
+    K, T = int(g["cfg"][0]), float(g["cfg"][1])
+    prior = A.CodebookPrior((8, 2, 2), embed_dims=(1,), loss="kl", loss_coeff=1.0, update_with_autograd=True,
+                            mixture_cfg=dict(n_components=K, temperature=T, training_mode="mean", inference_mode="mean")).cuda()
+    with torch.no_grad():
+        prior.codebook_model.codebook.copy_(g["codebook"].cuda())
+    z = g["z"].cuda().requires_grad_(True)
+    prior.train()
+    enc, loss, _ = prior.encode(z)
+    ((enc * g["s_z"].cuda()).sum() + loss.sum()).backward()
+    rep = Report("CodebookPrior over a trained codebook vs the reference classes")
+    rep.check("encodings", enc, g["enc"], 1e-5)
+    rep.check("loss", loss, g["loss"], 5e-5)
+    rep.check("d/d latent", z.grad, g["g_z"], 5e-4)
+    rep.check("d/d codebook", prior.codebook_model.codebook.grad, g["g_codebook"], 5e-4)
+    rep.finish()
+
+
 def test_gaussian_transport_1024_dims_vs_oracle(A):
     """W2 + transport operator at the reference's latent-transport test size (D = 1024, transport_dims (1,2,3))."""
     import otvae_oracle as O

@@ -802,3 +802,42 @@ def test_stochastic_transport_operator_vs_reference():
     T, Cw = O.transport_operator_stochastic(wf["cs"], wf["ct"], 0.1, diag=False)
     assert rel_err(T, wf["T"]) < 1e-10 and (Cw - wf["Cw"]).abs().max() < 2e-10
     assert torch.linalg.eigvalsh(wf["Cw"]).min() > 1e-8
+
+
+@pytest.mark.parametrize("tag", ["fit_diag", "fit_full"])
+def test_gmm_forward_is_the_mixture_log_density(tag):
+    g = group(load_golden("gmm_autograd.npz"), tag)
+    diag = bool(int(g["cfg"][3]))
+    assert rel_err(O.gmm_log_prob(g["probe"], g["mean"], g["cov"], g["weights"], diag), g["log_prob"]) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["auto_diag", "auto_diag_lead", "auto_full", "auto_full_lead"])
+def test_gmm_update_with_autograd_log_prob_and_gradients(tag):
+    g = group(load_golden("gmm_autograd.npz"), tag)
+    diag = bool(int(g["cfg"][3]))
+    x, mean, raw_cov, raw_w = (g[k].clone().requires_grad_(True) for k in ("x", "mean", "raw_cov", "raw_weights"))
+    lp = O.gmm_autograd_log_prob(x, mean, raw_cov, raw_w, diag)
+    assert rel_err(lp, g["log_prob"]) < 1e-12
+    (lp * g["seed"]).sum().backward()
+    for got, name in ((x.grad, "g_x"), (mean.grad, "g_mean"), (raw_cov.grad, "g_raw_cov"), (raw_w.grad, "g_raw_weights")):
+        assert rel_err(got, g[name]) < 1e-10, name
+
+
+@pytest.mark.parametrize("tag", ["mean", "mean_lead", "argmax"])
+def test_codebook_update_with_autograd(tag):
+    g = group(load_golden("codebook_autograd.npz"), tag)
+    T = float(g["cfg"][3])
+    x, cb = g["x"].clone().requires_grad_(True), g["codebook"].clone().requires_grad_(True)
+    preds, probs, ent = O.codebook_forward(x, cb, T, "argmax" if tag == "argmax" else "mean")
+    assert rel_err(preds, g["preds"]) < 1e-5 and rel_err(probs, g["probs"]) < 1e-5 and rel_err(ent, g["entropy"]) < 1e-5
+    ((preds * g["s_pred"]).sum() + (probs * g["s_prob"]).sum() + (ent * g["s_ent"]).sum()).backward()
+    assert rel_err(x.grad, g["g_x"]) < 1e-4 and rel_err(cb.grad, g["g_codebook"]) < 1e-4
+
+
+def test_codebook_prior_with_trained_codebook():
+    g = group(load_golden("codebook_autograd.npz"), "prior")
+    z, cb = g["z"].clone().requires_grad_(True), g["codebook"].clone().requires_grad_(True)
+    enc, loss = O.codebook_prior_encode_soft_kl(z, cb, float(g["cfg"][1]))
+    assert rel_err(enc, g["enc"]) < 1e-5 and rel_err(loss, g["loss"]) < 1e-5
+    ((enc * g["s_z"]).sum() + loss.sum()).backward()
+    assert rel_err(z.grad, g["g_z"]) < 1e-4 and rel_err(cb.grad, g["g_codebook"]) < 1e-4

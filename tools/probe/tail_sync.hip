@@ -101,6 +101,62 @@ __global__ __launch_bounds__(256) void finalize(const double* __restrict__ parti
     }
 }
 
+// variant 4 (round 3): NO finalize launch and NO ticket.  Every block adds its 2C partial sums into slot (block % S) of a per-layer
+// accumulator with non-returning agent-scope fp64 atomics (unordered: the last bit of a sum depends on arrival order); the NEXT
+// producer's prologue adds the S slots in a fixed order and builds its table.  The accumulators of all layers are zeroed by one
+// memset node at the head of the graph.
+__global__ __launch_bounds__(256) void producer_slots(const float4* __restrict__ in, float4* __restrict__ out, int per_block,
+                                                      const double* __restrict__ slots_in, int S_in, double* slots_out, int S_out) {
+    __shared__ float tab[2 * C];
+    __shared__ double red[4][2][C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (slots_in) {
+        __shared__ double stage[16 * 2 * C];
+        for (int idx = tid; idx < S_in * 2 * C; idx += 256) stage[idx] = slots_in[idx];  // every load in flight at once
+        __syncthreads();
+        if (tid < 2 * C) {
+            double a = 0.0;
+            for (int sl = 0; sl < S_in; ++sl) a += stage[sl * 2 * C + tid];              // fixed order
+            red[0][0][tid] = a;   // (red[0] is [2][C] = 2C doubles)
+        }
+        __syncthreads();
+        if (tid < C) {
+            const double mu = red[0][0][tid] / 1e6, var = red[0][1][tid] / 1e6 - mu * mu;
+            const float is = (float)(1.0 / sqrt(fabs(var) + 1e-5));
+            tab[tid] = is;
+            tab[C + tid] = (float)(-mu) * is;
+        }
+    } else if (tid < 2 * C) tab[tid] = 0.f;
+    __syncthreads();
+    double s = 0.0, q = 0.0;
+    const int c4 = (tid * 4) % C;
+    for (int i = 0; i < per_block; ++i) {
+        const size_t e = ((size_t)blockIdx.x * per_block + i) * 256 + tid;
+        float4 v = in[e];
+        v.x = fmaf(v.x, tab[c4], tab[C + c4]) * 0.5f;
+        v.y = fmaf(v.y, tab[c4 + 1], tab[C + c4 + 1]) * 0.5f;
+        v.z = fmaf(v.z, tab[c4 + 2], tab[C + c4 + 2]) * 0.5f;
+        v.w = fmaf(v.w, tab[c4 + 3], tab[C + c4 + 3]) * 0.5f;
+        out[e] = v;
+        s += (double)v.x + (double)v.y;
+        q += (double)v.x * v.x + (double)v.w;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    __syncthreads();
+    if (lane < C) {
+        red[wave][0][lane] = s + lane;
+        red[wave][1][lane] = q + lane;
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+        const int which = tid / C, c = tid % C;
+        const double t = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        double* dst = slots_out + (size_t)(blockIdx.x % S_out) * 2 * C + tid;
+        __hip_atomic_fetch_add(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int main() {
     const int L = 40;
     for (int P : {64, 256, 1024}) {
@@ -122,8 +178,11 @@ int main() {
             CK(hipMemset(ticket, 0, 4));
             hipStream_t st;
             CK(hipStreamCreate(&st));
-            double res[4];
-            for (int variant = 0; variant < 4; ++variant) {  // 0 unfused, 1 fused fence, 2 fused agent atomics, 3 producers only
+            double res[10];
+            const int slot_counts[5] = {1, 2, 4, 8, 16};
+            double* slots;
+            CK(hipMalloc(&slots, (size_t)L * 64 * 2 * C * 8));
+            for (int variant = 0; variant < 9; ++variant) {  // 0 unfused, 1 fused fence, 2 fused agent atomics, 3 producers only, 4-6 slot atomics
                 hipGraph_t g;
                 hipGraphExec_t ge;
                 CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -136,8 +195,14 @@ int main() {
                         producer<1><<<P, 256, 0, st>>>(src, dst, per_block, table, sums, partial, P, ticket, sums);
                     else if (variant == 2)
                         producer<2><<<P, 256, 0, st>>>(src, dst, per_block, table, sums, partial, P, ticket, sums);
-                    else
+                    else if (variant == 3)
                         producer<0><<<P, 256, 0, st>>>(src, dst, per_block, table, nullptr, partial, P, ticket, sums);
+                    else {
+                        const int S = slot_counts[variant - 4];
+                        if (l == 0) CK(hipMemsetAsync(slots, 0, (size_t)L * 64 * 2 * C * 8, st));
+                        producer_slots<<<P, 256, 0, st>>>(src, dst, per_block, l ? slots + (size_t)(l - 1) * 64 * 2 * C : nullptr, S,
+                                                          slots + (size_t)l * 64 * 2 * C, S);
+                    }
                 }
                 CK(hipStreamEndCapture(st, &g));
                 CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
@@ -157,8 +222,9 @@ int main() {
             }
             unsigned tk;
             CK(hipMemcpy(&tk, ticket, 4, hipMemcpyDeviceToHost));
-            printf("P=%4d blocks x %2d KB each: per layer  unfused %6.2f us | fused(fence) %6.2f | fused(agent atomics) %6.2f | producer alone %6.2f   (ticket %u)\n",
-                   P, per_block * 4, res[0], res[1], res[2], res[3], tk);
+            printf("P=%4d blocks x %2d KB each: per layer  unfused %6.2f us | fused(fence) %6.2f | fused(agent atomics) %6.2f | producer alone %6.2f | slot atomics S=1 %6.2f  S=2 %6.2f  S=4 %6.2f  S=8 %6.2f  S=16 %6.2f   (ticket %u)\n",
+                   P, per_block * 4, res[0], res[1], res[2], res[3], res[4], res[5], res[6], res[7], res[8], tk);
+            hipFree(slots);
             hipFree(a); hipFree(b); hipFree(table); hipFree(partial); hipFree(sums); hipFree(ticket);
         }
     }
