@@ -284,6 +284,13 @@ int otvae_bn_act_bwd(const float* ga, const float* x, const float* scale, const 
 /* dst[i] = alpha * src[i], n contiguous floats (weight * conv_scale * lr_mult, bias * lr_mult and their gradients) */
 int otvae_scale_f32(const float* src, float alpha, int64_t n, float* dst, void* stream);
 
+/* ---- grouped / dilated ConvLayer (networks/cnn.py:66-67,103-104: nn.Conv2d(in, out, k, stride, padding, dilation, groups)).
+ * The layer's weight w [Cout][Cin / groups][KH][KW] (contiguous, as nn.Conv2d stores it) is expanded into the dense weight of the
+ * convolution entry points, dense [(KH-1) dil + 1][(KW-1) dil + 1][Cin][Cout] (HWIO memory): zeros between groups and in the holes
+ * of the dilation.  _bwd gathers the dense weight's gradient back onto w's layout.  The expanded kernel may span at most 7 x 7. */
+int otvae_weight_expand_fwd(const float* w, int Cout, int Cin, int groups, int KH, int KW, int dilation, float* dense, void* stream);
+int otvae_weight_expand_bwd(const float* gdense, int Cout, int Cin, int groups, int KH, int KW, int dilation, float* gw, void* stream);
+
 /* ---- GroupNorm / InstanceNorm2d in front of a ConvLayer's activation (networks/cnn.py:121-125: nn.GroupNorm(div_sqrt(C // groups), C),
  * nn.InstanceNorm2d(C) = G == C without gamma / beta).  x, out, ga, dx [N][HW][C] channels-last; statistics per (sample, group) over
  * the group's C / G channels and all HW positions (biased variance, eps inside the root); kind: the activation codes above. */

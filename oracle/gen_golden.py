@@ -95,6 +95,13 @@ CONV_CASES = [
     ("film_relu", "ConvLayer", 8, 8, 8, dict(normalization="batchnorm", activation="relu", additional_embed=5)),
     ("film_leaky_eq", "ConvLayer", 4, 8, 8, dict(down_sample=2, normalization="batchnorm", activation="leaky", equalized_lr=2., additional_embed=6)),
     ("film_1x1_gn", "Conv1x1", 8, 24, 8, dict(normalization="groupnorm", additional_embed=5)),
+    # grouped / dilated layers (cnn.py:66-67,103-104: nn.Conv2d(..., dilation, groups); GroupNorm(div_sqrt(C // groups), C) :123)
+    ("grp2_relu", "ConvLayer", 8, 8, 8, dict(normalization="batchnorm", activation="relu", groups=2)),
+    ("grp4_down_leaky_eq", "ConvLayer", 8, 16, 8, dict(down_sample=2, normalization="batchnorm", activation="leaky", equalized_lr=2., groups=4)),
+    ("grp2_1x1_gn", "Conv1x1", 8, 24, 8, dict(normalization="groupnorm", groups=2)),
+    ("dil2_relu", "ConvLayer", 4, 8, 8, dict(normalization="batchnorm", activation="relu", dilation=2, padding=2)),
+    ("dil3_grp2_up", "ConvLayer", 8, 4, 4, dict(up_sample=2, normalization="batchnorm", activation="relu", dilation=3, groups=2)),
+    ("dil2_nobias_silu", "ConvLayer", 6, 6, 8, dict(activation="silu", dilation=2, groups=3, bias=False)),
 ]
 
 

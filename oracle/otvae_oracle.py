@@ -105,19 +105,22 @@ _ACTIVATIONS = {  # cnn.py:128-147 (the reference tests the names in this order:
 
 def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: bool, relu: bool,
                norm: bool, ksize: int = 3, training: bool = True, act: Optional[str] = None,
-               equalized_lr: Optional[float] = None, other_norm: Optional[str] = None, embed: Optional[Tensor] = None) -> Tensor:
+               equalized_lr: Optional[float] = None, other_norm: Optional[str] = None, embed: Optional[Tensor] = None,
+               groups: int = 1, dilation: int = 1, padding: Optional[int] = None) -> Tensor:
     """``ConvLayer.forward`` (networks/cnn.py:183-192): BN -> act -> nearest x2 up -> conv (stride-2 4x4 when
     down-sampling, cnn.py:98-101).  ``p[prefix+'_normalization.running_*']`` are updated in place like
     nn.BatchNorm2d does in training mode.  ``act``: one of leaky / relu / selu / gelu / silu (overrides ``relu``);
-    ``equalized_lr``: weight * (1 / sqrt(fan_in)) * lr_mult, bias * lr_mult (cnn.py:114-118,186-188)."""
+    ``equalized_lr``: weight * (1 / sqrt(fan_in)) * lr_mult, bias * lr_mult (cnn.py:114-118,186-188); ``groups`` / ``dilation`` /
+    ``padding``: nn.Conv2d's (cnn.py:66-67,103-104), the weight is [out, in / groups, k, k]."""
     out = x
     if norm:
         out = F.batch_norm(out, p[prefix + "_normalization.running_mean"], p[prefix + "_normalization.running_var"],
                            p[prefix + "_normalization.weight"], p[prefix + "_normalization.bias"],
                            training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
-    if other_norm == "group":      # nn.GroupNorm(div_sqrt(C), C) (cnn.py:123, groups = 1)
+    if other_norm == "group":      # nn.GroupNorm(div_sqrt(C // groups), C) (cnn.py:123)
         c = out.shape[1]
-        g = next(d for d in range(1, c + 1) if c % d == 0 and d >= math.sqrt(c))
+        cg = c // groups
+        g = next(d for d in range(1, cg + 1) if cg % d == 0 and d >= math.sqrt(cg))
         out = F.group_norm(out, g, p[prefix + "_normalization.weight"], p[prefix + "_normalization.bias"], eps=BN_EPS)
     elif other_norm == "instance":  # nn.InstanceNorm2d(C): no affine, no running statistics (cnn.py:124)
         out = F.instance_norm(out, eps=BN_EPS)
@@ -143,7 +146,9 @@ def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: 
     if equalized_lr:
         w = w * (1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])) * equalized_lr
         bias = bias * equalized_lr if bias is not None else None
-    return F.conv2d(out, w, bias, stride=stride, padding=pad)
+    if padding is not None and not down:
+        pad = padding
+    return F.conv2d(out, w, bias, stride=stride, padding=pad, dilation=dilation, groups=groups)
 
 
 def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:

@@ -95,6 +95,8 @@ SIGNATURES = {
     "otvae_bn_act_bwd_parts": (i32, [i64]),
     "otvae_bn_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, vp]),
     "otvae_scale_f32": (i32, [vp, f32, i64, vp, vp]),
+    "otvae_weight_expand_fwd": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "otvae_weight_expand_bwd": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "otvae_group_norm_act_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]),
     "otvae_group_norm_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "otvae_colsum_f32": (i32, [vp, i32, i32, vp, vp]),

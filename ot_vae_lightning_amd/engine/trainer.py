@@ -125,7 +125,8 @@ class HipTrainer:
             p._otvae_grad_view = _dense_view(self.gflat, off, p.data).detach
         # dgrad-layout ([T][Cout][Cin]) copies of every conv weight, refreshed by ONE launch at the start of each step
         # (the ViT's Linear weights are 1x1 layers on the same kernels: [out, in] = [Cn, Cs], one tap)
-        self.conv_weights = [mod.weight for mod in model.modules() if isinstance(mod, ConvLayer)]
+        # (grouped / dilated layers hand the kernels an expanded temporary, functional._WeightExpandFn: nothing resident to refresh)
+        self.conv_weights = [mod.weight for mod in model.modules() if isinstance(mod, ConvLayer) and getattr(mod, "_expand", None) is None]
         self.conv_weights += [p_ for n_, p_ in model.named_parameters()
                               if p_.dim() == 2 and (n_.endswith("in_proj_weight") or getattr(p_, "_otvae_linear", False))]
         flat_ids = {id(p): off for p, off in zip(self.params, self.offsets)}

@@ -855,6 +855,32 @@ class _ScaleFn(torch.autograd.Function):
         return out, None
 
 
+class _WeightExpandFn(torch.autograd.Function):
+    """The dense HWIO weight of a grouped and / or dilated ConvLayer from its nn.Conv2d-shaped parameter [Cout, Cin / groups, KH, KW]
+    (csrc/weight_expand.hip): zeros between the groups and in the holes of the dilation."""
+
+    @staticmethod
+    def forward(ctx, w, cin, groups, dilation):
+        cout, cig, kh, kw = w.shape
+        if cig * groups != cin:
+            raise ValueError(f"grouped weight {tuple(w.shape)} does not match {cin} input channels in {groups} groups")
+        w = w.contiguous()
+        dense = new_hwio(cout, cin, (kh - 1) * dilation + 1, (kw - 1) * dilation + 1, device=w.device)
+        check(_lib.load().otvae_weight_expand_fwd(ptr(w), cout, cin, groups, kh, kw, dilation, ptr(dense), stream()),
+              "otvae_weight_expand_fwd")
+        ctx.geom = (cout, cin, groups, kh, kw, dilation)
+        return dense
+
+    @staticmethod
+    def backward(ctx, g):
+        cout, cin, groups, kh, kw, dilation = ctx.geom
+        g = hwio_weight(g)
+        gw = torch.empty((cout, cin // groups, kh, kw), device=g.device, dtype=g.dtype)
+        check(_lib.load().otvae_weight_expand_bwd(ptr(g), cout, cin, groups, kh, kw, dilation, ptr(gw), stream()),
+              "otvae_weight_expand_bwd")
+        return gw, None, None, None
+
+
 def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
     """One ConvLayer whose activation is not ReLU and / or whose weight and bias carry the equalized_lr multipliers: BatchNorm
     statistics (the fused path's kernels) -> ``_BnActFn`` -> the fused convolution kernels with neither BatchNorm nor activation."""
@@ -882,6 +908,9 @@ def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
         if kind != 0:
             a = _BnActFn.apply(a, None, None, None, kind, (None, None))
     w = br["weight"]
+    expand = br.get("expand")   # (groups, dilation): the parameter has nn.Conv2d's grouped shape, the kernels take the dense weight
+    if expand is not None:
+        w = _WeightExpandFn.apply(w, x.shape[1], int(expand[0]), int(expand[1]))
     w = w if is_hwio(w) else hwio_weight(w)
     bias = br.get("bias")
     ws, bs = float(br.get("wscale", 1.0)), float(br.get("bscale", 1.0))
@@ -908,7 +937,7 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
     if x.dtype != torch.float32:
         raise TypeError("the MI355X conv path computes in fp32")
     if any(br.get("act", 0) > 1 or br.get("wscale", 1.0) != 1.0 or br.get("bscale", 1.0) != 1.0 or br.get("group_norm") is not None
-           or br.get("film") is not None or br.get("dropout2d") is not None for br in branches):
+           or br.get("film") is not None or br.get("dropout2d") is not None or br.get("expand") is not None for br in branches):
         return tuple(_conv_layer_general(x, br, training) for br in branches)
     specs, tensors, params_ref, bns = [], [], [], []
     for br in branches:

@@ -10,8 +10,9 @@ stay channels-last between layers, and attention never materialises the TxT matr
 Activations other than ReLU (LeakyReLU(0.2), SELU, GELU, SiLU) and ``equalized_lr`` -- what the reference's
 configs/vae/defaults_imagenet.yaml trains with -- run unfused around the same kernels (functional._conv_layer_general,
 csrc/activation.hip), and so do GroupNorm / InstanceNorm2d (csrc/groupnorm.hip), FiLM conditioning (`additional_embed`) and
-Dropout2d (csrc/film_dropout2d.hip).  Grouped / dilated convolutions are rejected with ``NotImplementedError`` rather than
-silently run elsewhere.
+Dropout2d (csrc/film_dropout2d.hip).  Grouped and dilated layers keep nn.Conv2d's parameter shape and expand it per call into the
+dense weight the kernels take (csrc/weight_expand.hip: zeros between groups and in the holes of the dilation; up to 7 x 7 taps).
+Module-valued ``up_sample`` / ``down_sample`` are rejected with ``NotImplementedError`` rather than silently run elsewhere.
 """
 import math
 import warnings
@@ -55,8 +56,13 @@ class ConvLayer(nn.Module):
             stride = 2 if isinstance(down_sample, bool) else int(down_sample)
             padding = (kernel_size - 1) // 2
         groups = groups if in_features % groups == 0 and out_features % groups == 0 else 1
-        if groups != 1 or dilation != 1:
-            raise NotImplementedError("grouped / dilated convolutions are not supported on the MI355X path")
+        # grouped / dilated layers keep nn.Conv2d's parameter shape [out, in / groups, k, k]; the forward pass expands it into the
+        # dense weight the kernels take (functional._WeightExpandFn), whose taps may span 7 x 7 at most
+        self.groups, self.dilation = int(groups), (int(dilation), int(dilation))
+        self._expand = (int(groups), int(dilation)) if (groups != 1 or dilation != 1) else None
+        if (kernel_size - 1) * dilation + 1 > 7:
+            raise NotImplementedError(f"a {kernel_size} x {kernel_size} kernel with dilation {dilation} spans more than the 7 x 7 taps "
+                                      "of the MI355X convolution kernels")
         if stride not in (1, 2):
             raise NotImplementedError(f"stride {stride} is not supported on the MI355X path")
         up = 1
@@ -72,11 +78,14 @@ class ConvLayer(nn.Module):
 
         # parameters: same creation order and the same RNG draws as nn.Conv2d.reset_parameters (reference: ConvLayer
         # subclasses nn.Conv2d), written into HWIO memory
-        w0 = torch.empty(out_features, in_features, kernel_size, kernel_size)
+        w0 = torch.empty(out_features, in_features // groups, kernel_size, kernel_size)
         nn.init.kaiming_uniform_(w0, a=math.sqrt(5))
-        self.weight = nn.Parameter(HF.new_hwio(out_features, in_features, kernel_size, kernel_size))
+        if self._expand is None:
+            self.weight = nn.Parameter(HF.new_hwio(out_features, in_features, kernel_size, kernel_size))
+        else:
+            self.weight = nn.Parameter(torch.empty_like(w0))
         if bias:
-            fan_in = in_features * kernel_size * kernel_size
+            fan_in = (in_features // groups) * kernel_size * kernel_size
             bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
             self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
         else:
@@ -92,7 +101,7 @@ class ConvLayer(nn.Module):
             self._normalization = nn.Identity()
         elif "batch" in normalization.lower():
             self._normalization = nn.BatchNorm2d(in_features)  # parameter/buffer container; its forward is never called
-        elif "group" in normalization.lower():     # cnn.py:123 (groups == 1 here: grouped convolutions are not on this path)
+        elif "group" in normalization.lower():     # cnn.py:123
             self._normalization = nn.GroupNorm(div_sqrt(in_features // groups), in_features)
         elif "instance" in normalization.lower():  # cnn.py:124: no affine parameters, no running statistics
             self._normalization = nn.InstanceNorm2d(in_features)
@@ -123,7 +132,7 @@ class ConvLayer(nn.Module):
         # equalized learning rate (cnn.py:114-118,149-158,186-188): N(0, 1/lr_mult) weights, the forward pass multiplies the
         # weight by gain / sqrt(fan_in) * lr_mult and the bias by lr_mult
         self._lr_mult, self._gain = equalized_lr or 1, 1
-        self._conv_scale = self._gain / math.sqrt(in_features * kernel_size * kernel_size) if equalized_lr else 1
+        self._conv_scale = self._gain / math.sqrt((in_features // groups) * kernel_size * kernel_size) if equalized_lr else 1
         self._linear_scale = self._gain / math.sqrt(in_features) if equalized_lr else 1
         if equalized_lr:
             nn.init.normal_(w0, std=1 / self._lr_mult)
@@ -180,6 +189,7 @@ class ConvLayer(nn.Module):
         elif isinstance(self._normalization, nn.InstanceNorm2d):
             gn = (self.in_channels, None, None)
         return dict(group_norm=gn, film=self._film(embed), dropout2d=self._dropout2d(), weight=self.weight, bias=self.bias,
+                    expand=self._expand,
                     gamma=bn.weight if bn is not None else None, beta=bn.bias if bn is not None else None,
                     running_mean=bn.running_mean if bn is not None else None,
                     running_var=bn.running_var if bn is not None else None,

@@ -442,9 +442,47 @@ def test_autoencoder_plugin(A):
     assert set(logs) == {"train/loss/total", "train/loss/recon", "train/loss/prior"}
 
 
+def test_grouped_dilated_cnn_trains_through_the_captured_step(A):
+    """A CNN whose layers are grouped (and one dilated ConvLayer in front of it) through ``HipTrainer``: the grouped parameters sit in
+    the flat buffers with nn.Conv2d's shape, their gradients come back through the weight expansion (csrc/weight_expand.hip), and
+    the captured step equals the eagerly issued one bit for bit over three Adam steps; the input gradient of the dilated layer
+    matches torch's dilated convolution."""
+    import copy
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    enc = A.CNN(1, 16, 16, 1, capacity=4, down_sample=True, residual="add", groups=2)
+    dec = A.CNN(8, 1, 1, 16, capacity=4, up_sample=True, residual="add", groups=2)
+    assert any(m.groups == 2 and m.weight.shape[1] * 2 == m.in_channels for m in enc.modules() if isinstance(m, A.ConvLayer))
+    model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+    twin = copy.deepcopy(model)
+    x, eps = normal((8, 1, 16, 16), 5).cuda(), normal((8, 8, 1, 1), 6).cuda()
+    t_graph = A.HipTrainer(model, batch_shape=(8, 1, 16, 16), use_graph=True)
+    t_eager = A.HipTrainer(twin, batch_shape=(8, 1, 16, 16), use_graph=False)
+    for _ in range(3):
+        a, b = t_graph.step(x, eps), t_eager.step(x, eps)
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    assert torch.equal(t_graph.pflat, t_eager.pflat)
+    assert float((t_graph.pflat - t_graph.pflat.new_tensor(0)).abs().sum()) > 0
+    t_graph.close(); t_eager.close()
+    # a dilated, grouped layer against torch's own convolution
+    layer = A.ConvLayer(6, 6, activation="relu", dilation=2, padding=2, groups=3).cuda()
+    xi = normal((2, 6, 8, 8), 7).cuda().requires_grad_(True)
+    y = layer(xi)
+    y.square().sum().backward()
+    w = layer.weight.detach().clone().requires_grad_(True)
+    xr = xi.detach().clone().requires_grad_(True)
+    yr = F.conv2d(F.relu(xr), w, layer.bias.detach(), padding=2, dilation=2, groups=3)
+    yr.square().sum().backward()
+    assert float((y.detach() - yr.detach()).abs().max() / yr.detach().abs().max()) < 1e-5
+    assert float((xi.grad - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-5
+    assert float((layer.weight.grad - w.grad).abs().max() / w.grad.abs().max()) < 1e-5
+
+
 def test_error_behaviour(A):
     with pytest.raises(NotImplementedError):
-        A.ConvLayer(4, 4, groups=2)                    # grouped / dilated convolutions: not on this path
+        A.ConvLayer(4, 4, kernel_size=5, dilation=2)   # a 9 x 9 footprint: beyond the 7 x 7 taps of the convolution kernels
+    with pytest.raises(NotImplementedError):
+        A.ConvLayer(4, 4, up_sample=torch.nn.Upsample(scale_factor=2))   # module-valued resampling: not on this path
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, activation="tanh")           # not among the reference's activations either (cnn.py:147)
     with pytest.raises(NotImplementedError):

@@ -152,6 +152,13 @@ CONV_CTOR = {
     "film_relu": ("ConvLayer", dict(normalization="batchnorm", activation="relu", additional_embed=5)),
     "film_leaky_eq": ("ConvLayer", dict(down_sample=2, normalization="batchnorm", activation="leaky", equalized_lr=2., additional_embed=6)),
     "film_1x1_gn": ("Conv1x1", dict(normalization="groupnorm", additional_embed=5)),
+    # grouped / dilated layers (cnn.py:66-67,103-104) through the weight expansion of csrc/weight_expand.hip
+    "grp2_relu": ("ConvLayer", dict(normalization="batchnorm", activation="relu", groups=2)),
+    "grp4_down_leaky_eq": ("ConvLayer", dict(down_sample=2, normalization="batchnorm", activation="leaky", equalized_lr=2., groups=4)),
+    "grp2_1x1_gn": ("Conv1x1", dict(normalization="groupnorm", groups=2)),
+    "dil2_relu": ("ConvLayer", dict(normalization="batchnorm", activation="relu", dilation=2, padding=2)),
+    "dil3_grp2_up": ("ConvLayer", dict(up_sample=2, normalization="batchnorm", activation="relu", dilation=3, groups=2)),
+    "dil2_nobias_silu": ("ConvLayer", dict(activation="silu", dilation=2, groups=3, bias=False)),
 }
 
 

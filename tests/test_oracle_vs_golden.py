@@ -36,6 +36,13 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
     # FiLM conditioning: forward(x, embed)
     "film_relu": (False, False, False, True, 3, "relu", None, None), "film_leaky_eq": (True, False, False, True, 3, "leaky", 2.0, None),
     "film_1x1_gn": (False, False, False, False, 1, None, None, "group"),
+    # (..., activation, equalized_lr, normalisation, groups, dilation, padding): grouped / dilated layers (cnn.py:66-67,103-104)
+    "grp2_relu": (False, False, False, True, 3, "relu", None, None, 2, 1, None),
+    "grp4_down_leaky_eq": (True, False, False, True, 3, "leaky", 2.0, None, 4, 1, None),
+    "grp2_1x1_gn": (False, False, False, False, 1, None, None, "group", 2, 1, None),
+    "dil2_relu": (False, False, False, True, 3, "relu", None, None, 1, 2, 2),
+    "dil3_grp2_up": (False, True, False, True, 3, "relu", None, None, 2, 3, None),
+    "dil2_nobias_silu": (False, False, False, False, 3, "silu", None, None, 3, 2, None),
 }
 
 
@@ -43,7 +50,8 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
 def test_conv_layer(name):
     g = group(load_golden("convlayer.npz"), name)
     down, up, relu, norm, ks, *opt = CONV_GEOM[name]
-    act, eq, gn = (list(opt) + [None, None, None])[:3]
+    defaults = [None, None, None, 1, 1, None]
+    act, eq, gn, groups, dil, padding = list(opt) + defaults[len(opt):]
     p = {k[len("param/"):]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("param/")}
     if norm:
         c = g["x"].shape[1]
@@ -51,7 +59,8 @@ def test_conv_layer(name):
         p["_normalization.running_var"] = torch.ones(c)
     x = g["x"].clone().requires_grad_(True)
     emb = g["embed"].clone().requires_grad_(True) if "embed" in g else None
-    y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks, act=act, equalized_lr=eq, other_norm=gn, embed=emb)
+    y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks, act=act, equalized_lr=eq, other_norm=gn, embed=emb,
+                     groups=groups, dilation=dil, padding=padding)
     y.backward(g["gy"])
     if emb is not None:
         assert rel_err(emb.grad, g["gembed"]) < TIGHT
