@@ -277,7 +277,11 @@ class ConvBlock(nn.Module):
             out, sk = HF.conv_layers(x, [first.branch(embed=embed), self.skip.branch(out_stats=False)], training=self.training)
         else:
             out = first(x, embed)
-        fuse_add = self.residual == "add" and len(layers) > 1
+        # the skip is added inside the last layer's convolution epilogue -- unless something sits between that convolution and the
+        # sum in the reference's order `dropout(down(conv(...))) + skip` (cnn.py:183-192,331-335): an active Dropout2d
+        last_layer = layers[-1]
+        plain_tail = not (isinstance(last_layer, ConvLayer) and last_layer.training and isinstance(last_layer._dropout, nn.Dropout2d))
+        fuse_add = self.residual == "add" and len(layers) > 1 and plain_tail
         for i, layer in enumerate(layers[1:], start=1):
             last = i == len(layers) - 1
             out = layer(out, embed, residual=sk if (fuse_add and last) else None)

@@ -273,6 +273,27 @@ def test_conv_layer_dropout2d_matches_torch_given_its_own_mask(A):
     assert torch.equal(layer(x), plain(x))
 
 
+def test_conv_block_dropout_sits_before_the_residual_sum(A):
+    """`ConvBlock(residual="add", dropout=p)` without attention: the reference sums `dropout(conv(...)) + skip(x)`
+    (cnn.py:183-192,331-335), so a (sample, channel) map the last layer's Dropout2d removed shows the skip branch alone -- not zero,
+    which is what fusing the sum into the convolution in front of the dropout (rounds 1-2's shortcut for this case) gave."""
+    torch.manual_seed(5)
+    block = A.ConvBlock(8, 8, n_attn_heads=0, n_layers=2, residual="add", dropout=0.4).cuda().train()
+    x = normal((32, 8, 8, 8), 3).cuda()
+    out = block(x).detach()
+    skip = block.skip(x).detach()                 # training-mode BatchNorm statistics depend on x only: the same branch value
+    diff = (out - skip).abs().sum((2, 3))
+    dropped = diff == 0
+    rate = float(dropped.float().mean())
+    assert 0.25 < rate < 0.55, rate               # the last layer's maps vanish at about p; the sum does not
+    assert float(out.abs().sum((2, 3))[dropped].min()) > 0
+    block.eval()
+    a = block(x)
+    plain = A.ConvBlock(8, 8, n_attn_heads=0, n_layers=2, residual="add").cuda().eval()
+    plain.load_state_dict(block.state_dict())
+    assert torch.equal(a, plain(x))
+
+
 def test_cnn_leaky_equalized_lr_vs_reference_golden(A):
     """a whole encoder / decoder with ``activation="leaky", equalized_lr=1.`` (the reference's
     configs/vae/defaults_imagenet.yaml:26-27) against the reference's own CNN: outputs, input gradient, every parameter gradient
