@@ -102,6 +102,10 @@ CONV_CASES = [
     ("dil2_relu", "ConvLayer", 4, 8, 8, dict(normalization="batchnorm", activation="relu", dilation=2, padding=2)),
     ("dil3_grp2_up", "ConvLayer", 8, 4, 4, dict(up_sample=2, normalization="batchnorm", activation="relu", dilation=3, groups=2)),
     ("dil2_nobias_silu", "ConvLayer", 6, 6, 8, dict(activation="silu", dilation=2, groups=3, bias=False)),
+    # module-valued resampling (cnn.py:97,106): the user's module is applied as given, up between activation and convolution,
+    # down behind the convolution
+    ("mod_up_bilinear", "ConvLayer", 4, 8, 4, dict(up_sample=torch.nn.Upsample(scale_factor=2, mode="bilinear"), normalization="batchnorm", activation="relu")),
+    ("mod_down_avgpool", "ConvLayer", 4, 8, 8, dict(down_sample=torch.nn.AvgPool2d(2), normalization="batchnorm", activation="leaky")),
 ]
 
 

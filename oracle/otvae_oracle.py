@@ -106,7 +106,7 @@ _ACTIVATIONS = {  # cnn.py:128-147 (the reference tests the names in this order:
 def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: bool, relu: bool,
                norm: bool, ksize: int = 3, training: bool = True, act: Optional[str] = None,
                equalized_lr: Optional[float] = None, other_norm: Optional[str] = None, embed: Optional[Tensor] = None,
-               groups: int = 1, dilation: int = 1, padding: Optional[int] = None) -> Tensor:
+               groups: int = 1, dilation: int = 1, padding: Optional[int] = None, up_module=None, down_module=None) -> Tensor:
     """``ConvLayer.forward`` (networks/cnn.py:183-192): BN -> act -> nearest x2 up -> conv (stride-2 4x4 when
     down-sampling, cnn.py:98-101).  ``p[prefix+'_normalization.running_*']`` are updated in place like
     nn.BatchNorm2d does in training mode.  ``act``: one of leaky / relu / selu / gelu / silu (overrides ``relu``);
@@ -133,6 +133,8 @@ def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: 
         bi = F.linear(e, p[prefix + "_embed_proj_bias.weight"] * ls * lr, p[prefix + "_embed_proj_bias.bias"] * lr)
         out = out * sc[..., None, None] + bi[..., None, None]
     out = fn(out)
+    if up_module is not None:   # a user-supplied nn.Module instead of the built-in nearest up-sampling (cnn.py:106,187)
+        out = up_module(out)
     if up:
         out = F.interpolate(out, scale_factor=2.0, mode="nearest")
     if down:
@@ -148,7 +150,8 @@ def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: 
         bias = bias * equalized_lr if bias is not None else None
     if padding is not None and not down:
         pad = padding
-    return F.conv2d(out, w, bias, stride=stride, padding=pad, dilation=dilation, groups=groups)
+    out = F.conv2d(out, w, bias, stride=stride, padding=pad, dilation=dilation, groups=groups)
+    return down_module(out) if down_module is not None else out   # a user-supplied down-sampling module (cnn.py:97,190)
 
 
 def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:

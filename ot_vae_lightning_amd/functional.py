@@ -907,6 +907,9 @@ def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
         a = _FilmFn.apply(a, film[0], film[1])
         if kind != 0:
             a = _BnActFn.apply(a, None, None, None, kind, (None, None))
+    up_module, down_module = br.get("up_module"), br.get("down_module")
+    if up_module is not None:   # a user-supplied module between the activation and the convolution (cnn.py:187)
+        a = as_nhwc(up_module(a))
     w = br["weight"]
     expand = br.get("expand")   # (groups, dilation): the parameter has nn.Conv2d's grouped shape, the kernels take the dense weight
     if expand is not None:
@@ -919,9 +922,13 @@ def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
     if bias is not None and bs != 1.0:
         bias = _ScaleFn.apply(bias, bs)
     drop = br.get("dropout2d")  # (p, key): nn.Dropout2d behind the convolution, training mode only
+    if down_module is not None and br.get("residual") is not None:
+        raise ValueError("a residual cannot be fused in front of a down-sampling module")
     plain = dict(weight=w, bias=bias, residual=br.get("residual"), stride=br["stride"], pad=br["pad"], up=br["up"], relu=False,
-                 out_stats=br.get("out_stats", False) and drop is None)
+                 out_stats=br.get("out_stats", False) and drop is None and down_module is None)
     y = conv_layers(a, [plain], training=training)[0]
+    if down_module is not None:  # behind the convolution, in front of the dropout (cnn.py:190-191)
+        y = as_nhwc(down_module(y))
     if drop is not None and training:
         y = dropout2d(y, drop[0], drop[1], stream_id=int(drop[2]))
     return y
@@ -937,7 +944,8 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
     if x.dtype != torch.float32:
         raise TypeError("the MI355X conv path computes in fp32")
     if any(br.get("act", 0) > 1 or br.get("wscale", 1.0) != 1.0 or br.get("bscale", 1.0) != 1.0 or br.get("group_norm") is not None
-           or br.get("film") is not None or br.get("dropout2d") is not None or br.get("expand") is not None for br in branches):
+           or br.get("film") is not None or br.get("dropout2d") is not None or br.get("expand") is not None
+           or br.get("up_module") is not None or br.get("down_module") is not None for br in branches):
         return tuple(_conv_layer_general(x, br, training) for br in branches)
     specs, tensors, params_ref, bns = [], [], [], []
     for br in branches:

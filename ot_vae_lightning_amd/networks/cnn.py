@@ -12,7 +12,7 @@ configs/vae/defaults_imagenet.yaml trains with -- run unfused around the same ke
 csrc/activation.hip), and so do GroupNorm / InstanceNorm2d (csrc/groupnorm.hip), FiLM conditioning (`additional_embed`) and
 Dropout2d (csrc/film_dropout2d.hip).  Grouped and dilated layers keep nn.Conv2d's parameter shape and expand it per call into the
 dense weight the kernels take (csrc/weight_expand.hip: zeros between groups and in the holes of the dilation; up to 7 x 7 taps).
-Module-valued ``up_sample`` / ``down_sample`` are rejected with ``NotImplementedError`` rather than silently run elsewhere.
+A module-valued ``up_sample`` / ``down_sample`` (the user's own plug-in) is called as given, around the layer's kernels.
 """
 import math
 import warnings
@@ -45,8 +45,14 @@ class ConvLayer(nn.Module):
                  activation: Optional[str] = None, equalized_lr: Optional[float] = None, dropout: float = 0.,
                  kernel_size=3, stride=1, padding=1, dilation=1, groups: int = 1, bias: bool = True) -> None:
         super().__init__()
-        if isinstance(down_sample, nn.Module) or isinstance(up_sample, nn.Module):
-            raise NotImplementedError("module-valued down_sample/up_sample are not supported on the MI355X path")
+        # a user-supplied resampling MODULE is the user's plug-in: it is called as given (cnn.py:97,106), around the layer's own
+        # kernels (functional._conv_layer_general); only the reference's built-in nearest x2 / strided variants are fused
+        down_module = down_sample if isinstance(down_sample, nn.Module) else None
+        up_module = up_sample if isinstance(up_sample, nn.Module) else None
+        if down_module is not None:
+            down_sample = False
+        if up_module is not None:
+            up_sample = False
         kernel_size = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
         stride = stride if isinstance(stride, int) else stride[0]
         padding = padding if isinstance(padding, int) else padding[0]
@@ -90,8 +96,9 @@ class ConvLayer(nn.Module):
             self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
         else:
             self.register_parameter("bias", None)
-        self._down_sample = nn.Identity()
-        self._up_sample = nn.Upsample(scale_factor=up) if up > 1 else nn.Identity()
+        self._down_sample = down_module if down_module is not None else nn.Identity()
+        self._up_sample = up_module if up_module is not None else (nn.Upsample(scale_factor=up) if up > 1 else nn.Identity())
+        self._resample_modules = (up_module is not None, down_module is not None)
         self._dropout = nn.Dropout2d(dropout) if dropout and dropout > 0 else nn.Identity()   # cnn.py:112 (container: p)
         # FiLM conditioning (cnn.py:114-116): two Linear projections of the (activated) embedding, created in the reference's order
         self._embed_proj_scale = nn.Linear(additional_embed, in_features) if bool(additional_embed) else None
@@ -190,6 +197,8 @@ class ConvLayer(nn.Module):
             gn = (self.in_channels, None, None)
         return dict(group_norm=gn, film=self._film(embed), dropout2d=self._dropout2d(), weight=self.weight, bias=self.bias,
                     expand=self._expand,
+                    up_module=self._up_sample if self._resample_modules[0] else None,
+                    down_module=self._down_sample if self._resample_modules[1] else None,
                     gamma=bn.weight if bn is not None else None, beta=bn.bias if bn is not None else None,
                     running_mean=bn.running_mean if bn is not None else None,
                     running_var=bn.running_var if bn is not None else None,
@@ -278,9 +287,10 @@ class ConvBlock(nn.Module):
         else:
             out = first(x, embed)
         # the skip is added inside the last layer's convolution epilogue -- unless something sits between that convolution and the
-        # sum in the reference's order `dropout(down(conv(...))) + skip` (cnn.py:183-192,331-335): an active Dropout2d
+        # sum in the reference's order `dropout(down(conv(...))) + skip` (cnn.py:183-192,331-335): an active Dropout2d or a down-sampling module
         last_layer = layers[-1]
-        plain_tail = not (isinstance(last_layer, ConvLayer) and last_layer.training and isinstance(last_layer._dropout, nn.Dropout2d))
+        plain_tail = not (isinstance(last_layer, ConvLayer) and ((last_layer.training and isinstance(last_layer._dropout, nn.Dropout2d))
+                                                                  or last_layer._resample_modules[1]))
         fuse_add = self.residual == "add" and len(layers) > 1 and plain_tail
         for i, layer in enumerate(layers[1:], start=1):
             last = i == len(layers) - 1

@@ -482,8 +482,6 @@ def test_error_behaviour(A):
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, kernel_size=5, dilation=2)   # a 9 x 9 footprint: beyond the 7 x 7 taps of the convolution kernels
     with pytest.raises(NotImplementedError):
-        A.ConvLayer(4, 4, up_sample=torch.nn.Upsample(scale_factor=2))   # module-valued resampling: not on this path
-    with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, activation="tanh")           # not among the reference's activations either (cnn.py:147)
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, normalization="whatever")

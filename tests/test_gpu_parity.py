@@ -159,6 +159,9 @@ CONV_CTOR = {
     "dil2_relu": ("ConvLayer", dict(normalization="batchnorm", activation="relu", dilation=2, padding=2)),
     "dil3_grp2_up": ("ConvLayer", dict(up_sample=2, normalization="batchnorm", activation="relu", dilation=3, groups=2)),
     "dil2_nobias_silu": ("ConvLayer", dict(activation="silu", dilation=2, groups=3, bias=False)),
+    # user-supplied resampling modules (cnn.py:97,106) around the layer's kernels
+    "mod_up_bilinear": ("ConvLayer", dict(up_sample=torch.nn.Upsample(scale_factor=2, mode="bilinear"), normalization="batchnorm", activation="relu")),
+    "mod_down_avgpool": ("ConvLayer", dict(down_sample=torch.nn.AvgPool2d(2), normalization="batchnorm", activation="leaky")),
 }
 
 

@@ -43,6 +43,9 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
     "dil2_relu": (False, False, False, True, 3, "relu", None, None, 1, 2, 2),
     "dil3_grp2_up": (False, True, False, True, 3, "relu", None, None, 2, 3, None),
     "dil2_nobias_silu": (False, False, False, False, 3, "silu", None, None, 3, 2, None),
+    # (..., up module, down module): user-supplied resampling modules
+    "mod_up_bilinear": (False, False, False, True, 3, "relu", None, None, 1, 1, None, torch.nn.Upsample(scale_factor=2, mode="bilinear"), None),
+    "mod_down_avgpool": (False, False, False, True, 3, "leaky", None, None, 1, 1, None, None, torch.nn.AvgPool2d(2)),
 }
 
 
@@ -50,8 +53,8 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
 def test_conv_layer(name):
     g = group(load_golden("convlayer.npz"), name)
     down, up, relu, norm, ks, *opt = CONV_GEOM[name]
-    defaults = [None, None, None, 1, 1, None]
-    act, eq, gn, groups, dil, padding = list(opt) + defaults[len(opt):]
+    defaults = [None, None, None, 1, 1, None, None, None]
+    act, eq, gn, groups, dil, padding, up_mod, down_mod = list(opt) + defaults[len(opt):]
     p = {k[len("param/"):]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("param/")}
     if norm:
         c = g["x"].shape[1]
@@ -60,7 +63,7 @@ def test_conv_layer(name):
     x = g["x"].clone().requires_grad_(True)
     emb = g["embed"].clone().requires_grad_(True) if "embed" in g else None
     y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks, act=act, equalized_lr=eq, other_norm=gn, embed=emb,
-                     groups=groups, dilation=dil, padding=padding)
+                     groups=groups, dilation=dil, padding=padding, up_module=up_mod, down_module=down_mod)
     y.backward(g["gy"])
     if emb is not None:
         assert rel_err(emb.grad, g["gembed"]) < TIGHT
