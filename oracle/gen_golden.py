@@ -217,6 +217,60 @@ def gen_cnn_small_opts():
     save("cnn_small_opts.npz", out)
 
 
+CNN_VARIANTS = {
+    # name: (ctor args, ctor kwargs, input shape, embed width | None) -- corners of the CNN / ConvBlock constructors that no config uses
+    "cat_gn_silu_3layers": ((3, 12, 8, 2), dict(capacity=4, down_sample=True, residual="cat", n_layers=3, normalization="groupnorm",
+                                                 activation="silu"), (3, 3, 8, 8), None),
+    "cat_gn_silu_3layers_cap8": ((3, 16, 8, 2), dict(capacity=8, down_sample=True, residual="cat", n_layers=3, normalization="groupnorm",
+                                                      activation="silu"), (3, 3, 8, 8), None),
+    "add_film_gelu_eq_up": ((6, 3, 2, 8), dict(capacity=4, up_sample=True, residual="add", additional_embed=5, activation="gelu",
+                                                equalized_lr=1.0), (3, 6, 2, 2), 5),
+    "intermediate_nonorm_selu": ((4, 8), dict(intermediate_features=[6, 10], residual=None, normalization=None, activation="selu"),
+                                 (3, 4, 4, 4), None),
+    "intermediate_nonorm_selu_res": ((4, 8, 4, 4), dict(intermediate_features=[6, 10], residual=None, normalization=None, activation="selu"),
+                                     (3, 4, 4, 4), None),
+    "add_noattn_dilated_res": ((4, 4, 8, 8), dict(intermediate_features=[8], residual="add", max_attn_res=0, dilation=2, padding=2),
+                               (3, 4, 8, 8), None),
+    "grouped_in_leaky_nobias": ((2, 8, 8, 2), dict(capacity=4, down_sample=True, residual="add", groups=2, normalization="instancenorm",
+                                                    activation="leaky", bias=False), (3, 2, 8, 8), None),
+    "cat_1layer_k1_noattn_up": ((8, 2, 2, 8), dict(capacity=4, up_sample=True, residual="cat", max_attn_res=1, n_layers=1, kernel_size=1,
+                                                    padding=0), (3, 8, 2, 2), None),
+    "add_noattn_dilated": ((4, 4), dict(intermediate_features=[8], residual="add", max_attn_res=0, dilation=2, padding=2), (3, 4, 8, 8), None),
+}
+
+
+def gen_cnn_variants():
+    """Whole CNNs at corners of the constructor space (residual "cat" with three layers per block and GroupNorm, FiLM embeddings with
+    equalized_lr on the up-sampling path, `intermediate_features`, grouped InstanceNorm blocks without biases, one-layer 1x1 blocks,
+    dilated blocks without attention): output, input / embedding gradients, every parameter gradient and buffer."""
+    cnn = R.ref("networks.cnn")
+    out = {}
+    for name, (args, kw, xshape, ew) in CNN_VARIANTS.items():
+        try:
+            net = cnn.CNN(*args, **kw)
+        except Exception as e:  # noqa: BLE001 -- a constructor corner the reference itself rejects: the error type is the golden
+            out[f"{name}/error"] = np.frombuffer(type(e).__name__.encode(), dtype=np.uint8)
+            print(f"  {name}: the reference raises {type(e).__name__}: {e}")
+            continue
+        net.train()
+        fill_state_dict(net.state_dict())
+        x = det_input(xshape, 0.35).requires_grad_(True)
+        emb = det_input((xshape[0], ew), 0.8, 0.9).requires_grad_(True) if ew else None
+        y = net(x, emb) if emb is not None else net(x)
+        g = det_input(tuple(y.shape), 1.3, 0.6)
+        y.backward(g)
+        out[f"{name}/x"], out[f"{name}/y"], out[f"{name}/gy"], out[f"{name}/gx"] = npy(x), npy(y), npy(g), npy(x.grad)
+        if emb is not None:
+            out[f"{name}/embed"], out[f"{name}/gembed"] = npy(emb), npy(emb.grad)
+        for k, p in net.named_parameters():
+            out[f"{name}/grad/{k}"] = npy(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)
+        for k, b in net.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                out[f"{name}/buf/{k}"] = npy(b)
+        print(f"  {name}: y {tuple(y.shape)}, {sum(p.numel() for p in net.parameters())} parameters")
+    save("cnn_variants.npz", out)
+
+
 # ------------------------------------------------------------------------------------------------ G4
 class _FixedEps:
     """Makes Normal.rsample draw a recorded eps (prior/gaussian.py:93 uses the global RNG)."""
@@ -1305,6 +1359,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants"]
     for w in which:
         globals()["gen_" + w]()

@@ -276,6 +276,57 @@ def test_conv_layer_dropout2d_matches_torch_given_its_own_mask(A):
     assert torch.equal(layer(x), plain(x))
 
 
+CNN_VARIANTS = {   # oracle/gen_golden.py: CNN_VARIANTS (constructor corners no config of the reference uses)
+    "cat_gn_silu_3layers": ((3, 12, 8, 2), dict(capacity=4, down_sample=True, residual="cat", n_layers=3, normalization="groupnorm", activation="silu")),
+    "cat_gn_silu_3layers_cap8": ((3, 16, 8, 2), dict(capacity=8, down_sample=True, residual="cat", n_layers=3, normalization="groupnorm", activation="silu")),
+    "add_film_gelu_eq_up": ((6, 3, 2, 8), dict(capacity=4, up_sample=True, residual="add", additional_embed=5, activation="gelu", equalized_lr=1.0)),
+    "intermediate_nonorm_selu": ((4, 8), dict(intermediate_features=[6, 10], residual=None, normalization=None, activation="selu")),
+    "intermediate_nonorm_selu_res": ((4, 8, 4, 4), dict(intermediate_features=[6, 10], residual=None, normalization=None, activation="selu")),
+    "add_noattn_dilated_res": ((4, 4, 8, 8), dict(intermediate_features=[8], residual="add", max_attn_res=0, dilation=2, padding=2)),
+    "grouped_in_leaky_nobias": ((2, 8, 8, 2), dict(capacity=4, down_sample=True, residual="add", groups=2, normalization="instancenorm", activation="leaky", bias=False)),
+    "cat_1layer_k1_noattn_up": ((8, 2, 2, 8), dict(capacity=4, up_sample=True, residual="cat", max_attn_res=1, n_layers=1, kernel_size=1, padding=0)),
+    "add_noattn_dilated": ((4, 4), dict(intermediate_features=[8], residual="add", max_attn_res=0, dilation=2, padding=2)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CNN_VARIANTS))
+def test_cnn_constructor_corners_vs_reference_golden(A, name):
+    """Whole CNNs at corners of the constructor space against the reference's own class (cnn_variants.npz): residual "cat" with
+    three layers per block under GroupNorm + SiLU, FiLM embeddings with equalized_lr on the up-sampling path, `intermediate_features`,
+    grouped InstanceNorm blocks without biases, one-layer 1x1 blocks, dilated blocks without attention; where the reference's
+    constructor raises, this one raises the same exception type."""
+    g = group(load_golden("cnn_variants.npz"), name)
+    args, kw = CNN_VARIANTS[name]
+    if "error" in g:
+        want = bytes(g["error"].numpy().astype("uint8")).decode()
+        with pytest.raises(Exception) as info:
+            A.CNN(*args, **kw)
+        assert type(info.value).__name__ == want, (type(info.value).__name__, want)
+        return
+    net = A.CNN(*args, **kw)
+    fill_state_dict(net.state_dict())
+    net = net.cuda().train()
+    x = g["x"].cuda().requires_grad_(True)
+    emb = g["embed"].cuda().requires_grad_(True) if "embed" in g else None
+    y = net(x, emb) if emb is not None else net(x)
+    y.backward(g["gy"].cuda())
+    rep = Report(f"CNN corner `{name}` vs reference golden")
+    rep.check("y", y, g["y"])
+    rep.check("gx", x.grad, g["gx"], tol=3e-4)
+    if emb is not None:
+        rep.check("gembed", emb.grad, g["gembed"], tol=3e-4)
+    gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith("grad/"))
+    names = {k for k, _ in net.named_parameters()}
+    assert names == {k[5:] for k in g if k.startswith("grad/")}, "parameter names differ from the reference's"
+    for k, p in net.named_parameters():
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        rep.check(f"grad/{k}", got, g[f"grad/{k}"], tol=5e-4, floor=1e-2 * gscale)
+    for k, b in net.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            rep.check(f"buf/{k}", b, g[f"buf/{k}"])
+    rep.finish()
+
+
 def test_conv_block_dropout_sits_before_the_residual_sum(A):
     """`ConvBlock(residual="add", dropout=p)` without attention: the reference sums `dropout(conv(...)) + skip(x)`
     (cnn.py:183-192,331-335), so a (sample, channel) map the last layer's Dropout2d removed shows the skip branch alone -- not zero,
