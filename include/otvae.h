@@ -258,8 +258,9 @@ int otvae_gaussian_prior_cond_bwd(const float* h, const float* eps, const float*
                                   float* g_prior_mean, float* g_prior_log_std, void* stream);
 
 /* ---- VAE.nelbo reduction (model/vae.py:158-176) ----------------------------------------------------------- */
-/* out[3] = {total, recon, prior}: recon = mean((pred-target)^2), prior = mean_B(prior_loss)/chw.
- * ws: double[otvae_nelbo_ws()] scratch. */
+/* out[3] = {total, recon, prior}: recon = mean((pred-target)^2) over numel entries, prior = mean(prior_loss[0..B))/chw.
+ * B = the number of entries of prior_loss: one per latent the prior saw = expansion * batch (model/vae.py:165-169,
+ * utils/__init__.py:154-175), independent of numel.  ws: double[otvae_nelbo_ws()] scratch. */
 int otvae_nelbo_ws(void);
 int otvae_nelbo_fwd(const float* pred, const float* target, int64_t numel, const float* prior_loss, int B,
                     float chw, double* ws, float* out, void* stream);

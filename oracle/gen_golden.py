@@ -298,6 +298,35 @@ def _mnist_vae(residual="add", loss_coeff=0.1):
     return m
 
 
+def gen_nelbo_expansion():
+    """`VAE(expansion=3)` (model/vae.py:158-229; utils.replicate_batch / mean_replicated_batch, utils/__init__.py:154-175): the encoder
+    output is replicated three times before the prior (three noise draws per image), the decoder runs on 3B latents, the reconstruction
+    loss sees the mean over the replicas, `preds` / `latents` are the first replica.  Small network (capacity 4, 16x16, B = 8)."""
+    cnn, pg, vae = R.ref("networks.cnn"), R.ref("prior.gaussian"), R.ref("model.vae")
+    enc = cnn.CNN(1, 16, 16, 1, capacity=4, down_sample=True, residual="add")
+    dec = cnn.CNN(8, 1, 1, 16, capacity=4, up_sample=True, residual="add")
+    fill_state_dict(enc.state_dict())
+    fill_state_dict(dec.state_dict())
+    m = vae.VAE(metrics=R._MetricCollection(), encoder=enc, decoder=dec, prior=pg.GaussianPrior(loss_coeff=0.1), expansion=3)
+    m.train()
+    B = 8
+    x = det_input((B, 1, 16, 16), 0.4)
+    eps = normal((3 * B, 8, 1, 1), seed=47)
+    with _FixedEps(eps):
+        loss, logs, art = m.nelbo({"samples": x, "target": x, "kwargs": {}}, 0)
+    loss.backward()
+    out = {"x": npy(x), "eps": npy(eps)}
+    out["loss"] = npy(torch.stack([logs["train/loss/total"], logs["train/loss/recon"], logs["train/loss/prior"]]))
+    out["preds"], out["latents"], out["preds_mean"] = npy(art["preds"]), npy(art["latents"]), npy(art["preds_mean"])
+    for pre, net in (("encoder.", m.encoder), ("decoder.", m.decoder)):
+        for k, p in net.named_parameters():
+            out[f"grad/{pre}{k}"] = npy(p.grad)
+        for k, b in net.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                out[f"buf/{pre}{k}"] = npy(b)
+    save("nelbo_expansion.npz", out)
+
+
 def gen_nelbo():
     out = {}
     for residual in ("add", None):
@@ -1359,6 +1388,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion"]
     for w in which:
         globals()["gen_" + w]()

@@ -251,15 +251,21 @@ def gaussian_prior_encode_options(x: Tensor, eps: Tensor, loss_coeff: float = 1.
 
 
 def vae_nelbo(x: Tensor, eps: Tensor, enc: Dict[str, Tensor], dec: Dict[str, Tensor], enc_arch, dec_arch,
-              loss_coeff: float = 1.0, step: int = 0, annealing_steps: int = 0, training: bool = True):
-    """``VAE.nelbo`` with expansion=1 (model/vae.py:165-189): loss = mse(decode(z), x) + mean_B(prior)/(C*H*W)."""
+              loss_coeff: float = 1.0, step: int = 0, annealing_steps: int = 0, training: bool = True, expansion: int = 1):
+    """``VAE.nelbo`` (model/vae.py:165-189): loss = mse(mean over replicas of decode(z), x) + mean(prior)/(C*H*W).  ``expansion`` = n
+    > 1: the encoder output is replicated n times, replica-major (utils.replicate_batch, utils/__init__.py:141-164: expand on a new
+    leading axis, then fold it into the batch), ``eps`` holds n*B draws, the prior term is the mean over all n*B entries, the
+    reconstruction loss sees the mean over the n replicas; `preds` / `latents` are the first replica's."""
+    b = x.shape[0]
     h = cnn_forward(x, enc, enc_arch, training=training)
-    z, prior = gaussian_prior_encode(h, eps, loss_coeff, step, annealing_steps)
-    preds = cnn_forward(z, dec, dec_arch, training=training)
+    hx = h if expansion <= 1 else h.unsqueeze(0).expand(expansion, *h.shape).reshape(expansion * b, *h.shape[1:])
+    z, prior = gaussian_prior_encode(hx, eps, loss_coeff, step, annealing_steps)
+    preds_all = cnn_forward(z, dec, dec_arch, training=training)
+    preds_mean = preds_all if expansion <= 1 else preds_all.reshape(expansion, b, *preds_all.shape[1:]).mean(0)
     prior_loss = prior.mean() / float(x[0].numel())
-    recon_loss = F.mse_loss(preds, x)
-    return dict(loss=recon_loss + prior_loss, recon=recon_loss, prior=prior_loss, preds=preds, latents=z,
-                enc_out=h)
+    recon_loss = F.mse_loss(preds_mean, x)
+    return dict(loss=recon_loss + prior_loss, recon=recon_loss, prior=prior_loss, preds=preds_all[:b], latents=z[:b],
+                preds_mean=preds_mean, enc_out=h)
 
 
 def adam_step(params: Sequence[Tensor], grads: Sequence[Tensor], exp_avg: Sequence[Tensor],

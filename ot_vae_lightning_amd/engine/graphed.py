@@ -82,7 +82,8 @@ class GraphedNelbo:
             old.graph_f = old.graph_b = None
             if tuple(engine.x.shape) != tuple(samples.shape):
                 engine.x = torch.zeros_like(samples)
-                engine.eps = torch.zeros((samples.shape[0], *model.latent_size), device=samples.device, dtype=torch.float32)
+                engine.eps = torch.zeros((samples.shape[0] * max(1, int(getattr(model, "expansion", 1) or 1)), *model.latent_size),
+                                         device=samples.device, dtype=torch.float32)
         else:
             # the engine's layout (flat parameter / gradient buffers, gradient slots, resident transposed weights, static batch);
             # its optimizer is never run

@@ -163,7 +163,8 @@ class HipTrainer:
         self._graph_b2 = None
         # static I/O
         self.x = torch.zeros(batch_shape, device=dev, dtype=torch.float32)
-        lat = (batch_shape[0], *model.latent_size)
+        # one noise draw per latent the prior sees: `expansion` replicas of every image (VAE(expansion=n), model/vae.py:158-167)
+        lat = (batch_shape[0] * max(1, int(getattr(model, "expansion", 1) or 1)), *model.latent_size)
         self.eps = torch.zeros(lat, device=dev, dtype=torch.float32)
         # further per-batch keyword tensors of ``model.nelbo`` (e.g. ``labels`` of a conditional model): resident copies of the
         # examples given here, refreshed by ``step(..., name=tensor)``

@@ -118,7 +118,15 @@ class VAE(VisionModule):
         # of the encoder with the encoder's own backward): the ONE tensor through which the loss depends on the encoder
         self._last_cut = encodings if encodings.requires_grad else None
         if expand:
+            # an explicit noise tensor (`eps`, this package's extension of GaussianPrior.forward) holds one draw per REPLICATED latent --
+            # the reference draws inside the prior, after the replication -- so it is not replicated with the other keywords
+            eps = kwargs.pop("eps", None) if self.expansion and self.expansion > 1 else None
             encodings, kwargs = self._expand(encodings), self._expand(kwargs)
+            if eps is not None:
+                if eps.shape[0] != encodings.shape[0]:
+                    raise ValueError(f"`eps` must hold one draw per replicated latent: {encodings.shape[0]} = expansion * batch, "
+                                     f"got {eps.shape[0]}")
+                kwargs["eps"] = eps
         if self.prior is None:
             results = encodings, torch.zeros(encodings.size(0), device=encodings.device, dtype=encodings.dtype), {}
         else:
@@ -129,7 +137,7 @@ class VAE(VisionModule):
     @VisionModule.postprocess
     def decode(self, latents: Tensor, expand_kwargs: bool = False, **kwargs) -> Tensor:
         if expand_kwargs:
-            kwargs = self._expand(kwargs)
+            kwargs = self._expand({k: v for k, v in kwargs.items() if k != "eps"})   # (the prior's noise is no decoder input)
         with self._filter(self._decode_func, kwargs.keys()) as decode:
             return decode(latents, **kwargs)
 

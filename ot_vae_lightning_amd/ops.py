@@ -262,43 +262,48 @@ def _nelbo_fwd(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor], chw: 
 
 def _nelbo_fwd_launch(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor], chw: float):
     lib = _lib.load()
-    b, numel = pred.shape[0], pred.numel()
+    numel = pred.numel()
+    # the prior term is a mean over ITS entries: one per latent the prior saw = expansion * batch (model/vae.py:165-169), which is
+    # the batch of `pred` (the mean over the replicas) only when expansion = 1
+    n_prior = prior_loss.numel() if prior_loss is not None else pred.shape[0]
+    if prior_loss is not None:
+        prior_loss = prior_loss.contiguous()
     ws = torch.empty(lib.otvae_nelbo_ws(), device=pred.device, dtype=torch.float64)
     out = torch.empty(3, device=pred.device, dtype=torch.float32)
-    check(lib.otvae_nelbo_fwd(ptr(pred), ptr(target), numel, ptr(prior_loss), b, float(chw), ptr(ws), ptr(out), stream()),
+    check(lib.otvae_nelbo_fwd(ptr(pred), ptr(target), numel, ptr(prior_loss), n_prior, float(chw), ptr(ws), ptr(out), stream()),
           "otvae_nelbo_fwd")
     return out
 
 
-def _nelbo_bwd(gout: Tensor, pred: Tensor, target: Tensor, has_prior: bool, chw: float):
+def _nelbo_bwd(gout: Tensor, pred: Tensor, target: Tensor, n_prior: int, chw: float):
     lib = _lib.load()
-    b, numel = pred.shape[0], pred.numel()
+    numel = pred.numel()
     gout = gout.contiguous()
     gpred = torch.empty_strided(pred.shape, pred.stride(), device=pred.device, dtype=pred.dtype)
-    gprior = torch.empty(b if has_prior else 0, device=pred.device, dtype=torch.float32)
-    check(lib.otvae_nelbo_bwd(ptr(pred), ptr(target), numel, b, float(chw), ptr(gout), ptr(gpred), ptr(gprior) if has_prior else None,
-                              stream()), "otvae_nelbo_bwd")
+    gprior = torch.empty(n_prior, device=pred.device, dtype=torch.float32)
+    check(lib.otvae_nelbo_bwd(ptr(pred), ptr(target), numel, max(n_prior, 1), float(chw), ptr(gout), ptr(gpred),
+                              ptr(gprior) if n_prior else None, stream()), "otvae_nelbo_bwd")
     return gpred, gprior
 
 
 _define("nelbo_loss", "(Tensor pred, Tensor target, Tensor? prior_loss, float chw) -> Tensor", _nelbo_fwd,
         lambda pred, target, prior_loss, chw: pred.new_empty(3))
-_define("nelbo_loss_backward", "(Tensor gout, Tensor pred, Tensor target, bool has_prior, float chw) -> (Tensor, Tensor)", _nelbo_bwd,
-        lambda gout, pred, target, has_prior, chw: (torch.empty_strided(pred.shape, pred.stride(), device=pred.device, dtype=pred.dtype),
-                                                    pred.new_empty(pred.shape[0] if has_prior else 0)))
+_define("nelbo_loss_backward", "(Tensor gout, Tensor pred, Tensor target, int n_prior, float chw) -> (Tensor, Tensor)", _nelbo_bwd,
+        lambda gout, pred, target, n_prior, chw: (torch.empty_strided(pred.shape, pred.stride(), device=pred.device, dtype=pred.dtype),
+                                                  pred.new_empty(n_prior)))
 
 
 def _nelbo_setup(ctx, inputs, output):
     pred, target, prior_loss, chw = inputs
     ctx.save_for_backward(pred, target)
-    ctx.cfg = (prior_loss is not None, chw)
+    ctx.cfg = (0 if prior_loss is None else prior_loss.numel(), tuple(prior_loss.shape) if prior_loss is not None else None, chw)
 
 
 def _nelbo_backward(ctx, gout):
     pred, target = ctx.saved_tensors
-    has_prior, chw = ctx.cfg
-    gpred, gprior = torch.ops.otvae.nelbo_loss_backward(gout, pred, target, has_prior, chw)
-    return gpred, None, (gprior if has_prior else None), None
+    n_prior, pshape, chw = ctx.cfg
+    gpred, gprior = torch.ops.otvae.nelbo_loss_backward(gout, pred, target, n_prior, chw)
+    return gpred, None, (gprior.reshape(pshape) if n_prior else None), None
 
 
 torch.library.register_autograd("otvae::nelbo_loss", _nelbo_backward, setup_context=_nelbo_setup)

@@ -385,6 +385,48 @@ def _mnist_vae(A, residual, loss_coeff=0.1):
     return A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=loss_coeff)).cuda().train()
 
 
+def test_nelbo_with_expansion_vs_reference_golden(A):
+    """`VAE(expansion=3)` (model/vae.py:158-229; utils.replicate_batch / mean_replicated_batch): three noise draws per image, the decoder
+    on 3B latents, the reconstruction loss on the mean over the replicas, `preds` / `latents` = the first replica -- loss vector,
+    artifacts, every parameter gradient and BatchNorm buffer against the reference's own classes (nelbo_expansion.npz); then the same
+    model through HipTrainer (captured step = eager step)."""
+    z = load_golden("nelbo_expansion.npz")
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+
+    def make():
+        enc = A.CNN(1, 16, 16, 1, capacity=4, down_sample=True, residual="add")
+        dec = A.CNN(8, 1, 1, 16, capacity=4, up_sample=True, residual="add")
+        fill_state_dict(enc.state_dict())
+        fill_state_dict(dec.state_dict())
+        return A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1), expansion=3).cuda().train()
+
+    model = make()
+    x, eps = g["x"].cuda(), g["eps"].cuda()
+    loss, logs, art = model.nelbo({"samples": x, "target": x, "kwargs": {"eps": eps}}, 0)
+    loss.backward()
+    rep = Report("VAE(expansion=3).nelbo vs reference golden (B=8)")
+    rep.check("loss [total, recon, prior]", torch.stack([logs["train/loss/total"], logs["train/loss/recon"], logs["train/loss/prior"]]), g["loss"])
+    rep.check("preds", art["preds"], g["preds"])
+    rep.check("latents", art["latents"], g["latents"])
+    rep.check("preds_mean", art["preds_mean"], g["preds_mean"])
+    gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith("grad/"))
+    for pre, net in (("encoder.", model.encoder), ("decoder.", model.decoder)):
+        for k, p in net.named_parameters():
+            rep.check(f"grad/{pre}{k}", p.grad, g[f"grad/{pre}{k}"], tol=5e-4, floor=1e-2 * gscale)
+        for k, b in net.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                rep.check(f"buf/{pre}{k}", b, g[f"buf/{pre}{k}"])
+    rep.finish()
+    # the trainer sizes its noise buffer for the replicas; captured and eager steps agree
+    ta = A.HipTrainer(make(), batch_shape=(8, 1, 16, 16), use_graph=True)
+    tb = A.HipTrainer(make(), batch_shape=(8, 1, 16, 16), use_graph=False)
+    assert ta.eps.shape[0] == 24
+    for _ in range(2):
+        assert torch.equal(ta.step(x, eps), tb.step(x, eps))
+    assert torch.equal(ta.pflat, tb.pflat)
+    ta.close(); tb.close()
+
+
 @pytest.mark.parametrize("residual", ["add", "None"])
 def test_nelbo_and_adam_vs_reference_golden(A, residual):
     g = group(load_golden("nelbo_mnist.npz"), residual)

@@ -853,3 +853,27 @@ def test_codebook_prior_with_trained_codebook():
     assert rel_err(enc, g["enc"]) < 1e-5 and rel_err(loss, g["loss"]) < 1e-5
     ((enc * g["s_z"]).sum() + loss.sum()).backward()
     assert rel_err(z.grad, g["g_z"]) < 1e-4 and rel_err(cb.grad, g["g_codebook"]) < 1e-4
+
+
+def test_nelbo_with_expansion():
+    z = load_golden("nelbo_expansion.npz")
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    ea = O.cnn_arch(1, 16, 16, 1, capacity=4, down_sample=True, residual="add")
+    da = O.cnn_arch(8, 1, 1, 16, capacity=4, up_sample=True, residual="add")
+    enc, dec = _build_params(ea), _build_params(da)
+    for d in (enc, dec):
+        for k, v in d.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+    r = O.vae_nelbo(g["x"], g["eps"], enc, dec, ea, da, loss_coeff=0.1, expansion=3)
+    r["loss"].backward()
+    assert rel_err(torch.stack([r["loss"], r["recon"], r["prior"]]), g["loss"]) < TIGHT
+    for k in ("preds", "latents", "preds_mean"):
+        assert rel_err(r[k], g[k]) < 1e-5, k
+    gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith("grad/"))
+    for pre, d in (("encoder.", enc), ("decoder.", dec)):
+        for k, v in d.items():
+            if v.requires_grad:
+                assert (v.grad - g[f"grad/{pre}{k}"]).abs().max() < 2e-4 * gscale, k
+            elif "running" in k:
+                assert rel_err(v, g[f"buf/{pre}{k}"]) < 1e-5, k
