@@ -874,6 +874,94 @@ def gen_codebook_autograd():
     save("codebook_autograd.npz", out)
 
 
+class _RecordingOperator(torch.nn.Module):
+    """stands in for a TransportOperator: records what the callback hands it"""
+
+    def __init__(self, *size, **kwargs):
+        super().__init__()
+        self.size, self.calls = size, []
+
+    def update(self, source_samples=None, target_samples=None):
+        self.calls.append((1, source_samples) if source_samples is not None else (0, target_samples))
+
+    def reset(self):
+        self.calls.append((2, None))
+
+    def compute(self):
+        return torch.tensor([1.0, 3.0])
+
+    def forward(self, x):
+        return 2 * x
+
+
+class _RoutingModule:
+    training = True
+    device = torch.device("cpu")
+
+    def encode(self, x, **kw):
+        return x[:, :2, ::2, ::2] * 10
+
+    def decode(self, z, **kw):
+        return z
+
+    def eval(self):
+        self.training = False
+
+    def train(self):
+        self.training = True
+
+    def log(self, *a, **k):
+        pass
+
+
+ROUTING_GRID = [(s_, t_, u_, c_, dims, False, None) for s_ in (False, True) for t_ in (False, True) for u_ in (False, True)
+                for c_ in (False, True) for dims in ((1,), (1, 2, 3))]
+# + a verbose callback (its encode fallback for step outputs without latents, batch 0 only) and class filtering (`class_idx`, the
+#   condition under the step output's key 'y')
+ROUTING_GRID += [(False, True, False, False, (1,), True, None), (True, True, True, True, (1,), True, None),
+                 (False, False, True, False, (1,), False, 1), (True, True, False, True, (2, 3), False, 0)]
+
+
+def gen_latent_transport_routing():
+    """The routing logic of the LatentTransport callback (ot/transport_callback.py:173-237, layouts :289-330) driven through its own
+    hooks with a recording operator: for every combination of source_latents_from_train / target_latents_from_train / unpaired /
+    common_operator and two `transport_dims`, the sequence of operator calls (reset / source / target and the tensors handed over)
+    during four training and four validation batches -- even batches carry `latents` in the step output, odd ones only `samples` --
+    and what `transport()` returns."""
+    tc = R.ref("ot.transport_callback")
+    out = {}
+    x = [torch.arange(2 * 3 * 4 * 4, dtype=torch.float32).reshape(2, 3, 4, 4) + 1000.0 * i for i in range(8)]
+    labels = torch.tensor([1, 0])
+    for idx, (src, tgt, unp, common, dims, verbose, cls) in enumerate(ROUTING_GRID):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cb = tc.LatentTransport(size=(2, 2, 2), transport_dims=dims, transport_operator=_RecordingOperator,
+                                    transformations=lambda t: t + 100.0, logging_prefix="t", target_latents_from_train=tgt,
+                                    source_latents_from_train=src, unpaired=unp, common_operator=common, verbose=verbose, class_idx=cls)
+        mod = _RoutingModule()
+        cb.on_validation_epoch_start(None, mod)
+        for b in range(4):
+            o = {"samples": x[b], "kwargs": {}, "y": labels}
+            if b % 2 == 0:
+                o["latents"] = mod.encode(x[b]) + 1.0
+            cb.on_train_batch_end(None, mod, o, None, b)
+        for b in range(4):
+            o = {"samples": x[4 + b], "kwargs": {}, "y": labels}
+            if b % 2 == 0:
+                o["latents"] = mod.encode(x[4 + b]) + 1.0
+            cb.on_validation_batch_end(None, mod, o, None, b, 0)
+        calls = cb.transport_operator.calls
+        out[f"{idx}/flags"] = np.array([int(src), int(tgt), int(unp), int(common), len(dims), int(verbose), -1 if cls is None else cls])
+        out[f"{idx}/kinds"] = np.array([k for k, _ in calls])
+        for j, (_, t) in enumerate(calls):
+            if t is not None:
+                out[f"{idx}/call{j}"] = npy(t)
+        out[f"{idx}/transported"] = npy(cb.transport(mod.encode(x[0])))
+        out[f"{idx}/op_size"] = np.array(cb.transport_operator.size)
+    save("latent_transport_routing.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1388,6 +1476,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing"]
     for w in which:
         globals()["gen_" + w]()

@@ -9,6 +9,7 @@ same points Lightning would.  Everything numeric happens in the ``TransportOpera
 Routing rules (transport_callback.py:173-237), with ``unpaired`` = source and target must come from different batches:
 
     train batch end   target <- outputs[latents_key]           if target_latents_from_train and (paired or no source-from-train or even batch)
+                      (no `latents_key` in the output: target <- encode(samples) only on batch 0 of a `verbose` callback, as the reference)
                       source <- encode(transform(samples))     if source_latents_from_train and (paired or no target-from-train or odd batch)
     val batch end     target <- outputs[latents_key] / encode  if not target_latents_from_train and (paired or source-from-train or even batch)
                       source <- encode(transform(samples))     if not source_latents_from_train and (paired or target-from-train or odd batch)
@@ -157,7 +158,11 @@ class LatentTransport:
         if tgt and (not self.unpaired or not src or batch_idx % 2 == 0):
             if self.latents_key in outputs:
                 self.update_transport_operator(outputs[self.latents_key].detach(), source=False)
-            else:
+            elif self.verbose and batch_idx == 0:
+                # The reference encodes the samples itself when the step output carries no latents -- but that fallback sits INSIDE
+                # its `if self.verbose and batch_idx == 0:` warning block (transport_callback.py:189-203): without `verbose`, or on
+                # any later batch, a step output without `latents_key` feeds nothing to the target.  Kept as is: the statistics a
+                # user gets must be the reference's (VAE.training_step always returns the latents, so this path is a corner).
                 samples, kwargs = self._get_samples(pl_module, outputs)
                 self.update_transport_operator(self._eval_encode(pl_module, samples, **kwargs), source=False)
         if src and (not self.unpaired or not tgt or batch_idx % 2 == 1):

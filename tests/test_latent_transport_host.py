@@ -145,3 +145,51 @@ def test_class_filter_errors_and_conditional_fan_out():
     assert [t.class_idx for t in cc.transports] == [0, 1, 2] and len(RecordingOperator.made) == 3
     cc.on_validation_epoch_start(None, m)
     assert all(op.calls == [("reset", None)] for op in RecordingOperator.made)
+
+
+def test_routing_equals_the_reference_callback_over_the_flag_grid():
+    """The same scripted run (validation-epoch start, four training batches, four validation batches; even batches carry `latents`) through
+    this callback and -- recorded in tests/golden/latent_transport_routing.npz by oracle/gen_golden.py -- through the reference's own
+    LatentTransport with a recording operator, for all 32 combinations of source_latents_from_train / target_latents_from_train /
+    unpaired / common_operator x transport_dims in {(1,), (1,2,3)} (+ verbose and class_idx cases): the same calls in the same order with the same tensors, the
+    same operator size, the same `transport()` result."""
+    import numpy as np
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "latent_transport_routing.npz"))
+    grid = [(s_, t_, u_, c_, dims, False, None) for s_ in (False, True) for t_ in (False, True) for u_ in (False, True)
+            for c_ in (False, True) for dims in ((1,), (1, 2, 3))]
+    # + a verbose callback (encode fallback on batch 0 only, as the reference) and class filtering
+    grid += [(False, True, False, False, (1,), True, None), (True, True, True, True, (1,), True, None),
+             (False, False, True, False, (1,), False, 1), (True, True, False, True, (2, 3), False, 0)]
+    labels = torch.tensor([1, 0])
+    x = [torch.arange(2 * 3 * 4 * 4, dtype=torch.float32).reshape(2, 3, 4, 4) + 1000.0 * i for i in range(8)]
+    for idx, (src, tgt, unp, common, dims, verbose, cls) in enumerate(grid):
+        assert list(z[f"{idx}/flags"]) == [int(src), int(tgt), int(unp), int(common), len(dims), int(verbose), -1 if cls is None else cls]
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cb = make(transport_dims=dims, target_latents_from_train=tgt, source_latents_from_train=src, unpaired=unp,
+                      common_operator=common, verbose=verbose, class_idx=cls)
+        mod = Module()
+        cb.on_validation_epoch_start(None, mod)
+        for b in range(4):
+            o = {"samples": x[b], "kwargs": {}, "y": labels}
+            if b % 2 == 0:
+                o["latents"] = x[b][:, :2, ::2, ::2] * 10 + 1.0
+            cb.on_train_batch_end(None, mod, o, None, b)
+        for b in range(4):
+            o = {"samples": x[4 + b], "kwargs": {}, "y": labels}
+            if b % 2 == 0:
+                o["latents"] = x[4 + b][:, :2, ::2, ::2] * 10 + 1.0
+            cb.on_validation_batch_end(None, mod, o, None, b, 0)
+        calls = cb.transport_operator.calls
+        kinds = [{"target": 0, "source": 1, "reset": 2}[k] for k, _ in calls]
+        tag = (src, tgt, unp, common, dims, verbose, cls)
+        assert kinds == list(z[f"{idx}/kinds"]), tag
+        for j, (_, t) in enumerate(calls):
+            if t is not None:
+                want = torch.from_numpy(z[f"{idx}/call{j}"])
+                assert t.shape == want.shape and torch.equal(t, want), (tag, j)
+        assert list(cb.transport_operator.size) == list(z[f"{idx}/op_size"]), tag
+        got = cb.transport(x[0][:, :2, ::2, ::2] * 10)
+        assert torch.equal(got, torch.from_numpy(z[f"{idx}/transported"])), tag
