@@ -962,6 +962,39 @@ def gen_latent_transport_routing():
     save("latent_transport_routing.npz", out)
 
 
+def _layout_cases():
+    import itertools
+    cases = []
+    for shape in ((2, 2, 3, 4), (3, 2, 3, 2, 2), (2, 5)):
+        dims = list(range(1, len(shape)))
+        for r in range(1, len(dims) + 1):
+            for perm in itertools.permutations(dims, r):
+                if len(perm) > 2 and list(perm) != sorted(perm) and perm != tuple(reversed(sorted(perm))):
+                    continue   # (all orders of one and two axes, sorted / reversed orders of longer ones)
+                for bf in (True, False):
+                    for fb in (True, False):
+                        cases.append((shape, perm, bf, fb))
+    return cases
+
+
+def gen_layouts():
+    """utils.permute_and_flatten / unflatten_and_unpermute (utils/__init__.py:233-311) -- the [B, C, H, W] <-> [positions, B, dim] /
+    [B * positions, dim] layouts of LatentTransport and CodebookPrior -- over every choice of axes (in any order), batch_first and
+    flatten_batch for 2-, 4- and 5-dimensional inputs: the rearranged tensor and the round trip."""
+    U = R.ref("utils")
+    out = {}
+    cases = _layout_cases()
+    for i, (shape, perm, bf, fb) in enumerate(cases):
+        x = torch.arange(int(np.prod(shape)), dtype=torch.float32).reshape(shape)
+        y = U.permute_and_flatten(x, perm, batch_first=bf, flatten_batch=fb)
+        back = U.unflatten_and_unpermute(y, x.shape, perm, batch_first=bf, flatten_batch=fb)
+        out[f"{i}/cfg"] = np.array(list(shape) + [-1] + list(perm) + [-1, int(bf), int(fb)])
+        out[f"{i}/y"] = npy(y)
+        out[f"{i}/roundtrip_ok"] = np.array([int(torch.equal(back, x))])
+    out["n"] = np.array([len(cases)])
+    save("layouts.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1476,6 +1509,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts"]
     for w in which:
         globals()["gen_" + w]()

@@ -193,3 +193,27 @@ def test_routing_equals_the_reference_callback_over_the_flag_grid():
         assert list(cb.transport_operator.size) == list(z[f"{idx}/op_size"]), tag
         got = cb.transport(x[0][:, :2, ::2, ::2] * 10)
         assert torch.equal(got, torch.from_numpy(z[f"{idx}/transported"])), tag
+
+
+def test_layout_functions_equal_the_reference_over_all_axis_choices():
+    """``utils.permute_and_flatten`` / ``unflatten_and_unpermute`` against the reference's functions (tests/golden/layouts.npz, recorded by
+    oracle/gen_golden.py from utils/__init__.py:233-311): every choice and order of axes, batch_first, flatten_batch, for 2-, 4- and
+    5-dimensional inputs -- the rearranged tensor bit for bit, and the round trip wherever the reference's own round trip holds."""
+    import os
+    import numpy as np
+    from ot_vae_lightning_amd import utils as U
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "layouts.npz"))
+    n = int(z["n"][0])
+    assert n > 150
+    for i in range(n):
+        cfg = [int(v) for v in z[f"{i}/cfg"]]
+        a = cfg.index(-1)
+        b = cfg.index(-1, a + 1)
+        shape, perm, bf, fb = tuple(cfg[:a]), tuple(cfg[a + 1:b]), bool(cfg[b + 1]), bool(cfg[b + 2])
+        x = torch.arange(int(np.prod(shape)), dtype=torch.float32).reshape(shape)
+        y = U.permute_and_flatten(x, perm, batch_first=bf, flatten_batch=fb)
+        want = torch.from_numpy(z[f"{i}/y"])
+        assert y.shape == want.shape and torch.equal(y, want), (shape, perm, bf, fb)
+        if int(z[f"{i}/roundtrip_ok"][0]):
+            back = U.unflatten_and_unpermute(y, x.shape, perm, batch_first=bf, flatten_batch=fb)
+            assert torch.equal(back, x), (shape, perm, bf, fb, "round trip")
