@@ -995,6 +995,37 @@ def gen_layouts():
     save("layouts.npz", out)
 
 
+def gen_cnn_shapes():
+    """The shape inference of the CNN constructor (networks/cnn.py:605-672): get_block_scaling, get_channel_list and div_sqrt over a grid
+    of (in_features, out_features, in_resolution, out_resolution, scaling factor, capacity) / all n <= 600."""
+    cnn = R.ref("networks.cnn")
+    rows = []
+    for cin in (1, 3, 8, 24):
+        for cout in (8, 16, 64, 256, 300):
+            for rin in (4, 8, 16, 32, 64, 128):
+                for rout in (1, 2, 4, 8):
+                    if rout >= rin:
+                        continue
+                    for sf in (2, 4, 8):
+                        for cap in (4, 8, 16, 24):
+                            feats, res = cnn.get_channel_list(cin, cout, rin, rout, sf, cap)
+                            rows.append([cin, cout, rin, rout, sf, cap, len(feats)] + list(feats) + list(res))
+    width = max(len(r) for r in rows)
+    out = {"channel_list": np.array([r + [-1] * (width - len(r)) for r in rows], dtype=np.int64)}
+    out["div_sqrt"] = np.array([int(cnn.div_sqrt(n)) for n in range(1, 601)], dtype=np.int64)
+    sc = []
+    for hi in (2, 4, 8, 16, 32, 64, 128, 256):
+        for lo in (1, 2, 4, 8, 16):
+            if lo >= hi:
+                continue
+            for m in (2, 4, 8, 16):
+                v = cnn.get_block_scaling(hi, lo, m)
+                sc.append([hi, lo, m, len(v)] + list(v))
+    width = max(len(r) for r in sc)
+    out["block_scaling"] = np.array([r + [-1] * (width - len(r)) for r in sc], dtype=np.int64)
+    save("cnn_shapes.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1509,6 +1540,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes"]
     for w in which:
         globals()["gen_" + w]()
