@@ -1026,6 +1026,35 @@ def gen_cnn_shapes():
     save("cnn_shapes.npz", out)
 
 
+def gen_utils_small():
+    """The small tensor helpers of utils/__init__.py:123-218 the hot path calls: replicate_batch / mean_replicated_batch /
+    std_replicated_batch (VAE expansion), ema / ema_inplace (running statistics), laplace_smoothing (mixture weights)."""
+    U = R.ref("utils")
+    out = {}
+    g = torch.Generator().manual_seed(201)
+    x = torch.randn(4, 3, 2, generator=g)
+    for n in (0, 1, 2, 3):
+        r = U.replicate_batch({"a": x, "b": [x[:, 0], 7]}, n)
+        out[f"replicate{n}/a"], out[f"replicate{n}/b0"] = npy(r["a"]), npy(r["b"][0])
+        e = torch.randn(max(n, 1) * 4, 3, generator=g)
+        out[f"reduce{n}/in"], out[f"reduce{n}/mean"] = npy(e), npy(U.mean_replicated_batch(e, n))
+        if n > 1:
+            out[f"reduce{n}/std"] = npy(U.std_replicated_batch(e, n))
+    avg, new = torch.randn(5, 3, generator=g), torch.randn(5, 3, generator=g)
+    for tag, decay in (("none", None), ("d0", 0.0), ("d09", 0.9), ("d1", 1.0)):
+        out[f"ema/{tag}"] = npy(U.ema(avg.clone(), new, decay))
+        inp = avg.clone()
+        U.ema_inplace(inp, new, decay)
+        out[f"ema_inplace/{tag}"] = npy(inp)
+    out["ema/avg"], out["ema/new"] = npy(avg), npy(new)
+    cnt = torch.tensor([[0.0, 3.0, 1.0, 0.0], [2.0, 2.0, 2.0, 2.0], [0.0, 0.0, 0.0, 0.0]])
+    out["laplace/in"] = npy(cnt)
+    out["laplace/eps1e-5"] = npy(U.laplace_smoothing(cnt, 4))
+    out["laplace/eps0.5"] = npy(U.laplace_smoothing(cnt, 4, eps=0.5))
+    out["laplace/none"] = npy(U.laplace_smoothing(cnt, 4, eps=None))
+    save("utils_small.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1540,6 +1569,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small"]
     for w in which:
         globals()["gen_" + w]()
