@@ -515,6 +515,15 @@ int otvae_codebook_probs_bwd(const float* x, const float* codebook, const float*
 int otvae_codebook_probs_bwd_atoms(const float* x, const float* codebook, const float* probs, const float* gprobs,
                                    const float* gentropy, int nb, int B, int K, int d, float temperature, float* gx,
                                    float* coef_ws, float* gc, void* stream);
+
+/* CodebookModel.energy for the metrics besides the hot path's euclidean p = 2 (ot/distribution_models/codebook_model.py:155-168):
+ * metric 0: 1 / (cdist_p(x, c) + 1e-8) for any p > 0; metric 1 ('cosine'): |x . c| / ((sum |x|^p)(sum |c|^p) + 1e-8)^(1/p).
+ * E [nb][B][K], raw (MixtureMixin.assign applies topk and the temperature afterwards, base.py:216-224).  _bwd: gx [nb][B][d] and /
+ * or gc [nb][K][d] (NULL = not wanted) from gE, summed in a fixed order. */
+int otvae_codebook_energy(const float* x, const float* codebook, int nb, int B, int K, int d, int metric, float p, float* E,
+                          void* stream);
+int otvae_codebook_energy_bwd(const float* x, const float* codebook, const float* gE, int nb, int B, int K, int d, int metric,
+                              float p, float* gx, float* gc, void* stream);
 /* k-means sufficient statistics for one-hot ('argmax') assignments (MixtureMixin.kmean_iteration, base.py:241-252):
  * counts[nb][K] = number of samples per atom, sums[nb][K][d] = their sum, members added in increasing sample order. */
 int otvae_codebook_kmeans(const float* x, const int64_t* idx, int nb, int B, int K, int d, float* counts, float* sums,

@@ -1055,6 +1055,57 @@ def gen_utils_small():
     save("utils_small.npz", out)
 
 
+CODEBOOK_OPTION_CASES = [
+    # tag, metric, p, topk, mode, temperature
+    ("cos_p2_mean", "cosine", 2.0, None, "mean", 0.5), ("cos_p1_argmax", "cosine", 1.0, None, "argmax", 1.0),
+    ("cos_p05_mean_top3", "cosine", 0.5, 3, "mean", 0.7), ("euc_p1_mean", "euclidean", 1.0, None, "mean", 0.6),
+    ("euc_p05_argmax", "euclidean", 0.5, None, "argmax", 1.0), ("euc_p3_mean_top2", "euclidean", 3.0, 2, "mean", 0.8),
+    ("euc_p2_mean_top3", "euclidean", 2.0, 3, "mean", 0.5), ("euc_p2_argmax_top1", "euclidean", 2.0, 1, "argmax", 1.0),
+    ("cos_p2_sample_top1", "cosine", 2.0, 1, "sample", 1.0),
+]
+
+
+def gen_codebook_options():
+    """CodebookModel with `metric='cosine'`, p != 2 and `topk` (base.py:166-235, codebook_model.py:150-168), the codebook a trained
+    parameter so that both gradients show: energies, predictions, assignment probabilities and the gradients of a seeded scalar of
+    (predictions, probabilities) with respect to the samples and the codebook; GaussianMixtureModel with `topk` (assignment weights)."""
+    cb = R.ref("ot.distribution_models.codebook_model")
+    out = {}
+    K, d, B = 6, 4, 24
+    for tag, metric, p, topk, mode, T in CODEBOOK_OPTION_CASES:
+        g = torch.Generator().manual_seed(211)
+        mix = dict(n_components=K, metric=metric, p=p, topk=topk, temperature=T, training_mode=mode, inference_mode=mode)
+        model = cb.CodebookModel(2, d, mixture_cfg=mix, update_with_autograd=True)
+        with torch.no_grad():
+            model.codebook.copy_(torch.randn(model.codebook.shape, generator=g) * 1.2 + 0.3)
+        x = (torch.randn(2, B, d, generator=g) * 1.5 + 0.2).requires_grad_(True)
+        s_pred, s_prob = torch.randn(2, B, d, generator=g), torch.randn(2, B, K, generator=g)
+        model.train()
+        torch.manual_seed(7)
+        energy = model.energy(x)
+        preds, _, dist = model(x)
+        ((preds * s_pred).sum() + (dist.probs * s_prob).sum()).backward()
+        out[f"{tag}/codebook"], out[f"{tag}/x"], out[f"{tag}/s_pred"], out[f"{tag}/s_prob"] = npy(model.codebook), npy(x), npy(s_pred), npy(s_prob)
+        out[f"{tag}/energy"], out[f"{tag}/preds"], out[f"{tag}/probs"] = npy(energy), npy(preds), npy(dist.probs)
+        out[f"{tag}/g_x"], out[f"{tag}/g_codebook"] = npy(x.grad), npy(model.codebook.grad)
+    # a Gaussian mixture with topk
+    gm = R.ref("ot.distribution_models.gassian_mixture_model")
+    for tag, topk, mode in (("gmm_top2_mean", 2, "mean"), ("gmm_top1_sample", 1, "sample"), ("gmm_top3_argmax", 3, "argmax")):
+        g = torch.Generator().manual_seed(221)
+        mix = dict(n_components=5, topk=topk, temperature=0.9, training_mode=mode, inference_mode=mode)
+        model = gm.GaussianMixtureModel(3, mixture_cfg=mix, w2_cfg=dict(diag=True, make_pd=True, dtype=torch.double), dtype=torch.double)
+        with torch.no_grad():
+            model.mean.copy_(torch.randn(model.mean.shape, generator=g, dtype=torch.double) * 2.0)
+            model.cov = torch.rand(model.cov.shape, generator=g, dtype=torch.double) + 0.5
+        x = torch.randn(20, 3, generator=g, dtype=torch.double) * 2.0
+        model.eval()
+        torch.manual_seed(8)
+        w, _, dist = model.assign(x)
+        out[f"{tag}/mean"], out[f"{tag}/cov"], out[f"{tag}/x"] = npy(model.mean), npy(model.parametrizations.cov.original), npy(x)
+        out[f"{tag}/weights"], out[f"{tag}/probs"] = npy(w), npy(dist.probs)
+    save("codebook_options.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1569,6 +1620,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options"]
     for w in which:
         globals()["gen_" + w]()

@@ -556,6 +556,30 @@ def codebook_prior_encode_soft_kl(z: Tensor, codebook: Tensor, temperature: floa
     return preds.reshape(h, w, b, c).permute(2, 3, 0, 1), loss
 
 
+def codebook_energy_general(x: Tensor, codebook: Tensor, metric: str = "euclidean", p: float = 2.0) -> Tensor:
+    """``CodebookModel.energy`` (codebook_model.py:150-168): 'euclidean': 1 / (cdist_p + 1e-8); 'cosine':
+    |x . c| / ((sum |x|^p)(sum |c|^p) + 1e-8)^(1/p).  [*, B, d] x [*, K, d] -> [*, B, K]."""
+    if metric == "euclidean":
+        return 1 / (torch.cdist(x, codebook, p) + 1e-8)
+    norm_x = x.abs().pow(p).sum(-1, keepdim=True)
+    norm_c = codebook.abs().pow(p).sum(-1).unsqueeze(-2)
+    dot = (x @ codebook.transpose(-2, -1)).abs()
+    return dot / (norm_x * norm_c + 1e-8) ** (1 / p)
+
+
+def mixture_assign(energy: Tensor, topk: Optional[int], temperature: float, mode: str):
+    """``MixtureMixin.assign`` (base.py:206-239) without the random draw: top-k restriction, soft-max, and the weights of the
+    deterministic modes ('mean', 'argmax'; with topk == 1 the soft weights whatever the mode).  -> (weights, probs)"""
+    if topk is not None and topk > 0:
+        val, idx = torch.topk(energy, topk, dim=-1)
+        energy = torch.full_like(energy, float("-inf")).scatter(-1, idx, val)
+    probs = torch.softmax(energy / temperature, dim=-1)
+    if mode == "mean" or topk == 1:
+        return probs, probs
+    assert mode == "argmax", mode
+    return F.one_hot(probs.argmax(-1), probs.size(-1)).type_as(probs), probs
+
+
 def codebook_kmeans_stats(x: Tensor, codebook: Tensor, temperature: float = 1.0, mode: str = "argmax"):
     """``kmean_iteration`` (base.py:241-252) with one-hot ('argmax') or soft ('mean') weights:
     (counts [*, K], sums [*, K, d])."""

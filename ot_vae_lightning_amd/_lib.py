@@ -149,6 +149,8 @@ SIGNATURES = {
     "otvae_codebook_probs": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "otvae_codebook_probs_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]),
     "otvae_codebook_probs_bwd_atoms": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "otvae_codebook_energy": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),
+    "otvae_codebook_energy_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "otvae_codebook_kmeans": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
 }
 

@@ -1316,6 +1316,157 @@ extern "C" int otvae_codebook_probs_bwd_atoms(const float* x, const float* codeb
     return codebook_probs_bwd_launch(x, codebook, probs, gprobs, gentropy, nb, B, K, d, temperature, gx, coef_ws, gc, stream);
 }
 
+// ---- CodebookModel.energy for the other metrics (reference ot/distribution_models/codebook_model.py:155-168) ------------------------
+//   metric 0 ('euclidean', any p > 0):  E = 1 / (cdist_p(x, c) + 1e-8),           cdist_p = (sum_j |x_j - c_j|^p)^(1/p)
+//   metric 1 ('cosine'):                E = |x . c| / ((sum_j |x_j|^p)(sum_j |c_j|^p) + 1e-8)^(1/p)
+// E [nb][B][K] fp32, no temperature (MixtureMixin.assign divides afterwards: topk masking sits in between, base.py:216-224).
+// The p = 2 euclidean energies of the hot path never materialise (otvae_codebook_assign / _probs); this is the general route.
+__device__ __forceinline__ float cb_powabs(float t, float p) { return p == 2.f ? t * t : (p == 1.f ? fabsf(t) : __powf(fabsf(t), p)); }
+
+__global__ __launch_bounds__(256) void codebook_energy_kernel(const float* __restrict__ x, const float* __restrict__ cb, int B, int K,
+                                                              int d, int metric, float p, float* __restrict__ E) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * K) return;
+    const int r = i / K, k = i - r * K;
+    const float* xr = x + ((size_t)b * B + r) * d;
+    const float* ck = cb + ((size_t)b * K + k) * d;
+    float e;
+    if (metric == 0) {
+        float s = 0.f;
+        for (int j = 0; j < d; ++j) s += cb_powabs(xr[j] - ck[j], p);
+        const float dist = p == 2.f ? sqrtf(s) : (p == 1.f ? s : __powf(s, 1.f / p));
+        e = 1.f / (dist + 1e-8f);
+    } else {
+        float nx = 0.f, nc = 0.f, dot = 0.f;
+        for (int j = 0; j < d; ++j) {
+            nx += cb_powabs(xr[j], p);
+            nc += cb_powabs(ck[j], p);
+            dot = fmaf(xr[j], ck[j], dot);
+        }
+        e = fabsf(dot) / __powf(nx * nc + 1e-8f, 1.f / p);
+    }
+    E[((size_t)b * B + r) * K + k] = e;
+}
+
+// d E[r][k] / d x_r[j] (which = 0) or / d c_k[j] (which = 1), the factor shared by the two backward kernels.  Conventions at the
+// kinks follow torch's backward formulas: cdist gives 0 where the distance is 0 (or, for p < 1, where the coordinate difference
+// is 0); |t|^p differentiates to 0 at t = 0 (torch: sign(0) = 0).
+__device__ __forceinline__ float cb_dabs_pow(float t, float p) {  // d |t|^p / d t
+    if (t == 0.f) return 0.f;
+    const float a = fabsf(t);
+    const float m = p == 2.f ? 2.f * a : (p == 1.f ? 1.f : p * __powf(a, p - 1.f));
+    return t > 0.f ? m : -m;
+}
+
+struct CbPair {  // what depends on the (sample, atom) pair only
+    float a, b, c;
+};
+__device__ __forceinline__ CbPair cb_pair(const float* __restrict__ xr, const float* __restrict__ ck, int d, int metric, float p) {
+    CbPair o = {0.f, 0.f, 0.f};
+    if (metric == 0) {
+        float s = 0.f;
+        for (int j = 0; j < d; ++j) s += cb_powabs(xr[j] - ck[j], p);
+        const float dist = p == 2.f ? sqrtf(s) : (p == 1.f ? s : __powf(s, 1.f / p));
+        // dE/d dist = -1 / (dist + eps)^2;  d dist / d diff_j = (1 / p) s^(1/p - 1) d|diff_j|^p
+        o.a = dist > 0.f ? -1.f / ((dist + 1e-8f) * (dist + 1e-8f)) * (1.f / p) * (p == 1.f ? 1.f : __powf(s, 1.f / p - 1.f)) : 0.f;
+    } else {
+        float nx = 0.f, nc = 0.f, dot = 0.f;
+        for (int j = 0; j < d; ++j) {
+            nx += cb_powabs(xr[j], p);
+            nc += cb_powabs(ck[j], p);
+            dot = fmaf(xr[j], ck[j], dot);
+        }
+        const float D = nx * nc + 1e-8f, Dp = __powf(D, -1.f / p);
+        o.a = (dot > 0.f ? 1.f : (dot < 0.f ? -1.f : 0.f)) * Dp;   // d E / d dot
+        const float t = -fabsf(dot) * (1.f / p) * Dp / D;           // d E / d D
+        o.b = t * nc;                                               // d E / d nx
+        o.c = t * nx;                                               // d E / d nc
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(256) void codebook_energy_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                                    const float* __restrict__ gE, int B, int K, int d, int metric,
+                                                                    float p, float* __restrict__ gx) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (r >= B) return;
+    const float* xr = x + ((size_t)b * B + r) * d;
+    for (int j = 0; j < d; ++j) {
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) {   // fixed order: lanes stride over the atoms, then the wave tree
+            const float* ck = cb + ((size_t)b * K + k) * d;
+            const CbPair q = cb_pair(xr, ck, d, metric, p);
+            const float g = gE[((size_t)b * B + r) * K + k];
+            float v;
+            if (metric == 0) {
+                const float diff = xr[j] - ck[j];
+                v = (p < 1.f && diff == 0.f) ? 0.f : q.a * cb_dabs_pow(diff, p);
+            } else {
+                v = q.a * ck[j] + q.b * cb_dabs_pow(xr[j], p);
+            }
+            acc = fmaf(g, v, acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) gx[((size_t)b * B + r) * d + j] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void codebook_energy_bwd_c_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                                    const float* __restrict__ gE, int B, int K, int d, int metric,
+                                                                    float p, float* __restrict__ gc) {
+    const int k = blockIdx.x, b = blockIdx.y;
+    const float* ck = cb + ((size_t)b * K + k) * d;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < B; ++r) {          // samples in increasing order (fixed)
+            const float* xr = x + ((size_t)b * B + r) * d;
+            const CbPair q = cb_pair(xr, ck, d, metric, p);
+            const float g = gE[((size_t)b * B + r) * K + k];
+            float v;
+            if (metric == 0) {
+                const float diff = xr[j] - ck[j];
+                v = (p < 1.f && diff == 0.f) ? 0.f : -q.a * cb_dabs_pow(diff, p);
+            } else {
+                v = q.a * xr[j] + q.c * cb_dabs_pow(ck[j], p);
+            }
+            acc = fmaf(g, v, acc);
+        }
+        gc[((size_t)b * K + k) * d + j] = acc;
+    }
+}
+
+static int codebook_energy_check(const char* who, const void* a, const void* b, const void* c, int nb, int B, int K, int d, int metric,
+                                 float p) {
+    OTVAE_REQUIRE(a && b && c && nb > 0 && B > 0 && K > 0 && d > 0, "%s: bad argument", who);
+    OTVAE_REQUIRE((metric == 0 || metric == 1) && p > 0.f, "%s: metric %d (0 euclidean, 1 cosine), p = %g", who, metric, (double)p);
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_codebook_energy(const float* x, const float* codebook, int nb, int B, int K, int d, int metric, float p, float* E,
+                                     void* stream) {
+    if (int rc = codebook_energy_check("otvae_codebook_energy", x, codebook, E, nb, B, K, d, metric, p)) return rc;
+    codebook_energy_kernel<<<dim3(cdiv((int64_t)B * K, 256), nb), 256, 0, (hipStream_t)stream>>>(x, codebook, B, K, d, metric, p, E);
+    OTVAE_CHECK_LAUNCH("otvae_codebook_energy");
+    return OTVAE_OK;
+}
+
+// gx [nb][B][d] and / or gc [nb][K][d] (either may be NULL) from gE [nb][B][K]
+extern "C" int otvae_codebook_energy_bwd(const float* x, const float* codebook, const float* gE, int nb, int B, int K, int d, int metric,
+                                         float p, float* gx, float* gc, void* stream) {
+    if (int rc = codebook_energy_check("otvae_codebook_energy_bwd", x, codebook, gE, nb, B, K, d, metric, p)) return rc;
+    OTVAE_REQUIRE(gx || gc, "otvae_codebook_energy_bwd: nothing to compute");
+    if (gx) {
+        codebook_energy_bwd_x_kernel<<<dim3(cdiv(B, 4), nb), 256, 0, (hipStream_t)stream>>>(x, codebook, gE, B, K, d, metric, p, gx);
+        OTVAE_CHECK_LAUNCH("otvae_codebook_energy_bwd(samples)");
+    }
+    if (gc) {
+        codebook_energy_bwd_c_kernel<<<dim3(K, nb), 256, 0, (hipStream_t)stream>>>(x, codebook, gE, B, K, d, metric, p, gc);
+        OTVAE_CHECK_LAUNCH("otvae_codebook_energy_bwd(atoms)");
+    }
+    return OTVAE_OK;
+}
+
 // One-hot k-means accumulation (MixtureMixin.kmean_iteration with 'argmax' weights, base.py:241-252):
 // counts[b][k] = #{r : idx_r = k}, sums[b][k][:] = sum_{r : idx_r = k} x_r, members added in increasing r (fixed order).
 // One block per (atom, problem): the block scans the index vector once, then its threads own the d coordinates.

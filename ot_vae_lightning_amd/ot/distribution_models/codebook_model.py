@@ -7,7 +7,8 @@ statistics -- runs in HIP kernels (``otvae_codebook_assign / _probs / _kmeans``)
 follows is a handful of tiny tensor expressions kept in the reference's own order (boolean-mask updates, Laplace
 smoothing over the observed atoms), and ``w2`` composes the HIP Sinkhorn solver exactly as the reference does.
 
-Supported: ``metric='euclidean'``, ``p=2``, ``topk=None``, the assignment modes ``'argmax'``, ``'sample'`` (one-hot) and
+Supported: ``metric='euclidean'`` (the hot path: p = 2, energies never materialised) and ``'cosine'`` / any ``p > 0`` / ``topk``
+(energies materialised by ``otvae_codebook_energy``, then ``MixtureMixin.assign``'s top-k restriction and soft-max), the assignment modes ``'argmax'``, ``'sample'`` (one-hot) and
 ``'mean'`` (soft: the assignment distribution itself, as ``DiscreteTransport`` uses it in the reference's
 tests/test_latent_transport.py:92-101; its weighted sums ``probs^T @ samples`` go through ``matrix_utils.mm`` =
 ``otvae_gemm_f32``), the Gumbel modes (``gumbel_weights``: ``otvae_softmax_rows`` with injectable draws), and
@@ -25,7 +26,7 @@ from torch import Tensor
 
 from ... import _lib, utils
 from ..._lib import check, ptr, stream
-from ..matrix_utils import mm
+from ..matrix_utils import mm, softmax_rows
 from ..w2_utils import sinkhorn_log
 from .base import MIXTURE_MODES, DistributionModel, gumbel_weights
 
@@ -102,6 +103,44 @@ class _AssignmentProbsFn(torch.autograd.Function):
         return gx, None, None, None
 
 
+class _CodebookEnergyFn(torch.autograd.Function):
+    """``CodebookModel.energy`` for the metrics besides the hot path's euclidean p = 2 (codebook_model.py:155-168) on
+    ``otvae_codebook_energy`` / ``_bwd``: raw energies [nb, B, K], differentiable in the samples and the atoms."""
+
+    @staticmethod
+    def forward(ctx, x3, c3, metric, p):
+        nb, bsz, d = x3.shape
+        K = c3.shape[1]
+        e = torch.empty((nb, bsz, K), device=x3.device, dtype=torch.float32)
+        check(_lib.load().otvae_codebook_energy(ptr(x3), ptr(c3), nb, bsz, K, d, int(metric), float(p), ptr(e), stream()),
+              "otvae_codebook_energy")
+        ctx.save_for_backward(x3, c3)
+        ctx.cfg = (int(metric), float(p))
+        return e
+
+    @staticmethod
+    def backward(ctx, ge):
+        x3, c3 = ctx.saved_tensors
+        metric, p = ctx.cfg
+        nb, bsz, d = x3.shape
+        gx = torch.empty_like(x3) if ctx.needs_input_grad[0] else None
+        gc = torch.empty_like(c3) if ctx.needs_input_grad[1] else None
+        if gx is None and gc is None:
+            return None, None, None, None
+        check(_lib.load().otvae_codebook_energy_bwd(ptr(x3), ptr(c3), ptr(ge.contiguous().float()), nb, bsz, c3.shape[1], d, metric, p,
+                                                   ptr(gx), ptr(gc), stream()), "otvae_codebook_energy_bwd")
+        return gx, gc, None, None
+
+
+def topk_energy(energy: Tensor, topk: Optional[int]) -> Tensor:
+    """``MixtureMixin.assign``'s restriction to the k largest energies per sample (base.py:217-220): everything else becomes -inf,
+    i.e. weight 0 after the soft-max; gradients reach the kept entries only.  (Index glue on a [*, B, K] tensor, as the reference.)"""
+    if topk is None or topk <= 0:
+        return energy
+    val, idx = torch.topk(energy, int(topk), dim=-1)
+    return torch.full_like(energy, float("-inf")).scatter(-1, idx, val)
+
+
 class CodebookModel(DistributionModel):
     Distribution = CategoricalEmbeddings
 
@@ -114,8 +153,10 @@ class CodebookModel(DistributionModel):
         cfg.update(mixture_cfg)
         if cfg["n_components"] is None:
             raise TypeError("mixture_cfg must give `n_components`")
-        if cfg["metric"] != "euclidean" or float(cfg["p"]) != 2.0 or cfg["topk"] not in (None, 0):
-            raise NotImplementedError("the MI355X CodebookModel implements metric='euclidean', p=2, topk=None")
+        if cfg["metric"] not in ("euclidean", "cosine"):   # (the reference raises from `energy`, codebook_model.py:168)
+            raise NotImplementedError(f"Supported `metric`: 'cosine', 'euclidean'. Got `metric`={cfg['metric']}")
+        if not float(cfg["p"]) > 0:
+            raise ValueError("`p` must be positive")
         for m in (cfg["training_mode"], cfg["inference_mode"]):
             if m not in MIXTURE_MODES:
                 raise NotImplementedError(f"assignment mode {m!r}: expected one of {MIXTURE_MODES}")
@@ -172,8 +213,23 @@ class CodebookModel(DistributionModel):
         c3 = cb.float().expand(*lead, self.n_components, self.dim).reshape(-1, self.n_components, self.dim).contiguous()
         return x3, c3, lead
 
+    @property
+    def _general(self) -> bool:
+        """anything but the hot path's euclidean p = 2 energies without topk: the energies are materialised
+        (``otvae_codebook_energy``), restricted to the top k, and normalised by ``otvae_softmax_rows``"""
+        return self.metric != "euclidean" or self.p != 2.0 or (self.topk is not None and self.topk > 0)
+
+    def _energy3(self, samples: Tensor):
+        x3, c3, lead = self._flat(samples)
+        return _CodebookEnergyFn.apply(x3, c3, 0 if self.metric == "euclidean" else 1, self.p), x3, c3, lead
+
     def _argmax(self, samples: Tensor) -> Tuple[Tensor, Tensor]:
         lib = _lib.load()
+        if self._general:
+            e, x3, c3, lead = self._energy3(samples)
+            idx = topk_energy(e, self.topk).argmax(-1)                                  # [nb, B]
+            enc = torch.gather(c3, 1, idx.unsqueeze(-1).expand(-1, -1, self.dim))
+            return enc.reshape(*lead, x3.shape[1], self.dim), idx.reshape(*lead, x3.shape[1])
         x3, c3, lead = self._flat(samples)
         nb, bsz = x3.shape[0], x3.shape[1]
         idx = torch.empty((nb, bsz), device=x3.device, dtype=torch.int64)
@@ -184,6 +240,10 @@ class CodebookModel(DistributionModel):
 
     def assignment_probs(self, samples: Tensor, with_entropy: bool = False):
         """softmax(energy / temperature) [*, B, K] (and its entropy [*, B]); differentiable with respect to ``samples``"""
+        if self._general:
+            e, x3, c3, lead = self._energy3(samples)
+            probs = softmax_rows(topk_energy(e, self.topk), 1.0 / self.temperature).reshape(*lead, x3.shape[1], self.n_components)
+            return (probs, D.Categorical(probs).entropy()) if with_entropy else probs
         x3, c3, lead = self._flat(samples)
         bsz = x3.shape[1]
         out = _AssignmentProbsFn.apply(x3, c3, self.temperature, with_entropy)
@@ -195,6 +255,9 @@ class CodebookModel(DistributionModel):
         """1 / (|x - c_k|_2 + 1e-8) [*, B, K] (codebook_model.py:150-156); only the tiny atoms-vs-atoms case of ``w2``
         goes through here, the assignment kernels never materialise it."""
         self._validate_samples(samples)
+        if self.metric != "euclidean" or self.p != 2.0:
+            e, x3, _, lead = self._energy3(samples)
+            return e.reshape(*lead, x3.shape[1], self.n_components).type_as(self.codebook)
         # (kept on torch.cdist: the Gumbel assignment modes differentiate through this value, and otvae_sqdist has no backward)
         return 1 / (torch.cdist(samples.type_as(self.codebook), self.codebook, self.p) + 1e-8)
 
@@ -212,13 +275,13 @@ class CodebookModel(DistributionModel):
         distribution = D.Categorical(probs)
         indices = distribution.sample()
         mode = self.mode
-        if mode == "mean":
+        if mode == "mean" or self.topk == 1:   # (base.py:228: with one atom left the soft weights are the one-hot weights)
             weights = probs
         elif mode == "sample":
             weights = F.one_hot(indices, self.n_components).type_as(probs)
         elif "gumbel" in mode:
             noise, self.gumbel_noise = getattr(self, "gumbel_noise", None), None   # injected draws are used once
-            weights = gumbel_weights(self.energy(samples), self.temperature, "hard" in mode, noise).type_as(probs)
+            weights = gumbel_weights(topk_energy(self.energy(samples), self.topk), self.temperature, "hard" in mode, noise).type_as(probs)
         else:
             _, idx = self._argmax(samples)
             weights = F.one_hot(idx, self.n_components).type_as(probs)
@@ -228,7 +291,7 @@ class CodebookModel(DistributionModel):
         """(weights @ codebook, sampled indices, assignment distribution) -- codebook_model.py:145-148.  In 'argmax'
         mode the product with a one-hot matrix is the gather the assignment kernel already did."""
         self._validate_samples(features)
-        if self.mode == "argmax" and not self.update_with_autograd:
+        if self.mode == "argmax" and not self.update_with_autograd and self.topk != 1:
             preds, _ = self._argmax(features)
             distribution = D.Categorical(self.assignment_probs(features))
             return preds.type_as(self.codebook), distribution.sample(), distribution

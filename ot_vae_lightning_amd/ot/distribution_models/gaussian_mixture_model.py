@@ -56,12 +56,11 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         cfg.update(mixture_cfg)
         if cfg["n_components"] is None:
             raise TypeError("mixture_cfg must give `n_components`")
-        if cfg["topk"] not in (None, 0):
-            raise NotImplementedError("topk assignment is not implemented on the MI355X path")
         for m in (cfg["training_mode"], cfg["inference_mode"]):
             if m not in MIXTURE_MODES:
                 raise NotImplementedError(f"assignment mode {m!r}: expected one of {MIXTURE_MODES}")
         self.n_components = int(cfg["n_components"])
+        self.topk = cfg["topk"]     # (metric and p do not enter a Gaussian mixture's energies, gassian_mixture_model.py:91-99)
         self.temperature = float(cfg["temperature"])
         self.training_mode, self.inference_mode = cfg["training_mode"], cfg["inference_mode"]
         self.kmeans_iter = int(cfg["kmeans_iter"])
@@ -184,12 +183,15 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
 
     def assign(self, samples: Tensor):
         """(assignment weights [*, B, K], sampled indices [*, B], Categorical(softmax weights)) -- base.py:206-239"""
-        energy = self.energy(samples)
+        from .codebook_model import topk_energy
+        energy = topk_energy(self.energy(samples), self.topk)     # base.py:217-220
         weights = softmax_rows(energy, 1.0 / self.temperature)
         distribution = D.Categorical(weights)
         indices = distribution.sample()
         mode = self.mode
-        if mode == "sample":
+        if mode == "mean" or self.topk == 1:
+            pass
+        elif mode == "sample":
             weights = F.one_hot(indices, self.n_components).type_as(weights)
         elif mode == "argmax":
             weights = F.one_hot(weights.argmax(-1), self.n_components).type_as(weights)

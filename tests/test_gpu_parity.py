@@ -1211,6 +1211,56 @@ def test_codebook_update_with_autograd(A, tag):
         model.update(x.detach())
 
 
+CODEBOOK_OPTION_CASES = [("cos_p2_mean", "cosine", 2.0, None, "mean", 0.5), ("cos_p1_argmax", "cosine", 1.0, None, "argmax", 1.0),
+                         ("cos_p05_mean_top3", "cosine", 0.5, 3, "mean", 0.7), ("euc_p1_mean", "euclidean", 1.0, None, "mean", 0.6),
+                         ("euc_p05_argmax", "euclidean", 0.5, None, "argmax", 1.0), ("euc_p3_mean_top2", "euclidean", 3.0, 2, "mean", 0.8),
+                         ("euc_p2_mean_top3", "euclidean", 2.0, 3, "mean", 0.5), ("euc_p2_argmax_top1", "euclidean", 2.0, 1, "argmax", 1.0),
+                         ("cos_p2_sample_top1", "cosine", 2.0, 1, "sample", 1.0)]
+
+
+@pytest.mark.parametrize("case", CODEBOOK_OPTION_CASES, ids=[c[0] for c in CODEBOOK_OPTION_CASES])
+def test_codebook_metric_p_topk(A, case):
+    """`CodebookModel` with `metric='cosine'`, p != 2 and `topk` (reference base.py:166-235, codebook_model.py:150-168) on
+    `otvae_codebook_energy/_bwd`: energies, predictions, assignment probabilities and the gradients of a seeded scalar with respect to
+    samples and (trained) codebook against the reference's own class (codebook_options.npz)."""
+    tag, metric, p, topk, mode, T = case
+    g = group(load_golden("codebook_options.npz"), tag)
+    K, d = g["codebook"].shape[-2:]
+    model = A.CodebookModel(2, d, mixture_cfg=dict(n_components=K, metric=metric, p=p, topk=topk, temperature=T, training_mode=mode,
+                                                   inference_mode=mode), update_with_autograd=True).cuda()
+    with torch.no_grad():
+        model.codebook.copy_(g["codebook"].cuda())
+    x = g["x"].cuda().requires_grad_(True)
+    model.train()
+    energy = model.energy(x)
+    preds, _, dist = model(x)
+    ((preds * g["s_pred"].cuda()).sum() + (dist.probs * g["s_prob"].cuda()).sum()).backward()
+    rep = Report(f"CodebookModel(metric={metric}, p={p}, topk={topk}, mode={mode}) vs the reference class")
+    rep.check("energy", energy, g["energy"], 2e-5)
+    rep.check("predictions", preds, g["preds"], 5e-5)
+    rep.check("assignment probabilities", dist.probs, g["probs"], 1e-4)
+    rep.check("d/d samples", x.grad, g["g_x"], 1e-3)
+    rep.check("d/d codebook", model.codebook.grad, g["g_codebook"], 1e-3)
+    rep.finish()
+
+
+@pytest.mark.parametrize("tag,topk,mode", [("gmm_top2_mean", 2, "mean"), ("gmm_top1_sample", 1, "sample"), ("gmm_top3_argmax", 3, "argmax")])
+def test_gmm_topk_assignment(A, tag, topk, mode):
+    """`GaussianMixtureModel(topk=k)`: MixtureMixin.assign restricted to the k most likely components (base.py:217-220,228)."""
+    g = group(load_golden("codebook_options.npz"), tag)
+    model = A.GaussianMixtureModel(3, mixture_cfg=dict(n_components=5, topk=topk, temperature=0.9, training_mode=mode, inference_mode=mode),
+                                   w2_cfg=dict(diag=True, make_pd=True, dtype=torch.double), dtype=torch.double).cuda()
+    with torch.no_grad():
+        model.mean.copy_(g["mean"].cuda())
+        model.parametrizations.cov.original.copy_(g["cov"].cuda())
+    model.eval()
+    w, _, dist = model.assign(g["x"].cuda())
+    rep = Report(f"GaussianMixtureModel(topk={topk}, mode={mode}).assign vs the reference class")
+    rep.check("assignment probabilities", dist.probs, g["probs"], 1e-9)
+    rep.check("weights", w, g["weights"], 1e-9)
+    rep.finish()
+
+
 def test_codebook_prior_with_trained_codebook(A):
     """CodebookPrior(loss='kl', soft mode) over a CodebookModel(update_with_autograd=True): encodings, loss and the gradients of
     (seeded encodings + loss) with respect to the latent and the codebook against the reference classes."""
@@ -2297,6 +2347,6 @@ def test_gaussian_mixture_model_on_the_references_recovery_experiment(A):
     streamed.fit()
     rep.check("update: component means", streamed.mean, torch.from_numpy(g["update_mean"]), 1e-9)
     rep.check("update: W2 to the sampling mixture", streamed.w2(truth_gpu), torch.from_numpy(g["w2_update"]), 1e-6)
-    with pytest.raises(NotImplementedError):
-        A.GaussianMixtureModel(*lead, dim, **{**cfg, "mixture_cfg": {**cfg["mixture_cfg"], "topk": 2}})
+    with pytest.raises(NotImplementedError):   # an assignment mode the reference does not have either (base.py:236-237)
+        A.GaussianMixtureModel(*lead, dim, **{**cfg, "mixture_cfg": {**cfg["mixture_cfg"], "training_mode": "nearest"}})
     rep.finish()

@@ -877,3 +877,32 @@ def test_nelbo_with_expansion():
                 assert (v.grad - g[f"grad/{pre}{k}"]).abs().max() < 2e-4 * gscale, k
             elif "running" in k:
                 assert rel_err(v, g[f"buf/{pre}{k}"]) < 1e-5, k
+
+
+CODEBOOK_OPTION_CASES = [("cos_p2_mean", "cosine", 2.0, None, "mean", 0.5), ("cos_p1_argmax", "cosine", 1.0, None, "argmax", 1.0),
+                         ("cos_p05_mean_top3", "cosine", 0.5, 3, "mean", 0.7), ("euc_p1_mean", "euclidean", 1.0, None, "mean", 0.6),
+                         ("euc_p05_argmax", "euclidean", 0.5, None, "argmax", 1.0), ("euc_p3_mean_top2", "euclidean", 3.0, 2, "mean", 0.8),
+                         ("euc_p2_mean_top3", "euclidean", 2.0, 3, "mean", 0.5), ("euc_p2_argmax_top1", "euclidean", 2.0, 1, "argmax", 1.0),
+                         ("cos_p2_sample_top1", "cosine", 2.0, 1, "sample", 1.0)]
+
+
+@pytest.mark.parametrize("case", CODEBOOK_OPTION_CASES, ids=[c[0] for c in CODEBOOK_OPTION_CASES])
+def test_codebook_metric_p_topk(case):
+    tag, metric, p, topk, mode, T = case
+    g = group(load_golden("codebook_options.npz"), tag)
+    x, cb = g["x"].clone().requires_grad_(True), g["codebook"].clone().requires_grad_(True)
+    e = O.codebook_energy_general(x, cb, metric, p)
+    assert rel_err(e, g["energy"]) < 1e-6
+    w, probs = O.mixture_assign(e, topk, T, "mean" if mode == "sample" else mode)
+    preds = w @ cb
+    assert rel_err(probs, g["probs"]) < 1e-5 and rel_err(preds, g["preds"]) < 1e-5
+    ((preds * g["s_pred"]).sum() + (probs * g["s_prob"]).sum()).backward()
+    assert rel_err(x.grad, g["g_x"]) < 1e-4 and rel_err(cb.grad, g["g_codebook"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag,topk,mode", [("gmm_top2_mean", 2, "mean"), ("gmm_top1_sample", 1, "sample"), ("gmm_top3_argmax", 3, "argmax")])
+def test_gmm_topk_assignment(tag, topk, mode):
+    g = group(load_golden("codebook_options.npz"), tag)
+    e = O.gmm_diag_energy(g["x"], g["mean"], g["cov"] + 1e-8, torch.full((5,), 0.2, dtype=torch.double))
+    w, probs = O.mixture_assign(e, topk, 0.9, "mean" if mode == "sample" else mode)
+    assert rel_err(probs, g["probs"]) < 1e-9 and rel_err(w, g["weights"]) < 1e-9
