@@ -106,6 +106,7 @@ CONV_CASES = [
     # down behind the convolution
     ("mod_up_bilinear", "ConvLayer", 4, 8, 4, dict(up_sample=torch.nn.Upsample(scale_factor=2, mode="bilinear"), normalization="batchnorm", activation="relu")),
     ("mod_down_avgpool", "ConvLayer", 4, 8, 8, dict(down_sample=torch.nn.AvgPool2d(2), normalization="batchnorm", activation="leaky")),
+    ("up4_relu", "ConvLayer", 4, 4, 2, dict(up_sample=4, normalization="batchnorm", activation="relu")),   # nn.Upsample(scale_factor=4), cnn.py:107
 ]
 
 

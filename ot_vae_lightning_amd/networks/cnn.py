@@ -77,7 +77,9 @@ class ConvLayer(nn.Module):
         elif isinstance(up_sample, int) and up_sample > 0:
             up = int(up_sample)
         if up not in (1, 2):
-            raise NotImplementedError(f"up_sample factor {up} is not supported on the MI355X path")
+            # the kernels fuse the nearest x2 up-sampling only; any other factor runs as the reference's own nn.Upsample module
+            # around them (the same route as a user-supplied module)
+            up_module, up = nn.Upsample(scale_factor=up), 1
         self.in_channels, self.out_channels = in_features, out_features
         self.kernel_size, self.stride, self.padding = (kernel_size, kernel_size), (stride, stride), (padding, padding)
         self._up = up

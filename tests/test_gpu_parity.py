@@ -162,6 +162,7 @@ CONV_CTOR = {
     # user-supplied resampling modules (cnn.py:97,106) around the layer's kernels
     "mod_up_bilinear": ("ConvLayer", dict(up_sample=torch.nn.Upsample(scale_factor=2, mode="bilinear"), normalization="batchnorm", activation="relu")),
     "mod_down_avgpool": ("ConvLayer", dict(down_sample=torch.nn.AvgPool2d(2), normalization="batchnorm", activation="leaky")),
+    "up4_relu": ("ConvLayer", dict(up_sample=4, normalization="batchnorm", activation="relu")),
 }
 
 

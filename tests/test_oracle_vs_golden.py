@@ -46,6 +46,7 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
     # (..., up module, down module): user-supplied resampling modules
     "mod_up_bilinear": (False, False, False, True, 3, "relu", None, None, 1, 1, None, torch.nn.Upsample(scale_factor=2, mode="bilinear"), None),
     "mod_down_avgpool": (False, False, False, True, 3, "leaky", None, None, 1, 1, None, None, torch.nn.AvgPool2d(2)),
+    "up4_relu": (False, False, False, True, 3, "relu", None, None, 1, 1, None, torch.nn.Upsample(scale_factor=4), None),
 }
 
 
