@@ -1069,6 +1069,7 @@ class _LayerNormFn(torch.autograd.Function):
                                       ptr(rstd), stream()), "otvae_layernorm_fwd")
         ctx.save_for_backward(s if s is not None else x2, gamma, mean, rstd)
         ctx.has_res = res is not None
+        ctx.pref = (gamma, beta)   # the parameters themselves: a trainer's flat-buffer slots hang on them (_grad_buffer)
         return y.reshape(x.shape)
 
     @staticmethod
@@ -1078,7 +1079,9 @@ class _LayerNormFn(torch.autograd.Function):
         m, d = xs.shape
         g2 = gy.reshape(m, d).contiguous()
         gx = torch.empty_like(xs)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        # written straight into the trainer's gradient slots when the parameters have them (one copy launch per parameter saved:
+        # 28 per step of the reference's ViT); a parameter normalising twice in one step would need accumulation: not on this path
+        dgamma, dbeta = _grad_buffer(ctx.pref[0], gamma), _grad_buffer(ctx.pref[1], gamma)
         ws = torch.empty(lib.otvae_layernorm_bwd_ws(m, d), device=xs.device, dtype=torch.float32)
         check(lib.otvae_layernorm_bwd(ptr(xs), ptr(g2), ptr(gamma), ptr(mean), ptr(rstd), m, d, ptr(gx), ptr(dgamma), ptr(dbeta),
                                       ptr(ws), stream()), "otvae_layernorm_bwd")
@@ -1103,6 +1106,7 @@ class _LayerNormDropoutFn(torch.autograd.Function):
                                               int(stream_id), ptr(s), ptr(y), ptr(mean), ptr(rstd), ptr(used), stream()),
               "otvae_layernorm_dropout_fwd")
         ctx.save_for_backward(s, gamma, mean, rstd, used)
+        ctx.pref = (gamma, beta)
         ctx.p = float(p)
         ctx.mark_non_differentiable(used)
         return y.reshape(x.shape), used
@@ -1114,7 +1118,7 @@ class _LayerNormDropoutFn(torch.autograd.Function):
         m, d = xs.shape
         g2 = gy.reshape(m, d).contiguous()
         gres, gx = torch.empty_like(xs), torch.empty_like(xs)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        dgamma, dbeta = _grad_buffer(ctx.pref[0], gamma), _grad_buffer(ctx.pref[1], gamma)
         ws = torch.empty(lib.otvae_layernorm_bwd_ws(m, d), device=xs.device, dtype=torch.float32)
         check(lib.otvae_layernorm_dropout_bwd(ptr(xs), ptr(g2), ptr(gamma), ptr(mean), ptr(rstd), m, d, ctx.p, ptr(used), ptr(gres),
                                               ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws), stream()), "otvae_layernorm_dropout_bwd")
