@@ -1280,6 +1280,65 @@ def gen_vit():
     save("vit.npz", out)
 
 
+VIT_VARIANTS = {
+    # name: (ctor kwargs, input kind) -- corners of the ViT constructor no golden of rounds 1-2 visits
+    "out_embed_and_class": (dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, mlp_dim=32, channels=2, n_embed_tokens=2,
+                                 output_tokens=["embed", "class"], num_classes=5), "image"),
+    "patches_in_patches_out": (dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, mlp_dim=32, channels=2, n_embed_tokens=1,
+                                    output_tokens="input", embed_to_patch=True), "image"),
+    "default_patch_rect_image": (dict(image_size=(8, 16), dim=16, depth=1, heads=4, channels=1, n_embed_tokens=1), "image"),
+    "preprocess_identity": (dict(image_size=8, patch_size=4, dim=16, depth=1, preprocess_depth=0, heads=2, mlp_dim=32, channels=2,
+                                 n_embed_tokens=2, output_tokens="embed", num_classes=3), "image"),
+    "class_only": (dict(image_size=8, patch_size=4, dim=16, depth=2, heads=2, mlp_dim=32, channels=2, n_embed_tokens=1,
+                        output_tokens="class", num_classes=3), "image"),
+    "tokens_in_embed_none": (dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, mlp_dim=32, channels=2, n_embed_tokens=None,
+                                  n_input_tokens=3, patch_to_embed=False, output_tokens="embed"), "tokens"),
+    "no_embed_tokens": (dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, mlp_dim=32, channels=2, n_embed_tokens=0,
+                             output_tokens="input"), "image"),
+    "time_output_without_time": (dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, channels=2, output_tokens="time"), "image"),
+    "bad_patch": (dict(image_size=10, patch_size=4, dim=16, depth=1, heads=2, channels=2), "image"),
+    "bad_output_token": (dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, channels=2, output_tokens="latent"), "image"),
+}
+
+
+def gen_vit_variants():
+    """The ViT at corners of its constructor (networks/vit.py:71-193): several output token types, patches in -> patches out, the
+    default patch size on a rectangular image, `preprocess_depth=0`, the class token as only output, token inputs with
+    `n_embed_tokens=None`, no embed tokens; and the exception types of invalid configurations.  dropout 0, closed-form weights."""
+    vit = R.ref("networks.vit")
+    out = {}
+    B = 3
+    for name, (kw, kind) in VIT_VARIANTS.items():
+        try:
+            net = vit.ViT(dropout=0.0, emb_dropout=0., **kw)
+            net.train()
+            fill_vit_state_dict(net.state_dict())
+            if kind == "image":
+                h, w = kw["image_size"] if isinstance(kw["image_size"], tuple) else (kw["image_size"],) * 2
+                x = det_input((B, kw["channels"], h, w), 0.3)
+            else:
+                x = det_input((B, kw["n_input_tokens"], kw["dim"]), 0.8)
+            x = x.clone().requires_grad_(True)
+            labels = torch.arange(B) % kw["num_classes"] if kw.get("num_classes") else None
+            y = net(x, labels=labels)
+            g = det_input(tuple(y.shape), 1.1, 0.5)
+            y.backward(g)
+        except Exception as e:  # noqa: BLE001 -- a corner the reference rejects (or breaks on): the error type is the golden
+            out[f"{name}/error"] = np.frombuffer(type(e).__name__.encode(), dtype=np.uint8)
+            print(f"  {name}: the reference raises {type(e).__name__}: {str(e)[:90]}")
+            continue
+        out[f"{name}/x"], out[f"{name}/y"], out[f"{name}/gy"], out[f"{name}/gx"] = npy(x), npy(y), npy(g), npy(x.grad)
+        out[f"{name}/out_size"] = np.array(list(net.out_size))
+        out[f"{name}/param_names"] = np.array([k for k, _ in net.state_dict().items()])
+        out[f"{name}/param_shapes"] = np.array([";".join(str(d) for d in v.shape) for _, v in net.state_dict().items()])
+        if labels is not None:
+            out[f"{name}/labels"] = npy(labels)
+        for k, p in net.named_parameters():
+            out[f"{name}/grad/{k}"] = npy(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)
+        print(f"  {name}: y {tuple(y.shape)}")
+    save("vit_variants.npz", out)
+
+
 def gen_vit_causal():
     """G16: the d32 ViT of G12 with ``causal_mask=True`` (every layer's attention sees tokens <= t only,
     networks/vit.py:215-217,225): output and input gradient for both roles."""
@@ -1621,6 +1680,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants"]
     for w in which:
         globals()["gen_" + w]()

@@ -331,6 +331,8 @@ class ViT(nn.Module):
         """tokens[:, indices]: a slice when the indices are one run (an index LIST would be uploaded from the host on every
         call, which a graph capture cannot hold), else through a device-resident index tensor"""
         idx = self.output_tokens_indices if which == "output" else self.cross_tokens_indices
+        if not idx:   # e.g. output_tokens='time' without a time token: the reference's tokens[:, []] is an empty selection too
+            return tokens[:, :0]
         if idx == list(range(idx[0], idx[0] + len(idx))):
             return tokens[:, idx[0]:idx[0] + len(idx)]
         cache = self.__dict__.setdefault("_index_cache", {})

@@ -1951,6 +1951,69 @@ def test_vit_vs_reference_golden(A, tag, role):
     assert tuple(net.out_size) == tuple(y.shape[1:])
 
 
+VIT_VARIANTS = {   # oracle/gen_golden.py: VIT_VARIANTS
+    "out_embed_and_class": dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, mlp_dim=32, channels=2, n_embed_tokens=2,
+                                output_tokens=["embed", "class"], num_classes=5),
+    "patches_in_patches_out": dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, mlp_dim=32, channels=2, n_embed_tokens=1,
+                                   output_tokens="input", embed_to_patch=True),
+    "default_patch_rect_image": dict(image_size=(8, 16), dim=16, depth=1, heads=4, channels=1, n_embed_tokens=1),
+    "preprocess_identity": dict(image_size=8, patch_size=4, dim=16, depth=1, preprocess_depth=0, heads=2, mlp_dim=32, channels=2,
+                                n_embed_tokens=2, output_tokens="embed", num_classes=3),
+    "class_only": dict(image_size=8, patch_size=4, dim=16, depth=2, heads=2, mlp_dim=32, channels=2, n_embed_tokens=1,
+                       output_tokens="class", num_classes=3),
+    "tokens_in_embed_none": dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, mlp_dim=32, channels=2, n_embed_tokens=None,
+                                 n_input_tokens=3, patch_to_embed=False, output_tokens="embed"),
+    "no_embed_tokens": dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, mlp_dim=32, channels=2, n_embed_tokens=0,
+                            output_tokens="input"),
+    "time_output_without_time": dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, channels=2, output_tokens="time"),
+    "bad_patch": dict(image_size=10, patch_size=4, dim=16, depth=1, heads=2, channels=2),
+    "bad_output_token": dict(image_size=8, patch_size=4, dim=16, depth=1, heads=2, channels=2, output_tokens="latent"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VIT_VARIANTS))
+def test_vit_constructor_corners_vs_reference_golden(A, name):
+    """The ViT at corners of its constructor against the reference's own class (vit_variants.npz): several output token types,
+    patches in -> patches out, the default patch size on a rectangular image, `preprocess_depth=0`, the class token as the only
+    output, token inputs with `n_embed_tokens=None`, no embed tokens, an empty output selection; state_dict keys and shapes, `out_size`,
+    output, input gradient and every parameter gradient; where the reference raises, the same exception type."""
+    from detfill import fill_vit_state_dict
+    z = load_golden("vit_variants.npz")
+    kw = VIT_VARIANTS[name]
+    if f"{name}/error" in z.files:
+        want = bytes(z[f"{name}/error"].astype("uint8")).decode()
+        with pytest.raises(Exception) as info:
+            net = A.ViT(dropout=0.0, emb_dropout=0., **kw)
+        assert type(info.value).__name__ == want, (type(info.value).__name__, want)
+        return
+    names = [str(n) for n in z[f"{name}/param_names"]]
+    shapes = [tuple(int(d) for d in str(sh).split(";") if d) for sh in z[f"{name}/param_shapes"]]
+    g = {k[len(name) + 1:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "/") and "param_" not in k}
+    net = A.ViT(dropout=0.0, emb_dropout=0., **kw)
+    sd = net.state_dict()
+    assert list(sd.keys()) == names or set(sd.keys()) == set(names), (sorted(set(sd) ^ set(names)))
+    assert all(tuple(sd[k].shape) == sh for k, sh in zip(names, shapes))
+    ordered = {k: torch.zeros(sh) for k, sh in zip(names, shapes)}      # the reference's key order decides the fill phases
+    fill_vit_state_dict(ordered)
+    net.load_state_dict(ordered)
+    net = net.cuda().train()
+    assert list(net.out_size) == [int(v) for v in g["out_size"]]
+    x = g["x"].cuda().requires_grad_(True)
+    labels = g["labels"].cuda() if "labels" in g else None
+    y = net(x, labels=labels)
+    rep = Report(f"ViT corner `{name}` vs reference golden")
+    assert tuple(y.shape) == tuple(g["y"].shape)
+    if y.numel():
+        y.backward(g["gy"].cuda())
+        rep.check("output", y, g["y"], 1e-5)
+        rep.check("input gradient", x.grad, g["gx"], 2e-4)
+        gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith("grad/"))
+        for k, p in net.named_parameters():
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            rep.check(f"grad/{k}", got, g[f"grad/{k}"], tol=1e-3, floor=1e-2 * gscale)
+    rep.finish()
+
+
 @pytest.mark.parametrize("role", ["enc", "dec"])
 def test_vit_with_causal_mask_vs_reference_golden(A, role):
     """``ViT(causal_mask=True)`` (reference networks/vit.py:215-217,225: every layer's attention restricted to tokens <= t)
