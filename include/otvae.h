@@ -257,6 +257,16 @@ int otvae_gaussian_prior_cond_bwd(const float* h, const float* eps, const float*
                                   const float* gz, const float* gloss, int B, int n, float coeff, float* gh,
                                   float* g_prior_mean, float* g_prior_log_std, void* stream);
 
+/* The same with the options ConditionalGaussianPrior inherits from GaussianPrior (prior/conditional_gaussian.py:44-50 over
+ * prior/gaussian.py:58-96, prior/base.py:65-68): mode bit 0 = empirical_kl (log q(z) - log p_y(z)), bit 1 = fixed_var (unit variance, h
+ * holds the means only), and a re-parametrisation dimension other than 1: h [B][S][2 D] ([B][S][D] with fixed_var) = torch.chunk on a
+ * dimension with S entries in front of it; eps, z and the gathered prior rows [B][S * D]. */
+int otvae_gaussian_prior_cond_ex_fwd(const float* h, const float* eps, const float* prior_mean, const float* prior_log_std, int B, int S,
+                                     int D, float coeff, int mode, float* z, float* loss, void* stream);
+int otvae_gaussian_prior_cond_ex_bwd(const float* h, const float* eps, const float* prior_mean, const float* prior_log_std,
+                                     const float* gz, const float* gloss, int B, int S, int D, float coeff, int mode, float* gh,
+                                     float* g_prior_mean, float* g_prior_log_std, void* stream);
+
 /* ---- VAE.nelbo reduction (model/vae.py:158-176) ----------------------------------------------------------- */
 /* out[3] = {total, recon, prior}: recon = mean((pred-target)^2) over numel entries, prior = mean(prior_loss[0..B))/chw.
  * B = the number of entries of prior_loss: one per latent the prior saw = expansion * batch (model/vae.py:165-169,

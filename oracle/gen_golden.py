@@ -457,6 +457,56 @@ def gen_prior():
     save("prior.npz", out)
 
 
+PRIOR_CORNERS = {
+    # name: (class, kwargs, x shape, labels?) -- re-parametrisation dimensions other than 1 and the options ConditionalGaussianPrior inherits
+    "g_reparam2": ("GaussianPrior", dict(loss_coeff=0.4, reparam_dim=2), (5, 3, 8), False),
+    "g_reparam_last_4d": ("GaussianPrior", dict(loss_coeff=1.0, reparam_dim=-1), (4, 2, 3, 6), False),
+    "g_reparam2_empirical": ("GaussianPrior", dict(loss_coeff=0.6, reparam_dim=2, empirical_kl=True), (5, 3, 8), False),
+    "c_empirical": ("ConditionalGaussianPrior", dict(dim=(6, 1, 1), num_classes=4, loss_coeff=0.3, empirical_kl=True), (6, 12, 1, 1), True),
+    "c_fixed_var": ("ConditionalGaussianPrior", dict(dim=(6, 1, 1), num_classes=4, loss_coeff=0.8, fixed_var=True), (6, 6, 1, 1), True),
+    "c_fixed_empirical": ("ConditionalGaussianPrior", dict(dim=(2, 5), num_classes=3, loss_coeff=1.2, fixed_var=True, empirical_kl=True), (6, 2, 5), True),
+    "c_reparam2": ("ConditionalGaussianPrior", dict(dim=(3, 4), num_classes=5, loss_coeff=0.5, reparam_dim=2), (6, 3, 8), True),
+    "c_reparam2_ema": ("ConditionalGaussianPrior", dict(dim=(3, 4), num_classes=5, loss_coeff=0.5, reparam_dim=2, embedding_ema_decay=0.9), (6, 3, 8), True),
+}
+
+
+def gen_prior_corners():
+    """GaussianPrior with `reparam_dim` != 1 and ConditionalGaussianPrior with the options it inherits (empirical_kl, fixed_var,
+    reparam_dim; prior/gaussian.py:58-96, prior/conditional_gaussian.py:44-93): z, loss and the gradients of a seeded scalar with
+    respect to the input and the class embeddings, `out_size`; for the EMA variant the buffers after the step."""
+    pg, pc = R.ref("prior.gaussian"), R.ref("prior.conditional_gaussian")
+    out = {}
+    for name, (cls, kw, xshape, cond) in PRIOR_CORNERS.items():
+        torch.manual_seed(31)
+        prior = (pg.GaussianPrior if cls == "GaussianPrior" else pc.ConditionalGaussianPrior)(**kw)
+        prior.train()
+        x = det_input(xshape, 0.4, 0.8).requires_grad_(True)
+        zshape = list(xshape)
+        if not kw.get("fixed_var", False):
+            zshape[kw.get("reparam_dim", 1)] //= 2
+        eps = normal(tuple(zshape), seed=9)
+        labels = (torch.arange(xshape[0]) * 2 + 1) % kw["num_classes"] if cond else None
+        with _FixedEps(eps):
+            z, loss, art = prior(x, step=0, **({"labels": labels} if cond else {}))
+        gz, gl = det_input(tuple(z.shape), 2.2), det_input(tuple(loss.shape), 0.1)
+        (z * gz).sum().add((loss * gl).sum()).backward()
+        out[f"{name}/x"], out[f"{name}/eps"], out[f"{name}/z"], out[f"{name}/loss"] = npy(x), npy(eps), npy(z), npy(loss)
+        out[f"{name}/gz"], out[f"{name}/gl"], out[f"{name}/gx"] = npy(gz), npy(gl), npy(x.grad)
+        out[f"{name}/out_size"] = np.array(list(prior.out_size(torch.Size(xshape[1:]))))
+        if cond:
+            out[f"{name}/labels"] = npy(labels)
+            for k, v in prior.state_dict().items():
+                out[f"{name}/state/{k}"] = npy(v)
+            for k, p in prior.named_parameters():
+                if p.grad is not None:
+                    out[f"{name}/grad/{k}"] = npy(p.grad)
+            # the embeddings BEFORE the step (the EMA variant rewrites them): regenerated from the seed by the tests
+            torch.manual_seed(31)
+            ref0 = pc.ConditionalGaussianPrior(**kw)
+            out[f"{name}/init/_mu.weight"], out[f"{name}/init/_log_std.weight"] = npy(ref0._mu.weight), npy(ref0._log_std.weight)
+    save("prior_corners.npz", out)
+
+
 # ------------------------------------------------------------------------------------------------ G6
 def gen_sinkhorn():
     w2 = R.ref("ot.w2_utils")
@@ -1680,6 +1730,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners"]
     for w in which:
         globals()["gen_" + w]()

@@ -250,6 +250,28 @@ def gaussian_prior_encode_options(x: Tensor, eps: Tensor, loss_coeff: float = 1.
     return z, loss * loss_coeff
 
 
+def prior_encode_general(x: Tensor, eps: Tensor, loss_coeff: float = 1.0, empirical_kl: bool = False, fixed_var: bool = False,
+                         reparam_dim: int = 1, prior_mean: Optional[Tensor] = None, prior_log_std: Optional[Tensor] = None):
+    """``GaussianPrior.encode`` / ``ConditionalGaussianPrior.encode`` in full generality (prior/gaussian.py:63-96,
+    prior/conditional_gaussian.py:81-93, prior/base.py:65-68): q from ``reparametrization`` (fixed_var: N(x, 1); else chunk(x, 2,
+    reparam_dim) -> N(mu, exp(log_var / 2))), p = N(0, 1) or N(prior_mean, exp(prior_log_std)) (the gathered class rows, shaped like
+    z), z = mu + eps sd, loss = closed-form KL(q || p) or log q(z) - log p(z), summed over the non-batch dimensions."""
+    if fixed_var:
+        mu, sd = x, torch.ones_like(x)
+    else:
+        mu, log_var = torch.chunk(x, 2, reparam_dim)
+        sd = (log_var / 2).exp()
+    z = mu + eps * sd
+    pm = torch.zeros_like(mu) if prior_mean is None else prior_mean.reshape(mu.shape)
+    ps = torch.ones_like(mu) if prior_log_std is None else prior_log_std.reshape(mu.shape).exp()
+    dims = list(range(1, mu.dim()))
+    if empirical_kl:
+        loss = (torch.distributions.Normal(mu, sd).log_prob(z) - torch.distributions.Normal(pm, ps).log_prob(z)).sum(dims)
+    else:
+        loss = torch.sum(0.5 * ((mu - pm) ** 2 / ps ** 2 + (ps ** 2).log() - (sd ** 2).log() + sd ** 2 / ps ** 2 - 1), dim=dims)
+    return z, loss * loss_coeff
+
+
 def vae_nelbo(x: Tensor, eps: Tensor, enc: Dict[str, Tensor], dec: Dict[str, Tensor], enc_arch, dec_arch,
               loss_coeff: float = 1.0, step: int = 0, annealing_steps: int = 0, training: bool = True, expansion: int = 1):
     """``VAE.nelbo`` (model/vae.py:165-189): loss = mse(mean over replicas of decode(z), x) + mean(prior)/(C*H*W).  ``expansion`` = n

@@ -214,6 +214,109 @@ extern "C" int otvae_gaussian_prior_cond_bwd(const float* h, const float* eps, c
     return OTVAE_OK;
 }
 
+// ---- ConditionalGaussianPrior with the options it inherits (prior/conditional_gaussian.py:44-93 over prior/gaussian.py:58-96,
+// prior/base.py:65-68): empirical_kl (mode bit 0), fixed_var (bit 1) and a re-parametrisation dimension other than 1.  h is
+// [B][S][2 D] (fixed_var: [B][S][D]): within each of the S slices the first D entries are the means, the next D the log-variances
+// (torch.chunk on dimension r of a contiguous tensor: S = the sizes in front of r, D = half of r's size times the sizes behind it).
+// eps / z / pm / pl are [B][S * D].  With l = log sigma_p, ip = exp(-2 l), dm = mu - mu_p, lsd = log sigma_q (0 when fixed):
+//   closed form   KL = l - lsd + (sigma_q^2 + dm^2) ip / 2 - 1/2
+//   empirical     KL = log q(z) - log p(z) = ((z - mu_p)^2 ip - eps^2) / 2 - lsd + l,   z = mu + eps sigma_q
+__global__ __launch_bounds__(256) void gaussian_prior_cond_ex_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                                                         const float* __restrict__ pm, const float* __restrict__ pl,
+                                                                         int S, int D, float coeff, int mode, float* __restrict__ z,
+                                                                         float* __restrict__ loss) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, n = S * D;
+    const bool emp = mode & 1, fixed = mode & 2;
+    const float* hb = h + (size_t)b * S * (fixed ? D : 2 * D);
+    float kl = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int s = i / D, d = i - s * D;
+        const float mu = fixed ? hb[i] : hb[(size_t)s * 2 * D + d];
+        const float lsd = fixed ? 0.f : 0.5f * hb[(size_t)s * 2 * D + D + d];
+        const float sd = fixed ? 1.f : __expf(lsd);
+        const float e = eps[(size_t)b * n + i];
+        const float zz = fmaf(e, sd, mu);
+        z[(size_t)b * n + i] = zz;
+        const float l = pl[(size_t)b * n + i], ip = __expf(-2.f * l), mp = pm[(size_t)b * n + i];
+        if (emp) {
+            const float dz = zz - mp;
+            kl += 0.5f * (dz * dz * ip - e * e) - lsd + l;
+        } else {
+            const float dm = mu - mp;
+            kl += l - lsd + 0.5f * (sd * sd + dm * dm) * ip - 0.5f;
+        }
+    }
+    kl = wave_sum(kl);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kl;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[b] = coeff * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void gaussian_prior_cond_ex_bwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                                                         const float* __restrict__ pm, const float* __restrict__ pl,
+                                                                         const float* __restrict__ gz, const float* __restrict__ gloss,
+                                                                         int S, int D, float coeff, int mode, float* __restrict__ gh,
+                                                                         float* __restrict__ gpm, float* __restrict__ gpl) {
+    const int b = blockIdx.x, n = S * D;
+    const bool emp = mode & 1, fixed = mode & 2;
+    const size_t row = (size_t)S * (fixed ? D : 2 * D);
+    const float* hb = h + (size_t)b * row;
+    float* gb = gh + (size_t)b * row;
+    const float gl = (gloss ? gloss[b] : 0.f) * coeff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int s = i / D, d = i - s * D;
+        const float mu = fixed ? hb[i] : hb[(size_t)s * 2 * D + d];
+        const float lsd = fixed ? 0.f : 0.5f * hb[(size_t)s * 2 * D + D + d];
+        const float sd = fixed ? 1.f : __expf(lsd);
+        const float e = eps[(size_t)b * n + i];
+        const float g = gz ? gz[(size_t)b * n + i] : 0.f;
+        const float l = pl[(size_t)b * n + i], ip = __expf(-2.f * l), mp = pm[(size_t)b * n + i];
+        float dmu, dlv, dmp, dl;   // d KL / d (mu, log_var, mu_p, l)
+        if (emp) {
+            const float dz = fmaf(e, sd, mu) - mp;
+            dmu = dz * ip;
+            dlv = 0.5f * (dz * ip * e * sd) - 0.5f;
+            dmp = -dz * ip;
+            dl = 1.f - dz * dz * ip;
+        } else {
+            const float dm = mu - mp;
+            dmu = dm * ip;
+            dlv = 0.5f * (sd * sd * ip - 1.f);
+            dmp = -dm * ip;
+            dl = 1.f - (sd * sd + dm * dm) * ip;
+        }
+        if (fixed) {
+            gb[i] = fmaf(gl, dmu, g);
+        } else {
+            gb[(size_t)s * 2 * D + d] = fmaf(gl, dmu, g);
+            gb[(size_t)s * 2 * D + D + d] = fmaf(gl, dlv, 0.5f * g * e * sd);
+        }
+        if (gpm) gpm[(size_t)b * n + i] = gl * dmp;
+        if (gpl) gpl[(size_t)b * n + i] = gl * dl;
+    }
+}
+
+extern "C" int otvae_gaussian_prior_cond_ex_fwd(const float* h, const float* eps, const float* prior_mean, const float* prior_log_std,
+                                                int B, int S, int D, float coeff, int mode, float* z, float* loss, void* stream) {
+    OTVAE_REQUIRE(h && eps && prior_mean && prior_log_std && z && loss && B > 0 && S > 0 && D > 0 && mode >= 0 && mode <= 3,
+                  "otvae_gaussian_prior_cond_ex_fwd: bad argument");
+    gaussian_prior_cond_ex_fwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(h, eps, prior_mean, prior_log_std, S, D, coeff, mode, z, loss);
+    OTVAE_CHECK_LAUNCH("otvae_gaussian_prior_cond_ex_fwd");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_gaussian_prior_cond_ex_bwd(const float* h, const float* eps, const float* prior_mean, const float* prior_log_std,
+                                                const float* gz, const float* gloss, int B, int S, int D, float coeff, int mode,
+                                                float* gh, float* g_prior_mean, float* g_prior_log_std, void* stream) {
+    OTVAE_REQUIRE(h && eps && prior_mean && prior_log_std && gh && B > 0 && S > 0 && D > 0 && mode >= 0 && mode <= 3,
+                  "otvae_gaussian_prior_cond_ex_bwd: bad argument");
+    gaussian_prior_cond_ex_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(h, eps, prior_mean, prior_log_std, gz, gloss, S, D, coeff, mode,
+                                                                          gh, g_prior_mean, g_prior_log_std);
+    OTVAE_CHECK_LAUNCH("otvae_gaussian_prior_cond_ex_bwd");
+    return OTVAE_OK;
+}
+
 // ---- nelbo ---------------------------------------------------------------------------------------------------
 #define NELBO_PARTS 256
 extern "C" int otvae_nelbo_ws(void) { return NELBO_PARTS + 8; }

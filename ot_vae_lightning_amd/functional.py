@@ -1402,54 +1402,114 @@ class _GaussianPriorExFn(torch.autograd.Function):
     ``otvae_gaussian_prior_ex_fwd / _bwd`` on h flattened to [B, S = 1, D (or 2D)]."""
 
     @staticmethod
-    def forward(ctx, h, eps, temp, coeff, mode):
+    def forward(ctx, h, eps, temp, coeff, mode, s_):
         lib = _lib.load()
         b = h.shape[0]
-        d = h.shape[1] if mode & 2 else h.shape[1] // 2
-        z = torch.empty((b, d), device=h.device, dtype=torch.float32)
+        d = (h.shape[1] if mode & 2 else h.shape[1] // 2) // s_
+        z = torch.empty((b, s_ * d), device=h.device, dtype=torch.float32)
         loss = torch.empty(b, device=h.device, dtype=torch.float32)
-        check(lib.otvae_gaussian_prior_ex_fwd(ptr(h), ptr(eps), ptr(temp), b, 1, d, float(coeff), int(mode), ptr(z), ptr(loss), stream()),
+        check(lib.otvae_gaussian_prior_ex_fwd(ptr(h), ptr(eps), ptr(temp), b, s_, d, float(coeff), int(mode), ptr(z), ptr(loss), stream()),
               "otvae_gaussian_prior_ex_fwd")
         ctx.save_for_backward(h, eps, temp)
-        ctx.cfg = (float(coeff), int(mode), d)
+        ctx.cfg = (float(coeff), int(mode), d, int(s_))
         ctx.set_materialize_grads(False)
         return z, loss
 
     @staticmethod
     def backward(ctx, gz, gloss):
         if gz is None and gloss is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         h, eps, temp = ctx.saved_tensors
-        coeff, mode, d = ctx.cfg
+        coeff, mode, d, s_ = ctx.cfg
         gh = torch.empty_like(h)
         gz = gz.contiguous() if gz is not None else None
         gloss = gloss.contiguous() if gloss is not None else None
-        check(_lib.load().otvae_gaussian_prior_ex_bwd(ptr(h), ptr(eps), ptr(temp), ptr(gz), ptr(gloss), h.shape[0], 1, d, coeff, mode,
+        check(_lib.load().otvae_gaussian_prior_ex_bwd(ptr(h), ptr(eps), ptr(temp), ptr(gz), ptr(gloss), h.shape[0], s_, d, coeff, mode,
                                                       ptr(gh), stream()), "otvae_gaussian_prior_ex_bwd")
-        return gh, None, None, None, None
+        return gh, None, None, None, None, None
+
+
+def _reparam_layout(h: Tensor, reparam_dim: int, fixed_var: bool):
+    """(S, out_shape) of ``torch.chunk(h, 2, reparam_dim)`` on a contiguous h: within each of the S = prod(sizes between the batch and
+    the chunked dimension) slices the first half holds the means and the second the log-variances, which is the [B][S][2 D] layout
+    the kernels read in place (no gather of the two halves).  fixed_var: nothing is chunked."""
+    r = reparam_dim if reparam_dim >= 0 else h.dim() + reparam_dim
+    if fixed_var:
+        return 1, list(h.shape)
+    if not 1 <= r < h.dim():
+        raise ValueError(f"`reparam_dim`={reparam_dim} must address a non-batch dimension of a {h.dim()}-d input")
+    if h.shape[r] % 2:
+        raise ValueError(f"dimension {r} of size {h.shape[r]} cannot be split into mean and log-variance halves")
+    s_ = 1
+    for k in range(1, r):
+        s_ *= h.shape[k]
+    out_shape = list(h.shape)
+    out_shape[r] //= 2
+    return s_, out_shape
 
 
 def gaussian_prior_ex(h: Tensor, eps: Tensor, coeff: float, empirical_kl: bool = False, fixed_var: bool = False,
-                      temperature: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-    """(z, coeff * loss[B]) of ``GaussianPrior(empirical_kl=, fixed_var=)`` (reference prior/gaussian.py:63-96, prior/base.py:65-68)
-    for h [B, 2C, ...] re-parametrised on dim 1 (fixed_var: [B, C, ...], z = h + s eps with s = 1 or temperature[b] + 1e-8)."""
+                      temperature: Optional[Tensor] = None, reparam_dim: int = 1) -> Tuple[Tensor, Tensor]:
+    """(z, coeff * loss[B]) of ``GaussianPrior(empirical_kl=, fixed_var=, reparam_dim=)`` (reference prior/gaussian.py:63-96,
+    prior/base.py:65-68) for h re-parametrised on ``reparam_dim`` (fixed_var: z = h + s eps with s = 1 or temperature[b] + 1e-8)."""
     _lib.require_cuda(h, "prior input")
     b = h.shape[0]
-    out_shape = list(h.shape)
-    if not fixed_var:
-        out_shape[1] //= 2
-        # mu | log_var are the two halves of dim 1: flattened per half so that the kernel sees [B, 2 n]
-        mu, lv = h.chunk(2, dim=1)
-        flat = torch.cat([mu.reshape(b, -1), lv.reshape(b, -1)], dim=1)
-    else:
-        flat = h.reshape(b, -1)
+    s_, out_shape = _reparam_layout(h, reparam_dim, fixed_var)
+    flat = h.contiguous().reshape(b, -1)
     temp = None
     if temperature is not None:
         if not fixed_var:
             raise ValueError("a temperature (`time`) is only meaningful with fixed_var=True")
         temp = temperature.reshape(b).float().contiguous()
     mode = (1 if empirical_kl else 0) | (2 if fixed_var else 0)
-    z, loss = _GaussianPriorExFn.apply(flat.float().contiguous(), eps.reshape(b, -1).float().contiguous(), temp, float(coeff), mode)
+    z, loss = _GaussianPriorExFn.apply(flat.float(), eps.reshape(b, -1).float().contiguous(), temp, float(coeff), mode, s_)
+    return z.reshape(out_shape), loss
+
+
+class _CondGaussianPriorExFn(torch.autograd.Function):
+    """``ConditionalGaussianPrior`` with empirical_kl / fixed_var / a re-parametrisation dimension other than 1:
+    ``otvae_gaussian_prior_cond_ex_fwd / _bwd``"""
+
+    @staticmethod
+    def forward(ctx, h, eps, pm, pl, coeff, mode, s_):
+        lib = _lib.load()
+        b, n = eps.shape
+        z = torch.empty_like(eps)
+        loss = torch.empty(b, device=h.device, dtype=torch.float32)
+        check(lib.otvae_gaussian_prior_cond_ex_fwd(ptr(h), ptr(eps), ptr(pm), ptr(pl), b, s_, n // s_, float(coeff), int(mode), ptr(z),
+                                                   ptr(loss), stream()), "otvae_gaussian_prior_cond_ex_fwd")
+        ctx.save_for_backward(h, eps, pm, pl)
+        ctx.cfg = (float(coeff), int(mode), int(s_))
+        ctx.set_materialize_grads(False)
+        return z, loss
+
+    @staticmethod
+    def backward(ctx, gz, gloss):
+        if gz is None and gloss is None:
+            return (None,) * 7
+        h, eps, pm, pl = ctx.saved_tensors
+        coeff, mode, s_ = ctx.cfg
+        b, n = eps.shape
+        gz = gz.contiguous() if gz is not None else None
+        gloss = gloss.contiguous() if gloss is not None else None
+        gh = torch.empty_like(h)
+        gpm = torch.empty_like(pm) if ctx.needs_input_grad[2] else None
+        gpl = torch.empty_like(pl) if ctx.needs_input_grad[3] else None
+        check(_lib.load().otvae_gaussian_prior_cond_ex_bwd(ptr(h), ptr(eps), ptr(pm), ptr(pl), ptr(gz), ptr(gloss), b, s_, n // s_, coeff,
+                                                           mode, ptr(gh), ptr(gpm), ptr(gpl), stream()), "otvae_gaussian_prior_cond_ex_bwd")
+        return gh, None, gpm, gpl, None, None, None
+
+
+def gaussian_prior_conditional_ex(h: Tensor, eps: Tensor, prior_mean: Tensor, prior_log_std: Tensor, coeff: float,
+                                  empirical_kl: bool = False, fixed_var: bool = False, reparam_dim: int = 1):
+    """(z, coeff * loss[B]) of ``ConditionalGaussianPrior`` with the options it inherits (prior/conditional_gaussian.py:84-93): the prior
+    rows [B, prod(dim)] are laid out like z."""
+    _lib.require_cuda(h, "prior input")
+    b = h.shape[0]
+    s_, out_shape = _reparam_layout(h, reparam_dim, fixed_var)
+    flat = lambda t: t.contiguous().reshape(b, -1).float()  # noqa: E731
+    mode = (1 if empirical_kl else 0) | (2 if fixed_var else 0)
+    z, loss = _CondGaussianPriorExFn.apply(flat(h), flat(eps), flat(prior_mean), flat(prior_log_std), float(coeff), mode, s_)
     return z.reshape(out_shape), loss
 
 

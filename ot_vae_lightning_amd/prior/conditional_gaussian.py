@@ -42,11 +42,15 @@ class ConditionalGaussianPrior(GaussianPrior, utils.DDPMixin):
 
     def _encode(self, x: Tensor, coeff: float, labels: Tensor, eps: Optional[Tensor] = None):
         shape = list(x.shape)
-        shape[1] //= 2
+        if not self.fixed_var:
+            shape[self.reparam_dim] //= 2
         if eps is None:
             eps = torch.randn(shape, device=x.device, dtype=x.dtype)
         pm, pl = self._mu(labels), self._log_std(labels)            # [B, prod(dim)] rows of the class embeddings
-        z, loss = HF.gaussian_prior_conditional(x, eps, pm, pl, coeff)
+        if self.fixed_var or self.empirical_kl or self.reparam_dim not in (1, 1 - x.dim()):
+            z, loss = HF.gaussian_prior_conditional_ex(x, eps, pm, pl, coeff, self.empirical_kl, self.fixed_var, self.reparam_dim)
+        else:
+            z, loss = HF.gaussian_prior_conditional(x, eps, pm, pl, coeff)
         q = self.reparametrization(x.detach())
         if self.decay is not None and self.decay > 0 and self.training:
             self.ema_update(q, labels)

@@ -37,9 +37,6 @@ class GaussianPrior(Prior):
     def __init__(self, loss_coeff: float = 1., empirical_kl: bool = False, reparam_dim: int = 1,
                  annealing_steps: int = 0, fixed_var: bool = False):
         super().__init__(loss_coeff, annealing_steps)
-        if reparam_dim != 1:
-            raise NotImplementedError("GaussianPrior on the MI355X path re-parametrises on dim 1 (every configuration of the "
-                                      "reference does)")
         self.empirical_kl, self.reparam_dim, self.fixed_var = empirical_kl, reparam_dim, fixed_var
 
     def out_size(self, size):
@@ -63,11 +60,11 @@ class GaussianPrior(Prior):
     def _encode(self, x: Tensor, coeff: float, eps: Optional[Tensor] = None, time: Optional[Tensor] = None):
         shape = list(x.shape)
         if not self.fixed_var:
-            shape[1] //= 2
+            shape[self.reparam_dim] //= 2
         if eps is None:
             eps = torch.randn(shape, device=x.device, dtype=x.dtype)
-        if self.fixed_var or self.empirical_kl:
-            z, loss = HF.gaussian_prior_ex(x, eps, coeff, self.empirical_kl, self.fixed_var, time)
+        if self.fixed_var or self.empirical_kl or self.reparam_dim not in (1, 1 - x.dim()):
+            z, loss = HF.gaussian_prior_ex(x, eps, coeff, self.empirical_kl, self.fixed_var, time, self.reparam_dim)
         else:
             z, loss = HF.gaussian_prior(x, eps, coeff)
         zd = z.detach()  # the lazily built distributions must not keep this step's autograd graph alive

@@ -1262,6 +1262,39 @@ def test_gmm_topk_assignment(A, tag, topk, mode):
     rep.finish()
 
 
+@pytest.mark.parametrize("name", ["g_reparam2", "g_reparam_last_4d", "g_reparam2_empirical", "c_empirical", "c_fixed_var", "c_fixed_empirical",
+                                  "c_reparam2", "c_reparam2_ema"])
+def test_prior_corners_vs_reference_golden(A, name):
+    """GaussianPrior with `reparam_dim` != 1 and ConditionalGaussianPrior with the options it inherits (empirical_kl, fixed_var,
+    reparam_dim; prior/gaussian.py:58-96, prior/conditional_gaussian.py:44-93) against the reference's own classes (prior_corners.npz):
+    z, loss, `out_size`, the gradients with respect to the input and the class embeddings; EMA variant: the buffers after the step."""
+    from test_oracle_vs_golden import PRIOR_CORNERS
+    g = group(load_golden("prior_corners.npz"), name)
+    cls, kw = PRIOR_CORNERS[name]
+    prior = getattr(A, cls)(**kw).cuda().train()
+    cond = cls == "ConditionalGaussianPrior"
+    if cond:
+        with torch.no_grad():
+            prior._mu.weight.copy_(g["init/_mu.weight"].cuda())
+            prior._log_std.weight.copy_(g["init/_log_std.weight"].cuda())
+    x = g["x"].cuda().requires_grad_(True)
+    extra = {"labels": g["labels"].cuda()} if cond else {}
+    z, loss, _ = prior(x, step=0, eps=g["eps"].cuda(), **extra)
+    ((z * g["gz"].cuda()).sum() + (loss * g["gl"].cuda()).sum()).backward()
+    rep = Report(f"{cls}({kw}) vs the reference class")
+    assert list(prior.out_size(torch.Size(tuple(x.shape[1:])))) == [int(v) for v in g["out_size"]] and tuple(z.shape) == tuple(g["z"].shape)
+    rep.check("z", z, g["z"], 1e-6)
+    rep.check("loss", loss, g["loss"], 1e-5)
+    rep.check("d/d input", x.grad, g["gx"], 1e-5)
+    if cond:
+        for k, p in prior.named_parameters():
+            if f"grad/{k}" in g:
+                rep.check(f"d/d {k}", p.grad, g[f"grad/{k}"], 1e-5)
+        for k, v in prior.state_dict().items():
+            rep.check(f"state {k}", v, g[f"state/{k}"], 1e-5)
+    rep.finish()
+
+
 def test_codebook_prior_with_trained_codebook(A):
     """CodebookPrior(loss='kl', soft mode) over a CodebookModel(update_with_autograd=True): encodings, loss and the gradients of
     (seeded encodings + loss) with respect to the latent and the codebook against the reference classes."""

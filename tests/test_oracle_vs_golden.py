@@ -907,3 +907,33 @@ def test_gmm_topk_assignment(tag, topk, mode):
     e = O.gmm_diag_energy(g["x"], g["mean"], g["cov"] + 1e-8, torch.full((5,), 0.2, dtype=torch.double))
     w, probs = O.mixture_assign(e, topk, 0.9, "mean" if mode == "sample" else mode)
     assert rel_err(probs, g["probs"]) < 1e-9 and rel_err(w, g["weights"]) < 1e-9
+
+
+PRIOR_CORNERS = {
+    "g_reparam2": ("GaussianPrior", dict(loss_coeff=0.4, reparam_dim=2)),
+    "g_reparam_last_4d": ("GaussianPrior", dict(loss_coeff=1.0, reparam_dim=-1)),
+    "g_reparam2_empirical": ("GaussianPrior", dict(loss_coeff=0.6, reparam_dim=2, empirical_kl=True)),
+    "c_empirical": ("ConditionalGaussianPrior", dict(dim=(6, 1, 1), num_classes=4, loss_coeff=0.3, empirical_kl=True)),
+    "c_fixed_var": ("ConditionalGaussianPrior", dict(dim=(6, 1, 1), num_classes=4, loss_coeff=0.8, fixed_var=True)),
+    "c_fixed_empirical": ("ConditionalGaussianPrior", dict(dim=(2, 5), num_classes=3, loss_coeff=1.2, fixed_var=True, empirical_kl=True)),
+    "c_reparam2": ("ConditionalGaussianPrior", dict(dim=(3, 4), num_classes=5, loss_coeff=0.5, reparam_dim=2)),
+    "c_reparam2_ema": ("ConditionalGaussianPrior", dict(dim=(3, 4), num_classes=5, loss_coeff=0.5, reparam_dim=2, embedding_ema_decay=0.9)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PRIOR_CORNERS))
+def test_prior_corners(name):
+    g = group(load_golden("prior_corners.npz"), name)
+    cls, kw = PRIOR_CORNERS[name]
+    x = g["x"].clone().requires_grad_(True)
+    pm = pl = None
+    if cls == "ConditionalGaussianPrior":
+        mw, lw = g["init/_mu.weight"].clone().requires_grad_(True), g["init/_log_std.weight"].clone().requires_grad_(True)
+        pm, pl = mw[g["labels"]], lw[g["labels"]]
+    z, loss = O.prior_encode_general(x, g["eps"], kw["loss_coeff"], kw.get("empirical_kl", False), kw.get("fixed_var", False),
+                                     kw.get("reparam_dim", 1), pm, pl)
+    assert rel_err(z, g["z"]) < 1e-6 and rel_err(loss, g["loss"]) < 2e-6
+    ((z * g["gz"]).sum() + (loss * g["gl"]).sum()).backward()
+    assert rel_err(x.grad, g["gx"]) < 1e-5
+    if cls == "ConditionalGaussianPrior" and "grad/_mu.weight" in g:
+        assert rel_err(mw.grad, g["grad/_mu.weight"]) < 1e-5 and rel_err(lw.grad, g["grad/_log_std.weight"]) < 1e-5
