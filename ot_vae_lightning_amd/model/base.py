@@ -53,6 +53,12 @@ class VisionModule(_Base):
         self.inference_preprocess = inference_preprocess
         self.inference_postprocess = inference_postprocess
         self._inference_flag = False
+        if ema_decay is not None:
+            # the reference keeps an exponential moving average of the parameters through the third-party `torch_ema` package inside
+            # Lightning's hooks (model/base.py:99,146-176: on_before_zero_grad / store + copy_to around validation).  That loop is not
+            # part of this package: refusing is better than accepting the argument and training without the average
+            raise NotImplementedError("`ema_decay`: the parameter moving average of the reference's Lightning hooks (torch_ema) is "
+                                      "not implemented on the MI355X path")
         self.ema_decay = ema_decay
 
     def optim_parameters(self):

@@ -482,6 +482,9 @@ def test_error_behaviour(A):
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, kernel_size=5, dilation=2)   # a 9 x 9 footprint: beyond the 7 x 7 taps of the convolution kernels
     with pytest.raises(NotImplementedError):
+        A.VAE(encoder=A.CNN(1, 16, 16, 1, capacity=4, down_sample=True), decoder=A.CNN(8, 1, 1, 16, capacity=4, up_sample=True),
+              prior=A.GaussianPrior(), ema_decay=0.999)  # torch_ema inside Lightning's hooks: refused, not silently ignored
+    with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, activation="tanh")           # not among the reference's activations either (cnn.py:147)
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, normalization="whatever")
