@@ -1157,6 +1157,32 @@ def gen_codebook_options():
     save("codebook_options.npz", out)
 
 
+CKPT_KEYS = ["encoder.0.block.0.weight", "encoder.0.block.0.bias", "encoder.0.skip.weight", "encoder.1.block.0.weight",
+             "decoder.0.block.0.weight", "decoder.encoder.weight", "prior._mu.weight", "encoder_extra.weight"]
+CKPT_CASES = [(None, ""), ("encoder", ""), ("encoder", "enc."), ("encoder.0", ""), ("encoder.0.block", "b."), ("decoder", ""),
+              ("prior", ""), ("enc", ""), ("missing", ""), ("encoder_extra", ""), ("decoder.encoder", "x.")]
+
+
+def gen_partial_checkpoint():
+    """PartialCheckpoint.state_dict's key selection (utils/partial_checkpoint.py:55-66) and human_format (:10-21): which keys of a
+    checkpoint are taken for an attribute name, and what they are renamed to."""
+    import tempfile
+    pcm = R.ref("utils.partial_checkpoint")
+    out = {}
+    sd = {k: torch.full((1,), float(i)) for i, k in enumerate(CKPT_KEYS)}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "c.ckpt")
+        torch.save({"state_dict": sd}, path)
+        for i, (attr, rep) in enumerate(CKPT_CASES):
+            got = pcm.PartialCheckpoint(path, attr_name=attr, replace_str=rep).state_dict
+            out[f"case{i}/keys"] = np.array(list(got.keys()) or [""])
+            out[f"case{i}/values"] = np.array([float(v) for v in got.values()] or [-1.0])
+    nums = [0, 1, 12, 999, 1000, 1234, 99950, 1234567, 1e9, 2.5e12, 123456789012345.0, -4321]
+    out["human/nums"] = np.array(nums, dtype=np.float64)
+    out["human/text"] = np.array([pcm.human_format(n) for n in nums])
+    save("partial_checkpoint.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1730,6 +1756,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint"]
     for w in which:
         globals()["gen_" + w]()

@@ -113,3 +113,24 @@ def test_inference_transforms_travel_with_the_checkpoint(tmp_path):
 def test_human_format():
     assert [human_format(n) for n in (0, 999, 1000, 1234567, 1.72e6, 2.5e9, 3e13, 7e16)] == \
         ["0", "999", "1K", "1.23M", "1.72M", "2.5B", "30T", "70000T"]
+
+
+def test_key_selection_and_human_format_equal_the_reference(tmp_path):
+    """``PartialCheckpoint.state_dict`` and ``human_format`` against the reference's own functions (tests/golden/partial_checkpoint.npz,
+    recorded by oracle/gen_golden.py from utils/partial_checkpoint.py:10-66): which keys an attribute name selects -- incl. a name that
+    is only a substring of some key (nothing selected) and one that is absent altogether (the whole file) -- and their new names."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "partial_checkpoint.npz"))
+    keys = ["encoder.0.block.0.weight", "encoder.0.block.0.bias", "encoder.0.skip.weight", "encoder.1.block.0.weight",
+            "decoder.0.block.0.weight", "decoder.encoder.weight", "prior._mu.weight", "encoder_extra.weight"]
+    cases = [(None, ""), ("encoder", ""), ("encoder", "enc."), ("encoder.0", ""), ("encoder.0.block", "b."), ("decoder", ""),
+             ("prior", ""), ("enc", ""), ("missing", ""), ("encoder_extra", ""), ("decoder.encoder", "x.")]
+    path = str(tmp_path / "c.ckpt")
+    torch.save({"state_dict": {k: torch.full((1,), float(i)) for i, k in enumerate(keys)}}, path)
+    for i, (attr, rep) in enumerate(cases):
+        got = PartialCheckpoint(path, attr_name=attr, replace_str=rep).state_dict
+        want_keys = [str(k) for k in z[f"case{i}/keys"] if str(k)]
+        assert list(got.keys()) == want_keys, (attr, rep)
+        assert [float(v) for v in got.values()] == [float(v) for v in z[f"case{i}/values"] if v >= 0], (attr, rep)
+    for n, text in zip(z["human/nums"], z["human/text"]):
+        assert human_format(float(n)) == str(text), n
