@@ -1183,6 +1183,81 @@ def gen_partial_checkpoint():
     save("partial_checkpoint.npz", out)
 
 
+def _matrix_zoo():
+    """small symmetric / asymmetric matrices with the structure the validators of ot/matrix_utils.py branch on"""
+    g = torch.Generator().manual_seed(301)
+    a = torch.randn(5, 5, generator=g, dtype=torch.double)
+    pd = a @ a.T + 0.5 * torch.eye(5, dtype=torch.double)
+    low = a[:, :2] @ a[:, :2].T                                              # rank 2: positive SEMI-definite
+    indef = a + a.T
+    asym = pd + 1e-3 * torch.triu(torch.ones(5, 5, dtype=torch.double), 1)   # symmetric up to 1e-3
+    nearly = pd + 1e-6 * torch.triu(torch.ones(5, 5, dtype=torch.double), 1)  # ... up to 1e-6 (inside the 1e-8 sum-of-squares test)
+    neg = -pd
+    batch = torch.stack([pd, low, indef, neg])
+    return dict(pd=pd, low=low, indef=indef, asym=asym, nearly=nearly, neg=neg, batch=batch, diag_vec=torch.tensor([[1.0, 0.0, -2.0], [0.5, 2.0, 3.0]], dtype=torch.double))
+
+
+def gen_matrix_utils():
+    """ot/matrix_utils.py:59-158 function by function on a zoo of matrices (definite, semi-definite, indefinite, asymmetric, batched):
+    is_symmetric, min_eig, is_pd / is_spd (strict and not), make_psd (all four flag combinations, also diagonal 'matrices' given as
+    vectors), sqrtm / invsqrtm, mean_cov (full and diag); and the exception type of w2_gaussian / compute_transport_operators on
+    invalid arguments (ot/w2_utils.py:605-708)."""
+    mu_, w2 = R.ref("ot.matrix_utils"), R.ref("ot.w2_utils")
+    out = {}
+    zoo = _matrix_zoo()
+    for name, m in zoo.items():
+        out[f"zoo/{name}"] = npy(m)
+        if name == "diag_vec":
+            for strict in (False, True):
+                fixed, corr = mu_.make_psd(m.clone(), strict=strict, return_correction=True, diag=True)
+                out[f"make_psd_diag/strict{int(strict)}/out"], out[f"make_psd_diag/strict{int(strict)}/corr"] = npy(fixed), npy(corr)
+            continue
+        out[f"{name}/is_symmetric"] = npy(mu_.is_symmetric(m).to(torch.int64))
+        if name in ("asym",):
+            continue
+        out[f"{name}/min_eig"] = npy(mu_.min_eig(m))
+        for strict in (False, True):
+            out[f"{name}/is_pd/strict{int(strict)}"] = npy(mu_.is_pd(m, strict=strict).to(torch.int64))
+            out[f"{name}/is_spd/strict{int(strict)}"] = npy(mu_.is_spd(m, strict=strict).to(torch.int64))
+            fixed, corr = mu_.make_psd(m.clone(), strict=strict, return_correction=True)
+            out[f"{name}/make_psd/strict{int(strict)}/out"], out[f"{name}/make_psd/strict{int(strict)}/corr"] = npy(fixed), npy(corr)
+        if name in ("pd",):
+            out[f"{name}/sqrtm"], out[f"{name}/invsqrtm"] = npy(mu_.sqrtm(m)), npy(mu_.invsqrtm(m))
+        if name == "low":
+            out[f"{name}/sqrtm"] = npy(mu_.sqrtm(m))
+    # mean_cov
+    g = torch.Generator().manual_seed(302)
+    x = torch.randn(2, 30, 4, generator=g, dtype=torch.double)
+    n = torch.tensor([30.0, 30.0], dtype=torch.double)
+    mean, cov = mu_.mean_cov(x.sum(-2), x.transpose(-1, -2) @ x, n)
+    out["mean_cov/x"], out["mean_cov/mean"], out["mean_cov/cov"] = npy(x), npy(mean), npy(cov)
+    mean_d, var_d = mu_.mean_cov(x.sum(-2), (x ** 2).sum(-2), n, diag=True)
+    out["mean_cov/mean_diag"], out["mean_cov/var_diag"] = npy(mean_d), npy(var_d)
+    # argument errors
+    pd, indef, asym = zoo["pd"], zoo["indef"], zoo["asym"]
+    m5 = torch.zeros(5, dtype=torch.double)
+    calls = {
+        "w2_indef_source": lambda: w2.w2_gaussian(m5, m5, indef, pd),
+        "w2_indef_target": lambda: w2.w2_gaussian(m5, m5, pd, indef),
+        "w2_asym": lambda: w2.w2_gaussian(m5, m5, asym, pd),
+        "w2_shape": lambda: w2.w2_gaussian(m5, torch.zeros(4, dtype=torch.double), pd, pd),
+        "w2_indef_make_pd": lambda: w2.w2_gaussian(m5, m5, indef, pd, make_pd=True),
+        "ops_indef": lambda: w2.compute_transport_operators(indef, pd, stochastic=False, diag=False, pg_star=0.0),
+        "ops_pg_star_range": lambda: w2.compute_transport_operators(pd, pd, stochastic=False, diag=False, pg_star=1.5),
+        "ops_diag_negative": lambda: w2.compute_transport_operators(torch.tensor([1.0, -1.0], dtype=torch.double), torch.ones(2, dtype=torch.double), stochastic=False, diag=True, pg_star=0.0),
+    }
+    for name, fn in calls.items():
+        try:
+            res = fn()
+            val = res[0] if isinstance(res, tuple) else res
+            out[f"err/{name}/value"] = npy(val)
+            print(f"  {name}: returns")
+        except Exception as e:  # noqa: BLE001
+            out[f"err/{name}/error"] = np.frombuffer(type(e).__name__.encode(), dtype=np.uint8)
+            print(f"  {name}: {type(e).__name__}: {str(e)[:80]}")
+    save("matrix_utils.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1756,6 +1831,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint", "matrix_utils"]
     for w in which:
         globals()["gen_" + w]()

@@ -1316,6 +1316,71 @@ def test_codebook_prior_with_trained_codebook(A):
     rep.finish()
 
 
+def test_matrix_utils_function_by_function_vs_reference_golden(A):
+    """ot/matrix_utils.py:59-158 function by function on a zoo of matrices (definite, semi-definite, indefinite, slightly asymmetric,
+    batched) against the reference's own functions (matrix_utils.npz): is_symmetric, min_eig, is_pd / is_spd, make_psd in all flag
+    combinations (also for diagonal 'matrices' given as vectors), sqrtm / invsqrtm, mean_cov; and for invalid arguments of w2_gaussian /
+    compute_transport_operators (ot/w2_utils.py:605-708) the same exception type -- or the same value where the reference accepts."""
+    from ot_vae_lightning_amd.ot import matrix_utils as MU
+    z = load_golden("matrix_utils.npz")
+    g = {k: torch.from_numpy(z[k]) for k in z.files if not k.endswith("/error")}
+    rep = Report("matrix_utils function by function vs the reference")
+    for name in ("pd", "low", "indef", "asym", "nearly", "neg", "batch"):
+        m = g[f"zoo/{name}"].cuda()
+        assert torch.equal(MU.is_symmetric(m).cpu().to(torch.int64).reshape(-1), g[f"{name}/is_symmetric"].reshape(-1)), name
+        if name == "asym":
+            continue
+        scale = float(m.abs().max())   # (a semi-definite matrix's smallest eigenvalue is rounding noise of either sign: absolute comparison)
+        rep.check(f"{name}: min_eig", MU.min_eig(m), g[f"{name}/min_eig"], 1e-10, floor=scale)
+        for strict in (0, 1):
+            # (semi-definite `low`: its zero eigenvalues come out as +-1e-16 on either side; the verdict there is rounding in the reference too)
+            if name not in ("low", "batch"):
+                assert torch.equal(MU.is_pd(m, strict=bool(strict)).cpu().to(torch.int64).reshape(-1), g[f"{name}/is_pd/strict{strict}"].reshape(-1)), (name, strict)
+                assert torch.equal(MU.is_spd(m, strict=bool(strict)).cpu().to(torch.int64).reshape(-1), g[f"{name}/is_spd/strict{strict}"].reshape(-1)), (name, strict)
+            fixed, corr = MU.make_psd(m.clone(), strict=bool(strict), return_correction=True)
+            rep.check(f"{name}: make_psd(strict={strict})", fixed, g[f"{name}/make_psd/strict{strict}/out"], 1e-10)
+            rep.check(f"{name}: make_psd(strict={strict}) correction", corr, g[f"{name}/make_psd/strict{strict}/corr"], 1e-9, floor=scale)
+    rep.check("sqrtm(pd)", MU.sqrtm(g["zoo/pd"].cuda()), g["pd/sqrtm"], 1e-10)
+    rep.check("invsqrtm(pd)", MU.invsqrtm(g["zoo/pd"].cuda()), g["pd/invsqrtm"], 1e-9)
+    # (sqrtm of the rank-deficient matrix is NaN or not by the sign of a 1e-16 eigenvalue, in the reference as here: not compared)
+    for strict in (0, 1):
+        fixed, corr = MU.make_psd(g["zoo/diag_vec"].cuda(), strict=bool(strict), return_correction=True, diag=True)
+        rep.check(f"make_psd(diag, strict={strict})", fixed, g[f"make_psd_diag/strict{strict}/out"], 1e-12)
+        rep.check(f"make_psd(diag, strict={strict}) correction", corr, g[f"make_psd_diag/strict{strict}/corr"], 1e-12, floor=1e-12)
+    x = g["mean_cov/x"].cuda()
+    n = torch.tensor([30.0, 30.0], dtype=torch.double, device="cuda")
+    mean, cov = MU.mean_cov(x.sum(-2), x.transpose(-1, -2) @ x, n)
+    rep.check("mean_cov: mean", mean, g["mean_cov/mean"], 1e-12)
+    rep.check("mean_cov: cov", cov, g["mean_cov/cov"], 1e-11)
+    mean_d, var_d = MU.mean_cov(x.sum(-2), (x ** 2).sum(-2), n, diag=True)
+    rep.check("mean_cov(diag): mean", mean_d, g["mean_cov/mean_diag"], 1e-12)
+    rep.check("mean_cov(diag): var", var_d, g["mean_cov/var_diag"], 1e-11)
+    # argument errors
+    pd, indef, asym = g["zoo/pd"].cuda(), g["zoo/indef"].cuda(), g["zoo/asym"].cuda()
+    m5 = torch.zeros(5, dtype=torch.double, device="cuda")
+    calls = {
+        "w2_indef_source": lambda: A.w2_gaussian(m5, m5, indef, pd),
+        "w2_indef_target": lambda: A.w2_gaussian(m5, m5, pd, indef),
+        "w2_asym": lambda: A.w2_gaussian(m5, m5, asym, pd),
+        "w2_shape": lambda: A.w2_gaussian(m5, torch.zeros(4, dtype=torch.double, device="cuda"), pd, pd),
+        "w2_indef_make_pd": lambda: A.w2_gaussian(m5, m5, indef, pd, make_pd=True),
+        "ops_indef": lambda: A.compute_transport_operators(indef, pd, stochastic=False, diag=False, pg_star=0.0),
+        "ops_pg_star_range": lambda: A.compute_transport_operators(pd, pd, stochastic=False, diag=False, pg_star=1.5),
+        "ops_diag_negative": lambda: A.compute_transport_operators(torch.tensor([1.0, -1.0], dtype=torch.double, device="cuda"),
+                                                                   torch.ones(2, dtype=torch.double, device="cuda"), stochastic=False, diag=True, pg_star=0.0),
+    }
+    for name, fn in calls.items():
+        if f"err/{name}/error" in z.files:
+            want = bytes(z[f"err/{name}/error"].astype("uint8")).decode()
+            with pytest.raises(Exception) as info:
+                fn()
+            assert type(info.value).__name__ == want, (name, type(info.value).__name__, want)
+        else:
+            res = fn()
+            rep.check(f"{name}: value", res[0] if isinstance(res, tuple) else res, g[f"err/{name}/value"], 1e-8)
+    rep.finish()
+
+
 def test_gaussian_transport_1024_dims_vs_oracle(A):
     """W2 + transport operator at the reference's latent-transport test size (D = 1024, transport_dims (1,2,3))."""
     import otvae_oracle as O
