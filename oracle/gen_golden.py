@@ -1258,6 +1258,42 @@ def gen_matrix_utils():
     save("matrix_utils.npz", out)
 
 
+GT_CASES = {
+    # name: (size, transport_cfg) -- GaussianTransport with a leading (per-position) shape, diagonal models, a perception-distortion mix
+    "lead3_full": ((3, 6), dict(diag=False, stochastic=False, pg_star=0.0, make_pd=True, verbose=False, dtype=torch.double)),
+    "lead3_diag": ((3, 6), dict(diag=True, stochastic=False, pg_star=0.0, make_pd=True, verbose=False, dtype=torch.double)),
+    "lead2x2_full_pg": ((2, 2, 5), dict(diag=False, stochastic=False, pg_star=0.3, make_pd=True, verbose=False, dtype=torch.double)),
+    "nolead_diag_pg": ((7,), dict(diag=True, stochastic=False, pg_star=0.6, make_pd=True, verbose=False, dtype=torch.double)),
+    "lead3_full_ema": ((3, 6), dict(diag=False, stochastic=False, pg_star=0.0, make_pd=True, verbose=False, dtype=torch.double)),
+}
+
+
+def gen_gaussian_transport_shapes():
+    """GaussianTransport with leading (per-position) shapes, diagonal models and pg_star > 0 (ot/transport/gaussian_transport.py:41-95,
+    what LatentTransport(common_operator=False) builds): two updates per side, compute, transport of [*, B, D] and of [*, D] inputs."""
+    gt = R.ref("ot.transport.gaussian_transport")
+    out = {}
+    for name, (size, tcfg) in GT_CASES.items():
+        g = torch.Generator().manual_seed(401 + len(size))
+        lead, d, B = size[:-1], size[-1], 40
+        decay = 0.8 if name.endswith("_ema") else None
+        cfg = dict(update_decay=decay, dtype=torch.double)
+        op = gt.GaussianTransport(*size, source_cfg=cfg, target_cfg=cfg, transport_cfg=tcfg)
+        mix = torch.randn(*lead, d, d, generator=g, dtype=torch.double) / math.sqrt(d)
+        src = [torch.randn(*lead, B, d, generator=g, dtype=torch.double) @ mix * 1.3 + 0.4 for _ in range(2)]
+        tgt = [torch.randn(*lead, B, d, generator=g, dtype=torch.double) * 0.7 - 0.1 for _ in range(2)]
+        for a, b in zip(src, tgt):
+            op.update(source_samples=a, target_samples=b)
+        dist = op.compute()
+        out[f"{name}/src"], out[f"{name}/tgt"] = npy(torch.stack(src)), npy(torch.stack(tgt))
+        out[f"{name}/w2"], out[f"{name}/T"] = npy(dist), npy(op.transport_operator)
+        out[f"{name}/src_mean"], out[f"{name}/src_cov"] = npy(op.source_model.mean), npy(op.source_model.cov)
+        probe = src[0][..., :5, :]
+        out[f"{name}/moved_batch"] = npy(op.transport(probe))
+        out[f"{name}/moved_single"] = npy(op.transport(probe[..., 0, :]))
+    save("gaussian_transport_shapes.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1831,6 +1867,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint", "matrix_utils"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint", "matrix_utils", "gaussian_transport_shapes"]
     for w in which:
         globals()["gen_" + w]()

@@ -1381,6 +1381,38 @@ def test_matrix_utils_function_by_function_vs_reference_golden(A):
     rep.finish()
 
 
+GT_CASES = {
+    "lead3_full": ((3, 6), dict(diag=False, stochastic=False, pg_star=0.0, make_pd=True, verbose=False, dtype=torch.double)),
+    "lead3_diag": ((3, 6), dict(diag=True, stochastic=False, pg_star=0.0, make_pd=True, verbose=False, dtype=torch.double)),
+    "lead2x2_full_pg": ((2, 2, 5), dict(diag=False, stochastic=False, pg_star=0.3, make_pd=True, verbose=False, dtype=torch.double)),
+    "nolead_diag_pg": ((7,), dict(diag=True, stochastic=False, pg_star=0.6, make_pd=True, verbose=False, dtype=torch.double)),
+    "lead3_full_ema": ((3, 6), dict(diag=False, stochastic=False, pg_star=0.0, make_pd=True, verbose=False, dtype=torch.double)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GT_CASES))
+def test_gaussian_transport_leading_shapes_vs_reference_golden(A, name):
+    """`GaussianTransport` with leading (per-position) shapes, diagonal models, pg_star > 0 and EMA statistics -- what
+    `LatentTransport(common_operator=False)` builds (ot/transport/gaussian_transport.py:41-95) -- against the reference's own class
+    (gaussian_transport_shapes.npz): distance, operator, fitted moments, transport of [*, B, D] and of [*, D] inputs."""
+    g = group(load_golden("gaussian_transport_shapes.npz"), name)
+    size, tcfg = GT_CASES[name]
+    cfg = dict(update_decay=0.8 if name.endswith("_ema") else None, dtype=torch.double)
+    op = A.GaussianTransport(*size, source_cfg=cfg, target_cfg=cfg, transport_cfg=tcfg).cuda()
+    for a, b in zip(g["src"].cuda(), g["tgt"].cuda()):
+        op.update(source_samples=a, target_samples=b)
+    dist = op.compute()
+    rep = Report(f"GaussianTransport{size} {name} vs the reference class")
+    rep.check("W2^2", dist, g["w2"], 1e-8)
+    rep.check("operator", op.transport_operator, g["T"], 1e-8)
+    rep.check("source mean", op.source_model.mean, g["src_mean"], 1e-11)
+    rep.check("source cov", op.source_model.cov, g["src_cov"], 1e-10)
+    probe = g["src"][0][..., :5, :].cuda()
+    rep.check("transport [*, B, D]", op.transport(probe), g["moved_batch"], 1e-8)
+    rep.check("transport [*, D]", op.transport(probe[..., 0, :]), g["moved_single"], 1e-8)
+    rep.finish()
+
+
 def test_gaussian_transport_1024_dims_vs_oracle(A):
     """W2 + transport operator at the reference's latent-transport test size (D = 1024, transport_dims (1,2,3))."""
     import otvae_oracle as O
