@@ -344,6 +344,11 @@ int otvae_mvn_logprob_bwd(const double* g, const double* y, const double* L, int
 /* ---- Adam (model/vae.py:148-151; torch.optim.Adam defaults) over one flat buffer --------------------------- */
 /* hyper (device): float[4] = {lr, beta1, beta2, eps}; step (device int32) is the 1-based count of THIS update
  * (incremented by otvae_step_begin). grad_scale multiplies g first (1/world_size for data-parallel means). */
+/* dst[i][0..n[i]) = src[i][0..n[i]) for `count` contiguous fp32 ranges in one launch per 32 (pointer tables on the HOST, passed to the
+ * kernel by value): the gradients autograd left in p.grad (embeddings, learned tokens) into their slots of the flat gradient buffer
+ * that otvae_adam_step reads -- what the reference's optimizer finds in p.grad (model/vae.py:148-151). */
+int otvae_copy_batched(int count, const float* const* src, float* const* dst, const int64_t* n, void* stream);
+
 int otvae_step_begin(int32_t* step, void* stream);
 int otvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                     const int32_t* step, float grad_scale, void* stream);

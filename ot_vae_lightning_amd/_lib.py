@@ -90,6 +90,7 @@ SIGNATURES = {
     "otvae_gaussian_prior_cond_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     "otvae_gaussian_prior_cond_ex_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp]),
     "otvae_gaussian_prior_cond_ex_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp]),
+    "otvae_copy_batched": (i32, [i32, vp, vp, vp, vp]),
     "otvae_nelbo_ws": (i32, []),
     "otvae_nelbo_fwd": (i32, [vp, vp, i64, vp, i32, f32, vp, vp, vp]),
     "otvae_nelbo_bwd": (i32, [vp, vp, i64, i32, f32, vp, vp, vp, vp]),

@@ -394,6 +394,42 @@ extern "C" int otvae_nelbo_bwd(const float* pred, const float* target, int64_t n
     return OTVAE_OK;
 }
 
+// ---- gradients that reached their parameter through plain autograd (embeddings, learned tokens ...) into their slots of the flat
+// gradient buffer: up to 32 (source, slot, length) triples per launch, passed by value (no device-side table: nothing to upload inside
+// a captured step).  One launch instead of one copy per parameter (engine.HipTrainer._collect_loose_grads).
+#define COPYB_MAX 32
+struct CopyBatch {
+    const float* src[COPYB_MAX];
+    float* dst[COPYB_MAX];
+    long long n[COPYB_MAX];
+};
+
+__global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatch d) {
+    const float* __restrict__ s = d.src[blockIdx.y];
+    float* __restrict__ t = d.dst[blockIdx.y];
+    const long long n = d.n[blockIdx.y];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) t[i] = s[i];
+}
+
+extern "C" int otvae_copy_batched(int count, const float* const* src, float* const* dst, const int64_t* n, void* stream) {
+    OTVAE_REQUIRE(count > 0 && src && dst && n, "otvae_copy_batched: bad argument");
+    for (int i0 = 0; i0 < count; i0 += COPYB_MAX) {
+        CopyBatch d;
+        const int c = imin(COPYB_MAX, count - i0);
+        long long longest = 0;
+        for (int i = 0; i < c; ++i) {
+            OTVAE_REQUIRE(src[i0 + i] && dst[i0 + i] && n[i0 + i] > 0, "otvae_copy_batched: entry %d", i0 + i);
+            d.src[i] = src[i0 + i];
+            d.dst[i] = dst[i0 + i];
+            d.n[i] = n[i0 + i];
+            longest = n[i0 + i] > longest ? n[i0 + i] : longest;
+        }
+        copy_batched_kernel<<<dim3(imin(cdiv(longest, 1024), 256), c), 256, 0, (hipStream_t)stream>>>(d);
+        OTVAE_CHECK_LAUNCH("otvae_copy_batched");
+    }
+    return OTVAE_OK;
+}
+
 // ---- Adam ----------------------------------------------------------------------------------------------------
 __global__ void step_begin_kernel(int32_t* step) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;

@@ -250,6 +250,7 @@ class HipTrainer:
         ``params``: the parameters whose backward has just run (two-phase backward: a slot of the other phase may already
         be under its all-reduce and must not be written)."""
         loose = self.__dict__.setdefault("_loose_params", set())
+        pairs = []
         for p in (self.params if params is None else params):
             g = p.grad
             if g is None:
@@ -258,8 +259,17 @@ class HipTrainer:
                 continue
             slot = p._otvae_grad_view()
             if g.data_ptr() != slot.data_ptr():
-                slot.copy_(g)
+                if g.dtype == torch.float32 and g.is_contiguous() and slot.is_contiguous():
+                    pairs.append((g, slot))
+                else:
+                    slot.copy_(g)
                 loose.add(id(p))
+        if pairs:  # one launch for all of them (the ViT: embed / class tokens, position embeddings, the prior's class embeddings)
+            n = len(pairs)
+            src = (C.c_void_p * n)(*[g.data_ptr() for g, _ in pairs])
+            dst = (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in pairs])
+            cnt = (C.c_int64 * n)(*[g.numel() for g, _ in pairs])
+            check(self.lib.otvae_copy_batched(n, src, dst, cnt, stream()), "otvae_copy_batched")
 
     def _backward(self, loss, **kw) -> None:
         """``loss.backward()`` seeded at the nelbo kernel's [total, recon, prior] vector with a resident [1, 0, 0]: the
