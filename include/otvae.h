@@ -315,6 +315,10 @@ int otvae_group_norm_act_bwd(const float* ga, const float* x, const float* gamma
                              void* stream);
 /* dst[c] = sum_r src[r][c] in fixed order, src [R][C] */
 int otvae_colsum_f32(const float* src, int R, int C, float* dst, void* stream);
+/* Backward pass of an embedding lookup (nn.Embedding: the ViT's class token, networks/vit.py:167,203; the class rows of
+ * ConditionalGaussianPrior, prior/conditional_gaussian.py:76-77): gw[k][:] = sum of g[b][:] over the b with idx[b] == k, in
+ * increasing b.  g [B][d], idx [B] int64, gw [K][d] (every row written). */
+int otvae_embedding_bwd(const float* g, const int64_t* idx, int B, int K, int d, float* gw, void* stream);
 
 /* ---- FiLM conditioning (`additional_embed`) and Dropout2d of ConvLayer (networks/cnn.py:112-118,160-192); x, out, g [N][HW][C] ------- */
 /* out = x * scale[n][c] + bias[n][c] (scale / bias [N][C]: the two Linear projections of the activated embedding) */

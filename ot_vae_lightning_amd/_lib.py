@@ -103,6 +103,7 @@ SIGNATURES = {
     "otvae_group_norm_act_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]),
     "otvae_group_norm_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "otvae_colsum_f32": (i32, [vp, i32, i32, vp, vp]),
+    "otvae_embedding_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "otvae_film_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "otvae_film_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "otvae_dropout2d_fwd": (i32, [vp, i32, i32, i32, f32, vp, i32, vp, vp, vp]),

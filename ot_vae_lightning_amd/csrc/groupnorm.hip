@@ -143,18 +143,55 @@ extern "C" int otvae_group_norm_act_bwd(const float* ga, const float* x, const f
     return OTVAE_OK;
 }
 
-// dst[c] = sum_r src[r][c] (fixed order over r): the per-sample parameter partials above -> d gamma, d beta
+// dst[c] = sum_r src[r][c] in a fixed order: 64 columns x 4 row lanes per block, a row lane adds rows q, q + 4, ... in fp64, the four
+// lanes are combined in lane order through LDS.  (d gamma / d beta of the per-sample parameter partials above; the batch sum behind
+// a parameter that was broadcast over the batch: the ViT's position embeddings and learned tokens.)
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, int R, int C, float* __restrict__ dst) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double part[4][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s = 0.0;
-    for (int r = 0; r < R; ++r) s += (double)src[(size_t)r * C + c];
-    dst[c] = (float)s;
+    if (c < C) {
+#pragma unroll 8
+        for (int r = q; r < R; r += 4) s += (double)src[(size_t)r * C + c];
+    }
+    part[q][cl] = s;
+    __syncthreads();
+    if (q == 0 && c < C) dst[c] = (float)((part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
+}
+
+// gw[k][:] = sum_{b : idx[b] == k} g[b][:], rows added in increasing b (fixed order): the backward pass of an embedding lookup
+// (nn.Embedding: the ViT's class token, networks/vit.py:167,203; ConditionalGaussianPrior's class rows, prior/conditional_gaussian.py:76-77)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx, int B, int d,
+                                                            float* __restrict__ gw) {
+    // 64 columns x 4 sample lanes per block; a lane visits samples q, q + 4, ... (loads issued unconditionally, selected afterwards, so
+    // that they pipeline), the four lanes are combined in lane order: a fixed order of additions per (row, column)
+    __shared__ float part[4][64];
+    const int k = blockIdx.x, cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int j = blockIdx.y * 64 + cl;
+    float acc = 0.f;
+    if (j < d) {
+#pragma unroll 8
+        for (int b = q; b < B; b += 4) {
+            const float v = g[(size_t)b * d + j];
+            acc += idx[b] == (int64_t)k ? v : 0.f;
+        }
+    }
+    part[q][cl] = acc;
+    __syncthreads();
+    if (q == 0 && j < d) gw[(size_t)k * d + j] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
+extern "C" int otvae_embedding_bwd(const float* g, const int64_t* idx, int B, int K, int d, float* gw, void* stream) {
+    OTVAE_REQUIRE(g && idx && gw && B > 0 && K > 0 && d > 0, "otvae_embedding_bwd: bad argument");
+    embedding_bwd_kernel<<<dim3(K, cdiv(d, 64)), 256, 0, (hipStream_t)stream>>>(g, idx, B, d, gw);
+    OTVAE_CHECK_LAUNCH("otvae_embedding_bwd");
+    return OTVAE_OK;
 }
 
 extern "C" int otvae_colsum_f32(const float* src, int R, int C, float* dst, void* stream) {
     OTVAE_REQUIRE(src && dst && R > 0 && C > 0, "otvae_colsum_f32: bad argument");
-    colsum_f32_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(src, R, C, dst);
+    colsum_f32_kernel<<<cdiv(C, 64), 256, 0, (hipStream_t)stream>>>(src, R, C, dst);
     OTVAE_CHECK_LAUNCH("otvae_colsum_f32");
     return OTVAE_OK;
 }

@@ -1151,6 +1151,63 @@ def layer_norm_tokens(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5,
     return _LayerNormFn.apply(x, residual, gamma, beta, eps)
 
 
+class _EmbeddingFn(torch.autograd.Function):
+    """weight[idx] (nn.Embedding's lookup) whose backward is the library's deterministic row sum (``otvae_embedding_bwd``), written
+    straight into the parameter's gradient slot when a trainer gave it one"""
+
+    @staticmethod
+    def forward(ctx, weight, idx):
+        ctx.save_for_backward(idx)
+        ctx.pref = weight
+        ctx.shape = tuple(weight.shape)
+        return weight.detach()[idx]
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        k, d = ctx.shape
+        g2 = g.reshape(-1, d).contiguous().float()
+        gw = _grad_buffer(ctx.pref, ctx.pref)
+        check(_lib.load().otvae_embedding_bwd(ptr(g2), ptr(idx.reshape(-1).contiguous()), g2.shape[0], k, d, ptr(gw), stream()),
+              "otvae_embedding_bwd")
+        return gw, None
+
+
+def embedding(weight: Tensor, idx: Tensor) -> Tensor:
+    """``F.embedding(idx, weight)`` for a 2-D fp32 weight on the device, with a native backward"""
+    if not (weight.is_cuda and weight.dim() == 2 and weight.dtype == torch.float32 and weight.is_contiguous()):
+        return torch.nn.functional.embedding(idx, weight)
+    return _EmbeddingFn.apply(weight, idx)
+
+
+class _ExpandBatchFn(torch.autograd.Function):
+    """t [1 | none, *shape] -> [B, *shape] (materialised); backward: the sum over the batch by ``otvae_colsum_f32`` into the parameter's
+    gradient slot when it has one (position embeddings, learned tokens of the ViT)"""
+
+    @staticmethod
+    def forward(ctx, t, b, pref):
+        ctx.pref = pref if pref is not None else t
+        ctx.tshape = tuple(t.shape)
+        return t.reshape(1, -1).expand(b, -1).contiguous().reshape(b, *t.shape[(1 if t.dim() > 1 and t.shape[0] == 1 else 0):])
+
+    @staticmethod
+    def backward(ctx, g):
+        b = g.shape[0]
+        g2 = g.reshape(b, -1).contiguous().float()
+        slot = _grad_buffer(ctx.pref, ctx.pref) if tuple(ctx.pref.shape) == ctx.tshape else torch.empty(ctx.tshape, device=g.device, dtype=torch.float32)
+        check(_lib.load().otvae_colsum_f32(ptr(g2), b, g2.shape[1], ptr(slot), stream()), "otvae_colsum_f32")
+        return slot.reshape(ctx.tshape), None, None
+
+
+def expand_batch(t: Tensor, b: int, param: Optional[Tensor] = None) -> Tensor:
+    """``t.expand(b, ...)`` made dense, for a tensor that is the same for every sample of the batch; ``param``: the parameter ``t`` IS
+    (its gradient slot takes the batch sum directly); with a leading dimension of 1 that dimension becomes the batch"""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        lead = t if (t.dim() > 1 and t.shape[0] == 1) else t.unsqueeze(0)
+        return lead.expand(b, *lead.shape[1:]).contiguous()
+    return _ExpandBatchFn.apply(t, b, param)
+
+
 class _DropoutFn(torch.autograd.Function):
     """dropout(relu?(x)) over [..., D] tokens with a recomputed hash mask (no mask tensor)"""
 

@@ -227,10 +227,18 @@ class PositionalEmbedding(nn.Module):
             raise RuntimeError("the feature number of `input` must be equal to d_model")
         batched = input.dim() == 3
         seq_dim = int(batched and self.batch_first)
-        pos = self.position_embeddings.weight[:input.shape[seq_dim]]
-        if batched:
-            pos = pos.unsqueeze(int(not self.batch_first))
-        out = self.LayerNorm(input, residual=pos.expand_as(input))
+        w = self.position_embeddings.weight
+        n = input.shape[seq_dim]
+        if batched and self.batch_first and input.is_cuda:
+            # the positions broadcast over the batch: materialised once, their gradient summed over the batch by the library
+            # (functional.expand_batch) -- into the parameter's gradient slot when all max_length positions are in use
+            res = HF.expand_batch(w if n == w.shape[0] else w[:n].contiguous(), input.shape[0], w if n == w.shape[0] else None)
+        else:
+            pos = w[:n]
+            if batched:
+                pos = pos.unsqueeze(int(not self.batch_first))
+            res = pos.expand_as(input)
+        out = self.LayerNorm(input, residual=res)
         if not (self.training and self.p > 0):
             return out
         if dropout_key is not None and self.d_model % 4 == 0:
@@ -360,7 +368,7 @@ class ViT(nn.Module):
         if self.class_token is not None:
             if labels is None:
                 raise ValueError("`num_classes` specified but `labels` is None. Can't infer the class token.")
-            x = torch.cat((x, self.class_token(labels).unsqueeze(1)), dim=1)
+            x = torch.cat((x, HF.embedding(self.class_token.weight, labels).unsqueeze(1)), dim=1)
         return x
 
     def _add_time_token(self, x: Tensor, time: Optional[Tensor]) -> Tensor:
@@ -370,7 +378,7 @@ class ViT(nn.Module):
 
     def _add_embed_token(self, x: Tensor) -> Tensor:
         if self.embed_token is not None:
-            x = torch.cat((x, self.embed_token.expand(x.size(0), -1, -1)), dim=1)
+            x = torch.cat((x, HF.expand_batch(self.embed_token, x.size(0), self.embed_token)), dim=1)
         return x
 
     def forward(self, x: Tensor, labels: Optional[Tensor] = None, time: Optional[Tensor] = None) -> Tensor:

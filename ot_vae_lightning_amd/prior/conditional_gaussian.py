@@ -46,7 +46,8 @@ class ConditionalGaussianPrior(GaussianPrior, utils.DDPMixin):
             shape[self.reparam_dim] //= 2
         if eps is None:
             eps = torch.randn(shape, device=x.device, dtype=x.dtype)
-        pm, pl = self._mu(labels), self._log_std(labels)            # [B, prod(dim)] rows of the class embeddings
+        # [B, prod(dim)] rows of the class embeddings (nn.Embedding's lookup with the library's deterministic backward)
+        pm, pl = HF.embedding(self._mu.weight, labels), HF.embedding(self._log_std.weight, labels)
         if self.fixed_var or self.empirical_kl or self.reparam_dim not in (1, 1 - x.dim()):
             z, loss = HF.gaussian_prior_conditional_ex(x, eps, pm, pl, coeff, self.empirical_kl, self.fixed_var, self.reparam_dim)
         else:
