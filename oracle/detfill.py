@@ -87,3 +87,39 @@ def gmm_recovery_inputs():
     torch.manual_seed(104)
     order = torch.randperm(n)
     return (lead, k, dim, n), mean, var, truth, samples, order
+
+
+def edge_calls(w2, nu, dev="cpu"):
+    """(name -> thunk) of edge-case calls into the OT helpers and QKVAttention; shared by the generator (reference modules, CPU) and --
+    with the package's own modules and dev='cuda' -- by tests/test_gpu_parity.py"""
+    g = torch.Generator().manual_seed(501)
+    t = lambda *s, **k: torch.randn(*s, generator=g, dtype=torch.double, **k)  # noqa: E731
+    ms, mt = t(2, 3, 4), t(2, 5, 4)
+    vs, vt = torch.rand(2, 3, 4, generator=g, dtype=torch.double) + 0.3, torch.rand(2, 5, 4, generator=g, dtype=torch.double) + 0.3
+    ws = torch.tensor([[0.2, 0.3, 0.5], [0.6, 0.3, 0.1]], dtype=torch.double)
+    wt = torch.full((2, 5), 0.2, dtype=torch.double)
+    a, b = torch.full((4,), 0.25, dtype=torch.double), torch.full((6,), 1 / 6, dtype=torch.double)
+    C = torch.rand(4, 6, generator=g, dtype=torch.double)
+    T5 = t(5, 5)
+    x5, m5 = t(7, 5), t(5)
+    qkv = torch.randn(2, 3 * 4 * 2, 9, generator=g)
+    D = lambda v: v.to(dev)  # noqa: E731
+    return {
+        "gmm_ok_weights": lambda: w2.batch_ot_gmm(D(ms), D(mt), D(vs), D(vt), diag=True, weight_source=D(ws), weight_target=D(wt), max_iter=50),
+        "gmm_default_weights": lambda: w2.batch_ot_gmm(D(ms), D(mt), D(vs), D(vt), diag=True, max_iter=50),
+        "gmm_weights_not_normalised": lambda: w2.batch_ot_gmm(D(ms), D(mt), D(vs), D(vt), diag=True, weight_source=D(ws * 2), weight_target=D(wt)),
+        "gmm_negative_weight": lambda: w2.batch_ot_gmm(D(ms), D(mt), D(vs), D(vt), diag=True, weight_source=D(torch.tensor([[1.2, -0.2, 0.0], [0.6, 0.3, 0.1]], dtype=torch.double)), weight_target=D(wt)),
+        "gmm_negative_variance": lambda: w2.batch_ot_gmm(D(ms), D(mt), D(-vs), D(vt), diag=True),
+        "gmm_dim_mismatch": lambda: w2.batch_ot_gmm(D(ms), D(mt[..., :3]), D(vs), D(vt[..., :3]), diag=True),
+        "sinkhorn_one_iteration": lambda: w2.sinkhorn_log(D(a), D(b), D(C), reg=0.1, max_iter=1),
+        "sinkhorn_zero_iterations": lambda: w2.sinkhorn_log(D(a), D(b), D(C), reg=0.1, max_iter=0),
+        "sinkhorn_huge_threshold": lambda: w2.sinkhorn_log(D(a), D(b), D(C), reg=0.1, max_iter=100, threshold=1e9),
+        "sinkhorn_float32": lambda: w2.sinkhorn_log(D(a.float()), D(b.float()), D(C.float()), reg=0.05, max_iter=30),
+        "apply_dim_mismatch": lambda: w2.apply_transport(D(x5[:, :4]), D(m5), D(m5), D(T5), D(torch.zeros(5, 5, dtype=torch.double))),
+        "apply_zero_noise": lambda: w2.apply_transport(D(x5), D(m5), D(m5 + 1), D(T5), D(torch.zeros(5, 5, dtype=torch.double))),
+        "apply_diag": lambda: w2.apply_transport(D(x5), D(m5), D(m5 + 1), D(torch.rand(5, generator=torch.Generator().manual_seed(5), dtype=torch.double)), D(torch.zeros(5, dtype=torch.double)), diag=True),
+        "attention_bad_width": lambda: nu.QKVAttention(5)(D(qkv)),
+        "attention_ok": lambda: nu.QKVAttention(4)(D(qkv)),
+    }
+
+

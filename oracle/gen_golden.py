@@ -1294,6 +1294,25 @@ def gen_gaussian_transport_shapes():
     save("gaussian_transport_shapes.npz", out)
 
 
+def gen_edge_calls():
+    """Edge cases of the OT helpers (ot/w2_utils.py: batch_ot_gmm's weight / variance validation, sinkhorn_log with 0 / 1 iterations, a
+    threshold that stops at once and float32 inputs, apply_transport's shape check / zero noise / diagonal operator) and of QKVAttention
+    (a width the heads do not divide): the value the reference returns, or the type of the exception it raises."""
+    w2, nu = R.ref("ot.w2_utils"), R.ref("networks.nets_utils")
+    out = {}
+    from detfill import edge_calls
+    for name, fn in edge_calls(w2, nu).items():
+        try:
+            res = fn()
+            for i, v in enumerate(res if isinstance(res, tuple) else (res,)):
+                out[f"{name}/value{i}"] = npy(v)
+            print(f"  {name}: returns")
+        except Exception as e:  # noqa: BLE001
+            out[f"{name}/error"] = np.frombuffer(type(e).__name__.encode(), dtype=np.uint8)
+            print(f"  {name}: {type(e).__name__}: {str(e).strip()[:70]}")
+    save("edge_calls.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1867,6 +1886,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint", "matrix_utils", "gaussian_transport_shapes"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint", "matrix_utils", "gaussian_transport_shapes", "edge_calls"]
     for w in which:
         globals()["gen_" + w]()

@@ -991,6 +991,10 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+class _WidthError(AssertionError, ValueError):
+    """a channel width the heads do not divide"""
+
+
 def _attention_op(qkv4: Tensor, heads: int, scale: Optional[float]) -> Tensor:
     """``torch.ops.otvae.qkv_attention`` (ops.py) on a [N, 3*H*C, H, W] NHWC tensor: fused attention forward, its backward
     registered with ``torch.library.register_autograd``.  Head widths 1 and 2 (the 32x32 and 16x16 blocks, 83 % of the
@@ -998,7 +1002,8 @@ def _attention_op(qkv4: Tensor, heads: int, scale: Optional[float]) -> Tensor:
     another pass over the keys."""
     n, width, h, w = qkv4.shape
     if width % (3 * heads) != 0:
-        raise ValueError(f"tensor width: {width} must be divisible by (3 * n_heads): {3 * heads}")
+        # the reference checks this with `assert` (networks/nets_utils.py:71): an AssertionError to whoever catches that, and still a ValueError
+        raise _WidthError(f"tensor width: {width} must be divisible by (3 * n_heads): {3 * heads}")
     c = width // (3 * heads)
     scale = 1.0 / c if scale is None else float(scale)  # 1/C = the two C^-1/2 factors of QKVAttention
     need_aux = qkv4.requires_grad and torch.is_grad_enabled()

@@ -1413,6 +1413,34 @@ def test_gaussian_transport_leading_shapes_vs_reference_golden(A, name):
     rep.finish()
 
 
+def test_edge_calls_vs_reference_golden(A):
+    """Edge cases of the OT helpers and of QKVAttention against the reference (edge_calls.npz, the calls are oracle/detfill.py:
+    edge_calls): batch_ot_gmm's weight / variance validation, sinkhorn_log with 0 / 1 iterations, a threshold that stops at once,
+    float32 inputs, apply_transport's shape check / zero noise / diagonal operator, a width the attention heads do not divide --
+    the value the reference returns, or an exception of the type it raises (a shape mismatch the reference only notices inside a
+    torch product, as a RuntimeError, may be refused earlier here, as a ValueError)."""
+    from detfill import edge_calls
+    from ot_vae_lightning_amd.ot import w2_utils as W2
+    from ot_vae_lightning_amd.networks import nets_utils as NU
+    z = load_golden("edge_calls.npz")
+    rep = Report("edge calls vs the reference")
+    for name, fn in edge_calls(W2, NU, dev="cuda").items():
+        if f"{name}/error" in z.files:
+            want = bytes(z[f"{name}/error"].astype("uint8")).decode()
+            with pytest.raises(Exception) as info:
+                fn()
+            got = type(info.value)
+            ok = any(c.__name__ == want for c in got.__mro__) or (want == "RuntimeError" and issubclass(got, ValueError))
+            assert ok, (name, got.__name__, want)
+            continue
+        res = fn()
+        for i, v in enumerate(res if isinstance(res, tuple) else (res,)):
+            want_v = torch.from_numpy(z[f"{name}/value{i}"])
+            tol = 2e-5 if want_v.dtype == torch.float32 else 1e-8
+            rep.check(f"{name}[{i}]", v, want_v, tol)
+    rep.finish()
+
+
 def test_gaussian_transport_1024_dims_vs_oracle(A):
     """W2 + transport operator at the reference's latent-transport test size (D = 1024, transport_dims (1,2,3))."""
     import otvae_oracle as O
