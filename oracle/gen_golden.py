@@ -1313,6 +1313,42 @@ def gen_edge_calls():
     save("edge_calls.npz", out)
 
 
+STATE_DICT_CASES = {
+    # name: (module path, class, args, kwargs)
+    "gaussian_full": ("ot.distribution_models.gaussian_model", "GaussianModel", (3, 4), dict(dtype=torch.double)),
+    "gaussian_diag": ("ot.distribution_models.gaussian_model", "GaussianModel", (4,), dict(dtype=torch.double, w2_cfg=dict(diag=True))),
+    "gaussian_autograd": ("ot.distribution_models.gaussian_model", "GaussianModel", (4,), dict(dtype=torch.double, update_with_autograd=True)),
+    "gaussian_autograd_diag": ("ot.distribution_models.gaussian_model", "GaussianModel", (2, 4), dict(dtype=torch.double, update_with_autograd=True, w2_cfg=dict(diag=True))),
+    "gmm_diag": ("ot.distribution_models.gassian_mixture_model", "GaussianMixtureModel", (2, 3), dict(dtype=torch.double, mixture_cfg=dict(n_components=4), w2_cfg=dict(diag=True))),
+    "gmm_full_autograd": ("ot.distribution_models.gassian_mixture_model", "GaussianMixtureModel", (3,), dict(dtype=torch.double, mixture_cfg=dict(n_components=4), update_with_autograd=True)),
+    "codebook": ("ot.distribution_models.codebook_model", "CodebookModel", (2, 3), dict(mixture_cfg=dict(n_components=5))),
+    "codebook_autograd": ("ot.distribution_models.codebook_model", "CodebookModel", (3,), dict(mixture_cfg=dict(n_components=5), update_with_autograd=True)),
+    "gaussian_transport": ("ot.transport.gaussian_transport", "GaussianTransport", (2, 4), dict(source_cfg=dict(dtype=torch.double), target_cfg=dict(dtype=torch.double), store_source=True)),
+    "gmm_transport": ("ot.transport.gmm_transport", "GMMTransport", (4,), dict(transport_type="argmax", transport_cfg=dict(diag=True, dtype=torch.double),
+                      source_cfg=dict(dtype=torch.double, mixture_cfg=dict(n_components=3)), target_cfg=dict(dtype=torch.double, mixture_cfg=dict(n_components=3)))),
+    "discrete_transport": ("ot.transport.discrete_transport", "DiscreteTransport", (4,), dict(transport_type="argmax",
+                           source_cfg=dict(mixture_cfg=dict(n_components=3)), target_cfg=dict(mixture_cfg=dict(n_components=3)))),
+    "gaussian_prior": ("prior.gaussian", "GaussianPrior", (), dict(loss_coeff=0.5)),
+    "cond_prior": ("prior.conditional_gaussian", "ConditionalGaussianPrior", (), dict(dim=(2, 3), num_classes=4)),
+    "cond_prior_ema": ("prior.conditional_gaussian", "ConditionalGaussianPrior", (), dict(dim=(2, 3), num_classes=4, embedding_ema_decay=0.9)),
+    "codebook_prior": ("prior.codebook", "CodebookPrior", ((8, 2, 2), (1,)), dict(loss="kl", mixture_cfg=dict(n_components=6))),
+}
+
+
+def gen_state_dicts():
+    """The state_dict keys, shapes, dtypes and `requires_grad` flags of the distribution models, transport operators and priors for
+    several constructor options (what a checkpoint written by the reference holds and `load_state_dict` here must accept)."""
+    out = {}
+    for name, (mod, cls, args, kw) in STATE_DICT_CASES.items():
+        torch.manual_seed(1)
+        m = getattr(R.ref(mod), cls)(*args, **kw)
+        rows = [f"{k}|{tuple(v.shape)}|{v.dtype}" for k, v in m.state_dict().items()]
+        grads = [f"{k}|{int(p.requires_grad)}" for k, p in m.named_parameters()]
+        out[f"{name}/state"] = np.array(rows or [""])
+        out[f"{name}/params"] = np.array(grads or [""])
+    save("state_dicts.npz", out)
+
+
 def gen_stochastic():
     """The stochastic transport operator, eq. 19 (ot/w2_utils.py:391-458,732-786) for a DEGENERATE source (its raison d'etre):
     (T, Cw) for diagonal and full covariances, and ``apply_transport`` with the noise the reference drew (recorded as the
@@ -1886,6 +1922,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint", "matrix_utils", "gaussian_transport_shapes", "edge_calls"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint", "matrix_utils", "gaussian_transport_shapes", "edge_calls", "state_dicts"]
     for w in which:
         globals()["gen_" + w]()
