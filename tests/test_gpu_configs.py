@@ -1040,6 +1040,42 @@ def test_graphed_nelbo_gives_the_unmodified_loop_the_graph_route(A):
     tr.close()
 
 
+def test_graphed_nelbo_with_a_conditional_vit_vae(A):
+    """The graph route of the reference's own loop for configs[4]'s model: a conditional ViT VAE (class tokens, ConditionalGaussianPrior)
+    whose `labels` travel as a batch keyword -- `enable_graphed_step()` must replay them from resident copies: loss vector and gradients
+    bit-equal to HipTrainer's for the same weights, batch, labels and noise over three steps with changing labels."""
+    torch.manual_seed(4)
+    B, D = 32, 32
+    cfg = dict(image_size=16, patch_size=4, dim=D, depth=1, heads=4, mlp_dim=64, channels=3, dropout=0., emb_dropout=0., num_classes=10)
+
+    def make():
+        torch.manual_seed(9)
+        enc = A.ViT(n_embed_tokens=2, n_input_tokens=None, output_tokens="embed", patch_to_embed=True, embed_to_patch=False, **cfg)
+        dec = A.ViT(n_embed_tokens=None, n_input_tokens=1, output_tokens="embed", patch_to_embed=False, embed_to_patch=True, **cfg)
+        prior = A.ConditionalGaussianPrior(dim=(1, D), num_classes=10, loss_coeff=0.1)
+        return A.VAE(encoder=enc, decoder=dec, prior=prior, conditional=True).cuda().train()
+
+    xs = [normal((B, 3, 16, 16), 40 + i).cuda() for i in range(3)]
+    es = [normal((B, 1, D), 50 + i).cuda() for i in range(3)]
+    ys = [((torch.arange(B) * (i + 3)) % 10).cuda() for i in range(3)]
+    tr = A.HipTrainer(make(), batch_shape=(B, 3, 16, 16), use_graph=True, batch_kwargs={"labels": ys[0]})
+    model = make().enable_graphed_step()
+    for i in range(3):
+        want = tr.step(xs[i], es[i], labels=ys[i]).clone()
+        want_g = tr.gflat.clone()
+        for p in model.parameters():
+            p.grad = None
+        loss, logs, art = model.loss({"samples": xs[i], "target": xs[i], "kwargs": {"eps": es[i], "labels": ys[i]}}, i)
+        loss.backward()
+        got = torch.stack([logs["train/loss/total"], logs["train/loss/recon"], logs["train/loss/prior"]]).detach()
+        assert torch.equal(got, want), (i, got, want)
+        eng = model.loss._cap.engine
+        assert torch.equal(eng.gflat, want_g), f"step {i}: gradients differ from HipTrainer's"
+        with torch.no_grad():
+            eng.pflat.copy_(tr.pflat)
+    tr.close()
+
+
 @pytest.mark.parametrize("prior_kind", ["gaussian", "sinkhorn"])
 def test_segmented_capture_equals_forked_capture(A, prior_kind, monkeypatch):
     """the captured step as a chain of linear hipGraphs + side graphs ordered by events between graph launches
