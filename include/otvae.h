@@ -167,6 +167,20 @@ int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int C, float sc
 int otvae_attn_bwd_scaled(const float* qkv, const float* out, const float* lse, const float* gout, const float* aux, int N,
                           int T, int H, int C, float scale, float* gqkv, void* stream);
 
+/* The whole AttentionBlock forward (networks/cnn.py:212-240: proj_out(attention(qkv(BN(x)))) [+ the ConvBlock's skip, cnn.py:331-335])
+ * as ONE launch: a workgroup owns whole images, forms q / k / v of its tokens from the normalised input (scale / shift [H*C] = the
+ * BatchNorm affine in front of the bias-free 1x1 qkv convolution, both NULL without one; wqkv [H*C][3*H*C], wproj [H*C][H*C] in the
+ * HWIO order of otvae_conv_fwd), runs the attention of otvae_attn_fwd_scaled and applies the bias-free 1x1 output projection,
+ * the residual sum (nullable) and the per-channel partial sums of y for the next BatchNorm (stat_partial [2][H*C][rows], nullable;
+ * rows from otvae_attn_stage_plan).  qkv [N][T][3*H*C], out [N][T][H*C] (the attention output), lse and aux are written as by the
+ * three separate launches: the backward pass is theirs.  otvae_attn_stage_plan returns OTVAE_EUNSUPPORTED (no error text) for
+ * shapes the fused kernel does not take (T == 1, T % 4 != 0, a width that is not a power of two <= 64, heads that do not fit one
+ * workgroup): the caller then issues the three launches. */
+int otvae_attn_stage_plan(int N, int T, int H, int C, int need_aux, int* stat_rows);
+int otvae_attn_stage_fwd(const float* x, const float* scale, const float* shift, const float* wqkv, const float* wproj,
+                         const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv, float* out, float* lse,
+                         float* aux, float* y, double* stat_partial, void* stream);
+
 /* Element-wise dropout with the same counter-based masks (keep(row, col) of a [rows][D] tensor, D % 4 == 0), optionally
  * fused with the ReLU in front of it: y = keep ? act(x)/(1-p) : 0.  relu != 0: the dropout(relu(linear1(x))) of a training-
  * mode nn.TransformerEncoderLayer; relu == 0: PositionalEmbedding's embedding dropout (networks/vit.py:54-58).  The backward

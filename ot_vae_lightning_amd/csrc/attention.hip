@@ -126,18 +126,119 @@ struct FwdRec {
     static constexpr int KV = AUX ? ((2 * C + C * C + 3) & ~3) : 2 * C;
 };
 
-template <int C, int QPT, bool AUX>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int N, int T, int H, int SPB,
-                                                       float* __restrict__ out, float* __restrict__ lse,
-                                                       float* __restrict__ aux, float qk_scale) {
-    extern __shared__ __align__(16) float sm[];
+// The AttentionBlock's two 1x1 convolutions (reference networks/cnn.py:212-240: qkv = Conv1x1(BN(x)), proj_out(attention) [+ skip])
+// for the FUSED forward kernel: a block owns whole images (SPB % H == 0), forms q / k / v of its tokens from the normalised input while
+// it stages them, and applies the output projection, the residual sum and the next BatchNorm's partial sums to its tokens at the end.
+struct AttnStage {
+    const float* x;         // [N][T][HC] the block's input, channels-last
+    const float* scale;     // [HC] BatchNorm affine in front of the qkv convolution, or NULL
+    const float* shift;
+    const float* wqkv;      // [HC][3 HC]  (HWIO of the 1x1 kernel)
+    const float* wproj;     // [HC][HC]
+    const float* residual;  // [N][T][HC] or NULL
+    float* qkv;             // [N][T][3 HC] written for the backward pass
+    float* y;               // [N][T][HC]
+    double* stat_partial;   // [2][HC][gridDim.x] per-channel sum / sum of squares of y, or NULL
+};
+
+// out(tok, col) = sum_ci in[tok][ci] * W[ci][col] over the block's ntok tokens (LDS, row stride Cin, ntok % 4 == 0): a work item is
+// 4 consecutive tokens x one column, columns fastest (the lanes of a wave read W coalesced and one token row as an LDS broadcast).
+// store(tok0, col, a[4]) receives the four sums.
+template <class Store>
+__device__ __forceinline__ void token_gemm(const float* __restrict__ in, int ntok, int Cin, const float* __restrict__ W, int ldw,
+                                           int ncols, Store&& store) {
+    const int items = (ntok >> 2) * ncols;
+    const float inv_nc = 1.0f / (float)ncols;
+    for (int e = threadIdx.x; e < items; e += blockDim.x) {
+        const int tg = adiv(e, ncols, inv_nc), col = e - tg * ncols;
+        const float* r = in + (size_t)tg * 4 * Cin;
+        const float* w = W + col;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((Cin & 3) == 0) {
+#pragma unroll 2
+            for (int ci = 0; ci < Cin; ci += 4) {
+                float wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wv[u] = w[(size_t)(ci + u) * ldw];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 xv = *reinterpret_cast<const float4*>(r + t * Cin + ci);
+                    a[t] = fmaf(xv.x, wv[0], a[t]);
+                    a[t] = fmaf(xv.y, wv[1], a[t]);
+                    a[t] = fmaf(xv.z, wv[2], a[t]);
+                    a[t] = fmaf(xv.w, wv[3], a[t]);
+                }
+            }
+        } else {
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float wv = w[(size_t)ci * ldw];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[t] = fmaf(r[t * Cin + ci], wv, a[t]);
+            }
+        }
+        store(tg * 4, col, a);
+    }
+}
+
+template <int C, int QPT, bool AUX, bool FUSED>
+__device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const float* __restrict__ qkv, int N, int T, int H, int SPB,
+                                              float* __restrict__ out, float* __restrict__ lse, float* __restrict__ aux,
+                                              float qk_scale, const AttnStage& sg) {
     constexpr int KVS = FwdRec<C, AUX>::KV;
     const int HC = H * C, W3 = 3 * HC;
     const int TPS = T / QPT;  // threads per slice
     const long total = (long)N * H;
     const long slice0 = (long)blockIdx.x * SPB;
     const int nsl = (int)min((long)SPB, total - slice0);
-    stage_kv<C, KVS>(sm, qkv, slice0, nsl, T, H);
+    // FUSED: LDS = {k, v (, u)} records [SPB][T][KVS] | q [SPB / H][T][HC] | normalised input, later the attention output [SPB / H][T][HC]
+    float* qs = sm + (size_t)SPB * T * KVS;
+    float* xs = qs + (size_t)SPB * T * C;
+    const int ntok = FUSED ? nsl / H * T : 0;                 // slice0 % H == 0 and (N H) % H == 0: whole images
+    const size_t tok0 = FUSED ? (size_t)(slice0 / H) * T : 0;  // first token of the block in [N][T]
+    if constexpr (FUSED) {
+        const float* xg = sg.x + tok0 * HC;
+        const int nx = ntok * HC;
+        if ((HC & 3) == 0) {
+            for (int i = threadIdx.x * 4; i < nx; i += blockDim.x * 4) {
+                float4 v = *reinterpret_cast<const float4*>(xg + i);
+                if (sg.scale) {
+                    const int c0 = i % HC;
+                    const float4 a = *reinterpret_cast<const float4*>(sg.scale + c0), b = *reinterpret_cast<const float4*>(sg.shift + c0);
+                    v.x = fmaf(v.x, a.x, b.x), v.y = fmaf(v.y, a.y, b.y), v.z = fmaf(v.z, a.z, b.z), v.w = fmaf(v.w, a.w, b.w);
+                }
+                *reinterpret_cast<float4*>(xs + i) = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+                float v = xg[i];
+                if (sg.scale) v = fmaf(v, sg.scale[i % HC], sg.shift[i % HC]);
+                xs[i] = v;
+            }
+        }
+        __syncthreads();
+        float* gq = sg.qkv + tok0 * W3;
+        token_gemm(xs, ntok, HC, sg.wqkv, W3, W3, [&](int t0_, int col, const float (&a)[4]) {
+            const int part = col / HC, hc = col - part * HC;
+            const int img = t0_ / T, tt = t0_ - img * T;
+            float* dst;
+            int stride;
+            if (part == 0) {
+                dst = qs + (size_t)t0_ * HC + hc;
+                stride = HC;
+            } else {
+                const int h_ = hc / C, c_ = hc - h_ * C;
+                dst = sm + ((size_t)(img * H + h_) * T + tt) * KVS + (part - 1) * C + c_;
+                stride = KVS;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dst[t * stride] = a[t];
+                gq[(size_t)(t0_ + t) * W3 + col] = a[t];
+            }
+        });
+    } else {
+        stage_kv<C, KVS>(sm, qkv, slice0, nsl, T, H);
+    }
     __syncthreads();
     const int sl = adiv((int)threadIdx.x, TPS, 1.0f / (float)TPS);
     const bool active = sl < nsl;
@@ -222,12 +323,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
         __syncthreads();
     }
-    if (!active) return;  // idle lanes stayed for the block barriers above; they read slice 0 and wrote nothing
+    if constexpr (!FUSED) {
+        if (!active) return;  // idle lanes stayed for the block barriers above; they read slice 0 and wrote nothing
+    }
+    const int img_l = FUSED ? (int)(n - slice0 / H) : 0;  // the lane's image within the block
+    if (!FUSED || active) {
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            q[i][c] = qkv[(n * T + t0 + i) * W3 + h * C + c] * inv_c;
+            if constexpr (FUSED) q[i][c] = qs[((size_t)img_l * T + t0 + i) * HC + h * C + c] * inv_c;
+            else q[i][c] = qkv[(n * T + t0 + i) * W3 + h * C + c] * inv_c;
             acc[i][c] = 0.f;
         }
 #pragma unroll
@@ -345,7 +451,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         const float rl = 1.f / l[i];
         float* o = out + (n * T + t0 + i) * HC + h * C;
 #pragma unroll
-        for (int c = 0; c < C; ++c) o[c] = acc[i][c] * rl;
+        for (int c = 0; c < C; ++c) {
+            o[c] = acc[i][c] * rl;
+            if constexpr (FUSED) xs[((size_t)img_l * T + t0 + i) * HC + h * C + c] = acc[i][c] * rl;  // (the input tile is dead by now)
+        }
         lse[(n * H + h) * T + t0 + i] = mx[i] * LN2 + __logf(l[i]);  // natural-log LSE
         if constexpr (AUX) {
             float* ao = aux + (((size_t)n * H + h) * T + t0 + i) * (C * C);
@@ -356,6 +465,60 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                     ao[c2 * C + c] = (am[i][c2 * C + c] - (acc[i][c2] * rl - vbar[c2]) * am[i][C * C + c]) * rl;
         }
     }
+    }  // active
+    if constexpr (FUSED) {
+        // output projection + residual of the block's tokens; a thread's column is fixed (blockDim.x % HC == 0), so it also carries that
+        // column's sums for the next BatchNorm: lanes of a wave (shuffles over the lane bits above HC), waves (LDS), one partial per block
+        __syncthreads();
+        float* yg = sg.y + tok0 * HC;
+        const float* rg = sg.residual ? sg.residual + tok0 * HC : nullptr;
+        double s1 = 0., s2 = 0.;
+        token_gemm(xs, ntok, HC, sg.wproj, HC, HC, [&](int t0_, int col, const float (&a)[4]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const size_t o = (size_t)(t0_ + t) * HC + col;
+                float v = a[t];
+                if (rg) v += rg[o];
+                yg[o] = v;
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            }
+        });
+        if (sg.stat_partial) {
+            for (int m = HC; m < 64; m <<= 1) {
+                s1 += __shfl_xor(s1, m, 64);
+                s2 += __shfl_xor(s2, m, 64);
+            }
+            double* red = reinterpret_cast<double*>(qs);  // q is in registers since the barrier above; [waves][2][HC]
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+            if (lane < HC) {
+                red[(wave * 2 + 0) * HC + lane] = s1;
+                red[(wave * 2 + 1) * HC + lane] = s2;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < 2 * HC) {
+                const int which = threadIdx.x / HC, cc = threadIdx.x - which * HC;
+                double t = red[which * HC + cc];
+                for (int w = 1; w < nw; ++w) t += red[(w * 2 + which) * HC + cc];
+                sg.stat_partial[((size_t)which * HC + cc) * gridDim.x + blockIdx.x] = t;
+            }
+        }
+    }
+}
+
+template <int C, int QPT, bool AUX>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int N, int T, int H, int SPB,
+                                                       float* __restrict__ out, float* __restrict__ lse,
+                                                       float* __restrict__ aux, float qk_scale) {
+    extern __shared__ __align__(16) float sm[];
+    attn_fwd_body<C, QPT, AUX, false>(sm, qkv, N, T, H, SPB, out, lse, aux, qk_scale, AttnStage{});
+}
+
+template <int C, int QPT, bool AUX>
+__global__ __launch_bounds__(256) void attn_stage_fwd_kernel(AttnStage sg, int N, int T, int H, int SPB, float* __restrict__ out,
+                                                             float* __restrict__ lse, float* __restrict__ aux, float qk_scale) {
+    extern __shared__ __align__(16) float sm[];
+    attn_fwd_body<C, QPT, AUX, true>(sm, nullptr, N, T, H, SPB, out, lse, aux, qk_scale, sg);
 }
 
 template <int C, int QPT, bool AUX>
@@ -786,6 +949,84 @@ extern "C" int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int 
     ATTN_C_SWITCH(C, FWD_K)
 #undef FWD_K
     OTVAE_CHECK_LAUNCH("otvae_attn_fwd");
+    return OTVAE_OK;
+}
+
+// ---- the fused AttentionBlock forward (attn_stage_fwd_kernel)
+static inline bool attn_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+// Launch shape, or OTVAE_EUNSUPPORTED when the stage has to run as three launches: a block must own whole images (spb % H == 0), the token
+// GEMMs want T % 4 == 0, the per-column statistics a power-of-two width <= 64.
+static int attn_stage_shape(int N, int T, int H, int C, bool aux, int* qpt, int* spb, int* grid, int* nthr, size_t* lds, bool quiet) {
+    const int HC = H * C;
+#define STAGE_NO(...)                                  \
+    do {                                               \
+        if (!quiet) otvae_set_error(__VA_ARGS__);      \
+        return OTVAE_EUNSUPPORTED;                     \
+    } while (0)
+    if (N <= 0 || T <= 1 || H <= 0 || C <= 0) STAGE_NO("otvae_attn_stage: bad sizes / T == 1");
+    if (T % 4 != 0 || HC > 64 || (HC & (HC - 1)) != 0) STAGE_NO("otvae_attn_stage: needs T %% 4 == 0 and a power-of-two width <= 64 (T=%d, width=%d)", T, HC);
+    switch (C) {
+        case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 32: break;
+        default: STAGE_NO("otvae_attn_stage: head width %d not instantiated", C);
+    }
+    *qpt = pick_qpt(T, C);
+    const int tps = T / *qpt;
+    if (tps > 256 || (*qpt == 4 && C > 4)) STAGE_NO("otvae_attn_stage: T = %d with head width %d unsupported", T, C);
+    const int rkv = aux ? ((2 * C + C * C + 3) & ~3) : 2 * C;
+    const int per_slice = T * (rkv + 2 * C);  // records + q + input / output tile
+    int s = imin(256 / tps, ATTN_LDS_FLOATS / per_slice) / H * H;
+    if (s < H) STAGE_NO("otvae_attn_stage: the %d heads of an image do not fit one workgroup (T=%d)", H, T);
+    // fill the chip: halve the images per block while the grid is short of one block per CU
+    while ((int64_t)N * H / s < 256 && s % (2 * H) == 0 && ((s / 2) * tps) % 64 == 0 && (s / 2 / H) * T >= 16) s /= 2;
+    if ((s / H) * T < 16) STAGE_NO("otvae_attn_stage: fewer than 16 tokens per workgroup");
+    *spb = s;
+    *grid = (int)cdiv((int64_t)N * H, s);
+    *nthr = attn_threads(s, T, *qpt);
+    *lds = (size_t)s * per_slice * sizeof(float);
+#undef STAGE_NO
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_attn_stage_plan(int N, int T, int H, int C, int need_aux, int* stat_rows) {
+    int qpt, spb, grid, nthr;
+    size_t lds;
+    int rc = attn_stage_shape(N, T, H, C, need_aux && C <= 2, &qpt, &spb, &grid, &nthr, &lds, true);
+    if (rc) return rc;
+    if (stat_rows) *stat_rows = grid;
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_attn_stage_fwd(const float* x, const float* scale, const float* shift, const float* wqkv, const float* wproj,
+                                    const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv, float* out, float* lse,
+                                    float* aux, float* y, double* stat_partial, void* stream) {
+    OTVAE_REQUIRE(x && wqkv && wproj && qkv && out && lse && y, "otvae_attn_stage_fwd: NULL tensor");
+    OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_attn_stage_fwd: scale/shift must come together");
+    OTVAE_REQUIRE(qk_scale > 0.f, "otvae_attn_stage_fwd: scale must be positive");
+    if (C > 2) aux = nullptr;
+    int qpt, spb, grid, nthr;
+    size_t lds;
+    int rc = attn_stage_shape(N, T, H, C, aux != nullptr, &qpt, &spb, &grid, &nthr, &lds, false);
+    if (rc) return rc;
+    OTVAE_REQUIRE(attn_aligned16(x) && attn_aligned16(scale) && attn_aligned16(shift), "otvae_attn_stage_fwd: x / scale / shift must be 16-byte aligned");
+    const AttnStage sg = {x, scale, shift, wqkv, wproj, residual, qkv, y, stat_partial};
+    hipStream_t st = (hipStream_t)stream;
+#define STAGE_K(CC)                                                                                                        \
+    do {                                                                                                                   \
+        if (qpt == 4) {                                                                                                    \
+            if constexpr (CC <= 2) {                                                                                       \
+                if (aux) attn_stage_fwd_kernel<CC, 4, true><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, aux, qk_scale); \
+                else attn_stage_fwd_kernel<CC, 4, false><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); \
+            } else if constexpr (CC <= 4) attn_stage_fwd_kernel<CC, 4, false><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); \
+        } else {                                                                                                           \
+            if constexpr (CC <= 2) {                                                                                       \
+                if (aux) attn_stage_fwd_kernel<CC, 1, true><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, aux, qk_scale); \
+                else attn_stage_fwd_kernel<CC, 1, false><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); \
+            } else attn_stage_fwd_kernel<CC, 1, false><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); \
+        }                                                                                                                  \
+    } while (0)
+    ATTN_C_SWITCH(C, STAGE_K)
+#undef STAGE_K
+    OTVAE_CHECK_LAUNCH("otvae_attn_stage_fwd");
     return OTVAE_OK;
 }
 

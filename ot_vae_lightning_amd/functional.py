@@ -1021,6 +1021,114 @@ def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:
     return _attention_op(as_nhwc(qkv), n_heads, None)
 
 
+# OTVAE_ATTN_STAGE=0 (A/B switch): the AttentionBlock runs as its three launches (qkv convolution, attention, output projection)
+ATTN_STAGE = os.environ.get("OTVAE_ATTN_STAGE", "1") != "0"
+_STAGE_PLAN_CACHE: dict = {}
+
+
+def _plain_1x1(br: dict, cout: int, cin: int) -> bool:
+    w = br["weight"]
+    return (br.get("act", 0) <= 1 and not br["relu"] and br.get("wscale", 1.0) == 1.0 and br.get("bscale", 1.0) == 1.0
+            and br.get("group_norm") is None and br.get("film") is None and br.get("dropout2d") is None and br.get("expand") is None
+            and br.get("up_module") is None and br.get("down_module") is None and br.get("bias") is None
+            and br["stride"] == 1 and br["pad"] == 0 and br["up"] == 1 and tuple(w.shape) == (cout, cin, 1, 1) and is_hwio(w))
+
+
+class _AttnStageFn(torch.autograd.Function):
+    """y = proj_out(attention(qkv(BN(x)))) [+ residual] in one launch (``otvae_attn_stage_fwd``); the backward pass is the three
+    stages' own (output projection, attention, qkv convolution + BatchNorm), fed from what the fused kernel wrote."""
+
+    @staticmethod
+    def forward(ctx, x, meta, wq, gamma, beta, wp, res):
+        lib = _lib.load()
+        heads, scale, stats, pref_q, pref_p, rows, need_aux, stats_out = meta
+        mean, invstd, scales, shifts, training = stats
+        n, hc, hh, ww = x.shape
+        t, c = hh * ww, hc // heads
+        qkv = empty_nhwc(n, 3 * hc, hh, ww, x)
+        out = empty_nhwc(n, hc, hh, ww, x)
+        y = empty_nhwc(n, hc, hh, ww, x)
+        lse = torch.empty((n, heads, t), device=x.device, dtype=torch.float32)
+        aux = torch.empty((n, heads, t, c * c), device=x.device, dtype=torch.float32) if (need_aux and c <= 2) else None
+        part = torch.empty((rows, 2, hc), device=x.device, dtype=torch.float64) if stats_out is not None else None
+        check(lib.otvae_attn_stage_fwd(ptr(x), ptr(scales[0]), ptr(shifts[0]), ptr(wq), ptr(wp), ptr(res), n, t, heads, c, scale,
+                                       ptr(qkv), ptr(out), ptr(lse), ptr(aux), ptr(y), ptr(part), stream()), "otvae_attn_stage_fwd")
+        if stats_out is not None:
+            stats_out.append((part, rows, hc))
+        ctx.cfg = (heads, scale, stats, pref_q, pref_p, gamma is not None, res is not None)
+        ctx.geoms = (_geom(x, wq, 1, 0, 1)[0], _geom(out, wp, 1, 0, 1)[0])
+        ctx.save_for_backward(x, wq, gamma, beta, wp, res, qkv, out, lse, aux)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, wq, gamma, beta, wp, res, qkv, out, lse, aux = ctx.saved_tensors
+        heads, scale, stats, pref_q, pref_p, has_norm, has_res = ctx.cfg
+        training = stats[4]
+        n, hc, hh, ww = x.shape
+        t, c = hh * ww, hc // heads
+        sp_p = ConvSpec(1, 0, 1, False, False, False, has_res, False)
+        gout, per_p = conv_backward_launch(out, (wp, None, None, None, res), (sp_p,), (ctx.geoms[1],),
+                                           (None, None, [None], [None], training), (pref_p,), (gy,), True)
+        gqkv = torch.empty_strided(qkv.shape, qkv.stride(), device=qkv.device, dtype=qkv.dtype)
+        check(lib.otvae_attn_bwd_scaled(ptr(qkv), ptr(out), ptr(lse), ptr(gout), ptr(aux), n, t, heads, c, scale, ptr(gqkv), stream()),
+              "otvae_attn_bwd")
+        sp_q = ConvSpec(1, 0, 1, False, has_norm, False, False, False)
+        dx, per_q = conv_backward_launch(x, (wq, None, gamma, beta, None), (sp_q,), (ctx.geoms[0],), stats, (pref_q,), (gqkv,),
+                                         ctx.needs_input_grad[0])
+        return dx, None, per_q[0][0], per_q[0][2], per_q[0][3], per_p[0][0], per_p[0][4]
+
+
+def attention_stage(x: Tensor, qkv_branch: dict, n_heads: int, proj_branch: dict, training: bool = True) -> Optional[Tensor]:
+    """The reference's AttentionBlock (networks/cnn.py:212-240) on a channels-last x as ONE launch, or None when the fused kernel does
+    not take this configuration (the caller then runs qkv convolution, attention and projection as three launches): both 1x1
+    convolutions must be plain (no bias, activation, FiLM, equalized learning rate, group norm), the width a power of two <= 64."""
+    if not ATTN_STAGE or x.dim() != 4 or x.dtype != torch.float32 or not x.is_cuda:
+        return None
+    n, hc, hh, ww = x.shape
+    if n_heads <= 0 or hc % n_heads != 0:
+        return None  # (the three-launch path raises the reference's error)
+    if not (_plain_1x1(qkv_branch, 3 * hc, hc) and _plain_1x1(proj_branch, hc, hc)):
+        return None
+    if proj_branch.get("gamma") is not None or qkv_branch.get("residual") is not None:
+        return None
+    lib = _lib.load()
+    t, c = hh * ww, hc // n_heads
+    res = proj_branch.get("residual")
+    wq, wp = qkv_branch["weight"], proj_branch["weight"]
+    need_aux = torch.is_grad_enabled() and any(v is not None and v.requires_grad for v in (x, wq, wp, qkv_branch.get("gamma"), res))
+    key = (n, t, n_heads, c, need_aux)
+    rows = _STAGE_PLAN_CACHE.get(key)
+    if rows is None:
+        r = C.c_int(0)
+        rows = _STAGE_PLAN_CACHE[key] = r.value if lib.otvae_attn_stage_plan(n, t, n_heads, c, int(need_aux), C.byref(r)) == 0 else 0
+    if rows == 0:
+        return None
+    x = as_nhwc(x)
+    if res is not None:
+        res = as_nhwc(res)
+    has_norm = qkv_branch.get("gamma") is not None
+    mean = invstd = None
+    scales, shifts = [None], [None]
+    if has_norm:
+        bn = BNBranch(qkv_branch["gamma"], qkv_branch["beta"], qkv_branch.get("running_mean"), qkv_branch.get("running_var"),
+                      qkv_branch.get("num_batches_tracked"))
+        if training:
+            mean, invstd, scales, shifts = bn_batch_stats(x, [bn])
+        else:
+            mean, invstd, s0, h0 = bn_eval_affine(bn)
+            scales, shifts = [s0], [h0]
+    stats = (mean, invstd, scales, shifts, training)
+    stats_out: Optional[list] = [] if (proj_branch.get("out_stats", False) and training) else None
+    meta = (n_heads, 1.0 / c, stats, (wq, None, qkv_branch.get("gamma"), qkv_branch.get("beta")), (wp, None, None, None), rows,
+            need_aux, stats_out)
+    y = _AttnStageFn.apply(x, meta, wq, qkv_branch.get("gamma"), qkv_branch.get("beta"), wp, res)
+    if stats_out:
+        y._otvae_stats = stats_out[0]
+    return y
+
+
 # ------------------------------------------------------------------------------------------------ prior / loss
 # ------------------------------------------------------------------------------------------------ token streams (ViT)
 def tokens_as_nhwc(x: Tensor) -> Tensor:

@@ -248,9 +248,13 @@ class AttentionBlock(nn.Module):
         self.proj_out = Conv1x1(channels, channels, equalized_lr=equalized_lr, groups=groups)
 
     def forward(self, x: Tensor, embed: Optional[Tensor] = None, *, residual: Optional[Tensor] = None) -> Tensor:
-        qkv = self.qkv(x, embed, out_stats=False)           # [N, 3*C, H, W] channels-last; feeds attention, no BN
-        h = HF.qkv_attention(qkv, self.attention.n_heads)   # [N, C, H, W]
-        return self.proj_out(h, residual=residual)
+        qb, pb = self.qkv.branch(None, False, embed), self.proj_out.branch(residual, True)
+        y = HF.attention_stage(x, qb, self.attention.n_heads, pb, training=self.qkv.training)   # one launch where the shapes allow
+        if y is not None:
+            return y
+        qkv = HF.conv_layers(x, [qb], training=self.qkv.training)[0]          # [N, 3*C, H, W] channels-last; feeds attention, no BN
+        h = HF.qkv_attention(qkv, self.attention.n_heads)                     # [N, C, H, W]
+        return HF.conv_layers(h, [pb], training=self.proj_out.training)[0]
 
 
 class ConvBlock(nn.Module):
