@@ -174,7 +174,7 @@ int otvae_attn_bwd_scaled(const float* qkv, const float* out, const float* lse, 
  * the residual sum (nullable) and the per-channel partial sums of y for the next BatchNorm (stat_partial [2][H*C][rows], nullable;
  * rows from otvae_attn_stage_plan).  qkv [N][T][3*H*C], out [N][T][H*C] (the attention output), lse and aux are written as by the
  * three separate launches: the backward pass is theirs.  otvae_attn_stage_plan returns OTVAE_EUNSUPPORTED (no error text) for
- * shapes the fused kernel does not take (T == 1, T % 4 != 0, a width that is not a power of two <= 64, heads that do not fit one
+ * shapes the fused kernel does not take (T == 1, T % 4 != 0, a width that is not a power of two <= 32, heads that do not fit one
  * workgroup): the caller then issues the three launches. */
 int otvae_attn_stage_plan(int N, int T, int H, int C, int need_aux, int* stat_rows);
 int otvae_attn_stage_fwd(const float* x, const float* scale, const float* shift, const float* wqkv, const float* wproj,

@@ -141,42 +141,166 @@ struct AttnStage {
     double* stat_partial;   // [2][HC][gridDim.x] per-channel sum / sum of squares of y, or NULL
 };
 
-// out(tok, col) = sum_ci in[tok][ci] * W[ci][col] over the block's ntok tokens (LDS, row stride Cin, ntok % 4 == 0): a work item is
-// 4 consecutive tokens x one column, columns fastest (the lanes of a wave read W coalesced and one token row as an LDS broadcast).
-// store(tok0, col, a[4]) receives the four sums.
-template <class Store>
-__device__ __forceinline__ void token_gemm(const float* __restrict__ in, int ntok, int Cin, const float* __restrict__ W, int ldw,
-                                           int ncols, Store&& store) {
-    const int items = (ntok >> 2) * ncols;
-    const float inv_nc = 1.0f / (float)ncols;
+// n floats global -> LDS, 16 bytes per lane when the source allows; eight loads of a thread in flight at once (a load -> store loop
+// pays one memory round trip per trip: 24 of them for the 48 KiB of a 64-wide block's qkv weights on 128 threads)
+__device__ __forceinline__ void stage_weights(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int step = blockDim.x * 4;
+        int i0 = threadIdx.x * 4;
+        for (; i0 + 7 * step < n; i0 += 8 * step) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + i0 + u * step);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(dst + i0 + u * step) = v[u];
+        }
+        for (; i0 < n; i0 += step) *reinterpret_cast<float4*>(dst + i0) = *reinterpret_cast<const float4*>(src + i0);
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// out(tok, col) = sum_ci in[tok][ci] * W[ci][col] over the block's ntok tokens (LDS, row stride Cin, ntok % 4 == 0) with W [Cin][ncols]
+// in LDS as well: a work item is 4 consecutive tokens x NC adjacent columns, columns fastest (the lanes of a wave read W rows
+// conflict-free and one token row as a broadcast).  store(tok0, col0, a[4][NC]) receives the sums.
+template <int NC, class Store>
+__device__ __forceinline__ void token_gemm(const float* __restrict__ in, int ntok, int Cin, const float* __restrict__ W, int ncols,
+                                           Store&& store) {
+    const int cg = ncols / NC;
+    const int items = (ntok >> 2) * cg;
+    const float inv_cg = 1.0f / (float)cg;
     for (int e = threadIdx.x; e < items; e += blockDim.x) {
-        const int tg = adiv(e, ncols, inv_nc), col = e - tg * ncols;
+        const int tg = adiv(e, cg, inv_cg), col = (e - tg * cg) * NC;
         const float* r = in + (size_t)tg * 4 * Cin;
         const float* w = W + col;
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        float a[4][NC];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) a[t][j] = 0.f;
         if ((Cin & 3) == 0) {
 #pragma unroll 2
             for (int ci = 0; ci < Cin; ci += 4) {
-                float wv[4];
+                float wv[4][NC];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) wv[u] = w[(size_t)(ci + u) * ldw];
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) wv[u][j] = w[(ci + u) * ncols + j];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float4 xv = *reinterpret_cast<const float4*>(r + t * Cin + ci);
-                    a[t] = fmaf(xv.x, wv[0], a[t]);
-                    a[t] = fmaf(xv.y, wv[1], a[t]);
-                    a[t] = fmaf(xv.z, wv[2], a[t]);
-                    a[t] = fmaf(xv.w, wv[3], a[t]);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) {
+                        a[t][j] = fmaf(xv.x, wv[0][j], a[t][j]);
+                        a[t][j] = fmaf(xv.y, wv[1][j], a[t][j]);
+                        a[t][j] = fmaf(xv.z, wv[2][j], a[t][j]);
+                        a[t][j] = fmaf(xv.w, wv[3][j], a[t][j]);
+                    }
                 }
             }
         } else {
             for (int ci = 0; ci < Cin; ++ci) {
-                const float wv = w[(size_t)ci * ldw];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) a[t] = fmaf(r[t * Cin + ci], wv, a[t]);
+                for (int j = 0; j < NC; ++j) {
+                    const float wv = w[ci * ncols + j];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a[t][j] = fmaf(r[t * Cin + ci], wv, a[t][j]);
+                }
             }
         }
         store(tg * 4, col, a);
+    }
+}
+
+// q / k / v of the block's tokens from the normalised input tile: q -> qs [tok][HC], k / v -> the slices' records, all three -> global
+template <int C, int KVS, int NC>
+__device__ __forceinline__ void stage_qkv(float* __restrict__ sm, float* __restrict__ qs, const float* __restrict__ xs,
+                                          const float* __restrict__ wl, int ntok, int T, int H, float* __restrict__ gq) {
+    const int HC = H * C, W3 = 3 * HC;
+    token_gemm<NC>(xs, ntok, HC, wl, W3, [&](int t0_, int col0, const float (&a)[4][NC]) {
+        const int img = t0_ / T, tt = t0_ - img * T;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int col = col0 + j;
+            const int part = col / HC, hc = col - part * HC;
+            float* dst;
+            int stride;
+            if (part == 0) {
+                dst = qs + (size_t)t0_ * HC + hc;
+                stride = HC;
+            } else {
+                const int h_ = hc / C, c_ = hc - h_ * C;
+                dst = sm + ((size_t)(img * H + h_) * T + tt) * KVS + (part - 1) * C + c_;
+                stride = KVS;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[t * stride] = a[t][j];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float* g = gq + (size_t)(t0_ + t) * W3 + col0;
+            if constexpr (NC == 2) *reinterpret_cast<float2*>(g) = make_float2(a[t][0], a[t][1]);
+            else g[0] = a[t][0];
+        }
+    });
+}
+
+// output projection + residual of the block's tokens (attention output in xs, wproj in wl); a thread's NC columns are fixed
+// (blockDim.x % (HC / NC) == 0), so it also carries their sums for the next BatchNorm: lanes of a wave (shuffles over the lane bits
+// above HC / NC), waves (LDS, red [waves][2][HC] doubles), one partial per block
+template <int NC>
+__device__ __forceinline__ void stage_project(const float* __restrict__ xs, const float* __restrict__ wl, double* __restrict__ red,
+                                              int ntok, int HC, float* __restrict__ yg, const float* __restrict__ rg,
+                                              double* __restrict__ stat_partial) {
+    double s1[NC], s2[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) s1[j] = s2[j] = 0.;
+    token_gemm<NC>(xs, ntok, HC, wl, HC, [&](int t0_, int col0, const float (&a)[4][NC]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const size_t o = (size_t)(t0_ + t) * HC + col0;
+            float v[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) v[j] = a[t][j];
+            if (rg) {
+                if constexpr (NC == 2) {
+                    const float2 rv = *reinterpret_cast<const float2*>(rg + o);
+                    v[0] += rv.x, v[1] += rv.y;
+                } else v[0] += rg[o];
+            }
+            if constexpr (NC == 2) *reinterpret_cast<float2*>(yg + o) = make_float2(v[0], v[1]);
+            else yg[o] = v[0];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                s1[j] += (double)v[j];
+                s2[j] += (double)v[j] * (double)v[j];
+            }
+        }
+    });
+    if (stat_partial) {
+        const int cg = HC / NC;
+        for (int m = cg; m < 64; m <<= 1) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                s1[j] += __shfl_xor(s1[j], m, 64);
+                s2[j] += __shfl_xor(s2[j], m, 64);
+            }
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        if (lane < cg) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                red[(wave * 2 + 0) * HC + lane * NC + j] = s1[j];
+                red[(wave * 2 + 1) * HC + lane * NC + j] = s2[j];
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * HC) {
+            const int which = threadIdx.x / HC, cc = threadIdx.x - which * HC;
+            double t = red[which * HC + cc];
+            for (int w = 1; w < nw; ++w) t += red[(w * 2 + which) * HC + cc];
+            stat_partial[((size_t)which * HC + cc) * gridDim.x + blockIdx.x] = t;
+        }
     }
 }
 
@@ -191,8 +315,10 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const floa
     const long slice0 = (long)blockIdx.x * SPB;
     const int nsl = (int)min((long)SPB, total - slice0);
     // FUSED: LDS = {k, v (, u)} records [SPB][T][KVS] | q [SPB / H][T][HC] | normalised input, later the attention output [SPB / H][T][HC]
+    //              | the 1x1 kernels' weights
     float* qs = sm + (size_t)SPB * T * KVS;
     float* xs = qs + (size_t)SPB * T * C;
+    float* wl = xs + (size_t)SPB * T * C;  // [HC][3 HC] qkv weights, later [HC][HC] projection weights
     const int ntok = FUSED ? nsl / H * T : 0;                 // slice0 % H == 0 and (N H) % H == 0: whole images
     const size_t tok0 = FUSED ? (size_t)(slice0 / H) * T : 0;  // first token of the block in [N][T]
     if constexpr (FUSED) {
@@ -215,31 +341,16 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const floa
                 xs[i] = v;
             }
         }
+        stage_weights(wl, sg.wqkv, HC * W3);
         __syncthreads();
         float* gq = sg.qkv + tok0 * W3;
-        token_gemm(xs, ntok, HC, sg.wqkv, W3, W3, [&](int t0_, int col, const float (&a)[4]) {
-            const int part = col / HC, hc = col - part * HC;
-            const int img = t0_ / T, tt = t0_ - img * T;
-            float* dst;
-            int stride;
-            if (part == 0) {
-                dst = qs + (size_t)t0_ * HC + hc;
-                stride = HC;
-            } else {
-                const int h_ = hc / C, c_ = hc - h_ * C;
-                dst = sm + ((size_t)(img * H + h_) * T + tt) * KVS + (part - 1) * C + c_;
-                stride = KVS;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                dst[t * stride] = a[t];
-                gq[(size_t)(t0_ + t) * W3 + col] = a[t];
-            }
-        });
+        if (HC & 1) stage_qkv<C, KVS, 1>(sm, qs, xs, wl, ntok, T, H, gq);
+        else stage_qkv<C, KVS, 2>(sm, qs, xs, wl, ntok, T, H, gq);
     } else {
         stage_kv<C, KVS>(sm, qkv, slice0, nsl, T, H);
     }
     __syncthreads();
+    if constexpr (FUSED) stage_weights(wl, sg.wproj, HC * HC);  // (the qkv weights are dead; visible after the barrier in front of the projection)
     const int sl = adiv((int)threadIdx.x, TPS, 1.0f / (float)TPS);
     const bool active = sl < nsl;
     const int t0 = (threadIdx.x - sl * TPS) * QPT;
@@ -467,42 +578,12 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const floa
     }
     }  // active
     if constexpr (FUSED) {
-        // output projection + residual of the block's tokens; a thread's column is fixed (blockDim.x % HC == 0), so it also carries that
-        // column's sums for the next BatchNorm: lanes of a wave (shuffles over the lane bits above HC), waves (LDS), one partial per block
         __syncthreads();
         float* yg = sg.y + tok0 * HC;
         const float* rg = sg.residual ? sg.residual + tok0 * HC : nullptr;
-        double s1 = 0., s2 = 0.;
-        token_gemm(xs, ntok, HC, sg.wproj, HC, HC, [&](int t0_, int col, const float (&a)[4]) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const size_t o = (size_t)(t0_ + t) * HC + col;
-                float v = a[t];
-                if (rg) v += rg[o];
-                yg[o] = v;
-                s1 += (double)v;
-                s2 += (double)v * (double)v;
-            }
-        });
-        if (sg.stat_partial) {
-            for (int m = HC; m < 64; m <<= 1) {
-                s1 += __shfl_xor(s1, m, 64);
-                s2 += __shfl_xor(s2, m, 64);
-            }
-            double* red = reinterpret_cast<double*>(qs);  // q is in registers since the barrier above; [waves][2][HC]
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-            if (lane < HC) {
-                red[(wave * 2 + 0) * HC + lane] = s1;
-                red[(wave * 2 + 1) * HC + lane] = s2;
-            }
-            __syncthreads();
-            if ((int)threadIdx.x < 2 * HC) {
-                const int which = threadIdx.x / HC, cc = threadIdx.x - which * HC;
-                double t = red[which * HC + cc];
-                for (int w = 1; w < nw; ++w) t += red[(w * 2 + which) * HC + cc];
-                sg.stat_partial[((size_t)which * HC + cc) * gridDim.x + blockIdx.x] = t;
-            }
-        }
+        double* red = reinterpret_cast<double*>(qs);  // (q has been in registers since the barrier behind the staging)
+        if (HC & 1) stage_project<1>(xs, wl, red, ntok, HC, yg, rg, sg.stat_partial);
+        else stage_project<2>(xs, wl, red, ntok, HC, yg, rg, sg.stat_partial);
     }
 }
 
@@ -953,6 +1034,20 @@ extern "C" int otvae_attn_fwd_scaled(const float* qkv, int N, int T, int H, int 
 }
 
 // ---- the fused AttentionBlock forward (attn_stage_fwd_kernel)
+#define ATTN_STAGE_LDS_FLOATS 24576  // 96 KiB of the CU's 160: above 64 KiB a kernel has to be told (stage_lds_ok), two workgroups still share a CU
+template <auto Kernel>
+static int stage_lds_ok(size_t lds) {
+    static size_t granted = 64 * 1024;  // per kernel instantiation
+    if (lds <= granted) return OTVAE_OK;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             ATTN_STAGE_LDS_FLOATS * sizeof(float));
+    if (e != hipSuccess) {
+        otvae_set_error("otvae_attn_stage_fwd: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
+        return OTVAE_ELAUNCH;
+    }
+    granted = ATTN_STAGE_LDS_FLOATS * sizeof(float);
+    return OTVAE_OK;
+}
 static inline bool attn_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // Launch shape, or OTVAE_EUNSUPPORTED when the stage has to run as three launches: a block must own whole images (spb % H == 0), the token
 // GEMMs want T % 4 == 0, the per-column statistics a power-of-two width <= 64.
@@ -964,7 +1059,9 @@ static int attn_stage_shape(int N, int T, int H, int C, bool aux, int* qpt, int*
         return OTVAE_EUNSUPPORTED;                     \
     } while (0)
     if (N <= 0 || T <= 1 || H <= 0 || C <= 0) STAGE_NO("otvae_attn_stage: bad sizes / T == 1");
-    if (T % 4 != 0 || HC > 64 || (HC & (HC - 1)) != 0) STAGE_NO("otvae_attn_stage: needs T %% 4 == 0 and a power-of-two width <= 64 (T=%d, width=%d)", T, HC);
+    // width 64 (48 KiB of qkv weights per workgroup, 16 tokens to spend them on at the 2x2 maps where it occurs) measured SLOWER than the
+    // three launches: 26 us against 6.7 + 5.5 + 4.4 (profiles/r03_attn_stage_ab.txt)
+    if (T % 4 != 0 || HC > 32 || (HC & (HC - 1)) != 0) STAGE_NO("otvae_attn_stage: needs T %% 4 == 0 and a power-of-two width <= 32 (T=%d, width=%d)", T, HC);
     switch (C) {
         case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 32: break;
         default: STAGE_NO("otvae_attn_stage: head width %d not instantiated", C);
@@ -974,7 +1071,8 @@ static int attn_stage_shape(int N, int T, int H, int C, bool aux, int* qpt, int*
     if (tps > 256 || (*qpt == 4 && C > 4)) STAGE_NO("otvae_attn_stage: T = %d with head width %d unsupported", T, C);
     const int rkv = aux ? ((2 * C + C * C + 3) & ~3) : 2 * C;
     const int per_slice = T * (rkv + 2 * C);  // records + q + input / output tile
-    int s = imin(256 / tps, ATTN_LDS_FLOATS / per_slice) / H * H;
+    const int wfloats = 3 * HC * HC;          // the qkv weights (the projection's reuse their place)
+    int s = imin(256 / tps, (ATTN_STAGE_LDS_FLOATS - wfloats) / per_slice) / H * H;
     if (s < H) STAGE_NO("otvae_attn_stage: the %d heads of an image do not fit one workgroup (T=%d)", H, T);
     // fill the chip: halve the images per block while the grid is short of one block per CU
     while ((int64_t)N * H / s < 256 && s % (2 * H) == 0 && ((s / 2) * tps) % 64 == 0 && (s / 2 / H) * T >= 16) s /= 2;
@@ -982,7 +1080,7 @@ static int attn_stage_shape(int N, int T, int H, int C, bool aux, int* qpt, int*
     *spb = s;
     *grid = (int)cdiv((int64_t)N * H, s);
     *nthr = attn_threads(s, T, *qpt);
-    *lds = (size_t)s * per_slice * sizeof(float);
+    *lds = ((size_t)s * per_slice + wfloats) * sizeof(float);
 #undef STAGE_NO
     return OTVAE_OK;
 }
@@ -1008,20 +1106,22 @@ extern "C" int otvae_attn_stage_fwd(const float* x, const float* scale, const fl
     int rc = attn_stage_shape(N, T, H, C, aux != nullptr, &qpt, &spb, &grid, &nthr, &lds, false);
     if (rc) return rc;
     OTVAE_REQUIRE(attn_aligned16(x) && attn_aligned16(scale) && attn_aligned16(shift), "otvae_attn_stage_fwd: x / scale / shift must be 16-byte aligned");
+    OTVAE_REQUIRE(((uintptr_t)qkv & 7) == 0 && ((uintptr_t)y & 7) == 0 && ((uintptr_t)residual & 7) == 0,
+                  "otvae_attn_stage_fwd: qkv / y / residual must be 8-byte aligned");
     const AttnStage sg = {x, scale, shift, wqkv, wproj, residual, qkv, y, stat_partial};
     hipStream_t st = (hipStream_t)stream;
 #define STAGE_K(CC)                                                                                                        \
     do {                                                                                                                   \
         if (qpt == 4) {                                                                                                    \
             if constexpr (CC <= 2) {                                                                                       \
-                if (aux) attn_stage_fwd_kernel<CC, 4, true><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, aux, qk_scale); \
-                else attn_stage_fwd_kernel<CC, 4, false><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); \
-            } else if constexpr (CC <= 4) attn_stage_fwd_kernel<CC, 4, false><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); \
+                if (aux) { rc = stage_lds_ok<&attn_stage_fwd_kernel<CC, 4, true>>(lds); if (rc) return rc; (attn_stage_fwd_kernel<CC, 4, true>)<<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, aux, qk_scale); } \
+                else { rc = stage_lds_ok<&attn_stage_fwd_kernel<CC, 4, false>>(lds); if (rc) return rc; (attn_stage_fwd_kernel<CC, 4, false>)<<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); } \
+            } else if constexpr (CC <= 4) { rc = stage_lds_ok<&attn_stage_fwd_kernel<CC, 4, false>>(lds); if (rc) return rc; (attn_stage_fwd_kernel<CC, 4, false>)<<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); } \
         } else {                                                                                                           \
             if constexpr (CC <= 2) {                                                                                       \
-                if (aux) attn_stage_fwd_kernel<CC, 1, true><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, aux, qk_scale); \
-                else attn_stage_fwd_kernel<CC, 1, false><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); \
-            } else attn_stage_fwd_kernel<CC, 1, false><<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); \
+                if (aux) { rc = stage_lds_ok<&attn_stage_fwd_kernel<CC, 1, true>>(lds); if (rc) return rc; (attn_stage_fwd_kernel<CC, 1, true>)<<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, aux, qk_scale); } \
+                else { rc = stage_lds_ok<&attn_stage_fwd_kernel<CC, 1, false>>(lds); if (rc) return rc; (attn_stage_fwd_kernel<CC, 1, false>)<<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); } \
+            } else { rc = stage_lds_ok<&attn_stage_fwd_kernel<CC, 1, false>>(lds); if (rc) return rc; (attn_stage_fwd_kernel<CC, 1, false>)<<<grid, nthr, lds, st>>>(sg, N, T, H, spb, out, lse, nullptr, qk_scale); } \
         }                                                                                                                  \
     } while (0)
     ATTN_C_SWITCH(C, STAGE_K)

@@ -1083,7 +1083,7 @@ class _AttnStageFn(torch.autograd.Function):
 def attention_stage(x: Tensor, qkv_branch: dict, n_heads: int, proj_branch: dict, training: bool = True) -> Optional[Tensor]:
     """The reference's AttentionBlock (networks/cnn.py:212-240) on a channels-last x as ONE launch, or None when the fused kernel does
     not take this configuration (the caller then runs qkv convolution, attention and projection as three launches): both 1x1
-    convolutions must be plain (no bias, activation, FiLM, equalized learning rate, group norm), the width a power of two <= 64."""
+    convolutions must be plain (no bias, activation, FiLM, equalized learning rate, group norm), the width a power of two <= 32."""
     if not ATTN_STAGE or x.dim() != 4 or x.dtype != torch.float32 or not x.is_cuda:
         return None
     n, hc, hh, ww = x.shape

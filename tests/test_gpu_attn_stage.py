@@ -12,8 +12,8 @@ from detfill import normal
 
 pytestmark = pytest.mark.gpu
 
-# (batch, width, side, heads): the five fused stages of the MNIST / CIFAR autoencoders + ragged batches (a last workgroup with fewer images)
-SHAPES = [(8, 8, 16, 4), (6, 16, 8, 4), (9, 32, 4, 4), (13, 64, 2, 8), (3, 1, 32, 1), (5, 4, 4, 2), (4, 16, 16, 4), (7, 64, 4, 8)]
+# (batch, width, side, heads): the fused stages of the MNIST / CIFAR autoencoders + ragged batches (a last workgroup with fewer images)
+SHAPES = [(8, 8, 16, 4), (6, 16, 8, 4), (9, 32, 4, 8), (13, 32, 2, 8), (3, 1, 32, 1), (5, 4, 4, 2), (4, 16, 16, 4), (7, 32, 4, 4), (5, 2, 8, 2)]
 TOL = 1e-4
 
 
@@ -128,7 +128,7 @@ def test_stage_eval_mode_and_no_norm(A):
 def test_stage_plan_rejects_what_it_cannot_take(A):
     lib = A._lib.load()
     rows = C.c_int(0)
-    for n, t, h, c in [(4, 1, 16, 16), (4, 9, 2, 4), (4, 16, 3, 4), (4, 16, 8, 16), (4, 1024, 4, 2)]:
+    for n, t, h, c in [(4, 1, 16, 16), (4, 9, 2, 4), (4, 16, 3, 4), (4, 16, 8, 16), (4, 4, 8, 8), (4, 1024, 4, 2)]:
         assert lib.otvae_attn_stage_plan(n, t, h, c, 1, C.byref(rows)) != 0, (n, t, h, c)
     # ... and such blocks still run (three launches)
     from ot_vae_lightning_amd import functional as HF
