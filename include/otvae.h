@@ -181,6 +181,18 @@ int otvae_attn_stage_fwd(const float* x, const float* scale, const float* shift,
                          const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv, float* out, float* lse,
                          float* aux, float* y, double* stat_partial, void* stream);
 
+/* The AttentionBlock's backward pass as ONE launch on what otvae_attn_stage_fwd wrote (qkv, out, lse, aux): the attention output's
+ * gradient is formed from gy [N][T][H*C] (gout = gy . wproj^T), the attention backward of otvae_attn_bwd_scaled writes gqkv
+ * [N][T][3*H*C] (read afterwards by the qkv weight-gradient job), and gv [N][T][H*C] = gqkv . wqkv^T, the gradient of the qkv
+ * convolution's normalised input, leaves with the BatchNorm-backward partial sums bn_partial [2][H*C][rows] (sum gv, sum gv * xhat per
+ * channel, xhat = (x - mean) * invstd: what otvae_conv_bwd_data emits for otvae_bn_bwd_finalize; mean / invstd / x / bn_partial all
+ * NULL without a BatchNorm).  rows from otvae_attn_stage_bwd_plan, which returns OTVAE_EUNSUPPORTED for shapes the kernel does not
+ * take (the caller then issues the three launches). */
+int otvae_attn_stage_bwd_plan(int N, int T, int H, int C, int* bn_rows);
+int otvae_attn_stage_bwd(const float* gy, const float* wproj, const float* wqkv, const float* x, const float* mean,
+                         const float* invstd, const float* qkv, const float* out, const float* lse, const float* aux, int N, int T,
+                         int H, int C, float qk_scale, float* gqkv, float* gv, double* bn_partial, void* stream);
+
 /* Element-wise dropout with the same counter-based masks (keep(row, col) of a [rows][D] tensor, D % 4 == 0), optionally
  * fused with the ReLU in front of it: y = keep ? act(x)/(1-p) : 0.  relu != 0: the dropout(relu(linear1(x))) of a training-
  * mode nn.TransformerEncoderLayer; relu == 0: PositionalEmbedding's embedding dropout (networks/vit.py:54-58).  The backward

@@ -12,6 +12,7 @@
 //     amortised over QPT pairs and QPT independent exp/FMA chains hide each other's latency;
 //   * for C == 1 the row maximum is closed-form (q * max_s k or q * min_s k), so the forward needs a single pass.
 #include "common.h"
+#include <type_traits>
 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
@@ -245,6 +246,37 @@ __device__ __forceinline__ void stage_qkv(float* __restrict__ sm, float* __restr
     });
 }
 
+// Per-block partial of per-column double sums carried by threads whose NC columns are fixed (column group = thread % (HC / NC)):
+// lanes of a wave (shuffles over the lane bits above HC / NC), waves (LDS, red [waves][2][HC] doubles), then partial [2][HC][gridDim.x].
+// All threads of the block call it.
+template <int NC>
+__device__ __forceinline__ void column_sums_to_partial(double (&s1)[NC], double (&s2)[NC], double* __restrict__ red, int HC,
+                                                       double* __restrict__ partial) {
+    const int cg = HC / NC;
+    for (int m = cg; m < 64; m <<= 1) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            s1[j] += __shfl_xor(s1[j], m, 64);
+            s2[j] += __shfl_xor(s2[j], m, 64);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane < cg) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            red[(wave * 2 + 0) * HC + lane * NC + j] = s1[j];
+            red[(wave * 2 + 1) * HC + lane * NC + j] = s2[j];
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * HC) {
+        const int which = threadIdx.x / HC, cc = threadIdx.x - which * HC;
+        double t = red[which * HC + cc];
+        for (int w = 1; w < nw; ++w) t += red[(w * 2 + which) * HC + cc];
+        partial[((size_t)which * HC + cc) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // output projection + residual of the block's tokens (attention output in xs, wproj in wl); a thread's NC columns are fixed
 // (blockDim.x % (HC / NC) == 0), so it also carries their sums for the next BatchNorm: lanes of a wave (shuffles over the lane bits
 // above HC / NC), waves (LDS, red [waves][2][HC] doubles), one partial per block
@@ -277,31 +309,7 @@ __device__ __forceinline__ void stage_project(const float* __restrict__ xs, cons
             }
         }
     });
-    if (stat_partial) {
-        const int cg = HC / NC;
-        for (int m = cg; m < 64; m <<= 1) {
-#pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                s1[j] += __shfl_xor(s1[j], m, 64);
-                s2[j] += __shfl_xor(s2[j], m, 64);
-            }
-        }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        if (lane < cg) {
-#pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                red[(wave * 2 + 0) * HC + lane * NC + j] = s1[j];
-                red[(wave * 2 + 1) * HC + lane * NC + j] = s2[j];
-            }
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < 2 * HC) {
-            const int which = threadIdx.x / HC, cc = threadIdx.x - which * HC;
-            double t = red[which * HC + cc];
-            for (int w = 1; w < nw; ++w) t += red[(w * 2 + which) * HC + cc];
-            stat_partial[((size_t)which * HC + cc) * gridDim.x + blockIdx.x] = t;
-        }
-    }
+    if (stat_partial) column_sums_to_partial<NC>(s1, s2, red, HC, stat_partial);
 }
 
 template <int C, int QPT, bool AUX, bool FUSED>
@@ -315,10 +323,11 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const floa
     const long slice0 = (long)blockIdx.x * SPB;
     const int nsl = (int)min((long)SPB, total - slice0);
     // FUSED: LDS = {k, v (, u)} records [SPB][T][KVS] | q [SPB / H][T][HC] | normalised input, later the attention output [SPB / H][T][HC]
-    //              | the 1x1 kernels' weights
+    //              | the two 1x1 kernels' weights
     float* qs = sm + (size_t)SPB * T * KVS;
     float* xs = qs + (size_t)SPB * T * C;
-    float* wl = xs + (size_t)SPB * T * C;  // [HC][3 HC] qkv weights, later [HC][HC] projection weights
+    float* wl = xs + (size_t)SPB * T * C;  // [HC][3 HC] qkv weights
+    float* wpl = wl + 3 * HC * HC;         // [HC][HC] projection weights (all weight loads fly with the input tile's)
     const int ntok = FUSED ? nsl / H * T : 0;                 // slice0 % H == 0 and (N H) % H == 0: whole images
     const size_t tok0 = FUSED ? (size_t)(slice0 / H) * T : 0;  // first token of the block in [N][T]
     if constexpr (FUSED) {
@@ -342,6 +351,7 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const floa
             }
         }
         stage_weights(wl, sg.wqkv, HC * W3);
+        stage_weights(wpl, sg.wproj, HC * HC);
         __syncthreads();
         float* gq = sg.qkv + tok0 * W3;
         if (HC & 1) stage_qkv<C, KVS, 1>(sm, qs, xs, wl, ntok, T, H, gq);
@@ -350,7 +360,6 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const floa
         stage_kv<C, KVS>(sm, qkv, slice0, nsl, T, H);
     }
     __syncthreads();
-    if constexpr (FUSED) stage_weights(wl, sg.wproj, HC * HC);  // (the qkv weights are dead; visible after the barrier in front of the projection)
     const int sl = adiv((int)threadIdx.x, TPS, 1.0f / (float)TPS);
     const bool active = sl < nsl;
     const int t0 = (threadIdx.x - sl * TPS) * QPT;
@@ -582,8 +591,8 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const floa
         float* yg = sg.y + tok0 * HC;
         const float* rg = sg.residual ? sg.residual + tok0 * HC : nullptr;
         double* red = reinterpret_cast<double*>(qs);  // (q has been in registers since the barrier behind the staging)
-        if (HC & 1) stage_project<1>(xs, wl, red, ntok, HC, yg, rg, sg.stat_partial);
-        else stage_project<2>(xs, wl, red, ntok, HC, yg, rg, sg.stat_partial);
+        if (HC & 1) stage_project<1>(xs, wpl, red, ntok, HC, yg, rg, sg.stat_partial);
+        else stage_project<2>(xs, wpl, red, ntok, HC, yg, rg, sg.stat_partial);
     }
 }
 
@@ -602,12 +611,47 @@ __global__ __launch_bounds__(256) void attn_stage_fwd_kernel(AttnStage sg, int N
     attn_fwd_body<C, QPT, AUX, true>(sm, nullptr, N, T, H, SPB, out, lse, aux, qk_scale, sg);
 }
 
-template <int C, int QPT, bool AUX>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
-                                                       const float* __restrict__ lse_g, const float* __restrict__ gout,
-                                                       const float* __restrict__ aux, int N, int T, int H, int SPB,
-                                                       float* __restrict__ gqkv, float qk_scale) {
-    extern __shared__ __align__(16) float sm[];
+// The backward pass of the AttentionBlock's three stages for the FUSED backward kernel: the attention output's gradient is formed from
+// the block output's gradient (gout = gy . wproj^T) while the records are staged, and the gradient of the normalised input
+// (gv = dqkv . wqkv^T) with its BatchNorm-backward sums leaves in the epilogue; dqkv is still written (the qkv weight gradient reads it).
+struct AttnStageBwd {
+    const float* gy;      // [N][T][HC] gradient of the block's output
+    const float* wproj;   // [HC][HC]
+    const float* wqkv;    // [HC][3 HC]
+    const float* x;       // [N][T][HC] the block's input (read for the BatchNorm sums only)
+    const float* mean;    // [HC] batch statistics of x, or NULL (no BatchNorm in front of the qkv convolution)
+    const float* invstd;
+    float* gv;            // [N][T][HC] gradient of the qkv convolution's (normalised) input
+    double* bn_partial;   // [2][HC][gridDim.x]: sum gv, sum gv * xhat per channel, or NULL
+};
+
+// n = rows * cols floats global [rows][cols] -> LDS [cols][rows]
+__device__ __forceinline__ void stage_weights_t(float* __restrict__ dst, const float* __restrict__ src, int rows, int cols) {
+    const int n = rows * cols;
+    const float inv_cols = 1.0f / (float)cols;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            v[u] = i < n ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < n) {
+                const int r = adiv(i, cols, inv_cols), c = i - r * cols;
+                dst[c * rows + r] = v[u];
+            }
+        }
+    }
+}
+
+template <int C, int QPT, bool AUX, bool FUSED>
+__device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const float* __restrict__ qkv, const float* __restrict__ out,
+                                              const float* __restrict__ lse_g, const float* __restrict__ gout,
+                                              const float* __restrict__ aux, int N, int T, int H, int SPB,
+                                              float* __restrict__ gqkv, float qk_scale, const AttnStageBwd& sg) {
     constexpr int RKV = Rec<C>::KV, RQG = Rec<C>::QG;
     const int HC = H * C, W3 = 3 * HC;
     const int TPS = T / QPT;
@@ -616,8 +660,36 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const int nsl = (int)min((long)SPB, total - slice0);
     float* s_kv = sm;
     float* s_qg = sm + (size_t)SPB * T * RKV;
+    // FUSED: behind the records the gy tile [SPB / H][T][HC] (later the reduction scratch) and the transposed 1x1 weights; the records'
+    // place is reused for the dqkv tile [SPB / H][T][3 HC] of the epilogue
+    float* s_gy = s_qg + (size_t)SPB * T * RQG;
+    float* wl = s_gy + (size_t)SPB * T * C;  // wproj^T [HC][HC]
+    float* wql = wl + HC * HC;               // wqkv^T [3 HC][HC]
+    const int ntok = FUSED ? nsl / H * T : 0;
+    const size_t tok0 = FUSED ? (size_t)(slice0 / H) * T : 0;
     const float inv_c = qk_scale;
     stage_kv<C>(s_kv, qkv, slice0, nsl, T, H);
+    if constexpr (FUSED) {
+        stage_weights(s_gy, sg.gy + tok0 * HC, ntok * HC);
+        stage_weights_t(wl, sg.wproj, HC, HC);  // wl[co][ci] = wproj[ci][co]
+        stage_weights_t(wql, sg.wqkv, HC, W3);  // wql[col][ci] = wqkv[ci][col] for the epilogue
+        __syncthreads();
+        // gout[tok][ci] = sum_co gy[tok][co] wproj[ci][co] -> the gout slot of the query records
+        auto put = [&](int t0_, int col0, const auto& a) {
+            constexpr int NC_ = sizeof(a[0]) / sizeof(float);
+            const int img = t0_ / T, tt = t0_ - img * T;
+#pragma unroll
+            for (int j = 0; j < NC_; ++j) {
+                const int hc = col0 + j, h_ = hc / C, c_ = hc - h_ * C;
+                float* dst = s_qg + ((size_t)(img * H + h_) * T + tt) * RQG + C + c_;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dst[t * RQG] = a[t][j];
+            }
+        };
+        if (HC & 1) token_gemm<1>(s_gy, ntok, HC, wl, HC, put);
+        else token_gemm<2>(s_gy, ntok, HC, wl, HC, put);
+        __syncthreads();
+    }
     // query records {q/C, gout, lse, delta = sum_c gout*out}
     const float inv_t = 1.0f / (float)T, inv_hq = 1.0f / (float)H;
     const int qn0 = (int)(slice0 / H), qh0 = (int)(slice0 - (long)qn0 * H);
@@ -630,14 +702,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const int h = hs - dn * H;
         float* r = s_qg + (size_t)it * RQG;
         const float* qp = qkv + (n * T + t) * W3 + h * C;
-        const float* gp = gout + (n * T + t) * HC + h * C;
+        const float* gp = FUSED ? r + C : gout + (n * T + t) * HC + h * C;
         const float* op = out + (n * T + t) * HC + h * C;
         float d = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float g = gp[c];
             r[c] = qp[c] * inv_c;
-            r[C + c] = g;
+            if constexpr (!FUSED) r[C + c] = g;
             d = fmaf(g, op[c], d);
         }
         r[2 * C] = lse_g[(n * H + h) * T + t] * LOG2E;  // log2-domain LSE
@@ -645,8 +717,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
     __syncthreads();
     const int sl = adiv((int)threadIdx.x, TPS, 1.0f / (float)TPS);
-    if (sl >= nsl) return;
+    const bool active = sl < nsl;
+    if constexpr (!FUSED) {
+        if (!active) return;
+    }
     const int t0 = (threadIdx.x - sl * TPS) * QPT;
+    float res[FUSED ? QPT : 1][3][C];  // FUSED: the lane's dq | dk | dv rows, kept past the barrier that frees the records
     long n;
     int h;
     {
@@ -656,6 +732,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         n = bn0 + dn;
         h = hs - dn * H;
     }
+    if (!FUSED || active) {
     const float* kv = s_kv + (size_t)sl * T * RKV;
     const float* qg = s_qg + (size_t)sl * T * RQG;
 
@@ -810,7 +887,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 }
             }
         }
-        if constexpr (C == 1 && QPT == 4) {
+        if constexpr (C == 1 && QPT == 4 && !FUSED) {
             // one head of one channel, the whole workgroup on one image (T = 1024): the lane's 4 tokens are 12 consecutive
             // floats q|k|v q|k|v ..., a wave's 3 KiB are contiguous.  They pass through LDS (the staging area is free now)
             // so that every store instruction writes 1 KiB of consecutive addresses, 16 bytes per lane.
@@ -831,6 +908,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 return;
             }
         }
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int j = 0; j < QP; ++j)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    res[2 * j][0][c] = dqv[2 * j][c], res[2 * j + 1][0][c] = dqv[2 * j + 1][c];
+                    res[2 * j][1][c] = dk2[j][c].x, res[2 * j + 1][1][c] = dk2[j][c].y;
+                    res[2 * j][2][c] = dv2[j][c].x, res[2 * j + 1][2][c] = dv2[j][c].y;
+                }
+        } else {
 #pragma unroll
         for (int j = 0; j < QP; ++j) {
             float* o0 = gqkv + (n * T + t0 + 2 * j) * W3 + h * C;
@@ -844,6 +931,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 o0[2 * HC + c] = dv2[j][c].x;
                 o1[2 * HC + c] = dv2[j][c].y;
             }
+        }
         }
     } else {
         float k[QPT][C], v[QPT][C], dk[QPT][C], dv[QPT][C];
@@ -884,7 +972,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 }
             }
         }
-        if constexpr (C == 1 && QPT == 4) {
+        if constexpr (C == 1 && QPT == 4 && !FUSED) {
             // one head of one channel, the whole workgroup on one image (T = 1024): see the packed branch above
             if (H == 1 && T == 1024 && (reinterpret_cast<uintptr_t>(gqkv) & 15) == 0) {
                 __syncthreads();  // every wave is done with the key / query records
@@ -903,6 +991,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 return;
             }
         }
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int i = 0; i < QPT; ++i)
+#pragma unroll
+                for (int c = 0; c < C; ++c) res[i][0][c] = dqv[i][c], res[i][1][c] = dk[i][c], res[i][2][c] = dv[i][c];
+        } else {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             float* o = gqkv + (n * T + t0 + i) * W3 + h * C;
@@ -913,8 +1007,84 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 o[2 * HC + c] = dv[i][c];
             }
         }
+        }
+    }
+    }  // active
+    if constexpr (FUSED) {
+        __syncthreads();  // every wave is done with the key / query records: their place takes the dqkv tile [ntok][3 HC]
+        float* dq_s = sm;
+        if (active) {
+            const int img_l = (int)(n - slice0 / H);
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                float* o = dq_s + ((size_t)img_l * T + t0 + i) * W3 + h * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = res[i][0][c], o[HC + c] = res[i][1][c], o[2 * HC + c] = res[i][2][c];
+            }
+        }
+        __syncthreads();
+        // dqkv of the block's tokens is one contiguous piece of [N][T][3 HC]
+        {
+            float* g = gqkv + tok0 * W3;
+            const int nq = ntok * W3;
+            if ((nq & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+                for (int i = threadIdx.x * 4; i < nq; i += blockDim.x * 4) *reinterpret_cast<float4*>(g + i) = *reinterpret_cast<const float4*>(dq_s + i);
+            } else {
+                for (int i = threadIdx.x; i < nq; i += blockDim.x) g[i] = dq_s[i];
+            }
+        }
+        // gv[tok][ci] = sum_col dqkv[tok][col] wqkv[ci][col], with the BatchNorm-backward sums of the thread's columns
+        float* gvg = sg.gv + tok0 * HC;
+        const float* xg = sg.x ? sg.x + tok0 * HC : nullptr;
+        auto project = [&](auto nc_tag) {
+            constexpr int NC_ = decltype(nc_tag)::value;
+            double s1[NC_], s2[NC_];
+#pragma unroll
+            for (int j = 0; j < NC_; ++j) s1[j] = s2[j] = 0.;
+            float mu[NC_], is[NC_];
+            const int col_t = (threadIdx.x % (HC / NC_)) * NC_;  // the thread's columns (blockDim.x % (HC / NC) == 0)
+#pragma unroll
+            for (int j = 0; j < NC_; ++j) mu[j] = sg.mean ? sg.mean[col_t + j] : 0.f, is[j] = sg.mean ? sg.invstd[col_t + j] : 0.f;
+            token_gemm<NC_>(dq_s, ntok, W3, wql, HC, [&](int t0_, int col0, const float (&a)[4][NC_]) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const size_t o = (size_t)(t0_ + t) * HC + col0;
+                    if constexpr (NC_ == 2) *reinterpret_cast<float2*>(gvg + o) = make_float2(a[t][0], a[t][1]);
+                    else gvg[o] = a[t][0];
+                    if (sg.mean) {
+#pragma unroll
+                        for (int j = 0; j < NC_; ++j) {
+                            const float xv = xg[o + j];
+                            s1[j] += (double)a[t][j];
+                            s2[j] += (double)a[t][j] * (double)((xv - mu[j]) * is[j]);
+                        }
+                    }
+                }
+            });
+            if (sg.bn_partial) column_sums_to_partial<NC_>(s1, s2, reinterpret_cast<double*>(s_gy), HC, sg.bn_partial);
+        };
+        if (HC & 1) project(std::integral_constant<int, 1>{});
+        else project(std::integral_constant<int, 2>{});
     }
 }
+
+template <int C, int QPT, bool AUX>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                       const float* __restrict__ lse_g, const float* __restrict__ gout,
+                                                       const float* __restrict__ aux, int N, int T, int H, int SPB,
+                                                       float* __restrict__ gqkv, float qk_scale) {
+    extern __shared__ __align__(16) float sm[];
+    attn_bwd_body<C, QPT, AUX, false>(sm, qkv, out, lse_g, gout, aux, N, T, H, SPB, gqkv, qk_scale, AttnStageBwd{});
+}
+
+template <int C, int QPT, bool AUX>
+__global__ __launch_bounds__(256) void attn_stage_bwd_kernel(AttnStageBwd sg, const float* __restrict__ qkv, const float* __restrict__ out,
+                                                             const float* __restrict__ lse_g, const float* __restrict__ aux, int N, int T,
+                                                             int H, int SPB, float* __restrict__ gqkv, float qk_scale) {
+    extern __shared__ __align__(16) float sm[];
+    attn_bwd_body<C, QPT, AUX, true>(sm, qkv, out, lse_g, nullptr, aux, N, T, H, SPB, gqkv, qk_scale, sg);
+}
+
 
 // T == 1 (the 1x1 bottleneck block of the encoder): one key, so the softmax weight is 1 -- out = v, lse = the single score,
 // dq = dk = 0 and dv = gout.  Elementwise kernels at the launch floor instead of the staged ones (13 + 18 us there).
@@ -1051,7 +1221,8 @@ static int stage_lds_ok(size_t lds) {
 static inline bool attn_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // Launch shape, or OTVAE_EUNSUPPORTED when the stage has to run as three launches: a block must own whole images (spb % H == 0), the token
 // GEMMs want T % 4 == 0, the per-column statistics a power-of-two width <= 64.
-static int attn_stage_shape(int N, int T, int H, int C, bool aux, int* qpt, int* spb, int* grid, int* nthr, size_t* lds, bool quiet) {
+static int attn_stage_shape(int N, int T, int H, int C, bool aux, bool backward, int* qpt, int* spb, int* grid, int* nthr, size_t* lds,
+                            bool quiet) {
     const int HC = H * C;
 #define STAGE_NO(...)                                  \
     do {                                               \
@@ -1069,9 +1240,10 @@ static int attn_stage_shape(int N, int T, int H, int C, bool aux, int* qpt, int*
     *qpt = pick_qpt(T, C);
     const int tps = T / *qpt;
     if (tps > 256 || (*qpt == 4 && C > 4)) STAGE_NO("otvae_attn_stage: T = %d with head width %d unsupported", T, C);
+    // forward: {k, v (, u)} records + q + input / output tile; backward: {k, v} + {q, gout, lse, delta} records + gy tile
     const int rkv = aux ? ((2 * C + C * C + 3) & ~3) : 2 * C;
-    const int per_slice = T * (rkv + 2 * C);  // records + q + input / output tile
-    const int wfloats = 3 * HC * HC;          // the qkv weights (the projection's reuse their place)
+    const int per_slice = backward ? T * (2 * C + ((2 * C + 2 + 3) & ~3) + C) : T * (rkv + 2 * C);
+    const int wfloats = 4 * HC * HC;          // both 1x1 kernels' weights
     int s = imin(256 / tps, (ATTN_STAGE_LDS_FLOATS - wfloats) / per_slice) / H * H;
     if (s < H) STAGE_NO("otvae_attn_stage: the %d heads of an image do not fit one workgroup (T=%d)", H, T);
     // fill the chip: halve the images per block while the grid is short of one block per CU
@@ -1088,9 +1260,18 @@ static int attn_stage_shape(int N, int T, int H, int C, bool aux, int* qpt, int*
 extern "C" int otvae_attn_stage_plan(int N, int T, int H, int C, int need_aux, int* stat_rows) {
     int qpt, spb, grid, nthr;
     size_t lds;
-    int rc = attn_stage_shape(N, T, H, C, need_aux && C <= 2, &qpt, &spb, &grid, &nthr, &lds, true);
+    int rc = attn_stage_shape(N, T, H, C, need_aux && C <= 2, false, &qpt, &spb, &grid, &nthr, &lds, true);
     if (rc) return rc;
     if (stat_rows) *stat_rows = grid;
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_attn_stage_bwd_plan(int N, int T, int H, int C, int* bn_rows) {
+    int qpt, spb, grid, nthr;
+    size_t lds;
+    int rc = attn_stage_shape(N, T, H, C, false, true, &qpt, &spb, &grid, &nthr, &lds, true);
+    if (rc) return rc;
+    if (bn_rows) *bn_rows = grid;
     return OTVAE_OK;
 }
 
@@ -1103,7 +1284,7 @@ extern "C" int otvae_attn_stage_fwd(const float* x, const float* scale, const fl
     if (C > 2) aux = nullptr;
     int qpt, spb, grid, nthr;
     size_t lds;
-    int rc = attn_stage_shape(N, T, H, C, aux != nullptr, &qpt, &spb, &grid, &nthr, &lds, false);
+    int rc = attn_stage_shape(N, T, H, C, aux != nullptr, false, &qpt, &spb, &grid, &nthr, &lds, false);
     if (rc) return rc;
     OTVAE_REQUIRE(attn_aligned16(x) && attn_aligned16(scale) && attn_aligned16(shift), "otvae_attn_stage_fwd: x / scale / shift must be 16-byte aligned");
     OTVAE_REQUIRE(((uintptr_t)qkv & 7) == 0 && ((uintptr_t)y & 7) == 0 && ((uintptr_t)residual & 7) == 0,
@@ -1127,6 +1308,48 @@ extern "C" int otvae_attn_stage_fwd(const float* x, const float* scale, const fl
     ATTN_C_SWITCH(C, STAGE_K)
 #undef STAGE_K
     OTVAE_CHECK_LAUNCH("otvae_attn_stage_fwd");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_attn_stage_bwd(const float* gy, const float* wproj, const float* wqkv, const float* x, const float* mean,
+                                    const float* invstd, const float* qkv, const float* out, const float* lse, const float* aux, int N,
+                                    int T, int H, int C, float qk_scale, float* gqkv, float* gv, double* bn_partial, void* stream) {
+    OTVAE_REQUIRE(gy && wproj && wqkv && qkv && out && lse && gqkv && gv, "otvae_attn_stage_bwd: NULL tensor");
+    OTVAE_REQUIRE((mean == nullptr) == (invstd == nullptr), "otvae_attn_stage_bwd: mean/invstd must come together");
+    OTVAE_REQUIRE(!mean || (x && bn_partial), "otvae_attn_stage_bwd: x and bn_partial are needed for the BatchNorm sums");
+    OTVAE_REQUIRE(qk_scale > 0.f, "otvae_attn_stage_bwd: scale must be positive");
+    if (C > 2) aux = nullptr;
+    int qpt, spb, grid, nthr;
+    size_t lds;
+    int rc = attn_stage_shape(N, T, H, C, false, true, &qpt, &spb, &grid, &nthr, &lds, false);
+    if (rc) return rc;
+    OTVAE_REQUIRE(((uintptr_t)gv & 7) == 0, "otvae_attn_stage_bwd: gv must be 8-byte aligned");
+    const AttnStageBwd sg = {gy, wproj, wqkv, x, mean, invstd, gv, bn_partial};
+    hipStream_t st = (hipStream_t)stream;
+#define STAGE_BK(K_)                                                                                  \
+    {                                                                                                 \
+        rc = stage_lds_ok<&K_>(lds);                                                                  \
+        if (rc) return rc;                                                                            \
+        K_<<<grid, nthr, lds, st>>>(sg, qkv, out, lse, aux, N, T, H, spb, gqkv, qk_scale);            \
+    }
+#define STAGE_B(CC)                                                                                   \
+    do {                                                                                              \
+        if (qpt == 4) {                                                                               \
+            if constexpr (CC <= 2) {                                                                  \
+                if (aux) STAGE_BK((attn_stage_bwd_kernel<CC, 4, true>))                               \
+                else STAGE_BK((attn_stage_bwd_kernel<CC, 4, false>))                                  \
+            } else if constexpr (CC <= 4) STAGE_BK((attn_stage_bwd_kernel<CC, 4, false>))             \
+        } else {                                                                                      \
+            if constexpr (CC <= 2) {                                                                  \
+                if (aux) STAGE_BK((attn_stage_bwd_kernel<CC, 1, true>))                               \
+                else STAGE_BK((attn_stage_bwd_kernel<CC, 1, false>))                                  \
+            } else STAGE_BK((attn_stage_bwd_kernel<CC, 1, false>))                                    \
+        }                                                                                             \
+    } while (0)
+    ATTN_C_SWITCH(C, STAGE_B)
+#undef STAGE_B
+#undef STAGE_BK
+    OTVAE_CHECK_LAUNCH("otvae_attn_stage_bwd");
     return OTVAE_OK;
 }
 

@@ -539,9 +539,14 @@ def conv_forward_launch(x, specs, stats, tensors):
     return outs, geoms, out_stats
 
 
-def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_dx):
+def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_dx, pre_dgrad=None, fork="now"):
     """Weight / bias / BatchNorm / data gradients of 1 or 2 ConvLayer branches (one ``otvae_conv_multi`` call + the BatchNorm
-    backward pair).  Returns (dx | None, [(gw, gb, dgamma, dbeta, gresidual) per branch])."""
+    backward pair).  Returns (dx | None, [(gw, gb, dgamma, dbeta, gresidual) per branch]).  ``pre_dgrad[b]`` = (gv, bn_partial, rows,
+    ld): branch b's data gradient (and BatchNorm-backward partial sums) already computed by another kernel (the fused AttentionBlock
+    backward): no data-gradient job is issued for it.  ``fork`` (side-stream route only): "now" = fork the weight-gradient jobs where the
+    data-gradient job is launched; "queue" = leave them queued for the next call's fork; "after_bn" = the fork point is here but the
+    side stream's launches are recorded after the BatchNorm backward pair (with no data-gradient job in this call they would otherwise
+    become the first successor of the launch stream's last kernel, and a captured graph keeps only the first successor on its queue)."""
     lib = _lib.load()
     mean, invstd, scales, shifts, training = stats
     nbr = len(specs)
@@ -595,7 +600,13 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
         # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
         gv = None
         part = None
-        if need_dx or sp.has_norm:
+        pre = pre_dgrad[b] if pre_dgrad is not None else None
+        if pre is not None:
+            gv, part, p_pre, cp_pre = pre
+            if sp.has_norm:
+                cspad = cp_pre
+                ps.append(p_pre)
+        elif need_dx or sp.has_norm:
             wd = getattr(pw, "_otvae_wd", None) if pw is not None else None
             if wd is None:
                 wd = torch.empty(g.KH * g.KW * g.Cn * g.Cs, device=x.device, dtype=torch.float32)
@@ -622,14 +633,17 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
         # weight-gradient jobs on the side stream (see _PendingReduce), data-gradient jobs on the launch stream.  The data
         # job is issued FIRST: in a captured step the graph executor keeps the first child of a node on its parent's queue, so
         # the critical chain stays on one queue and only the side branch pays the cross-queue dependency (~12 us each)
-        ev = _PendingReduce.fork_point(x.device) if _PendingReduce.queue_weight_jobs(x.device, wjobs, nw, [x] + keep) else None
+        go = _PendingReduce.queue_weight_jobs(x.device, wjobs, nw, [x] + keep)
+        ev = _PendingReduce.fork_point(x.device) if (go and fork != "queue") else None
         if nd:
             check(lib.otvae_conv_multi(nd, djobs, stream()), "otvae_conv_multi(backward, data)")
             if JOB_TRACE is not None:
                 _trace_jobs(djobs, nd)
-        if ev is not None:
+        if ev is not None and fork != "after_bn":
             _PendingReduce.issue(x.device, ev)
+            ev = None
     else:
+        ev = None
         njobs = nw + nd
         jobs = (_lib.ConvJob * njobs)()
         for i, (is_w, k) in enumerate(order):
@@ -660,6 +674,8 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
             dx = empty_nhwc(n, cs, hs, ws, x)
             check(lib.otvae_bn_bwd_apply(nbn, ptr_array([per_branch[b][2] for b in bn_idx]), ptr(x), ptr(coef),
                                          m_in, cs, ptr(dx), stream()), "otvae_bn_bwd_apply")
+    if ev is not None:
+        _PendingReduce.issue(x.device, ev)
     if need_dx:
         for b, sp in enumerate(specs):
             if not sp.has_norm:
@@ -1023,7 +1039,9 @@ def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:
 
 # OTVAE_ATTN_STAGE=0 (A/B switch): the AttentionBlock runs as its three launches (qkv convolution, attention, output projection)
 ATTN_STAGE = os.environ.get("OTVAE_ATTN_STAGE", "1") != "0"
+ATTN_STAGE_BWD = os.environ.get("OTVAE_ATTN_STAGE_BWD", "1") != "0"  # ... and its backward pass likewise (one launch instead of three)
 _STAGE_PLAN_CACHE: dict = {}
+_STAGE_BWD_PLAN_CACHE: dict = {}
 
 
 def _plain_1x1(br: dict, cout: int, cin: int) -> bool:
@@ -1069,12 +1087,32 @@ class _AttnStageFn(torch.autograd.Function):
         n, hc, hh, ww = x.shape
         t, c = hh * ww, hc // heads
         sp_p = ConvSpec(1, 0, 1, False, False, False, has_res, False)
-        gout, per_p = conv_backward_launch(out, (wp, None, None, None, res), (sp_p,), (ctx.geoms[1],),
-                                           (None, None, [None], [None], training), (pref_p,), (gy,), True)
+        sp_q = ConvSpec(1, 0, 1, False, has_norm, False, False, False)
+        no_stats = (None, None, [None], [None], training)
         gqkv = torch.empty_strided(qkv.shape, qkv.stride(), device=qkv.device, dtype=qkv.dtype)
+        key = (n, t, heads, c)
+        rows = _STAGE_BWD_PLAN_CACHE.get(key)
+        if rows is None:
+            r = C.c_int(0)
+            rows = _STAGE_BWD_PLAN_CACHE[key] = r.value if lib.otvae_attn_stage_bwd_plan(n, t, heads, c, C.byref(r)) == 0 else 0
+        if rows and ATTN_STAGE_BWD:
+            # one launch for projection data gradient + attention backward + qkv data gradient with the BatchNorm sums
+            gy = as_nhwc(gy)
+            gv = empty_nhwc(n, hc, hh, ww, x)
+            part = torch.empty((rows, 2, hc), device=x.device, dtype=torch.float64) if has_norm else None
+            check(lib.otvae_attn_stage_bwd(ptr(gy), ptr(wp), ptr(wq), ptr(x), ptr(stats[0]) if has_norm else None,
+                                           ptr(stats[1]) if has_norm else None, ptr(qkv), ptr(out), ptr(lse), ptr(aux), n, t, heads, c, scale,
+                                           ptr(gqkv), ptr(gv), ptr(part), stream()), "otvae_attn_stage_bwd")
+            # both weight-gradient jobs in one side-stream launch, forked behind the kernel above; the launch stream's next nodes (the
+            # BatchNorm backward pair) are recorded first
+            _, per_p = conv_backward_launch(out, (wp, None, None, None, res), (sp_p,), (ctx.geoms[1],), no_stats, (pref_p,), (gy,), False,
+                                            fork="queue")
+            dx, per_q = conv_backward_launch(x, (wq, None, gamma, beta, None), (sp_q,), (ctx.geoms[0],), stats, (pref_q,), (gqkv,),
+                                             ctx.needs_input_grad[0], pre_dgrad=[(gv, part, rows, hc)], fork="after_bn")
+            return dx, None, per_q[0][0], per_q[0][2], per_q[0][3], per_p[0][0], per_p[0][4]
+        gout, per_p = conv_backward_launch(out, (wp, None, None, None, res), (sp_p,), (ctx.geoms[1],), no_stats, (pref_p,), (gy,), True)
         check(lib.otvae_attn_bwd_scaled(ptr(qkv), ptr(out), ptr(lse), ptr(gout), ptr(aux), n, t, heads, c, scale, ptr(gqkv), stream()),
               "otvae_attn_bwd")
-        sp_q = ConvSpec(1, 0, 1, False, has_norm, False, False, False)
         dx, per_q = conv_backward_launch(x, (wq, None, gamma, beta, None), (sp_q,), (ctx.geoms[0],), stats, (pref_q,), (gqkv,),
                                          ctx.needs_input_grad[0])
         return dx, None, per_q[0][0], per_q[0][2], per_q[0][3], per_p[0][0], per_p[0][4]

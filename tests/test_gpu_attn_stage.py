@@ -1,4 +1,4 @@
-"""GPU parity of the one-launch AttentionBlock forward (``otvae_attn_stage_fwd``, reference networks/cnn.py:212-240) -- run with
+"""GPU parity of the one-launch AttentionBlock forward and backward (``otvae_attn_stage_fwd`` / ``_bwd``, reference networks/cnn.py:212-240) -- run with
 ``-m gpu``: against the CPU oracle's ``attention_block`` (values, BatchNorm running buffers, every gradient), and against the same
 block issued as its three launches (``OTVAE_ATTN_STAGE=0``'s route), including the statistics partials the next BatchNorm picks up."""
 import ctypes as C
@@ -35,10 +35,10 @@ def _block(A, width, heads, seed, norm="batchnorm"):
     return blk
 
 
-def _run(blk, x, res, gy, fused):
+def _run(blk, x, res, gy, fused, fused_bwd=True):
     from ot_vae_lightning_amd import functional as HF
-    old = HF.ATTN_STAGE
-    HF.ATTN_STAGE = fused
+    old = HF.ATTN_STAGE, HF.ATTN_STAGE_BWD
+    HF.ATTN_STAGE, HF.ATTN_STAGE_BWD = fused, fused_bwd
     try:
         for p in blk.parameters():
             p.grad = None
@@ -51,7 +51,7 @@ def _run(blk, x, res, gy, fused):
         grads = {k: p.grad.detach().clone() for k, p in blk.named_parameters()}
         return y.detach(), st, x.grad, (r.grad if r is not None else None), grads
     finally:
-        HF.ATTN_STAGE = old
+        HF.ATTN_STAGE, HF.ATTN_STAGE_BWD = old
 
 
 @pytest.mark.parametrize("n,width,side,heads", SHAPES)
@@ -75,6 +75,14 @@ def test_stage_vs_oracle_and_three_launches(A, n, width, side, heads, with_res):
     assert rel_err(y1, y0) < TOL and rel_err(dx1, dx0) < TOL
     for k in g0:
         assert rel_err(g1[k], g0[k]) < TOL, k
+    # -- the fused forward with the three-launch backward (what shapes take whose backward kernel does not fit)
+    blk.load_state_dict(sd0)
+    y2, _, dx2, _, g2 = _run(blk, x, res, gy, True, fused_bwd=False)
+    assert torch.equal(y2, y1) and rel_err(dx2, dx0) < TOL
+    for k in g0:
+        assert rel_err(g2[k], g0[k]) < TOL, k
+    blk.load_state_dict(sd0)
+    _run(blk, x, res, gy, False)
     if with_res:
         assert torch.equal(dr1, dr0)
     for k in sd1:
@@ -117,6 +125,8 @@ def test_stage_eval_mode_and_no_norm(A):
         gy = HF.as_nhwc(normal((5, 16, 8, 8), 7).cuda())
         y1, st1, dx1, _, g1 = _run(blk, x, None, gy, True)
         y0, st0, dx0, _, g0 = _run(blk, x, None, gy, False)
+        y2, _, dx2, _, g2 = _run(blk, x, None, gy, True, fused_bwd=False)
+        assert torch.equal(y2, y1) and rel_err(dx2, dx0) < TOL
         assert st1 is None and st0 is None
         assert rel_err(y1, y0) < TOL and rel_err(dx1, dx0) < TOL
         for k in g0:
