@@ -172,7 +172,7 @@ int otvae_attn_bwd_scaled(const float* qkv, const float* out, const float* lse, 
  * BatchNorm affine in front of the bias-free 1x1 qkv convolution, both NULL without one; wqkv [H*C][3*H*C], wproj [H*C][H*C] in the
  * HWIO order of otvae_conv_fwd), runs the attention of otvae_attn_fwd_scaled and applies the bias-free 1x1 output projection,
  * the residual sum (nullable) and the per-channel partial sums of y for the next BatchNorm (stat_partial [2][H*C][rows], nullable;
- * rows from otvae_attn_stage_plan).  qkv [N][T][3*H*C], out [N][T][H*C] (the attention output), lse and aux are written as by the
+ * rows from otvae_attn_stage_plan).  qkv [N][T][3*H*C] (nullable: only a three-launch backward pass reads it), out [N][T][H*C] (the attention output), lse and aux are written as by the
  * three separate launches: the backward pass is theirs.  otvae_attn_stage_plan returns OTVAE_EUNSUPPORTED (no error text) for
  * shapes the fused kernel does not take (T == 1, T % 4 != 0, a width that is not a power of two <= 32, heads that do not fit one
  * workgroup): the caller then issues the three launches. */
@@ -186,12 +186,15 @@ int otvae_attn_stage_fwd(const float* x, const float* scale, const float* shift,
  * [N][T][3*H*C] (read afterwards by the qkv weight-gradient job), and gv [N][T][H*C] = gqkv . wqkv^T, the gradient of the qkv
  * convolution's normalised input, leaves with the BatchNorm-backward partial sums bn_partial [2][H*C][rows] (sum gv, sum gv * xhat per
  * channel, xhat = (x - mean) * invstd: what otvae_conv_bwd_data emits for otvae_bn_bwd_finalize; mean / invstd / x / bn_partial all
- * NULL without a BatchNorm).  rows from otvae_attn_stage_bwd_plan, which returns OTVAE_EUNSUPPORTED for shapes the kernel does not
+ * NULL without a BatchNorm).  qkv == NULL (otvae_attn_stage_fwd was given qkv == NULL and wrote none: 12 of the 28 bytes per value it
+ * moves at the small maps): q / k / v are formed again from x through scale / shift, the forward kernel's arithmetic.  rows from
+ * otvae_attn_stage_bwd_plan, which returns OTVAE_EUNSUPPORTED for shapes the kernel does not
  * take (the caller then issues the three launches). */
 int otvae_attn_stage_bwd_plan(int N, int T, int H, int C, int* bn_rows);
 int otvae_attn_stage_bwd(const float* gy, const float* wproj, const float* wqkv, const float* x, const float* mean,
-                         const float* invstd, const float* qkv, const float* out, const float* lse, const float* aux, int N, int T,
-                         int H, int C, float qk_scale, float* gqkv, float* gv, double* bn_partial, void* stream);
+                         const float* invstd, const float* scale, const float* shift, const float* qkv, const float* out,
+                         const float* lse, const float* aux, int N, int T, int H, int C, float qk_scale, float* gqkv, float* gv,
+                         double* bn_partial, void* stream);
 
 /* Element-wise dropout with the same counter-based masks (keep(row, col) of a [rows][D] tensor, D % 4 == 0), optionally
  * fused with the ReLU in front of it: y = keep ? act(x)/(1-p) : 0.  relu != 0: the dropout(relu(linear1(x))) of a training-

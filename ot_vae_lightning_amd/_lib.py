@@ -70,7 +70,7 @@ SIGNATURES = {
     "otvae_attn_stage_plan": (i32, [i32, i32, i32, i32, i32, vp]),
     "otvae_attn_stage_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "otvae_attn_stage_bwd_plan": (i32, [i32, i32, i32, i32, vp]),
-    "otvae_attn_stage_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "otvae_attn_stage_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     "otvae_attn_dropout_fwd": (i32, [vp, i32, i32, i32, i32, f32, f32, i32, vp, i32, vp, vp, vp, vp]),
     "otvae_attn_dropout_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, vp]),
     "otvae_attn_dropout_mask": (i32, [i32, i32, i32, f32, vp, vp, vp]),

@@ -137,7 +137,7 @@ struct AttnStage {
     const float* wqkv;      // [HC][3 HC]  (HWIO of the 1x1 kernel)
     const float* wproj;     // [HC][HC]
     const float* residual;  // [N][T][HC] or NULL
-    float* qkv;             // [N][T][3 HC] written for the backward pass
+    float* qkv;             // [N][T][3 HC] written for a three-launch backward pass, or NULL
     float* y;               // [N][T][HC]
     double* stat_partial;   // [2][HC][gridDim.x] per-channel sum / sum of squares of y, or NULL
 };
@@ -158,6 +158,28 @@ __device__ __forceinline__ void stage_weights(float* __restrict__ dst, const flo
         for (; i0 < n; i0 += step) *reinterpret_cast<float4*>(dst + i0) = *reinterpret_cast<const float4*>(src + i0);
     } else {
         for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// the block's n = ntok * HC input values (contiguous in [N][T][HC]) -> LDS, through the BatchNorm affine when there is one
+__device__ __forceinline__ void stage_input_tile(float* __restrict__ xs, const float* __restrict__ xg, int nx, int HC,
+                                                 const float* __restrict__ scale, const float* __restrict__ shift) {
+    if ((HC & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < nx; i += blockDim.x * 4) {
+            float4 v = *reinterpret_cast<const float4*>(xg + i);
+            if (scale) {
+                const int c0 = i % HC;
+                const float4 a = *reinterpret_cast<const float4*>(scale + c0), b = *reinterpret_cast<const float4*>(shift + c0);
+                v.x = fmaf(v.x, a.x, b.x), v.y = fmaf(v.y, a.y, b.y), v.z = fmaf(v.z, a.z, b.z), v.w = fmaf(v.w, a.w, b.w);
+            }
+            *reinterpret_cast<float4*>(xs + i) = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+            float v = xg[i];
+            if (scale) v = fmaf(v, scale[i % HC], shift[i % HC]);
+            xs[i] = v;
+        }
     }
 }
 
@@ -213,10 +235,12 @@ __device__ __forceinline__ void token_gemm(const float* __restrict__ in, int nto
     }
 }
 
-// q / k / v of the block's tokens from the normalised input tile: q -> qs [tok][HC], k / v -> the slices' records, all three -> global
-template <int C, int KVS, int NC>
-__device__ __forceinline__ void stage_qkv(float* __restrict__ sm, float* __restrict__ qs, const float* __restrict__ xs,
-                                          const float* __restrict__ wl, int ntok, int T, int H, float* __restrict__ gq) {
+// q / k / v of the block's tokens from the normalised input tile: q (times qmul) -> qd[(slice-major token) * qstride + c] when QREC (the
+// backward kernel's query records) or qd [tok][HC] otherwise, k / v -> the slices' records, all three -> global when gq != NULL
+template <int C, int KVS, int NC, bool QREC>
+__device__ __forceinline__ void stage_qkv(float* __restrict__ kvrec, float* __restrict__ qd, int qstride, float qmul,
+                                          const float* __restrict__ xs, const float* __restrict__ wl, int ntok, int T, int H,
+                                          float* __restrict__ gq) {
     const int HC = H * C, W3 = 3 * HC;
     token_gemm<NC>(xs, ntok, HC, wl, W3, [&](int t0_, int col0, const float (&a)[4][NC]) {
         const int img = t0_ / T, tt = t0_ - img * T;
@@ -224,24 +248,33 @@ __device__ __forceinline__ void stage_qkv(float* __restrict__ sm, float* __restr
         for (int j = 0; j < NC; ++j) {
             const int col = col0 + j;
             const int part = col / HC, hc = col - part * HC;
+            const int h_ = hc / C, c_ = hc - h_ * C;
             float* dst;
             int stride;
+            float mul = 1.f;
             if (part == 0) {
-                dst = qs + (size_t)t0_ * HC + hc;
-                stride = HC;
+                if constexpr (QREC) {
+                    dst = qd + ((size_t)(img * H + h_) * T + tt) * qstride + c_;
+                    stride = qstride;
+                } else {
+                    dst = qd + (size_t)t0_ * HC + hc;
+                    stride = HC;
+                }
+                mul = qmul;
             } else {
-                const int h_ = hc / C, c_ = hc - h_ * C;
-                dst = sm + ((size_t)(img * H + h_) * T + tt) * KVS + (part - 1) * C + c_;
+                dst = kvrec + ((size_t)(img * H + h_) * T + tt) * KVS + (part - 1) * C + c_;
                 stride = KVS;
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dst[t * stride] = a[t][j];
+            for (int t = 0; t < 4; ++t) dst[t * stride] = a[t][j] * mul;
         }
+        if (gq) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float* g = gq + (size_t)(t0_ + t) * W3 + col0;
-            if constexpr (NC == 2) *reinterpret_cast<float2*>(g) = make_float2(a[t][0], a[t][1]);
-            else g[0] = a[t][0];
+            for (int t = 0; t < 4; ++t) {
+                float* g = gq + (size_t)(t0_ + t) * W3 + col0;
+                if constexpr (NC == 2) *reinterpret_cast<float2*>(g) = make_float2(a[t][0], a[t][1]);
+                else g[0] = a[t][0];
+            }
         }
     });
 }
@@ -331,31 +364,13 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const floa
     const int ntok = FUSED ? nsl / H * T : 0;                 // slice0 % H == 0 and (N H) % H == 0: whole images
     const size_t tok0 = FUSED ? (size_t)(slice0 / H) * T : 0;  // first token of the block in [N][T]
     if constexpr (FUSED) {
-        const float* xg = sg.x + tok0 * HC;
-        const int nx = ntok * HC;
-        if ((HC & 3) == 0) {
-            for (int i = threadIdx.x * 4; i < nx; i += blockDim.x * 4) {
-                float4 v = *reinterpret_cast<const float4*>(xg + i);
-                if (sg.scale) {
-                    const int c0 = i % HC;
-                    const float4 a = *reinterpret_cast<const float4*>(sg.scale + c0), b = *reinterpret_cast<const float4*>(sg.shift + c0);
-                    v.x = fmaf(v.x, a.x, b.x), v.y = fmaf(v.y, a.y, b.y), v.z = fmaf(v.z, a.z, b.z), v.w = fmaf(v.w, a.w, b.w);
-                }
-                *reinterpret_cast<float4*>(xs + i) = v;
-            }
-        } else {
-            for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-                float v = xg[i];
-                if (sg.scale) v = fmaf(v, sg.scale[i % HC], sg.shift[i % HC]);
-                xs[i] = v;
-            }
-        }
+        stage_input_tile(xs, sg.x + tok0 * HC, ntok * HC, HC, sg.scale, sg.shift);
         stage_weights(wl, sg.wqkv, HC * W3);
         stage_weights(wpl, sg.wproj, HC * HC);
         __syncthreads();
-        float* gq = sg.qkv + tok0 * W3;
-        if (HC & 1) stage_qkv<C, KVS, 1>(sm, qs, xs, wl, ntok, T, H, gq);
-        else stage_qkv<C, KVS, 2>(sm, qs, xs, wl, ntok, T, H, gq);
+        float* gq = sg.qkv ? sg.qkv + tok0 * W3 : nullptr;  // (NULL: the backward kernel forms q / k / v again from x)
+        if (HC & 1) stage_qkv<C, KVS, 1, false>(sm, qs, 0, 1.f, xs, wl, ntok, T, H, gq);
+        else stage_qkv<C, KVS, 2, false>(sm, qs, 0, 1.f, xs, wl, ntok, T, H, gq);
     } else {
         stage_kv<C, KVS>(sm, qkv, slice0, nsl, T, H);
     }
@@ -623,6 +638,8 @@ struct AttnStageBwd {
     const float* invstd;
     float* gv;            // [N][T][HC] gradient of the qkv convolution's (normalised) input
     double* bn_partial;   // [2][HC][gridDim.x]: sum gv, sum gv * xhat per channel, or NULL
+    const float* scale;   // qkv == NULL (the forward kernel did not write it): the BatchNorm affine [HC] (or NULL) with which q / k / v
+    const float* shift;   // are formed again from x
 };
 
 // n = rows * cols floats global [rows][cols] -> LDS [cols][rows]
@@ -665,11 +682,18 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
     float* s_gy = s_qg + (size_t)SPB * T * RQG;
     float* wl = s_gy + (size_t)SPB * T * C;  // wproj^T [HC][HC]
     float* wql = wl + HC * HC;               // wqkv^T [3 HC][HC]
+    float* wq3 = wql + 3 * HC * HC;          // wqkv [HC][3 HC] and the normalised input tile [SPB / H][T][HC]: only when q / k / v are
+    float* s_x = wq3 + 3 * HC * HC;          // formed again here (qkv == NULL)
+    const bool recompute = FUSED && qkv == nullptr;
     const int ntok = FUSED ? nsl / H * T : 0;
     const size_t tok0 = FUSED ? (size_t)(slice0 / H) * T : 0;
     const float inv_c = qk_scale;
-    stage_kv<C>(s_kv, qkv, slice0, nsl, T, H);
+    if (!recompute) stage_kv<C>(s_kv, qkv, slice0, nsl, T, H);
     if constexpr (FUSED) {
+        if (recompute) {
+            stage_input_tile(s_x, sg.x + tok0 * HC, ntok * HC, HC, sg.scale, sg.shift);
+            stage_weights(wq3, sg.wqkv, HC * W3);
+        }
         stage_weights(s_gy, sg.gy + tok0 * HC, ntok * HC);
         stage_weights_t(wl, sg.wproj, HC, HC);  // wl[co][ci] = wproj[ci][co]
         stage_weights_t(wql, sg.wqkv, HC, W3);  // wql[col][ci] = wqkv[ci][col] for the epilogue
@@ -688,6 +712,10 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
         };
         if (HC & 1) token_gemm<1>(s_gy, ntok, HC, wl, HC, put);
         else token_gemm<2>(s_gy, ntok, HC, wl, HC, put);
+        if (recompute) {  // q * scale -> the q slot of the query records, k / v -> the key records
+            if (HC & 1) stage_qkv<C, RKV, 1, true>(s_kv, s_qg, RQG, inv_c, s_x, wq3, ntok, T, H, nullptr);
+            else stage_qkv<C, RKV, 2, true>(s_kv, s_qg, RQG, inv_c, s_x, wq3, ntok, T, H, nullptr);
+        }
         __syncthreads();
     }
     // query records {q/C, gout, lse, delta = sum_c gout*out}
@@ -708,7 +736,7 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float g = gp[c];
-            r[c] = qp[c] * inv_c;
+            if (!recompute) r[c] = qp[c] * inv_c;
             if constexpr (!FUSED) r[C + c] = g;
             d = fmaf(g, op[c], d);
         }
@@ -1240,10 +1268,10 @@ static int attn_stage_shape(int N, int T, int H, int C, bool aux, bool backward,
     *qpt = pick_qpt(T, C);
     const int tps = T / *qpt;
     if (tps > 256 || (*qpt == 4 && C > 4)) STAGE_NO("otvae_attn_stage: T = %d with head width %d unsupported", T, C);
-    // forward: {k, v (, u)} records + q + input / output tile; backward: {k, v} + {q, gout, lse, delta} records + gy tile
+    // forward: {k, v (, u)} records + q + input / output tile; backward: {k, v} + {q, gout, lse, delta} records + gy tile + x tile
     const int rkv = aux ? ((2 * C + C * C + 3) & ~3) : 2 * C;
-    const int per_slice = backward ? T * (2 * C + ((2 * C + 2 + 3) & ~3) + C) : T * (rkv + 2 * C);
-    const int wfloats = 4 * HC * HC;          // both 1x1 kernels' weights
+    const int per_slice = backward ? T * (2 * C + ((2 * C + 2 + 3) & ~3) + 2 * C) : T * (rkv + 2 * C);
+    const int wfloats = (backward ? 7 : 4) * HC * HC;  // both 1x1 kernels' weights (backward: transposed, + wqkv as it is for q / k / v)
     int s = imin(256 / tps, (ATTN_STAGE_LDS_FLOATS - wfloats) / per_slice) / H * H;
     if (s < H) STAGE_NO("otvae_attn_stage: the %d heads of an image do not fit one workgroup (T=%d)", H, T);
     // fill the chip: halve the images per block while the grid is short of one block per CU
@@ -1278,7 +1306,7 @@ extern "C" int otvae_attn_stage_bwd_plan(int N, int T, int H, int C, int* bn_row
 extern "C" int otvae_attn_stage_fwd(const float* x, const float* scale, const float* shift, const float* wqkv, const float* wproj,
                                     const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv, float* out, float* lse,
                                     float* aux, float* y, double* stat_partial, void* stream) {
-    OTVAE_REQUIRE(x && wqkv && wproj && qkv && out && lse && y, "otvae_attn_stage_fwd: NULL tensor");
+    OTVAE_REQUIRE(x && wqkv && wproj && out && lse && y, "otvae_attn_stage_fwd: NULL tensor");
     OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_attn_stage_fwd: scale/shift must come together");
     OTVAE_REQUIRE(qk_scale > 0.f, "otvae_attn_stage_fwd: scale must be positive");
     if (C > 2) aux = nullptr;
@@ -1312,9 +1340,13 @@ extern "C" int otvae_attn_stage_fwd(const float* x, const float* scale, const fl
 }
 
 extern "C" int otvae_attn_stage_bwd(const float* gy, const float* wproj, const float* wqkv, const float* x, const float* mean,
-                                    const float* invstd, const float* qkv, const float* out, const float* lse, const float* aux, int N,
-                                    int T, int H, int C, float qk_scale, float* gqkv, float* gv, double* bn_partial, void* stream) {
-    OTVAE_REQUIRE(gy && wproj && wqkv && qkv && out && lse && gqkv && gv, "otvae_attn_stage_bwd: NULL tensor");
+                                    const float* invstd, const float* scale, const float* shift, const float* qkv, const float* out,
+                                    const float* lse, const float* aux, int N, int T, int H, int C, float qk_scale, float* gqkv, float* gv,
+                                    double* bn_partial, void* stream) {
+    OTVAE_REQUIRE(gy && wproj && wqkv && out && lse && gqkv && gv, "otvae_attn_stage_bwd: NULL tensor");
+    OTVAE_REQUIRE(qkv || x, "otvae_attn_stage_bwd: without the saved qkv the block input x is needed");
+    OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_attn_stage_bwd: scale/shift must come together");
+    OTVAE_REQUIRE(attn_aligned16(x) && attn_aligned16(scale) && attn_aligned16(shift), "otvae_attn_stage_bwd: x / scale / shift must be 16-byte aligned");
     OTVAE_REQUIRE((mean == nullptr) == (invstd == nullptr), "otvae_attn_stage_bwd: mean/invstd must come together");
     OTVAE_REQUIRE(!mean || (x && bn_partial), "otvae_attn_stage_bwd: x and bn_partial are needed for the BatchNorm sums");
     OTVAE_REQUIRE(qk_scale > 0.f, "otvae_attn_stage_bwd: scale must be positive");
@@ -1324,7 +1356,7 @@ extern "C" int otvae_attn_stage_bwd(const float* gy, const float* wproj, const f
     int rc = attn_stage_shape(N, T, H, C, false, true, &qpt, &spb, &grid, &nthr, &lds, false);
     if (rc) return rc;
     OTVAE_REQUIRE(((uintptr_t)gv & 7) == 0, "otvae_attn_stage_bwd: gv must be 8-byte aligned");
-    const AttnStageBwd sg = {gy, wproj, wqkv, x, mean, invstd, gv, bn_partial};
+    const AttnStageBwd sg = {gy, wproj, wqkv, x, mean, invstd, gv, bn_partial, scale, shift};
     hipStream_t st = (hipStream_t)stream;
 #define STAGE_BK(K_)                                                                                  \
     {                                                                                                 \

@@ -1040,6 +1040,8 @@ def qkv_attention(qkv: Tensor, n_heads: int) -> Tensor:
 # OTVAE_ATTN_STAGE=0 (A/B switch): the AttentionBlock runs as its three launches (qkv convolution, attention, output projection)
 ATTN_STAGE = os.environ.get("OTVAE_ATTN_STAGE", "1") != "0"
 ATTN_STAGE_BWD = os.environ.get("OTVAE_ATTN_STAGE_BWD", "1") != "0"  # ... and its backward pass likewise (one launch instead of three)
+# OTVAE_ATTN_STAGE_QKV=1 (A/B switch): the forward kernel writes qkv and the backward kernel reads it instead of forming q / k / v again
+ATTN_STAGE_KEEP_QKV = os.environ.get("OTVAE_ATTN_STAGE_QKV", "0") == "1"
 _STAGE_PLAN_CACHE: dict = {}
 _STAGE_BWD_PLAN_CACHE: dict = {}
 
@@ -1050,6 +1052,16 @@ def _plain_1x1(br: dict, cout: int, cin: int) -> bool:
             and br.get("group_norm") is None and br.get("film") is None and br.get("dropout2d") is None and br.get("expand") is None
             and br.get("up_module") is None and br.get("down_module") is None and br.get("bias") is None
             and br["stride"] == 1 and br["pad"] == 0 and br["up"] == 1 and tuple(w.shape) == (cout, cin, 1, 1) and is_hwio(w))
+
+
+def _stage_bwd_rows(n: int, t: int, heads: int, c: int) -> int:
+    """partial-sum rows of the one-launch AttentionBlock backward (``otvae_attn_stage_bwd``), 0 when it does not take the shape"""
+    key = (n, t, heads, c)
+    rows = _STAGE_BWD_PLAN_CACHE.get(key)
+    if rows is None:
+        r = C.c_int(0)
+        rows = _STAGE_BWD_PLAN_CACHE[key] = r.value if _lib.load().otvae_attn_stage_bwd_plan(n, t, heads, c, C.byref(r)) == 0 else 0
+    return rows
 
 
 class _AttnStageFn(torch.autograd.Function):
@@ -1063,7 +1075,9 @@ class _AttnStageFn(torch.autograd.Function):
         mean, invstd, scales, shifts, training = stats
         n, hc, hh, ww = x.shape
         t, c = hh * ww, hc // heads
-        qkv = empty_nhwc(n, 3 * hc, hh, ww, x)
+        # the fused backward kernel forms q / k / v again from x: qkv is written only for a three-launch backward pass
+        need_qkv = need_aux and (ATTN_STAGE_KEEP_QKV or not (ATTN_STAGE_BWD and _stage_bwd_rows(n, t, heads, c)))
+        qkv = empty_nhwc(n, 3 * hc, hh, ww, x) if need_qkv else None
         out = empty_nhwc(n, hc, hh, ww, x)
         y = empty_nhwc(n, hc, hh, ww, x)
         lse = torch.empty((n, heads, t), device=x.device, dtype=torch.float32)
@@ -1089,24 +1103,22 @@ class _AttnStageFn(torch.autograd.Function):
         sp_p = ConvSpec(1, 0, 1, False, False, False, has_res, False)
         sp_q = ConvSpec(1, 0, 1, False, has_norm, False, False, False)
         no_stats = (None, None, [None], [None], training)
-        gqkv = torch.empty_strided(qkv.shape, qkv.stride(), device=qkv.device, dtype=qkv.dtype)
-        key = (n, t, heads, c)
-        rows = _STAGE_BWD_PLAN_CACHE.get(key)
-        if rows is None:
-            r = C.c_int(0)
-            rows = _STAGE_BWD_PLAN_CACHE[key] = r.value if lib.otvae_attn_stage_bwd_plan(n, t, heads, c, C.byref(r)) == 0 else 0
-        if rows and ATTN_STAGE_BWD:
+        gqkv = empty_nhwc(n, 3 * hc, hh, ww, x)
+        rows = _stage_bwd_rows(n, t, heads, c)
+        if qkv is None or (rows and ATTN_STAGE_BWD):
             # one launch for projection data gradient + attention backward + qkv data gradient with the BatchNorm sums
             gy = as_nhwc(gy)
+            # both weight-gradient jobs share one side-stream launch, forked behind the fused kernel and recorded behind the launch
+            # stream's next nodes (see fork=).  (A fork point of its own for the projection's job, in front of the fused kernel so that it
+            # can run beside it, measured 0.01-0.02 ms SLOWER per step: profiles/r03_attn_stage_ab.txt.)
+            _, per_p = conv_backward_launch(out, (wp, None, None, None, res), (sp_p,), (ctx.geoms[1],), no_stats, (pref_p,), (gy,), False,
+                                            fork="queue")
             gv = empty_nhwc(n, hc, hh, ww, x)
             part = torch.empty((rows, 2, hc), device=x.device, dtype=torch.float64) if has_norm else None
             check(lib.otvae_attn_stage_bwd(ptr(gy), ptr(wp), ptr(wq), ptr(x), ptr(stats[0]) if has_norm else None,
-                                           ptr(stats[1]) if has_norm else None, ptr(qkv), ptr(out), ptr(lse), ptr(aux), n, t, heads, c, scale,
-                                           ptr(gqkv), ptr(gv), ptr(part), stream()), "otvae_attn_stage_bwd")
-            # both weight-gradient jobs in one side-stream launch, forked behind the kernel above; the launch stream's next nodes (the
-            # BatchNorm backward pair) are recorded first
-            _, per_p = conv_backward_launch(out, (wp, None, None, None, res), (sp_p,), (ctx.geoms[1],), no_stats, (pref_p,), (gy,), False,
-                                            fork="queue")
+                                           ptr(stats[1]) if has_norm else None, ptr(stats[2][0]) if has_norm else None,
+                                           ptr(stats[3][0]) if has_norm else None, ptr(qkv), ptr(out), ptr(lse), ptr(aux), n, t, heads, c,
+                                           scale, ptr(gqkv), ptr(gv), ptr(part), stream()), "otvae_attn_stage_bwd")
             dx, per_q = conv_backward_launch(x, (wq, None, gamma, beta, None), (sp_q,), (ctx.geoms[0],), stats, (pref_q,), (gqkv,),
                                              ctx.needs_input_grad[0], pre_dgrad=[(gv, part, rows, hc)], fork="after_bn")
             return dx, None, per_q[0][0], per_q[0][2], per_q[0][3], per_p[0][0], per_p[0][4]

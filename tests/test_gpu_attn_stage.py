@@ -146,3 +146,41 @@ def test_stage_plan_rejects_what_it_cannot_take(A):
     x = HF.as_nhwc(normal((3, 12, 4, 4), 3).cuda())
     y = blk(x)
     assert y.shape == x.shape and torch.isfinite(y).all()
+
+
+def test_stage_bwd_with_saved_qkv_equals_recomputed(A):
+    """``otvae_attn_stage_bwd`` through the C ABI: given the qkv tensor the forward kernel can write it reads q / k / v from there; given
+    NULL it forms them again from x -- the same arithmetic, so the same bits."""
+    from ot_vae_lightning_amd import functional as HF
+    from ot_vae_lightning_amd._lib import ptr, stream, check
+    lib = A._lib.load()
+    n, hc, side, heads = 6, 16, 8, 4
+    t, c = side * side, hc // heads
+    x = HF.as_nhwc(normal((n, hc, side, side), 3).cuda())
+    gy = HF.as_nhwc(normal((n, hc, side, side), 4).cuda())
+    wq = normal((hc, 3 * hc), 5).mul_(0.3).cuda()
+    wp = normal((hc, hc), 6).mul_(0.3).cuda()
+    scale, shift = normal((hc,), 7).mul_(0.2).add_(1.0).cuda(), normal((hc,), 8).mul_(0.1).cuda()
+    mean, invstd = normal((hc,), 9).mul_(0.1).cuda(), normal((hc,), 10).abs_().add_(0.5).cuda()
+    rows, rows_b = C.c_int(0), C.c_int(0)
+    assert lib.otvae_attn_stage_plan(n, t, heads, c, 1, C.byref(rows)) == 0
+    assert lib.otvae_attn_stage_bwd_plan(n, t, heads, c, C.byref(rows_b)) == 0
+    e = lambda *shape, dt=torch.float32: torch.empty(shape, device="cuda", dtype=dt)  # noqa: E731
+    qkv, out, y, lse = e(n, t, 3 * hc), e(n, t, hc), e(n, t, hc), e(n, heads, t)
+    check(lib.otvae_attn_stage_fwd(ptr(x), ptr(scale), ptr(shift), ptr(wq), ptr(wp), None, n, t, heads, c, 1.0 / c, ptr(qkv), ptr(out),
+                                   ptr(lse), None, ptr(y), None, stream()), "fwd")
+    res = []
+    for saved in (qkv, None):
+        gqkv, gv, part = e(n, t, 3 * hc), e(n, t, hc), e(rows_b.value, 2, hc, dt=torch.float64)
+        check(lib.otvae_attn_stage_bwd(ptr(gy), ptr(wp), ptr(wq), ptr(x), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(saved),
+                                       ptr(out), ptr(lse), None, n, t, heads, c, 1.0 / c, ptr(gqkv), ptr(gv), ptr(part), stream()), "bwd")
+        torch.cuda.synchronize()
+        res.append((gqkv, gv, part))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # and the forward kernel without the qkv output writes the same out / y / lse
+    out2, y2, lse2 = e(n, t, hc), e(n, t, hc), e(n, heads, t)
+    check(lib.otvae_attn_stage_fwd(ptr(x), ptr(scale), ptr(shift), ptr(wq), ptr(wp), None, n, t, heads, c, 1.0 / c, None, ptr(out2),
+                                   ptr(lse2), None, ptr(y2), None, stream()), "fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out) and torch.equal(y2, y) and torch.equal(lse2, lse)
