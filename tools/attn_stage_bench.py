@@ -1,8 +1,8 @@
 """The AttentionBlock's forward at the benchmark's stage shapes (batch 1024), isolated: one fused launch (``otvae_attn_stage_fwd``) against
 the three launches it replaces (1x1 qkv convolution with the BatchNorm prologue, attention, 1x1 projection with the residual sum and the
-statistics epilogue), and likewise the backward pass (``otvae_attn_stage_bwd`` against projection data gradient + attention backward +
-qkv data gradient with the BatchNorm sums).  Every variant is 20 dependent repetitions inside one hipGraph, timed with HIP events on the
-launch stream; us per repetition.  Usage: python tools/attn_stage_bench.py [batch]"""
+statistics epilogue).  Every variant is 20 dependent repetitions of the module's forward inside one hipGraph, timed with HIP events on
+the launch stream; us per repetition.  (The backward pass is compared inside the captured training step: profiles/r03_attn_stage_ab.txt.)
+Usage: python tools/attn_stage_bench.py [batch]"""
 import os
 import sys
 
@@ -38,39 +38,22 @@ def graph_time(fn, iters=20):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    print(f"# batch {n}; us per AttentionBlock pass, 20 dependent repetitions per hipGraph")
-    print(f"{'stage':<26}{'fwd fused':>10}{'fwd 3 launches':>16}{'bwd fused':>11}{'bwd 3 launches':>16}")
+    print(f"# batch {n}; us per AttentionBlock forward (BatchNorm statistics pass + finalize included on both sides), 20 repetitions per hipGraph")
+    print(f"{'stage':<28}{'one launch':>12}{'three launches':>16}")
     for side, width, heads in STAGES:
         blk = AttentionBlock(width, heads=heads, normalization="batchnorm").cuda().train()
         x = HF.as_nhwc(torch.randn(n, width, side, side, device="cuda"))
         res = HF.as_nhwc(torch.randn(n, width, side, side, device="cuda"))
-        gy = HF.as_nhwc(torch.randn(n, width, side, side, device="cuda"))
         row = []
-        for fused in (True, False):
-            HF.ATTN_STAGE, HF.ATTN_STAGE_BWD = fused, fused
-            xr = x.clone().requires_grad_(True)
-            state = {}
-
-            def fwd():
-                state["y"] = blk(xr, residual=res)
-
-            def bwd():
-                for p in blk.parameters():
-                    p.grad = None
-                xr.grad = None
-                state["y"].backward(gy, retain_graph=True)
-
-            tf = graph_time(fwd)
-            fwd()
-            tb = graph_time(bwd)
-            row.append((tf, tb))
-        HF.ATTN_STAGE = HF.ATTN_STAGE_BWD = True
-        fused_ok = HF.attention_stage(x, blk.qkv.branch(None, False), heads, blk.proj_out.branch(res, True), training=False) is not None
+        with torch.no_grad():
+            for fused in (True, False):
+                HF.ATTN_STAGE = fused
+                row.append(graph_time(lambda: blk(x, residual=res)))
+            HF.ATTN_STAGE = True
+            fused_ok = HF.attention_stage(x, blk.qkv.branch(None, False), heads, blk.proj_out.branch(res, True), training=False) is not None
         name = f"{side}x{side}, width {width}, {heads} heads" + ("" if fused_ok else " *")
-        print(f"{name:<26}{row[0][0]:>10.1f}{row[1][0]:>16.1f}{row[0][1]:>11.1f}{row[1][1]:>16.1f}")
-    print("* shape the fused kernels do not take: both columns are the three launches")
-    print("(forward columns include the BatchNorm statistics pass + finalize launch of the qkv layer, backward columns the BatchNorm backward pair "
-          "and the two weight-gradient jobs with their reductions: the same launches on both sides)")
+        print(f"{name:<28}{row[0]:>12.1f}{row[1]:>16.1f}")
+    print("* shape the fused kernel does not take: both columns are the three launches")
 
 
 if __name__ == "__main__":
