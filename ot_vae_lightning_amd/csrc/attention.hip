@@ -186,9 +186,11 @@ __device__ __forceinline__ void stage_input_tile(float* __restrict__ xs, const f
 // out(tok, col) = sum_ci in[tok][ci] * W[ci][col] over the block's ntok tokens (LDS, row stride Cin, ntok % 4 == 0) with W [Cin][ncols]
 // in LDS as well: a work item is 4 consecutive tokens x NC adjacent columns, columns fastest (the lanes of a wave read W rows
 // conflict-free and one token row as a broadcast).  store(tok0, col0, a[4][NC]) receives the sums.
-template <int NC, class Store>
+// The token rows may also lie in global memory (a wave's lanes read the same row: one L1 line per load); sc / sh != NULL: row values
+// pass through x * sc[ci] + sh[ci] first when AFF (the BatchNorm affine the LDS tile would have applied).
+template <int NC, bool AFF = false, class Store>
 __device__ __forceinline__ void token_gemm(const float* __restrict__ in, int ntok, int Cin, const float* __restrict__ W, int ncols,
-                                           Store&& store) {
+                                           Store&& store, const float* __restrict__ sc = nullptr, const float* __restrict__ sh = nullptr) {
     const int cg = ncols / NC;
     const int items = (ntok >> 2) * cg;
     const float inv_cg = 1.0f / (float)cg;
@@ -209,9 +211,12 @@ __device__ __forceinline__ void token_gemm(const float* __restrict__ in, int nto
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int j = 0; j < NC; ++j) wv[u][j] = w[(ci + u) * ncols + j];
+                float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (AFF) av = *reinterpret_cast<const float4*>(sc + ci), bv = *reinterpret_cast<const float4*>(sh + ci);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float4 xv = *reinterpret_cast<const float4*>(r + t * Cin + ci);
+                    float4 xv = *reinterpret_cast<const float4*>(r + t * Cin + ci);
+                    if constexpr (AFF) xv.x = fmaf(xv.x, av.x, bv.x), xv.y = fmaf(xv.y, av.y, bv.y), xv.z = fmaf(xv.z, av.z, bv.z), xv.w = fmaf(xv.w, av.w, bv.w);
 #pragma unroll
                     for (int j = 0; j < NC; ++j) {
                         a[t][j] = fmaf(xv.x, wv[0][j], a[t][j]);
@@ -223,11 +228,15 @@ __device__ __forceinline__ void token_gemm(const float* __restrict__ in, int nto
             }
         } else {
             for (int ci = 0; ci < Cin; ++ci) {
+                const float a1 = AFF ? sc[ci] : 1.f, b1 = AFF ? sh[ci] : 0.f;
+                float xr[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xr[t] = AFF ? fmaf(r[t * Cin + ci], a1, b1) : r[t * Cin + ci];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     const float wv = w[ci * ncols + j];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) a[t][j] = fmaf(r[t * Cin + ci], wv, a[t][j]);
+                    for (int t = 0; t < 4; ++t) a[t][j] = fmaf(xr[t], wv, a[t][j]);
                 }
             }
         }
@@ -237,12 +246,13 @@ __device__ __forceinline__ void token_gemm(const float* __restrict__ in, int nto
 
 // q / k / v of the block's tokens from the normalised input tile: q (times qmul) -> qd[(slice-major token) * qstride + c] when QREC (the
 // backward kernel's query records) or qd [tok][HC] otherwise, k / v -> the slices' records, all three -> global when gq != NULL
-template <int C, int KVS, int NC, bool QREC>
+template <int C, int KVS, int NC, bool QREC, bool AFF = false>
 __device__ __forceinline__ void stage_qkv(float* __restrict__ kvrec, float* __restrict__ qd, int qstride, float qmul,
                                           const float* __restrict__ xs, const float* __restrict__ wl, int ntok, int T, int H,
-                                          float* __restrict__ gq) {
+                                          float* __restrict__ gq, const float* __restrict__ sc = nullptr,
+                                          const float* __restrict__ sh = nullptr) {
     const int HC = H * C, W3 = 3 * HC;
-    token_gemm<NC>(xs, ntok, HC, wl, W3, [&](int t0_, int col0, const float (&a)[4][NC]) {
+    token_gemm<NC, AFF>(xs, ntok, HC, wl, W3, [&](int t0_, int col0, const float (&a)[4][NC]) {
         const int img = t0_ / T, tt = t0_ - img * T;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
@@ -276,7 +286,7 @@ __device__ __forceinline__ void stage_qkv(float* __restrict__ kvrec, float* __re
                 else g[0] = a[t][0];
             }
         }
-    });
+    }, sc, sh);
 }
 
 // Per-block partial of per-column double sums carried by threads whose NC columns are fixed (column group = thread % (HC / NC)):
@@ -640,6 +650,8 @@ struct AttnStageBwd {
     double* bn_partial;   // [2][HC][gridDim.x]: sum gv, sum gv * xhat per channel, or NULL
     const float* scale;   // qkv == NULL (the forward kernel did not write it): the BatchNorm affine [HC] (or NULL) with which q / k / v
     const float* shift;   // are formed again from x
+    int direct;           // != 0: no LDS tiles of gy and x, the token products read their rows from global memory (the records alone then
+                          // leave room for a third workgroup per CU at 256 tokens x 4 heads: 88 -> 94 us for the pair loops otherwise)
 };
 
 // n = rows * cols floats global [rows][cols] -> LDS [cols][rows]
@@ -677,24 +689,26 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
     const int nsl = (int)min((long)SPB, total - slice0);
     float* s_kv = sm;
     float* s_qg = sm + (size_t)SPB * T * RKV;
-    // FUSED: behind the records the gy tile [SPB / H][T][HC] (later the reduction scratch) and the transposed 1x1 weights; the records'
+    // FUSED: behind the records the 1x1 kernels' weights, the reduction scratch and (unless sg.direct) the gy and x tiles; the records'
     // place is reused for the dqkv tile [SPB / H][T][3 HC] of the epilogue
-    float* s_gy = s_qg + (size_t)SPB * T * RQG;
-    float* wl = s_gy + (size_t)SPB * T * C;  // wproj^T [HC][HC]
-    float* wql = wl + HC * HC;               // wqkv^T [3 HC][HC]
-    float* wq3 = wql + 3 * HC * HC;          // wqkv [HC][3 HC] and the normalised input tile [SPB / H][T][HC]: only when q / k / v are
-    float* s_x = wq3 + 3 * HC * HC;          // formed again here (qkv == NULL)
+    float* wl = s_qg + (size_t)SPB * T * RQG;  // wproj^T [HC][HC]
+    float* wql = wl + HC * HC;                 // wqkv^T [3 HC][HC]
+    float* wq3 = wql + 3 * HC * HC;            // wqkv [HC][3 HC] (for q / k / v formed again here: qkv == NULL)
+    float* s_red = wl + ((7 * HC * HC + 3) & ~3);  // [4 waves][2][HC] doubles of the BatchNorm sums' reduction
+    float* s_gy = s_red + 16 * HC;             // gy tile and normalised input tile [SPB / H][T][HC] each -- not allocated when sg.direct
+    float* s_x = s_gy + (size_t)SPB * T * C;
     const bool recompute = FUSED && qkv == nullptr;
+    const bool direct = FUSED && sg.direct != 0;
     const int ntok = FUSED ? nsl / H * T : 0;
     const size_t tok0 = FUSED ? (size_t)(slice0 / H) * T : 0;
     const float inv_c = qk_scale;
     if (!recompute) stage_kv<C>(s_kv, qkv, slice0, nsl, T, H);
     if constexpr (FUSED) {
         if (recompute) {
-            stage_input_tile(s_x, sg.x + tok0 * HC, ntok * HC, HC, sg.scale, sg.shift);
+            if (!direct) stage_input_tile(s_x, sg.x + tok0 * HC, ntok * HC, HC, sg.scale, sg.shift);
             stage_weights(wq3, sg.wqkv, HC * W3);
         }
-        stage_weights(s_gy, sg.gy + tok0 * HC, ntok * HC);
+        if (!direct) stage_weights(s_gy, sg.gy + tok0 * HC, ntok * HC);
         stage_weights_t(wl, sg.wproj, HC, HC);  // wl[co][ci] = wproj[ci][co]
         stage_weights_t(wql, sg.wqkv, HC, W3);  // wql[col][ci] = wqkv[ci][col] for the epilogue
         __syncthreads();
@@ -710,11 +724,18 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
                 for (int t = 0; t < 4; ++t) dst[t * RQG] = a[t][j];
             }
         };
-        if (HC & 1) token_gemm<1>(s_gy, ntok, HC, wl, HC, put);
-        else token_gemm<2>(s_gy, ntok, HC, wl, HC, put);
+        const float* gy_rows = direct ? sg.gy + tok0 * HC : s_gy;
+        if (HC & 1) token_gemm<1>(gy_rows, ntok, HC, wl, HC, put);
+        else token_gemm<2>(gy_rows, ntok, HC, wl, HC, put);
         if (recompute) {  // q * scale -> the q slot of the query records, k / v -> the key records
-            if (HC & 1) stage_qkv<C, RKV, 1, true>(s_kv, s_qg, RQG, inv_c, s_x, wq3, ntok, T, H, nullptr);
-            else stage_qkv<C, RKV, 2, true>(s_kv, s_qg, RQG, inv_c, s_x, wq3, ntok, T, H, nullptr);
+            const float* x_rows = direct ? sg.x + tok0 * HC : s_x;
+            if (direct && sg.scale) {
+                if (HC & 1) stage_qkv<C, RKV, 1, true, true>(s_kv, s_qg, RQG, inv_c, x_rows, wq3, ntok, T, H, nullptr, sg.scale, sg.shift);
+                else stage_qkv<C, RKV, 2, true, true>(s_kv, s_qg, RQG, inv_c, x_rows, wq3, ntok, T, H, nullptr, sg.scale, sg.shift);
+            } else {
+                if (HC & 1) stage_qkv<C, RKV, 1, true>(s_kv, s_qg, RQG, inv_c, x_rows, wq3, ntok, T, H, nullptr);
+                else stage_qkv<C, RKV, 2, true>(s_kv, s_qg, RQG, inv_c, x_rows, wq3, ntok, T, H, nullptr);
+            }
         }
         __syncthreads();
     }
@@ -1089,7 +1110,7 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
                     }
                 }
             });
-            if (sg.bn_partial) column_sums_to_partial<NC_>(s1, s2, reinterpret_cast<double*>(s_gy), HC, sg.bn_partial);
+            if (sg.bn_partial) column_sums_to_partial<NC_>(s1, s2, reinterpret_cast<double*>(s_red), HC, sg.bn_partial);
         };
         if (HC & 1) project(std::integral_constant<int, 1>{});
         else project(std::integral_constant<int, 2>{});
@@ -1250,7 +1271,7 @@ static inline bool attn_aligned16(const void* p) { return ((uintptr_t)p & 15) ==
 // Launch shape, or OTVAE_EUNSUPPORTED when the stage has to run as three launches: a block must own whole images (spb % H == 0), the token
 // GEMMs want T % 4 == 0, the per-column statistics a power-of-two width <= 64.
 static int attn_stage_shape(int N, int T, int H, int C, bool aux, bool backward, int* qpt, int* spb, int* grid, int* nthr, size_t* lds,
-                            bool quiet) {
+                            bool quiet, int* direct = nullptr) {
     const int HC = H * C;
 #define STAGE_NO(...)                                  \
     do {                                               \
@@ -1270,8 +1291,21 @@ static int attn_stage_shape(int N, int T, int H, int C, bool aux, bool backward,
     if (tps > 256 || (*qpt == 4 && C > 4)) STAGE_NO("otvae_attn_stage: T = %d with head width %d unsupported", T, C);
     // forward: {k, v (, u)} records + q + input / output tile; backward: {k, v} + {q, gout, lse, delta} records + gy tile + x tile
     const int rkv = aux ? ((2 * C + C * C + 3) & ~3) : 2 * C;
-    const int per_slice = backward ? T * (2 * C + ((2 * C + 2 + 3) & ~3) + 2 * C) : T * (rkv + 2 * C);
-    const int wfloats = (backward ? 7 : 4) * HC * HC;  // both 1x1 kernels' weights (backward: transposed, + wqkv as it is for q / k / v)
+    // backward: the gy and x tiles are left out (direct = 1: their rows are read from global memory) when that lets a third workgroup
+    // share the CU's 160 KiB
+    const int rec_slice = T * (2 * C + ((2 * C + 2 + 3) & ~3));
+    const int bw_floats = ((7 * HC * HC + 3) & ~3) + 16 * HC;  // transposed weights + wqkv as it is + reduction scratch
+    static const int direct_env = getenv("OTVAE_ATTN_STAGE_DIRECT") ? atoi(getenv("OTVAE_ATTN_STAGE_DIRECT")) : 1;  // A/B switch: 0 = tiles
+    if (direct) *direct = 0;
+    if (backward && direct && direct_env) {
+        const int s3 = imin(256 / tps, (ATTN_STAGE_LDS_FLOATS - bw_floats) / rec_slice) / H * H;
+        const size_t third = 160 * 1024 / 3;
+        if (s3 >= H && ((size_t)s3 * (rec_slice + 2 * T * C) + bw_floats) * sizeof(float) > third &&
+            ((size_t)s3 * rec_slice + bw_floats) * sizeof(float) <= third)
+            *direct = 1;
+    }
+    const int per_slice = backward ? rec_slice + ((direct && *direct) ? 0 : 2 * T * C) : T * (rkv + 2 * C);
+    const int wfloats = backward ? bw_floats : 4 * HC * HC;  // (forward: both 1x1 kernels' weights)
     int s = imin(256 / tps, (ATTN_STAGE_LDS_FLOATS - wfloats) / per_slice) / H * H;
     if (s < H) STAGE_NO("otvae_attn_stage: the %d heads of an image do not fit one workgroup (T=%d)", H, T);
     // fill the chip: halve the images per block while the grid is short of one block per CU
@@ -1297,7 +1331,8 @@ extern "C" int otvae_attn_stage_plan(int N, int T, int H, int C, int need_aux, i
 extern "C" int otvae_attn_stage_bwd_plan(int N, int T, int H, int C, int* bn_rows) {
     int qpt, spb, grid, nthr;
     size_t lds;
-    int rc = attn_stage_shape(N, T, H, C, false, true, &qpt, &spb, &grid, &nthr, &lds, true);
+    int direct;
+    int rc = attn_stage_shape(N, T, H, C, false, true, &qpt, &spb, &grid, &nthr, &lds, true, &direct);
     if (rc) return rc;
     if (bn_rows) *bn_rows = grid;
     return OTVAE_OK;
@@ -1353,10 +1388,11 @@ extern "C" int otvae_attn_stage_bwd(const float* gy, const float* wproj, const f
     if (C > 2) aux = nullptr;
     int qpt, spb, grid, nthr;
     size_t lds;
-    int rc = attn_stage_shape(N, T, H, C, false, true, &qpt, &spb, &grid, &nthr, &lds, false);
+    int direct = 0;
+    int rc = attn_stage_shape(N, T, H, C, false, true, &qpt, &spb, &grid, &nthr, &lds, false, &direct);
     if (rc) return rc;
-    OTVAE_REQUIRE(((uintptr_t)gv & 7) == 0, "otvae_attn_stage_bwd: gv must be 8-byte aligned");
-    const AttnStageBwd sg = {gy, wproj, wqkv, x, mean, invstd, gv, bn_partial, scale, shift};
+    OTVAE_REQUIRE(((uintptr_t)gv & 7) == 0 && attn_aligned16(gy), "otvae_attn_stage_bwd: gv must be 8-byte, gy 16-byte aligned");
+    const AttnStageBwd sg = {gy, wproj, wqkv, x, mean, invstd, gv, bn_partial, scale, shift, direct};
     hipStream_t st = (hipStream_t)stream;
 #define STAGE_BK(K_)                                                                                  \
     {                                                                                                 \

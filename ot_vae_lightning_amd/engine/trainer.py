@@ -558,6 +558,10 @@ class HipTrainer:
             self.model._last_nelbo = None
         self._captured = False
         self.use_graph = False
+        # graphs, side streams and events of the step sit in reference cycles (closures of the capture): collect them HERE, with the device
+        # idle, rather than at whatever allocation of the caller's next code the collector happens to run
+        import gc
+        gc.collect()
         torch.cuda.synchronize(self.device)
         check_solver = getattr(getattr(self.model, "prior", None), "raise_if_starved", None)
         if check_solver is not None:
