@@ -31,6 +31,9 @@ from ..networks.cnn import ConvLayer
 from .dp import FlatGradReducer
 from .segments import SEGMENT_CALLS, SegmentedStep
 
+# OTVAE_STATS_SIDE=0 (A/B switch): the latent-statistics update of a captured step stays on the launch stream behind the backward pass
+STATS_ON_SIDE = os.environ.get("OTVAE_STATS_SIDE", "1") != "0"
+
 __all__ = ["HipTrainer", "flatten_parameters"]
 
 
@@ -222,6 +225,15 @@ class HipTrainer:
             self._refresh_wd()
             loss, logs, art = self.model.nelbo(self._batch(), 0)
             self.latents = art["latents"].detach()
+            stats_on_side = (STATS_ON_SIDE and self.latent_stats is not None and self._segments is None
+                             and torch.cuda.is_current_stream_capturing())
+            if stats_on_side:
+                # the latent statistics depend on the forward pass only and nothing in the step reads them: they go to the side
+                # stream with the first weight-gradient fork of the backward pass (joined with it in flush)
+                from ..functional import _PendingReduce as _PR
+                lat_ = self.latents.flatten(1)
+                _PR._held.setdefault(self.device, []).append(lat_)
+                _PR._side_prologue[self.device] = lambda: self.latent_stats.update(target_samples=lat_)
             self._backward(loss)
         finally:
             PriorLane.enabled = False
@@ -236,8 +248,10 @@ class HipTrainer:
         self._collect_loose_grads()
         self._logs = {k: v.detach() for k, v in logs.items()}  # no reference into the autograd graph survives the step
         if self.latent_stats is not None:
-            lat = self.latents.flatten(1)  # [B, D] with transport_dims = (1, 2, 3)
-            self.latent_stats.update(target_samples=lat)
+            pending = _PendingReduce._side_prologue.pop(self.device, None)
+            if not stats_on_side or pending is not None:  # (not taken by a fork: in line, as in an eagerly issued step)
+                lat = self.latents.flatten(1)  # [B, D] with transport_dims = (1, 2, 3)
+                self.latent_stats.update(target_samples=lat)
         return self._logs
 
     def _batch(self):

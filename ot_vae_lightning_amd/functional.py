@@ -188,6 +188,7 @@ class _PendingReduce:
     _side = {}
     _held = {}
     _wq = {}       # device -> [queued weight-gradient jobs, backward calls they came from]
+    _side_prologue = {}  # device -> callable run once on the side stream at the next fork (see issue)
     _forked = {}   # device -> the side stream has work of this backward pass
     _reduced = {}  # device -> leading entries of _state whose partials the side stream has already reduced
 
@@ -278,6 +279,13 @@ class _PendingReduce:
             return
         side = _PendingReduce.side_stream(device)
         side.wait_event(ev)
+        pro = _PendingReduce._side_prologue.pop(device, None)
+        if pro is not None:
+            # work of the step that nothing on the launch stream waits for (the trainer's latent-statistics update): it rides on this
+            # fork, in front of the weight-gradient jobs -- no graph branch of its own (a lane of its own cost more than it took off
+            # the chain, engine/trainer.py)
+            with torch.cuda.stream(side):
+                pro()
         n = len(q[0])
         arr = (_lib.ConvJob * n)(*q[0])
         check(_lib.load().otvae_conv_multi(n, arr, C.c_void_p(side.cuda_stream)), "otvae_conv_multi(backward, weights)")
@@ -316,6 +324,7 @@ class _PendingReduce:
         if q:
             q[0].clear()
             q[1] = 0
+        _PendingReduce._side_prologue.pop(device, None)
         _PendingReduce._reduced[device] = 0
 
     @staticmethod
