@@ -31,7 +31,7 @@ from ..networks.cnn import ConvLayer
 from .dp import FlatGradReducer
 from .segments import SEGMENT_CALLS, SegmentedStep
 
-# OTVAE_STATS_SIDE=0 (A/B switch): the latent-statistics update of a captured step stays on the launch stream behind the backward pass
+# OTVAE_STATS_SIDE=0 (A/B switch): the loss value and the latent-statistics update of a captured step stay on the launch stream
 STATS_ON_SIDE = os.environ.get("OTVAE_STATS_SIDE", "1") != "0"
 
 __all__ = ["HipTrainer", "flatten_parameters"]
@@ -223,17 +223,22 @@ class HipTrainer:
         # of launches they take off the chain; removed.)
         try:
             self._refresh_wd()
-            loss, logs, art = self.model.nelbo(self._batch(), 0)
+            from ..functional import _PendingReduce as _PR
+            # what depends on the forward pass only and is read by nothing before the optimizer -- the loss value (ops._nelbo_fwd_launch)
+            # and the latent statistics -- goes to the side stream with the first weight-gradient fork of the backward pass (joined with
+            # it in flush); only in a captured single-graph step, where that fork exists
+            on_side = (STATS_ON_SIDE and self._segments is None and HF.WGRAD_SIDE_STREAM == 1 and torch.cuda.is_current_stream_capturing())
+            _PR._defer[self.device] = on_side
+            try:
+                loss, logs, art = self.model.nelbo(self._batch(), 0)
+            finally:
+                _PR._defer[self.device] = False
             self.latents = art["latents"].detach()
-            stats_on_side = (STATS_ON_SIDE and self.latent_stats is not None and self._segments is None
-                             and torch.cuda.is_current_stream_capturing())
-            if stats_on_side:
-                # the latent statistics depend on the forward pass only and nothing in the step reads them: they go to the side
-                # stream with the first weight-gradient fork of the backward pass (joined with it in flush)
-                from ..functional import _PendingReduce as _PR
+            if on_side and self.latent_stats is not None:
                 lat_ = self.latents.flatten(1)
-                _PR._held.setdefault(self.device, []).append(lat_)
-                _PR._side_prologue[self.device] = lambda: self.latent_stats.update(target_samples=lat_)
+                _PR._defer[self.device] = True
+                _PR.defer_to_side(self.device, lambda: self.latent_stats.update(target_samples=lat_), lat_)
+                _PR._defer[self.device] = False
             self._backward(loss)
         finally:
             PriorLane.enabled = False
@@ -247,11 +252,10 @@ class HipTrainer:
         _PendingReduce.flush(self.device)  # normally already done by the autograd-engine callback at the end of backward
         self._collect_loose_grads()
         self._logs = {k: v.detach() for k, v in logs.items()}  # no reference into the autograd graph survives the step
-        if self.latent_stats is not None:
-            pending = _PendingReduce._side_prologue.pop(self.device, None)
-            if not stats_on_side or pending is not None:  # (not taken by a fork: in line, as in an eagerly issued step)
-                lat = self.latents.flatten(1)  # [B, D] with transport_dims = (1, 2, 3)
-                self.latent_stats.update(target_samples=lat)
+        _PendingReduce.run_deferred_inline(self.device)  # (a pass without forks: nothing took the deferred work)
+        if self.latent_stats is not None and not on_side:
+            lat = self.latents.flatten(1)  # [B, D] with transport_dims = (1, 2, 3)
+            self.latent_stats.update(target_samples=lat)
         return self._logs
 
     def _batch(self):

@@ -188,7 +188,8 @@ class _PendingReduce:
     _side = {}
     _held = {}
     _wq = {}       # device -> [queued weight-gradient jobs, backward calls they came from]
-    _side_prologue = {}  # device -> callable run once on the side stream at the next fork (see issue)
+    _side_prologue = {}  # device -> callables run once on the side stream at the next fork (see issue)
+    _defer = {}          # device -> True while a training engine's captured forward pass runs: defer_to_side accepts work
     _forked = {}   # device -> the side stream has work of this backward pass
     _reduced = {}  # device -> leading entries of _state whose partials the side stream has already reduced
 
@@ -210,6 +211,22 @@ class _PendingReduce:
         q[1] += 1
         _PendingReduce._held.setdefault(device, []).extend(t for t in tensors if t is not None)
         return q[1] >= WGRAD_GROUP
+
+    @staticmethod
+    def defer_to_side(device, fn, *tensors) -> bool:
+        """Queues ``fn`` (launches on the then-current stream) for the side stream's next fork if a training engine allows it for this
+        step (``_defer``); ``tensors`` = everything it touches, held until the join.  False: the caller launches in line."""
+        if not _PendingReduce._defer.get(device):
+            return False
+        _PendingReduce._side_prologue.setdefault(device, []).append(fn)
+        _PendingReduce._held.setdefault(device, []).extend(t for t in tensors if t is not None)
+        return True
+
+    @staticmethod
+    def run_deferred_inline(device) -> None:
+        """what no fork has taken (a pass without weight-gradient forks) runs on the current stream"""
+        for pro in _PendingReduce._side_prologue.pop(device, None) or ():
+            pro()
 
     @staticmethod
     def fork_point(device):
@@ -279,13 +296,14 @@ class _PendingReduce:
             return
         side = _PendingReduce.side_stream(device)
         side.wait_event(ev)
-        pro = _PendingReduce._side_prologue.pop(device, None)
-        if pro is not None:
-            # work of the step that nothing on the launch stream waits for (the trainer's latent-statistics update): it rides on this
-            # fork, in front of the weight-gradient jobs -- no graph branch of its own (a lane of its own cost more than it took off
-            # the chain, engine/trainer.py)
+        pros = _PendingReduce._side_prologue.pop(device, None)
+        if pros:
+            # work of the step that nothing on the launch stream waits for (the loss VALUE, the trainer's latent-statistics update): it
+            # rides on this fork, in front of the weight-gradient jobs -- no graph branch of its own (a lane of its own cost more than
+            # it took off the chain, engine/trainer.py)
             with torch.cuda.stream(side):
-                pro()
+                for pro in pros:
+                    pro()
         n = len(q[0])
         arr = (_lib.ConvJob * n)(*q[0])
         check(_lib.load().otvae_conv_multi(n, arr, C.c_void_p(side.cuda_stream)), "otvae_conv_multi(backward, weights)")

@@ -256,11 +256,12 @@ def _nelbo_fwd(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor], chw: 
         # behind it -- the backward pass needs pred and target, not this value
         PriorLane.hold(pred.device, pred, target, prior_loss)
         with PriorLane.section(pred.device):
-            return _nelbo_fwd_launch(pred, target, prior_loss, chw)
+            return _nelbo_fwd_launch(pred, target, prior_loss, chw, allow_defer=False)  # (ordered behind the lane's work, not the side stream's)
     return _nelbo_fwd_launch(pred, target, prior_loss, chw)
 
 
-def _nelbo_fwd_launch(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor], chw: float):
+def _nelbo_fwd_launch(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor], chw: float, allow_defer: bool = True):
+    from .functional import _PendingReduce
     lib = _lib.load()
     numel = pred.numel()
     # the prior term is a mean over ITS entries: one per latent the prior saw = expansion * batch (model/vae.py:165-169), which is
@@ -270,8 +271,15 @@ def _nelbo_fwd_launch(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor]
         prior_loss = prior_loss.contiguous()
     ws = torch.empty(lib.otvae_nelbo_ws(), device=pred.device, dtype=torch.float64)
     out = torch.empty(3, device=pred.device, dtype=torch.float32)
-    check(lib.otvae_nelbo_fwd(ptr(pred), ptr(target), numel, ptr(prior_loss), n_prior, float(chw), ptr(ws), ptr(out), stream()),
-          "otvae_nelbo_fwd")
+
+    def launch():
+        check(lib.otvae_nelbo_fwd(ptr(pred), ptr(target), numel, ptr(prior_loss), n_prior, float(chw), ptr(ws), ptr(out), stream()),
+              "otvae_nelbo_fwd")
+
+    # inside a training engine's captured step the loss VALUE goes to the side stream with the backward pass's first weight-gradient
+    # fork: the backward pass needs pred and target, not this value (functional._PendingReduce.defer_to_side)
+    if not (allow_defer and _PendingReduce.defer_to_side(pred.device, launch, pred, target, prior_loss, ws, out)):
+        launch()
     return out
 
 
