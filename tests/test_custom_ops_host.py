@@ -57,3 +57,49 @@ def test_fake_implementations_give_the_kernels_shapes():
         assert torch.ops.otvae.sinkhorn_prior_backward(cost, None, zz, yy, pi, 1.0).shape == zz.shape
         loss, mu, q, vt = torch.ops.otvae.gaussian_w2_prior(zz, None, None, None, None, None, 1.0)
         assert loss.shape == (64,) and mu.shape == (1, 16) and q.shape == (16, 16) and q.dtype == torch.float64 and vt.shape == (1, 16, 16)
+
+
+def test_deferred_side_work_bookkeeping():
+    """``_PendingReduce.defer_to_side``: work is accepted only while a training engine has opened the window for the device, runs once
+    (in line when no fork took it), and an interrupted pass leaves nothing behind."""
+    from ot_vae_lightning_amd.functional import _PendingReduce as PR
+    dev = torch.device("cpu")
+    ran = []
+    assert PR.defer_to_side(dev, lambda: ran.append("no")) is False and not PR._side_prologue.get(dev)
+    PR._defer[dev] = True
+    t = torch.zeros(3)
+    try:
+        assert PR.defer_to_side(dev, lambda: ran.append("a"), t, None) is True
+        assert PR.defer_to_side(dev, lambda: ran.append("b")) is True
+    finally:
+        PR._defer[dev] = False
+    assert ran == [] and any(h is t for h in PR._held[dev])
+    PR.run_deferred_inline(dev)
+    assert ran == ["a", "b"]
+    PR.run_deferred_inline(dev)  # nothing is left
+    assert ran == ["a", "b"]
+    PR._defer[dev] = True
+    PR.defer_to_side(dev, lambda: ran.append("c"))
+    PR._defer[dev] = False
+    PR._held[dev].clear()
+    PR._side_prologue.pop(dev, None)
+    assert ran == ["a", "b"]
+
+
+def test_attention_stage_declines_what_it_cannot_fuse_without_touching_the_device():
+    """``functional.attention_stage`` answers None (the caller issues three launches) for CPU tensors, non-fp32 inputs, head counts that do
+    not divide the width and for 1x1 layers that are not plain, before it loads the HIP library."""
+    from ot_vae_lightning_amd import functional as HF
+    w_q, w_p = HF.new_hwio(24, 8, 1, 1), HF.new_hwio(8, 8, 1, 1)
+    plain = dict(stride=1, pad=0, up=1, relu=False, act=0, wscale=1.0, bscale=1.0)
+    qb, pb = dict(weight=w_q, **plain), dict(weight=w_p, **plain)
+    x = torch.zeros(2, 8, 4, 4)
+    assert HF.attention_stage(x, qb, 4, pb) is None                      # CPU tensor
+    assert HF.attention_stage(x.double(), qb, 4, pb) is None             # not fp32
+    assert HF._plain_1x1(qb, 24, 8) and HF._plain_1x1(pb, 8, 8)
+    assert not HF._plain_1x1(dict(qb, bias=torch.zeros(24)), 24, 8)      # bias
+    assert not HF._plain_1x1(dict(qb, relu=True), 24, 8)                 # activation in front
+    assert not HF._plain_1x1(dict(qb, wscale=0.5), 24, 8)                # equalized learning rate
+    assert not HF._plain_1x1(dict(qb, film=(x, x)), 24, 8)               # FiLM conditioning
+    assert not HF._plain_1x1(dict(qb, stride=2), 24, 8)
+    assert not HF._plain_1x1(qb, 16, 8)                                  # not 3 x width outputs
