@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void step_begin_guarded_kernel(int32_t* step, 
 
 extern "C" int otvae_step_begin_guarded(int32_t* step, const float* state, float* backup, int64_t n, void* stream) {
     OTVAE_REQUIRE(step && (n == 0 || (state && backup)) && n >= 0, "otvae_step_begin_guarded: bad argument");
-    step_begin_guarded_kernel<<<imax(1, imin(cdiv(n, 256), 64)), 256, 0, (hipStream_t)stream>>>(step, state, backup, n);
+    step_begin_guarded_kernel<<<imax(1, imin(cdiv(n, 1024), 1024)), 256, 0, (hipStream_t)stream>>>(step, state, backup, n);
     OTVAE_CHECK_LAUNCH("otvae_step_begin_guarded");
     return OTVAE_OK;
 }

@@ -17,13 +17,15 @@ statistics, RNG counters) advances inside the replayed graphs exactly as in the 
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
 from torch import Tensor
 
+from .lifetime import GraphSet, capture_guard
 from .segments import SEGMENT_CALLS, SegmentedStep
-from .trainer import HipTrainer
+from .trainer import HipTrainer, _dense_view
 
 __all__ = ["GraphedNelbo"]
 
@@ -34,7 +36,7 @@ class _Replay(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cap, *params):
-        cap.graph_f.replay()
+        cap.graph("f").replay()
         ctx.cap = cap
         ctx.set_materialize_grads(False)
         return cap.out3.detach()
@@ -45,13 +47,23 @@ class _Replay(torch.autograd.Function):
         if g is None:
             return (None,) * (1 + len(cap.params))
         cap.seed.copy_(g)
-        cap.graph_b.replay()
+        cap.graph("b").replay()
         # fresh view objects: autograd keeps ("steals") a gradient it holds the only reference to instead of cloning it
         return (None, *[p._otvae_grad_view() for p in cap.params])
 
 
 class _Capture:
-    __slots__ = ("key", "engine", "graph_f", "graph_b", "out3", "seed", "params", "artifacts", "logs_keys")
+    """One captured (forward graph "f", backward graph "b") pair and its static tensors.  The graphs live in a ``GraphSet``
+    (engine/lifetime.py): released by ``GraphedNelbo.close()`` / a re-capture, or by the finalizer when the last holder -- the
+    ``GraphedNelbo`` or an autograd node of a loss that is still alive -- lets go."""
+    __slots__ = ("key", "engine", "graphs", "out3", "seed", "params", "artifacts", "logs_keys", "__weakref__")
+
+    def graph(self, name: str):
+        g = self.graphs.get(name)
+        if g is None:
+            raise RuntimeError("this loss belongs to a captured step that has been released (GraphedNelbo.close() or a re-capture "
+                               "for another batch shape): call the model again")
+        return g
 
 
 class GraphedNelbo:
@@ -60,10 +72,33 @@ class GraphedNelbo:
     coefficient (a kernel argument that changes per step), a batch whose shapes differ from the captured ones (captured anew)."""
 
     def __init__(self, model, warmup: int = 2):
-        self.model = model
+        # the model holds this object (model.loss): a strong reference back -- or a bound method of the model -- would close a
+        # reference cycle and leave the captured graphs to the cyclic collector (engine/lifetime.py)
+        self._model_ref = weakref.ref(model)
         self.warmup = warmup
         self._cap: Optional[_Capture] = None
-        self._nelbo = model.nelbo  # the bound method, before anything re-points model.loss
+        nelbo = model.nelbo  # before anything re-points model.loss
+        self._nelbo_func = nelbo.__func__ if getattr(nelbo, "__self__", None) is model else None
+        self._nelbo_obj = None if self._nelbo_func is not None else nelbo
+
+    @property
+    def model(self):
+        m = self._model_ref()
+        if m is None:
+            raise ReferenceError("the model of this GraphedNelbo no longer exists")
+        return m
+
+    def _nelbo(self, batch, batch_idx):
+        if self._nelbo_func is not None:
+            return self._nelbo_func(self.model, batch, batch_idx)
+        return self._nelbo_obj(batch, batch_idx)
+
+    def close(self) -> None:
+        """Releases the captured graphs now (device synchronize, then destruction in reverse capture order).  The next training
+        call captures again."""
+        cap, self._cap = self._cap, None
+        if cap is not None:
+            cap.graphs.release()
 
     # ---- capture ---------------------------------------------------------------------------------------------
     @staticmethod
@@ -79,7 +114,7 @@ class GraphedNelbo:
         old = self._cap
         if old is not None:  # re-capture for a new batch shape: the parameters stay where the first engine put them
             engine = old.engine
-            old.graph_f = old.graph_b = None
+            old.graphs.release()   # waits for the device: replays of the old graphs may still be in flight
             if tuple(engine.x.shape) != tuple(samples.shape):
                 engine.x = torch.zeros_like(samples)
                 engine.eps = torch.zeros((samples.shape[0] * max(1, int(getattr(model, "expansion", 1) or 1)), *model.latent_size),
@@ -87,11 +122,14 @@ class GraphedNelbo:
         else:
             # the engine's layout (flat parameter / gradient buffers, gradient slots, resident transposed weights, static batch);
             # its optimizer is never run
-            engine = HipTrainer(model, batch_shape=tuple(samples.shape), use_graph=False, data_parallel=False, step_guard=None)
+            engine = HipTrainer(model, batch_shape=tuple(samples.shape), use_graph=False, data_parallel=False, step_guard=None,
+                                weak_model=True)
         engine.batch_kwargs = {k: v.detach().clone() for k, v in kwargs.items() if isinstance(v, Tensor) and k != "eps"}
         engine._rng_key = None
         cap = _Capture()
         cap.key, cap.engine = self._key(batch), engine
+        cap.graphs = GraphSet(engine.device)
+        weakref.finalize(cap, GraphSet.release, cap.graphs)
         cap.params = engine.params
         cap.seed = torch.tensor([1.0, 0.0, 0.0], device=engine.device)
         engine._seed = cap.seed
@@ -130,26 +168,27 @@ class GraphedNelbo:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         mode = dict(capture_error_mode=os.environ.get("OTVAE_CAPTURE_ERROR_MODE", "thread_local"))
-        cap.graph_f = torch.cuda.CUDAGraph()
         cstream = torch.cuda.Stream(device=engine.device)   # ONE capture stream for the forward and the backward graphs (segments.py)
-        with torch.cuda.graph(cap.graph_f, stream=cstream, **mode):
-            loss, logs, art = forward()
-            cap.out3 = model._last_nelbo
-        if SEGMENT_CALLS > 0 and HF.WGRAD_SIDE_STREAM == 1:
-            # the backward pass as a chain of linear graphs + side graphs (engine/segments.py): ~0.1 ms of host time per replay
-            # instead of ~0.8 ms for one graph with a fork per layer, which matters on this host-bound route
-            cap.graph_b = SegmentedStep(engine.device, HF._PendingReduce.side_stream(engine.device), pool=cap.graph_f.pool(),
-                                        stream=cstream)
-            HF._PendingReduce.begin_segments(engine.device, cap.graph_b)
-            try:
-                with cap.graph_b:
+        with capture_guard():
+            with torch.cuda.graph(cap.graphs.new("f"), stream=cstream, **mode):
+                loss, logs, art = forward()
+                cap.out3 = model._last_nelbo
+            pool = cap.graphs.get("f").pool()
+            if SEGMENT_CALLS > 0 and HF.WGRAD_SIDE_STREAM == 1:
+                # the backward pass as a chain of linear graphs + side graphs (engine/segments.py): ~0.1 ms of host time per replay
+                # instead of ~0.8 ms for one graph with a fork per layer, which matters on this host-bound route
+                seg = SegmentedStep(engine.device, HF._PendingReduce.side_stream(engine.device), pool=pool, stream=cstream)
+                cap.graphs.put("b", seg)
+                HF._PendingReduce.begin_segments(engine.device, seg)
+                try:
+                    with seg:
+                        backward(loss)
+                finally:
+                    HF._PendingReduce.end_segments(engine.device)
+                del seg
+            else:
+                with torch.cuda.graph(cap.graphs.new("b"), pool=pool, stream=cstream, **mode):
                     backward(loss)
-            finally:
-                HF._PendingReduce.end_segments(engine.device)
-        else:
-            cap.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cap.graph_b, pool=cap.graph_f.pool(), stream=cstream, **mode):
-                backward(loss)
         cap.out3 = cap.out3.detach()
         # tensors only (preds, latents, preds_mean ...): a prior's lazily built distribution objects could hold the captured pass's
         # autograd graph -- and with it AccumulateGrad nodes bound to the capture stream -- alive for good
@@ -174,12 +213,17 @@ class GraphedNelbo:
         if self._cap is None or self._cap.key != self._key(batch):
             self._cap = self._capture(batch)
         cap, eng = self._cap, self._cap.engine
-        for p in cap.params:
+        # A gradient that IS its slot of the flat buffer (autograd kept the view the last backward returned) would be overwritten by
+        # this step's backward graph and then added to itself.  It is either stale zeros (zero_grad(set_to_none=False)) or the sum
+        # of earlier micro-batches (gradient accumulation, Lightning's accumulate_grad_batches > 1): move ALL such gradients out
+        # of the buffer with one copy, as views of the copy -- autograd then accumulates this step's slots onto them.
+        acc = None
+        for p, off in zip(cap.params, eng.offsets):
             g = p.grad
             if g is not None and g.data_ptr() == p._otvae_grad_view().data_ptr():
-                # zero_grad(set_to_none=False) left the slot view in place: the backward graph will overwrite the slot and autograd
-                # would then add the slot to itself
-                p.grad = None
+                if acc is None:
+                    acc = eng.gflat.clone()
+                p.grad = _dense_view(acc, off, p.data)
         eng.x.copy_(samples, non_blocking=True)
         if batch["target"] is not samples:
             raise ValueError("GraphedNelbo replays VAE.nelbo with target = samples (what batch_preprocess builds)")

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -29,6 +30,7 @@ from .._lib import check, ptr, stream
 from .. import functional as HF
 from ..networks.cnn import ConvLayer
 from .dp import FlatGradReducer
+from .lifetime import GraphSet, capture_guard
 from .segments import SEGMENT_CALLS, SegmentedStep
 
 # OTVAE_STATS_SIDE=0 (A/B switch): the loss value and the latent-statistics update of a captured step stay on the launch stream
@@ -74,9 +76,12 @@ class HipTrainer:
     def __init__(self, model, batch_shape, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, use_graph: bool = True, latent_stats=None, dp_overlap: Optional[bool] = None,
                  batch_kwargs: Optional[Dict[str, Tensor]] = None, gradient_clip_val: Optional[float] = None,
-                 data_parallel: bool = True, step_guard: Optional[str] = "auto"):
+                 data_parallel: bool = True, step_guard: Optional[str] = "auto", weak_model: bool = False):
         self.lib = _lib.load()
-        self.model = model
+        # weak_model: the engine is owned BY the model (GraphedNelbo sits in model.loss): a strong reference back would close a
+        # cycle model -> loss -> capture -> engine -> model and leave the captured graphs to the cyclic collector (lifetime.py)
+        self._model_ref = weakref.ref(model)
+        self._model_strong = None if weak_model else model
         self.params = list(model.optim_parameters())
         if not self.params:
             raise ValueError("model has no trainable parameters")
@@ -105,23 +110,9 @@ class HipTrainer:
         #   None:   unguarded (round-2 behaviour).  "auto" = "loss" on one rank, "full" on several.
         self._guard_arg = step_guard
         self.guard = torch.zeros(2, device=dev, dtype=torch.int32)  # {skipped steps, step number of the last skip}
-        # every floating-point running buffer of the model (BatchNorm running_mean / running_var) as a view of ONE flat range, so
-        # that a guarded step can keep a copy from its start and a refused step can put it back (csrc/loss_optim.hip: a NaN does
-        # not survive the next ReLU, later layers would average garbage into their buffers)
+        # EVERYTHING a step mutates besides what the optimizer owns lives in ONE flat range of 4-byte words (`_rebase_step_state`,
+        # called at the end of this constructor): a guarded step keeps a copy from its start and a refused step puts it back
         self.rflat = self.rbackup = None
-        if step_guard is not None:
-            bufs = [b for n_, b in model.named_buffers() if b.dtype == torch.float32 and ("running_mean" in n_ or "running_var" in n_)]
-            if bufs:
-                total = sum((b.numel() + 3) // 4 * 4 for b in bufs)
-                self.rflat = torch.zeros(total, device=dev, dtype=torch.float32)
-                off = 0
-                with torch.no_grad():
-                    for b in bufs:
-                        v = self.rflat[off: off + b.numel()].view(b.shape)
-                        v.copy_(b)
-                        b.data = v
-                        off += (b.numel() + 3) // 4 * 4
-                self.rbackup = torch.empty_like(self.rflat)
         # a FRESH tensor object per call (autograd steals a gradient it holds the only reference to and clones it otherwise),
         # made from a slot view built once: detach() is one shallow copy instead of slice + view + permute
         for p, off in zip(self.params, self.offsets):
@@ -163,7 +154,6 @@ class HipTrainer:
             dp_overlap = self.world > 1 and os.environ.get("OTVAE_DP_OVERLAP", "1") != "0"
         self._dec_range = self._decoder_range() if dp_overlap else None
         self.dp_overlap = self._dec_range is not None
-        self._graph_b2 = None
         # static I/O
         self.x = torch.zeros(batch_shape, device=dev, dtype=torch.float32)
         # one noise draw per latent the prior sees: `expansion` replicas of every image (VAE(expansion=n), model/vae.py:158-167)
@@ -187,11 +177,72 @@ class HipTrainer:
         self.out: Optional[Tensor] = None
         self.latents: Optional[Tensor] = None
         self.use_graph = use_graph
-        self._graph_fb = None
-        self._graph_opt = None
-        self._segments: Optional[SegmentedStep] = None
+        # the captured step's hipGraphs: "fb" (forward + backward [+ Adam]), "b2" (the encoder's backward, data-parallel overlap),
+        # "opt" (Adam behind the all-reduce), or "segments" (a SegmentedStep).  The GraphSet is their ONLY strong owner; an engine
+        # dropped without close() releases them through the same ordered path (engine/lifetime.py)
+        self._gs = GraphSet(dev)
+        self._finalizer = weakref.finalize(self, GraphSet.release, self._gs)
         self._captured = False
         self.n_steps = 0
+        if self.step_guard is not None:
+            self._rebase_step_state()
+
+    def _step_state_tensors(self) -> List[Tensor]:
+        """Every tensor OBJECT (buffer, parameter outside the flat buffer, RNG key ...) whose storage a training step writes besides
+        parameters / moments / gradients: all buffers of the model (BatchNorm running statistics and counters, the EMA embeddings of
+        a ConditionalGaussianPrior, GaussianW2Prior's warm-start flag), parameters the optimizer does not own (frozen ones an EMA
+        rewrites), the dropout key counters, the running statistics of the latent operator, and what modules declare through
+        ``_otvae_step_state(latent_shape, device)`` (state that is not a registered buffer: GaussianW2Prior's warm-start basis)."""
+        model = self.model
+        flat_ids = {id(p) for p in self.params}
+        ts: List[Tensor] = [b for b in model.buffers()]
+        ts += [p for p in model.parameters() if id(p) not in flat_ids]
+        for mod in model.modules():
+            key = mod.__dict__.get("_dropout_key")
+            if isinstance(key, Tensor):
+                ts.append(key)
+            decl = getattr(mod, "_otvae_step_state", None)
+            if decl is not None:
+                ts += list(decl(tuple(self.eps.shape), self.device))
+        if self.latent_stats is not None:
+            ts += [b for b in self.latent_stats.buffers()] + [p for p in self.latent_stats.parameters()]
+        seen, out = set(), []
+        for t in ts:
+            if t is None or id(t) in seen or t.numel() == 0 or t.device != self.device or not t.is_contiguous():
+                continue
+            seen.add(id(t))
+            out.append(t)
+        return out
+
+    def _rebase_step_state(self) -> None:
+        """Moves the storage of every tensor of ``_step_state_tensors`` into one flat byte range (16-byte aligned slots, any dtype:
+        the guard kernels copy 4-byte words bit for bit), ``rflat``; ``rbackup`` holds the copy a guarded step takes at its start."""
+        ts = self._step_state_tensors()
+        if not ts:
+            return
+        offs, total = [], 0
+        for t in ts:
+            offs.append(total)
+            total += (t.numel() * t.element_size() + 15) // 16 * 16
+        flat = torch.zeros(total, device=self.device, dtype=torch.uint8)
+        with torch.no_grad():
+            for t, off in zip(ts, offs):
+                v = flat[off: off + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+                v.copy_(t.data)
+                t.data = v
+        self.rflat = flat.view(torch.float32)
+        self.rbackup = torch.empty_like(self.rflat)
+
+    @property
+    def model(self):
+        m = self._model_ref()
+        if m is None:
+            raise ReferenceError("the model of this engine no longer exists")
+        return m
+
+    @property
+    def _segments(self) -> Optional[SegmentedStep]:
+        return self._gs.get("segments")
 
     # -- pieces of a step ----------------------------------------------------------------------------------------
     def _refresh_wd(self):
@@ -216,7 +267,7 @@ class HipTrainer:
         self._step_begin()
         for p in self.params:
             p.grad = None
-        from ..functional import PriorLane
+        from ..functional import PriorLane, _PendingReduce
         PriorLane.enabled = True  # the prior's OT work may run beside the decoder: this method joins it (functional.PriorLane)
         # (Round 3 tried to put the step's small off-chain launches -- the refresh of the transposed weights, the loss vector, the
         # latent statistics -- on the same lane: 2.80 -> 2.86 ms at batch 1024, the extra graph branches cost more than the ~40 us
@@ -235,11 +286,16 @@ class HipTrainer:
                 _PR._defer[self.device] = False
             self.latents = art["latents"].detach()
             if on_side and self.latent_stats is not None:
-                lat_ = self.latents.flatten(1)
+                lat_, stats_ = self.latents.flatten(1), self.latent_stats
                 _PR._defer[self.device] = True
-                _PR.defer_to_side(self.device, lambda: self.latent_stats.update(target_samples=lat_), lat_)
+                _PR.defer_to_side(self.device, lambda: stats_.update(target_samples=lat_), lat_)
                 _PR._defer[self.device] = False
             self._backward(loss)
+        except BaseException:
+            # a pass that raised (in the forward pass as well: the deferred loss / statistics launches are queued there) must leave
+            # nothing behind for the next step's first fork to run against this step's tensors
+            _PendingReduce.reset(self.device)
+            raise
         finally:
             PriorLane.enabled = False
             PriorLane.join(self.device)  # (already joined by the prior's backward when it took part in the pass)
@@ -248,7 +304,6 @@ class HipTrainer:
         # warm-up stream into the capture: "AccumulateGrad node's stream does not match ...")
         if hasattr(self.model, "_last_cut"):
             self.model._last_cut = None
-        from ..functional import _PendingReduce
         _PendingReduce.flush(self.device)  # normally already done by the autograd-engine callback at the end of backward
         self._collect_loose_grads()
         self._logs = {k: v.detach() for k, v in logs.items()}  # no reference into the autograd graph survives the step
@@ -448,46 +503,49 @@ class HipTrainer:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self._graph_fb = torch.cuda.CUDAGraph()
         # "thread_local": only this thread's calls are policed while the stream captures.  Under the default ("global")
         # an event query from another thread -- the RCCL watchdog polling the collectives of earlier steps -- is an
         # illegal call that kills the capture, and the process with it, whenever the poll happens to land inside it
         mode = dict(capture_error_mode=os.environ.get("OTVAE_CAPTURE_ERROR_MODE", "thread_local"))
-        if self.dp_overlap:
-            with torch.cuda.graph(self._graph_fb, **mode):
-                logs = self._phase1()
-                self._out_static = self._loss_vector(logs)
-            self._graph_b2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_b2, pool=self._graph_fb.pool(), **mode):  # the cut tensors live in graph 1's pool
-                self._phase2()
-            self._graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_opt, pool=self._graph_fb.pool(), **mode):
-                self._adam()
-        elif self.world == 1 and not self.reducer.active and SEGMENT_CALLS > 0 and HF.WGRAD_SIDE_STREAM == 1:
-            # a chain of linear graphs + side graphs instead of one graph with a fork per layer (engine/segments.py)
-            self._graph_fb = None
-            side = HF._PendingReduce.side_stream(self.device)
-            self._segments = SegmentedStep(self.device, side)
-            HF._PendingReduce.begin_segments(self.device, self._segments, may_cut=lambda: not HF.PriorLane.is_open(self.device))
-            try:
-                with self._segments:
-                    logs = self._forward_backward()   # its backward pass cuts the graph and ends with a joining cut
+        gs = self._gs
+        # capture_guard: graphs parked by engines that died inside an earlier capture are destroyed first, and the cyclic collector
+        # stays off until the capture ends (a graph destroyed inside an open capture aborts the process: engine/lifetime.py)
+        with capture_guard():
+            if self.dp_overlap:
+                with torch.cuda.graph(gs.new("fb"), **mode):
+                    logs = self._phase1()
+                    self._out_static = self._loss_vector(logs)
+                pool = gs.get("fb").pool()
+                with torch.cuda.graph(gs.new("b2"), pool=pool, **mode):  # the cut tensors live in graph 1's pool
+                    self._phase2()
+                with torch.cuda.graph(gs.new("opt"), pool=pool, **mode):
+                    self._adam()
+            elif self.world == 1 and not self.reducer.active and SEGMENT_CALLS > 0 and HF.WGRAD_SIDE_STREAM == 1:
+                # a chain of linear graphs + side graphs instead of one graph with a fork per layer (engine/segments.py)
+                side = HF._PendingReduce.side_stream(self.device)
+                seg = SegmentedStep(self.device, side)
+                gs.put("segments", seg)
+                dev_ = self.device
+                HF._PendingReduce.begin_segments(dev_, seg, may_cut=lambda: not HF.PriorLane.is_open(dev_))
+                try:
+                    with seg:
+                        logs = self._forward_backward()   # its backward pass cuts the graph and ends with a joining cut
+                        self._adam()
+                        self._out_static = self._loss_vector(logs)
+                finally:
+                    HF._PendingReduce.end_segments(dev_)
+                del seg
+            elif self.world == 1 and not self.reducer.active:
+                with torch.cuda.graph(gs.new("fb"), **mode):
+                    logs = self._forward_backward()
                     self._adam()
                     self._out_static = self._loss_vector(logs)
-            finally:
-                HF._PendingReduce.end_segments(self.device)
-        elif self.world == 1 and not self.reducer.active:
-            with torch.cuda.graph(self._graph_fb, **mode):
-                logs = self._forward_backward()
-                self._adam()
-                self._out_static = self._loss_vector(logs)
-        else:
-            with torch.cuda.graph(self._graph_fb, **mode):
-                logs = self._forward_backward()
-                self._out_static = self._loss_vector(logs)
-            self._graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_opt, **mode):
-                self._adam()
+            else:
+                with torch.cuda.graph(gs.new("fb"), **mode):
+                    logs = self._forward_backward()
+                    self._out_static = self._loss_vector(logs)
+                with torch.cuda.graph(gs.new("opt"), **mode):
+                    self._adam()
         # the warm-up/capture must not count as training: restore parameters, moments, step and BN buffers
         with torch.no_grad():
             self.pflat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self.step_count.copy_(snap[3])
@@ -531,18 +589,16 @@ class HipTrainer:
         if self.use_graph and not annealing:  # the annealing coefficient is a kernel argument: not replayable
             if not self._captured:
                 self.capture()
-            if self._segments is not None:
-                self._segments.replay()
-            else:
-                self._graph_fb.replay()
+            gs = self._gs
+            (gs.get("segments") or gs.get("fb")).replay()
             if self.dp_overlap:
                 self.reducer.allreduce_range(*self._dec_range, wait=False)  # side stream, under the encoder's backward
-                self._graph_b2.replay()
+                gs.get("b2").replay()
                 self._allreduce_split_tail()
-                self._graph_opt.replay()
-            elif self._graph_opt is not None:
+                gs.get("opt").replay()
+            elif gs.get("opt") is not None:
                 self._allreduce()
-                self._graph_opt.replay()
+                gs.get("opt").replay()
             out = self._out_static
         else:
             logs = self._eager_step()
@@ -555,33 +611,27 @@ class HipTrainer:
         return out
 
     def close(self) -> None:
-        """Releases what the step holds on the device in the order a communicator teardown needs: wait for the
-        reducer's stream and the device, drop the captured graphs (their private pool and the kernels' baked-in
-        addresses), drop the cut tensors.  After ``close()`` the process group may be destroyed; the trainer must not be
-        stepped again.  (the abort seen in round 1 was the RCCL watchdog's event poll landing inside
-        a global-mode stream capture, not the teardown order; this method exists so that callers need not rely on that.)"""
+        """Releases what the step holds on the device, in a stated order: wait for the reducer's stream, then
+        ``GraphSet.release`` (device synchronize, graphs destroyed in reverse capture order -- or parked, should this be called
+        while a capture is open), then the step's static tensors (they live in the graphs' private pool, which goes back to the
+        allocator with the last of them).  After ``close()`` the process group may be destroyed; the trainer must not be stepped
+        again.  An engine that is dropped WITHOUT ``close()`` takes the same path through its finalizer (engine/lifetime.py says
+        why the order matters: a graph destroyed while a capture is open aborts the process)."""
         if self.reducer.stream is not None:
             self.reducer.stream.synchronize()
-        torch.cuda.synchronize(self.device)
-        self._graph_fb = self._graph_b2 = self._graph_opt = None
-        if self._segments is not None:
-            self._segments.release()
-            self._segments = None
+        self._gs.release()
         self._out_static = None
         self._cut = None
         self._logs = None
         self.latents = None
-        if hasattr(self.model, "_last_cut"):
-            self.model._last_cut = None
-            self.model._last_nelbo = None
+        self._watch = None
+        model = self._model_ref()
+        if model is not None and hasattr(model, "_last_cut"):
+            model._last_cut = None
+            model._last_nelbo = None
         self._captured = False
         self.use_graph = False
-        # graphs, side streams and events of the step sit in reference cycles (closures of the capture): collect them HERE, with the device
-        # idle, rather than at whatever allocation of the caller's next code the collector happens to run
-        import gc
-        gc.collect()
-        torch.cuda.synchronize(self.device)
-        check_solver = getattr(getattr(self.model, "prior", None), "raise_if_starved", None)
+        check_solver = getattr(getattr(model, "prior", None), "raise_if_starved", None)
         if check_solver is not None:
             check_solver()
 

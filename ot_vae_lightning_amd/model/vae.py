@@ -81,7 +81,17 @@ class VAE(VisionModule):
         ``training_step`` calls, model/base.py:122-129) becomes an ``engine.GraphedNelbo`` over ``self.nelbo`` -- one autograd node
         that replays a captured forward graph and, in ``backward``, a captured backward graph; gradients land in ``p.grad``."""
         from ..engine.graphed import GraphedNelbo
+        self.disable_graphed_step()
         self.loss = GraphedNelbo(self, warmup=warmup)
+        return self
+
+    def disable_graphed_step(self) -> "VAE":
+        """Back to the eagerly issued ``nelbo``; the captured graphs are released now (``GraphedNelbo.close``).  Not required before
+        dropping the model: a model that simply goes out of scope releases them the same way (engine/lifetime.py)."""
+        cur = self.__dict__.get("loss")
+        if cur is not None and hasattr(cur, "close"):
+            cur.close()
+            self.loss = self.nelbo
         return self
 
     def recon_loss(self, reconstructions: Tensor, target: Tensor, **kwargs) -> Tensor:

@@ -85,6 +85,19 @@ class GaussianW2Prior(Prior):
     def out_size(self, size):
         return size
 
+    def _otvae_step_state(self, latent_shape, device):
+        """(engine.HipTrainer's step guard) the warm-start basis is state a training step rewrites without being a registered buffer:
+        allocated here, before the first step, so that a refused step can put the previous basis back together with `_warm`"""
+        d = 1
+        for n_ in latent_shape[1:]:
+            d *= int(n_)
+        if d > 128:
+            return []
+        if self._v_prev is None or self._v_prev.shape[-1] != d or self._v_prev.device != device:
+            self._v_prev = torch.zeros((1, d, d), device=device, dtype=torch.float64)
+            self._warm.zero_()
+        return [self._v_prev]
+
     def sample(self, shape, device) -> Tensor:
         x = torch.randn(*shape, device=device)
         if self.target_cov is None and self.target_mean is None:

@@ -42,16 +42,3 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
 @pytest.fixture(scope="session")
 def has_gpu():
     return torch.cuda.is_available()
-
-
-@pytest.fixture(autouse=True)
-def _release_device_state(request):
-    """GPU tests build trainers, captured graphs, side streams and events; what one test leaves to the garbage collector would
-    otherwise be destroyed at an arbitrary allocation inside a later test (possibly while that test is capturing a graph).  Collect
-    at the test boundary, with the device idle."""
-    yield
-    if request.node.get_closest_marker("gpu") is not None and torch.cuda.is_available():
-        import gc
-        torch.cuda.synchronize()
-        gc.collect()
-        torch.cuda.synchronize()

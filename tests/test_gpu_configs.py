@@ -1223,6 +1223,50 @@ def test_step_guard_skips_a_bad_step_and_leaves_no_trace(A, mode):
         t.close()
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_step_guard_covers_latent_statistics_and_the_w2_prior_warm_start(A, graph):
+    """a refused step must leave no trace in ANYTHING a step mutates -- the running sums of the latent operator
+    (``HipTrainer(latent_stats=...)``: n, sum x, sum x x^T in fp64), GaussianW2Prior's warm-start basis and flag, BatchNorm's counters.
+    Trainer A sees [good, good, NaN batch, good], trainer B the three good batches: everything bit-identical afterwards."""
+    B = 192
+    xs = [mnist_like(B, 171 + i).cuda() for i in range(3)]
+    bad = xs[0].clone()
+    bad[5, 0, 9, 9] = float("nan")
+
+    def make():
+        torch.manual_seed(8)
+        enc = A.CNN(1, 64, 32, 1, capacity=8, down_sample=True, residual="add")
+        dec = A.CNN(64, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+        model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianW2Prior(loss_coeff=0.1)).cuda().train()
+        op = A.GaussianTransport(64, source_cfg=dict(dtype=torch.double, reduce_on_update=False),
+                                 target_cfg=dict(dtype=torch.double, reduce_on_update=False)).cuda()
+        return A.HipTrainer(model, batch_shape=(B, 1, 32, 32), use_graph=graph, latent_stats=op), op
+
+    (ta, opa), (tb, opb) = make(), make()
+    ta.step(xs[0]); ta.step(xs[1])
+    out_bad = ta.step(bad).clone()
+    ta.step(xs[2])
+    for x in xs:
+        tb.step(x)
+    torch.cuda.synchronize()
+    assert torch.isnan(out_bad[0]) and ta.skipped_steps == 1 and tb.skipped_steps == 0
+    assert int(ta.step_count) == int(tb.step_count) == 3
+    for name in ("pflat", "m", "v"):
+        assert torch.equal(getattr(ta, name), getattr(tb, name)), name
+    for (ka, va), (kb, vb) in zip(ta.model.state_dict().items(), tb.model.state_dict().items()):
+        assert torch.equal(va, vb), ka                       # incl. num_batches_tracked now
+    pa, pb = ta.model.prior, tb.model.prior
+    assert int(pa._warm) == int(pb._warm) == 1 and torch.equal(pa._v_prev, pb._v_prev) and torch.isfinite(pa._v_prev).all()
+    sa, sb = dict(opa.named_buffers()), dict(opb.named_buffers())
+    assert sa.keys() == sb.keys() and any("_running_sum_cov" in k for k in sa)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+        assert torch.isfinite(sa[k].double()).all(), k
+    n_obs = [v for k, v in sa.items() if k.endswith("target_model._n_obs")][0]
+    assert float(n_obs.sum()) == 3 * B
+    ta.close(); tb.close()
+
+
 def test_step_guard_survives_a_starved_sinkhorn_solve_in_a_captured_step(A, monkeypatch):
     """The persistent Sinkhorn solver's workgroups wait for each other; starved (poll budget 0, baked into the captured step)
     every replay ends in NaN-poisoned plan / loss: the guarded Adam must leave the parameters untouched and count the steps."""
