@@ -428,6 +428,19 @@ int64_t otvae_sinkhorn_ws(int dtype, int nb, int N, int M);
 int otvae_sinkhorn_log(int dtype, const void* a, const void* b, const void* C, int nb, int N, int M,
                        double reg, int max_iter, double threshold, void* ws,
                        void* pi, void* u, void* v, int32_t* iters_done, void* stream);
+/* The reference's sinkhorn_log is plain torch arithmetic: autograd differentiates it through every iteration with respect to
+ * a, b and C (ot/w2_utils.py:301-319).  These two entry points are that derivative.  otvae_sinkhorn_log_tape: the same solve (one
+ * launch per half-iteration, identical arithmetic and stopping rule) that also keeps what the reverse sweep needs in `tape`
+ * (otvae_sinkhorn_tape_bytes: Cr, Cr^T, log marginals, the potentials of every iteration, the iteration count).
+ * otvae_sinkhorn_log_bwd: gpi[nb][N][M] = dL/dpi -> gC[nb][N][M], ga[nb][N], gb[nb][M] (each may be NULL; ga / gb need a / b),
+ * ws: otvae_sinkhorn_bwd_ws bytes.  The iteration count the forward stopped at is read on the device (no host sync). */
+int64_t otvae_sinkhorn_tape_bytes(int dtype, int nb, int N, int M, int max_iter);
+int64_t otvae_sinkhorn_bwd_ws(int dtype, int nb, int N, int M, int max_iter);
+int otvae_sinkhorn_log_tape(int dtype, const void* a, const void* b, const void* C, int nb, int N, int M, double reg,
+                            int max_iter, double threshold, void* tape, void* pi, void* u, void* v, int32_t* iters_done,
+                            void* stream);
+int otvae_sinkhorn_log_bwd(int dtype, const void* gpi, const void* pi, const void* a, const void* b, int nb, int N, int M,
+                           double reg, int max_iter, void* tape, void* ws, void* gC, void* ga, void* gb, void* stream);
 /* The same solve on C / max(C) per problem, the `cost_matrix / max_per_mat` of batch_ot_gmm (ot/w2_utils.py:265-266), without
  * a pass that finds the maximum or divides: pmax[nb][P] are partial maxima of each problem's C (otvae_sqdist_max leaves them),
  * reduced inside the solver's first kernel; cmax[nb] (may be NULL) receives the maxima.  a / b may be NULL in both entry points:

@@ -549,6 +549,81 @@ def gen_sinkhorn():
     save("sinkhorn.npz", out)
 
 
+def gen_sinkhorn_autograd():
+    """The reference's ``sinkhorn_log`` is plain torch arithmetic: autograd runs through all of its iterations
+    (ot/w2_utils.py:301-319).  Recorded here from the REAL function: (i) gradients of a weighted sum of the plan with respect to
+    a, b and C (incl. a batched problem that leaves the loop early), (ii) the composition a minibatch-OT loss makes of it --
+    C = |z_i - y_j|^2, Cn = C / max C, pi = sinkhorn_log(1/N, 1/M, Cn, 0.05, 50, 0), loss = sum(C * pi) (batch_ot_gmm's read-out,
+    :265-269) and loss_n = sum(Cn * pi) -- with dloss/dz, next to the gradient the envelope convention (plan detached) gives."""
+    w2 = R.ref("ot.w2_utils")
+    out = {}
+
+    def problem(lead, n, m, dtype, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(*lead, n, 5, generator=g, dtype=torch.float64)
+        y = torch.randn(*lead, m, 5, generator=g, dtype=torch.float64) * 1.2 + 0.3
+        C = ((x.unsqueeze(-2) - y.unsqueeze(-3)) ** 2).sum(-1)
+        C = C / C.amax(dim=(-2, -1), keepdim=True)
+        a = torch.rand(*lead, n, generator=g, dtype=torch.float64) + 0.1
+        b = torch.rand(*lead, m, generator=g, dtype=torch.float64) + 0.1
+        a, b = a / a.sum(-1, keepdim=True), b / b.sum(-1, keepdim=True)
+        W = torch.randn(*lead, n, m, generator=g, dtype=torch.float64)
+        return a.to(dtype), b.to(dtype), C.to(dtype), W.to(dtype)
+
+    direct = [
+        ("n7_f64", (), 7, 7, torch.float64, 0.05, 50, 0.0),
+        ("n7x9_f32", (), 7, 9, torch.float32, 0.05, 50, 0.0),
+        ("n64_f32", (), 64, 64, torch.float32, 0.05, 50, 0.0),
+        ("n64_f64", (), 64, 64, torch.float64, 0.05, 50, 0.0),
+        ("n48x80_f64_reg01", (), 48, 80, torch.float64, 0.1, 30, 0.0),
+        ("batch23_f64_thr", (2, 3), 16, 24, torch.float64, 0.05, 300, 1e-5),
+        ("n256_f32", (), 256, 256, torch.float32, 0.05, 50, 0.0),
+        ("n256_f64", (), 256, 256, torch.float64, 0.05, 50, 0.0),
+    ]
+    for i, (name, lead, n, m, dt, reg, it, thr) in enumerate(direct):
+        a, b, C, W = problem(lead, n, m, dt, 700 + i)
+        a.requires_grad_(True), b.requires_grad_(True), C.requires_grad_(True)
+        pi = w2.sinkhorn_log(a, b, C, reg=reg, max_iter=it, threshold=thr)
+        (pi * W).sum().backward()
+        k = f"direct/{name}"
+        out[f"{k}/cfg"] = np.array([reg, it, thr], dtype=np.float64)
+        out[f"{k}/seed"] = np.array([700 + i, n, m])   # inputs = problem(lead, n, m, dtype, seed) (tests/test_gpu_sinkhorn_autograd.py)
+        keep = (("a", a), ("b", b), ("C", C), ("W", W), ("pi", pi)) if n <= 64 else (("pi_corner", pi[..., :8, :8]),)
+        for nm, t in keep + (("ga", a.grad), ("gb", b.grad), ("gC", C.grad)):
+            out[f"{k}/{nm}"] = npy(t)
+
+    for i, (n, m, d, dt) in enumerate(((7, 7, 3, torch.float64), (7, 7, 3, torch.float32), (64, 64, 16, torch.float64),
+                                       (64, 64, 16, torch.float32), (256, 256, 32, torch.float64), (256, 256, 32, torch.float32))):
+        g = torch.Generator().manual_seed(800 + i)
+        z0 = (torch.randn(n, d, generator=g, dtype=torch.float64) * 1.3 + 0.2).to(dt)
+        y = torch.randn(m, d, generator=g, dtype=torch.float64).to(dt)
+        a, b = torch.full((n,), 1.0 / n, dtype=dt), torch.full((m,), 1.0 / m, dtype=dt)
+        k = f"prior/n{n}_{'f64' if dt == torch.float64 else 'f32'}"
+        res = {}
+        for mode in ("full", "envelope"):
+            z = z0.clone().requires_grad_(True)
+            C = (z ** 2).sum(-1, keepdim=True) + (y ** 2).sum(-1).unsqueeze(-2) - 2 * (z @ y.T)
+            Cn = C / C.max()
+            if mode == "full":
+                pi = w2.sinkhorn_log(a, b, Cn, reg=0.05, max_iter=50, threshold=0.0)
+            else:
+                with torch.no_grad():
+                    pi = w2.sinkhorn_log(a, b, Cn, reg=0.05, max_iter=50, threshold=0.0)
+            loss = (C * pi).sum()
+            loss.backward()
+            res[mode] = (loss.detach(), z.grad.clone())
+        z = z0.clone().requires_grad_(True)
+        C = (z ** 2).sum(-1, keepdim=True) + (y ** 2).sum(-1).unsqueeze(-2) - 2 * (z @ y.T)
+        Cn = C / C.max()
+        pi = w2.sinkhorn_log(a, b, Cn, reg=0.05, max_iter=50, threshold=0.0)
+        loss_n = (Cn * pi).sum()
+        loss_n.backward()
+        out[f"{k}/z"], out[f"{k}/y"] = npy(z0), npy(y)
+        out[f"{k}/loss"], out[f"{k}/gz_full"], out[f"{k}/gz_envelope"] = npy(res["full"][0]), npy(res["full"][1]), npy(res["envelope"][1])
+        out[f"{k}/loss_n"], out[f"{k}/gz_n"] = npy(loss_n), npy(z.grad)
+    save("sinkhorn_autograd.npz", out)
+
+
 # ------------------------------------------------------------------------------------------------ G7
 def gen_gaussian_ot():
     mu_ = R.ref("ot.matrix_utils")
@@ -1922,6 +1997,6 @@ def gen_w2_prior():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["convlayer", "attention", "cnn_small", "nelbo", "prior", "sinkhorn", "gaussian_ot", "codebook",
-                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint", "matrix_utils", "gaussian_transport_shapes", "edge_calls", "state_dicts"]
+                             "codebook_kmeans", "discrete", "gmm", "vit", "vit_vae", "gmm_recovery", "vit_causal", "w2_prior", "nelbo_b32", "mixture_modes", "gmm_full", "stochastic", "vit_cross", "vit_autoregressive", "cnn_small_opts", "gmm_autograd", "codebook_autograd", "cnn_variants", "nelbo_expansion", "latent_transport_routing", "layouts", "cnn_shapes", "utils_small", "codebook_options", "vit_variants", "prior_corners", "partial_checkpoint", "matrix_utils", "gaussian_transport_shapes", "edge_calls", "state_dicts", "sinkhorn_autograd"]
     for w in which:
         globals()["gen_" + w]()

@@ -124,6 +124,10 @@ SIGNATURES = {
     "otvae_grad_clip_coef": (i32, [vp, i64, f32, f32, vp, vp, vp]),
     "otvae_sinkhorn_ws": (i64, [i32, i32, i32, i32]),
     "otvae_sinkhorn_log": (i32, [i32, vp, vp, vp, i32, i32, i32, f64, i32, f64, vp, vp, vp, vp, vp, vp]),
+    "otvae_sinkhorn_tape_bytes": (i64, [i32, i32, i32, i32, i32]),
+    "otvae_sinkhorn_bwd_ws": (i64, [i32, i32, i32, i32, i32]),
+    "otvae_sinkhorn_log_tape": (i32, [i32, vp, vp, vp, i32, i32, i32, f64, i32, f64, vp, vp, vp, vp, vp, vp]),
+    "otvae_sinkhorn_log_bwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp]),
     "otvae_sinkhorn_log_normalized": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, f64, i32, f64, vp, vp, vp, vp, vp, vp, vp]),
     "otvae_sinkhorn_prior_ws": (i64, [i32, i32, i32]),
     "otvae_sinkhorn_prior_fwd": (i32, [i32, vp, vp, i32, i32, i32, f64, i32, f64, f64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

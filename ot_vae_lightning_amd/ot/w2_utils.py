@@ -73,22 +73,112 @@ def sinkhorn_log_potentials(a: Tensor, b: Tensor, C: Tensor, reg: float = 1e-5, 
     return pi.reshape(*lead, n, m), u.reshape(*lead, n), v.reshape(*lead, m), iters
 
 
+class _SinkhornLogFn(torch.autograd.Function):
+    """``sinkhorn_log`` with the reference's autograd semantics: the reference function is plain torch arithmetic, so a gradient
+    reaches a, b and C THROUGH every iteration (ot/w2_utils.py:301-319).  Forward = ``otvae_sinkhorn_log_tape`` (the same solve, one
+    launch per half-iteration, every potential kept), backward = ``otvae_sinkhorn_log_bwd`` (the reverse sweep: 2 row-reduction
+    passes per iteration + one pass that forms the cost gradient; csrc/sinkhorn_diff.hip)."""
+
+    @staticmethod
+    def forward(ctx, a2, b2, c3, reg, max_iter, threshold):
+        lib = _lib.load()
+        nb, n, m = c3.shape
+        dt = _dt(c3)
+        tape = torch.empty(lib.otvae_sinkhorn_tape_bytes(dt, nb, n, m, int(max_iter)), device=c3.device, dtype=torch.uint8)
+        pi = torch.empty_like(c3)
+        iters = torch.zeros(1, device=c3.device, dtype=torch.int32)
+        check(lib.otvae_sinkhorn_log_tape(dt, ptr(a2), ptr(b2), ptr(c3), nb, n, m, float(reg), int(max_iter), float(threshold),
+                                          ptr(tape), ptr(pi), None, None, ptr(iters), stream()), "otvae_sinkhorn_log_tape")
+        ctx.save_for_backward(a2, b2, pi, tape)
+        ctx.cfg = (dt, nb, n, m, float(reg), int(max_iter))
+        return pi
+
+    @staticmethod
+    def backward(ctx, gpi):
+        a2, b2, pi, tape = ctx.saved_tensors
+        dt, nb, n, m, reg, max_iter = ctx.cfg
+        lib = _lib.load()
+        gpi = gpi.to(pi.dtype).contiguous()
+        need_a, need_b, need_c = ctx.needs_input_grad[:3]
+        ws = torch.empty(lib.otvae_sinkhorn_bwd_ws(dt, nb, n, m, max_iter), device=pi.device, dtype=torch.uint8)
+        gc = torch.empty_like(pi) if need_c else None
+        ga = torch.empty_like(a2) if need_a else None
+        gb = torch.empty_like(b2) if need_b else None
+        check(lib.otvae_sinkhorn_log_bwd(dt, ptr(gpi), ptr(pi), ptr(a2), ptr(b2), nb, n, m, reg, max_iter, ptr(tape), ptr(ws),
+                                         ptr(gc), ptr(ga), ptr(gb), stream()), "otvae_sinkhorn_log_bwd")
+        return ga, gb, gc, None, None, None
+
+
 def sinkhorn_log(a: Tensor, b: Tensor, C: Tensor, reg: float = 1e-5, max_iter: int = 1000,
                  threshold: float = STABILITY_CONST) -> Tensor:
     """Entropic OT plan by log-domain Sinkhorn iterations: a [*, N], b [*, M], C [*, N, M] -> pi [*, N, M].
     Same arithmetic and stopping rule as the reference (stop every problem of the batch at the first iteration
     where the smallest per-problem L1 change of (u, v) is below ``threshold``); the test runs on the device, so
-    unlike the reference there is no host synchronisation per iteration."""
+    unlike the reference there is no host synchronisation per iteration.
+
+    Autograd: as in the reference (plain torch arithmetic, ot/w2_utils.py:301-319) the plan is differentiable with respect to
+    ``a``, ``b`` and ``C`` through all iterations: when any of them requires a gradient the call takes the tape-recording solver
+    and carries ``_SinkhornLogFn``'s backward; otherwise the single-launch solver runs and the result has no ``grad_fn``."""
+    if torch.is_grad_enabled() and any(isinstance(t, Tensor) and t.requires_grad for t in (a, b, C)):
+        _lib.require_cuda(C, "C")
+        if C.dim() < 2 or a.shape[-1] != C.shape[-2] or b.shape[-1] != C.shape[-1]:
+            raise ValueError(f"sinkhorn_log: a {tuple(a.shape)}, b {tuple(b.shape)} do not match C {tuple(C.shape)}")
+        _dt(C)
+        lead = C.shape[:-2]
+        n, m = C.shape[-2:]
+        a2 = a.to(C.dtype).expand(*lead, n).reshape(-1, n).contiguous()
+        b2 = b.to(C.dtype).expand(*lead, m).reshape(-1, m).contiguous()
+        pi = _SinkhornLogFn.apply(a2, b2, C.reshape(-1, n, m).contiguous(), reg, max_iter, threshold)
+        return pi.reshape(*lead, n, m)
     return sinkhorn_log_potentials(a, b, C, reg, max_iter, threshold)[0]
 
 
+class _SqEuclideanCostFn(torch.autograd.Function):
+    """C_ij = |x_i - y_j|^2 with its gradient: gx_i = 2 sum_j G_ij (x_i - y_j), gy_j = 2 sum_i G_ij (y_j - x_i) -- the plan-times-samples
+    kernel of the minibatch-OT prior (``otvae_ot_cost_grad``) with the upstream gradient in the plan's place."""
+
+    @staticmethod
+    def forward(ctx, x3, y3):
+        lib = _lib.load()
+        nb, n, d = x3.shape
+        m = y3.shape[1]
+        out = torch.empty((nb, n, m), device=x3.device, dtype=x3.dtype)
+        check(lib.otvae_sqdist(_dt(x3), ptr(x3), ptr(y3), nb, n, m, d, ptr(out), stream()), "otvae_sqdist")
+        ctx.save_for_backward(x3, y3)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x3, y3 = ctx.saved_tensors
+        lib = _lib.load()
+        nb, n, d = x3.shape
+        m = y3.shape[1]
+        g = g.contiguous()
+        one = torch.ones(1, device=g.device, dtype=g.dtype)
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x3)
+            for k in range(nb):
+                check(lib.otvae_ot_cost_grad(_dt(x3), ptr(x3[k]), ptr(y3[k]), ptr(g[k]), ptr(one), 1, 1.0, None, n, m, d, ptr(gx[k]),
+                                             stream()), "otvae_ot_cost_grad")
+        if ctx.needs_input_grad[1]:
+            gy = torch.empty_like(y3)
+            gt = g.transpose(1, 2).contiguous()
+            for k in range(nb):
+                check(lib.otvae_ot_cost_grad(_dt(x3), ptr(y3[k]), ptr(x3[k]), ptr(gt[k]), ptr(one), 1, 1.0, None, m, n, d, ptr(gy[k]),
+                                             stream()), "otvae_ot_cost_grad")
+        return gx, gy
+
+
 def sq_euclidean_cost(x: Tensor, y: Tensor) -> Tensor:
-    """C[*, i, j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j for x [*, N, D], y [*, M, D]."""
+    """C[*, i, j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j for x [*, N, D], y [*, M, D]; differentiable with respect to both."""
     lib = _lib.load()
     _lib.require_cuda(x, "x")
     lead, n, d = x.shape[:-2], x.shape[-2], x.shape[-1]
     m = y.shape[-2]
     x3, y3 = x.reshape(-1, n, d).contiguous(), y.to(x.dtype).reshape(-1, m, d).contiguous()
+    if torch.is_grad_enabled() and (x3.requires_grad or y3.requires_grad):
+        return _SqEuclideanCostFn.apply(x3, y3).reshape(*lead, n, m)
     out = torch.empty((x3.shape[0], n, m), device=x.device, dtype=x.dtype)
     check(lib.otvae_sqdist(_dt(x), ptr(x3), ptr(y3), x3.shape[0], n, m, d, ptr(out), stream()), "otvae_sqdist")
     return out.reshape(*lead, n, m)

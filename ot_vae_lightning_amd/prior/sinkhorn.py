@@ -54,13 +54,27 @@ class _SinkhornLossFn(torch.autograd.Function):
 class SinkhornPrior(Prior):
     """Deterministic encoder + entropic OT between the minibatch of latents and a minibatch of N(0, I) draws.
     ``forward`` returns (z, loss[B], artifacts) with loss[b] = OT cost (identical for every b so that the VAE's
-    ``prior_loss.mean()`` equals it)."""
+    ``prior_loss.mean()`` equals it).
+
+    The loss VALUE is the reference's own composition (``sinkhorn_log`` on C / max C, read-out sum(C * pi): ot/w2_utils.py:265-269,
+    276-319).  Its GRADIENT comes in two conventions, and they are NOT close:
+
+    * ``differentiate_plan=False`` (default, the training configuration of BASELINE configs 2-3): the envelope form -- the plan is
+      a constant, d loss / d z_i = 2 sum_j pi_ij (z_i - y_j).  This is what the composition gives when the solve runs under
+      ``torch.no_grad()``; it is the gradient of the converged OT cost and is cheap (one plan-times-samples product).
+    * ``differentiate_plan=True``: what autograd gives for the composition of the reference's functions as written -- the
+      gradient also flows through the cost normalisation and through all ``max_iter`` iterations of ``sinkhorn_log``
+      (``ot.sinkhorn_log``'s backward, csrc/sinkhorn_diff.hip).  With reg = 0.05 and 50 iterations on a max-normalised cost the plan
+      is far from converged and the two gradients differ by 37 % (N = 7), 93 % (N = 64), 97 % (N = 256) of the gradient's
+      largest entry on the recorded problems (tests/golden/sinkhorn_autograd.npz: ``gz_full`` vs ``gz_envelope``, both from the
+      reference's function).  Costs 2 max_iter + 5 extra launches per step and runs on the launch stream."""
 
     def __init__(self, reg: float = 0.05, max_iter: int = 50, threshold: float = 0., loss_coeff: float = 1.,
-                 annealing_steps: int = 0, seed: int = None):
+                 annealing_steps: int = 0, seed: int = None, differentiate_plan: bool = False):
         super().__init__(loss_coeff, annealing_steps)
         self.reg, self.max_iter, self.threshold = reg, max_iter, threshold
         self.seed = seed
+        self.differentiate_plan = bool(differentiate_plan)
         self.last_iters = None  # device int32: iterations of the last solve (-1: the solver was starved, loss is NaN)
 
     def out_size(self, size):
@@ -95,6 +109,17 @@ class SinkhornPrior(Prior):
         zf = z.flatten(1)
         if prior_samples is None:
             prior_samples = self._draw(zf) if zf.dtype == torch.float32 else torch.randn_like(zf)
+        if self.differentiate_plan and torch.is_grad_enabled() and zf.requires_grad:
+            y = prior_samples.flatten(1).to(zf.dtype)
+            n, m = zf.shape[0], y.shape[0]
+            C = W.sq_euclidean_cost(zf, y)                     # differentiable (plan-times-samples kernel in its backward)
+            Cn = C / C.amax()                                  # the maximum takes part in the gradient, as under autograd
+            a = torch.full((n,), 1.0 / n, device=zf.device, dtype=zf.dtype)
+            b = torch.full((m,), 1.0 / m, device=zf.device, dtype=zf.dtype)
+            pi = W.sinkhorn_log(a, b, Cn, self.reg, self.max_iter, self.threshold)   # carries _SinkhornLogFn's backward
+            loss = ((C * pi).sum() * _scale).expand(n)
+            self.last_iters = None
+            return z, loss, {"prior_samples": prior_samples}
         z_out, loss, self.last_iters = _SinkhornLossFn.apply(zf, prior_samples.flatten(1), self.reg, self.max_iter, self.threshold,
                                                              _scale)
         return z_out.view(z.shape), loss, {"prior_samples": prior_samples}
