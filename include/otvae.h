@@ -398,6 +398,15 @@ int otvae_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
 int otvae_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step,
                             float grad_scale, const float* grad_scale_dev, const float* watch_loss, int32_t* guard,
                             float* state, const float* backup, int64_t n_state, void* stream);
+/* The superset entry: otvae_adam_step_guarded's arguments (guard / watch_loss / state may be NULL: unguarded) plus the parameter
+ * moving average of the reference's `ema_decay` option (model/base.py:99,153-190; kept there by the third-party torch_ema package,
+ * requirements.txt:10, unpinned): ema_shadow[n] -= (1 - d) (ema_shadow - p_new), d = min(ema_decay, (1 + t) / (10 + t)) with t the
+ * device step counter (one update per accepted optimizer step), in the optimizer's own pass.  A refused step leaves the shadow alone. */
+int otvae_adam_step_ema(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step,
+                        float grad_scale, const float* grad_scale_dev, const float* watch_loss, int32_t* guard, float* state,
+                        const float* backup, int64_t n_state, float* ema_shadow, double ema_decay, void* stream);
+/* The same moving-average update alone, with the caller's effective decay (a stock optimizer stepped by the reference's own loop) */
+int otvae_ema_update(float* shadow, const float* p, int64_t n, double decay, void* stream);
 /* The running buffers of a guarded step.  A NaN that reaches a BatchNorm does not stay one (the next ReLU maps the NaN-normalised
  * tensor to zeros), so later layers would fold finite but meaningless batch statistics into their running buffers:
  * otvae_step_begin_guarded increments *step like otvae_step_begin AND copies state[n_state] (every running buffer of the model,
@@ -537,6 +546,10 @@ int otvae_gemm_f32(int transA, int transB, int nb, int m, int n, int k, float al
  * softmax(energy / temperature) (base.py:216-224) and F.gumbel_softmax (:234-235); dtype 0 = fp32, 1 = fp64 */
 int otvae_softmax_rows(int dtype, const void* x, int64_t rows, int K, double scale, void* y, void* stream);
 int otvae_softmax_rows_bwd(int dtype, const void* y, const void* gy, int64_t rows, int K, double scale, void* gx, void* stream);
+/* out[rows] = log sum_k exp(x[r][k]) (torch.logsumexp over the last dimension: the mixture log-density read-out of
+ * GaussianMixtureModel, gaussian_model.py:129-132 on a MixtureSameFamily) and its backward gx[r][k] = g[r] exp(x[r][k] - lse[r]) */
+int otvae_lse_rows(int dtype, const void* x, int64_t rows, int K, void* out, void* stream);
+int otvae_lse_rows_bwd(int dtype, const void* x, const void* lse, const void* g, int64_t rows, int K, void* gx, void* stream);
 /* w2_gaussian tail (ot/w2_utils.py:78-80): out[nb] = |ms-mt|^2 + tr(cs + ct - 2*sqrt_mix) */
 int otvae_w2_tail(const double* ms, const double* mt, const double* cs, const double* ct, const double* sqrt_mix,
                   int nb, int D, double* out, void* stream);

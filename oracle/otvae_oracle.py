@@ -367,6 +367,40 @@ def ema(avg: Tensor, new: Tensor, decay: Optional[float]) -> Tensor:
     return avg * decay + new * (1 - decay)
 
 
+class ParamEMARef:
+    """The parameter moving average of the reference's ``ema_decay`` option (model/base.py:99,146-190).  The arithmetic lives in the
+    third-party ``torch_ema`` package (requirements.txt:10 ``torch-ema``, UNPINNED, absent from /root/reference and from this image):
+    this restates its published update rule (torch_ema 0.3 ``ExponentialMovingAverage``, ``use_num_updates=True``) operation by
+    operation -- ``tmp = shadow - param; tmp.mul_(1 - d); shadow.sub_(tmp)`` with ``d = min(decay, (1 + n) / (10 + n))`` -- and
+    ``store / copy_to / restore`` as copies.  PARITY UNPINNED for this one class: there is no reference-side vector to hold it to."""
+
+    def __init__(self, params, decay: float):
+        self.decay, self.num_updates = decay, 0
+        self.shadow = [p.clone().detach() for p in params]
+        self.collected = None
+
+    def update(self, params):
+        self.num_updates += 1
+        d = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+        one_minus_decay = 1.0 - d
+        with torch.no_grad():
+            for s_, p in zip(self.shadow, params):
+                tmp = s_ - p
+                tmp.mul_(one_minus_decay)
+                s_.sub_(tmp)
+
+    def store(self, params):
+        self.collected = [p.clone() for p in params]
+
+    def copy_to(self, params):
+        for s_, p in zip(self.shadow, params):
+            p.data.copy_(s_)
+
+    def restore(self, params):
+        for c_, p in zip(self.collected, params):
+            p.data.copy_(c_)
+
+
 def mean_cov(sum_x: Tensor, sum_xx: Tensor, n, diag: bool = False):
     """``mean_cov`` (ot/matrix_utils.py:145-158)."""
     n = torch.as_tensor(n, dtype=sum_x.dtype)

@@ -118,6 +118,8 @@ SIGNATURES = {
     "otvae_step_begin": (i32, [vp, vp]),
     "otvae_adam_step": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp]),
     "otvae_adam_step_dev": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "otvae_adam_step_ema": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp, vp, vp, vp, vp, i64, vp, f64, vp]),
+    "otvae_ema_update": (i32, [vp, vp, i64, f64, vp]),
     "otvae_adam_step_guarded": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp, vp, vp, vp, vp, i64, vp]),
     "otvae_step_begin_guarded": (i32, [vp, vp, vp, i64, vp]),
     "otvae_grad_clip_ws": (i32, []),
@@ -155,6 +157,8 @@ SIGNATURES = {
     "otvae_gemm_f32": (i32, [i32, i32, i32, i32, i32, i32, f32, vp, i32, vp, i32, f32, vp, vp]),
     "otvae_softmax_rows": (i32, [i32, vp, i64, i32, f64, vp, vp]),
     "otvae_softmax_rows_bwd": (i32, [i32, vp, vp, i64, i32, f64, vp, vp]),
+    "otvae_lse_rows": (i32, [i32, vp, i64, i32, vp, vp]),
+    "otvae_lse_rows_bwd": (i32, [i32, vp, vp, vp, i64, i32, vp, vp]),
     "otvae_w2_tail": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "otvae_apply_transport": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "otvae_codebook_assign": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),

@@ -1258,23 +1258,34 @@ int eigh_block_onesided(const double* A, int nb, int D, int fn, double* out, dou
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     static const bool no_follow = getenv("OTVAE_EIGH_NO_FOLLOW") != nullptr;  // A/B switch
-    static std::mutex follow_mutex;
-    static int* follow_flags = nullptr;  // [HJB_MAX_SWEEPS], mapped host memory
-    static hipEvent_t follow_ev[2];
-    std::unique_lock<std::mutex> follow_lock(follow_mutex, std::defer_lock);
+    // The pinned flags, the two events and the lock are PER DEVICE: events are bound to the device that was current when
+    // they were made, so one process-wide pair failed hipEventRecord on a second GPU's stream, and one lock serialised the solves
+    // of all devices.  Indexed by the calling thread's current device, which is the stream's device under torch.
+    struct FollowState {
+        std::mutex mu;
+        int* flags = nullptr;  // [HJB_MAX_SWEEPS], mapped host memory
+        hipEvent_t ev[2];
+    };
+    static FollowState follow_tab[16];
+    int follow_dev = -1;
     bool follow = cap == hipStreamCaptureStatusNone && !no_follow;
+    if (follow && (hipGetDevice(&follow_dev) != hipSuccess || follow_dev < 0 || follow_dev >= 16)) follow = false;
+    FollowState& fs = follow_tab[follow ? follow_dev : 0];
+    std::unique_lock<std::mutex> follow_lock(fs.mu, std::defer_lock);
     if (follow) {
         follow_lock.lock();
-        if (!follow_flags) {
+        if (!fs.flags) {
             int* f = nullptr;
             if (hipHostMalloc((void**)&f, HJB_MAX_SWEEPS * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
-                hipEventCreateWithFlags(&follow_ev[0], hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&follow_ev[1], hipEventDisableTiming) == hipSuccess)
-                follow_flags = f;
+                hipEventCreateWithFlags(&fs.ev[0], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&fs.ev[1], hipEventDisableTiming) == hipSuccess)
+                fs.flags = f;
             else
                 follow = false;  // (no pinned memory: the blind budget still gives the right answer)
         }
     }
+    int* const follow_flags = fs.flags;
+    hipEvent_t* const follow_ev = fs.ev;
     int issued = 0;
     for (int sweep = 0; sweep < HJB_MAX_SWEEPS; ++sweep) {
         if (follow && sweep >= 2) {

@@ -835,6 +835,56 @@ extern "C" int otvae_softmax_rows_bwd(int dtype, const void* y, const void* gy, 
     return OTVAE_OK;
 }
 
+// out[r] = log sum_k exp(x[r][k]) (one wave per row) and its backward gx[r][k] = g[r] exp(x[r][k] - out[r]): the mixture log-density
+// read-out of GaussianMixtureModel.predict (gaussian_model.py:129-132 on a MixtureSameFamily: logsumexp over the components)
+template <typename T>
+__global__ __launch_bounds__(256) void lse_rows_kernel(const T* __restrict__ x, long rows, int K, T* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const T* xr = x + r * K;
+    T mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmax(mx, xr[k]);
+    mx = wave_max(mx);
+    T sum = (T)0;
+    if (mx > -INFINITY && mx < INFINITY)
+        for (int k = lane; k < K; k += 64) sum += exp(xr[k] - mx);
+    sum = wave_sum(sum);
+    // torch.logsumexp: an all -inf row gives -inf, a row holding +inf gives +inf
+    if (lane == 0) out[r] = (mx > -INFINITY && mx < INFINITY) ? mx + log(sum) : mx;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lse_rows_bwd_kernel(const T* __restrict__ x, const T* __restrict__ lse, const T* __restrict__ g,
+                                                           long rows, int K, T* __restrict__ gx) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const T l = lse[r], gr = g[r];
+    for (int k = lane; k < K; k += 64) gx[r * K + k] = gr * exp(x[r * K + k] - l);
+}
+
+extern "C" int otvae_lse_rows(int dtype, const void* x, int64_t rows, int K, void* out, void* stream) {
+    OTVAE_REQUIRE(x && out && rows > 0 && K > 0 && (dtype == 0 || dtype == 1), "otvae_lse_rows: bad argument");
+    const int grid = cdiv(rows, 4);
+    if (dtype == 0) lse_rows_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, rows, K, (float*)out);
+    else lse_rows_kernel<double><<<grid, 256, 0, (hipStream_t)stream>>>((const double*)x, rows, K, (double*)out);
+    OTVAE_CHECK_LAUNCH("otvae_lse_rows");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_lse_rows_bwd(int dtype, const void* x, const void* lse, const void* g, int64_t rows, int K, void* gx, void* stream) {
+    OTVAE_REQUIRE(x && lse && g && gx && rows > 0 && K > 0 && (dtype == 0 || dtype == 1), "otvae_lse_rows_bwd: bad argument");
+    const int grid = cdiv(rows, 4);
+    if (dtype == 0)
+        lse_rows_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, (const float*)lse, (const float*)g, rows, K, (float*)gx);
+    else
+        lse_rows_bwd_kernel<double><<<grid, 256, 0, (hipStream_t)stream>>>((const double*)x, (const double*)lse, (const double*)g, rows, K,
+                                                                            (double*)gx);
+    OTVAE_CHECK_LAUNCH("otvae_lse_rows_bwd");
+    return OTVAE_OK;
+}
+
 // The same product on the fp64 matrix cores for the large operands (D = 1024 latent transport: the products around the
 // eigendecompositions were 2-4 ms each on the kernel above).  64 x 64 output tile per workgroup, 4 waves x (16 rows x 64 columns) =
 // 4 v_mfma_f64_16x16x4_f64 accumulators per wave, K in chunks of 16 through LDS (k-major for both operands, so that lane

@@ -471,7 +471,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    int32_t* __restrict__ step, float grad_scale,
                                                    const float* __restrict__ scale_dev, int32_t* __restrict__ guard,
                                                    const float* __restrict__ watch_loss, float* __restrict__ state,
-                                                   const float* __restrict__ backup, int64_t n_state) {
+                                                   const float* __restrict__ backup, int64_t n_state,
+                                                   float* __restrict__ ema = nullptr, double ema_decay = 0.0) {
     if (scale_dev) grad_scale = *scale_dev;  // clip coefficient x 1/world, left by grad_clip_final_kernel
     if (guard) {
         bool ok = isfinite(grad_scale);
@@ -490,6 +491,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
     const int t = *step;
+    // Parameter moving average (the reference's `ema_decay`, model/base.py:153-190, kept there by the third-party torch_ema package:
+    // shadow -= (1 - d) (shadow - p), d = min(decay, (1 + n) / (10 + n)), n = updates so far incl. this one) folded into the
+    // optimizer's pass: one update per ACCEPTED optimizer step, so n is the device step counter t; the three roundings are
+    // torch_ema's own (sub, mul by the fp32 image of 1 - d, sub: no fused multiply-add)
+    float ema_omd = 0.f;
+    if (ema) {
+        const double d = fmin(ema_decay, (1.0 + (double)t) / (10.0 + (double)t));
+        ema_omd = (float)(1.0 - d);
+    }
     const float bc1 = 1.f - powf(b1, (float)t);
     const float bc2s = sqrtf(1.f - powf(b2, (float)t));
     const float step_size = lr / bc1;
@@ -511,6 +521,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(p)[i] = pv;
         reinterpret_cast<float4*>(m)[i] = mv;
         reinterpret_cast<float4*>(v)[i] = vv;
+        if (ema) {
+            float4 sv = reinterpret_cast<float4*>(ema)[i];
+            sv.x = __fsub_rn(sv.x, __fmul_rn(__fsub_rn(sv.x, pv.x), ema_omd));
+            sv.y = __fsub_rn(sv.y, __fmul_rn(__fsub_rn(sv.y, pv.y), ema_omd));
+            sv.z = __fsub_rn(sv.z, __fmul_rn(__fsub_rn(sv.z, pv.z), ema_omd));
+            sv.w = __fsub_rn(sv.w, __fmul_rn(__fsub_rn(sv.w, pv.w), ema_omd));
+            reinterpret_cast<float4*>(ema)[i] = sv;
+        }
     }
     // tail
     for (int64_t i = (n4 << 2) + blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -519,8 +537,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float vv = fmaf(b2, v[i], (1.f - b2) * gg * gg);
         m[i] = mm;
         v[i] = vv;
-        p[i] -= step_size * mm / (sqrtf(vv) / bc2s + eps);
+        const float pn = p[i] - step_size * mm / (sqrtf(vv) / bc2s + eps);
+        p[i] = pn;
+        if (ema) ema[i] = __fsub_rn(ema[i], __fmul_rn(__fsub_rn(ema[i], pn), ema_omd));
     }
+}
+
+// shadow -= (1 - d) (shadow - p) with the caller's effective decay d (the host-driven route: a stock optimizer stepped by the
+// reference's own loop; `ParamEMA.update`, engine/ema.py)
+__global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ shadow, const float* __restrict__ p, int64_t n, float omd) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        shadow[i] = __fsub_rn(shadow[i], __fmul_rn(__fsub_rn(shadow[i], p[i]), omd));
+}
+
+extern "C" int otvae_ema_update(float* shadow, const float* p, int64_t n, double decay, void* stream) {
+    OTVAE_REQUIRE(shadow && p && n > 0 && decay >= 0.0 && decay <= 1.0, "otvae_ema_update: bad argument");
+    ema_update_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(shadow, p, n, (float)(1.0 - decay));
+    OTVAE_CHECK_LAUNCH("otvae_ema_update");
+    return OTVAE_OK;
 }
 
 extern "C" int otvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
@@ -542,6 +576,23 @@ extern "C" int otvae_adam_step_dev(float* p, const float* g, float* m, float* v,
     adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, const_cast<int32_t*>(step), 1.f,
                                                                             grad_scale_dev, nullptr, nullptr, nullptr, nullptr, 0);
     OTVAE_CHECK_LAUNCH("otvae_adam_step_dev");
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_adam_step_ema(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int32_t* step,
+                                   float grad_scale, const float* grad_scale_dev, const float* watch_loss, int32_t* guard,
+                                   float* state, const float* backup, int64_t n_state, float* ema_shadow, double ema_decay,
+                                   void* stream) {
+    OTVAE_REQUIRE(p && g && m && v && hyper && step && n > 0, "otvae_adam_step_ema: bad argument");
+    OTVAE_REQUIRE(n_state >= 0 && (n_state == 0 || (state && backup && guard)), "otvae_adam_step_ema: state / backup / guard missing");
+    OTVAE_REQUIRE(!watch_loss || guard, "otvae_adam_step_ema: a watched loss needs the guard counters");
+    OTVAE_REQUIRE(!ema_shadow || (ema_decay >= 0.0 && ema_decay <= 1.0), "otvae_adam_step_ema: ema_decay must lie in [0, 1]");
+    OTVAE_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                      (!ema_shadow || (uintptr_t)ema_shadow % 16 == 0),
+                  "otvae_adam_step_ema: buffers must be 16-byte aligned");
+    adam_kernel<<<imin(cdiv(n, 1024), 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, hyper, step, grad_scale, grad_scale_dev, guard,
+                                                                            watch_loss, state, backup, n_state, ema_shadow, ema_decay);
+    OTVAE_CHECK_LAUNCH("otvae_adam_step_ema");
     return OTVAE_OK;
 }
 

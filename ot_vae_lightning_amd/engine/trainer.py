@@ -95,6 +95,13 @@ class HipTrainer:
         self.v = torch.zeros_like(self.pflat)
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps], device=dev, dtype=torch.float32)
         self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
+        # the reference's `ema_decay` (model/base.py:99,146-190): the moving average of the parameters is updated by the optimizer
+        # kernel itself (otvae_adam_step_ema); the model's epoch hooks swap it in and out around evaluation (engine/ema.py)
+        self.ema = None
+        if getattr(model, "ema_decay", None) is not None and not weak_model:
+            from .ema import ParamEMA
+            self.ema = ParamEMA(self.params, model.ema_decay, flat=self.pflat, in_optimizer=True, step_tensor=self.step_count)
+            model._ema = self.ema
         # global-norm clipping of the (rank-averaged) gradient, the reference's DDP overlay (configs/ddp.yaml:4); the two
         # floats are {scale Adam applies to the summed gradient, norm of the averaged gradient} of the last step
         self.gradient_clip_val = None if not gradient_clip_val else float(gradient_clip_val)
@@ -278,7 +285,13 @@ class HipTrainer:
             # what depends on the forward pass only and is read by nothing before the optimizer -- the loss value (ops._nelbo_fwd_launch)
             # and the latent statistics -- goes to the side stream with the first weight-gradient fork of the backward pass (joined with
             # it in flush); only in a captured single-graph step, where that fork exists
-            on_side = (STATS_ON_SIDE and self._segments is None and HF.WGRAD_SIDE_STREAM == 1 and torch.cuda.is_current_stream_capturing())
+            # ... and only for the package's own `VAE.nelbo`: between `nelbo()` returning and the join in `flush` the loss vector is not
+            # yet written on the launch stream, so a subclass whose nelbo READS the loss it just computed (combining terms, stacking
+            # logs) would capture garbage -- for such a model the value is launched in line
+            from ..model.vae import VAE as _VAE
+            own_nelbo = getattr(type(self.model), "nelbo", None) is _VAE.nelbo
+            on_side = (STATS_ON_SIDE and own_nelbo and self._segments is None and HF.WGRAD_SIDE_STREAM == 1 and
+                       torch.cuda.is_current_stream_capturing())
             _PR._defer[self.device] = on_side
             try:
                 loss, logs, art = self.model.nelbo(self._batch(), 0)
@@ -437,7 +450,17 @@ class HipTrainer:
         if norm:  # max_norm 0: the norm is only reported (out[0] = grad_scale)
             check(lib.otvae_grad_clip_coef(ptr(self.gflat), self.gflat.numel(), self.reducer.grad_scale, self.gradient_clip_val or 0.0,
                                            ptr(self._clip_ws), ptr(self.clip_out), stream()), "otvae_grad_clip_coef")
-        if self.step_guard is not None:
+        if self.ema is not None:
+            guarded = self.step_guard is not None
+            watch = getattr(self.model, "_last_out3", None) if guarded else None
+            self._watch = watch
+            check(lib.otvae_adam_step_ema(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
+                                          ptr(self.hyper), ptr(self.step_count), self.reducer.grad_scale,
+                                          ptr(self.clip_out) if norm else None, ptr(watch), ptr(self.guard) if guarded else None,
+                                          ptr(self.rflat) if guarded else None, ptr(self.rbackup) if guarded else None,
+                                          0 if (self.rflat is None or not guarded) else self.rflat.numel(),
+                                          ptr(self.ema.shadow), self.ema.decay, stream()), "otvae_adam_step_ema")
+        elif self.step_guard is not None:
             watch = getattr(self.model, "_last_out3", None)  # [total, recon, prior] of this step (static inside a captured step)
             self._watch = watch
             check(lib.otvae_adam_step_guarded(ptr(self.pflat), ptr(self.gflat), ptr(self.m), ptr(self.v), self.pflat.numel(),
@@ -495,6 +518,8 @@ class HipTrainer:
         state += [mod.__dict__["_dropout_key"] for mod in self.model.modules() if isinstance(mod.__dict__.get("_dropout_key"), Tensor)]
         if self.latent_stats is not None:
             state += [t for t in self.latent_stats.buffers()] + [p.data for p in self.latent_stats.parameters()]
+        if self.ema is not None:
+            state.append(self.ema.shadow)
         state_snap = [t.clone() for t in state]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())

@@ -1762,7 +1762,12 @@ def gaussian_prior_conditional_ex(h: Tensor, eps: Tensor, prior_mean: Tensor, pr
 
 def nelbo_loss(pred: Tensor, target: Tensor, prior_loss: Optional[Tensor]) -> Tensor:
     """[total, recon, prior] of VAE.nelbo (reference model/vae.py:158-176): recon = mse(pred, target),
-    prior = mean(prior_loss) / prod(target.shape[1:])."""
+    prior = mean(prior_loss) / prod(target.shape[1:]).
+
+    Contract inside a training engine's CAPTURED step (``engine.HipTrainer`` with the package's own ``VAE.nelbo``): the value is
+    launched on the side stream with the backward pass's first fork and is complete on the launch stream only behind
+    ``_PendingReduce.flush`` (before the step guard / optimizer read it) -- nothing may READ the returned vector on the launch
+    stream before that join.  The engine switches the deferral off for a model class that overrides ``nelbo``."""
     _lib.require_cuda(pred, "pred")
     pred = as_nhwc(pred) if pred.dim() == 4 else pred.contiguous()
     target = as_nhwc(target) if target.dim() == 4 else target.contiguous()

@@ -53,16 +53,40 @@ class VisionModule(_Base):
         self.inference_preprocess = inference_preprocess
         self.inference_postprocess = inference_postprocess
         self._inference_flag = False
-        if ema_decay is not None:
-            # the reference keeps an exponential moving average of the parameters through the third-party `torch_ema` package inside
-            # Lightning's hooks (model/base.py:99,146-176: on_before_zero_grad / store + copy_to around validation).  That loop is not
-            # part of this package: refusing is better than accepting the argument and training without the average
-            raise NotImplementedError("`ema_decay`: the parameter moving average of the reference's Lightning hooks (torch_ema) is "
-                                      "not implemented on the MI355X path")
+        # the reference's parameter moving average (model/base.py:99,146-190): created at `on_fit_start` (or by engine.HipTrainer, which
+        # folds the update into its optimizer kernel), swapped in around evaluation by the epoch hooks below (engine/ema.py)
         self.ema_decay = ema_decay
+        self._ema = None
 
     def optim_parameters(self):
         return (p for p in self.parameters() if p.requires_grad)
+
+    # ---- parameter moving average: the reference's hooks (model/base.py:146-190), same names, same order of operations
+    def on_fit_start(self) -> None:
+        if self.ema_decay is not None and self._ema is None:
+            from ..engine.ema import ParamEMA
+            self._ema = ParamEMA(self.optim_parameters(), decay=self.ema_decay)
+
+    def on_before_zero_grad(self, optimizer=None) -> None:
+        if self._ema is not None:
+            self._ema.update(self.optim_parameters())
+
+    def _ema_swap_in(self) -> None:
+        if self.inference_preprocess is not None and self.inference_postprocess is not None:
+            self.inference = True   # (the reference fills in default transforms at on_fit_start; without any, the flag stays off)
+        if self._ema is not None:
+            self._ema.store()
+            self._ema.copy_to()
+
+    def _ema_swap_out(self, *args) -> None:
+        if self._ema is not None:
+            self._ema.restore()
+
+    def on_train_epoch_start(self) -> None:
+        self.inference = False
+
+    on_validation_epoch_start = on_test_epoch_start = on_predict_epoch_start = _ema_swap_in
+    on_validation_epoch_end = on_test_epoch_end = on_predict_epoch_end = _ema_swap_out
 
     def training_step(self, batch, batch_idx, optimizer_idx=0):
         loss_fn = self.loss[optimizer_idx] if hasattr(self.loss, "__getitem__") else self.loss

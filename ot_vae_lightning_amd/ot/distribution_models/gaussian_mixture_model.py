@@ -24,7 +24,7 @@ from ..._lib import check, ptr, stream
 from ..w2_utils import W2Mixin, batch_ot_gmm
 from .base import MIXTURE_MODES, DistributionModel, gumbel_weights
 from .gaussian_model import ExpScaleTril, MakePositiveDefinite, Symmetric, mvn_log_prob
-from ..matrix_utils import eigh_vectors, eye_like, matmul64, mm, softmax_rows
+from ..matrix_utils import eigh_vectors, eye_like, lse_rows, matmul64, mm, softmax_rows
 
 __all__ = ["GaussianMixtureModel"]
 
@@ -218,12 +218,12 @@ class GaussianMixtureModel(DistributionModel, W2Mixin):
         through ``mvn_log_prob`` (csrc/mvn.hip)."""
         self._validate_samples(samples)
         if not self.update_with_autograd:
-            return torch.logsumexp(self.energy(samples), dim=-1)
+            return lse_rows(self.energy(samples))
         x = samples.type_as(self.mean).unsqueeze(-3)                                  # [*, 1, B, d] against K components
         scale = self.cov ** 0.5 if self.diag else self.cov
         comp = mvn_log_prob(x, self.mean, scale, self.diag).transpose(-1, -2)         # [*, K, B] -> [*, B, K]
         logw = torch.log_softmax(torch.log(self.weights), dim=-1).unsqueeze(-2)
-        return torch.logsumexp(comp + logw, dim=-1)
+        return lse_rows(comp + logw)
 
     def encode(self, samples: Tensor):
         """(expected component mean per sample, sampled indices, assignment distribution): the triple CodebookModel.predict returns

@@ -10,7 +10,7 @@ from .. import _lib
 from .._lib import check, ptr, stream
 
 __all__ = ["eye_like", "sqrtm", "invsqrtm", "is_spd", "is_pd", "is_symmetric", "min_eig", "make_psd", "mean_cov",
-           "STABILITY_CONST", "eigvals_and_fn", "matmul64", "eigh_vectors", "spectral_fn", "psd_shift", "pinv_sym", "cholesky", "mm", "softmax_rows"]
+           "STABILITY_CONST", "eigvals_and_fn", "matmul64", "eigh_vectors", "spectral_fn", "psd_shift", "pinv_sym", "cholesky", "mm", "softmax_rows", "lse_rows"]
 
 STABILITY_CONST = 1e-8
 
@@ -266,3 +266,34 @@ def softmax_rows(x: Tensor, scale: float = 1.0) -> Tensor:
     if x.dtype not in (torch.float32, torch.float64):
         raise TypeError("softmax_rows computes in fp32 or fp64")
     return _SoftmaxRowsFn.apply(x, scale)
+
+
+class _LseRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x2 = x.contiguous()
+        rows, k = x2.numel() // x2.shape[-1], x2.shape[-1]
+        out = torch.empty(x2.shape[:-1], device=x2.device, dtype=x2.dtype)
+        check(_lib.load().otvae_lse_rows(int(x2.dtype == torch.float64), ptr(x2), rows, k, ptr(out), stream()), "otvae_lse_rows")
+        ctx.save_for_backward(x2, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, out = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(x2)
+        rows, k = x2.numel() // x2.shape[-1], x2.shape[-1]
+        check(_lib.load().otvae_lse_rows_bwd(int(x2.dtype == torch.float64), ptr(x2), ptr(out), ptr(g), rows, k, ptr(gx), stream()),
+              "otvae_lse_rows_bwd")
+        return gx
+
+
+def lse_rows(x: Tensor) -> Tensor:
+    """torch.logsumexp(x, dim=-1) on the library's kernel (fp32 / fp64), differentiable: the mixture log-density read-out"""
+    _lib.require_cuda(x, "x")
+    if x.dtype not in (torch.float32, torch.float64):
+        raise TypeError("lse_rows computes in fp32 or fp64")
+    if x.numel() == 0:
+        return x.new_empty(x.shape[:-1])
+    return _LseRowsFn.apply(x)

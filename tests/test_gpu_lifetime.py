@@ -152,3 +152,65 @@ def test_graphed_nelbo_accumulates_gradients_over_micro_batches():
         got = run(True, zero_with_none)
         err = float((got - eager).abs().max() / eager.abs().max())
         assert err < 2e-6, (zero_with_none, err)   # same kernels; the sum's association differs by one rounding at most
+
+
+def test_parameter_ema_in_the_optimizer_kernel_vs_the_torch_ema_rule():
+    """``ema_decay`` (reference model/base.py:99,146-190): HipTrainer folds the average into its Adam kernel.  Held
+    against the oracle's restatement of torch_ema's update rule applied to the SAME parameter trajectory (bit-exact: three fp32
+    roundings either way), then the store / copy_to / restore swap of the evaluation hooks, then the step guard (a refused step
+    leaves the average alone), then the host-driven route (``on_fit_start`` + ``on_before_zero_grad`` around a stock optimizer)."""
+    import otvae_oracle as O
+    import ot_vae_lightning_amd as A
+    from detfill import mnist_like, normal
+    B = 32
+    xs = [mnist_like(B, 50 + i).cuda() for i in range(4)]
+    es = [normal((B, 128, 1, 1), 60 + i).cuda() for i in range(4)]
+
+    def make(**kw):
+        torch.manual_seed(17)
+        enc = A.CNN(1, 256, 32, 1, capacity=8, down_sample=True, residual="add")
+        dec = A.CNN(128, 1, 1, 32, capacity=8, up_sample=True, residual="add")
+        return A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1), **kw).cuda().train()
+
+    for graph in (False, True):
+        model = make(ema_decay=0.9)
+        tr = A.HipTrainer(model, batch_shape=(B, 1, 32, 32), use_graph=graph)
+        assert model._ema is tr.ema and tr.ema.in_optimizer
+        ref = O.ParamEMARef([tr.pflat.detach().cpu()], 0.9)
+        for i in range(4):
+            tr.step(xs[i], es[i])
+            ref.update([tr.pflat.detach().cpu()])
+        assert torch.equal(tr.ema.shadow.cpu(), ref.shadow[0]), f"graph={graph}: shadow differs from the torch_ema rule"
+        assert not torch.equal(tr.ema.shadow, tr.pflat)
+        # the evaluation swap (reference hooks: store + copy_to at epoch start, restore at its end)
+        live = tr.pflat.clone()
+        model.on_validation_epoch_start()
+        assert torch.equal(tr.pflat, tr.ema.shadow)
+        assert torch.equal(next(model.encoder.parameters()).detach().flatten().sort()[0],
+                           tr.ema.shadow[: next(model.encoder.parameters()).numel()].sort()[0])   # the modules see the average
+        model.on_validation_epoch_end()
+        assert torch.equal(tr.pflat, live)
+        # a refused step (NaN batch) leaves the average and the count alone
+        bad = xs[0].clone()
+        bad[1, 0, 3, 3] = float("nan")
+        before = tr.ema.shadow.clone()
+        tr.step(bad, es[0])
+        torch.cuda.synchronize()
+        assert tr.skipped_steps == 1 and torch.equal(tr.ema.shadow, before) and tr.ema.state_dict()["num_updates"] == 4
+        tr.close()
+
+    # host-driven route: the reference's loop with a stock optimizer
+    model = make(ema_decay=0.95)
+    model.batch_preprocess = lambda b: {"samples": b[0], "target": b[0], "kwargs": {"eps": b[1]}}
+    params = list(model.optim_parameters())
+    opt = torch.optim.SGD(params, lr=0.05)
+    model.on_fit_start()
+    ref = O.ParamEMARef([p.detach().cpu().contiguous() for p in params], 0.95)
+    for i in range(3):
+        model.training_step((xs[i], es[i]), i)["loss"].backward()
+        opt.step()
+        model.on_before_zero_grad(opt)
+        opt.zero_grad()
+        ref.update([p.detach().cpu().contiguous() for p in params])
+    for s_, r_ in zip(model._ema.shadow, ref.shadow):
+        assert torch.equal(s_.cpu().contiguous(), r_)
