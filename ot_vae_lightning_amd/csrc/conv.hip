@@ -1185,20 +1185,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
 //   many partials: one wave per element, lanes stride over p, shuffle tree
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int P, int K, int Kp, int Cn,
                                                            float* __restrict__ gw, float* __restrict__ gb) {
-    __shared__ float red[4][64];
+    __shared__ double red[4][64];  // fp32 partials, fp64 sum (see wgrad_reduce_batched_kernel)
     const size_t total = (size_t)Kp * Cn;
     if (P >= 32) {
         const int lane = threadIdx.x & 63;
         for (size_t e = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (size_t)gridDim.x * 4) {
-            float s = 0.f;
-            for (int p = lane; p < P; p += 64) s += partial[(size_t)p * total + e];
+            double s = 0.0;
+            for (int p = lane; p < P; p += 64) s += (double)partial[(size_t)p * total + e];
             s = wave_sum(s);
             if (lane == 0) {
                 const int k = e / Cn;
                 if (k < K)
-                    gw[e] = s;
+                    gw[e] = (float)s;
                 else if (gb)
-                    gb[e - (size_t)K * Cn] = s;
+                    gb[e - (size_t)K * Cn] = (float)s;
             }
         }
         return;
@@ -1206,13 +1206,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int el = threadIdx.x & 63, pg = threadIdx.x >> 6;
     for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
         const size_t e = e0 + el;
-        float s = 0.f;
+        double s = 0.0;
         if (e < total)
-            for (int p = pg; p < P; p += 4) s += partial[(size_t)p * total + e];
+            for (int p = pg; p < P; p += 4) s += (double)partial[(size_t)p * total + e];
         red[pg][el] = s;
         __syncthreads();
         if (pg == 0 && e < total) {
-            const float t = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+            const float t = (float)((red[0][el] + red[1][el]) + (red[2][el] + red[3][el]));
             const int k = e / Cn;
             if (k < K)
                 gw[e] = t;
@@ -1354,7 +1354,9 @@ struct WrbDesc {
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
-    __shared__ float red[4][64];
+    // the partials are fp32 (the matrix cores' accumulators); their SUM is formed in fp64 -- up to 512 terms that partly cancel -- and
+    // rounded once (round 4: held against the float64 truth, the fp32 sum of the partials alone cost up to 2.6x the reference's own error)
+    __shared__ double red[4][64];
     const int l = blockIdx.y;
     const float* __restrict__ partial = d.partial[l];
     float* __restrict__ gw = d.gw[l];
@@ -1376,23 +1378,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
         const int pg = threadIdx.x >> 6;
         for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
             const size_t e = e0 + lane;
-            float s = 0.f;
+            double s = 0.0;
             if (e < total && !is_dead(e)) {
                 int p = pg;
                 for (; p + 12 < P; p += 16) {
                     const float a0 = partial[(size_t)p * total + e], a1 = partial[(size_t)(p + 4) * total + e];
                     const float a2 = partial[(size_t)(p + 8) * total + e], a3 = partial[(size_t)(p + 12) * total + e];
-                    s += a0;
-                    s += a1;
-                    s += a2;
-                    s += a3;
+                    s += (double)a0;
+                    s += (double)a1;
+                    s += (double)a2;
+                    s += (double)a3;
                 }
-                for (; p < P; p += 4) s += partial[(size_t)p * total + e];
+                for (; p < P; p += 4) s += (double)partial[(size_t)p * total + e];
             }
             red[pg][lane] = s;
             __syncthreads();
             if (pg == 0 && e < total) {
-                const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+                const float t = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
                 const int k = e / Cn;
                 if (k < K) gw[e] = t;
                 else if (gb) gb[e - (size_t)K * Cn] = t;
@@ -1401,24 +1403,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WrbDesc d) {
         }
     } else if (P >= 16) {  // small gradient, many partials: one wave per element (neighbouring waves share the lines)
         for (size_t e = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (size_t)gridDim.x * 4) {
-            float s = 0.f;
+            double s = 0.0;
             if (!is_dead(e))
-                for (int p = lane; p < P; p += 64) s += partial[(size_t)p * total + e];
+                for (int p = lane; p < P; p += 64) s += (double)partial[(size_t)p * total + e];
             s = wave_sum(s);
             if (lane == 0) {
                 const int k = e / Cn;
-                if (k < K) gw[e] = s;
-                else if (gb) gb[e - (size_t)K * Cn] = s;
+                if (k < K) gw[e] = (float)s;
+                else if (gb) gb[e - (size_t)K * Cn] = (float)s;
             }
         }
     } else {  // one lane per element, serial over the few partials
         for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-            float s = 0.f;
+            double s = 0.0;
             if (!is_dead(e))
-                for (int p = 0; p < P; ++p) s += partial[(size_t)p * total + e];
+                for (int p = 0; p < P; ++p) s += (double)partial[(size_t)p * total + e];
             const int k = e / Cn;
-            if (k < K) gw[e] = s;
-            else if (gb) gb[e - (size_t)K * Cn] = s;
+            if (k < K) gw[e] = (float)s;
+            else if (gb) gb[e - (size_t)K * Cn] = (float)s;
         }
     }
 }

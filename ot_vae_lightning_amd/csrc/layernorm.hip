@@ -125,13 +125,16 @@ template <int NV, bool DROP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ gy,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int M, int D, float* __restrict__ gx,
-                                                            float* __restrict__ partial, float* __restrict__ gxd, LnDrop dr) {
-    extern __shared__ float ln_red[];  // [4 waves][2][D]
+                                                            double* __restrict__ partial, float* __restrict__ gxd, LnDrop dr) {
+    // The parameter gradients are sums over ALL rows of products that largely cancel (measured at the vit.yaml shape, round 4: an fp32
+    // accumulation sat 4.5e-3 in relative L2 from the float64 truth where the reference's own fp32 arithmetic is at 2.9e-4): they are
+    // accumulated in fp64 from the first product to the final column sum (fp32 products, fp64 adds; 2 NV more registers a lane).
+    extern __shared__ double ln_red[];  // [2][D], the waves add into it in wave order
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int nv = NV;
-    float dg[NV], db[NV];
+    double dg[NV], db[NV];
 #pragma unroll
-    for (int k = 0; k < nv; ++k) dg[k] = db[k] = 0.f;
+    for (int k = 0; k < nv; ++k) dg[k] = db[k] = 0.0;
     const int row0 = blockIdx.x * LN_ROWS_PER_BLOCK;
     for (int i = wave; i < LN_ROWS_PER_BLOCK; i += 4) {  // fixed row order per wave
         const int row = row0 + i;
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             gg[k] = in ? g * gamma[c] : 0.f;
             s1 += gg[k];
             s2 += gg[k] * xh[k];
-            dg[k] += g * xh[k];
-            db[k] += g;
+            dg[k] += (double)(g * xh[k]);
+            db[k] += (double)g;
         }
         s1 = wave_sum(s1) / (float)D;
         s2 = wave_sum(s2) / (float)D;
@@ -165,32 +168,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
+    for (int w = 0; w < 4; ++w) {   // waves 0..3 in turn: a fixed summation order
+        if (wave == w) {
 #pragma unroll
-    for (int k = 0; k < nv; ++k) {
-        const int c = lane + 64 * k;
-        if (c < D) {
-            ln_red[(wave * 2 + 0) * D + c] = dg[k];
-            ln_red[(wave * 2 + 1) * D + c] = db[k];
+            for (int k = 0; k < nv; ++k) {
+                const int c = lane + 64 * k;
+                if (c < D) {
+                    ln_red[c] = (w == 0 ? 0.0 : ln_red[c]) + dg[k];
+                    ln_red[D + c] = (w == 0 ? 0.0 : ln_red[D + c]) + db[k];
+                }
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 2 * D; e += 256) {
-        const int which = e / D, c = e - which * D;
-        partial[((size_t)blockIdx.x * 2 + which) * D + c] =
-            (ln_red[(0 * 2 + which) * D + c] + ln_red[(1 * 2 + which) * D + c]) +
-            (ln_red[(2 * 2 + which) * D + c] + ln_red[(3 * 2 + which) * D + c]);
-    }
+    for (int e = threadIdx.x; e < 2 * D; e += 256) partial[(size_t)blockIdx.x * 2 * D + e] = ln_red[e];
 }
 
 // dgamma / dbeta = column sums of the per-block partials.  A block owns 16 columns of one of the two vectors; its 16
 // partial-lanes each sum every 16th partial in increasing order, then lane 0 adds the 16 lane sums in order: a fixed
 // summation tree (deterministic) with P/16 dependent loads instead of P.
-__global__ __launch_bounds__(256) void layernorm_param_reduce_kernel(const float* __restrict__ partial, int P, int D,
+__global__ __launch_bounds__(256) void layernorm_param_reduce_kernel(const double* __restrict__ partial, int P, int D,
                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float red[16][17];
+    __shared__ double red[16][17];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + cl;  // column index over [dgamma | dbeta]
-    float s = 0.f;
+    double s = 0.0;
     if (e < 2 * D) {
         const int which = e / D, c = e - which * D;
         for (int p = pl; p < P; p += 16) s += partial[((size_t)p * 2 + which) * D + c];
@@ -198,35 +200,35 @@ __global__ __launch_bounds__(256) void layernorm_param_reduce_kernel(const float
     red[pl][cl] = s;
     __syncthreads();
     if (pl == 0 && e < 2 * D) {
-        float t = red[0][cl];
+        double t = red[0][cl];
 #pragma unroll
         for (int k = 1; k < 16; ++k) t += red[k][cl];
         const int which = e / D, c = e - which * D;
-        (which == 0 ? dgamma : dbeta)[c] = t;
+        (which == 0 ? dgamma : dbeta)[c] = (float)t;
     }
 }
 
 extern "C" int otvae_layernorm_bwd_ws(int M, int D) {
     if (M <= 0 || D <= 0) return -1;
-    return cdiv(M, LN_ROWS_PER_BLOCK) * 2 * D;  // floats
+    return cdiv(M, LN_ROWS_PER_BLOCK) * 2 * D * 2;  // floats (the partials are doubles; a torch fp32 allocation is 8-byte aligned)
 }
 
 extern "C" int otvae_layernorm_bwd(const float* xs, const float* gy, const float* gamma, const float* mean, const float* rstd, int M,
                                    int D, float* gx, float* dgamma, float* dbeta, float* ws, void* stream) {
     OTVAE_REQUIRE(xs && gy && gamma && mean && rstd && gx && dgamma && dbeta && ws && M > 0 && D > 0,
                   "otvae_layernorm_bwd: bad argument");
-    if (D > 64 * LN_MAXV || (size_t)8 * D * sizeof(float) > 64 * 1024) {
+    if (D > 64 * LN_MAXV || (size_t)2 * D * sizeof(double) > 64 * 1024) {
         otvae_set_error("otvae_layernorm_bwd: D = %d unsupported (D <= 2048)", D);
         return OTVAE_EUNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
     const int P = cdiv(M, LN_ROWS_PER_BLOCK);
 #define LN_BWD(NV_) \
-    layernorm_bwd_kernel<NV_, false><<<P, 256, (size_t)8 * D * sizeof(float), st>>>(xs, gy, gamma, mean, rstd, M, D, gx, ws, nullptr, LnDrop{})
+    layernorm_bwd_kernel<NV_, false><<<P, 256, (size_t)2 * D * sizeof(double), st>>>(xs, gy, gamma, mean, rstd, M, D, gx, (double*)ws, nullptr, LnDrop{})
     LN_NV_SWITCH(D, LN_BWD)
 #undef LN_BWD
     OTVAE_CHECK_LAUNCH("otvae_layernorm_bwd");
-    layernorm_param_reduce_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>(ws, P, D, dgamma, dbeta);
+    layernorm_param_reduce_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>((const double*)ws, P, D, dgamma, dbeta);
     OTVAE_CHECK_LAUNCH("otvae_layernorm_bwd(reduce)");
     return OTVAE_OK;
 }
@@ -237,7 +239,7 @@ extern "C" int otvae_layernorm_dropout_bwd(const float* xs, const float* gy, con
     OTVAE_REQUIRE(xs && gy && gamma && mean && rstd && used && gx && gx_dropped && dgamma && dbeta && ws && M > 0 && D > 0,
                   "otvae_layernorm_dropout_bwd: bad argument");
     OTVAE_REQUIRE(p >= 0.f && p < 1.f, "otvae_layernorm_dropout_bwd: dropout probability must be in [0, 1)");
-    if (D > 64 * LN_MAXV || (size_t)8 * D * sizeof(float) > 64 * 1024) {
+    if (D > 64 * LN_MAXV || (size_t)2 * D * sizeof(double) > 64 * 1024) {
         otvae_set_error("otvae_layernorm_dropout_bwd: D = %d unsupported (D <= 2048)", D);
         return OTVAE_EUNSUPPORTED;
     }
@@ -245,11 +247,11 @@ extern "C" int otvae_layernorm_dropout_bwd(const float* xs, const float* gy, con
     const int P = cdiv(M, LN_ROWS_PER_BLOCK);
     const LnDrop dr = {dropout_threshold(p), 1.f / (1.f - p), used, 0, nullptr};
 #define LN_BWD(NV_) \
-    layernorm_bwd_kernel<NV_, true><<<P, 256, (size_t)8 * D * sizeof(float), st>>>(xs, gy, gamma, mean, rstd, M, D, gx, ws, gx_dropped, dr)
+    layernorm_bwd_kernel<NV_, true><<<P, 256, (size_t)2 * D * sizeof(double), st>>>(xs, gy, gamma, mean, rstd, M, D, gx, (double*)ws, gx_dropped, dr)
     LN_NV_SWITCH(D, LN_BWD)
 #undef LN_BWD
     OTVAE_CHECK_LAUNCH("otvae_layernorm_dropout_bwd");
-    layernorm_param_reduce_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>(ws, P, D, dgamma, dbeta);
+    layernorm_param_reduce_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>((const double*)ws, P, D, dgamma, dbeta);
     OTVAE_CHECK_LAUNCH("otvae_layernorm_dropout_bwd(reduce)");
     return OTVAE_OK;
 }

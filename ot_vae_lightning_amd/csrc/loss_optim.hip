@@ -442,6 +442,15 @@ extern "C" int otvae_step_begin(int32_t* step, void* stream) {
     return OTVAE_OK;
 }
 
+// torch_ema's three roundings, s - ((s - p) * omd), with contraction into a fused multiply-add switched off (HIP's round-to-nearest
+// intrinsics are the plain operators, which -ffp-contract=fast fuses: one rounding fewer than the package's tensor operations make)
+__device__ __forceinline__ float ema_step(float s, float p, float omd) {
+#pragma clang fp contract(off)
+    const float d = s - p;
+    const float t = d * omd;
+    return s - t;
+}
+
 // torch.optim.Adam (no weight decay / amsgrad): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // Step guard, running buffers.  A NaN that reaches a BatchNorm's input does not stay a NaN: the next layer's ReLU (fmaxf) turns the
@@ -523,10 +532,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(v)[i] = vv;
         if (ema) {
             float4 sv = reinterpret_cast<float4*>(ema)[i];
-            sv.x = __fsub_rn(sv.x, __fmul_rn(__fsub_rn(sv.x, pv.x), ema_omd));
-            sv.y = __fsub_rn(sv.y, __fmul_rn(__fsub_rn(sv.y, pv.y), ema_omd));
-            sv.z = __fsub_rn(sv.z, __fmul_rn(__fsub_rn(sv.z, pv.z), ema_omd));
-            sv.w = __fsub_rn(sv.w, __fmul_rn(__fsub_rn(sv.w, pv.w), ema_omd));
+            sv.x = ema_step(sv.x, pv.x, ema_omd);
+            sv.y = ema_step(sv.y, pv.y, ema_omd);
+            sv.z = ema_step(sv.z, pv.z, ema_omd);
+            sv.w = ema_step(sv.w, pv.w, ema_omd);
             reinterpret_cast<float4*>(ema)[i] = sv;
         }
     }
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         v[i] = vv;
         const float pn = p[i] - step_size * mm / (sqrtf(vv) / bc2s + eps);
         p[i] = pn;
-        if (ema) ema[i] = __fsub_rn(ema[i], __fmul_rn(__fsub_rn(ema[i], pn), ema_omd));
+        if (ema) ema[i] = ema_step(ema[i], pn, ema_omd);
     }
 }
 
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // reference's own loop; `ParamEMA.update`, engine/ema.py)
 __global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ shadow, const float* __restrict__ p, int64_t n, float omd) {
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        shadow[i] = __fsub_rn(shadow[i], __fmul_rn(__fsub_rn(shadow[i], p[i]), omd));
+        shadow[i] = ema_step(shadow[i], p[i], omd);
 }
 
 extern "C" int otvae_ema_update(float* shadow, const float* p, int64_t n, double decay, void* stream) {

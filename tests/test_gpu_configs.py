@@ -481,9 +481,10 @@ def test_grouped_dilated_cnn_trains_through_the_captured_step(A):
 def test_error_behaviour(A):
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, kernel_size=5, dilation=2)   # a 9 x 9 footprint: beyond the 7 x 7 taps of the convolution kernels
-    with pytest.raises(NotImplementedError):
-        A.VAE(encoder=A.CNN(1, 16, 16, 1, capacity=4, down_sample=True), decoder=A.CNN(8, 1, 1, 16, capacity=4, up_sample=True),
-              prior=A.GaussianPrior(), ema_decay=0.999)  # torch_ema inside Lightning's hooks: refused, not silently ignored
+    # (round 4: `ema_decay` is built -- tests/test_gpu_lifetime.py::test_parameter_ema_... -- and no longer refused)
+    m_ = A.VAE(encoder=A.CNN(1, 16, 16, 1, capacity=4, down_sample=True), decoder=A.CNN(8, 1, 1, 16, capacity=4, up_sample=True),
+               prior=A.GaussianPrior(), ema_decay=0.999)
+    assert m_.ema_decay == 0.999 and m_._ema is None   # created at on_fit_start / by the engine, as in the reference
     with pytest.raises(NotImplementedError):
         A.ConvLayer(4, 4, activation="tanh")           # not among the reference's activations either (cnn.py:147)
     with pytest.raises(NotImplementedError):
@@ -759,6 +760,13 @@ def test_config5_conditional_vit_vae_at_the_yaml_shape_vs_oracle(A):
     prior_loss = prior_l.mean() / float(x[0].numel())
     recon = torch.nn.functional.mse_loss(preds, x)
     (recon + prior_loss).backward()
+    # the same step in float64: the truth both fp32 sides are measured against
+    p64 = {role: {k: v.detach().double().requires_grad_(True) for k, v in pcpu[role].items()} for role in ("enc", "dec")}
+    mw64, lw64 = mu_w.double().requires_grad_(True), ls_w.double().requires_grad_(True)
+    h64 = O.vit_forward(x.double(), p64["enc"], **vit("enc"))
+    z64, prior_l64 = O.cond_gaussian_prior_encode(h64, eps.double(), mw64, lw64, labels, 0.1, 0, 0)
+    preds64 = O.vit_forward(z64, p64["dec"], **vit("dec"))
+    (torch.nn.functional.mse_loss(preds64, x.double()) + prior_l64.mean() / float(x[0].numel())).backward()
     # product: the captured step
     nets = {}
     for role in ("enc", "dec"):
@@ -775,21 +783,30 @@ def test_config5_conditional_vit_vae_at_the_yaml_shape_vs_oracle(A):
     torch.cuda.synchronize()
     rep.check("loss [total, recon, prior]", out, torch.stack([recon + prior_loss, recon, prior_loss]).detach(), 1e-5)
     rep.check("latents", tr.latents, z.detach(), 1e-5)
-    names, got, want = [], [], []
-    for pre, net, ref in (("encoder.", model.encoder, pcpu["enc"]), ("decoder.", model.decoder, pcpu["dec"])):
+    names, got, want, truth = [], [], [], []
+    for pre, net, ref, r64 in (("encoder.", model.encoder, pcpu["enc"], p64["enc"]), ("decoder.", model.decoder, pcpu["dec"], p64["dec"])):
         for k, p_ in net.named_parameters():
             if ref[k].grad is None:
                 continue
             names.append(pre + k)
             got.append(p_._otvae_grad_view())
             want.append(ref[k].grad)
-    for k, p_, ref in (("prior._mu.weight", prior._mu.weight, mw), ("prior._log_std.weight", prior._log_std.weight, lw)):
+            truth.append(r64[k].grad)
+    for k, p_, ref, r64 in (("prior._mu.weight", prior._mu.weight, mw, mw64), ("prior._log_std.weight", prior._log_std.weight, lw, lw64)):
         names.append(k)
         got.append(p_._otvae_grad_view())
         want.append(ref.grad)
-    # measured at this shape: the LayerNorm in front of the decoder's transformer (one latent token + 64 learned tokens per image,
-    # its parameter gradients sum 64 x 65 x 256 products in fp32 on both sides) differs by 4.7e-3 in relative L2
-    rep.check_grads("gradients (captured step)", got, want, names, tol_l2=8e-3, tol_max=1e-2)
+        truth.append(r64.grad)
+    # Round 3 bounded this at 8e-3 / 1e-2 because ONE tensor -- the LayerNorm in front of the decoder's transformer, whose parameter
+    # gradients sum 64 x 65 x 256 products in fp32 on both sides -- sat 4.7e-3 from the fp32 oracle.  Now both fp32 sides are held to
+    # the float64 truth: every tensor's bound is the standing 2e-3 / 5e-3 or 1.5x the reference arithmetic's own fp32 error on it
+    # KNOWN GAP, measured (round 4, gpurun_out/parity_report.txt): the two parameters of that one LayerNorm sit 4.5e-3 / 2.6e-3 (rel L2)
+    # from the truth where the reference's fp32 arithmetic sits 2.9e-4 / 1.0e-3.  Both are sums over 64 x 65 rows that cancel to a
+    # small remainder (the reference's own 1e-3 shows the conditioning); accumulating them in fp64 (csrc/layernorm.hip, this round)
+    # did not move the number, so the excess is in the per-row gradient that arrives from the transformer's first layer, not in
+    # the sum.  Not diagnosed further; every other tensor of the step holds the rule.
+    known = {"decoder.positional_embed.LayerNorm.weight": (8e-3, 1e-2), "decoder.positional_embed.LayerNorm.bias": (8e-3, 1e-2)}
+    rep.check_grads_vs_truth("gradients (captured step)", got, want, truth, names, known=known)
     tr.close()
     rep.finish()
 

@@ -46,6 +46,49 @@ class Report:
         if not ok:
             self.failed.append((name, err, tol))
 
+    def check_vs_truth(self, name, got, ref32, truth, floor=0.0, contract=TOL32, factor=1.5):
+        """The bound VERDICT r3 #7 prescribes instead of a constant fitted to the measurement: with the fp64 truth of the quantity
+        computed in the test, |hip - truth| <= max(contract * scale, factor * |reference_fp32 - truth|) -- the north-star's fp32
+        contract (1e-4 relative) or, where fp32 itself cannot hold that, 1.5x the reference's OWN fp32 error on the same inputs.
+        scale = max(|truth|_inf, floor); both errors are recorded."""
+        t = truth.detach().double().cpu()
+        scale = max(t.abs().max().item(), floor, 1e-30)
+        e_hip = (got.detach().double().cpu() - t).abs().max().item() / scale
+        e_ref = (ref32.detach().double().cpu() - t).abs().max().item() / scale
+        tol = max(contract, factor * e_ref)
+        ok = e_hip <= tol and math.isfinite(e_hip)
+        self.rows.append((f"{name} vs fp64 truth [reference fp32 vs truth: {e_ref:.2e}]", e_hip, tol, ok))
+        if not ok:
+            self.failed.append((name, e_hip, tol))
+
+    def check_grads_vs_truth(self, name, got, ref32, truth, names=None, contract_l2=GRAD_TOL_L2, contract_max=GRAD_TOL_MAX, factor=1.5,
+                             known=None):
+        """``check_grads`` with the evidence-based bound of ``check_vs_truth``: per tensor, HIP and the fp32 reference are both
+        measured against the fp64 truth (same floors as ``check_grads``), and the tensor's bound is the standing contract or
+        ``factor`` x the reference's own fp32 error on it, whichever is larger."""
+        got, ref32, truth = ([t.detach().double().cpu() for t in lst] for lst in (got, ref32, truth))
+        rms_scale = max(float(b.norm()) / max(b.numel(), 1) ** 0.5 for b in truth)
+        max_scale = max(float(b.abs().max()) for b in truth)
+        worst = (0.0, 1.0, 0.0, "")
+        for i, (a, r, b) in enumerate(zip(got, ref32, truth)):
+            n = b.numel() ** 0.5
+            d2, dm = max(float(b.norm()), 1e-2 * rms_scale * n, 1e-30), max(float(b.abs().max()), 1e-2 * max_scale, 1e-30)
+            h2, hm = float((a - b).norm()) / d2, float((a - b).abs().max()) / dm
+            r2, rm = float((r - b).norm()) / d2, float((r - b).abs().max()) / dm
+            t2, tm = max(contract_l2, factor * r2), max(contract_max, factor * rm)
+            tag = f"{name}: {names[i] if names else i}"
+            if known and names and names[i] in known:   # a documented, measured accuracy gap: its own (looser) bound, reported as such
+                t2, tm = known[names[i]]
+                self.rows.append((tag + f" KNOWN GAP (rel L2) [reference fp32: {r2:.2e}]", h2, t2, h2 <= t2))
+            if not (h2 <= t2 and hm <= tm and math.isfinite(h2) and math.isfinite(hm)):
+                self.failed.append((tag, (h2, hm), (t2, tm)))
+                self.rows.append((tag + f" (rel L2) [reference fp32: {r2:.2e}]", h2, t2, h2 <= t2))
+                self.rows.append((tag + f" (max) [reference fp32: {rm:.2e}]", hm, tm, hm <= tm))
+            if max(h2 / t2, hm / tm) > worst[0] / worst[1]:
+                worst = (max(h2, hm), t2 if h2 / t2 >= hm / tm else tm, max(r2, rm), tag)
+        self.rows.append((f"{name}: {len(got)} tensors vs fp64 truth, tightest [{worst[3]}; reference fp32 there: {worst[2]:.2e}]",
+                          worst[0], worst[1], worst[0] <= worst[1]))
+
     def check_grads(self, name, got, want, names=None, tol_l2=GRAD_TOL_L2, tol_max=GRAD_TOL_MAX):
         """Element-wise gradient comparison, tensor by tensor (per-parameter L2 NORMS pass a permuted or
         sign-flipped gradient).  Per tensor: |got - want|_2 / |want|_2 and max|got - want| / max|want|, each against the
@@ -211,6 +254,26 @@ def test_attention_vs_reference_golden(A):
 
 
 # ------------------------------------------------------------------------------------------------ G3 small CNN
+def _cnn_small_truth(nm, cap, res, g):
+    """float64 parameter gradients of the small CNN (oracle, CPU) on the golden's input / output gradient and the same weight fill"""
+    import otvae_oracle as O
+    if nm == "enc":
+        arch = O.cnn_arch(1, 16, 16, 1, capacity=cap, down_sample=True, residual=res)
+        shell = __import__("ot_vae_lightning_amd").CNN(1, 16, 16, 1, capacity=cap, down_sample=True, residual=res)
+    else:
+        arch = O.cnn_arch(8, 1, 1, 16, capacity=cap, up_sample=True, residual=res)
+        shell = __import__("ot_vae_lightning_amd").CNN(8, 1, 1, 16, capacity=cap, up_sample=True, residual=res)
+    sd = shell.state_dict()
+    fill_state_dict(sd)
+    names = [k for k, _ in shell.named_parameters()]
+    p64 = {k: v.detach().double().contiguous().clone() for k, v in sd.items()}
+    for k in names:
+        p64[k].requires_grad_(True)
+    y = O.cnn_forward(g["x"].double(), p64, arch)
+    y.backward(g["gy"].double())
+    return {k: p64[k].grad for k in names}
+
+
 @pytest.mark.parametrize("residual", ["add", "None", "cat"])
 def test_cnn_small_vs_reference_golden(A, residual):
     z = load_golden("cnn_small.npz")
@@ -231,8 +294,13 @@ def test_cnn_small_vs_reference_golden(A, residual):
         rep.check(f"{nm}/y", y, g["y"])
         rep.check(f"{nm}/gx", x.grad, g["gx"], tol=2e-4)
         gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith("grad/"))
+        # fp64 truth of every parameter gradient from the oracle on the same deterministic weights: the bound is the fp32 contract
+        # or 1.5x the REFERENCE's own fp32 error (the golden), not a constant (round 3: 5e-4 against a measured 4.943e-4)
+        truth = _cnn_small_truth(nm, cap, res, g)
         for k, p in net.named_parameters():
-            rep.check(f"{nm}/grad/{k}", p.grad, g[f"grad/{k}"], tol=5e-4, floor=3e-3 * gscale)
+            # contract: the standing 5e-4 of these per-layer gradient checks -- but against the TRUTH, where the worst tensor measures
+            # 1.3e-4 (the 4.9e-4 of round 3 was mostly the golden's own fp32 error: 4.9e-5 ... 2.0e-4 from the truth)
+            rep.check_vs_truth(f"{nm}/grad/{k}", p.grad, g[f"grad/{k}"], truth[k], floor=3e-3 * gscale, contract=5e-4)
         for k, b in net.named_buffers():
             if not k.endswith("num_batches_tracked"):
                 rep.check(f"{nm}/buf/{k}", b, g[f"buf/{k}"])
@@ -1628,7 +1696,11 @@ def test_attention_slice_layouts_vs_float64(A, T, H, C):
     out.backward(gout.cuda())
     rep.check("out", out, ref.detach(), 1e-5)
     w = 2 * H * C
-    rep.check("d/dq, d/dk", x.grad[:, :w], ref_in.grad[:, :w], 2e-5, floor=float(ref_in.grad[:, :w].abs().max()))
+    # the same formula in fp32 (what the reference computes) for the evidence-based bound: round 3 held this gradient to 2e-5, a
+    # constant 1 % above the measured 1.965e-5
+    ref32_in = qkv.clone().requires_grad_(True)
+    oracle.qkv_attention(ref32_in, H).backward(gout)
+    rep.check_vs_truth("d/dq, d/dk", x.grad[:, :w], ref32_in.grad[:, :w], ref_in.grad[:, :w])
     rep.check("d/dv", x.grad[:, w:], ref_in.grad[:, w:], 1e-5)
     rep.finish()
 
@@ -1814,10 +1886,13 @@ def test_codebook_prior_vs_reference_golden(A):
         # reference's fp32 value sits 3.0e-4 from the fp64 truth, the HIP value 3.5e-4, on opposite sides -- hence up to 7e-4
         # between them and the 2e-3 bound against the golden.  1e-4 is not attainable for this quantity in fp32 by either.
         e_hip, e_ref = rel_err(loss.double().cpu(), truth[kind]), rel_err(g[f"eval/loss_{kind}"].double(), truth[kind])
-        rep.rows.append((f"eval/loss_{kind}: HIP vs fp64 truth", e_hip, 1e-3, e_hip < 1e-3))
-        rep.rows.append((f"eval/loss_{kind}: reference fp32 golden vs fp64 truth (for comparison)", e_ref, 1e-3, True))
-        assert e_hip < 1e-3 and e_hip <= 2.0 * e_ref + 1e-6, (kind, e_hip, e_ref)
-        rep.check(f"eval/loss_{kind} vs reference golden", loss, g[f"eval/loss_{kind}"], 2e-3)
+        # the rule of VERDICT r3 #7: the fp32 contract or 1.5x the reference's own fp32 error against the fp64 truth (round 3 had
+        # "< 1e-3 and <= 2x the reference's", and 2e-3 against the golden)
+        tol = max(TOL32, 1.5 * e_ref)
+        rep.rows.append((f"eval/loss_{kind}: HIP vs fp64 truth [reference fp32 vs truth: {e_ref:.2e}]", e_hip, tol, e_hip <= tol))
+        assert e_hip <= tol, (kind, e_hip, e_ref)
+        # against the golden itself nothing tighter than the two errors' sum can hold (they sit on opposite sides of the truth)
+        rep.check(f"eval/loss_{kind} vs reference golden", loss, g[f"eval/loss_{kind}"], 1.05 * (tol + e_ref))
     rep.check("eval/z", z, g["eval/z"], 1e-6)
     xg = xe.clone().requires_grad_(True)                      # the entropy losses are differentiable (otvae_codebook_probs_bwd)
     prior(xg, step=100)[1].sum().backward()
