@@ -33,25 +33,33 @@ def main(all_calls=False):
     for ci, c in enumerate(trace):
         jobs = c["jobs"]
         desc = []
-        by = fl = 0
+        by = fl = flx = flp = 0
         for i, j in enumerate(jobs):
             g = dict(zip(bench.GEOM_FIELDS, j["geom"]))
-            b_, f_ = bench._job_algorithmic(j)
+            b_, f_ = bench._job_algorithmic(j)      # bytes, LIVE flops (operands that exist; round 3 printed the padded count)
             by += b_
             fl += f_
+            flx += bench._job_flops(j)["executed"]
+            flp += bench._job_flops(j)["padded"]
             desc.append(f"{KIND[j['kind']]}{'*' if c['packed_mask'] >> i & 1 else ''} {g['Cs']}->{g['Cn']} k{g['KH']} s{g['stride']} up{g['up']} "
                         f"{g['Hs']}x{g['Ws']}->{g['Ho']}x{g['Wo']}")
-        rows.append((ci, c["uniform_tap"], c["packed_mask"], by, fl, " | ".join(desc)))
+        rows.append((ci, c["uniform_tap"], c["packed_mask"], by, (fl, flx, flp), " | ".join(desc)))
     # time every call alone (re-issued on synthetic tensors through bench's builder, one call per graph)
-    for ci, ut, mask, by, fl, desc in rows:
+    print("FLOP columns: live (operands that exist) / executed by the kernel (dead taps dropped) / padded (2*y*KH*KW*Cs, rounds 1-3); TF/s and the\n"
+          "fraction of the 157.3 TFLOP/s fp32 matrix peak are for the LIVE count; no launch may exceed 1.0 of a hardware peak")
+    worst = 0.0
+    for ci, ut, mask, by, (fl, flx, flp), desc in rows:
         c = trace[ci]
         one = dict(jobs=c["jobs"], packed_mask=(1 << len(c["jobs"])) - 1, uniform_tap=1)
         t = time_call(lib, one)
         each = ""
         if len(c["jobs"]) > 1 and mask:
             each = "  alone: " + " ".join(f"{time_call(lib, dict(jobs=[j])) * 1e6:.1f}" for j in c["jobs"])
-        print(f"call {ci:3d} ut={ut:2d} mask={mask:04b} {t*1e6:7.1f} us  {by/1e6:7.2f} MB {fl/1e9:6.3f} GF  "
-              f"{by/t/1e9:7.0f} GB/s {fl/t/1e12:6.1f} TF/s  {desc}{each}", flush=True)
+        worst = max(worst, fl / t / 1e12 / bench.FP32_MFMA_PEAK_TFLOPS, by / t / 1e9 / bench.HBM_PEAK_GBS)
+        print(f"call {ci:3d} ut={ut:2d} mask={mask:04b} {t*1e6:7.1f} us  {by/1e6:7.2f} MB {fl/1e9:6.3f}/{flx/1e9:6.3f}/{flp/1e9:6.3f} GF  "
+              f"{by/t/1e9:7.0f} GB/s {fl/t/1e12:6.1f} TF/s ({fl/t/1e12/bench.FP32_MFMA_PEAK_TFLOPS:5.3f} of peak; padded convention "
+              f"{flp/t/1e12/bench.FP32_MFMA_PEAK_TFLOPS:5.3f})  {desc}{each}", flush=True)
+    print(f"largest fraction of a hardware peak over all calls (live FLOPs / algorithmic bytes): {worst:.3f}")
 
 
 def time_call(lib, c, iters=20):

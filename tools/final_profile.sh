@@ -39,7 +39,7 @@ tail -2 "$O/pytest_gpu.log"
 cp gpurun_out/parity_report.txt "$O/parity_report.txt" 2>/dev/null || true
 # reduce the raw traces here (gpurun merges at most 64 MiB back) and drop them
 export OTVAE_PROFILES_OUT="$O/profiles"; mkdir -p "$OTVAE_PROFILES_OUT"
-T=${OTVAE_ROUND_TAG:-r03}
+T=${OTVAE_ROUND_TAG:-r04}
 python3 tools/summarize_profiles.py "$O/trace" ${T}_final
 python3 tools/summarize_profiles.py --replay "$O/trace" ${T}_final
 python3 tools/summarize_profiles.py --replay "$O/trace_sk" ${T}_sinkhorn_wl

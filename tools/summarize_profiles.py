@@ -59,6 +59,7 @@ def replay_stats(src, tag, steps=20):
     wall = int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])
     out = os.path.join(OUT, f"{tag}_replay_kernel_stats.csv")
     with open(out, "w") as w:
+        w.write("# csrc_sha256=%s\n" % csrc_digest())
         w.write("# %d consecutive graph replays: %d launches/step, kernel-busy %.3f ms/step, wall %.3f ms/step\n" %
                 (steps, len(seg) // steps, tot / 1e6 / steps, wall / 1e6 / steps))
         w.write("kernel,calls_per_step,avg_us,ms_per_step,percent\n")
