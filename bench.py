@@ -193,10 +193,14 @@ def parity_check(A, batch=PER_GPU_BATCH):
 #               Says how close the kernel runs to ITS OWN instructions' nominal rate (rounds 1-3 reported only this one).
 #   ALGORITHM -- the fewest vector operations ANY kernel needs per pair, at the cycle table's best rates (v_exp_f32: 8 issue cycles per
 #               wave-instruction; v_pk_fma_f32: 4 cycles for two FMAs).  One head channel: forward = score 1 FMA + 1 exp + value 1 FMA +
-#               row sum 1 = 1 exp + 3 FMA (VERDICT r3 #2d) -> 8 + 3 * 2 = 14 cycles; backward (recompute p = exp(s - lse), dP = go v,
-#               dS = p (dP - delta), dv += p go, dk += dS q, dq += dS k) = 1 exp + 7 FMA -> 8 + 7 * 2 = 22 cycles.
+#               row sum 1 = 1 exp + 3 FMA (VERDICT r3 #2d) -> 8 + 3 * 2 = 14 cycles.  Backward: the textbook pass (recompute p, dP = go v,
+#               dS = p (dP - delta), dv += p go, dk += dS q, dq += dS k) is 1 exp + 7 FMA = 22 cycles, but dq needs no pair work at all
+#               when the forward keeps the per-query moments sum_s p (v - out) k (head widths <= 2; csrc/attention.hip), which leaves
+#               score 1 + exp + dP 1 + dS 1 + dv 1 + dk 1 = 1 exp + 5 FMA -> 8 + 5 * 2 = 18 cycles: the fewest known, and what this
+#               kernel's stream has, so for the backward the two bounds coincide and `frac` says how far the kernel is from
+#               issuing them at the table's rates.
 ISSUE_BOUND_TPAIRS = 1024 * 2.4e9 * 64 / 18.0 / 1e12
-ALG_ISSUE_CYCLES_PER_PAIR_C1 = {"fwd": 8 + 3 * 2, "bwd": 8 + 7 * 2}
+ALG_ISSUE_CYCLES_PER_PAIR_C1 = {"fwd": 8 + 3 * 2, "bwd": 8 + 5 * 2}
 ALG_ISSUE_BOUND_TPAIRS = {k: 1024 * 2.4e9 * 64 / v / 1e12 for k, v in ALG_ISSUE_CYCLES_PER_PAIR_C1.items()}
 
 
@@ -254,8 +258,35 @@ def time_dominant_kernel(A, trainer, iters=30):
     tokens = n * 1024
     alg_bytes = tokens * 9 * 4
     pair_evals = n * 1024 * 1024
+    # the same stage's FORWARD launch (attn_stage_fwd_kernel<1,4,true>), for the 1 exp + 3 FMA bound
+    rows_f = C.c_int(0)
+    L.check(lib.otvae_attn_stage_plan(n, t, heads, c, 1, C.byref(rows_f)), "otvae_attn_stage_plan")
+    part_f = torch.empty(rows_f.value, 2, 1, device="cuda", dtype=torch.float64)
+    y_f, res_f = torch.empty(n, t, 1, device="cuda"), torch.randn(n, t, 1, device="cuda")
+
+    def launch_f():
+        L.check(lib.otvae_attn_stage_fwd(L.ptr(x), L.ptr(one), L.ptr(zero), L.ptr(wq), L.ptr(wp), L.ptr(res_f), n, t, heads, c, 1.0 / c, None,
+                                         L.ptr(out), L.ptr(lse), L.ptr(aux), L.ptr(y_f), L.ptr(part_f), L.stream()), "otvae_attn_stage_fwd")
+
+    for _ in range(3):
+        launch_f()
+    torch.cuda.synchronize()
+    graph_f = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph_f, capture_error_mode="thread_local"):
+        for _ in range(iters):
+            launch_f()
+    for _ in range(5):
+        graph_f.replay()
+    torch.cuda.synchronize()
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    f0.record()
+    for _ in range(4):
+        graph_f.replay()
+    f1.record()
+    torch.cuda.synchronize()
+    ms_f = f0.elapsed_time(f1) / (4 * iters)
     return {"kernel": "attn_stage_bwd_kernel<1,4,true> (T=1024,H=1,C=1)", "ms": ms, "alg_bytes": alg_bytes, "pair_evals": pair_evals,
-            "pmc_traffic_bytes": pmc_traffic("attn_stage_bwd_kernel<1, 4, true>")}
+            "pmc_traffic_bytes": pmc_traffic("attn_stage_bwd_kernel<1, 4, true>"), "ms_fwd": ms_f}
 
 
 # Issue model of the head-width-2 attention kernels (T = 256, 4 heads: encoder block 0 / decoder block 3), from the ISA of the
@@ -747,8 +778,14 @@ def main():
             line["roofline_issue"] = {"bound": "valu_issue", "kernel": longest["kernel"], "achieved": round(tp, 3),
                                       "peak": round(ALG_ISSUE_BOUND_TPAIRS["bwd"], 3), "unit": "T (query,key) pairs/s",
                                       "frac": round(tp / ALG_ISSUE_BOUND_TPAIRS["bwd"], 4),
-                                      "peak_definition": "algorithmic minimum: 1 v_exp_f32 (8 issue cycles) + 7 FMA as packed pairs (2 cycles each) per pair",
+                                      "peak_definition": "algorithmic minimum: 1 v_exp_f32 (8 issue cycles) + 5 FMA as packed pairs (2 cycles each) per pair (dq from the forward's moments)",
                                       "peak_own_isa": round(ISSUE_BOUND_TPAIRS, 3), "frac_own_isa": round(tp / ISSUE_BOUND_TPAIRS, 4)}
+            tpf = longest["pair_evals"] / longest["ms_fwd"] / 1e9
+            line["roofline_issue_fwd"] = {"bound": "valu_issue", "kernel": "attn_stage_fwd_kernel<1,4,true> (T=1024,H=1,C=1)",
+                                          "avg_launch_ms": round(longest["ms_fwd"], 4), "achieved": round(tpf, 3),
+                                          "peak": round(ALG_ISSUE_BOUND_TPAIRS["fwd"], 3), "unit": "T (query,key) pairs/s",
+                                          "frac": round(tpf / ALG_ISSUE_BOUND_TPAIRS["fwd"], 4),
+                                          "peak_definition": "algorithmic minimum: 1 v_exp_f32 (8 issue cycles) + 3 FMA as packed pairs (2 cycles each) per pair"}
         try:
             line["roofline_issue_c2"] = {"bound": "valu_issue", **time_attention_c2(A)}
         except Exception as e:  # noqa: BLE001
