@@ -790,6 +790,7 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
     // (kept in registers: this lane's queries are also its keys of phase B, so the three gradients of a token are
     // stored together at the end -- whole q|k|v rows instead of three strided partial-line passes)
     float dqv[QPT][C];
+    constexpr bool PHB = !FUSED && !AUX;   // the bare kernel's pair passes with the consistent delta (phase A, non-AUX branch)
     if constexpr (AUX) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -852,6 +853,19 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
             }
     } else {
         float q[QPT][C], go[QPT][C], dq[QPT][C], ls[QPT], dl[QPT];
+        // CONSISTENT delta (round 4; the bare kernel only, see below).  dS = p (dP - delta) with delta = gout . out taken from the
+        // FORWARD pass's output: when a row's softmax is peaked (p* -> 1) the true dP* - delta is (1 - p*) x something, while the
+        // rounding of `out` (accumulated by another kernel) and of this pass's dP* are independent, so the difference carries an
+        // absolute error eps |dP| instead of eps (1 - p*) |dP| -- and it is the same sign for every key of the row, i.e. an error
+        // along sum_s p k_s in dq (and along q_t in every dk).  Measured on the vit.yaml step (tools/diag/vit_ln_grad.py): dq 3.4e-4
+        // from the float64 truth where torch's fp32 softmax backward (which subtracts sum_s p dP formed from the SAME p and dP) is
+        // at 7.6e-5, and -- the errors being aligned -- a LayerNorm parameter gradient downstream 4.5e-3 off against 2.9e-4.
+        // Here the residual r = sum_s p (dP - delta) (zero for a consistent delta), sum_s p and sum_s p k ride along the pass:
+        // delta' = delta + r / sum p is what this pass's own p and dP define, dq is corrected by - (r / sum p) sum_s p k (the two
+        // terms share their rounding, so the correction cancels the error instead of adding one), and the record's delta is
+        // replaced by delta' for phase B.
+        constexpr bool FIXD = PHB;
+        float rs[FIXD ? QPT : 1], sp[FIXD ? QPT : 1], bk[FIXD ? QPT : 1][FIXD ? C : 1];
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const float* r = qg + (size_t)(t0 + i) * RQG;
@@ -860,9 +874,11 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
                 q[i][c] = r[c] * LOG2E;
                 go[i][c] = r[C + c];
                 dq[i][c] = 0.f;
+                if constexpr (FIXD) bk[i][c] = 0.f;
             }
             ls[i] = r[2 * C];
             dl[i] = r[2 * C + 1];
+            if constexpr (FIXD) rs[i] = sp[i] = 0.f;
         }
 #pragma unroll 4
         for (int s = 0; s < T; ++s) {
@@ -875,16 +891,38 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
             }
 #pragma unroll
             for (int i = 0; i < QPT; ++i) {
-                float sc = -ls[i], dp = -dl[i];
+                // FIXD: the score and dP chains are spelled exactly as phase B spells them (same operands, same order, dP started at
+                // zero and delta subtracted afterwards), so that both phases hold bit-identical p and dP: delta' is only
+                // consistent with the values it was formed from
+                float sc = -ls[i], dp = FIXD ? 0.f : -dl[i];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     sc = fmaf(q[i][c], kk[c], sc);
                     dp = fmaf(go[i][c], vv[c], dp);
                 }
-                const float ds = EXP2(sc) * dp;
+                if constexpr (FIXD) dp -= dl[i];
+                const float pp = EXP2(sc);
+                const float ds = pp * dp;
 #pragma unroll
                 for (int c = 0; c < C; ++c) dq[i][c] = fmaf(ds, kk[c], dq[i][c]);
+                if constexpr (FIXD) {
+                    rs[i] += ds;
+                    sp[i] += pp;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) bk[i][c] = fmaf(pp, kk[c], bk[i][c]);
+                }
             }
+        }
+        if constexpr (FIXD) {
+            __syncthreads();   // every lane has read its queries' delta
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                const float corr = rs[i] / sp[i];
+#pragma unroll
+                for (int c = 0; c < C; ++c) dq[i][c] = fmaf(-corr, bk[i][c], dq[i][c]);
+                s_qg[((size_t)sl * T + t0 + i) * RQG + 2 * C + 1] = dl[i] + corr;
+            }
+            __syncthreads();   // phase B reads the corrected records
         }
 #pragma unroll
         for (int i = 0; i < QPT; ++i)
@@ -904,7 +942,8 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
             const float* r1 = r0 + RKV;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                k2[j][c] = (f2){r0[c] * LOG2E, r1[c] * LOG2E};
+                // (PHB: the bare kernel with a consistent delta keeps the keys unscaled and scales the QUERY by log2 e, as phase A does)
+                k2[j][c] = PHB ? (f2){r0[c], r1[c]} : (f2){r0[c] * LOG2E, r1[c] * LOG2E};
                 v2[j][c] = (f2){r0[C + c], r1[C + c]};
                 dk2[j][c] = dv2[j][c] = (f2){0.f, 0.f};
             }
@@ -912,21 +951,23 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
 #pragma unroll 4
         for (int t = 0; t < T; ++t) {
             const float* r = qg + (size_t)t * RQG;
-            f2 qq[C], gg[C];
+            f2 qq[C], gg[C], ql[PHB ? C : 1];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 qq[c] = (f2){r[c], r[c]};
                 gg[c] = (f2){r[C + c], r[C + c]};
+                if constexpr (PHB) ql[c] = (f2){r[c] * LOG2E, r[c] * LOG2E};
             }
             const float nls = -r[2 * C], ndl = -r[2 * C + 1];
 #pragma unroll
             for (int j = 0; j < QP; ++j) {
-                f2 sc = (f2){nls, nls}, dp = (f2){ndl, ndl};
+                f2 sc = (f2){nls, nls}, dp = PHB ? (f2){0.f, 0.f} : (f2){ndl, ndl};
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    sc = __builtin_elementwise_fma(k2[j][c], qq[c], sc);
-                    dp = __builtin_elementwise_fma(v2[j][c], gg[c], dp);
+                    sc = __builtin_elementwise_fma(PHB ? ql[c] : qq[c], k2[j][c], sc);
+                    dp = __builtin_elementwise_fma(gg[c], v2[j][c], dp);
                 }
+                if constexpr (PHB) dp += (f2){ndl, ndl};
                 const f2 p = (f2){EXP2(sc.x), EXP2(sc.y)};
                 const f2 ds = p * dp;
 #pragma unroll
@@ -989,7 +1030,7 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
             const float* r = kv + (size_t)(t0 + i) * RKV;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                k[i][c] = r[c] * LOG2E;
+                k[i][c] = PHB ? r[c] : r[c] * LOG2E;   // (PHB: phase A's spelling of the score, see there)
                 v[i][c] = r[C + c];
                 dk[i][c] = dv[i][c] = 0.f;
             }
@@ -997,21 +1038,23 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
 #pragma unroll 4
         for (int t = 0; t < T; ++t) {
             const float* r = qg + (size_t)t * RQG;
-            float qq[C], gg[C];
+            float qq[C], gg[C], ql[PHB ? C : 1];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 qq[c] = r[c];
                 gg[c] = r[C + c];
+                if constexpr (PHB) ql[c] = r[c] * LOG2E;
             }
             const float ls = r[2 * C], dl = r[2 * C + 1];
 #pragma unroll
             for (int i = 0; i < QPT; ++i) {
-                float sc = -ls, dp = -dl;
+                float sc = -ls, dp = PHB ? 0.f : -dl;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    sc = fmaf(k[i][c], qq[c], sc);
-                    dp = fmaf(v[i][c], gg[c], dp);
+                    sc = fmaf(PHB ? ql[c] : qq[c], k[i][c], sc);
+                    dp = fmaf(gg[c], v[i][c], dp);
                 }
+                if constexpr (PHB) dp -= dl;
                 const float p = EXP2(sc);
                 const float ds = p * dp;
 #pragma unroll
