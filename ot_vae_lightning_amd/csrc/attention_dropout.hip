@@ -147,14 +147,31 @@ __global__ __launch_bounds__(256) void attn_drop_bwd_kernel(AttnIn in, const flo
         L2 = lse[s * Tq + t] * LOG2E;
         rh = row_hash(ck, (uint32_t)(s * Tq + t));
         const int jend = causal ? t + 1 : Tk;
+        // consistent delta (round 4, as in csrc/attention.hip phase A): delta = gout . out comes from the forward pass's output, whose
+        // rounding is independent of this pass's p and dP; on a peaked row dP* - delta then carries an absolute error eps |dP| where
+        // the true value is (1 - p*) x something, the same sign for every key.  r = sum p (dP - delta) (zero for a consistent delta),
+        // sum p and sum p k ride along; delta' = delta + r / sum p goes into the query record for phase B (which recomputes p and dP
+        // with the same operands in the same order: bit-identical), dq is corrected by - (r / sum p) sum p k.
+        float rsum = 0.f, psum = 0.f, bk[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) bk[c] = 0.f;
         for (int j = 0; j < jend; ++j) {
             const float* r = rec + j * RS;
             const float p = EXP2(fmaf(dotr<C>(q, r), qs, -L2));
             const float dp = keep_pair(rh, j, thresh) ? dotr<C>(g, r + C) * inv_keep : 0.f;
             const float ds = p * (dp - delta);
+            rsum += ds;
+            psum += p;
 #pragma unroll
-            for (int c = 0; c < C; ++c) dq[c] = fmaf(ds, r[c], dq[c]);
+            for (int c = 0; c < C; ++c) {
+                dq[c] = fmaf(ds, r[c], dq[c]);
+                bk[c] = fmaf(p, r[c], bk[c]);
+            }
         }
+        const float corr = psum > 0.f ? rsum / psum : 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) dq[c] = fmaf(-corr, bk[c], dq[c]);
+        delta += corr;
         float* gqp = gr.gq + n * gr.q_img + (long)t * gr.q_row + h * C;
 #pragma unroll
         for (int c = 0; c < C; ++c) gqp[c] = dq[c] * scale;
