@@ -129,7 +129,7 @@ class GraphedNelbo:
         cap = _Capture()
         cap.key, cap.engine = self._key(batch), engine
         cap.graphs = GraphSet(engine.device)
-        weakref.finalize(cap, GraphSet.release, cap.graphs)
+        weakref.finalize(cap, GraphSet.release, cap.graphs).atexit = False   # (see HipTrainer: not at interpreter exit)
         cap.params = engine.params
         cap.seed = torch.tensor([1.0, 0.0, 0.0], device=engine.device)
         engine._seed = cap.seed

@@ -189,6 +189,9 @@ class HipTrainer:
         # dropped without close() releases them through the same ordered path (engine/lifetime.py)
         self._gs = GraphSet(dev)
         self._finalizer = weakref.finalize(self, GraphSet.release, self._gs)
+        # not at interpreter exit: no capture can be open there, and what is still alive then goes down with the process as it
+        # always has (the ordered path is for owners that die while the program runs)
+        self._finalizer.atexit = False
         self._captured = False
         self.n_steps = 0
         if self.step_guard is not None:
