@@ -17,12 +17,13 @@ Rules enforced here:
 * graphs are destroyed only by ``_destroy``: the device is synchronised first and the calling thread has no capture open;
 * ``GraphSet.release()`` asked for while a capture is open (an owner dropped by reference count or by the collector inside
   somebody's capture) PARKS the graphs; they are destroyed at the next safe point (``drain()``: the start of the next capture,
-  the next ``release`` / ``close`` outside a capture, interpreter exit);
+  the next ``release`` / ``close`` outside a capture);
 * every capture of this package runs inside ``capture_guard()``: parked graphs are destroyed before the capture begins and the
   cyclic collector is switched off until it ends, so that no destructor of a foreign object graph (a user's own dropped
   ``CUDAGraph`` in a cycle) can run inside it either;
 * owners attach ``weakref.finalize(owner, GraphSet.release, graphset)``: an owner that is dropped without ``close()`` releases
-  its graphs through the same ordered path the moment it dies.
+  its graphs through the same ordered path the moment it dies (the finalizers are NOT run at interpreter exit: no capture can be
+  open there, and what is still alive then goes down with the process as it always has).
 """
 from __future__ import annotations
 
