@@ -781,16 +781,19 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
         n = bn0 + dn;
         h = hs - dn * H;
     }
-    if (!FUSED || active) {
+    // (declared ahead of the `active` sections: phase A and phase B are separate sections since round 4, with a block barrier between
+    // them that EVERY thread reaches; an idle lane's pointers are never dereferenced)
     const float* kv = s_kv + (size_t)sl * T * RKV;
     const float* qg = s_qg + (size_t)sl * T * RQG;
+    float dqv[QPT][C];
+    constexpr bool PHB = !AUX;   // the pair passes with the consistent delta (phase A, non-AUX branch): bare and one-launch kernels alike
+    float dl_new[PHB ? QPT : 1];
+    if (!FUSED || active) {
 
     // ---- phase A: dQ.  With the forward pass's key moments (AUX) it is a few FMAs per query; otherwise this lane's QPT
     // queries against every key
     // (kept in registers: this lane's queries are also its keys of phase B, so the three gradients of a token are
     // stored together at the end -- whole q|k|v rows instead of three strided partial-line passes)
-    float dqv[QPT][C];
-    constexpr bool PHB = !FUSED && !AUX;   // the bare kernel's pair passes with the consistent delta (phase A, non-AUX branch)
     if constexpr (AUX) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -864,7 +867,7 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
         // delta' = delta + r / sum p is what this pass's own p and dP define, dq is corrected by - (r / sum p) sum_s p k (the two
         // terms share their rounding, so the correction cancels the error instead of adding one), and the record's delta is
         // replaced by delta' for phase B.
-        constexpr bool FIXD = PHB;
+        constexpr bool FIXD = PHB;   // (= true in this branch)
         float rs[FIXD ? QPT : 1], sp[FIXD ? QPT : 1], bk[FIXD ? QPT : 1][FIXD ? C : 1];
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -914,21 +917,29 @@ __device__ __forceinline__ void attn_bwd_body(float* __restrict__ sm, const floa
             }
         }
         if constexpr (FIXD) {
-            __syncthreads();   // every lane has read its queries' delta
 #pragma unroll
             for (int i = 0; i < QPT; ++i) {
                 const float corr = rs[i] / sp[i];
 #pragma unroll
                 for (int c = 0; c < C; ++c) dq[i][c] = fmaf(-corr, bk[i][c], dq[i][c]);
-                s_qg[((size_t)sl * T + t0 + i) * RQG + 2 * C + 1] = dl[i] + corr;
+                dl_new[i] = dl[i] + corr;
             }
-            __syncthreads();   // phase B reads the corrected records
         }
 #pragma unroll
         for (int i = 0; i < QPT; ++i)
 #pragma unroll
             for (int c = 0; c < C; ++c) dqv[i][c] = dq[i][c] * inv_c;
     }
+    }   // (end of the phase A section)
+    if constexpr (PHB) {
+        __syncthreads();   // every lane has read its queries' delta
+        if (!FUSED || active) {
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) s_qg[((size_t)sl * T + t0 + i) * RQG + 2 * C + 1] = dl_new[i];
+        }
+        __syncthreads();   // phase B reads the corrected records
+    }
+    if (!FUSED || active) {
     // ---- phase B: this lane's QPT keys against every query -> dK, dV.  Two keys at a time in packed registers (spelled
     // out: left to itself the compiler folds the "- lse" / "- delta" into source-negation modifiers of scalar FMAs and
     // packs only the accumulations)
