@@ -120,3 +120,51 @@ def test_differentiated_sinkhorn_prior_trains_a_vae_step():
         tr.close()
     for o in outs:
         assert torch.isfinite(o).all() and (o[:, 2] > 0).all(), o
+
+
+def test_sinkhorn_log_autograd_at_the_benchmark_size_vs_oracle():
+    """BASELINE configs[2]'s plan size (1024 x 1024, reg 0.05, 50 iterations, fp32): the reverse sweep against the oracle's autograd
+    (CPU, the reference's arithmetic: pinned to the reference's own gradients by tests/test_oracle_vs_golden.py), plus two
+    size-independent properties of the exact derivative: (i) the plan's row sums are a for ANY cost after a full iteration (the last
+    half-iteration normalises the rows), so the gradient of sum_j pi_ij with respect to C vanishes; (ii) d/dC of sum(pi * W) is
+    linear in W."""
+    import time
+    import otvae_oracle as O
+    from ot_vae_lightning_amd.ot import sinkhorn_log
+    n = 1024
+    g = torch.Generator().manual_seed(77)
+    z, y = torch.randn(n, 16, generator=g) * 1.2 + 0.1, torch.randn(n, 16, generator=g)
+    C0 = ((z.unsqueeze(1) - y.unsqueeze(0)) ** 2).sum(-1)
+    C0 = C0 / C0.max()
+    W = torch.randn(n, n, generator=g)
+    a = torch.full((n,), 1.0 / n)
+    b = torch.full((n,), 1.0 / n)
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    Cc = C0.clone().requires_grad_(True)
+    (O.sinkhorn_log(a, b, Cc, reg=0.05, max_iter=50, threshold=0.0) * W).sum().backward()
+    Cg = C0.cuda().requires_grad_(True)
+    ag, bg, Wg = a.cuda(), b.cuda(), W.cuda()
+    pi = sinkhorn_log(ag, bg, Cg, reg=0.05, max_iter=50, threshold=0.0)
+    (pi * Wg).sum().backward()
+    err = rel_err(Cg.grad, Cc.grad)
+    assert err < 1e-4, err
+    # (i) row sums do not depend on C
+    Cr = C0.cuda().requires_grad_(True)
+    sinkhorn_log(ag, bg, Cr, reg=0.05, max_iter=50, threshold=0.0).sum(-1)[::7].sum().backward()
+    assert float(Cr.grad.abs().max()) < 1e-4 * float(Cg.grad.abs().max()), float(Cr.grad.abs().max())
+    # (ii) linearity in the upstream gradient
+    W2 = torch.randn(n, n, generator=g).cuda()
+    grads = []
+    for w_ in (Wg, W2, 0.5 * Wg - 2.0 * W2):
+        Ck = C0.cuda().requires_grad_(True)
+        (sinkhorn_log(ag, bg, Ck, reg=0.05, max_iter=50, threshold=0.0) * w_).sum().backward()
+        grads.append(Ck.grad)
+    assert rel_err(grads[2], 0.5 * grads[0] - 2.0 * grads[1]) < 2e-5
+    # timing of the differentiable route at this size (reported, not asserted)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        Ck = C0.cuda().requires_grad_(True)
+        (sinkhorn_log(ag, bg, Ck, reg=0.05, max_iter=50, threshold=0.0) * Wg).sum().backward()
+    torch.cuda.synchronize()
+    print(f"\n[sinkhorn autograd 1024^2 fp32, 50 iterations] forward + backward {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
