@@ -422,6 +422,16 @@ int otvae_grad_clip_ws(void);
 int otvae_grad_clip_coef(const float* g, int64_t n, float grad_scale, float max_norm, double* ws, float* out,
                          void* stream);
 
+/* ---- generic convolution: any stride, square footprints up to 32 x 32 (the fallback behind the tuned kernels, which take strides 1 / 2
+ * and footprints up to 7 x 7): what `ConvLayer(down_sample=s)` makes for s >= 4 -- a (2 s) x (2 s) kernel with stride s, e.g. the
+ * 8 x 8 / stride 4 layers of CNN(scaling_factor=4) (networks/cnn.py:98-101,605-621).  Plain direct convolutions (no BatchNorm / activation
+ * fusion, geom->up must be 1), NHWC activations, HWIO weights, fp32, deterministic. ---- */
+int otvae_conv_generic_fwd(const otvae_conv_geom* geom, const float* x, const float* w_hwio, const float* bias, float* y, void* stream);
+int otvae_conv_generic_bwd_data(const otvae_conv_geom* geom, const float* gy, const float* w_hwio, float* gx, void* stream);
+int64_t otvae_conv_generic_bwd_weight_ws(const otvae_conv_geom* geom, int has_bias); /* floats */
+int otvae_conv_generic_bwd_weight(const otvae_conv_geom* geom, const float* x, const float* gy, int has_bias, float* ws,
+                                  float* gw_hwio, float* gb, void* stream);
+
 /* ---- standard-normal draws (prior/gaussian.py:93 `q.rsample()`, the prior samples of the minibatch-OT prior) ---------- */
 /* out[n] ~ N(0, 1) from a counter-based hash of (key[0] = seed, key[1] = call counter, stream_id, element index): the
  * values do not depend on the launch shape.  key = device int64[3] {seed, counter, 0}; advance != 0: the call's last

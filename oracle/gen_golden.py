@@ -107,6 +107,15 @@ CONV_CASES = [
     ("mod_up_bilinear", "ConvLayer", 4, 8, 4, dict(up_sample=torch.nn.Upsample(scale_factor=2, mode="bilinear"), normalization="batchnorm", activation="relu")),
     ("mod_down_avgpool", "ConvLayer", 4, 8, 8, dict(down_sample=torch.nn.AvgPool2d(2), normalization="batchnorm", activation="leaky")),
     ("up4_relu", "ConvLayer", 4, 4, 2, dict(up_sample=4, normalization="batchnorm", activation="relu")),   # nn.Upsample(scale_factor=4), cnn.py:107
+    # strides other than 1 / 2 and footprints beyond 7 x 7 (round 4: the direct-convolution fallback): `down_sample = s` makes a
+    # (2 s) x (2 s) kernel with stride s, padding s - 1 (cnn.py:98-101) -- the layers of CNN(scaling_factor=4)
+    ("down4_relu", "ConvLayer", 4, 8, 16, dict(down_sample=4, normalization="batchnorm", activation="relu")),
+    ("down4_skip", "Conv1x1", 8, 16, 8, dict(down_sample=4, normalization="batchnorm")),
+    ("down8_leaky", "ConvLayer", 3, 8, 32, dict(down_sample=8, activation="leaky")),
+    ("stride3_k5", "ConvLayer", 4, 6, 9, dict(kernel_size=5, stride=3, padding=2, normalization="batchnorm", activation="relu")),
+    ("k9_same_relu", "ConvLayer", 3, 4, 12, dict(kernel_size=9, padding=4, activation="relu")),
+    ("dil4_grp2_silu", "ConvLayer", 4, 6, 12, dict(normalization="batchnorm", activation="silu", dilation=4, padding=4, groups=2)),
+    ("up2_k9", "ConvLayer", 4, 4, 4, dict(up_sample=2, kernel_size=9, padding=4, normalization="batchnorm", activation="relu")),
 ]
 
 
@@ -237,6 +246,10 @@ CNN_VARIANTS = {
     "cat_1layer_k1_noattn_up": ((8, 2, 2, 8), dict(capacity=4, up_sample=True, residual="cat", max_attn_res=1, n_layers=1, kernel_size=1,
                                                     padding=0), (3, 8, 2, 2), None),
     "add_noattn_dilated": ((4, 4), dict(intermediate_features=[8], residual="add", max_attn_res=0, dilation=2, padding=2), (3, 4, 8, 8), None),
+    # round 4: a scaling factor of 4 per block (get_block_scaling, cnn.py:605-621): 8 x 8 kernels with stride 4 on the way down,
+    # nn.Upsample(4) + 3 x 3 on the way up
+    "down4_add": ((2, 16, 16, 1), dict(capacity=4, down_sample=4, residual="add"), (3, 2, 16, 16), None),
+    "up4_add": ((8, 2, 1, 16), dict(capacity=4, up_sample=4, residual="add"), (3, 8, 1, 1), None),
 }
 
 

@@ -106,9 +106,11 @@ _ACTIVATIONS = {  # cnn.py:128-147 (the reference tests the names in this order:
 def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: bool, relu: bool,
                norm: bool, ksize: int = 3, training: bool = True, act: Optional[str] = None,
                equalized_lr: Optional[float] = None, other_norm: Optional[str] = None, embed: Optional[Tensor] = None,
-               groups: int = 1, dilation: int = 1, padding: Optional[int] = None, up_module=None, down_module=None) -> Tensor:
+               groups: int = 1, dilation: int = 1, padding: Optional[int] = None, up_module=None, down_module=None,
+               stride: Optional[int] = None) -> Tensor:
     """``ConvLayer.forward`` (networks/cnn.py:183-192): BN -> act -> nearest x2 up -> conv (stride-2 4x4 when
-    down-sampling, cnn.py:98-101).  ``p[prefix+'_normalization.running_*']`` are updated in place like
+    down-sampling, cnn.py:98-101; ``down`` may be the integer factor s: a max(2 s, ksize) kernel with stride s; ``stride``: a plain
+    nn.Conv2d stride without down-sampling).  ``p[prefix+'_normalization.running_*']`` are updated in place like
     nn.BatchNorm2d does in training mode.  ``act``: one of leaky / relu / selu / gelu / silu (overrides ``relu``);
     ``equalized_lr``: weight * (1 / sqrt(fan_in)) * lr_mult, bias * lr_mult (cnn.py:114-118,186-188); ``groups`` / ``dilation`` /
     ``padding``: nn.Conv2d's (cnn.py:66-67,103-104), the weight is [out, in / groups, k, k]."""
@@ -138,10 +140,11 @@ def conv_layer(x: Tensor, p: Dict[str, Tensor], prefix: str, *, down: bool, up: 
     if up:
         out = F.interpolate(out, scale_factor=2.0, mode="nearest")
     if down:
-        k = max(4, ksize)
-        stride, pad = 2, (k - 1) // 2
+        f = 2 if down is True else int(down)
+        k = max(2 * f, ksize)
+        stride, pad = f, (k - 1) // 2
     else:
-        k, stride, pad = ksize, 1, (1 if ksize == 3 else 0)
+        k, stride, pad = ksize, (stride or 1), (1 if ksize == 3 else 0)
     w = p[prefix + "weight"]
     assert w.shape[-1] == k, (prefix, w.shape, k)
     bias = p.get(prefix + "bias")

@@ -124,6 +124,10 @@ SIGNATURES = {
     "otvae_step_begin_guarded": (i32, [vp, vp, vp, i64, vp]),
     "otvae_grad_clip_ws": (i32, []),
     "otvae_grad_clip_coef": (i32, [vp, i64, f32, f32, vp, vp, vp]),
+    "otvae_conv_generic_fwd": (i32, [pg, vp, vp, vp, vp, vp]),
+    "otvae_conv_generic_bwd_data": (i32, [pg, vp, vp, vp, vp]),
+    "otvae_conv_generic_bwd_weight_ws": (i64, [pg, i32]),
+    "otvae_conv_generic_bwd_weight": (i32, [pg, vp, vp, i32, vp, vp, vp, vp]),
     "otvae_sinkhorn_ws": (i64, [i32, i32, i32, i32]),
     "otvae_sinkhorn_log": (i32, [i32, vp, vp, vp, i32, i32, i32, f64, i32, f64, vp, vp, vp, vp, vp, vp]),
     "otvae_sinkhorn_tape_bytes": (i64, [i32, i32, i32, i32, i32]),

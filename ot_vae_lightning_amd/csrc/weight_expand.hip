@@ -46,8 +46,8 @@ static int weight_expand_check(const char* who, const void* a, const void* b, in
     OTVAE_REQUIRE(a && b, "%s: NULL tensor", who);
     OTVAE_REQUIRE(Cout > 0 && Cin > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0, "%s: %d -> %d channels in %d groups", who,
                   Cin, Cout, groups);
-    OTVAE_REQUIRE(KH >= 1 && KW >= 1 && dil >= 1 && (KH - 1) * dil + 1 <= 7 && (KW - 1) * dil + 1 <= 7,
-                  "%s: a %d x %d kernel with dilation %d exceeds the 7 x 7 taps of the convolution kernels", who, KH, KW, dil);
+    OTVAE_REQUIRE(KH >= 1 && KW >= 1 && dil >= 1 && (KH - 1) * dil + 1 <= 32 && (KW - 1) * dil + 1 <= 32,
+                  "%s: a %d x %d kernel with dilation %d exceeds the 32 x 32 taps of the convolution kernels", who, KH, KW, dil);
     return OTVAE_OK;
 }
 

@@ -924,6 +924,45 @@ class _WeightExpandFn(torch.autograd.Function):
         return gw, None, None, None
 
 
+class _GenericConvFn(torch.autograd.Function):
+    """y = conv(x, w) + bias for ANY stride and footprints up to 32 x 32 (csrc/conv_generic.hip): the fallback behind the tuned kernels
+    (strides 1 / 2, footprints up to 7 x 7) for the layers `down_sample >= 4` / `CNN(scaling_factor >= 4)` make (cnn.py:98-101)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, params_ref):
+        lib = _lib.load()
+        n, cs, hs, ws_ = x.shape
+        cn, _, kh, kw = w.shape
+        ho, wo = (hs + 2 * pad - kh) // stride + 1, (ws_ + 2 * pad - kw) // stride + 1
+        if ho <= 0 or wo <= 0:
+            raise ValueError(f"a {kh} x {kw} kernel with stride {stride}, padding {pad} does not fit a {hs} x {ws_} map")
+        g = ConvGeom(n, hs, ws_, cs, 1, ho, wo, cn, kh, kw, stride, pad)
+        y = empty_nhwc(n, cn, ho, wo, x)
+        check(lib.otvae_conv_generic_fwd(C.byref(g), ptr(x), ptr(w), ptr(bias), ptr(y), stream()), "otvae_conv_generic_fwd")
+        ctx.save_for_backward(x, w, bias)
+        ctx.g, ctx.pref = g, params_ref
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, bias = ctx.saved_tensors
+        lib = _lib.load()
+        g = ctx.g
+        gy = as_nhwc(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_strided(x.shape, x.stride(), device=x.device, dtype=x.dtype)
+            check(lib.otvae_conv_generic_bwd_data(C.byref(g), ptr(gy), ptr(w), ptr(gx), stream()), "otvae_conv_generic_bwd_data")
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            has_bias = bias is not None
+            ws = torch.empty(lib.otvae_conv_generic_bwd_weight_ws(C.byref(g), int(has_bias)), device=x.device, dtype=torch.float32)
+            gw = _grad_buffer(ctx.pref[0], w)
+            gb = _grad_buffer(ctx.pref[1], bias) if has_bias else None
+            check(lib.otvae_conv_generic_bwd_weight(C.byref(g), ptr(x), ptr(gy), int(has_bias), ptr(ws), ptr(gw), ptr(gb), stream()),
+                  "otvae_conv_generic_bwd_weight")
+        return gx, gw, gb, None, None, None
+
+
 def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
     """One ConvLayer whose activation is not ReLU and / or whose weight and bias carry the equalized_lr multipliers: BatchNorm
     statistics (the fused path's kernels) -> ``_BnActFn`` -> the fused convolution kernels with neither BatchNorm nor activation."""
@@ -967,9 +1006,15 @@ def _conv_layer_general(x: Tensor, br: dict, training: bool) -> Tensor:
     drop = br.get("dropout2d")  # (p, key): nn.Dropout2d behind the convolution, training mode only
     if down_module is not None and br.get("residual") is not None:
         raise ValueError("a residual cannot be fused in front of a down-sampling module")
-    plain = dict(weight=w, bias=bias, residual=br.get("residual"), stride=br["stride"], pad=br["pad"], up=br["up"], relu=False,
-                 out_stats=br.get("out_stats", False) and drop is None and down_module is None)
-    y = conv_layers(a, [plain], training=training)[0]
+    if br.get("generic"):   # a stride / footprint the tuned kernels do not take: the direct-convolution fallback
+        direct = w is br["weight"] and (bias is None or bias is br.get("bias"))   # gradients may go straight into the parameters' slots
+        y = _GenericConvFn.apply(as_nhwc(a), w, bias, int(br["stride"]), int(br["pad"]), (br["weight"], br.get("bias")) if direct else (None, None))
+        if br.get("residual") is not None:
+            y = y + as_nhwc(br["residual"])
+    else:
+        plain = dict(weight=w, bias=bias, residual=br.get("residual"), stride=br["stride"], pad=br["pad"], up=br["up"], relu=False,
+                     out_stats=br.get("out_stats", False) and drop is None and down_module is None)
+        y = conv_layers(a, [plain], training=training)[0]
     if down_module is not None:  # behind the convolution, in front of the dropout (cnn.py:190-191)
         y = as_nhwc(down_module(y))
     if drop is not None and training:
@@ -988,7 +1033,7 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
         raise TypeError("the MI355X conv path computes in fp32")
     if any(br.get("act", 0) > 1 or br.get("wscale", 1.0) != 1.0 or br.get("bscale", 1.0) != 1.0 or br.get("group_norm") is not None
            or br.get("film") is not None or br.get("dropout2d") is not None or br.get("expand") is not None
-           or br.get("up_module") is not None or br.get("down_module") is not None for br in branches):
+           or br.get("up_module") is not None or br.get("down_module") is not None or br.get("generic") for br in branches):
         return tuple(_conv_layer_general(x, br, training) for br in branches)
     specs, tensors, params_ref, bns = [], [], [], []
     for br in branches:

@@ -66,19 +66,24 @@ class ConvLayer(nn.Module):
         # dense weight the kernels take (functional._WeightExpandFn), whose taps may span 7 x 7 at most
         self.groups, self.dilation = int(groups), (int(dilation), int(dilation))
         self._expand = (int(groups), int(dilation)) if (groups != 1 or dilation != 1) else None
-        if (kernel_size - 1) * dilation + 1 > 7:
-            raise NotImplementedError(f"a {kernel_size} x {kernel_size} kernel with dilation {dilation} spans more than the 7 x 7 taps "
+        # The tuned kernels take strides 1 / 2 and footprints up to 7 x 7 taps.  Anything else the reference's constructor can make --
+        # `down_sample = s >= 4` is a (2 s) x (2 s) kernel with stride s (cnn.py:98-101; CNN(scaling_factor=4): 8 x 8, stride 4) -- runs
+        # on the direct-convolution fallback (csrc/conv_generic.hip) with the normalisation / activation unfused around it
+        footprint = (kernel_size - 1) * dilation + 1
+        self._generic = footprint > 7 or stride not in (1, 2)
+        if footprint > 32:
+            raise NotImplementedError(f"a {kernel_size} x {kernel_size} kernel with dilation {dilation} spans more than the 32 x 32 taps "
                                       "of the MI355X convolution kernels")
-        if stride not in (1, 2):
-            raise NotImplementedError(f"stride {stride} is not supported on the MI355X path")
+        if stride < 1:
+            raise ValueError(f"stride must be positive, got {stride}")
         up = 1
         if isinstance(up_sample, bool):
             up = 2 if up_sample else 1
         elif isinstance(up_sample, int) and up_sample > 0:
             up = int(up_sample)
-        if up not in (1, 2):
-            # the kernels fuse the nearest x2 up-sampling only; any other factor runs as the reference's own nn.Upsample module
-            # around them (the same route as a user-supplied module)
+        if up not in (1, 2) or (up == 2 and self._generic):
+            # the kernels fuse the nearest x2 up-sampling only (and the direct-convolution fallback none); any other factor runs as the
+            # reference's own nn.Upsample module around them (the same route as a user-supplied module)
             up_module, up = nn.Upsample(scale_factor=up), 1
         self.in_channels, self.out_channels = in_features, out_features
         self.kernel_size, self.stride, self.padding = (kernel_size, kernel_size), (stride, stride), (padding, padding)
@@ -206,7 +211,7 @@ class ConvLayer(nn.Module):
                     running_var=bn.running_var if bn is not None else None,
                     num_batches_tracked=bn.num_batches_tracked if bn is not None else None,
                     residual=residual, stride=self.stride[0], pad=self.padding[0], up=self._up,
-                    relu=isinstance(self._activation, nn.ReLU), act=self._act_kind,
+                    relu=isinstance(self._activation, nn.ReLU), act=self._act_kind, generic=self._generic,
                     wscale=float(self._conv_scale * self._lr_mult), bscale=float(self._lr_mult), out_stats=out_stats)
 
     def forward(self, x: Tensor, embed: Optional[Tensor] = None, *, residual: Optional[Tensor] = None,

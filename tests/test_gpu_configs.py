@@ -478,9 +478,33 @@ def test_grouped_dilated_cnn_trains_through_the_captured_step(A):
     assert float((layer.weight.grad - w.grad).abs().max() / w.grad.abs().max()) < 1e-5
 
 
+def test_scaling_factor_4_cnn_trains_through_the_captured_step(A):
+    """Round 4: `CNN(down_sample=4)` / `CNN(up_sample=4)` (8 x 8 kernels with stride 4, nn.Upsample(4) + 3 x 3: the reference's scaling
+    factor 4, cnn.py:98-101,605-621) as a VAE through ``HipTrainer``: the direct-convolution fallback writes its weight gradients
+    into the flat buffer, the captured step equals the eagerly issued one bit for bit over three Adam steps, and the loss falls."""
+    import copy
+    torch.manual_seed(4)
+    enc = A.CNN(1, 32, 16, 1, capacity=4, down_sample=4, residual="add")
+    dec = A.CNN(16, 1, 1, 16, capacity=4, up_sample=4, residual="add")
+    assert any(m._generic and m.stride == (4, 4) and m.kernel_size == (8, 8) for m in enc.modules() if isinstance(m, A.ConvLayer))
+    model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+    twin = copy.deepcopy(model)
+    x, eps = normal((16, 1, 16, 16), 15).cuda(), normal((16, 16, 1, 1), 16).cuda()
+    t_graph = A.HipTrainer(model, batch_shape=(16, 1, 16, 16), use_graph=True)
+    t_eager = A.HipTrainer(twin, batch_shape=(16, 1, 16, 16), use_graph=False)
+    losses = []
+    for _ in range(6):
+        a, b = t_graph.step(x, eps), t_eager.step(x, eps)
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+        losses.append(float(a[0]))
+    assert torch.equal(t_graph.pflat, t_eager.pflat) and losses[-1] < losses[0], losses
+    t_graph.close(); t_eager.close()
+
+
 def test_error_behaviour(A):
+    assert A.ConvLayer(4, 4, kernel_size=5, dilation=2)._generic   # a 9 x 9 footprint: the direct-convolution fallback since round 4
     with pytest.raises(NotImplementedError):
-        A.ConvLayer(4, 4, kernel_size=5, dilation=2)   # a 9 x 9 footprint: beyond the 7 x 7 taps of the convolution kernels
+        A.ConvLayer(4, 4, kernel_size=17, dilation=3)  # a 49 x 49 footprint: beyond the 32 x 32 taps of any kernel here
     # (round 4: `ema_decay` is built -- tests/test_gpu_lifetime.py::test_parameter_ema_... -- and no longer refused)
     m_ = A.VAE(encoder=A.CNN(1, 16, 16, 1, capacity=4, down_sample=True), decoder=A.CNN(8, 1, 1, 16, capacity=4, up_sample=True),
                prior=A.GaussianPrior(), ema_decay=0.999)

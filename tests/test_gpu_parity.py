@@ -211,6 +211,14 @@ CONV_CTOR = {
     "mod_up_bilinear": ("ConvLayer", dict(up_sample=torch.nn.Upsample(scale_factor=2, mode="bilinear"), normalization="batchnorm", activation="relu")),
     "mod_down_avgpool": ("ConvLayer", dict(down_sample=torch.nn.AvgPool2d(2), normalization="batchnorm", activation="leaky")),
     "up4_relu": ("ConvLayer", dict(up_sample=4, normalization="batchnorm", activation="relu")),
+    # round 4: strides other than 1 / 2, footprints beyond 7 x 7 (csrc/conv_generic.hip)
+    "down4_relu": ("ConvLayer", dict(down_sample=4, normalization="batchnorm", activation="relu")),
+    "down4_skip": ("Conv1x1", dict(down_sample=4, normalization="batchnorm")),
+    "down8_leaky": ("ConvLayer", dict(down_sample=8, activation="leaky")),
+    "stride3_k5": ("ConvLayer", dict(kernel_size=5, stride=3, padding=2, normalization="batchnorm", activation="relu")),
+    "k9_same_relu": ("ConvLayer", dict(kernel_size=9, padding=4, activation="relu")),
+    "dil4_grp2_silu": ("ConvLayer", dict(normalization="batchnorm", activation="silu", dilation=4, padding=4, groups=2)),
+    "up2_k9": ("ConvLayer", dict(up_sample=2, kernel_size=9, padding=4, normalization="batchnorm", activation="relu")),
 }
 
 
@@ -360,6 +368,8 @@ CNN_VARIANTS = {   # oracle/gen_golden.py: CNN_VARIANTS (constructor corners no 
     "grouped_in_leaky_nobias": ((2, 8, 8, 2), dict(capacity=4, down_sample=True, residual="add", groups=2, normalization="instancenorm", activation="leaky", bias=False)),
     "cat_1layer_k1_noattn_up": ((8, 2, 2, 8), dict(capacity=4, up_sample=True, residual="cat", max_attn_res=1, n_layers=1, kernel_size=1, padding=0)),
     "add_noattn_dilated": ((4, 4), dict(intermediate_features=[8], residual="add", max_attn_res=0, dilation=2, padding=2)),
+    "down4_add": ((2, 16, 16, 1), dict(capacity=4, down_sample=4, residual="add")),
+    "up4_add": ((8, 2, 1, 16), dict(capacity=4, up_sample=4, residual="add")),
 }
 
 

@@ -47,6 +47,13 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
     "mod_up_bilinear": (False, False, False, True, 3, "relu", None, None, 1, 1, None, torch.nn.Upsample(scale_factor=2, mode="bilinear"), None),
     "mod_down_avgpool": (False, False, False, True, 3, "leaky", None, None, 1, 1, None, None, torch.nn.AvgPool2d(2)),
     "up4_relu": (False, False, False, True, 3, "relu", None, None, 1, 1, None, torch.nn.Upsample(scale_factor=4), None),
+    # (..., stride): strides other than 1 / 2 and footprints beyond 7 x 7 (`down` = the integer factor)
+    "down4_relu": (4, False, False, True, 3, "relu"), "down4_skip": (4, False, False, True, 1, None),
+    "down8_leaky": (8, False, False, False, 3, "leaky"),
+    "stride3_k5": (False, False, False, True, 5, "relu", None, None, 1, 1, 2, None, None, 3),
+    "k9_same_relu": (False, False, False, False, 9, "relu", None, None, 1, 1, 4),
+    "dil4_grp2_silu": (False, False, False, True, 3, "silu", None, None, 2, 4, 4),
+    "up2_k9": (False, True, False, True, 9, "relu", None, None, 1, 1, 4),
 }
 
 
@@ -54,8 +61,8 @@ CONV_GEOM = {  # name -> (down, up, relu, norm, ksize)
 def test_conv_layer(name):
     g = group(load_golden("convlayer.npz"), name)
     down, up, relu, norm, ks, *opt = CONV_GEOM[name]
-    defaults = [None, None, None, 1, 1, None, None, None]
-    act, eq, gn, groups, dil, padding, up_mod, down_mod = list(opt) + defaults[len(opt):]
+    defaults = [None, None, None, 1, 1, None, None, None, None]
+    act, eq, gn, groups, dil, padding, up_mod, down_mod, stride = list(opt) + defaults[len(opt):]
     p = {k[len("param/"):]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("param/")}
     if norm:
         c = g["x"].shape[1]
@@ -64,7 +71,7 @@ def test_conv_layer(name):
     x = g["x"].clone().requires_grad_(True)
     emb = g["embed"].clone().requires_grad_(True) if "embed" in g else None
     y = O.conv_layer(x, p, "", down=down, up=up, relu=relu, norm=norm, ksize=ks, act=act, equalized_lr=eq, other_norm=gn, embed=emb,
-                     groups=groups, dilation=dil, padding=padding, up_module=up_mod, down_module=down_mod)
+                     groups=groups, dilation=dil, padding=padding, up_module=up_mod, down_module=down_mod, stride=stride)
     y.backward(g["gy"])
     if emb is not None:
         assert rel_err(emb.grad, g["gembed"]) < TIGHT
