@@ -88,6 +88,24 @@ class GraphedNelbo:
             raise ReferenceError("the model of this GraphedNelbo no longer exists")
         return m
 
+    def __deepcopy__(self, memo):
+        """``copy.deepcopy(model)`` copies ``model.loss`` with it: the copy must point at the COPIED model (a weak reference is atomic
+        for deepcopy: it would keep pointing at the original) and starts without captured graphs (it captures on its first call)."""
+        import copy
+        m = self._model_ref()
+        twin = memo.get(id(m)) if m is not None else None
+        if twin is None:
+            raise copy.Error("a GraphedNelbo can only be deep-copied as part of its model (copy.deepcopy(model))")
+        new = GraphedNelbo.__new__(GraphedNelbo)
+        new._model_ref, new.warmup, new._cap = weakref.ref(twin), self.warmup, None
+        new._nelbo_func = self._nelbo_func
+        new._nelbo_obj = None if self._nelbo_obj is None else copy.deepcopy(self._nelbo_obj, memo)
+        return new
+
+    def __reduce__(self):
+        raise TypeError("a GraphedNelbo holds captured hipGraphs and cannot be pickled: save model.state_dict() (what a Lightning "
+                        "checkpoint holds), or call model.disable_graphed_step() first")
+
     def _nelbo(self, batch, batch_idx):
         if self._nelbo_func is not None:
             return self._nelbo_func(self.model, batch, batch_idx)

@@ -81,3 +81,25 @@ def test_a_dropped_owner_releases_through_its_finalizer_also_from_the_collector_
         gc.collect()                                                # ... and it runs inside a capture
         assert FakeGraph.log == ["refcount"] and lifetime.parked() == 1
     assert lifetime.drain() == 1 and FakeGraph.log == ["refcount", "cycle"]
+
+
+def test_a_graphed_model_deep_copies_onto_its_own_copy():
+    """``model.loss = GraphedNelbo(model)`` holds the model weakly (no reference cycle); ``copy.deepcopy(model)`` must bind the copied
+    ``loss`` to the COPY, not to the original."""
+    import copy
+    import ot_vae_lightning_amd as A
+    enc = A.CNN(1, 16, 16, 1, capacity=4, down_sample=True, residual="add")
+    dec = A.CNN(8, 1, 1, 16, capacity=4, up_sample=True, residual="add")
+    model = A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).enable_graphed_step()
+    twin = copy.deepcopy(model)
+    assert twin.loss is not model.loss and twin.loss.model is twin and model.loss.model is model and twin.loss._cap is None
+    with pytest.raises(copy.Error):
+        copy.deepcopy(model.loss)
+    with pytest.raises(TypeError):
+        import pickle
+        pickle.dumps(model.loss)
+    ref = weakref.ref(model)
+    graphed = weakref.ref(model.loss)
+    del model
+    gc.collect()
+    assert ref() is None and graphed() is None     # nothing but the model kept its GraphedNelbo alive
