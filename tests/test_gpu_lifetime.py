@@ -199,18 +199,29 @@ def test_parameter_ema_in_the_optimizer_kernel_vs_the_torch_ema_rule():
         assert tr.skipped_steps == 1 and torch.equal(tr.ema.shadow, before) and tr.ema.state_dict()["num_updates"] == 4
         tr.close()
 
-    # host-driven route: the reference's loop with a stock optimizer
-    model = make(ema_decay=0.95)
-    model.batch_preprocess = lambda b: {"samples": b[0], "target": b[0], "kwargs": {"eps": b[1]}}
-    params = list(model.optim_parameters())
-    opt = torch.optim.SGD(params, lr=0.05)
-    model.on_fit_start()
-    ref = O.ParamEMARef([p.detach().cpu().contiguous() for p in params], 0.95)
-    for i in range(3):
-        model.training_step((xs[i], es[i]), i)["loss"].backward()
-        opt.step()
-        model.on_before_zero_grad(opt)
-        opt.zero_grad()
-        ref.update([p.detach().cpu().contiguous() for p in params])
-    for s_, r_ in zip(model._ema.shadow, ref.shadow):
-        assert torch.equal(s_.cpu().contiguous(), r_)
+    # host-driven route: the reference's loop with a stock optimizer -- issued eagerly, and through the graph route (whose first call
+    # moves the parameters into a flat buffer AFTER on_fit_start made the average)
+    for graphed in (False, True):
+        model = make(ema_decay=0.95)
+        model.batch_preprocess = lambda b: {"samples": b[0], "target": b[0], "kwargs": {"eps": b[1]}}
+        if graphed:
+            model.enable_graphed_step()
+        params = list(model.optim_parameters())
+        opt = torch.optim.SGD(params, lr=0.05)
+        model.on_fit_start()
+        ref = O.ParamEMARef([p.detach().cpu().contiguous() for p in params], 0.95)
+        for i in range(3):
+            model.training_step((xs[i], es[i]), i)["loss"].backward()
+            opt.step()
+            model.on_before_zero_grad(opt)
+            opt.zero_grad()
+            ref.update([p.detach().cpu().contiguous() for p in params])
+        for s_, r_ in zip(model._ema.shadow, ref.shadow):
+            assert torch.equal(s_.cpu().contiguous(), r_), f"graphed={graphed}"
+        live = [p.detach().clone() for p in params]
+        model.on_validation_epoch_start()
+        assert all(torch.equal(p.detach(), s_) for p, s_ in zip(params, model._ema.shadow))
+        model.on_validation_epoch_end()
+        assert all(torch.equal(p.detach(), l_) for p, l_ in zip(params, live))
+        if graphed:
+            model.disable_graphed_step()
