@@ -512,6 +512,7 @@ class HipTrainer:
         """Warm-up eagerly on a side stream (allocator + lazy kernel loading), then capture."""
         if self._captured or not self.use_graph:
             return
+        self._gs.release()   # (graphs of an earlier attempt that raised half-way)
         snap = (self.pflat.clone(), self.m.clone(), self.v.clone(), self.step_count.clone(), self.guard.clone())
         # everything else a step mutates: every buffer of the model (BatchNorm running statistics, EMA embeddings of a
         # ConditionalGaussianPrior ...), parameters outside the flat buffer (frozen ones an EMA rewrites), the dropout
