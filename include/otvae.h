@@ -121,6 +121,33 @@ int otvae_wgrad_reduce_batched(int n, const float* const* partial, const int* P,
 #define OTVAE_JOB_FWD 0
 #define OTVAE_JOB_BWD_DATA 1
 #define OTVAE_JOB_BWD_WEIGHT 2
+/* ---- BatchNorm statistic SLOTS (round 4): cross-block sums without a finalize launch, bit-reproducible --------------------------------
+ * Instead of P per-block partials a producer may add its per-channel sums into 16 accumulators of int64 fixed-point limbs with integer
+ * atomics (associative: the totals do not depend on arrival order); layout and arithmetic in csrc/common.h.  `slots` buffers hold
+ * otvae_bn_slots_words(ld) int64 words and must be ZERO before the producer runs.  A consumer kernel that is handed an otvae_bn_fold
+ * turns the sums into (scale, shift) in its own prologue -- every block for itself -- and its first block leaves mean / invstd / scale /
+ * shift in global memory for the backward pass and advances the running buffers: what otvae_bn_finalize did in a launch of its own
+ * (reference: nn.BatchNorm2d in training mode, networks/cnn.py:122,184).  otvae_bn_finalize_slots is the stand-alone form. */
+typedef struct otvae_bn_fold {
+    const void* slots;            /* NULL: no fold */
+    int32_t ld;                   /* channel stride of the slots (>= channels) */
+    int32_t reserved;
+    int64_t count;                /* elements per channel: N * H * W of the normalised tensor */
+    float eps, momentum;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;          /* nullable (with running_var, num_batches_tracked) */
+    float* running_var;
+    int64_t* num_batches_tracked;
+    float* mean_out;              /* nullable pair: the branch that publishes the statistics the branches share */
+    float* invstd_out;
+    float* scale_out;             /* this branch's affine, for the backward pass */
+    float* shift_out;
+} otvae_bn_fold;
+int64_t otvae_bn_slots_words(int ld);
+int otvae_bn_stats_slots(const float* x, int64_t M, int C, void* slots, int ld, void* stream);
+int otvae_bn_finalize_slots(int n_bn, const otvae_bn_fold* folds, int C, void* stream);
+
 typedef struct otvae_conv_job {
     int32_t kind;               /* OTVAE_JOB_* */
     int32_t relu;               /* ReLU after the (optional) affine of the layer INPUT x */
@@ -143,6 +170,8 @@ typedef struct otvae_conv_job {
     float* wpartial;            /* BWD_WEIGHT workspace */
     float* gw;                  /* BWD_WEIGHT */
     float* gb;
+    void* stat_slots;           /* FWD (nullable, instead of stat_partial): statistic slots of the OUTPUT, channel stride = the ld of otvae_conv_fwd_stats_ws */
+    otvae_bn_fold fold;         /* FWD (fold.slots nullable): the BatchNorm of the INPUT x folded into this launch; scale / shift are then ignored */
 } otvae_conv_job;
 int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream);
 /* Introspection for measurement (bench.py's per-kernel roofline): what the calling thread's last otvae_conv_multi did --
@@ -180,6 +209,11 @@ int otvae_attn_stage_plan(int N, int T, int H, int C, int need_aux, int* stat_ro
 int otvae_attn_stage_fwd(const float* x, const float* scale, const float* shift, const float* wqkv, const float* wproj,
                          const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv, float* out, float* lse,
                          float* aux, float* y, double* stat_partial, void* stream);
+/* The same launch with the BatchNorm in front of the qkv convolution FOLDED IN (fold->slots != NULL: scale / shift are ignored, see
+ * otvae_bn_fold) and / or the output's statistics into statistic slots (stat_slots, channel stride H * C) instead of stat_partial. */
+int otvae_attn_stage_fwd_fold(const float* x, const otvae_bn_fold* fold, const float* scale, const float* shift, const float* wqkv,
+                              const float* wproj, const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv,
+                              float* out, float* lse, float* aux, float* y, double* stat_partial, void* stat_slots, void* stream);
 
 /* The AttentionBlock's backward pass as ONE launch on what otvae_attn_stage_fwd wrote (qkv, out, lse, aux): the attention output's
  * gradient is formed from gy [N][T][H*C] (gout = gy . wproj^T), the attention backward of otvae_attn_bwd_scaled writes gqkv

@@ -32,10 +32,18 @@ JOB_FWD, JOB_BWD_DATA, JOB_BWD_WEIGHT = 0, 1, 2
 DEFER_DENSE, DEFER_SPARSE = 1, 2  # otvae_conv_job.defer_reduce (include/otvae.h)
 
 
+class BnFold(C.Structure):  # otvae_bn_fold
+    _fields_ = [("slots", C.c_void_p), ("ld", C.c_int32), ("reserved", C.c_int32), ("count", C.c_int64), ("eps", C.c_float),
+                ("momentum", C.c_float)] + [(n, C.c_void_p) for n in ("gamma", "beta", "running_mean", "running_var",
+                                                                      "num_batches_tracked", "mean_out", "invstd_out", "scale_out",
+                                                                      "shift_out")]
+
+
 class ConvJob(C.Structure):  # otvae_conv_job
     _fields_ = ([(n, C.c_int32) for n in ("kind", "relu", "has_bias", "defer_reduce")] + [("geom", ConvGeom)] +
                 [(n, C.c_void_p) for n in ("x", "scale", "shift", "w", "bias", "residual", "y", "stat_partial", "gy",
-                                           "mean", "invstd", "gv", "bn_partial", "wpartial", "gw", "gb")])
+                                           "mean", "invstd", "gv", "bn_partial", "wpartial", "gw", "gb", "stat_slots")] +
+                [("fold", BnFold)])
 
 
 pj = C.POINTER(ConvJob)
@@ -47,6 +55,9 @@ SIGNATURES = {
     "otvae_device_info": (i32, [pi32, pi32, C.c_char_p, i32]),
     "otvae_bn_stats_nparts": (i32, [i64, i32]),
     "otvae_bn_stats": (i32, [vp, i64, i32, vp, vp]),
+    "otvae_bn_slots_words": (i64, [i32]),
+    "otvae_bn_stats_slots": (i32, [vp, i64, i32, vp, i32, vp]),
+    "otvae_bn_finalize_slots": (i32, [i32, C.POINTER(BnFold), i32, vp]),
     "otvae_bn_finalize": (i32, [vp, i32, i32, i64, i32, f32, f32, vp, vp, i32, pp, pp, pp, pp, pp, pp, pp, vp]),
     "otvae_conv_fwd_stats_ws": (i32, [pg, pi32, pi32]),
     "otvae_conv_fwd": (i32, [pg, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
@@ -69,6 +80,7 @@ SIGNATURES = {
     "otvae_attn_bwd_scaled": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]),
     "otvae_attn_stage_plan": (i32, [i32, i32, i32, i32, i32, vp]),
     "otvae_attn_stage_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "otvae_attn_stage_fwd_fold": (i32, [vp, C.POINTER(BnFold), vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "otvae_attn_stage_bwd_plan": (i32, [i32, i32, i32, i32, vp]),
     "otvae_attn_stage_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     "otvae_attn_dropout_fwd": (i32, [vp, i32, i32, i32, i32, f32, f32, i32, vp, i32, vp, vp, vp, vp]),

@@ -139,7 +139,8 @@ struct AttnStage {
     const float* residual;  // [N][T][HC] or NULL
     float* qkv;             // [N][T][3 HC] written for a three-launch backward pass, or NULL
     float* y;               // [N][T][HC]
-    double* stat_partial;   // [2][HC][gridDim.x] per-channel sum / sum of squares of y, or NULL
+    double* stat_partial;   // [2][HC][gridDim.x] per-channel sum / sum of squares of y, or NULL (bit 0 set: statistic slots, common.h)
+    BnFold fold;            // fold.slots != NULL: the BatchNorm in front of the qkv convolution folded into this launch (scale / shift unused)
 };
 
 // n floats global -> LDS, 16 bytes per lane when the source allows; eight loads of a thread in flight at once (a load -> store loop
@@ -316,7 +317,7 @@ __device__ __forceinline__ void column_sums_to_partial(double (&s1)[NC], double 
         const int which = threadIdx.x / HC, cc = threadIdx.x - which * HC;
         double t = red[which * HC + cc];
         for (int w = 1; w < nw; ++w) t += red[(w * 2 + which) * HC + cc];
-        partial[((size_t)which * HC + cc) * gridDim.x + blockIdx.x] = t;
+        bn_stat_out(partial, which, HC, cc, gridDim.x, blockIdx.x, t);
     }
 }
 
@@ -374,7 +375,13 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ sm, const floa
     const int ntok = FUSED ? nsl / H * T : 0;                 // slice0 % H == 0 and (N H) % H == 0: whole images
     const size_t tok0 = FUSED ? (size_t)(slice0 / H) * T : 0;  // first token of the block in [N][T]
     if constexpr (FUSED) {
-        stage_input_tile(xs, sg.x + tok0 * HC, ntok * HC, HC, sg.scale, sg.shift);
+        if (sg.fold.slots) {   // every block turns the statistic slots into the affine itself (common.h); HC <= 32 here
+            __shared__ __align__(16) float bn_tab[2][32];
+            bn_fold_prologue(sg.fold, HC, bn_tab[0], bn_tab[1], blockIdx.x == 0);
+            stage_input_tile(xs, sg.x + tok0 * HC, ntok * HC, HC, bn_tab[0], bn_tab[1]);
+        } else {
+            stage_input_tile(xs, sg.x + tok0 * HC, ntok * HC, HC, sg.scale, sg.shift);
+        }
         stage_weights(wl, sg.wqkv, HC * W3);
         stage_weights(wpl, sg.wproj, HC * HC);
         __syncthreads();
@@ -1392,9 +1399,41 @@ extern "C" int otvae_attn_stage_bwd_plan(int N, int T, int H, int C, int* bn_row
     return OTVAE_OK;
 }
 
+static int attn_stage_fwd_impl(const float* x, const float* scale, const float* shift, const float* wqkv, const float* wproj,
+                               const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv, float* out, float* lse,
+                               float* aux, float* y, double* stat_partial, const BnFold& fold, void* stream);
+
 extern "C" int otvae_attn_stage_fwd(const float* x, const float* scale, const float* shift, const float* wqkv, const float* wproj,
                                     const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv, float* out, float* lse,
                                     float* aux, float* y, double* stat_partial, void* stream) {
+    return attn_stage_fwd_impl(x, scale, shift, wqkv, wproj, residual, N, T, H, C, qk_scale, qkv, out, lse, aux, y, stat_partial, BnFold{},
+                               stream);
+}
+
+// the same launch with the round-4 extras: the BatchNorm in front of the qkv convolution folded in (fold->slots != NULL; scale / shift
+// are then ignored) and / or the output's statistics into slots (stat_slots != NULL, channel stride H * C) instead of partials
+extern "C" int otvae_attn_stage_fwd_fold(const float* x, const otvae_bn_fold* fold, const float* scale, const float* shift,
+                                         const float* wqkv, const float* wproj, const float* residual, int N, int T, int H, int C,
+                                         float qk_scale, float* qkv, float* out, float* lse, float* aux, float* y, double* stat_partial,
+                                         void* stat_slots, void* stream) {
+    OTVAE_REQUIRE(!(stat_partial && stat_slots), "otvae_attn_stage_fwd_fold: statistics go to partials OR to slots");
+    BnFold f = {};
+    if (fold && fold->slots) {
+        OTVAE_REQUIRE(fold->ld >= H * C && fold->count > 0 && fold->gamma && fold->beta && fold->scale_out && fold->shift_out &&
+                          (fold->mean_out == nullptr) == (fold->invstd_out == nullptr),
+                      "otvae_attn_stage_fwd_fold: incomplete BatchNorm fold descriptor");
+        f.slots = (const long long*)fold->slots, f.ld = fold->ld, f.count = fold->count, f.eps = fold->eps, f.momentum = fold->momentum;
+        f.gamma = fold->gamma, f.beta = fold->beta, f.rmean = fold->running_mean, f.rvar = fold->running_var;
+        f.nbt = (long long*)fold->num_batches_tracked;
+        f.mean_out = fold->mean_out, f.invstd_out = fold->invstd_out, f.scale_out = fold->scale_out, f.shift_out = fold->shift_out;
+    }
+    return attn_stage_fwd_impl(x, scale, shift, wqkv, wproj, residual, N, T, H, C, qk_scale, qkv, out, lse, aux, y,
+                               stat_slots ? bn_tag_slots(stat_slots) : stat_partial, f, stream);
+}
+
+static int attn_stage_fwd_impl(const float* x, const float* scale, const float* shift, const float* wqkv, const float* wproj,
+                               const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv, float* out, float* lse,
+                               float* aux, float* y, double* stat_partial, const BnFold& fold, void* stream) {
     OTVAE_REQUIRE(x && wqkv && wproj && out && lse && y, "otvae_attn_stage_fwd: NULL tensor");
     OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_attn_stage_fwd: scale/shift must come together");
     OTVAE_REQUIRE(qk_scale > 0.f, "otvae_attn_stage_fwd: scale must be positive");
@@ -1406,7 +1445,7 @@ extern "C" int otvae_attn_stage_fwd(const float* x, const float* scale, const fl
     OTVAE_REQUIRE(attn_aligned16(x) && attn_aligned16(scale) && attn_aligned16(shift), "otvae_attn_stage_fwd: x / scale / shift must be 16-byte aligned");
     OTVAE_REQUIRE(((uintptr_t)qkv & 7) == 0 && ((uintptr_t)y & 7) == 0 && ((uintptr_t)residual & 7) == 0,
                   "otvae_attn_stage_fwd: qkv / y / residual must be 8-byte aligned");
-    const AttnStage sg = {x, scale, shift, wqkv, wproj, residual, qkv, y, stat_partial};
+    const AttnStage sg = {x, scale, shift, wqkv, wproj, residual, qkv, y, stat_partial, fold};
     hipStream_t st = (hipStream_t)stream;
 #define STAGE_K(CC)                                                                                                        \
     do {                                                                                                                   \

@@ -15,7 +15,8 @@ extern "C" int otvae_bn_stats_nparts(int64_t M, int C) {
 }
 
 // thread (rr, c): rows rr, rr+RPB*P ... of channel c (C <= 256), or loops channels (C > 256)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C, double* __restrict__ partial,
+                                                       long long* __restrict__ slots = nullptr, int ld = 0) {
     __shared__ double sh[2][256];
     const int P = gridDim.x;
     if (C <= 256) {
@@ -38,8 +39,13 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
                 ts += sh[0][r * C + threadIdx.x];
                 tq += sh[1][r * C + threadIdx.x];
             }
-            partial[((size_t)0 * C + threadIdx.x) * P + blockIdx.x] = ts;
-            partial[((size_t)1 * C + threadIdx.x) * P + blockIdx.x] = tq;
+            if (slots) {
+                bn_slot_add(slots, ld, blockIdx.x, 0, threadIdx.x, ts);
+                bn_slot_add(slots, ld, blockIdx.x, 1, threadIdx.x, tq);
+            } else {
+                partial[((size_t)0 * C + threadIdx.x) * P + blockIdx.x] = ts;
+                partial[((size_t)1 * C + threadIdx.x) * P + blockIdx.x] = tq;
+            }
         }
     } else {
         for (int c = threadIdx.x; c < C; c += 256) {
@@ -49,8 +55,13 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
                 s += (double)v;
                 q += (double)v * (double)v;
             }
-            partial[((size_t)0 * C + c) * P + blockIdx.x] = s;
-            partial[((size_t)1 * C + c) * P + blockIdx.x] = q;
+            if (slots) {
+                bn_slot_add(slots, ld, blockIdx.x, 0, c, s);
+                bn_slot_add(slots, ld, blockIdx.x, 1, c, q);
+            } else {
+                partial[((size_t)0 * C + c) * P + blockIdx.x] = s;
+                partial[((size_t)1 * C + c) * P + blockIdx.x] = q;
+            }
         }
     }
 }
@@ -60,6 +71,54 @@ extern "C" int otvae_bn_stats(const float* x, int64_t M, int C, double* partial,
     const int P = otvae_bn_stats_nparts(M, C);
     bn_stats_kernel<<<P, 256, 0, (hipStream_t)stream>>>(x, M, C, partial);
     OTVAE_CHECK_LAUNCH("otvae_bn_stats");
+    return OTVAE_OK;
+}
+
+// ---- statistic slots (common.h): the sums land in BN_SLOTS accumulators instead of P partials; no finalize launch is needed when the
+// consumer folds them itself (BnFold), otvae_bn_finalize_slots is the stand-alone form for consumers that do not
+extern "C" int64_t otvae_bn_slots_words(int ld) { return ld > 0 ? (int64_t)bn_slot_words(ld) : -1; }
+
+extern "C" int otvae_bn_stats_slots(const float* x, int64_t M, int C, void* slots, int ld, void* stream) {
+    OTVAE_REQUIRE(x && slots && M > 0 && C > 0 && ld >= C, "otvae_bn_stats_slots: bad argument");
+    const int P = otvae_bn_stats_nparts(M, C);
+    bn_stats_kernel<<<P, 256, 0, (hipStream_t)stream>>>(x, M, C, nullptr, (long long*)slots, ld);
+    OTVAE_CHECK_LAUNCH("otvae_bn_stats_slots");
+    return OTVAE_OK;
+}
+
+static int bn_fold_from_abi(const char* who, const otvae_bn_fold* a, int C, BnFold* f) {
+    OTVAE_REQUIRE(a && a->slots && a->ld >= C && a->count > 0 && a->gamma && a->beta && a->scale_out && a->shift_out,
+                  "%s: incomplete BatchNorm fold descriptor", who);
+    OTVAE_REQUIRE((a->mean_out == nullptr) == (a->invstd_out == nullptr), "%s: mean_out and invstd_out come together", who);
+    f->slots = (const long long*)a->slots;
+    f->ld = a->ld;
+    f->count = a->count;
+    f->eps = a->eps;
+    f->momentum = a->momentum;
+    f->gamma = a->gamma;
+    f->beta = a->beta;
+    f->rmean = a->running_mean;
+    f->rvar = a->running_var;
+    f->nbt = (long long*)a->num_batches_tracked;
+    f->mean_out = a->mean_out;
+    f->invstd_out = a->invstd_out;
+    f->scale_out = a->scale_out;
+    f->shift_out = a->shift_out;
+    return OTVAE_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_slots_kernel(int n, BnFold f0, BnFold f1, int C) {
+    __shared__ float sink[2][1024];
+    for (int b = 0; b < n; ++b) bn_fold_prologue(b == 0 ? f0 : f1, C, sink[0], sink[1], true);
+}
+
+extern "C" int otvae_bn_finalize_slots(int n_bn, const otvae_bn_fold* folds, int C, void* stream) {
+    OTVAE_REQUIRE(n_bn >= 1 && n_bn <= 2 && folds && C > 0 && C <= 1024, "otvae_bn_finalize_slots: 1 or 2 branches, C <= 1024");
+    BnFold f[2] = {};
+    for (int b = 0; b < n_bn; ++b)
+        if (int rc = bn_fold_from_abi("otvae_bn_finalize_slots", folds + b, C, &f[b])) return rc;
+    bn_finalize_slots_kernel<<<1, 256, 0, (hipStream_t)stream>>>(n_bn, f[0], f[1], C);
+    OTVAE_CHECK_LAUNCH("otvae_bn_finalize_slots");
     return OTVAE_OK;
 }
 

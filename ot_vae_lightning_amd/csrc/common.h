@@ -64,3 +64,115 @@ __device__ __forceinline__ T wave_min(T v) {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// ---- BatchNorm statistic slots: cross-block sums WITHOUT a finalize launch, bit-reproducible (round 4) -------------------------------
+// A producer block adds its per-channel sums (sum x, sum x^2) into one of BN_SLOTS accumulators as two int64 fixed-point limbs
+// (hi: units of 2^-10, lo: the exact remainder in units of 2^-53, < 2^43) with non-returning agent-scope INTEGER atomics.  Integer
+// addition is associative: the totals do not depend on the order in which blocks arrive (fp64 atomics would), and 2048 blocks x 2^43 stay
+// below 2^63.  A value that is not finite (or beyond 2^51) cannot be represented: it raises the tensor's poison counter instead and the
+// consumer reads the statistics as NaN -- the propagation the plain fp64 partials had, which the device-side step guard relies on.
+// Layout: long long [BN_SLOTS][2 statistics][ld channels][2 limbs] + 2 words {poison counter, unused}; zero before the producer runs.
+// The consumer adds the BN_SLOTS slots in index order (exact integer sums) and converts once.
+#define BN_SLOTS 16
+
+__host__ __device__ inline size_t bn_slot_words(int ld) { return (size_t)BN_SLOTS * 2 * ld * 2 + 2; }
+
+__device__ __forceinline__ void bn_slot_add(long long* __restrict__ slots, int ld, unsigned block, int stat, int c, double v) {
+    if (!(fabs(v) < 2251799813685248.0)) {  // 2^51; also catches NaN
+        __hip_atomic_fetch_add(slots + (size_t)BN_SLOTS * 2 * ld * 2, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const double h = floor(v * 1024.0);
+    const double r = v - h * (1.0 / 1024.0);  // exact: 0 <= r < 2^-10
+    long long* dst = slots + ((((size_t)(block % BN_SLOTS) * 2 + stat) * ld + c) << 1);
+    __hip_atomic_fetch_add(dst, (long long)h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(dst + 1, (long long)floor(r * 9007199254740992.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the total of statistic `stat` of channel c (NaN when the producer met a value it could not represent)
+__device__ __forceinline__ double bn_slot_total(const long long* __restrict__ slots, int ld, int stat, int c) {
+    long long hi = 0, lo = 0;
+#pragma unroll
+    for (int s = 0; s < BN_SLOTS; ++s) {
+        const long long* p = slots + ((((size_t)s * 2 + stat) * ld + c) << 1);
+        hi += p[0];
+        lo += p[1];
+    }
+    if (slots[(size_t)BN_SLOTS * 2 * ld * 2] != 0) return __longlong_as_double(0x7ff8000000000000LL);
+    return (double)hi * (1.0 / 1024.0) + (double)lo * (1.0 / 9007199254740992.0);
+}
+
+// Everything the finalize launch took, for ONE branch (ConvLayer) that normalises a tensor whose statistics sit in slots: the consumer
+// kernel's prologue turns them into (scale, shift) in LDS -- every block for itself, S x 4 words per channel -- and its first block
+// also leaves mean / invstd / scale / shift in global memory for the backward pass and advances the running buffers
+// (nn.BatchNorm2d, training mode: momentum, unbiased running variance).
+struct BnFold {
+    const long long* slots;  // NULL: no fold (scale / shift come from global arrays as before)
+    int ld;
+    long long count;         // elements per channel (N * H * W of the normalised tensor)
+    float eps, momentum;
+    const float* gamma;
+    const float* beta;
+    float* rmean;            // nullable (with rvar, nbt): running statistics of THIS branch's BatchNorm
+    float* rvar;
+    long long* nbt;
+    float* mean_out;         // nullable: written when this branch is the one that publishes the shared mean / invstd
+    float* invstd_out;
+    float* scale_out;
+    float* shift_out;
+};
+
+// s_sc / s_sh: LDS, C floats each.  Ends with a block barrier.
+__device__ __forceinline__ void bn_fold_prologue(const BnFold& f, int C, float* s_sc, float* s_sh, bool first_block) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double s = bn_slot_total(f.slots, f.ld, 0, c), q = bn_slot_total(f.slots, f.ld, 1, c);
+        const double mu = s / (double)f.count;
+        double var = q / (double)f.count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float fmu = (float)mu;
+        const float fis = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float sc = f.gamma[c] * fis;
+        const float sh = fmaf(-fmu, sc, f.beta[c]);
+        s_sc[c] = sc;
+        s_sh[c] = sh;
+        if (first_block) {
+            f.scale_out[c] = sc;
+            f.shift_out[c] = sh;
+            if (f.mean_out) {
+                f.mean_out[c] = fmu;
+                f.invstd_out[c] = fis;
+            }
+            const double unbiased = f.count > 1 ? var * ((double)f.count / (double)(f.count - 1)) : var;
+            const bool fin = isfinite(fmu) && isfinite((float)unbiased);   // (as bn_finalize_kernel: a NaN statistic never enters the buffers)
+            if (f.rmean && fin) f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * fmu;
+            if (f.rvar && fin) f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * (float)unbiased;
+        }
+    }
+    if (first_block && threadIdx.x == 0 && f.nbt) *f.nbt += 1;
+    __syncthreads();
+}
+
+// A statistics destination is either the classic [2][ld][P] fp64 partials or (bit 0 of the pointer set: a device-code convention between
+// the host launchers of this library and its kernels, never part of the C ABI) the statistic slots above.
+__device__ __forceinline__ void bn_stat_out(double* partial, int which, int ld, int c, unsigned P, unsigned p, double t) {
+    if ((uintptr_t)partial & 1) bn_slot_add(reinterpret_cast<long long*>((uintptr_t)partial & ~(uintptr_t)1), ld, p, which, c, t);
+    else partial[((size_t)which * ld + c) * P + p] = t;
+}
+static inline double* bn_tag_slots(void* slots) { return reinterpret_cast<double*>((uintptr_t)slots | 1); }
+
+#define BN_TAB 1024   // channels a forward kernel keeps the BatchNorm affine of its input for in LDS (fold or copy)
+
+// (scale, shift) of the kernel's input into LDS: from the fold (every block computes them from the slots) or copied from the global
+// arrays a finalize launch left.  Ends with a block barrier.
+__device__ __forceinline__ void bn_tab_fill(const BnFold& f, const float* __restrict__ scale, const float* __restrict__ shift, int C,
+                                            float* s_sc, float* s_sh, bool first_block) {
+    if (f.slots) {
+        bn_fold_prologue(f, C, s_sc, s_sh, first_block);
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            s_sc[c] = scale[c];
+            s_sh[c] = shift[c];
+        }
+        __syncthreads();
+    }
+}

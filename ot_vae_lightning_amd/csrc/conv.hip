@@ -648,31 +648,51 @@ __device__ __forceinline__ void conv_gemm_body(char* __restrict__ smem, const Ge
                              (red[(2 * 2 + which) * BN + cc] + red[(3 * 2 + which) * BN + cc]);
             const unsigned p = bz * gx + bx;
             const unsigned Ptot = gx * gz;
-            partial[((size_t)which * CsPad + n0 + cc) * Ptot + p] = t;  // [2][CsPad][P]
+            bn_stat_out(partial, which, CsPad, n0 + cc, Ptot, p, t);  // [2][CsPad][P], or the statistic slots
         }
     }
 }
 
-template <int MODE, int NT, bool VEC, bool UT>
+// TAB (forward only): the BatchNorm affine of the input is kept in LDS -- computed by every block from the statistic slots (fold) or
+// copied from the global arrays -- and the body reads it there; TAB = false is the plain form (global arrays; any channel count).
+template <int MODE, int NT, bool VEC, bool UT, bool TAB = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(Geom g, const float* __restrict__ S, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int relu,
                                                         const float* __restrict__ Bmat, const float* __restrict__ bias,
                                                         const float* __restrict__ res, float* __restrict__ y,
                                                         const float* __restrict__ xin, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ gv,
-                                                        double* __restrict__ partial, int CsPad) {
+                                                        double* __restrict__ partial, int CsPad, BnFold fold) {
     __shared__ __align__(16) char smem[GemmSmem<NT>::bytes];
-    conv_gemm_body<MODE, NT, VEC, UT>(smem, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad,
-                                  blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
+    if constexpr (TAB) {
+        __shared__ __align__(16) float bn_tab[2][BN_TAB];
+        bn_tab_fill(fold, scale, shift, g.Cs, bn_tab[0], bn_tab[1], (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
+        conv_gemm_body<MODE, NT, VEC, UT>(smem, g, S, bn_tab[0], bn_tab[1], relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad,
+                                      blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
+    } else {
+        conv_gemm_body<MODE, NT, VEC, UT>(smem, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad,
+                                      blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
+    }
 }
 
 template <int MODE, bool VEC, bool UT>
 static void launch_gemm_v(int NT, dim3 grid, hipStream_t st, Geom g, const float* S, const float* scale, const float* shift,
                           int relu, const float* Bmat, const float* bias, const float* res, float* y, const float* xin,
-                          const float* mean, const float* invstd, float* gv, double* partial, int CsPad) {
-#define OTVAE_CG(N_)                                                                                                      \
-    conv_gemm_kernel<MODE, N_, VEC, UT><<<grid, 256, 0, st>>>(g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, \
-                                                          gv, partial, CsPad)
+                          const float* mean, const float* invstd, float* gv, double* partial, int CsPad, const BnFold& fold) {
+    // forward launches with a BatchNorm in front (and not more channels than the table holds) take the LDS-table form
+    const bool tab = MODE == 0 && (scale != nullptr || fold.slots != nullptr) && g.Cs <= BN_TAB;
+#define OTVAE_CG(N_)                                                                                                        \
+    do {                                                                                                                    \
+        if constexpr (MODE == 0) {                                                                                          \
+            if (tab) {                                                                                                      \
+                conv_gemm_kernel<MODE, N_, VEC, UT, true><<<grid, 256, 0, st>>>(g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, \
+                                                                            invstd, gv, partial, CsPad, fold);              \
+                break;                                                                                                      \
+            }                                                                                                               \
+        }                                                                                                                   \
+        conv_gemm_kernel<MODE, N_, VEC, UT, false><<<grid, 256, 0, st>>>(g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, \
+                                                                     gv, partial, CsPad, fold);                             \
+    } while (0)
     switch (NT) {
         case 1: OTVAE_CG(1); break;
         case 2: OTVAE_CG(2); break;
@@ -687,16 +707,16 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 template <int MODE>
 static void launch_gemm(int NT, dim3 grid, hipStream_t st, Geom g, const float* S, const float* scale, const float* shift,
                         int relu, const float* Bmat, const float* bias, const float* res, float* y, const float* xin,
-                        const float* mean, const float* invstd, float* gv, double* partial, int CsPad) {
+                        const float* mean, const float* invstd, float* gv, double* partial, int CsPad, const BnFold& fold = BnFold{}) {
     const bool vec = (g.Cs % 4 == 0) && (g.Cn % 4 == 0) && aligned16(S) && aligned16(Bmat) &&
                      (scale == nullptr || (aligned16(scale) && aligned16(shift)));
     const int CK = MODE == 0 ? g.Cs : g.Cn;
     if (vec && CK % KC == 0)  // a K-chunk lies inside one tap: uniform-tap pipeline
-        launch_gemm_v<MODE, true, true>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
+        launch_gemm_v<MODE, true, true>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad, fold);
     else if (vec)
-        launch_gemm_v<MODE, true, false>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
+        launch_gemm_v<MODE, true, false>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad, fold);
     else
-        launch_gemm_v<MODE, false, false>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad);
+        launch_gemm_v<MODE, false, false>(NT, grid, st, g, S, scale, shift, relu, Bmat, bias, res, y, xin, mean, invstd, gv, partial, CsPad, fold);
 }
 
 static void fwd_grid(const Geom& g, int& NT, dim3& grid, int& CnPad) {
@@ -727,19 +747,47 @@ extern "C" int otvae_conv_fwd_stats_ws(const otvae_conv_geom* gg, int* P, int* C
     return OTVAE_OK;
 }
 
-extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const float* scale, const float* shift, int relu,
-                              const float* wT, const float* bias, const float* residual, float* y, double* stat_partial,
-                              void* stream) {
+// host side of otvae_bn_fold -> the device descriptor (bn.hip holds the same conversion for otvae_bn_finalize_slots)
+static int fold_from_abi(const char* who, const otvae_bn_fold& a, int C, BnFold* f) {
+    *f = BnFold{};
+    if (!a.slots) return OTVAE_OK;
+    OTVAE_REQUIRE(a.ld >= C && a.count > 0 && a.gamma && a.beta && a.scale_out && a.shift_out, "%s: incomplete BatchNorm fold descriptor", who);
+    OTVAE_REQUIRE((a.mean_out == nullptr) == (a.invstd_out == nullptr), "%s: fold.mean_out and fold.invstd_out come together", who);
+    OTVAE_REQUIRE(C <= BN_TAB, "%s: a folded BatchNorm takes at most %d channels", who, BN_TAB);
+    f->slots = (const long long*)a.slots;
+    f->ld = a.ld;
+    f->count = a.count;
+    f->eps = a.eps;
+    f->momentum = a.momentum;
+    f->gamma = a.gamma;
+    f->beta = a.beta;
+    f->rmean = a.running_mean;
+    f->rvar = a.running_var;
+    f->nbt = (long long*)a.num_batches_tracked;
+    f->mean_out = a.mean_out;
+    f->invstd_out = a.invstd_out;
+    f->scale_out = a.scale_out;
+    f->shift_out = a.shift_out;
+    return OTVAE_OK;
+}
+
+// the forward launch with its two round-4 extras: the BatchNorm of the input folded in (fold.slots != NULL), and the output's statistics
+// into slots instead of partials (stat_slots != NULL)
+static int conv_fwd_ex(const otvae_conv_geom* gg, const float* x, const float* scale, const float* shift, int relu, const float* wT,
+                       const float* bias, const float* residual, float* y, double* stat_partial, void* stat_slots, const BnFold& fold,
+                       void* stream) {
     int rc = check_geom(gg, "otvae_conv_fwd");
     if (rc) return rc;
     OTVAE_REQUIRE(x && wT && y, "otvae_conv_fwd: NULL tensor");
     OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_conv_fwd: scale and shift must be given together");
+    OTVAE_REQUIRE(!(stat_partial && stat_slots), "otvae_conv_fwd: statistics go to partials OR to slots");
+    double* stat_dst = stat_slots ? bn_tag_slots(stat_slots) : stat_partial;
     Geom g = to_geom(gg);
     int NT, CnPad;
     dim3 grid;
     fwd_grid(g, NT, grid, CnPad);
     if (conv_small_ok(g)) {
-        conv_small_fwd(g, imin(grid.x, 1024), x, scale, shift, relu, wT, bias, residual, y, stat_partial, CnPad,
+        conv_small_fwd(g, imin(grid.x, 1024), x, scale, shift, relu, wT, bias, residual, y, stat_dst, CnPad, fold,
                        (hipStream_t)stream);
         OTVAE_CHECK_LAUNCH("otvae_conv_fwd(small)");
         return OTVAE_OK;
@@ -752,16 +800,22 @@ extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const f
             OTVAE_REQUIRE(aligned16(x) && aligned16(wT) && aligned16(y) && (!bias || aligned16(bias)) &&
                               (!residual || aligned16(residual)) && (!scale || (aligned16(scale) && aligned16(shift))),
                           "otvae_conv_fwd: tensors of a layer with channel counts %% 4 == 0 must be 16-byte aligned");
-            rc = conv_tile_fwd(pl, tg, sm, (hipStream_t)stream, x, scale, shift, relu, wT, bias, residual, y, stat_partial);
+            rc = conv_tile_fwd(pl, tg, sm, (hipStream_t)stream, x, scale, shift, relu, wT, bias, residual, y, stat_dst, fold);
             OTVAE_REQUIRE(rc == 0, "otvae_conv_fwd: no image-tile kernel for nt=%d rbw=%d", pl.nt, pl.rbw);
             OTVAE_CHECK_LAUNCH("otvae_conv_fwd(tile)");
             return OTVAE_OK;
         }
     }
     launch_gemm<0>(NT, grid, (hipStream_t)stream, g, x, scale, shift, relu, wT, bias, residual, y, nullptr, nullptr, nullptr,
-                   nullptr, stat_partial, CnPad);
+                   nullptr, stat_dst, CnPad, fold);
     OTVAE_CHECK_LAUNCH("otvae_conv_fwd");
     return OTVAE_OK;
+}
+
+extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const float* scale, const float* shift, int relu,
+                              const float* wT, const float* bias, const float* residual, float* y, double* stat_partial,
+                              void* stream) {
+    return conv_fwd_ex(gg, x, scale, shift, relu, wT, bias, residual, y, stat_partial, nullptr, BnFold{}, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ weight transpose
@@ -1507,6 +1561,7 @@ struct DevJob {
     int kind, NT, relu, cpad, Kp, has_bias, skip_dead;
     unsigned chunk;
     int gx, gy, gz, block0;
+    BnFold fold;          // fwd: the BatchNorm of x folded into this launch (fold.slots != NULL)
 };
 struct DevJobs {
     int n;
@@ -1525,8 +1580,15 @@ __global__ __launch_bounds__(256) void conv_jobs_kernel(DevJobs t) {
     const int bx = lb % J.gx;
     const int r = lb / J.gx;
     const int by = r % J.gy, bz = r / J.gy;
+    // forward jobs with a BatchNorm in front read its affine from LDS: folded from the statistic slots, or copied from the arrays a
+    // finalize launch left (the host packs such a job only with Cs <= BN_TAB)
+    __shared__ __align__(16) float bn_tab[2][BN_TAB];
+    const bool fwd_norm = J.kind == OTVAE_JOB_FWD && (J.scale != nullptr || J.fold.slots != nullptr);
+    if (fwd_norm) bn_tab_fill(J.fold, J.scale, J.shift, J.g.Cs, bn_tab[0], bn_tab[1], lb == 0);
+    const float* const fsc = fwd_norm ? bn_tab[0] : nullptr;
+    const float* const fsh = fwd_norm ? bn_tab[1] : nullptr;
 #define CJ_FWD(N_)                                                                                                        \
-    conv_gemm_body<0, N_, true, UT>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, J.bias, J.res, J.out, nullptr, nullptr, \
+    conv_gemm_body<0, N_, true, UT>(jobs_smem, J.g, J.a0, fsc, fsh, J.relu, J.b0, J.bias, J.res, J.out, nullptr, nullptr, \
                                 nullptr, nullptr, J.partial, J.cpad, bx, by, bz, J.gx, J.gz)
 #define CJ_DGRAD(N_)                                                                                                      \
     conv_gemm_body<1, N_, true, UT>(jobs_smem, J.g, J.a0, J.scale, J.shift, J.relu, J.b0, nullptr, nullptr, nullptr, J.xin,     \
@@ -1572,9 +1634,12 @@ static size_t job_smem_bytes(int kind, int NT) {
 
 static int run_single_job(const otvae_conv_job& jb, void* stream) {
     switch (jb.kind) {
-        case OTVAE_JOB_FWD:
-            return otvae_conv_fwd(&jb.geom, jb.x, jb.scale, jb.shift, jb.relu, jb.w, jb.bias, jb.residual, jb.y,
-                                  jb.stat_partial, stream);
+        case OTVAE_JOB_FWD: {
+            BnFold fold;
+            if (int rc = fold_from_abi("otvae_conv_multi", jb.fold, jb.geom.Cs, &fold)) return rc;
+            return conv_fwd_ex(&jb.geom, jb.x, jb.scale, jb.shift, jb.relu, jb.w, jb.bias, jb.residual, jb.y, jb.stat_partial,
+                               jb.stat_slots, fold, stream);
+        }
         case OTVAE_JOB_BWD_DATA:
             return otvae_conv_bwd_data(&jb.geom, jb.gy, jb.w, jb.x, jb.scale, jb.shift, jb.relu, jb.mean, jb.invstd, jb.gv,
                                        jb.bn_partial, stream);
@@ -1644,6 +1709,8 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
         int rc = check_geom(&jb.geom, "otvae_conv_multi");
         if (rc) return rc;
         OTVAE_REQUIRE((jb.scale == nullptr) == (jb.shift == nullptr), "otvae_conv_multi: job %d: scale/shift must come together", i);
+        OTVAE_REQUIRE(jb.kind == OTVAE_JOB_FWD || (jb.fold.slots == nullptr && jb.stat_slots == nullptr),
+                      "otvae_conv_multi: job %d: fold / stat_slots belong to forward jobs", i);
         Geom g = to_geom(&jb.geom);
         DevJob d = {};
         d.g = g;
@@ -1657,8 +1724,12 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             OTVAE_REQUIRE(jb.x && jb.w && jb.y, "otvae_conv_multi: job %d (forward): NULL tensor", i);
             dim3 grid;
             fwd_grid(g, d.NT, grid, d.cpad);
+            rc = fold_from_abi("otvae_conv_multi", jb.fold, g.Cs, &d.fold);
+            if (rc) return rc;
+            OTVAE_REQUIRE(!(jb.stat_partial && jb.stat_slots), "otvae_conv_multi: job %d: statistics go to partials OR to slots", i);
             packable = !conv_small_ok(g) && ch4 && aligned16(jb.x) && aligned16(jb.w) &&
-                       (jb.scale == nullptr || (aligned16(jb.scale) && aligned16(jb.shift)));
+                       (jb.scale == nullptr || (aligned16(jb.scale) && aligned16(jb.shift))) &&
+                       ((jb.scale == nullptr && jb.fold.slots == nullptr) || g.Cs <= BN_TAB);
             {
                 TilePlan pl;
                 dim3 tg;
@@ -1670,7 +1741,7 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             d.bias = jb.bias;
             d.res = jb.residual;
             d.out = jb.y;
-            d.partial = jb.stat_partial;
+            d.partial = jb.stat_slots ? bn_tag_slots(jb.stat_slots) : jb.stat_partial;
             d.gx = grid.x, d.gy = grid.y, d.gz = grid.z;
         } else if (jb.kind == OTVAE_JOB_BWD_DATA) {
             OTVAE_REQUIRE(jb.gy && jb.w && jb.gv, "otvae_conv_multi: job %d (data gradient): NULL tensor", i);

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) SMALL_OCC void conv_small_fwd_kernel(SmallGeom
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int relu, const float* __restrict__ wT,
                                                              const float* __restrict__ bias, const float* __restrict__ res,
-                                                             float* __restrict__ y, double* __restrict__ partial, int CnPad) {
+                                                             float* __restrict__ y, double* __restrict__ partial, int CnPad,
+                                                             BnFold fold) {
     constexpr int CSM = CS ? CS : SMALL_MAXC, CNM = CN ? CN : SMALL_MAXC;
     const int Cs = CS ? CS : g.Cs, Cn = CN ? CN : g.Cn;
     __shared__ __align__(16) float w_s[SMALL_MAXW];  // [tap][c][CNM]  (row padded to CNM when CN is generic)
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(256) SMALL_OCC void conv_small_fwd_kernel(SmallGeom
         b_s[c] = (bias && c < Cn) ? bias[c] : 0.f;
     }
     __syncthreads();
-    const bool affine = scale != nullptr;
+    if (fold.slots) bn_fold_prologue(fold, Cs, sc_s, sh_s, blockIdx.x == 0);  // the BatchNorm of x folded in (common.h); ends with a barrier
+    const bool affine = scale != nullptr || fold.slots != nullptr;
     float sc[CSM], sh[CSM];
 #pragma unroll
     for (int c = 0; c < CSM; ++c) {
@@ -207,8 +209,8 @@ __global__ __launch_bounds__(256) SMALL_OCC void conv_small_fwd_kernel(SmallGeom
         if (threadIdx.x < 2 * SMALL_MAXC) {
             const int which = threadIdx.x / SMALL_MAXC, c = threadIdx.x % SMALL_MAXC;
             if (c < Cn)
-                partial[((size_t)which * CnPad + c) * gridDim.x + blockIdx.x] =
-                    (redf[0][which][c] + redf[1][which][c]) + (redf[2][which][c] + redf[3][which][c]);
+                bn_stat_out(partial, which, CnPad, c, gridDim.x, blockIdx.x,
+                            (redf[0][which][c] + redf[1][which][c]) + (redf[2][which][c] + redf[3][which][c]));
         }
     }
 }
@@ -234,16 +236,16 @@ __global__ __launch_bounds__(256) SMALL_OCC void conv_small_fwd_kernel(SmallGeom
 
 int conv_small_fwd(const SmallGeom& g, int nblocks, const float* x, const float* scale, const float* shift, int relu,
                    const float* wT, const float* bias, const float* res, float* y, double* partial, int CnPad,
-                   hipStream_t st) {
+                   const BnFold& fold, hipStream_t st) {
 #define X(CS_, CN_, KS_)                                                                                          \
     if (g.Cs == CS_ && g.Cn == CN_ && g.KH == KS_ && g.KW == KS_) {                                               \
         conv_small_fwd_kernel<CS_, CN_, KS_><<<nblocks, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y, partial, \
-                                                                       CnPad);                                    \
+                                                                       CnPad, fold);                              \
         return 0;                                                                                                 \
     }
     SMALL_KS_CASES(X)
 #undef X
-    SMALL_DISPATCH(conv_small_fwd_kernel, <<<nblocks, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y, partial, CnPad));
+    SMALL_DISPATCH(conv_small_fwd_kernel, <<<nblocks, 256, 0, st>>>(g, x, scale, shift, relu, wT, bias, res, y, partial, CnPad, fold));
     return 0;
 }
 

@@ -31,7 +31,7 @@ struct TilePlan {
 bool conv_tile_plan(const Geom& g, int mode, TilePlan& pl, dim3& grid, size_t& smem);
 int conv_tile_fwd(const TilePlan& pl, dim3 grid, size_t smem, hipStream_t st, const float* x, const float* scale,
                   const float* shift, int relu, const float* wT, const float* bias, const float* res, float* y,
-                  double* partial);
+                  double* partial, const BnFold& fold = BnFold{});
 int conv_tile_dgrad(const TilePlan& pl, dim3 grid, size_t smem, hipStream_t st, const float* gy, const float* wD,
                     const float* x, const float* scale, const float* shift, int relu, const float* mean,
                     const float* invstd, float* gv, double* partial);

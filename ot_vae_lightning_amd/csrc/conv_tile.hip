@@ -36,9 +36,21 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float
                                                         // DGRAD epilogue
                                                         const float* __restrict__ xin, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ gv,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, BnFold fold) {
     constexpr int BN = 16 * NT;
     extern __shared__ __align__(16) float tsm[];
+    // forward: the BatchNorm affine of the input in LDS (CK <= 256 here) -- folded from the statistic slots by every block, or copied
+    // from the arrays a finalize launch left (common.h: bn_tab_fill)
+    __shared__ __align__(16) float bn_tab[2][256];
+    const float* sc_p = nullptr;
+    const float* sh_p = nullptr;
+    if constexpr (MODE == 0) {
+        if (scale != nullptr || fold.slots != nullptr) {
+            bn_tab_fill(fold, scale, shift, pl.CK, bn_tab[0], bn_tab[1], (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
+            sc_p = bn_tab[0];
+            sh_p = bn_tab[1];
+        }
+    }
     float* V = tsm;                                   // [IPB][Hv][Wv][CKp]
     float* Wl = tsm + pl.vfloats;                     // [tpc*CK][BN]
     double* red = reinterpret_cast<double*>(Wl + TILE_WMAX);  // [4 waves][2][BN]
@@ -82,9 +94,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float
                 if (dst[u] < 0) continue;
                 float4 a = v[u];
                 if (MODE == 0) {
-                    if (scale != nullptr) {
-                        const float4 sc = *reinterpret_cast<const float4*>(scale + cc[u]);
-                        const float4 sh = *reinterpret_cast<const float4*>(shift + cc[u]);
+                    if (sc_p != nullptr) {
+                        const float4 sc = *reinterpret_cast<const float4*>(sc_p + cc[u]);
+                        const float4 sh = *reinterpret_cast<const float4*>(sh_p + cc[u]);
                         a.x = fmaf(a.x, sc.x, sh.x);
                         a.y = fmaf(a.y, sc.y, sh.y);
                         a.z = fmaf(a.z, sc.z, sh.z);
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TilePlan pl, const float
                              (red[(2 * 2 + which) * BN + cc] + red[(3 * 2 + which) * BN + cc]);
             const unsigned p = blockIdx.z * gridDim.x + blockIdx.x;
             const unsigned Ptot = gridDim.x * gridDim.z;
-            if (n0 + cc < pl.cpad) partial[((size_t)which * pl.cpad + n0 + cc) * Ptot + p] = t;  // [2][cpad][P]
+            if (n0 + cc < pl.cpad) bn_stat_out(partial, which, pl.cpad, n0 + cc, Ptot, p, t);  // [2][cpad][P], or the statistic slots
         }
     }
 }
@@ -485,7 +497,8 @@ bool conv_tile_plan(const Geom& g, int mode, TilePlan& pl, dim3& grid, size_t& s
 template <int MODE>
 static int tile_launch(const TilePlan& pl, dim3 grid, size_t smem, hipStream_t st, const float* S, const float* scale,
                        const float* shift, int relu, const float* Wg, const float* bias, const float* res, float* y,
-                       const float* xin, const float* mean, const float* invstd, float* gv, double* partial) {
+                       const float* xin, const float* mean, const float* invstd, float* gv, double* partial,
+                       const BnFold& fold = BnFold{}) {
 #define TL(N_, R_)                                                                                                    \
     do {                                                                                                              \
         static bool attr_done = false;                                                                                \
@@ -495,7 +508,7 @@ static int tile_launch(const TilePlan& pl, dim3 grid, size_t smem, hipStream_t s
             attr_done = true;                                                                                         \
         }                                                                                                             \
         conv_tile_kernel<MODE, N_, R_><<<grid, 256, smem, st>>>(pl, S, scale, shift, relu, Wg, bias, res, y, xin, mean, \
-                                                                invstd, gv, partial);                                 \
+                                                                invstd, gv, partial, fold);                           \
     } while (0)
 #define TLR(N_)                                  \
     switch (pl.rbw) {                            \
@@ -528,9 +541,9 @@ static int tile_launch(const TilePlan& pl, dim3 grid, size_t smem, hipStream_t s
 
 int conv_tile_fwd(const TilePlan& pl, dim3 grid, size_t smem, hipStream_t st, const float* x, const float* scale,
                   const float* shift, int relu, const float* wT, const float* bias, const float* res, float* y,
-                  double* partial) {
+                  double* partial, const BnFold& fold) {
     return tile_launch<0>(pl, grid, smem, st, x, scale, shift, relu, wT, bias, res, y, nullptr, nullptr, nullptr, nullptr,
-                          partial);
+                          partial, fold);
 }
 
 int conv_tile_dgrad(const TilePlan& pl, dim3 grid, size_t smem, hipStream_t st, const float* gy, const float* wD,
