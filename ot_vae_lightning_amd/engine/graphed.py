@@ -157,7 +157,11 @@ class GraphedNelbo:
             if not explicit_eps:
                 engine._draw_eps()      # device-side generator: every replay draws fresh noise
             engine._refresh_wd()
-            loss, logs, art = self._nelbo(engine._batch(), 0)
+            HF.SlotArena.begin_step(engine.device)   # the BatchNorm statistic slots of this forward pass
+            try:
+                loss, logs, art = self._nelbo(engine._batch(), 0)
+            finally:
+                HF.SlotArena.end_step(engine.device)
             return loss, logs, art
 
         def backward(loss):

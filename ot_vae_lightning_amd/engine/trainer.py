@@ -272,6 +272,7 @@ class HipTrainer:
                                                     stream()), "otvae_step_begin_guarded")
         else:
             check(self.lib.otvae_step_begin(ptr(self.step_count), stream()), "otvae_step_begin")
+        HF.SlotArena.begin_step(self.device)   # the BatchNorm statistic slots of this step's forward pass (functional.SlotArena)
 
     def _forward_backward(self):
         self._step_begin()
@@ -313,6 +314,7 @@ class HipTrainer:
             _PendingReduce.reset(self.device)
             raise
         finally:
+            HF.SlotArena.end_step(self.device)
             PriorLane.enabled = False
             PriorLane.join(self.device)  # (already joined by the prior's backward when it took part in the pass)
         # the model's handle on the encoder output would keep this step's autograd graph -- and with it the parameters'
@@ -414,6 +416,7 @@ class HipTrainer:
                 # retain_graph: without it the engine also releases the saved tensors of the node that produced h
                 self._backward(loss, inputs=self._post_params + [h], retain_graph=True)
         finally:
+            HF.SlotArena.end_step(self.device)
             PriorLane.enabled = False
             PriorLane.join(self.device)
         self._cut = h

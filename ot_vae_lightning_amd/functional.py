@@ -117,16 +117,111 @@ class BNBranch:
         self.running_mean, self.running_var, self.num_batches_tracked = running_mean, running_var, num_batches_tracked
 
 
+# OTVAE_BN_SLOTS: 1 (default) = inside a training engine's step the BatchNorm sums of a layer's output go to STATISTIC SLOTS (csrc/common.h:
+# int64 fixed-point limbs added with integer atomics: order-independent, bit-reproducible) and the consumer kernel folds the finalize
+# arithmetic into its own prologue (no otvae_bn_finalize launch: 30 fewer dependent launches in the forward pass of the MNIST step);
+# 0 = per-block fp64 partials + a finalize launch (rounds 1-3).  The slots of a step come from one arena the engine zeroes at the
+# start of the step; outside an engine's step (plain module calls) the partial route is taken.
+BN_SLOTS_MODE = int(os.environ.get("OTVAE_BN_SLOTS", "1"))
+
+
+class SlotArena:
+    """int64 words for the statistic slots of one step (per device): zeroed and rewound by the engine at the start of every step
+    (``begin_step``), handed out in a fixed order (``take``), so that a captured step bakes the same addresses the warm-up steps used."""
+    _state: dict = {}   # device -> [tensor, offset, active]
+    WORDS = 1 << 20      # 8 MiB: ~60 tensors of 16 slots x 2 statistics x <= 768 channels x 2 limbs fit many times over
+
+    @staticmethod
+    def begin_step(device) -> None:
+        if BN_SLOTS_MODE == 0:
+            return
+        st = SlotArena._state.get(device)
+        if st is None:
+            st = SlotArena._state[device] = [torch.zeros(SlotArena.WORDS, device=device, dtype=torch.int64), 0, False]
+        st[0].zero_()
+        st[1], st[2] = 0, True
+
+    @staticmethod
+    def end_step(device) -> None:
+        st = SlotArena._state.get(device)
+        if st is not None:
+            st[2] = False
+
+    @staticmethod
+    def take(device, words: int) -> Optional[Tensor]:
+        st = SlotArena._state.get(device)
+        if st is None or not st[2]:
+            return None
+        words = (int(words) + 1) // 2 * 2   # 16-byte aligned views
+        if st[1] + words > st[0].numel():
+            return None   # (full: the caller keeps the partial route)
+        v = st[0][st[1]: st[1] + words]
+        st[1] += words
+        return v
+
+
+class PendingFold:
+    """Statistics of x that sit in slots and have not been turned into (mean, invstd, scale, shift) yet: the consumer launch folds that
+    into its prologue and ITS first block fills the four tensors (``fold_struct``); a consumer that cannot calls ``materialize``."""
+    __slots__ = ("slots", "ld", "count", "branches", "update", "mean", "invstd", "scales", "shifts", "done")
+
+    def __init__(self, slots, ld, count, branches, update, mean, invstd, scales, shifts):
+        self.slots, self.ld, self.count, self.branches, self.update = slots, ld, count, list(branches), update
+        self.mean, self.invstd, self.scales, self.shifts, self.done = mean, invstd, scales, shifts, False
+
+    def fold_struct(self, j: int, publish: bool) -> "_lib.BnFold":
+        br = self.branches[j]
+        f = _lib.BnFold()
+        f.slots, f.ld, f.count, f.eps, f.momentum = ptr(self.slots), int(self.ld), int(self.count), BN_EPS, BN_MOMENTUM
+        f.gamma, f.beta = ptr(br.gamma), ptr(br.beta)
+        if self.update:
+            f.running_mean, f.running_var, f.num_batches_tracked = ptr(br.running_mean), ptr(br.running_var), ptr(br.num_batches_tracked)
+        if publish:
+            f.mean_out, f.invstd_out = ptr(self.mean), ptr(self.invstd)
+        f.scale_out, f.shift_out = ptr(self.scales[j]), ptr(self.shifts[j])
+        return f
+
+    def materialize(self) -> None:
+        if self.done:
+            return
+        n = len(self.branches)
+        arr = (_lib.BnFold * n)(*[self.fold_struct(j, j == 0) for j in range(n)])
+        check(_lib.load().otvae_bn_finalize_slots(n, arr, int(self.mean.numel()), stream()), "otvae_bn_finalize_slots")
+        self.done = True
+
+
 @torch.no_grad()
-def bn_batch_stats(x: Tensor, branches: Sequence[BNBranch], update_running: bool = True):
+def bn_batch_stats(x: Tensor, branches: Sequence[BNBranch], update_running: bool = True, allow_fold: bool = False):
     """Training-mode statistics of x (NHWC) shared by all ``branches``: returns mean, invstd and one
     (scale, shift) pair per branch; updates the running buffers like nn.BatchNorm2d (networks/cnn.py:122).
     If x was produced by one of our conv kernels, its per-channel partial sums were already written by that kernel's
-    epilogue (``x._otvae_stats``) and no pass over x is needed."""
+    epilogue (``x._otvae_stats``) and no pass over x is needed.
+    ``allow_fold``: the caller's kernel can fold the finalize arithmetic into its prologue -- then, when the sums sit in statistic
+    slots, a fifth value (a ``PendingFold``) is returned and the four tensors are filled by that kernel's first block."""
     lib = _lib.load()
     n, c, h, w = x.shape
     m = n * h * w
+    mean = torch.empty(c, device=x.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    scales = [torch.empty_like(mean) for _ in branches]
+    shifts = [torch.empty_like(mean) for _ in branches]
+    nb = len(branches)
+    upd = update_running
     pre = getattr(x, "_otvae_stats", None)
+    slots = ld = None
+    if pre is not None and isinstance(pre[0], str):      # ("slots", slots, ld): the producer's epilogue used the statistic slots
+        _, slots, ld = pre
+    elif pre is None and 1 <= nb <= 2 and c <= 1024:
+        ld = c
+        slots = SlotArena.take(x.device, lib.otvae_bn_slots_words(ld))
+        if slots is not None:
+            check(lib.otvae_bn_stats_slots(ptr(x), m, c, ptr(slots), ld, stream()), "otvae_bn_stats_slots")
+    if slots is not None:
+        fold = PendingFold(slots, ld, m, branches, upd, mean, invstd, scales, shifts)
+        if allow_fold and 1 <= nb <= 2:
+            return mean, invstd, scales, shifts, fold
+        fold.materialize()
+        return (mean, invstd, scales, shifts, None) if allow_fold else (mean, invstd, scales, shifts)
     if pre is not None:
         partial, p, ld = pre
     else:
@@ -134,12 +229,6 @@ def bn_batch_stats(x: Tensor, branches: Sequence[BNBranch], update_running: bool
         ld = c
         partial = torch.empty((p, 2, c), device=x.device, dtype=torch.float64)
         check(lib.otvae_bn_stats(ptr(x), m, c, ptr(partial), stream()), "otvae_bn_stats")
-    mean = torch.empty(c, device=x.device, dtype=torch.float32)
-    invstd = torch.empty_like(mean)
-    scales = [torch.empty_like(mean) for _ in branches]
-    shifts = [torch.empty_like(mean) for _ in branches]
-    nb = len(branches)
-    upd = update_running
     check(lib.otvae_bn_finalize(
         ptr(partial), p, ld, m, c, BN_EPS, BN_MOMENTUM, ptr(mean), ptr(invstd), nb,
         ptr_array([b.gamma for b in branches]), ptr_array([b.beta for b in branches]),
@@ -147,7 +236,7 @@ def bn_batch_stats(x: Tensor, branches: Sequence[BNBranch], update_running: bool
         ptr_array([b.running_var if upd else None for b in branches]),
         ptr_array([b.num_batches_tracked if upd else None for b in branches]),
         ptr_array(scales), ptr_array(shifts), stream()), "otvae_bn_finalize")
-    return mean, invstd, scales, shifts
+    return (mean, invstd, scales, shifts, None) if allow_fold else (mean, invstd, scales, shifts)
 
 
 @torch.no_grad()
@@ -536,31 +625,47 @@ def conv_forward_launch(x, specs, stats, tensors):
     (weight, bias, gamma, beta, residual) per branch.  Returns (outputs, geometries, per-output statistics partials)."""
     lib = _lib.load()
     nbr = len(specs)
-    mean, invstd, scales, shifts, training = stats
+    mean, invstd, scales, shifts, training = stats[:5]
+    fold = stats[5] if len(stats) > 5 else None     # PendingFold: the BatchNorm finalize of x rides in this launch's prologue
+    if fold is not None and (fold.done or x.shape[1] > 1024):
+        fold.materialize()
+        fold = None
     outs, geoms, out_stats = [], [], []
     jobs = (_lib.ConvJob * nbr)()
     keep = []
+    jn = 0   # index among the normalised branches (= the PendingFold's branch order)
     for b, sp in enumerate(specs):
         w, bias, gamma, beta, res = tensors[5 * b: 5 * b + 5]
         g, ho, wo = _geom(x, w, sp.stride, sp.pad, sp.up)
         y = empty_nhwc(x.shape[0], w.shape[0], ho, wo, x)
-        part, st = None, None
+        part, st, slots_out = None, None, None
         if sp.out_stats:
             p_s, ld = _conv_plan(g, bias is not None)[:2]
-            part = torch.empty((p_s, 2, ld), device=x.device, dtype=torch.float64)
-            st = (part, p_s, ld)
+            slots_out = SlotArena.take(x.device, lib.otvae_bn_slots_words(ld)) if ld <= 1024 else None
+            if slots_out is not None:
+                st = ("slots", slots_out, ld)
+            else:
+                part = torch.empty((p_s, 2, ld), device=x.device, dtype=torch.float64)
+                st = (part, p_s, ld)
         jb = jobs[b]
         jb.kind, jb.relu, jb.geom = _lib.JOB_FWD, int(sp.relu), g
         jb.x = ptr(x)
-        jb.scale = ptr(scales[b]) if sp.has_norm else None
-        jb.shift = ptr(shifts[b]) if sp.has_norm else None
+        if sp.has_norm and fold is not None:
+            jb.fold = fold.fold_struct(jn, jn == 0)
+        else:
+            jb.scale = ptr(scales[b]) if sp.has_norm else None
+            jb.shift = ptr(shifts[b]) if sp.has_norm else None
+        jn += 1 if sp.has_norm else 0
         jb.w, jb.bias, jb.residual, jb.y, jb.stat_partial = ptr(w), ptr(bias), ptr(res), ptr(y), ptr(part)
+        jb.stat_slots = ptr(slots_out)
         keep.append(part)
         outs.append(y)
         geoms.append(g)
         out_stats.append(st)
     # both branches of a ConvBlock read the same x and are independent: one launch (otvae_conv_multi)
     check(lib.otvae_conv_multi(nbr, jobs, stream()), "otvae_conv_multi(forward)")
+    if fold is not None:
+        fold.done = True
     if JOB_TRACE is not None:
         _trace_jobs(jobs, nbr)
     return outs, geoms, out_stats
@@ -575,7 +680,7 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
     side stream's launches are recorded after the BatchNorm backward pair (with no data-gradient job in this call they would otherwise
     become the first successor of the launch stream's last kernel, and a captured graph keeps only the first successor on its queue)."""
     lib = _lib.load()
-    mean, invstd, scales, shifts, training = stats
+    mean, invstd, scales, shifts, training = stats[:5]
     nbr = len(specs)
     n, cs, hs, ws = x.shape
     m_in = n * hs * ws
@@ -1055,8 +1160,9 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
     scales: List[Optional[Tensor]] = [None] * len(specs)
     shifts: List[Optional[Tensor]] = [None] * len(specs)
     if bns:
+        fold = None
         if training:
-            mean, invstd, sc, sh = bn_batch_stats(x, bns)
+            mean, invstd, sc, sh, fold = bn_batch_stats(x, bns, allow_fold=True)
         else:
             if len(bns) > 1:
                 # running statistics of the branches may differ (loaded checkpoints): no shared (mean, invstd)
@@ -1068,7 +1174,7 @@ def conv_layers(x: Tensor, branches: Sequence[dict], training: bool = True):
             if sp.has_norm:
                 j = next(it)
                 scales[i], shifts[i] = sc[j], sh[j]
-    stats = (mean, invstd, scales, shifts, training)
+    stats = (mean, invstd, scales, shifts, training, fold if bns else None)
     stats_out: List[Optional[tuple]] = []
     out = _ConvBNFn.apply(x, tuple(specs), stats, tuple(params_ref), stats_out, *tensors)
     out = out if isinstance(out, tuple) else (out,)
@@ -1144,7 +1250,10 @@ class _AttnStageFn(torch.autograd.Function):
     def forward(ctx, x, meta, wq, gamma, beta, wp, res):
         lib = _lib.load()
         heads, scale, stats, pref_q, pref_p, rows, need_aux, stats_out = meta
-        mean, invstd, scales, shifts, training = stats
+        mean, invstd, scales, shifts, training = stats[:5]
+        fold = stats[5] if len(stats) > 5 else None
+        if fold is not None and fold.done:
+            fold = None
         n, hc, hh, ww = x.shape
         t, c = hh * ww, hc // heads
         # the fused backward kernel forms q / k / v again from x: qkv is written only for a three-launch backward pass
@@ -1154,11 +1263,25 @@ class _AttnStageFn(torch.autograd.Function):
         y = empty_nhwc(n, hc, hh, ww, x)
         lse = torch.empty((n, heads, t), device=x.device, dtype=torch.float32)
         aux = torch.empty((n, heads, t, c * c), device=x.device, dtype=torch.float32) if (need_aux and c <= 2) else None
-        part = torch.empty((rows, 2, hc), device=x.device, dtype=torch.float64) if stats_out is not None else None
-        check(lib.otvae_attn_stage_fwd(ptr(x), ptr(scales[0]), ptr(shifts[0]), ptr(wq), ptr(wp), ptr(res), n, t, heads, c, scale,
-                                       ptr(qkv), ptr(out), ptr(lse), ptr(aux), ptr(y), ptr(part), stream()), "otvae_attn_stage_fwd")
+        part = slots_out = None
         if stats_out is not None:
-            stats_out.append((part, rows, hc))
+            slots_out = SlotArena.take(x.device, lib.otvae_bn_slots_words(hc))
+            if slots_out is None:
+                part = torch.empty((rows, 2, hc), device=x.device, dtype=torch.float64)
+        if fold is not None or slots_out is not None:
+            # the BatchNorm finalize of x folded into the launch's prologue and / or the output's sums into statistic slots
+            fs = fold.fold_struct(0, True) if fold is not None else None
+            check(lib.otvae_attn_stage_fwd_fold(ptr(x), C.byref(fs) if fs is not None else None,
+                                                None if fold is not None else ptr(scales[0]), None if fold is not None else ptr(shifts[0]),
+                                                ptr(wq), ptr(wp), ptr(res), n, t, heads, c, scale, ptr(qkv), ptr(out), ptr(lse), ptr(aux),
+                                                ptr(y), ptr(part), ptr(slots_out), stream()), "otvae_attn_stage_fwd_fold")
+            if fold is not None:
+                fold.done = True
+        else:
+            check(lib.otvae_attn_stage_fwd(ptr(x), ptr(scales[0]), ptr(shifts[0]), ptr(wq), ptr(wp), ptr(res), n, t, heads, c, scale,
+                                           ptr(qkv), ptr(out), ptr(lse), ptr(aux), ptr(y), ptr(part), stream()), "otvae_attn_stage_fwd")
+        if stats_out is not None:
+            stats_out.append(("slots", slots_out, hc) if slots_out is not None else (part, rows, hc))
         ctx.cfg = (heads, scale, stats, pref_q, pref_p, gamma is not None, res is not None)
         ctx.geoms = (_geom(x, wq, 1, 0, 1)[0], _geom(out, wp, 1, 0, 1)[0])
         ctx.save_for_backward(x, wq, gamma, beta, wp, res, qkv, out, lse, aux)
@@ -1231,17 +1354,17 @@ def attention_stage(x: Tensor, qkv_branch: dict, n_heads: int, proj_branch: dict
     if res is not None:
         res = as_nhwc(res)
     has_norm = qkv_branch.get("gamma") is not None
-    mean = invstd = None
+    mean = invstd = fold = None
     scales, shifts = [None], [None]
     if has_norm:
         bn = BNBranch(qkv_branch["gamma"], qkv_branch["beta"], qkv_branch.get("running_mean"), qkv_branch.get("running_var"),
                       qkv_branch.get("num_batches_tracked"))
         if training:
-            mean, invstd, scales, shifts = bn_batch_stats(x, [bn])
+            mean, invstd, scales, shifts, fold = bn_batch_stats(x, [bn], allow_fold=True)
         else:
             mean, invstd, s0, h0 = bn_eval_affine(bn)
             scales, shifts = [s0], [h0]
-    stats = (mean, invstd, scales, shifts, training)
+    stats = (mean, invstd, scales, shifts, training, fold)
     stats_out: Optional[list] = [] if (proj_branch.get("out_stats", False) and training) else None
     meta = (n_heads, 1.0 / c, stats, (wq, None, qkv_branch.get("gamma"), qkv_branch.get("beta")), (wp, None, None, None), rows,
             need_aux, stats_out)

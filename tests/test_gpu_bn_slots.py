@@ -1,0 +1,155 @@
+"""BatchNorm statistic slots and the finalize folded into the consumer kernel (csrc/common.h ``bn_slot_add`` / ``bn_fold_prologue``,
+functional.SlotArena / PendingFold).
+
+What the reference computes here is nn.BatchNorm2d in training mode in front of every ConvLayer (networks/cnn.py:122, 183-192): batch
+mean / biased variance for the normalisation, momentum update of the running buffers with the unbiased variance.  The slots route
+must give those numbers (vs an fp64 restatement in the test), must not depend on the order in which blocks arrive (bit-equal
+repeats), must propagate a non-finite input as NaN statistics without touching the running buffers, and a training step taken
+with it must agree with the step taken through the per-block partials + finalize launch of rounds 1-3.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from detfill import mnist_like, normal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    assert torch.cuda.is_available()
+    import ot_vae_lightning_amd as pkg
+    return pkg
+
+
+def _truth(x, gamma, beta, rmean, rvar, eps=1e-5, momentum=0.1):
+    xd = x.double()
+    m = xd.numel() // xd.shape[1]
+    mu = xd.mean(dim=(0, 2, 3))
+    var = xd.var(dim=(0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    scale = gamma.double() * invstd
+    shift = beta.double() - mu * scale
+    unb = var * (m / (m - 1)) if m > 1 else var
+    return mu, invstd, scale, shift, (1 - momentum) * rmean.double() + momentum * mu, (1 - momentum) * rvar.double() + momentum * unb
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 5, 7), (32, 32, 16, 16), (2, 257, 3, 3), (1, 1024, 1, 1), (64, 8, 32, 32)])
+def test_slots_statistics_and_finalize_vs_fp64(A, shape):
+    from ot_vae_lightning_amd import _lib, functional as HF
+    from ot_vae_lightning_amd._lib import check, ptr, stream
+    lib = _lib.load()
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 3.0 + 1.5).cuda().contiguous(memory_format=torch.channels_last)
+    gam = [(torch.rand(c, generator=g) + 0.5).cuda() for _ in range(2)]
+    bet = [torch.randn(c, generator=g).cuda() for _ in range(2)]
+    rm0 = [torch.randn(c, generator=g).cuda() for _ in range(2)]
+    rv0 = [(torch.rand(c, generator=g) + 0.5).cuda() for _ in range(2)]
+    m = n * h * w
+
+    def run():
+        rm, rv = [t.clone() for t in rm0], [t.clone() for t in rv0]
+        nbt = [torch.tensor(3, device="cuda") for _ in range(2)]
+        slots = torch.zeros(lib.otvae_bn_slots_words(c), device="cuda", dtype=torch.int64)
+        check(lib.otvae_bn_stats_slots(ptr(x), m, c, ptr(slots), c, stream()), "stats_slots")
+        br = [HF.BNBranch(gam[j], bet[j], rm[j], rv[j], nbt[j]) for j in range(2)]
+        mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+        sc, sh = [torch.empty(c, device="cuda") for _ in range(2)], [torch.empty(c, device="cuda") for _ in range(2)]
+        fold = HF.PendingFold(slots, c, m, br, True, mean, invstd, sc, sh)
+        fold.materialize()
+        torch.cuda.synchronize()
+        return mean, invstd, sc, sh, rm, rv, nbt, slots
+
+    mean, invstd, sc, sh, rm, rv, nbt, slots = run()
+    assert int(slots[-2]) == 0, "no value was unrepresentable"
+    for j in range(2):
+        mu_t, is_t, sc_t, sh_t, rm_t, rv_t = _truth(x, gam[j], bet[j], rm0[j], rv0[j])
+        # the sums are exact (integer limbs); what is left is one rounding to fp32 per number
+        for got, want, name in ((mean, mu_t, "mean"), (invstd, is_t, "invstd"), (sc[j], sc_t, "scale"), (sh[j], sh_t, "shift"),
+                                (rm[j], rm_t, "running_mean"), (rv[j], rv_t, "running_var")):
+            err = float((got.double() - want).abs().max())
+            tol = 4e-7 * float(want.abs().max()) + 1e-7
+            assert err <= tol, (shape, j, name, err, tol)
+        assert int(nbt[j]) == 4
+    # order independence: the same bits every time, and the same numbers as the per-block fp64 partials of rounds 1-3 give
+    again = run()
+    for a, b in zip((mean, invstd, *sc, *sh, *rm, *rv), (again[0], again[1], *again[2], *again[3], *again[4], *again[5])):
+        assert torch.equal(a, b)
+    rm2, rv2 = [t.clone() for t in rm0], [t.clone() for t in rv0]
+    br = [HF.BNBranch(gam[j], bet[j], rm2[j], rv2[j], torch.tensor(3, device="cuda")) for j in range(2)]
+    mean_p, invstd_p, sc_p, sh_p = HF.bn_batch_stats(x, br)
+    for a, b in zip((mean, invstd, *sc, *sh, *rm, *rv), (mean_p, invstd_p, *sc_p, *sh_p, *rm2, *rv2)):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), float((a - b).abs().max())
+
+
+def test_slots_non_finite_input_reads_as_nan_and_keeps_the_running_buffers(A):
+    from ot_vae_lightning_amd import _lib, functional as HF
+    from ot_vae_lightning_amd._lib import check, ptr, stream
+    lib = _lib.load()
+    c = 16
+    x = torch.randn(8, c, 4, 4).cuda().contiguous(memory_format=torch.channels_last)
+    x[3, 5, 2, 1] = float("inf")
+    slots = torch.zeros(lib.otvae_bn_slots_words(c), device="cuda", dtype=torch.int64)
+    check(lib.otvae_bn_stats_slots(ptr(x), 8 * 16, c, ptr(slots), c, stream()), "stats_slots")
+    rm, rv, nbt = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"), torch.tensor(0, device="cuda")
+    br = [HF.BNBranch(torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), rm, rv, nbt)]
+    mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    sc, sh = [torch.empty(c, device="cuda")], [torch.empty(c, device="cuda")]
+    HF.PendingFold(slots, c, 128, br, True, mean, invstd, sc, sh).materialize()
+    torch.cuda.synchronize()
+    assert int(slots[-2]) > 0
+    assert torch.isnan(mean).all() and torch.isnan(sc[0]).all(), "an unrepresentable sum poisons the tensor's statistics"
+    assert torch.equal(rm, torch.zeros_like(rm)) and torch.equal(rv, torch.ones_like(rv)), "NaN statistics never enter the running buffers"
+
+
+CONFIGS = {
+    # BASELINE configs[1] / configs[3] shapes (MNIST 1x32x32 capacity 8 latent 128; CIFAR-10 3x32x32 capacity 16 latent 256); the
+    # default max_attn_res = 16 puts AttentionBlocks at 16x16 and below, max_attn_res = 32 at every resolution
+    "mnist": dict(cin=1, latent=128, capacity=8, max_attn_res=16),
+    "mnist_attn32": dict(cin=1, latent=128, capacity=8, max_attn_res=32),
+    "cifar": dict(cin=3, latent=256, capacity=16, max_attn_res=16),
+}
+
+
+def _model(A, seed, cin, latent, capacity, max_attn_res):
+    torch.manual_seed(seed)
+    enc = A.CNN(cin, 2 * latent, 32, 1, capacity=capacity, down_sample=True, residual="add", max_attn_res=max_attn_res)
+    dec = A.CNN(latent, cin, 1, 32, capacity=capacity, up_sample=True, residual="add", max_attn_res=max_attn_res)
+    return A.VAE(encoder=enc, decoder=dec, prior=A.GaussianPrior(loss_coeff=0.1)).cuda().train()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("cfg", list(CONFIGS))
+def test_training_steps_through_slots_agree_with_the_finalize_launch_route(A, monkeypatch, graph, cfg):
+    """Three optimizer steps with the forward BatchNorm finalize folded into the consumer kernels (statistic slots) against the same
+    steps through per-block partials + ``otvae_bn_finalize``: the two routes round the sums differently (exact integer limbs vs
+    a fixed-order fp64 sum), so the steps agree to fp32 rounding, not bit for bit; each route is bit-reproducible by itself."""
+    from ot_vae_lightning_amd import functional as HF
+    B, kw = 64, CONFIGS[cfg]
+    x = [normal((B, kw["cin"], 32, 32), 140 + i).cuda() if kw["cin"] > 1 else mnist_like(B, 140 + i).cuda() for i in range(3)]
+    eps = [normal((B, kw["latent"], 1, 1), 150 + i).cuda() for i in range(3)]
+    taken = []
+
+    def run(mode):
+        monkeypatch.setattr(HF, "BN_SLOTS_MODE", mode)
+        model = _model(A, 21, **kw)
+        tr = A.HipTrainer(model, batch_shape=(B, kw["cin"], 32, 32), use_graph=graph, data_parallel=False)
+        losses = [tr.step(x[i], eps[i]).clone() for i in range(3)]
+        torch.cuda.synchronize()
+        st = HF.SlotArena._state.get(tr.device)
+        taken.append(0 if (st is None or mode == 0) else st[1])
+        bufs = torch.cat([b.detach().float().flatten() for b in model.buffers()])
+        out = tr.pflat.clone(), torch.stack(losses), bufs
+        tr.close()
+        return out
+
+    a, b, a2 = run(1), run(0), run(1)
+    assert taken[0] > 0 and taken[1] == 0, "the slots route was taken (and only when asked for)"
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v), "the slots route is order independent: same bits on a second run"
+    for u, v, name in zip(a, b, ("params", "losses", "buffers")):
+        err = float((u.double() - v.double()).norm() / v.double().norm())
+        assert err < 2e-5, (name, err)
