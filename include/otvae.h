@@ -29,6 +29,11 @@ extern "C" {
 int otvae_abi_version(void);           /* bumps when a signature changes */
 const char* otvae_last_error(void);    /* host string describing the last non-OK return of this thread */
 int otvae_device_info(int* n_cu, int* wave_size, char* arch, int arch_len); /* host query helper */
+/* A HIP stream of the library's own on the calling thread's current device (hipStreamNonBlocking), for hosts whose framework hands out
+ * streams from a small round-robin pool (torch: 32 per device -- the 33rd "new" stream is the first one again, and two lanes of one
+ * captured step end up on one queue).  The Python mirror recycles the streams it creates and never destroys them. */
+int otvae_stream_create(void** stream);
+int otvae_stream_destroy(void* stream);
 
 /* Geometry of one ConvLayer (networks/cnn.py:48-154,183-192): input [N][Hs][Ws][Cs] --(nearest x`up`)-->
  * conv KHxKW / stride / pad --> [N][Ho][Wo][Cn].  `up` is 1 or 2; up==2 requires stride==1. */
@@ -122,16 +127,18 @@ int otvae_wgrad_reduce_batched(int n, const float* const* partial, const int* P,
 #define OTVAE_JOB_BWD_DATA 1
 #define OTVAE_JOB_BWD_WEIGHT 2
 /* ---- BatchNorm statistic SLOTS (round 4): cross-block sums without a finalize launch, bit-reproducible --------------------------------
- * Instead of P per-block partials a producer may add its per-channel sums into 16 accumulators of int64 fixed-point limbs with integer
- * atomics (associative: the totals do not depend on arrival order); layout and arithmetic in csrc/common.h.  `slots` buffers hold
- * otvae_bn_slots_words(ld) int64 words and must be ZERO before the producer runs.  A consumer kernel that is handed an otvae_bn_fold
+ * Instead of P per-block partials a producer may add its per-channel sums into `nslots` (1, 2, 4, 8 or 16: the caller's choice, the
+ * same number for the producer and the consumer of a buffer; few slots = fewer words for the consumer to read, many = less contention
+ * among a producer's blocks) accumulators of int64 fixed-point limbs with integer atomics (associative: the totals do not depend on
+ * arrival order); layout and arithmetic in csrc/common.h.  `slots` buffers hold otvae_bn_slots_words(ld) int64 words, are 16-byte
+ * aligned and must be ZERO before the producer runs.  A consumer kernel that is handed an otvae_bn_fold
  * turns the sums into (scale, shift) in its own prologue -- every block for itself -- and its first block leaves mean / invstd / scale /
  * shift in global memory for the backward pass and advances the running buffers: what otvae_bn_finalize did in a launch of its own
  * (reference: nn.BatchNorm2d in training mode, networks/cnn.py:122,184).  otvae_bn_finalize_slots is the stand-alone form. */
 typedef struct otvae_bn_fold {
     const void* slots;            /* NULL: no fold */
     int32_t ld;                   /* channel stride of the slots (>= channels) */
-    int32_t reserved;
+    int32_t nslots;               /* slots in use: 1, 2, 4, 8 or 16 -- what the producer of `slots` was given */
     int64_t count;                /* elements per channel: N * H * W of the normalised tensor */
     float eps, momentum;
     const float* gamma;
@@ -145,8 +152,15 @@ typedef struct otvae_bn_fold {
     float* shift_out;
 } otvae_bn_fold;
 int64_t otvae_bn_slots_words(int ld);
-int otvae_bn_stats_slots(const float* x, int64_t M, int C, void* slots, int ld, void* stream);
+int otvae_bn_stats_slots(const float* x, int64_t M, int C, void* slots, int ld, int nslots, void* stream);
 int otvae_bn_finalize_slots(int n_bn, const otvae_bn_fold* folds, int C, void* stream);
+/* The BatchNorm backward pair (otvae_bn_bwd_finalize + otvae_bn_bwd_apply below) as ONE launch, for sums (sum gv, sum gv * xhat) that a
+ * data-gradient job left in slots (otvae_conv_job.bn_slots, otvae_attn_stage_bwd_slots): the finalize arithmetic runs in the launch's
+ * prologue, its first block writes dgamma / dbeta.  dx == NULL: parameter gradients only (gv / x may then be NULL).  training == 0:
+ * eval-mode BatchNorm (a fixed affine: no batch-statistics terms in dx).  C <= 1024. */
+int otvae_bn_bwd_apply_slots(int nb, const float* const* gv, const float* x, const void* const* slots, const int* nslots, int ld,
+                             int64_t M, int C, const float* mean, const float* invstd, const float* const* gamma,
+                             float* const* dgamma, float* const* dbeta, int training, float* dx, void* stream);
 
 typedef struct otvae_conv_job {
     int32_t kind;               /* OTVAE_JOB_* */
@@ -171,6 +185,9 @@ typedef struct otvae_conv_job {
     float* gw;                  /* BWD_WEIGHT */
     float* gb;
     void* stat_slots;           /* FWD (nullable, instead of stat_partial): statistic slots of the OUTPUT, channel stride = the ld of otvae_conv_fwd_stats_ws */
+    void* bn_slots;             /* BWD_DATA (nullable, instead of bn_partial): statistic slots of the BatchNorm-backward sums, channel stride = the CsPad of otvae_conv_bwd_data_ws */
+    int32_t stat_nslots;        /* slots in use in stat_slots / bn_slots (1, 2, 4, 8 or 16) */
+    int32_t bn_nslots;
     otvae_bn_fold fold;         /* FWD (fold.slots nullable): the BatchNorm of the INPUT x folded into this launch; scale / shift are then ignored */
 } otvae_conv_job;
 int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream);
@@ -213,7 +230,8 @@ int otvae_attn_stage_fwd(const float* x, const float* scale, const float* shift,
  * otvae_bn_fold) and / or the output's statistics into statistic slots (stat_slots, channel stride H * C) instead of stat_partial. */
 int otvae_attn_stage_fwd_fold(const float* x, const otvae_bn_fold* fold, const float* scale, const float* shift, const float* wqkv,
                               const float* wproj, const float* residual, int N, int T, int H, int C, float qk_scale, float* qkv,
-                              float* out, float* lse, float* aux, float* y, double* stat_partial, void* stat_slots, void* stream);
+                              float* out, float* lse, float* aux, float* y, double* stat_partial, void* stat_slots, int stat_nslots,
+                              void* stream);
 
 /* The AttentionBlock's backward pass as ONE launch on what otvae_attn_stage_fwd wrote (qkv, out, lse, aux): the attention output's
  * gradient is formed from gy [N][T][H*C] (gout = gy . wproj^T), the attention backward of otvae_attn_bwd_scaled writes gqkv
@@ -229,6 +247,11 @@ int otvae_attn_stage_bwd(const float* gy, const float* wproj, const float* wqkv,
                          const float* invstd, const float* scale, const float* shift, const float* qkv, const float* out,
                          const float* lse, const float* aux, int N, int T, int H, int C, float qk_scale, float* gqkv, float* gv,
                          double* bn_partial, void* stream);
+/* The same launch with the BatchNorm-backward sums into statistic slots (channel stride H * C; consumed by otvae_bn_bwd_apply_slots). */
+int otvae_attn_stage_bwd_slots(const float* gy, const float* wproj, const float* wqkv, const float* x, const float* mean,
+                               const float* invstd, const float* scale, const float* shift, const float* qkv, const float* out,
+                               const float* lse, const float* aux, int N, int T, int H, int C, float qk_scale, float* gqkv, float* gv,
+                               void* bn_slots, int bn_nslots, void* stream);
 
 /* Element-wise dropout with the same counter-based masks (keep(row, col) of a [rows][D] tensor, D % 4 == 0), optionally
  * fused with the ReLU in front of it: y = keep ? act(x)/(1-p) : 0.  relu != 0: the dropout(relu(linear1(x))) of a training-
@@ -446,6 +469,10 @@ int otvae_ema_update(float* shadow, const float* p, int64_t n, double decay, voi
  * otvae_step_begin_guarded increments *step like otvae_step_begin AND copies state[n_state] (every running buffer of the model,
  * one flat fp32 range) to backup; a refused step (otvae_adam_step_guarded) copies it back.  n_state 0: no such buffers. */
 int otvae_step_begin_guarded(int32_t* step, const float* state, float* backup, int64_t n_state, void* stream);
+/* Round 4: counter + (n > 0) the guard's backup + the zeroing of `zero_words` int64 words (the BatchNorm statistic slots the step's
+ * kernels add into; 16-byte aligned, an even count, may be 0) as ONE launch.  otvae_zero_words: the zeroing alone. */
+int otvae_step_begin_slots(int32_t* step, const float* state, float* backup, int64_t n, void* zero, int64_t zero_words, void* stream);
+int otvae_zero_words(void* zero, int64_t zero_words, void* stream);
 
 /* ---- global-norm gradient clipping (configs/ddp.yaml:4 `gradient_clip_val: 1.0`, applied by Lightning through
  * torch.nn.utils.clip_grad_norm_) over the flat gradient buffer -------------------------------------------------- */

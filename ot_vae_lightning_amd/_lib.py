@@ -33,7 +33,7 @@ DEFER_DENSE, DEFER_SPARSE = 1, 2  # otvae_conv_job.defer_reduce (include/otvae.h
 
 
 class BnFold(C.Structure):  # otvae_bn_fold
-    _fields_ = [("slots", C.c_void_p), ("ld", C.c_int32), ("reserved", C.c_int32), ("count", C.c_int64), ("eps", C.c_float),
+    _fields_ = [("slots", C.c_void_p), ("ld", C.c_int32), ("nslots", C.c_int32), ("count", C.c_int64), ("eps", C.c_float),
                 ("momentum", C.c_float)] + [(n, C.c_void_p) for n in ("gamma", "beta", "running_mean", "running_var",
                                                                       "num_batches_tracked", "mean_out", "invstd_out", "scale_out",
                                                                       "shift_out")]
@@ -42,8 +42,9 @@ class BnFold(C.Structure):  # otvae_bn_fold
 class ConvJob(C.Structure):  # otvae_conv_job
     _fields_ = ([(n, C.c_int32) for n in ("kind", "relu", "has_bias", "defer_reduce")] + [("geom", ConvGeom)] +
                 [(n, C.c_void_p) for n in ("x", "scale", "shift", "w", "bias", "residual", "y", "stat_partial", "gy",
-                                           "mean", "invstd", "gv", "bn_partial", "wpartial", "gw", "gb", "stat_slots")] +
-                [("fold", BnFold)])
+                                           "mean", "invstd", "gv", "bn_partial", "wpartial", "gw", "gb", "stat_slots",
+                                           "bn_slots")] +
+                [("stat_nslots", C.c_int32), ("bn_nslots", C.c_int32), ("fold", BnFold)])
 
 
 pj = C.POINTER(ConvJob)
@@ -53,10 +54,13 @@ SIGNATURES = {
     "otvae_abi_version": (i32, []),
     "otvae_last_error": (C.c_char_p, []),
     "otvae_device_info": (i32, [pi32, pi32, C.c_char_p, i32]),
+    "otvae_stream_create": (i32, [pp]),
+    "otvae_stream_destroy": (i32, [vp]),
     "otvae_bn_stats_nparts": (i32, [i64, i32]),
     "otvae_bn_stats": (i32, [vp, i64, i32, vp, vp]),
     "otvae_bn_slots_words": (i64, [i32]),
-    "otvae_bn_stats_slots": (i32, [vp, i64, i32, vp, i32, vp]),
+    "otvae_bn_stats_slots": (i32, [vp, i64, i32, vp, i32, i32, vp]),
+    "otvae_bn_bwd_apply_slots": (i32, [i32, pp, vp, pp, pi32, i32, i64, i32, vp, vp, pp, pp, pp, i32, vp, vp]),
     "otvae_bn_finalize_slots": (i32, [i32, C.POINTER(BnFold), i32, vp]),
     "otvae_bn_finalize": (i32, [vp, i32, i32, i64, i32, f32, f32, vp, vp, i32, pp, pp, pp, pp, pp, pp, pp, vp]),
     "otvae_conv_fwd_stats_ws": (i32, [pg, pi32, pi32]),
@@ -80,7 +84,8 @@ SIGNATURES = {
     "otvae_attn_bwd_scaled": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]),
     "otvae_attn_stage_plan": (i32, [i32, i32, i32, i32, i32, vp]),
     "otvae_attn_stage_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
-    "otvae_attn_stage_fwd_fold": (i32, [vp, C.POINTER(BnFold), vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "otvae_attn_stage_fwd_fold": (i32, [vp, C.POINTER(BnFold), vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "otvae_attn_stage_bwd_slots": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, i32, vp]),
     "otvae_attn_stage_bwd_plan": (i32, [i32, i32, i32, i32, vp]),
     "otvae_attn_stage_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     "otvae_attn_dropout_fwd": (i32, [vp, i32, i32, i32, i32, f32, f32, i32, vp, i32, vp, vp, vp, vp]),
@@ -134,6 +139,8 @@ SIGNATURES = {
     "otvae_ema_update": (i32, [vp, vp, i64, f64, vp]),
     "otvae_adam_step_guarded": (i32, [vp, vp, vp, vp, i64, vp, vp, f32, vp, vp, vp, vp, vp, i64, vp]),
     "otvae_step_begin_guarded": (i32, [vp, vp, vp, i64, vp]),
+    "otvae_step_begin_slots": (i32, [vp, vp, vp, i64, vp, i64, vp]),
+    "otvae_zero_words": (i32, [vp, i64, vp]),
     "otvae_grad_clip_ws": (i32, []),
     "otvae_grad_clip_coef": (i32, [vp, i64, f32, f32, vp, vp, vp]),
     "otvae_conv_generic_fwd": (i32, [pg, vp, vp, vp, vp, vp]),
@@ -257,6 +264,45 @@ def stream():
     """Raw handle of torch's current HIP stream on the current device (torch.cuda.current_stream() builds a Stream object per
     call: 10 us of host time, ~90 times per eagerly issued step)."""
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+# ---- streams of our own ------------------------------------------------------------------------------------------------------------
+# torch.cuda.Stream() does not create a stream: it takes the next of a pool of 32 per device, round-robin.  A process that has built a
+# few engines (each with a capture stream, a warm-up stream, a reducer stream ...) gets, as its "new" side stream, the very queue its
+# capture stream or its prior lane already is -- a captured step whose fork waits on itself; the HIP graph executor then died in
+# hip::Graph::UpdateStreams at the first replay (found in round 4 when the test suite grew past that count).  Every side / lane /
+# capture / warm-up stream of this package therefore is a HIP stream of the library's own (otvae_stream_create), wrapped as a
+# torch.cuda.ExternalStream; a wrapper that dies hands its stream back to a free list (never destroyed: at most as many as were ever
+# alive at once).
+_free_streams: dict = {}   # device index -> [raw handles]
+
+
+class _OwnStream(torch.cuda.ExternalStream):
+    """ExternalStream over a stream of otvae_stream_create; hands the handle back when it dies.  (``__del__``, not ``weakref.finalize``:
+    a weak reference to a torch stream object crashed the interpreter's finalization, _PyWeakref_ClearRef, on torch 2.10.)"""
+
+    def __del__(self):
+        try:
+            _free_streams.setdefault(self._otvae_index, []).append(self._otvae_handle)
+        except Exception:   # interpreter shutdown: the module's globals are gone, and so is the need
+            pass
+
+
+def fresh_stream(device=None) -> "torch.cuda.Stream":
+    """A stream no other live stream of this process aliases (see above)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    free = _free_streams.setdefault(index, [])
+    if free:
+        handle = free.pop()
+    else:
+        out = C.c_void_p()
+        with torch.cuda.device(index):
+            check(load().otvae_stream_create(C.byref(out)), "otvae_stream_create")
+        handle = out.value
+    s = _OwnStream(handle, device=torch.device("cuda", index))
+    s._otvae_index, s._otvae_handle = index, handle
+    return s
 
 
 def require_cuda(t: torch.Tensor, name: str = "tensor") -> None:

@@ -1415,20 +1415,14 @@ extern "C" int otvae_attn_stage_fwd(const float* x, const float* scale, const fl
 extern "C" int otvae_attn_stage_fwd_fold(const float* x, const otvae_bn_fold* fold, const float* scale, const float* shift,
                                          const float* wqkv, const float* wproj, const float* residual, int N, int T, int H, int C,
                                          float qk_scale, float* qkv, float* out, float* lse, float* aux, float* y, double* stat_partial,
-                                         void* stat_slots, void* stream) {
+                                         void* stat_slots, int stat_nslots, void* stream) {
     OTVAE_REQUIRE(!(stat_partial && stat_slots), "otvae_attn_stage_fwd_fold: statistics go to partials OR to slots");
+    OTVAE_REQUIRE_SLOTS("otvae_attn_stage_fwd_fold", stat_slots, stat_nslots);
     BnFold f = {};
-    if (fold && fold->slots) {
-        OTVAE_REQUIRE(fold->ld >= H * C && fold->count > 0 && fold->gamma && fold->beta && fold->scale_out && fold->shift_out &&
-                          (fold->mean_out == nullptr) == (fold->invstd_out == nullptr),
-                      "otvae_attn_stage_fwd_fold: incomplete BatchNorm fold descriptor");
-        f.slots = (const long long*)fold->slots, f.ld = fold->ld, f.count = fold->count, f.eps = fold->eps, f.momentum = fold->momentum;
-        f.gamma = fold->gamma, f.beta = fold->beta, f.rmean = fold->running_mean, f.rvar = fold->running_var;
-        f.nbt = (long long*)fold->num_batches_tracked;
-        f.mean_out = fold->mean_out, f.invstd_out = fold->invstd_out, f.scale_out = fold->scale_out, f.shift_out = fold->shift_out;
-    }
+    if (fold)
+        if (int rc = bn_fold_from_abi("otvae_attn_stage_fwd_fold", *fold, H * C, &f)) return rc;
     return attn_stage_fwd_impl(x, scale, shift, wqkv, wproj, residual, N, T, H, C, qk_scale, qkv, out, lse, aux, y,
-                               stat_slots ? bn_tag_slots(stat_slots) : stat_partial, f, stream);
+                               stat_slots ? bn_tag_slots(stat_slots, stat_nslots) : stat_partial, f, stream);
 }
 
 static int attn_stage_fwd_impl(const float* x, const float* scale, const float* shift, const float* wqkv, const float* wproj,
@@ -1467,10 +1461,34 @@ static int attn_stage_fwd_impl(const float* x, const float* scale, const float* 
     return OTVAE_OK;
 }
 
+static int attn_stage_bwd_impl(const float* gy, const float* wproj, const float* wqkv, const float* x, const float* mean,
+                               const float* invstd, const float* scale, const float* shift, const float* qkv, const float* out,
+                               const float* lse, const float* aux, int N, int T, int H, int C, float qk_scale, float* gqkv, float* gv,
+                               double* bn_partial, void* stream);
+
 extern "C" int otvae_attn_stage_bwd(const float* gy, const float* wproj, const float* wqkv, const float* x, const float* mean,
                                     const float* invstd, const float* scale, const float* shift, const float* qkv, const float* out,
                                     const float* lse, const float* aux, int N, int T, int H, int C, float qk_scale, float* gqkv, float* gv,
                                     double* bn_partial, void* stream) {
+    return attn_stage_bwd_impl(gy, wproj, wqkv, x, mean, invstd, scale, shift, qkv, out, lse, aux, N, T, H, C, qk_scale, gqkv, gv,
+                               bn_partial, stream);
+}
+
+// the same launch with the BatchNorm-backward sums (sum gv, sum gv * xhat) into statistic slots (channel stride H * C) instead of partials
+extern "C" int otvae_attn_stage_bwd_slots(const float* gy, const float* wproj, const float* wqkv, const float* x, const float* mean,
+                                          const float* invstd, const float* scale, const float* shift, const float* qkv,
+                                          const float* out, const float* lse, const float* aux, int N, int T, int H, int C,
+                                          float qk_scale, float* gqkv, float* gv, void* bn_slots, int bn_nslots, void* stream) {
+    OTVAE_REQUIRE(bn_slots, "otvae_attn_stage_bwd_slots: NULL slots");
+    OTVAE_REQUIRE_SLOTS("otvae_attn_stage_bwd_slots", bn_slots, bn_nslots);
+    return attn_stage_bwd_impl(gy, wproj, wqkv, x, mean, invstd, scale, shift, qkv, out, lse, aux, N, T, H, C, qk_scale, gqkv, gv,
+                               bn_tag_slots(bn_slots, bn_nslots), stream);
+}
+
+static int attn_stage_bwd_impl(const float* gy, const float* wproj, const float* wqkv, const float* x, const float* mean,
+                               const float* invstd, const float* scale, const float* shift, const float* qkv, const float* out,
+                               const float* lse, const float* aux, int N, int T, int H, int C, float qk_scale, float* gqkv, float* gv,
+                               double* bn_partial, void* stream) {
     OTVAE_REQUIRE(gy && wproj && wqkv && out && lse && gqkv && gv, "otvae_attn_stage_bwd: NULL tensor");
     OTVAE_REQUIRE(qkv || x, "otvae_attn_stage_bwd: without the saved qkv the block input x is needed");
     OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_attn_stage_bwd: scale/shift must come together");

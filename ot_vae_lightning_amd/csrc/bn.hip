@@ -16,7 +16,7 @@ extern "C" int otvae_bn_stats_nparts(int64_t M, int C) {
 
 // thread (rr, c): rows rr, rr+RPB*P ... of channel c (C <= 256), or loops channels (C > 256)
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C, double* __restrict__ partial,
-                                                       long long* __restrict__ slots = nullptr, int ld = 0) {
+                                                       long long* __restrict__ slots = nullptr, int ld = 0, unsigned smask = 0) {
     __shared__ double sh[2][256];
     const int P = gridDim.x;
     if (C <= 256) {
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
                 tq += sh[1][r * C + threadIdx.x];
             }
             if (slots) {
-                bn_slot_add(slots, ld, blockIdx.x, 0, threadIdx.x, ts);
-                bn_slot_add(slots, ld, blockIdx.x, 1, threadIdx.x, tq);
+                bn_slot_add(slots, ld, blockIdx.x & smask, 0, threadIdx.x, ts);
+                bn_slot_add(slots, ld, blockIdx.x & smask, 1, threadIdx.x, tq);
             } else {
                 partial[((size_t)0 * C + threadIdx.x) * P + blockIdx.x] = ts;
                 partial[((size_t)1 * C + threadIdx.x) * P + blockIdx.x] = tq;
@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
                 q += (double)v * (double)v;
             }
             if (slots) {
-                bn_slot_add(slots, ld, blockIdx.x, 0, c, s);
-                bn_slot_add(slots, ld, blockIdx.x, 1, c, q);
+                bn_slot_add(slots, ld, blockIdx.x & smask, 0, c, s);
+                bn_slot_add(slots, ld, blockIdx.x & smask, 1, c, q);
             } else {
                 partial[((size_t)0 * C + c) * P + blockIdx.x] = s;
                 partial[((size_t)1 * C + c) * P + blockIdx.x] = q;
@@ -78,32 +78,12 @@ extern "C" int otvae_bn_stats(const float* x, int64_t M, int C, double* partial,
 // consumer folds them itself (BnFold), otvae_bn_finalize_slots is the stand-alone form for consumers that do not
 extern "C" int64_t otvae_bn_slots_words(int ld) { return ld > 0 ? (int64_t)bn_slot_words(ld) : -1; }
 
-extern "C" int otvae_bn_stats_slots(const float* x, int64_t M, int C, void* slots, int ld, void* stream) {
+extern "C" int otvae_bn_stats_slots(const float* x, int64_t M, int C, void* slots, int ld, int nslots, void* stream) {
     OTVAE_REQUIRE(x && slots && M > 0 && C > 0 && ld >= C, "otvae_bn_stats_slots: bad argument");
+    OTVAE_REQUIRE_SLOTS("otvae_bn_stats_slots", slots, nslots);
     const int P = otvae_bn_stats_nparts(M, C);
-    bn_stats_kernel<<<P, 256, 0, (hipStream_t)stream>>>(x, M, C, nullptr, (long long*)slots, ld);
+    bn_stats_kernel<<<P, 256, 0, (hipStream_t)stream>>>(x, M, C, nullptr, (long long*)slots, ld, (unsigned)nslots - 1u);
     OTVAE_CHECK_LAUNCH("otvae_bn_stats_slots");
-    return OTVAE_OK;
-}
-
-static int bn_fold_from_abi(const char* who, const otvae_bn_fold* a, int C, BnFold* f) {
-    OTVAE_REQUIRE(a && a->slots && a->ld >= C && a->count > 0 && a->gamma && a->beta && a->scale_out && a->shift_out,
-                  "%s: incomplete BatchNorm fold descriptor", who);
-    OTVAE_REQUIRE((a->mean_out == nullptr) == (a->invstd_out == nullptr), "%s: mean_out and invstd_out come together", who);
-    f->slots = (const long long*)a->slots;
-    f->ld = a->ld;
-    f->count = a->count;
-    f->eps = a->eps;
-    f->momentum = a->momentum;
-    f->gamma = a->gamma;
-    f->beta = a->beta;
-    f->rmean = a->running_mean;
-    f->rvar = a->running_var;
-    f->nbt = (long long*)a->num_batches_tracked;
-    f->mean_out = a->mean_out;
-    f->invstd_out = a->invstd_out;
-    f->scale_out = a->scale_out;
-    f->shift_out = a->shift_out;
     return OTVAE_OK;
 }
 
@@ -116,7 +96,10 @@ extern "C" int otvae_bn_finalize_slots(int n_bn, const otvae_bn_fold* folds, int
     OTVAE_REQUIRE(n_bn >= 1 && n_bn <= 2 && folds && C > 0 && C <= 1024, "otvae_bn_finalize_slots: 1 or 2 branches, C <= 1024");
     BnFold f[2] = {};
     for (int b = 0; b < n_bn; ++b)
-        if (int rc = bn_fold_from_abi("otvae_bn_finalize_slots", folds + b, C, &f[b])) return rc;
+    {
+        OTVAE_REQUIRE(folds[b].slots, "otvae_bn_finalize_slots: branch %d has no slots", b);
+        if (int rc = bn_fold_from_abi("otvae_bn_finalize_slots", folds[b], C, &f[b])) return rc;
+    }
     bn_finalize_slots_kernel<<<1, 256, 0, (hipStream_t)stream>>>(n_bn, f[0], f[1], C);
     OTVAE_CHECK_LAUNCH("otvae_bn_finalize_slots");
     return OTVAE_OK;
@@ -374,5 +357,119 @@ extern "C" int otvae_bn_bwd_apply(int nb, const float* const* gv, const float* x
         else bn_bwd_apply_kernel<2, false><<<grid, 256, 0, st>>>(gv[0], g1, x, coef, total, C, dx);
     }
     OTVAE_CHECK_LAUNCH("otvae_bn_bwd_apply");
+    return OTVAE_OK;
+}
+
+// ---- the backward pair with the sums in statistic slots: the finalize arithmetic (bn_bwd_finalize_kernel) runs in the apply launch's
+// prologue -- every block for itself from the S slots, into LDS -- and the first block writes dgamma / dbeta.  dx == NULL: one block,
+// parameter gradients only (the first layer of a network: nobody needs dL/dx).
+struct BnBwdFold {
+    const long long* slots[2];
+    int nslots[2];
+    int ld;
+    int training;
+    long long count;
+    const float* mean;
+    const float* invstd;
+    const float* gamma[2];
+    float* dgamma[2];
+    float* dbeta[2];
+};
+
+template <int NB, bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(BnBwdFold f, const float* __restrict__ g0, const float* __restrict__ g1,
+                                                                 const float* __restrict__ x, int64_t total, int C,
+                                                                 float* __restrict__ dx) {
+    __shared__ __align__(16) float tab[2 + NB][BN_TAB];   // A, B, k_0 (, k_1)
+    const bool first = blockIdx.x == 0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double is = (double)f.invstd[c], mu = (double)f.mean[c];
+        double A = 0.0, B = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double s1 = bn_slot_total(f.slots[b], f.ld, f.nslots[b], 0, c), s2 = bn_slot_total(f.slots[b], f.ld, f.nslots[b], 1, c);
+            const double k = (double)f.gamma[b][c] * is;
+            if (first) {
+                if (f.dbeta[b]) f.dbeta[b][c] = (float)s1;
+                if (f.dgamma[b]) f.dgamma[b][c] = (float)s2;
+            }
+            tab[2 + b][c] = (float)k;
+            A += k * s2;
+            B += k * s1;
+        }
+        A = A * is / (double)f.count;
+        B = B / (double)f.count - A * mu;
+        if (!f.training) A = B = 0.0;   // eval mode: BatchNorm is a fixed affine, no batch-statistics terms
+        tab[0][c] = (float)A;
+        tab[1][c] = (float)B;
+    }
+    __syncthreads();
+    if (!dx) return;
+    if constexpr (VEC) {
+        const int64_t n4 = total >> 2;
+        for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            const int c = (int)((i << 2) % C);
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+            const float4 a = *reinterpret_cast<const float4*>(&tab[0][c]);
+            const float4 b = *reinterpret_cast<const float4*>(&tab[1][c]);
+            const float4 k0 = *reinterpret_cast<const float4*>(&tab[2][c]);
+            const float4 gv0 = reinterpret_cast<const float4*>(g0)[i];
+            float4 r;
+            r.x = fmaf(k0.x, gv0.x, fmaf(-a.x, xv.x, -b.x));
+            r.y = fmaf(k0.y, gv0.y, fmaf(-a.y, xv.y, -b.y));
+            r.z = fmaf(k0.z, gv0.z, fmaf(-a.z, xv.z, -b.z));
+            r.w = fmaf(k0.w, gv0.w, fmaf(-a.w, xv.w, -b.w));
+            if constexpr (NB == 2) {
+                const float4 k1 = *reinterpret_cast<const float4*>(&tab[3][c]);
+                const float4 gv1 = reinterpret_cast<const float4*>(g1)[i];
+                r.x = fmaf(k1.x, gv1.x, r.x);
+                r.y = fmaf(k1.y, gv1.y, r.y);
+                r.z = fmaf(k1.z, gv1.z, r.z);
+                r.w = fmaf(k1.w, gv1.w, r.w);
+            }
+            reinterpret_cast<float4*>(dx)[i] = r;
+        }
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int c = (int)(i % C);
+            float r = fmaf(tab[2][c], g0[i], fmaf(-tab[0][c], x[i], -tab[1][c]));
+            if constexpr (NB == 2) r = fmaf(tab[3][c], g1[i], r);
+            dx[i] = r;
+        }
+    }
+}
+
+extern "C" int otvae_bn_bwd_apply_slots(int nb, const float* const* gv, const float* x, const void* const* slots, const int* nslots,
+                                        int ld, int64_t M, int C, const float* mean, const float* invstd, const float* const* gamma,
+                                        float* const* dgamma, float* const* dbeta, int training, float* dx, void* stream) {
+    OTVAE_REQUIRE(nb >= 1 && nb <= 2 && slots && nslots && mean && invstd && gamma && M > 0 && C > 0 && C <= BN_TAB && ld >= C,
+                  "otvae_bn_bwd_apply_slots: bad argument (1 or 2 branches, C <= %d)", BN_TAB);
+    OTVAE_REQUIRE(!dx || (gv && gv[0] && x && (nb == 1 || gv[1])), "otvae_bn_bwd_apply_slots: gv / x are needed for dx");
+    BnBwdFold f = {};
+    for (int b = 0; b < nb; ++b) {
+        OTVAE_REQUIRE(slots[b] && gamma[b], "otvae_bn_bwd_apply_slots: NULL branch %d", b);
+        OTVAE_REQUIRE_SLOTS("otvae_bn_bwd_apply_slots", slots[b], nslots[b]);
+        f.slots[b] = (const long long*)slots[b];
+        f.nslots[b] = nslots[b];
+        f.gamma[b] = gamma[b];
+        f.dgamma[b] = dgamma ? dgamma[b] : nullptr;
+        f.dbeta[b] = dbeta ? dbeta[b] : nullptr;
+    }
+    f.ld = ld, f.training = training, f.count = M, f.mean = mean, f.invstd = invstd;
+    const int64_t total = M * C;
+    const bool vec = (C % 4 == 0);
+    // one resident generation of blocks: every block pays the prologue (S x 4 words per channel and branch) before it streams
+    const int grid = dx ? imin(cdiv(vec ? total / 4 : total, 256), 2048) : 1;
+    hipStream_t st = (hipStream_t)stream;
+    const float* g0 = dx ? gv[0] : nullptr;
+    const float* g1 = (dx && nb == 2) ? gv[1] : nullptr;
+    if (nb == 1) {
+        if (vec) bn_bwd_apply_slots_kernel<1, true><<<grid, 256, 0, st>>>(f, g0, g1, x, total, C, dx);
+        else bn_bwd_apply_slots_kernel<1, false><<<grid, 256, 0, st>>>(f, g0, g1, x, total, C, dx);
+    } else {
+        if (vec) bn_bwd_apply_slots_kernel<2, true><<<grid, 256, 0, st>>>(f, g0, g1, x, total, C, dx);
+        else bn_bwd_apply_slots_kernel<2, false><<<grid, 256, 0, st>>>(f, g0, g1, x, total, C, dx);
+    }
+    OTVAE_CHECK_LAUNCH("otvae_bn_bwd_apply_slots");
     return OTVAE_OK;
 }

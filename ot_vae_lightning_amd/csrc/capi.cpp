@@ -36,3 +36,32 @@ extern "C" int otvae_device_info(int* n_cu, int* wave_size, char* arch, int arch
     }
     return OTVAE_OK;
 }
+
+// A HIP stream of the library's own on the calling thread's current device (non-blocking with respect to the null stream).  Why the
+// host side does not take its side streams from its framework's stream pool: such pools are small and hand their streams out round-robin
+// (torch: 32 per device), so the 33rd "new" stream IS the first one again -- two lanes of one captured step on the same queue.  Streams
+// created here are never destroyed by the library's host mirror (it recycles them); otvae_stream_destroy is for other hosts.
+extern "C" int otvae_stream_create(void** stream) {
+    if (!stream) {
+        otvae_set_error("otvae_stream_create: NULL argument");
+        return OTVAE_EINVAL;
+    }
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        otvae_set_error("otvae_stream_create: %s", hipGetErrorString(e));
+        return OTVAE_ELAUNCH;
+    }
+    *stream = (void*)s;
+    return OTVAE_OK;
+}
+
+extern "C" int otvae_stream_destroy(void* stream) {
+    if (!stream) return OTVAE_OK;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) {
+        otvae_set_error("otvae_stream_destroy: %s", hipGetErrorString(e));
+        return OTVAE_ELAUNCH;
+    }
+    return OTVAE_OK;
+}

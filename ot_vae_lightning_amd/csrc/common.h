@@ -66,34 +66,37 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // ---- BatchNorm statistic slots: cross-block sums WITHOUT a finalize launch, bit-reproducible (round 4) -------------------------------
-// A producer block adds its per-channel sums (sum x, sum x^2) into one of BN_SLOTS accumulators as two int64 fixed-point limbs
+// A producer block adds its per-channel sums (sum x, sum x^2) into one of S <= BN_SLOTS accumulators as two int64 fixed-point limbs
 // (hi: units of 2^-10, lo: the exact remainder in units of 2^-53, < 2^43) with non-returning agent-scope INTEGER atomics.  Integer
 // addition is associative: the totals do not depend on the order in which blocks arrive (fp64 atomics would), and 2048 blocks x 2^43 stay
 // below 2^63.  A value that is not finite (or beyond 2^51) cannot be represented: it raises the tensor's poison counter instead and the
 // consumer reads the statistics as NaN -- the propagation the plain fp64 partials had, which the device-side step guard relies on.
 // Layout: long long [BN_SLOTS][2 statistics][ld channels][2 limbs] + 2 words {poison counter, unused}; zero before the producer runs.
-// The consumer adds the BN_SLOTS slots in index order (exact integer sums) and converts once.
+// S (1, 2, 4, 8 or 16: the caller's choice, the same for the producer and the consumer of a buffer) trades contention among the
+// producer's blocks (few slots, many blocks) against words the consumer reads (S x 4 per channel and block): profiles/
+// r04_bn_finalize_probe.txt.  The consumer adds the S slots in index order (exact integer sums) and converts once.
 #define BN_SLOTS 16
 
 __host__ __device__ inline size_t bn_slot_words(int ld) { return (size_t)BN_SLOTS * 2 * ld * 2 + 2; }
+static inline bool bn_slots_ok(int nslots) { return nslots >= 1 && nslots <= BN_SLOTS && (nslots & (nslots - 1)) == 0; }
 
-__device__ __forceinline__ void bn_slot_add(long long* __restrict__ slots, int ld, unsigned block, int stat, int c, double v) {
+__device__ __forceinline__ void bn_slot_add(long long* __restrict__ slots, int ld, unsigned slot, int stat, int c, double v) {
     if (!(fabs(v) < 2251799813685248.0)) {  // 2^51; also catches NaN
         __hip_atomic_fetch_add(slots + (size_t)BN_SLOTS * 2 * ld * 2, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const double h = floor(v * 1024.0);
     const double r = v - h * (1.0 / 1024.0);  // exact: 0 <= r < 2^-10
-    long long* dst = slots + ((((size_t)(block % BN_SLOTS) * 2 + stat) * ld + c) << 1);
+    long long* dst = slots + ((((size_t)slot * 2 + stat) * ld + c) << 1);
     __hip_atomic_fetch_add(dst, (long long)h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(dst + 1, (long long)floor(r * 9007199254740992.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// the total of statistic `stat` of channel c (NaN when the producer met a value it could not represent)
-__device__ __forceinline__ double bn_slot_total(const long long* __restrict__ slots, int ld, int stat, int c) {
+// the total of statistic `stat` of channel c over the S slots in use (NaN when the producer met a value it could not represent)
+__device__ __forceinline__ double bn_slot_total(const long long* __restrict__ slots, int ld, int S, int stat, int c) {
     long long hi = 0, lo = 0;
-#pragma unroll
-    for (int s = 0; s < BN_SLOTS; ++s) {
+#pragma unroll 4
+    for (int s = 0; s < S; ++s) {
         const long long* p = slots + ((((size_t)s * 2 + stat) * ld + c) << 1);
         hi += p[0];
         lo += p[1];
@@ -109,6 +112,7 @@ __device__ __forceinline__ double bn_slot_total(const long long* __restrict__ sl
 struct BnFold {
     const long long* slots;  // NULL: no fold (scale / shift come from global arrays as before)
     int ld;
+    int nslots;              // S
     long long count;         // elements per channel (N * H * W of the normalised tensor)
     float eps, momentum;
     const float* gamma;
@@ -125,7 +129,7 @@ struct BnFold {
 // s_sc / s_sh: LDS, C floats each.  Ends with a block barrier.
 __device__ __forceinline__ void bn_fold_prologue(const BnFold& f, int C, float* s_sc, float* s_sh, bool first_block) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double s = bn_slot_total(f.slots, f.ld, 0, c), q = bn_slot_total(f.slots, f.ld, 1, c);
+        const double s = bn_slot_total(f.slots, f.ld, f.nslots, 0, c), q = bn_slot_total(f.slots, f.ld, f.nslots, 1, c);
         const double mu = s / (double)f.count;
         double var = q / (double)f.count - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -152,13 +156,48 @@ __device__ __forceinline__ void bn_fold_prologue(const BnFold& f, int C, float* 
     __syncthreads();
 }
 
-// A statistics destination is either the classic [2][ld][P] fp64 partials or (bit 0 of the pointer set: a device-code convention between
-// the host launchers of this library and its kernels, never part of the C ABI) the statistic slots above.
+// A statistics destination is either the classic [2][ld][P] fp64 partials or the statistic slots above -- then bit 0 of the pointer is
+// set and bits 1..3 hold log2 S (slot buffers are 16-byte aligned): a device-code convention between the host launchers of this library
+// and its kernels, never part of the C ABI.
 __device__ __forceinline__ void bn_stat_out(double* partial, int which, int ld, int c, unsigned P, unsigned p, double t) {
-    if ((uintptr_t)partial & 1) bn_slot_add(reinterpret_cast<long long*>((uintptr_t)partial & ~(uintptr_t)1), ld, p, which, c, t);
+    const uintptr_t a = (uintptr_t)partial;
+    if (a & 1) bn_slot_add(reinterpret_cast<long long*>(a & ~(uintptr_t)15), ld, p & ((1u << ((a >> 1) & 7)) - 1u), which, c, t);
     else partial[((size_t)which * ld + c) * P + p] = t;
 }
-static inline double* bn_tag_slots(void* slots) { return reinterpret_cast<double*>((uintptr_t)slots | 1); }
+static inline double* bn_tag_slots(void* slots, int nslots) {
+    int lg = 0;
+    while ((1 << lg) < nslots) ++lg;
+    return reinterpret_cast<double*>((uintptr_t)slots | 1u | ((uintptr_t)lg << 1));
+}
+// host-side check of a (slots, nslots) pair handed in through the C ABI
+#define OTVAE_REQUIRE_SLOTS(who, slots, nslots) \
+    OTVAE_REQUIRE(!(slots) || ((((uintptr_t)(slots)) & 15) == 0 && bn_slots_ok(nslots)), \
+                  "%s: statistic slots must be 16-byte aligned with 1, 2, 4, 8 or 16 slots in use (got %d)", who, (int)(nslots))
+
+// host side of otvae_bn_fold -> the device descriptor (a.slots == NULL: no fold, *f is cleared)
+static inline int bn_fold_from_abi(const char* who, const otvae_bn_fold& a, int C, BnFold* f) {
+    *f = BnFold{};
+    if (!a.slots) return OTVAE_OK;
+    OTVAE_REQUIRE(a.ld >= C && a.count > 0 && a.gamma && a.beta && a.scale_out && a.shift_out, "%s: incomplete BatchNorm fold descriptor", who);
+    OTVAE_REQUIRE((a.mean_out == nullptr) == (a.invstd_out == nullptr), "%s: fold.mean_out and fold.invstd_out come together", who);
+    OTVAE_REQUIRE_SLOTS(who, a.slots, a.nslots);
+    f->slots = (const long long*)a.slots;
+    f->ld = a.ld;
+    f->nslots = a.nslots;
+    f->count = a.count;
+    f->eps = a.eps;
+    f->momentum = a.momentum;
+    f->gamma = a.gamma;
+    f->beta = a.beta;
+    f->rmean = a.running_mean;
+    f->rvar = a.running_var;
+    f->nbt = (long long*)a.num_batches_tracked;
+    f->mean_out = a.mean_out;
+    f->invstd_out = a.invstd_out;
+    f->scale_out = a.scale_out;
+    f->shift_out = a.shift_out;
+    return OTVAE_OK;
+}
 
 #define BN_TAB 1024   // channels a forward kernel keeps the BatchNorm affine of its input for in LDS (fold or copy)
 

@@ -747,41 +747,17 @@ extern "C" int otvae_conv_fwd_stats_ws(const otvae_conv_geom* gg, int* P, int* C
     return OTVAE_OK;
 }
 
-// host side of otvae_bn_fold -> the device descriptor (bn.hip holds the same conversion for otvae_bn_finalize_slots)
-static int fold_from_abi(const char* who, const otvae_bn_fold& a, int C, BnFold* f) {
-    *f = BnFold{};
-    if (!a.slots) return OTVAE_OK;
-    OTVAE_REQUIRE(a.ld >= C && a.count > 0 && a.gamma && a.beta && a.scale_out && a.shift_out, "%s: incomplete BatchNorm fold descriptor", who);
-    OTVAE_REQUIRE((a.mean_out == nullptr) == (a.invstd_out == nullptr), "%s: fold.mean_out and fold.invstd_out come together", who);
-    OTVAE_REQUIRE(C <= BN_TAB, "%s: a folded BatchNorm takes at most %d channels", who, BN_TAB);
-    f->slots = (const long long*)a.slots;
-    f->ld = a.ld;
-    f->count = a.count;
-    f->eps = a.eps;
-    f->momentum = a.momentum;
-    f->gamma = a.gamma;
-    f->beta = a.beta;
-    f->rmean = a.running_mean;
-    f->rvar = a.running_var;
-    f->nbt = (long long*)a.num_batches_tracked;
-    f->mean_out = a.mean_out;
-    f->invstd_out = a.invstd_out;
-    f->scale_out = a.scale_out;
-    f->shift_out = a.shift_out;
-    return OTVAE_OK;
-}
+static inline bool g_cs_le_tab(const otvae_conv_geom* g) { return g->Cs <= BN_TAB; }
 
 // the forward launch with its two round-4 extras: the BatchNorm of the input folded in (fold.slots != NULL), and the output's statistics
 // into slots instead of partials (stat_slots != NULL)
 static int conv_fwd_ex(const otvae_conv_geom* gg, const float* x, const float* scale, const float* shift, int relu, const float* wT,
-                       const float* bias, const float* residual, float* y, double* stat_partial, void* stat_slots, const BnFold& fold,
-                       void* stream) {
+                       const float* bias, const float* residual, float* y, double* stat_dst, const BnFold& fold, void* stream) {
     int rc = check_geom(gg, "otvae_conv_fwd");
     if (rc) return rc;
     OTVAE_REQUIRE(x && wT && y, "otvae_conv_fwd: NULL tensor");
     OTVAE_REQUIRE((scale == nullptr) == (shift == nullptr), "otvae_conv_fwd: scale and shift must be given together");
-    OTVAE_REQUIRE(!(stat_partial && stat_slots), "otvae_conv_fwd: statistics go to partials OR to slots");
-    double* stat_dst = stat_slots ? bn_tag_slots(stat_slots) : stat_partial;
+    OTVAE_REQUIRE(fold.slots == nullptr || g_cs_le_tab(gg), "otvae_conv_fwd: a folded BatchNorm takes at most %d channels", BN_TAB);
     Geom g = to_geom(gg);
     int NT, CnPad;
     dim3 grid;
@@ -815,7 +791,7 @@ static int conv_fwd_ex(const otvae_conv_geom* gg, const float* x, const float* s
 extern "C" int otvae_conv_fwd(const otvae_conv_geom* gg, const float* x, const float* scale, const float* shift, int relu,
                               const float* wT, const float* bias, const float* residual, float* y, double* stat_partial,
                               void* stream) {
-    return conv_fwd_ex(gg, x, scale, shift, relu, wT, bias, residual, y, stat_partial, nullptr, BnFold{}, stream);
+    return conv_fwd_ex(gg, x, scale, shift, relu, wT, bias, residual, y, stat_partial, BnFold{}, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ weight transpose
@@ -898,9 +874,20 @@ extern "C" int otvae_conv_bwd_data_ws(const otvae_conv_geom* gg, int* P, int* Cs
     return OTVAE_OK;
 }
 
+// bn_partial: the [2][CsPad][P] partials, or tagged statistic slots (bn_tag_slots)
+static int conv_bwd_data_ex(const otvae_conv_geom* gg, const float* gy, const float* wD, const float* x, const float* scale,
+                            const float* shift, int relu, const float* mean, const float* invstd, float* gv, double* bn_partial,
+                            void* stream);
+
 extern "C" int otvae_conv_bwd_data(const otvae_conv_geom* gg, const float* gy, const float* wD, const float* x,
                                    const float* scale, const float* shift, int relu, const float* mean, const float* invstd,
                                    float* gv, double* bn_partial, void* stream) {
+    return conv_bwd_data_ex(gg, gy, wD, x, scale, shift, relu, mean, invstd, gv, bn_partial, stream);
+}
+
+static int conv_bwd_data_ex(const otvae_conv_geom* gg, const float* gy, const float* wD, const float* x, const float* scale,
+                            const float* shift, int relu, const float* mean, const float* invstd, float* gv, double* bn_partial,
+                            void* stream) {
     int rc = check_geom(gg, "otvae_conv_bwd_data");
     if (rc) return rc;
     OTVAE_REQUIRE(gy && wD && gv, "otvae_conv_bwd_data: NULL tensor");
@@ -1636,13 +1623,13 @@ static int run_single_job(const otvae_conv_job& jb, void* stream) {
     switch (jb.kind) {
         case OTVAE_JOB_FWD: {
             BnFold fold;
-            if (int rc = fold_from_abi("otvae_conv_multi", jb.fold, jb.geom.Cs, &fold)) return rc;
-            return conv_fwd_ex(&jb.geom, jb.x, jb.scale, jb.shift, jb.relu, jb.w, jb.bias, jb.residual, jb.y, jb.stat_partial,
-                               jb.stat_slots, fold, stream);
+            if (int rc = bn_fold_from_abi("otvae_conv_multi", jb.fold, jb.geom.Cs, &fold)) return rc;
+            return conv_fwd_ex(&jb.geom, jb.x, jb.scale, jb.shift, jb.relu, jb.w, jb.bias, jb.residual, jb.y,
+                               jb.stat_slots ? bn_tag_slots(jb.stat_slots, jb.stat_nslots) : jb.stat_partial, fold, stream);
         }
         case OTVAE_JOB_BWD_DATA:
-            return otvae_conv_bwd_data(&jb.geom, jb.gy, jb.w, jb.x, jb.scale, jb.shift, jb.relu, jb.mean, jb.invstd, jb.gv,
-                                       jb.bn_partial, stream);
+            return conv_bwd_data_ex(&jb.geom, jb.gy, jb.w, jb.x, jb.scale, jb.shift, jb.relu, jb.mean, jb.invstd, jb.gv,
+                                    jb.bn_slots ? bn_tag_slots(jb.bn_slots, jb.bn_nslots) : jb.bn_partial, stream);
         default:
             return otvae_conv_bwd_weight(&jb.geom, jb.x, jb.scale, jb.shift, jb.relu, jb.gy, jb.has_bias, jb.wpartial, jb.gw,
                                          jb.gb, jb.defer_reduce, stream);
@@ -1724,9 +1711,11 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             OTVAE_REQUIRE(jb.x && jb.w && jb.y, "otvae_conv_multi: job %d (forward): NULL tensor", i);
             dim3 grid;
             fwd_grid(g, d.NT, grid, d.cpad);
-            rc = fold_from_abi("otvae_conv_multi", jb.fold, g.Cs, &d.fold);
+            rc = bn_fold_from_abi("otvae_conv_multi", jb.fold, g.Cs, &d.fold);
             if (rc) return rc;
             OTVAE_REQUIRE(!(jb.stat_partial && jb.stat_slots), "otvae_conv_multi: job %d: statistics go to partials OR to slots", i);
+            OTVAE_REQUIRE_SLOTS("otvae_conv_multi (stat_slots)", jb.stat_slots, jb.stat_nslots);
+            OTVAE_REQUIRE(jb.fold.slots == nullptr || g.Cs <= BN_TAB, "otvae_conv_multi: job %d: a folded BatchNorm takes at most %d channels", i, BN_TAB);
             packable = !conv_small_ok(g) && ch4 && aligned16(jb.x) && aligned16(jb.w) &&
                        (jb.scale == nullptr || (aligned16(jb.scale) && aligned16(jb.shift))) &&
                        ((jb.scale == nullptr && jb.fold.slots == nullptr) || g.Cs <= BN_TAB);
@@ -1741,13 +1730,15 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             d.bias = jb.bias;
             d.res = jb.residual;
             d.out = jb.y;
-            d.partial = jb.stat_slots ? bn_tag_slots(jb.stat_slots) : jb.stat_partial;
+            d.partial = jb.stat_slots ? bn_tag_slots(jb.stat_slots, jb.stat_nslots) : jb.stat_partial;
             d.gx = grid.x, d.gy = grid.y, d.gz = grid.z;
         } else if (jb.kind == OTVAE_JOB_BWD_DATA) {
             OTVAE_REQUIRE(jb.gy && jb.w && jb.gv, "otvae_conv_multi: job %d (data gradient): NULL tensor", i);
             OTVAE_REQUIRE((jb.mean == nullptr) == (jb.invstd == nullptr), "otvae_conv_multi: job %d: mean/invstd must come together", i);
             OTVAE_REQUIRE(!(jb.relu || jb.mean) || jb.x, "otvae_conv_multi: job %d: x needed for the ReLU mask / BatchNorm sums", i);
-            OTVAE_REQUIRE(!jb.mean || jb.bn_partial, "otvae_conv_multi: job %d: bn_partial workspace missing", i);
+            OTVAE_REQUIRE(!jb.mean || jb.bn_partial || jb.bn_slots, "otvae_conv_multi: job %d: bn_partial workspace / bn_slots missing", i);
+            OTVAE_REQUIRE(!(jb.bn_partial && jb.bn_slots), "otvae_conv_multi: job %d: BatchNorm-backward sums go to partials OR to slots", i);
+            OTVAE_REQUIRE_SLOTS("otvae_conv_multi (bn_slots)", jb.bn_slots, jb.bn_nslots);
             dim3 grid;
             dgrad_grid(g, d.NT, grid, d.cpad);
             packable = !conv_small_ok(g) && ch4 && aligned16(jb.gy) && aligned16(jb.w);
@@ -1763,7 +1754,7 @@ extern "C" int otvae_conv_multi(int n, const otvae_conv_job* jobs, void* stream)
             d.mean = jb.mean;
             d.invstd = jb.invstd;
             d.out = jb.gv;
-            d.partial = jb.bn_partial;
+            d.partial = jb.bn_slots ? bn_tag_slots(jb.bn_slots, jb.bn_nslots) : jb.bn_partial;
             d.gx = grid.x, d.gy = grid.y, d.gz = grid.z;
         } else {
             OTVAE_REQUIRE(jb.x && jb.gy && jb.wpartial && jb.gw, "otvae_conv_multi: job %d (weight gradient): NULL tensor", i);

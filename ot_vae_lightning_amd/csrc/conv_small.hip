@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) SMALL_OCC void conv_small_dgrad_kernel(SmallGe
             const int which = threadIdx.x / SMALL_MAXC, c = threadIdx.x % SMALL_MAXC;
             if (c < Cs) {
                 const double t = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
-                partial[((size_t)which * CsPad + c) * gridDim.x + blockIdx.x] = t;
+                bn_stat_out(partial, which, CsPad, c, gridDim.x, blockIdx.x, t);
             }
         }
     }

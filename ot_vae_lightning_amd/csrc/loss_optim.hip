@@ -670,3 +670,38 @@ extern "C" int otvae_grad_clip_coef(const float* g, int64_t n, float grad_scale,
     OTVAE_CHECK_LAUNCH("otvae_grad_clip_coef(final)");
     return OTVAE_OK;
 }
+
+// ---- start of a step, round 4: the step counter, the step guard's backup of the running state (n may be 0) and the zeroing of the
+// BatchNorm statistic slots the step's kernels will add into (functional.SlotArena; zero_words int64 words, 16-byte aligned, may be 0)
+// as ONE launch
+__global__ __launch_bounds__(256) void step_begin_slots_kernel(int32_t* step, const float* __restrict__ state, float* __restrict__ backup,
+                                                               int64_t n, int4* __restrict__ zero, int64_t zero_n16) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) backup[i] = state[i];
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < zero_n16; i += (int64_t)gridDim.x * 256) zero[i] = make_int4(0, 0, 0, 0);
+}
+
+extern "C" int otvae_step_begin_slots(int32_t* step, const float* state, float* backup, int64_t n, void* zero, int64_t zero_words,
+                                      void* stream) {
+    OTVAE_REQUIRE(step && (n == 0 || (state && backup)) && n >= 0, "otvae_step_begin_slots: bad argument");
+    OTVAE_REQUIRE(zero_words >= 0 && (zero_words == 0 || (zero && ((uintptr_t)zero & 15) == 0 && zero_words % 2 == 0)),
+                  "otvae_step_begin_slots: the range to zero must be 16-byte aligned, an even number of int64 words");
+    const int64_t work = n > zero_words / 2 ? n : zero_words / 2;
+    step_begin_slots_kernel<<<imax(1, imin(cdiv(work, 1024), 1024)), 256, 0, (hipStream_t)stream>>>(step, state, backup, n, (int4*)zero,
+                                                                                                    zero_words / 2);
+    OTVAE_CHECK_LAUNCH("otvae_step_begin_slots");
+    return OTVAE_OK;
+}
+
+__global__ __launch_bounds__(256) void zero_words_kernel(int4* __restrict__ zero, int64_t n16) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) zero[i] = make_int4(0, 0, 0, 0);
+}
+
+// zero_words int64 words (16-byte aligned, an even count): the slots of a pass that has no step-begin launch of its own
+extern "C" int otvae_zero_words(void* zero, int64_t zero_words, void* stream) {
+    OTVAE_REQUIRE(zero && zero_words > 0 && ((uintptr_t)zero & 15) == 0 && zero_words % 2 == 0,
+                  "otvae_zero_words: the range must be 16-byte aligned, an even number of int64 words");
+    zero_words_kernel<<<imin(cdiv(zero_words / 2, 1024), 1024), 256, 0, (hipStream_t)stream>>>((int4*)zero, zero_words / 2);
+    OTVAE_CHECK_LAUNCH("otvae_zero_words");
+    return OTVAE_OK;
+}

@@ -9,6 +9,8 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from .. import _lib
+
 __all__ = ["FlatGradReducer", "world_size", "broadcast_module"]
 
 
@@ -28,7 +30,7 @@ class FlatGradReducer:
         self.world = world_size(group) if enabled else 1
         # a 1-rank process group still runs the collective (used to rehearse the multi-GPU call sequence on one GPU)
         self.active = enabled and dist.is_available() and dist.is_initialized()
-        self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and self.active) else None
+        self.stream = _lib.fresh_stream(flat.device) if (flat.is_cuda and self.active) else None
 
     @property
     def grad_scale(self) -> float:

@@ -23,6 +23,8 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
+from .. import _lib
+
 from .lifetime import GraphSet, capture_guard
 from .segments import SEGMENT_CALLS, SegmentedStep
 from .trainer import HipTrainer, _dense_view
@@ -167,7 +169,13 @@ class GraphedNelbo:
         def backward(loss):
             for p in engine.params:
                 p.grad = None
-            engine._backward(loss)
+            # the backward pass's statistic slots lie behind the forward pass's; zeroed again here: this graph may be replayed more than
+            # once per forward replay (retain_graph)
+            HF.SlotArena.resume(engine.device, rezero=True)
+            try:
+                engine._backward(loss)
+            finally:
+                HF.SlotArena.end_step(engine.device)
             HF._PendingReduce.flush(engine.device)
             engine._collect_loose_grads()
             for p in engine.params:    # the captured pass's own p.grad objects must not outlive the capture
@@ -182,7 +190,7 @@ class GraphedNelbo:
         state = [t for t in model.buffers()] + [p.data for p in model.parameters() if id(p) not in flat_ids]
         state += [m.__dict__["_dropout_key"] for m in model.modules() if isinstance(m.__dict__.get("_dropout_key"), Tensor)]
         snap = [t.clone() for t in state]
-        s = torch.cuda.Stream(device=engine.device)
+        s = _lib.fresh_stream(engine.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(self.warmup):
@@ -190,7 +198,7 @@ class GraphedNelbo:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         mode = dict(capture_error_mode=os.environ.get("OTVAE_CAPTURE_ERROR_MODE", "thread_local"))
-        cstream = torch.cuda.Stream(device=engine.device)   # ONE capture stream for the forward and the backward graphs (segments.py)
+        cstream = _lib.fresh_stream(engine.device)   # ONE capture stream for the forward and the backward graphs (segments.py)
         with capture_guard():
             with torch.cuda.graph(cap.graphs.new("f"), stream=cstream, **mode):
                 loss, logs, art = forward()

@@ -23,6 +23,8 @@ from typing import Callable, List, Optional
 
 import torch
 
+from .. import _lib
+
 __all__ = ["SegmentedStep", "SEGMENT_CALLS"]
 
 # backward calls (ConvBlock stages) per launch-stream graph; 0 (default) = the forked single graph of round 2.
@@ -79,7 +81,7 @@ class SegmentedStep:
     def __enter__(self):
         torch.cuda.synchronize(self.device)
         if self._stream is None:
-            self._stream = torch.cuda.Stream(device=self.device)
+            self._stream = _lib.fresh_stream(self.device)
         self._stream.wait_stream(torch.cuda.current_stream(self.device))
         self._ctx = torch.cuda.stream(self._stream)
         self._ctx.__enter__()

@@ -267,12 +267,13 @@ class HipTrainer:
                   "otvae_weight_transpose")
 
     def _step_begin(self):
-        if self.step_guard is not None and self.rflat is not None:
-            check(self.lib.otvae_step_begin_guarded(ptr(self.step_count), ptr(self.rflat), ptr(self.rbackup), self.rflat.numel(),
-                                                    stream()), "otvae_step_begin_guarded")
-        else:
-            check(self.lib.otvae_step_begin(ptr(self.step_count), stream()), "otvae_step_begin")
-        HF.SlotArena.begin_step(self.device)   # the BatchNorm statistic slots of this step's forward pass (functional.SlotArena)
+        # one launch: the step counter, the step guard's backup of the running state, the zeroing of this step's BatchNorm statistic
+        # slots (functional.SlotArena)
+        z = HF.SlotArena.begin_step(self.device, fused_zero=True)
+        guarded = self.step_guard is not None and self.rflat is not None
+        check(self.lib.otvae_step_begin_slots(ptr(self.step_count), ptr(self.rflat) if guarded else None,
+                                              ptr(self.rbackup) if guarded else None, self.rflat.numel() if guarded else 0,
+                                              ptr(z), z.numel() if z is not None else 0, stream()), "otvae_step_begin_slots")
 
     def _forward_backward(self):
         self._step_begin()
@@ -432,7 +433,11 @@ class HipTrainer:
         """the encoder's backward, from dL/dh that phase 1 left at the cut"""
         h = self._cut
         if h is not None:
-            torch.autograd.backward(h, h.grad, inputs=self._enc_params)
+            HF.SlotArena.resume(self.device)   # (the encoder's backward adds into slots behind the ones phase 1 took)
+            try:
+                torch.autograd.backward(h, h.grad, inputs=self._enc_params)
+            finally:
+                HF.SlotArena.end_step(self.device)
             h.grad = None
             from ..functional import _PendingReduce
             _PendingReduce.flush(self.device)
@@ -528,7 +533,7 @@ class HipTrainer:
         if self.ema is not None:
             state.append(self.ema.shadow)
         state_snap = [t.clone() for t in state]
-        s = torch.cuda.Stream(device=self.device)
+        s = _lib.fresh_stream(self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
@@ -540,6 +545,7 @@ class HipTrainer:
         # illegal call that kills the capture, and the process with it, whenever the poll happens to land inside it
         mode = dict(capture_error_mode=os.environ.get("OTVAE_CAPTURE_ERROR_MODE", "thread_local"))
         gs = self._gs
+        mode["stream"] = _lib.fresh_stream(self.device)   # a capture stream nothing else of this process aliases (_lib.fresh_stream)
         # capture_guard: graphs parked by engines that died inside an earlier capture are destroyed first, and the cyclic collector
         # stays off until the capture ends (a graph destroyed inside an open capture aborts the process: engine/lifetime.py)
         with capture_guard():

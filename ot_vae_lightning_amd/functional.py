@@ -117,29 +117,72 @@ class BNBranch:
         self.running_mean, self.running_var, self.num_batches_tracked = running_mean, running_var, num_batches_tracked
 
 
-# OTVAE_BN_SLOTS: 1 (default) = inside a training engine's step the BatchNorm sums of a layer's output go to STATISTIC SLOTS (csrc/common.h:
-# int64 fixed-point limbs added with integer atomics: order-independent, bit-reproducible) and the consumer kernel folds the finalize
-# arithmetic into its own prologue (no otvae_bn_finalize launch: 30 fewer dependent launches in the forward pass of the MNIST step);
-# 0 = per-block fp64 partials + a finalize launch (rounds 1-3).  The slots of a step come from one arena the engine zeroes at the
-# start of the step; outside an engine's step (plain module calls) the partial route is taken.
+# OTVAE_BN_SLOTS.  Inside a training engine's step the cross-block sums of BatchNorm can go to STATISTIC SLOTS (csrc/common.h: int64
+# fixed-point limbs added with integer atomics: order-independent, bit-reproducible) and the consumer kernel folds the finalize
+# arithmetic into its own prologue, so that the finalize launch disappears from the dependent chain:
+#   1 (default)  the forward pass: a layer output's (sum, sum of squares) -> the next conv / attention-stage launch.  30 launches
+#                fewer in the MNIST step, 2.67 -> 2.59 ms (same box, profiles/r04_bn_slots_ab.txt);
+#   2            also the backward pass: a data gradient's (sum gv, sum gv * xhat) -> otvae_bn_bwd_apply_slots (finalize + apply in one
+#                launch).  30 more launches gone, but SLOWER than 1 (2.62 ms): the backward finalize launches were hidden behind the
+#                weight-gradient stream, the slot atomics and the per-block prologue are not.  Kept, tested, off;
+#   0            per-block fp64 partials + finalize launches everywhere (rounds 1-3).
+# The slots of a step come from one arena that the engine zeroes in its step-begin launch; outside an engine's step (plain module
+# calls) the partial route is taken.
 BN_SLOTS_MODE = int(os.environ.get("OTVAE_BN_SLOTS", "1"))
 
 
+class Slots:
+    """one tensor's statistic slots: int64 view of the arena, channel stride, slots in use"""
+    __slots__ = ("buf", "ld", "n")
+
+    def __init__(self, buf: Tensor, ld: int, n: int):
+        self.buf, self.ld, self.n = buf, int(ld), int(n)
+
+
 class SlotArena:
-    """int64 words for the statistic slots of one step (per device): zeroed and rewound by the engine at the start of every step
-    (``begin_step``), handed out in a fixed order (``take``), so that a captured step bakes the same addresses the warm-up steps used."""
-    _state: dict = {}   # device -> [tensor, offset, active]
-    WORDS = 1 << 20      # 8 MiB: ~60 tensors of 16 slots x 2 statistics x <= 768 channels x 2 limbs fit many times over
+    """int64 words for the statistic slots of one step (per device).  ``begin_step`` rewinds it and zeroes what earlier steps used
+    (in the engine's own step-begin launch when ``fused_zero``); ``take`` hands out ranges in call order -- a captured step bakes the
+    addresses its warm-up steps used -- and zeroes on demand whatever lies beyond the part already zeroed (first step, growing shapes)."""
+    _state: dict = {}    # device -> [buf, offset, active, high-water mark, zeroed-up-to]
+    WORDS = 1 << 20       # 8 MiB; a tensor takes 64 * ld + 2 words: the MNIST step ~0.2 M words, forward and backward together
 
     @staticmethod
-    def begin_step(device) -> None:
-        if BN_SLOTS_MODE == 0:
-            return
+    def _zero(t: Tensor) -> None:
+        if t.numel():
+            check(_lib.load().otvae_zero_words(ptr(t), t.numel(), stream()), "otvae_zero_words")
+
+    @staticmethod
+    def ensure(device):
         st = SlotArena._state.get(device)
+        if st is None and BN_SLOTS_MODE != 0 and not torch.cuda.is_current_stream_capturing():   # (never allocated from a graph's pool)
+            st = SlotArena._state[device] = [torch.zeros(SlotArena.WORDS, device=device, dtype=torch.int64), 0, False, 0, 0]
+        return st
+
+    @staticmethod
+    def begin_step(device, fused_zero: bool = False) -> Optional[Tensor]:
+        """Returns the range the caller zeroes in a launch of its own (``fused_zero``), else None."""
+        st = SlotArena.ensure(device) if BN_SLOTS_MODE != 0 else None
         if st is None:
-            st = SlotArena._state[device] = [torch.zeros(SlotArena.WORDS, device=device, dtype=torch.int64), 0, False]
-        st[0].zero_()
-        st[1], st[2] = 0, True
+            return None
+        st[1], st[2], st[4] = 0, True, st[3]
+        if st[3] == 0:
+            return None
+        rng = st[0][: st[3]]
+        if fused_zero:
+            return rng
+        SlotArena._zero(rng)
+        return None
+
+    @staticmethod
+    def resume(device, rezero: bool = False) -> None:
+        """The step continues (backward pass) behind what ``begin_step`` .. ``end_step`` handed out.  ``rezero``: the ranges from here
+        on are zeroed again first -- a captured backward pass that may be replayed more than once per forward replay."""
+        st = SlotArena._state.get(device)
+        if st is None or BN_SLOTS_MODE == 0:
+            return
+        st[2] = True
+        if rezero and st[4] > st[1]:
+            SlotArena._zero(st[0][st[1]: st[4]])
 
     @staticmethod
     def end_step(device) -> None:
@@ -148,31 +191,43 @@ class SlotArena:
             st[2] = False
 
     @staticmethod
-    def take(device, words: int) -> Optional[Tensor]:
+    def pick(blocks: int) -> int:
+        """slots in use for a producer of ``blocks`` blocks (profiles/r04_bn_finalize_probe.txt: few blocks contend little and the
+        consumer reads S x 4 words per channel; a thousand blocks on 4 slots serialise)"""
+        return 4 if blocks <= 64 else (8 if blocks <= 256 else 16)
+
+    @staticmethod
+    def take(device, ld: int, blocks: int) -> Optional[Slots]:
         st = SlotArena._state.get(device)
-        if st is None or not st[2]:
+        if st is None or not st[2] or ld > 1024:
             return None
-        words = (int(words) + 1) // 2 * 2   # 16-byte aligned views
-        if st[1] + words > st[0].numel():
+        words = (int(_lib.load().otvae_bn_slots_words(int(ld))) + 1) // 2 * 2   # 16-byte aligned ranges
+        end = st[1] + words
+        if end > st[0].numel():
             return None   # (full: the caller keeps the partial route)
-        v = st[0][st[1]: st[1] + words]
-        st[1] += words
-        return v
+        if end > st[4]:
+            SlotArena._zero(st[0][st[4]: end])
+            st[4] = end
+        v = st[0][st[1]: end]
+        st[1] = end
+        st[3] = max(st[3], end)
+        return Slots(v, ld, SlotArena.pick(blocks))
 
 
 class PendingFold:
     """Statistics of x that sit in slots and have not been turned into (mean, invstd, scale, shift) yet: the consumer launch folds that
     into its prologue and ITS first block fills the four tensors (``fold_struct``); a consumer that cannot calls ``materialize``."""
-    __slots__ = ("slots", "ld", "count", "branches", "update", "mean", "invstd", "scales", "shifts", "done")
+    __slots__ = ("slots", "count", "branches", "update", "mean", "invstd", "scales", "shifts", "done")
 
-    def __init__(self, slots, ld, count, branches, update, mean, invstd, scales, shifts):
-        self.slots, self.ld, self.count, self.branches, self.update = slots, ld, count, list(branches), update
+    def __init__(self, slots: Slots, count, branches, update, mean, invstd, scales, shifts):
+        self.slots, self.count, self.branches, self.update = slots, count, list(branches), update
         self.mean, self.invstd, self.scales, self.shifts, self.done = mean, invstd, scales, shifts, False
 
     def fold_struct(self, j: int, publish: bool) -> "_lib.BnFold":
         br = self.branches[j]
         f = _lib.BnFold()
-        f.slots, f.ld, f.count, f.eps, f.momentum = ptr(self.slots), int(self.ld), int(self.count), BN_EPS, BN_MOMENTUM
+        f.slots, f.ld, f.nslots = ptr(self.slots.buf), self.slots.ld, self.slots.n
+        f.count, f.eps, f.momentum = int(self.count), BN_EPS, BN_MOMENTUM
         f.gamma, f.beta = ptr(br.gamma), ptr(br.beta)
         if self.update:
             f.running_mean, f.running_var, f.num_batches_tracked = ptr(br.running_mean), ptr(br.running_var), ptr(br.num_batches_tracked)
@@ -208,16 +263,15 @@ def bn_batch_stats(x: Tensor, branches: Sequence[BNBranch], update_running: bool
     nb = len(branches)
     upd = update_running
     pre = getattr(x, "_otvae_stats", None)
-    slots = ld = None
-    if pre is not None and isinstance(pre[0], str):      # ("slots", slots, ld): the producer's epilogue used the statistic slots
-        _, slots, ld = pre
-    elif pre is None and 1 <= nb <= 2 and c <= 1024:
-        ld = c
-        slots = SlotArena.take(x.device, lib.otvae_bn_slots_words(ld))
+    slots = None
+    if isinstance(pre, Slots):      # the producer's epilogue used the statistic slots
+        slots = pre
+    elif pre is None and 1 <= nb <= 2:
+        slots = SlotArena.take(x.device, c, lib.otvae_bn_stats_nparts(m, c))
         if slots is not None:
-            check(lib.otvae_bn_stats_slots(ptr(x), m, c, ptr(slots), ld, stream()), "otvae_bn_stats_slots")
+            check(lib.otvae_bn_stats_slots(ptr(x), m, c, ptr(slots.buf), slots.ld, slots.n, stream()), "otvae_bn_stats_slots")
     if slots is not None:
-        fold = PendingFold(slots, ld, m, branches, upd, mean, invstd, scales, shifts)
+        fold = PendingFold(slots, m, branches, upd, mean, invstd, scales, shifts)
         if allow_fold and 1 <= nb <= 2:
             return mean, invstd, scales, shifts, fold
         fold.materialize()
@@ -287,7 +341,7 @@ class _PendingReduce:
         """Next side stream of the device's pool (round robin: successive forks may run beside each other, too)."""
         pool = _PendingReduce._side.get(device)
         if pool is None:
-            pool = _PendingReduce._side[device] = [[torch.cuda.Stream(device=device) for _ in range(WGRAD_STREAMS)], 0]
+            pool = _PendingReduce._side[device] = [[_lib.fresh_stream(device) for _ in range(WGRAD_STREAMS)], 0]
         pool[1] = (pool[1] + 1) % len(pool[0])
         return pool[0][pool[1]]
 
@@ -524,7 +578,7 @@ class PriorLane:
     def stream(device) -> "torch.cuda.Stream":
         st = PriorLane._streams.get(device)
         if st is None:
-            st = PriorLane._streams[device] = torch.cuda.Stream(device=device)
+            st = PriorLane._streams[device] = _lib.fresh_stream(device)
         return st
 
     @staticmethod
@@ -641,9 +695,9 @@ def conv_forward_launch(x, specs, stats, tensors):
         part, st, slots_out = None, None, None
         if sp.out_stats:
             p_s, ld = _conv_plan(g, bias is not None)[:2]
-            slots_out = SlotArena.take(x.device, lib.otvae_bn_slots_words(ld)) if ld <= 1024 else None
+            slots_out = SlotArena.take(x.device, ld, p_s)
             if slots_out is not None:
-                st = ("slots", slots_out, ld)
+                st = slots_out
             else:
                 part = torch.empty((p_s, 2, ld), device=x.device, dtype=torch.float64)
                 st = (part, p_s, ld)
@@ -657,7 +711,8 @@ def conv_forward_launch(x, specs, stats, tensors):
             jb.shift = ptr(shifts[b]) if sp.has_norm else None
         jn += 1 if sp.has_norm else 0
         jb.w, jb.bias, jb.residual, jb.y, jb.stat_partial = ptr(w), ptr(bias), ptr(res), ptr(y), ptr(part)
-        jb.stat_slots = ptr(slots_out)
+        if slots_out is not None:
+            jb.stat_slots, jb.stat_nslots = ptr(slots_out.buf), slots_out.n
         keep.append(part)
         outs.append(y)
         geoms.append(g)
@@ -694,6 +749,8 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
     # all layers of the backward pass reduce in one launch; otherwise it runs right after the multi launch:
     # autograd may clone / accumulate the returned tensor before a deferred kernel would have filled it.
     wjobs, djobs = (_lib.ConvJob * nbr)(), (_lib.ConvJob * nbr)()
+    bwd_slots = BN_SLOTS_MODE >= 2 and cs <= 1024 and sum(1 for sp in specs if sp.has_norm) <= 2
+    slot_jobs: list = []
     nw = nd = 0
     order = []       # (is_weight_job, index) in issue order of the single-launch variant
     all_deferred = True
@@ -731,7 +788,7 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
                                gw.data_ptr(), gb.data_ptr() if gb is not None else None, g.Cs, 0 if _DENSE_REDUCE else dead_taps)
         # --- data gradient (needed for dx and for the BatchNorm parameter gradients)
         gv = None
-        part = None
+        part = None    # the BatchNorm-backward sums of this branch: fp64 partials (Tensor) or statistic slots (Slots)
         pre = pre_dgrad[b] if pre_dgrad is not None else None
         if pre is not None:
             gv, part, p_pre, cp_pre = pre
@@ -746,7 +803,18 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
                       "otvae_weight_transpose")
             gv = empty_nhwc(n, cs, hs, ws, x)
             if sp.has_norm:
-                part = torch.empty((p_d, 2, cp), device=x.device, dtype=torch.float64)
+                # slots only when every normalised branch of this call gets them (one consumer launch reads them all)
+                part = SlotArena.take(x.device, cp, p_d) if bwd_slots else None
+                if part is None:
+                    bwd_slots = False
+                    part = torch.empty((p_d, 2, cp), device=x.device, dtype=torch.float64)
+                    for b0, k0, p0, cp0 in slot_jobs:   # (the arena ran out between two branches: the earlier one goes back to partials)
+                        part0 = torch.empty((p0, 2, cp0), device=x.device, dtype=torch.float64)
+                        djobs[k0].bn_slots, djobs[k0].bn_nslots, djobs[k0].bn_partial = None, 0, ptr(part0)
+                        per_branch[b0] = per_branch[b0][:3] + (part0,) + per_branch[b0][4:]
+                    slot_jobs = []
+                else:
+                    slot_jobs.append((b, nd, p_d, cp))
                 cspad = cp
                 ps.append(p_d)
             jb = djobs[nd]
@@ -758,7 +826,11 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
             jb.shift = ptr(shifts[b]) if sp.has_norm else None
             jb.mean = ptr(mean) if sp.has_norm else None
             jb.invstd = ptr(invstd) if sp.has_norm else None
-            jb.gv, jb.bn_partial = ptr(gv), ptr(part)
+            jb.gv = ptr(gv)
+            if isinstance(part, Slots):
+                jb.bn_slots, jb.bn_nslots = ptr(part.buf), part.n
+            else:
+                jb.bn_partial = ptr(part)
             keep.append(wd)
         per_branch.append((gw, gb, gv, part, gy if sp.has_residual else None))
     if all_deferred and (WGRAD_SIDE_STREAM == 2 or (WGRAD_SIDE_STREAM == 1 and torch.cuda.is_current_stream_capturing())):
@@ -788,7 +860,26 @@ def conv_backward_launch(x, tensors, specs, geoms, stats, params_ref, gys, need_
     dgam = {b: None for b in range(nbr)}
     dbet = {b: None for b in range(nbr)}
     dx = None
-    if bn_idx:
+    kinds = {isinstance(per_branch[b][3], Slots) for b in bn_idx}
+    if bn_idx and kinds == {True}:
+        # sums in statistic slots: finalize + apply as one launch (otvae_bn_bwd_apply_slots), or the finalize half alone (dx not needed)
+        nbn = len(bn_idx)
+        for b in bn_idx:
+            dgam[b] = _grad_buffer(params_ref[b][2], tensors[5 * b + 2])
+            dbet[b] = _grad_buffer(params_ref[b][3], tensors[5 * b + 3])
+        sl = [per_branch[b][3] for b in bn_idx]
+        if any(s_.ld != sl[0].ld for s_ in sl):
+            raise RuntimeError("BatchNorm-backward slots of one layer input with different channel strides")
+        if need_dx:
+            dx = empty_nhwc(n, cs, hs, ws, x)
+        check(lib.otvae_bn_bwd_apply_slots(nbn, ptr_array([per_branch[b][2] for b in bn_idx]), ptr(x), ptr_array([s_.buf for s_ in sl]),
+                                           (C.c_int * nbn)(*[s_.n for s_ in sl]), sl[0].ld, m_in, cs, ptr(mean), ptr(invstd),
+                                           ptr_array([tensors[5 * b + 2] for b in bn_idx]), ptr_array([dgam[b] for b in bn_idx]),
+                                           ptr_array([dbet[b] for b in bn_idx]), int(bool(training)), ptr(dx) if need_dx else None,
+                                           stream()), "otvae_bn_bwd_apply_slots")
+    elif bn_idx:
+        if True in kinds:
+            raise RuntimeError("BatchNorm-backward sums of one layer input split between slots and partials")
         nbn = len(bn_idx)
         coef = torch.empty((2 + nbn, cs), device=x.device, dtype=torch.float32)
         gam_t = [tensors[5 * b + 2] for b in bn_idx]
@@ -1265,7 +1356,7 @@ class _AttnStageFn(torch.autograd.Function):
         aux = torch.empty((n, heads, t, c * c), device=x.device, dtype=torch.float32) if (need_aux and c <= 2) else None
         part = slots_out = None
         if stats_out is not None:
-            slots_out = SlotArena.take(x.device, lib.otvae_bn_slots_words(hc))
+            slots_out = SlotArena.take(x.device, hc, rows)
             if slots_out is None:
                 part = torch.empty((rows, 2, hc), device=x.device, dtype=torch.float64)
         if fold is not None or slots_out is not None:
@@ -1274,14 +1365,15 @@ class _AttnStageFn(torch.autograd.Function):
             check(lib.otvae_attn_stage_fwd_fold(ptr(x), C.byref(fs) if fs is not None else None,
                                                 None if fold is not None else ptr(scales[0]), None if fold is not None else ptr(shifts[0]),
                                                 ptr(wq), ptr(wp), ptr(res), n, t, heads, c, scale, ptr(qkv), ptr(out), ptr(lse), ptr(aux),
-                                                ptr(y), ptr(part), ptr(slots_out), stream()), "otvae_attn_stage_fwd_fold")
+                                                ptr(y), ptr(part), ptr(slots_out.buf) if slots_out is not None else None,
+                                                slots_out.n if slots_out is not None else 0, stream()), "otvae_attn_stage_fwd_fold")
             if fold is not None:
                 fold.done = True
         else:
             check(lib.otvae_attn_stage_fwd(ptr(x), ptr(scales[0]), ptr(shifts[0]), ptr(wq), ptr(wp), ptr(res), n, t, heads, c, scale,
                                            ptr(qkv), ptr(out), ptr(lse), ptr(aux), ptr(y), ptr(part), stream()), "otvae_attn_stage_fwd")
         if stats_out is not None:
-            stats_out.append(("slots", slots_out, hc) if slots_out is not None else (part, rows, hc))
+            stats_out.append(slots_out if slots_out is not None else (part, rows, hc))
         ctx.cfg = (heads, scale, stats, pref_q, pref_p, gamma is not None, res is not None)
         ctx.geoms = (_geom(x, wq, 1, 0, 1)[0], _geom(out, wp, 1, 0, 1)[0])
         ctx.save_for_backward(x, wq, gamma, beta, wp, res, qkv, out, lse, aux)
@@ -1309,11 +1401,19 @@ class _AttnStageFn(torch.autograd.Function):
             _, per_p = conv_backward_launch(out, (wp, None, None, None, res), (sp_p,), (ctx.geoms[1],), no_stats, (pref_p,), (gy,), False,
                                             fork="queue")
             gv = empty_nhwc(n, hc, hh, ww, x)
-            part = torch.empty((rows, 2, hc), device=x.device, dtype=torch.float64) if has_norm else None
-            check(lib.otvae_attn_stage_bwd(ptr(gy), ptr(wp), ptr(wq), ptr(x), ptr(stats[0]) if has_norm else None,
-                                           ptr(stats[1]) if has_norm else None, ptr(stats[2][0]) if has_norm else None,
-                                           ptr(stats[3][0]) if has_norm else None, ptr(qkv), ptr(out), ptr(lse), ptr(aux), n, t, heads, c,
-                                           scale, ptr(gqkv), ptr(gv), ptr(part), stream()), "otvae_attn_stage_bwd")
+            part = None
+            if has_norm:
+                part = SlotArena.take(x.device, hc, rows) if BN_SLOTS_MODE >= 2 else None   # statistic slots, else fp64 partials
+                if part is None:
+                    part = torch.empty((rows, 2, hc), device=x.device, dtype=torch.float64)
+            norm_args = (ptr(stats[0]), ptr(stats[1]), ptr(stats[2][0]), ptr(stats[3][0])) if has_norm else (None, None, None, None)
+            if isinstance(part, Slots):
+                check(lib.otvae_attn_stage_bwd_slots(ptr(gy), ptr(wp), ptr(wq), ptr(x), *norm_args, ptr(qkv), ptr(out), ptr(lse), ptr(aux),
+                                                     n, t, heads, c, scale, ptr(gqkv), ptr(gv), ptr(part.buf), part.n, stream()),
+                      "otvae_attn_stage_bwd_slots")
+            else:
+                check(lib.otvae_attn_stage_bwd(ptr(gy), ptr(wp), ptr(wq), ptr(x), *norm_args, ptr(qkv), ptr(out), ptr(lse), ptr(aux),
+                                               n, t, heads, c, scale, ptr(gqkv), ptr(gv), ptr(part), stream()), "otvae_attn_stage_bwd")
             dx, per_q = conv_backward_launch(x, (wq, None, gamma, beta, None), (sp_q,), (ctx.geoms[0],), stats, (pref_q,), (gqkv,),
                                              ctx.needs_input_grad[0], pre_dgrad=[(gv, part, rows, hc)], fork="after_bn")
             return dx, None, per_q[0][0], per_q[0][2], per_q[0][3], per_p[0][0], per_p[0][4]

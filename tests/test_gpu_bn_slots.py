@@ -36,8 +36,9 @@ def _truth(x, gamma, beta, rmean, rvar, eps=1e-5, momentum=0.1):
     return mu, invstd, scale, shift, (1 - momentum) * rmean.double() + momentum * mu, (1 - momentum) * rvar.double() + momentum * unb
 
 
+@pytest.mark.parametrize("nslots", [1, 4, 16])
 @pytest.mark.parametrize("shape", [(4, 3, 5, 7), (32, 32, 16, 16), (2, 257, 3, 3), (1, 1024, 1, 1), (64, 8, 32, 32)])
-def test_slots_statistics_and_finalize_vs_fp64(A, shape):
+def test_slots_statistics_and_finalize_vs_fp64(A, shape, nslots):
     from ot_vae_lightning_amd import _lib, functional as HF
     from ot_vae_lightning_amd._lib import check, ptr, stream
     lib = _lib.load()
@@ -54,11 +55,11 @@ def test_slots_statistics_and_finalize_vs_fp64(A, shape):
         rm, rv = [t.clone() for t in rm0], [t.clone() for t in rv0]
         nbt = [torch.tensor(3, device="cuda") for _ in range(2)]
         slots = torch.zeros(lib.otvae_bn_slots_words(c), device="cuda", dtype=torch.int64)
-        check(lib.otvae_bn_stats_slots(ptr(x), m, c, ptr(slots), c, stream()), "stats_slots")
+        check(lib.otvae_bn_stats_slots(ptr(x), m, c, ptr(slots), c, nslots, stream()), "stats_slots")
         br = [HF.BNBranch(gam[j], bet[j], rm[j], rv[j], nbt[j]) for j in range(2)]
         mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
         sc, sh = [torch.empty(c, device="cuda") for _ in range(2)], [torch.empty(c, device="cuda") for _ in range(2)]
-        fold = HF.PendingFold(slots, c, m, br, True, mean, invstd, sc, sh)
+        fold = HF.PendingFold(HF.Slots(slots, c, nslots), m, br, True, mean, invstd, sc, sh)
         fold.materialize()
         torch.cuda.synchronize()
         return mean, invstd, sc, sh, rm, rv, nbt, slots
@@ -93,16 +94,107 @@ def test_slots_non_finite_input_reads_as_nan_and_keeps_the_running_buffers(A):
     x = torch.randn(8, c, 4, 4).cuda().contiguous(memory_format=torch.channels_last)
     x[3, 5, 2, 1] = float("inf")
     slots = torch.zeros(lib.otvae_bn_slots_words(c), device="cuda", dtype=torch.int64)
-    check(lib.otvae_bn_stats_slots(ptr(x), 8 * 16, c, ptr(slots), c, stream()), "stats_slots")
+    check(lib.otvae_bn_stats_slots(ptr(x), 8 * 16, c, ptr(slots), c, 8, stream()), "stats_slots")
     rm, rv, nbt = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"), torch.tensor(0, device="cuda")
     br = [HF.BNBranch(torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), rm, rv, nbt)]
     mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
     sc, sh = [torch.empty(c, device="cuda")], [torch.empty(c, device="cuda")]
-    HF.PendingFold(slots, c, 128, br, True, mean, invstd, sc, sh).materialize()
+    HF.PendingFold(HF.Slots(slots, c, 8), 128, br, True, mean, invstd, sc, sh).materialize()
     torch.cuda.synchronize()
     assert int(slots[-2]) > 0
     assert torch.isnan(mean).all() and torch.isnan(sc[0]).all(), "an unrepresentable sum poisons the tensor's statistics"
     assert torch.equal(rm, torch.zeros_like(rm)) and torch.equal(rv, torch.ones_like(rv)), "NaN statistics never enter the running buffers"
+    with pytest.raises(ValueError, match="1, 2, 4, 8 or 16"):
+        check(lib.otvae_bn_stats_slots(ptr(x), 8 * 16, c, ptr(slots), c, 3, stream()), "stats_slots")
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("case", [(8, 8, 16, 16, 1), (4, 64, 2, 2, 2), (16, 6, 5, 5, 2), (2, 128, 1, 1, 1)])
+def test_backward_pair_through_slots_vs_finalize_and_apply_launches(A, case, training):
+    """A data-gradient job with its BatchNorm-backward sums into slots + ``otvae_bn_bwd_apply_slots`` against the same job with fp64
+    partials + ``otvae_bn_bwd_finalize`` + ``otvae_bn_bwd_apply``, and both against the fp64 formula
+    dx = sum_b k_b g_b - A x - B (csrc/bn.hip), dgamma = sum g xhat, dbeta = sum g."""
+    from ot_vae_lightning_amd import _lib, functional as HF
+    from ot_vae_lightning_amd._lib import check, ptr, ptr_array, stream
+    lib = _lib.load()
+    n, c, h, w, nb = case
+    g_ = torch.Generator().manual_seed(sum(case))
+    cl = torch.channels_last
+    x = (torch.randn(n, c, h, w, generator=g_) * 2 + 0.5).cuda().contiguous(memory_format=cl)
+    gv = [torch.randn(n, c, h, w, generator=g_).cuda().contiguous(memory_format=cl) for _ in range(nb)]
+    gam = [(torch.rand(c, generator=g_) + 0.5).cuda() for _ in range(nb)]
+    m = n * h * w
+    xd = x.double()
+    mu = xd.mean(dim=(0, 2, 3))
+    var = xd.var(dim=(0, 2, 3), unbiased=False)
+    mean, invstd = mu.float(), (1.0 / torch.sqrt(var + 1e-5)).float()
+    xhat = (xd - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+    # the sums, as a data-gradient kernel's epilogue leaves them: here from the stand-alone statistics kernels on (gv, gv * xhat)
+    slots, parts = [], []
+    for b in range(nb):
+        s1 = gv[b].double().sum(dim=(0, 2, 3))
+        s2 = (gv[b].double() * xhat).sum(dim=(0, 2, 3))
+        sl = torch.zeros(lib.otvae_bn_slots_words(c), device="cuda", dtype=torch.int64)
+        # one "block" per slot carrying a share of the total: limbs hi (2^-10 units) / lo (2^-53 units), as bn_slot_add splits them
+        S = 4
+        for k in range(S):
+            share = s1 / S if k < S - 1 else s1 - (s1 / S) * (S - 1)
+            share2 = s2 / S if k < S - 1 else s2 - (s2 / S) * (S - 1)
+            for stat, val in ((0, share), (1, share2)):
+                hi = torch.floor(val * 1024.0)
+                lo = torch.floor((val - hi / 1024.0) * 9007199254740992.0)
+                view = sl[: 16 * 2 * c * 2].view(16, 2, c, 2)
+                view[k, stat, :, 0] = hi.long()
+                view[k, stat, :, 1] = lo.long()
+        slots.append(HF.Slots(sl, c, S))
+        part = torch.zeros((2, c, 3), device="cuda", dtype=torch.float64)   # [2][CsPad][P], P = 3
+        part[0, :, 0], part[0, :, 1], part[0, :, 2] = s1 * 0.5, s1 * 0.25, s1 * 0.25
+        part[1, :, 0], part[1, :, 1], part[1, :, 2] = s2 * 0.5, s2 * 0.25, s2 * 0.25
+        parts.append(part)
+    # slots route
+    dga, dbe = [torch.empty(c, device="cuda") for _ in range(nb)], [torch.empty(c, device="cuda") for _ in range(nb)]
+    dx = torch.empty_like(x)
+    check(lib.otvae_bn_bwd_apply_slots(nb, ptr_array(gv), ptr(x), ptr_array([s_.buf for s_ in slots]), (C.c_int * nb)(*[s_.n for s_ in slots]),
+                                       c, m, c, ptr(mean), ptr(invstd), ptr_array(gam), ptr_array(dga), ptr_array(dbe), int(training),
+                                       ptr(dx), stream()), "apply_slots")
+    # parameter gradients only
+    dga0, dbe0 = [torch.empty(c, device="cuda") for _ in range(nb)], [torch.empty(c, device="cuda") for _ in range(nb)]
+    check(lib.otvae_bn_bwd_apply_slots(nb, None, None, ptr_array([s_.buf for s_ in slots]), (C.c_int * nb)(*[s_.n for s_ in slots]),
+                                       c, m, c, ptr(mean), ptr(invstd), ptr_array(gam), ptr_array(dga0), ptr_array(dbe0), int(training),
+                                       None, stream()), "apply_slots(no dx)")
+    # launches route
+    dga2, dbe2 = [torch.empty(c, device="cuda") for _ in range(nb)], [torch.empty(c, device="cuda") for _ in range(nb)]
+    coef = torch.empty((2 + nb, c), device="cuda")
+    check(lib.otvae_bn_bwd_finalize(nb, ptr_array(parts), (C.c_int * nb)(*([3] * nb)), c, m, c, ptr(mean), ptr(invstd), ptr_array(gam),
+                                    ptr_array(dga2), ptr_array(dbe2), ptr(coef), stream()), "finalize")
+    if not training:
+        coef[:2].zero_()
+    dx2 = torch.empty_like(x)
+    check(lib.otvae_bn_bwd_apply(nb, ptr_array(gv), ptr(x), ptr(coef), m, c, ptr(dx2), stream()), "apply")
+    torch.cuda.synchronize()
+    # fp64 truth
+    Aa = torch.zeros(c, dtype=torch.float64, device="cuda")
+    Bb = torch.zeros_like(Aa)
+    dx_t = torch.zeros_like(xd)
+    for b in range(nb):
+        s1 = gv[b].double().sum(dim=(0, 2, 3))
+        s2 = (gv[b].double() * xhat).sum(dim=(0, 2, 3))
+        k = gam[b].double() * invstd.double()
+        Aa += k * s2
+        Bb += k * s1
+        dx_t += k.view(1, -1, 1, 1) * gv[b].double()
+        for got in (dga[b], dga0[b], dga2[b]):
+            assert float((got.double() - s2).abs().max()) <= 1e-6 * float(s2.abs().max()) + 1e-6
+        for got in (dbe[b], dbe0[b], dbe2[b]):
+            assert float((got.double() - s1).abs().max()) <= 1e-6 * float(s1.abs().max()) + 1e-6
+    Aa = Aa * invstd.double() / m
+    Bb = Bb / m - Aa * mean.double()
+    if training:
+        dx_t = dx_t - Aa.view(1, -1, 1, 1) * xd - Bb.view(1, -1, 1, 1)
+    # dx is a difference of terms of size k |g| (on a 1x1 map with two samples they cancel almost completely): fp32 rounding of the terms
+    scale_ = max(float((gam[b].double() * invstd.double()).view(1, -1, 1, 1).mul(gv[b].double().abs()).max()) for b in range(nb))
+    assert float((dx.double() - dx_t).abs().max()) <= 2e-6 * scale_ + 1e-6
+    assert float((dx2.double() - dx_t).abs().max()) <= 2e-6 * scale_ + 1e-6
 
 
 CONFIGS = {
@@ -146,10 +238,11 @@ def test_training_steps_through_slots_agree_with_the_finalize_launch_route(A, mo
         tr.close()
         return out
 
-    a, b, a2 = run(1), run(0), run(1)
-    assert taken[0] > 0 and taken[1] == 0, "the slots route was taken (and only when asked for)"
+    a, b, a2, f = run(2), run(0), run(2), run(1)
+    assert taken[0] > taken[3] > 0 and taken[1] == 0, "slots were taken: forward + backward (2), forward only (1), never (0)"
     for u, v in zip(a, a2):
         assert torch.equal(u, v), "the slots route is order independent: same bits on a second run"
-    for u, v, name in zip(a, b, ("params", "losses", "buffers")):
-        err = float((u.double() - v.double()).norm() / v.double().norm())
-        assert err < 2e-5, (name, err)
+    for got in (a, f):
+        for u, v, name in zip(got, b, ("params", "losses", "buffers")):
+            err = float((u.double() - v.double()).norm() / v.double().norm())
+            assert err < 2e-5, (name, err)

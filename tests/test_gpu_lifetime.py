@@ -225,3 +225,39 @@ def test_parameter_ema_in_the_optimizer_kernel_vs_the_torch_ema_rule():
         assert all(torch.equal(p.detach(), l_) for p, l_ in zip(params, live))
         if graphed:
             model.disable_graphed_step()
+
+
+def test_fresh_streams_never_alias_each_other_or_the_framework_pool():
+    """``torch.cuda.Stream()`` takes the next of 32 pooled streams round-robin: the 33rd is the first again.  A side stream that IS the
+    capture stream (or the prior lane) gave a captured step whose fork waited on itself, and the HIP graph executor died in
+    hip::Graph::UpdateStreams at the first replay (round 4, once the suite had built enough engines).  ``_lib.fresh_stream`` hands out
+    HIP streams of the library's own: distinct while alive, recycled when their wrapper dies."""
+    import gc
+    from ot_vae_lightning_amd import _lib
+    pool = [torch.cuda.Stream() for _ in range(40)]
+    assert len({s.cuda_stream for s in pool}) <= 32, "the framework's pool wraps around (the premise of this test)"
+    mine = [_lib.fresh_stream("cuda") for _ in range(48)]
+    handles = {s.cuda_stream for s in mine}
+    assert len(handles) == 48 and not (handles & {s.cuda_stream for s in pool}) and 0 not in handles
+    # they are real streams: work, events, capture
+    a = torch.ones(1024, device="cuda")
+    with torch.cuda.stream(mine[0]):
+        b = a * 2
+    mine[1].wait_stream(mine[0])
+    with torch.cuda.stream(mine[1]):
+        c = b + 1
+    torch.cuda.current_stream().wait_stream(mine[1])
+    assert float(c.sum()) == 3 * 1024
+    g = torch.cuda.CUDAGraph()
+    out = torch.zeros(1024, device="cuda")
+    with torch.cuda.graph(g, stream=mine[2], capture_error_mode="thread_local"):
+        out.copy_(a * 5)
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(out.sum()) == 5 * 1024
+    del g
+    # a wrapper that dies hands its stream back; the next request reuses it instead of creating the 49th
+    victim = mine.pop().cuda_stream
+    gc.collect()
+    again = _lib.fresh_stream("cuda")
+    assert again.cuda_stream == victim
