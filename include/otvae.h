@@ -127,10 +127,11 @@ int otvae_wgrad_reduce_batched(int n, const float* const* partial, const int* P,
 #define OTVAE_JOB_BWD_DATA 1
 #define OTVAE_JOB_BWD_WEIGHT 2
 /* ---- BatchNorm statistic SLOTS (round 4): cross-block sums without a finalize launch, bit-reproducible --------------------------------
- * Instead of P per-block partials a producer may add its per-channel sums into `nslots` (1, 2, 4, 8 or 16: the caller's choice, the
- * same number for the producer and the consumer of a buffer; few slots = fewer words for the consumer to read, many = less contention
- * among a producer's blocks) accumulators of int64 fixed-point limbs with integer atomics (associative: the totals do not depend on
- * arrival order); layout and arithmetic in csrc/common.h.  `slots` buffers hold otvae_bn_slots_words(ld) int64 words, are 16-byte
+ * Instead of P per-block partials a producer may add its per-channel sums into `nslots` (a power of two <= 64: the caller's choice, the
+ * same number for the producer and the consumer of a buffer; atomics on one address are performed one after the other, ~0.1 us each,
+ * so nslots should grow with the producer's block count) accumulators of int64 fixed-point limbs with integer atomics (associative:
+ * the totals do not depend on arrival order); layout and arithmetic in csrc/common.h.  `slots` buffers hold
+ * otvae_bn_slots_words(ld, nslots) int64 words, are 16-byte
  * aligned and must be ZERO before the producer runs.  A consumer kernel that is handed an otvae_bn_fold
  * turns the sums into (scale, shift) in its own prologue -- every block for itself -- and its first block leaves mean / invstd / scale /
  * shift in global memory for the backward pass and advances the running buffers: what otvae_bn_finalize did in a launch of its own
@@ -138,7 +139,7 @@ int otvae_wgrad_reduce_batched(int n, const float* const* partial, const int* P,
 typedef struct otvae_bn_fold {
     const void* slots;            /* NULL: no fold */
     int32_t ld;                   /* channel stride of the slots (>= channels) */
-    int32_t nslots;               /* slots in use: 1, 2, 4, 8 or 16 -- what the producer of `slots` was given */
+    int32_t nslots;               /* slots in use (power of two <= 64): what the producer of `slots` was given */
     int64_t count;                /* elements per channel: N * H * W of the normalised tensor */
     float eps, momentum;
     const float* gamma;
@@ -151,7 +152,7 @@ typedef struct otvae_bn_fold {
     float* scale_out;             /* this branch's affine, for the backward pass */
     float* shift_out;
 } otvae_bn_fold;
-int64_t otvae_bn_slots_words(int ld);
+int64_t otvae_bn_slots_words(int ld, int nslots);
 int otvae_bn_stats_slots(const float* x, int64_t M, int C, void* slots, int ld, int nslots, void* stream);
 int otvae_bn_finalize_slots(int n_bn, const otvae_bn_fold* folds, int C, void* stream);
 /* The BatchNorm backward pair (otvae_bn_bwd_finalize + otvae_bn_bwd_apply below) as ONE launch, for sums (sum gv, sum gv * xhat) that a
@@ -186,7 +187,7 @@ typedef struct otvae_conv_job {
     float* gb;
     void* stat_slots;           /* FWD (nullable, instead of stat_partial): statistic slots of the OUTPUT, channel stride = the ld of otvae_conv_fwd_stats_ws */
     void* bn_slots;             /* BWD_DATA (nullable, instead of bn_partial): statistic slots of the BatchNorm-backward sums, channel stride = the CsPad of otvae_conv_bwd_data_ws */
-    int32_t stat_nslots;        /* slots in use in stat_slots / bn_slots (1, 2, 4, 8 or 16) */
+    int32_t stat_nslots;        /* slots in use in stat_slots / bn_slots (power of two <= 64) */
     int32_t bn_nslots;
     otvae_bn_fold fold;         /* FWD (fold.slots nullable): the BatchNorm of the INPUT x folded into this launch; scale / shift are then ignored */
 } otvae_conv_job;

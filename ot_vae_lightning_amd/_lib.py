@@ -58,7 +58,7 @@ SIGNATURES = {
     "otvae_stream_destroy": (i32, [vp]),
     "otvae_bn_stats_nparts": (i32, [i64, i32]),
     "otvae_bn_stats": (i32, [vp, i64, i32, vp, vp]),
-    "otvae_bn_slots_words": (i64, [i32]),
+    "otvae_bn_slots_words": (i64, [i32, i32]),
     "otvae_bn_stats_slots": (i32, [vp, i64, i32, vp, i32, i32, vp]),
     "otvae_bn_bwd_apply_slots": (i32, [i32, pp, vp, pp, pi32, i32, i64, i32, vp, vp, pp, pp, pp, i32, vp, vp]),
     "otvae_bn_finalize_slots": (i32, [i32, C.POINTER(BnFold), i32, vp]),

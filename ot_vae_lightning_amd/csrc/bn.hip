@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
                 tq += sh[1][r * C + threadIdx.x];
             }
             if (slots) {
-                bn_slot_add(slots, ld, blockIdx.x & smask, 0, threadIdx.x, ts);
-                bn_slot_add(slots, ld, blockIdx.x & smask, 1, threadIdx.x, tq);
+                bn_slot_add(slots, ld, smask + 1u, blockIdx.x & smask, 0, threadIdx.x, ts);
+                bn_slot_add(slots, ld, smask + 1u, blockIdx.x & smask, 1, threadIdx.x, tq);
             } else {
                 partial[((size_t)0 * C + threadIdx.x) * P + blockIdx.x] = ts;
                 partial[((size_t)1 * C + threadIdx.x) * P + blockIdx.x] = tq;
@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
                 q += (double)v * (double)v;
             }
             if (slots) {
-                bn_slot_add(slots, ld, blockIdx.x & smask, 0, c, s);
-                bn_slot_add(slots, ld, blockIdx.x & smask, 1, c, q);
+                bn_slot_add(slots, ld, smask + 1u, blockIdx.x & smask, 0, c, s);
+                bn_slot_add(slots, ld, smask + 1u, blockIdx.x & smask, 1, c, q);
             } else {
                 partial[((size_t)0 * C + c) * P + blockIdx.x] = s;
                 partial[((size_t)1 * C + c) * P + blockIdx.x] = q;
@@ -76,7 +76,7 @@ extern "C" int otvae_bn_stats(const float* x, int64_t M, int C, double* partial,
 
 // ---- statistic slots (common.h): the sums land in BN_SLOTS accumulators instead of P partials; no finalize launch is needed when the
 // consumer folds them itself (BnFold), otvae_bn_finalize_slots is the stand-alone form for consumers that do not
-extern "C" int64_t otvae_bn_slots_words(int ld) { return ld > 0 ? (int64_t)bn_slot_words(ld) : -1; }
+extern "C" int64_t otvae_bn_slots_words(int ld, int nslots) { return (ld > 0 && bn_slots_ok(nslots)) ? (int64_t)bn_slot_words(ld, nslots) : -1; }
 
 extern "C" int otvae_bn_stats_slots(const float* x, int64_t M, int C, void* slots, int ld, int nslots, void* stream) {
     OTVAE_REQUIRE(x && slots && M > 0 && C > 0 && ld >= C, "otvae_bn_stats_slots: bad argument");
@@ -387,7 +387,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(BnBwdFold f, co
         double A = 0.0, B = 0.0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const double s1 = bn_slot_total(f.slots[b], f.ld, f.nslots[b], 0, c), s2 = bn_slot_total(f.slots[b], f.ld, f.nslots[b], 1, c);
+            double s1, s2;
+            bn_slot_totals(f.slots[b], f.ld, f.nslots[b], c, s1, s2);
             const double k = (double)f.gamma[b][c] * is;
             if (first) {
                 if (f.dbeta[b]) f.dbeta[b][c] = (float)s1;

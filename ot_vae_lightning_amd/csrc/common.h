@@ -66,23 +66,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // ---- BatchNorm statistic slots: cross-block sums WITHOUT a finalize launch, bit-reproducible (round 4) -------------------------------
-// A producer block adds its per-channel sums (sum x, sum x^2) into one of S <= BN_SLOTS accumulators as two int64 fixed-point limbs
+// A producer block adds its per-channel sums (sum x, sum x^2) into one of S <= BN_SLOTS_MAX accumulators as two int64 fixed-point limbs
 // (hi: units of 2^-10, lo: the exact remainder in units of 2^-53, < 2^43) with non-returning agent-scope INTEGER atomics.  Integer
 // addition is associative: the totals do not depend on the order in which blocks arrive (fp64 atomics would), and 2048 blocks x 2^43 stay
 // below 2^63.  A value that is not finite (or beyond 2^51) cannot be represented: it raises the tensor's poison counter instead and the
 // consumer reads the statistics as NaN -- the propagation the plain fp64 partials had, which the device-side step guard relies on.
-// Layout: long long [BN_SLOTS][2 statistics][ld channels][2 limbs] + 2 words {poison counter, unused}; zero before the producer runs.
-// S (1, 2, 4, 8 or 16: the caller's choice, the same for the producer and the consumer of a buffer) trades contention among the
-// producer's blocks (few slots, many blocks) against words the consumer reads (S x 4 per channel and block): profiles/
-// r04_bn_finalize_probe.txt.  The consumer adds the S slots in index order (exact integer sums) and converts once.
-#define BN_SLOTS 16
+// Layout: long long [S][2 statistics][ld channels][2 limbs] + 2 words {poison counter, unused}; zero before the producer runs.
+// S (a power of two <= 64: the caller's choice, the same for the producer and the consumer of a buffer) sets how many blocks add into one
+// address: atomics on ONE address from all over the chip are performed one after the other, ~0.1 us each -- 64 of them were a 6 us tail
+// on the producing kernel (the first version of this round used S = 16 for 1024 blocks: profiles/r04_bn_slots_ab.txt) -- so S grows
+// with the producer's block count, and the consumer spreads the S x 2 x C loads over its threads (bn_fold_prologue).
+#define BN_SLOTS_MAX 64
 
-__host__ __device__ inline size_t bn_slot_words(int ld) { return (size_t)BN_SLOTS * 2 * ld * 2 + 2; }
-static inline bool bn_slots_ok(int nslots) { return nslots >= 1 && nslots <= BN_SLOTS && (nslots & (nslots - 1)) == 0; }
+__host__ __device__ inline size_t bn_slot_words(int ld, int S) { return (size_t)S * 2 * ld * 2 + 2; }
+static inline bool bn_slots_ok(int nslots) { return nslots >= 1 && nslots <= BN_SLOTS_MAX && (nslots & (nslots - 1)) == 0; }
 
-__device__ __forceinline__ void bn_slot_add(long long* __restrict__ slots, int ld, unsigned slot, int stat, int c, double v) {
+__device__ __forceinline__ void bn_slot_add(long long* __restrict__ slots, int ld, unsigned S, unsigned slot, int stat, int c, double v) {
     if (!(fabs(v) < 2251799813685248.0)) {  // 2^51; also catches NaN
-        __hip_atomic_fetch_add(slots + (size_t)BN_SLOTS * 2 * ld * 2, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(slots + (size_t)S * 2 * ld * 2, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const double h = floor(v * 1024.0);
@@ -92,17 +93,47 @@ __device__ __forceinline__ void bn_slot_add(long long* __restrict__ slots, int l
     __hip_atomic_fetch_add(dst + 1, (long long)floor(r * 9007199254740992.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// the total of statistic `stat` of channel c over the S slots in use (NaN when the producer met a value it could not represent)
-__device__ __forceinline__ double bn_slot_total(const long long* __restrict__ slots, int ld, int S, int stat, int c) {
-    long long hi = 0, lo = 0;
-#pragma unroll 4
-    for (int s = 0; s < S; ++s) {
-        const long long* p = slots + ((((size_t)s * 2 + stat) * ld + c) << 1);
-        hi += p[0];
-        lo += p[1];
+typedef long long bn_ll2 __attribute__((ext_vector_type(2)));
+
+// limb sums of both statistics of channel c over slots s0 .. s0 + N - 1, all 2 N 16-byte loads in flight before the first addition
+template <int N>
+__device__ __forceinline__ void bn_slot_sum_n(const long long* __restrict__ slots, int ld, int c, int s0, bn_ll2& sa, bn_ll2& sb) {
+    bn_ll2 a[N], b[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        a[s] = *reinterpret_cast<const bn_ll2*>(slots + ((((size_t)(s0 + s) * 2 + 0) * ld + c) << 1));
+        b[s] = *reinterpret_cast<const bn_ll2*>(slots + ((((size_t)(s0 + s) * 2 + 1) * ld + c) << 1));
     }
-    if (slots[(size_t)BN_SLOTS * 2 * ld * 2] != 0) return __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        sa += a[s];
+        sb += b[s];
+    }
+}
+
+__device__ __forceinline__ double bn_limbs_to_double(long long hi, long long lo) {
     return (double)hi * (1.0 / 1024.0) + (double)lo * (1.0 / 9007199254740992.0);
+}
+
+// the totals of both statistics of channel c over the S slots in use, by ONE thread (NaN when the producer met a value it could not
+// represent): the form for wide layers (few producer blocks, small S) and for the stand-alone finalize kernels
+__device__ __forceinline__ void bn_slot_totals(const long long* __restrict__ slots, int ld, int S, int c, double& t0, double& t1) {
+    bn_ll2 sa = {0, 0}, sb = {0, 0};
+    switch (S) {
+        case 1: bn_slot_sum_n<1>(slots, ld, c, 0, sa, sb); break;
+        case 2: bn_slot_sum_n<2>(slots, ld, c, 0, sa, sb); break;
+        case 4: bn_slot_sum_n<4>(slots, ld, c, 0, sa, sb); break;
+        case 8: bn_slot_sum_n<8>(slots, ld, c, 0, sa, sb); break;
+        default:
+            for (int s0 = 0; s0 < S; s0 += 16) bn_slot_sum_n<16>(slots, ld, c, s0, sa, sb);
+            break;
+    }
+    if (slots[(size_t)S * 2 * ld * 2] != 0) {
+        t0 = t1 = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    t0 = bn_limbs_to_double(sa.x, sa.y);
+    t1 = bn_limbs_to_double(sb.x, sb.y);
 }
 
 // Everything the finalize launch took, for ONE branch (ConvLayer) that normalises a tensor whose statistics sit in slots: the consumer
@@ -127,9 +158,48 @@ struct BnFold {
 };
 
 // s_sc / s_sh: LDS, C floats each.  Ends with a block barrier.
+// C <= BN_FOLD_WIDE channels: the S x 2 x C slot reads are spread over the block's threads (consecutive threads, consecutive channels:
+// coalesced 16-byte loads, at most a handful per thread, all in flight together) and summed with LDS integer atomics (associative:
+// same bits in any order); wider layers have few producer blocks, hence small S, and one thread per channel reads its slots itself.
+#define BN_FOLD_WIDE 64
 __device__ __forceinline__ void bn_fold_prologue(const BnFold& f, int C, float* s_sc, float* s_sh, bool first_block) {
+    __shared__ unsigned long long bn_acc[2 * BN_FOLD_WIDE * 2];   // [stat][c][limb]
+    const bool spread = C <= BN_FOLD_WIDE && f.nslots > 4;
+    if (spread) {
+        for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) bn_acc[i] = 0ULL;
+        __syncthreads();
+        const int W = 2 * C * f.nslots;
+        for (int w0 = threadIdx.x; w0 < W; w0 += 4 * blockDim.x) {
+            bn_ll2 v[4];
+            int at[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = w0 + u * blockDim.x;
+                at[u] = -1;
+                if (w < W) {
+                    const int c = w % C, r = w / C;   // r = s * 2 + stat
+                    v[u] = *reinterpret_cast<const bn_ll2*>(f.slots + (((size_t)r * f.ld + c) << 1));
+                    at[u] = ((r & 1) * C + c) * 2;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (at[u] >= 0) {
+                    atomicAdd(&bn_acc[at[u]], (unsigned long long)v[u].x);
+                    atomicAdd(&bn_acc[at[u] + 1], (unsigned long long)v[u].y);
+                }
+        }
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double s = bn_slot_total(f.slots, f.ld, f.nslots, 0, c), q = bn_slot_total(f.slots, f.ld, f.nslots, 1, c);
+        double s, q;
+        if (spread) {
+            const bool bad = f.slots[(size_t)f.nslots * 2 * f.ld * 2] != 0;
+            s = bad ? __longlong_as_double(0x7ff8000000000000LL) : bn_limbs_to_double((long long)bn_acc[c * 2], (long long)bn_acc[c * 2 + 1]);
+            q = bad ? s : bn_limbs_to_double((long long)bn_acc[(C + c) * 2], (long long)bn_acc[(C + c) * 2 + 1]);
+        } else {
+            bn_slot_totals(f.slots, f.ld, f.nslots, c, s, q);
+        }
         const double mu = s / (double)f.count;
         double var = q / (double)f.count - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -161,7 +231,10 @@ __device__ __forceinline__ void bn_fold_prologue(const BnFold& f, int C, float* 
 // and its kernels, never part of the C ABI.
 __device__ __forceinline__ void bn_stat_out(double* partial, int which, int ld, int c, unsigned P, unsigned p, double t) {
     const uintptr_t a = (uintptr_t)partial;
-    if (a & 1) bn_slot_add(reinterpret_cast<long long*>(a & ~(uintptr_t)15), ld, p & ((1u << ((a >> 1) & 7)) - 1u), which, c, t);
+    if (a & 1) {
+        const unsigned S = 1u << ((a >> 1) & 7);
+        bn_slot_add(reinterpret_cast<long long*>(a & ~(uintptr_t)15), ld, S, p & (S - 1u), which, c, t);
+    }
     else partial[((size_t)which * ld + c) * P + p] = t;
 }
 static inline double* bn_tag_slots(void* slots, int nslots) {
@@ -172,7 +245,7 @@ static inline double* bn_tag_slots(void* slots, int nslots) {
 // host-side check of a (slots, nslots) pair handed in through the C ABI
 #define OTVAE_REQUIRE_SLOTS(who, slots, nslots) \
     OTVAE_REQUIRE(!(slots) || ((((uintptr_t)(slots)) & 15) == 0 && bn_slots_ok(nslots)), \
-                  "%s: statistic slots must be 16-byte aligned with 1, 2, 4, 8 or 16 slots in use (got %d)", who, (int)(nslots))
+                  "%s: statistic slots must be 16-byte aligned with a power of two <= 64 slots in use (got %d)", who, (int)(nslots))
 
 // host side of otvae_bn_fold -> the device descriptor (a.slots == NULL: no fold, *f is cleared)
 static inline int bn_fold_from_abi(const char* who, const otvae_bn_fold& a, int C, BnFold* f) {

@@ -144,7 +144,7 @@ class SlotArena:
     (in the engine's own step-begin launch when ``fused_zero``); ``take`` hands out ranges in call order -- a captured step bakes the
     addresses its warm-up steps used -- and zeroes on demand whatever lies beyond the part already zeroed (first step, growing shapes)."""
     _state: dict = {}    # device -> [buf, offset, active, high-water mark, zeroed-up-to]
-    WORDS = 1 << 20       # 8 MiB; a tensor takes 64 * ld + 2 words: the MNIST step ~0.2 M words, forward and backward together
+    WORDS = 1 << 20       # 8 MiB; a tensor takes nslots * 4 * ld + 2 words
 
     @staticmethod
     def _zero(t: Tensor) -> None:
@@ -190,18 +190,25 @@ class SlotArena:
         if st is not None:
             st[2] = False
 
+    # producer blocks per slot address: atomics on one address are performed one after the other (~0.1 us each), so the tail a
+    # producer kernel pays is about this many tenths of a microsecond (profiles/r04_bn_slots_ab.txt)
+    ADDS_PER_SLOT = int(os.environ.get("OTVAE_BN_SLOT_ADDS", "16"))
+
     @staticmethod
     def pick(blocks: int) -> int:
-        """slots in use for a producer of ``blocks`` blocks (profiles/r04_bn_finalize_probe.txt: few blocks contend little and the
-        consumer reads S x 4 words per channel; a thousand blocks on 4 slots serialise)"""
-        return 4 if blocks <= 64 else (8 if blocks <= 256 else 16)
+        """slots in use for a producer of ``blocks`` blocks: a power of two in 4 .. 64"""
+        n = 4
+        while n < 64 and n * SlotArena.ADDS_PER_SLOT < blocks:
+            n *= 2
+        return n
 
     @staticmethod
     def take(device, ld: int, blocks: int) -> Optional[Slots]:
         st = SlotArena._state.get(device)
         if st is None or not st[2] or ld > 1024:
             return None
-        words = (int(_lib.load().otvae_bn_slots_words(int(ld))) + 1) // 2 * 2   # 16-byte aligned ranges
+        n = SlotArena.pick(blocks)
+        words = (int(_lib.load().otvae_bn_slots_words(int(ld), n)) + 1) // 2 * 2   # 16-byte aligned ranges
         end = st[1] + words
         if end > st[0].numel():
             return None   # (full: the caller keeps the partial route)
@@ -211,7 +218,7 @@ class SlotArena:
         v = st[0][st[1]: end]
         st[1] = end
         st[3] = max(st[3], end)
-        return Slots(v, ld, SlotArena.pick(blocks))
+        return Slots(v, ld, n)
 
 
 class PendingFold:

@@ -36,7 +36,7 @@ def _truth(x, gamma, beta, rmean, rvar, eps=1e-5, momentum=0.1):
     return mu, invstd, scale, shift, (1 - momentum) * rmean.double() + momentum * mu, (1 - momentum) * rvar.double() + momentum * unb
 
 
-@pytest.mark.parametrize("nslots", [1, 4, 16])
+@pytest.mark.parametrize("nslots", [1, 4, 16, 64])
 @pytest.mark.parametrize("shape", [(4, 3, 5, 7), (32, 32, 16, 16), (2, 257, 3, 3), (1, 1024, 1, 1), (64, 8, 32, 32)])
 def test_slots_statistics_and_finalize_vs_fp64(A, shape, nslots):
     from ot_vae_lightning_amd import _lib, functional as HF
@@ -54,7 +54,7 @@ def test_slots_statistics_and_finalize_vs_fp64(A, shape, nslots):
     def run():
         rm, rv = [t.clone() for t in rm0], [t.clone() for t in rv0]
         nbt = [torch.tensor(3, device="cuda") for _ in range(2)]
-        slots = torch.zeros(lib.otvae_bn_slots_words(c), device="cuda", dtype=torch.int64)
+        slots = torch.zeros(lib.otvae_bn_slots_words(c, nslots), device="cuda", dtype=torch.int64)
         check(lib.otvae_bn_stats_slots(ptr(x), m, c, ptr(slots), c, nslots, stream()), "stats_slots")
         br = [HF.BNBranch(gam[j], bet[j], rm[j], rv[j], nbt[j]) for j in range(2)]
         mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
@@ -93,7 +93,7 @@ def test_slots_non_finite_input_reads_as_nan_and_keeps_the_running_buffers(A):
     c = 16
     x = torch.randn(8, c, 4, 4).cuda().contiguous(memory_format=torch.channels_last)
     x[3, 5, 2, 1] = float("inf")
-    slots = torch.zeros(lib.otvae_bn_slots_words(c), device="cuda", dtype=torch.int64)
+    slots = torch.zeros(lib.otvae_bn_slots_words(c, 8), device="cuda", dtype=torch.int64)
     check(lib.otvae_bn_stats_slots(ptr(x), 8 * 16, c, ptr(slots), c, 8, stream()), "stats_slots")
     rm, rv, nbt = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"), torch.tensor(0, device="cuda")
     br = [HF.BNBranch(torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), rm, rv, nbt)]
@@ -104,7 +104,7 @@ def test_slots_non_finite_input_reads_as_nan_and_keeps_the_running_buffers(A):
     assert int(slots[-2]) > 0
     assert torch.isnan(mean).all() and torch.isnan(sc[0]).all(), "an unrepresentable sum poisons the tensor's statistics"
     assert torch.equal(rm, torch.zeros_like(rm)) and torch.equal(rv, torch.ones_like(rv)), "NaN statistics never enter the running buffers"
-    with pytest.raises(ValueError, match="1, 2, 4, 8 or 16"):
+    with pytest.raises(ValueError, match="power of two"):
         check(lib.otvae_bn_stats_slots(ptr(x), 8 * 16, c, ptr(slots), c, 3, stream()), "stats_slots")
 
 
@@ -134,7 +134,7 @@ def test_backward_pair_through_slots_vs_finalize_and_apply_launches(A, case, tra
     for b in range(nb):
         s1 = gv[b].double().sum(dim=(0, 2, 3))
         s2 = (gv[b].double() * xhat).sum(dim=(0, 2, 3))
-        sl = torch.zeros(lib.otvae_bn_slots_words(c), device="cuda", dtype=torch.int64)
+        sl = torch.zeros(lib.otvae_bn_slots_words(c, 4), device="cuda", dtype=torch.int64)
         # one "block" per slot carrying a share of the total: limbs hi (2^-10 units) / lo (2^-53 units), as bn_slot_add splits them
         S = 4
         for k in range(S):
@@ -143,7 +143,7 @@ def test_backward_pair_through_slots_vs_finalize_and_apply_launches(A, case, tra
             for stat, val in ((0, share), (1, share2)):
                 hi = torch.floor(val * 1024.0)
                 lo = torch.floor((val - hi / 1024.0) * 9007199254740992.0)
-                view = sl[: 16 * 2 * c * 2].view(16, 2, c, 2)
+                view = sl[: S * 2 * c * 2].view(S, 2, c, 2)
                 view[k, stat, :, 0] = hi.long()
                 view[k, stat, :, 1] = lo.long()
         slots.append(HF.Slots(sl, c, S))
