@@ -378,31 +378,74 @@ struct BnBwdFold {
 
 template <int NB, bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(BnBwdFold f, const float* __restrict__ g0, const float* __restrict__ g1,
-                                                                 const float* __restrict__ x, int64_t total, int C,
+                                                                 const float* __restrict__ x, int64_t total, int C, int Cpad,
                                                                  float* __restrict__ dx) {
-    __shared__ __align__(16) float tab[2 + NB][BN_TAB];   // A, B, k_0 (, k_1)
+    // dynamic LDS, sized by the layer (this kernel runs beside the weight-gradient stream's LDS-hungry kernels: a fixed table for 1024
+    // channels per block kept those off the CUs and cost the step more than the fused launch saved):
+    //   acc [NB][4 C] 64-bit limb totals (narrow layers with many slots only) | tab [2 + NB][Cpad] floats: A, B, k_0 (, k_1)
+    extern __shared__ __align__(16) unsigned char bw_smem[];
+    bool spread[NB];
+    int wn[NB], wtot = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {   // block-uniform
+        spread[b] = C <= BN_FOLD_WIDE && f.nslots[b] > 4;
+        wn[b] = spread[b] ? 2 * C * f.nslots[b] : 0;
+        wtot += wn[b];
+    }
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(bw_smem);
+    float* tab = reinterpret_cast<float*>(bw_smem + (wtot ? (size_t)NB * 4 * C * sizeof(unsigned long long) : 0));
     const bool first = blockIdx.x == 0;
+    if (wtot) {
+        // the slot reads of BOTH branches spread over the block: 16-byte loads, a handful per thread, all in flight together; summed with
+        // LDS integer atomics (associative: same bits in any order)
+        for (int i = threadIdx.x; i < NB * 4 * C; i += 256) acc[i] = 0ULL;
+        __syncthreads();
+        for (int w0 = threadIdx.x; w0 < wtot; w0 += 4 * 256) {
+            bn_ll2 v[4];
+            int at[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int w = w0 + u * 256;
+                at[u] = -1;
+                if (w < wtot) {
+                    const int b = (NB == 2 && w >= wn[0]) ? 1 : 0;
+                    if (b) w -= wn[0];
+                    const int c = w % C, r = w / C;   // r = s * 2 + stat
+                    v[u] = *reinterpret_cast<const bn_ll2*>(f.slots[b] + (((size_t)r * f.ld + c) << 1));
+                    at[u] = b * 4 * C + ((r & 1) * C + c) * 2;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (at[u] >= 0) {
+                    atomicAdd(&acc[at[u]], (unsigned long long)v[u].x);
+                    atomicAdd(&acc[at[u] + 1], (unsigned long long)v[u].y);
+                }
+        }
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < C; c += 256) {
         const double is = (double)f.invstd[c], mu = (double)f.mean[c];
         double A = 0.0, B = 0.0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             double s1, s2;
-            bn_slot_totals(f.slots[b], f.ld, f.nslots[b], c, s1, s2);
+            if (spread[b]) bn_block_totals_read(acc + b * 4 * C, f.slots[b], f.ld, f.nslots[b], C, c, s1, s2);
+            else bn_slot_totals(f.slots[b], f.ld, f.nslots[b], c, s1, s2);
             const double k = (double)f.gamma[b][c] * is;
             if (first) {
                 if (f.dbeta[b]) f.dbeta[b][c] = (float)s1;
                 if (f.dgamma[b]) f.dgamma[b][c] = (float)s2;
             }
-            tab[2 + b][c] = (float)k;
+            tab[(2 + b) * Cpad + c] = (float)k;
             A += k * s2;
             B += k * s1;
         }
         A = A * is / (double)f.count;
         B = B / (double)f.count - A * mu;
         if (!f.training) A = B = 0.0;   // eval mode: BatchNorm is a fixed affine, no batch-statistics terms
-        tab[0][c] = (float)A;
-        tab[1][c] = (float)B;
+        tab[c] = (float)A;
+        tab[Cpad + c] = (float)B;
     }
     __syncthreads();
     if (!dx) return;
@@ -411,9 +454,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(BnBwdFold f, co
         for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
             const int c = (int)((i << 2) % C);
             const float4 xv = reinterpret_cast<const float4*>(x)[i];
-            const float4 a = *reinterpret_cast<const float4*>(&tab[0][c]);
-            const float4 b = *reinterpret_cast<const float4*>(&tab[1][c]);
-            const float4 k0 = *reinterpret_cast<const float4*>(&tab[2][c]);
+            const float4 a = *reinterpret_cast<const float4*>(&tab[c]);
+            const float4 b = *reinterpret_cast<const float4*>(&tab[Cpad + c]);
+            const float4 k0 = *reinterpret_cast<const float4*>(&tab[2 * Cpad + c]);
             const float4 gv0 = reinterpret_cast<const float4*>(g0)[i];
             float4 r;
             r.x = fmaf(k0.x, gv0.x, fmaf(-a.x, xv.x, -b.x));
@@ -421,7 +464,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(BnBwdFold f, co
             r.z = fmaf(k0.z, gv0.z, fmaf(-a.z, xv.z, -b.z));
             r.w = fmaf(k0.w, gv0.w, fmaf(-a.w, xv.w, -b.w));
             if constexpr (NB == 2) {
-                const float4 k1 = *reinterpret_cast<const float4*>(&tab[3][c]);
+                const float4 k1 = *reinterpret_cast<const float4*>(&tab[3 * Cpad + c]);
                 const float4 gv1 = reinterpret_cast<const float4*>(g1)[i];
                 r.x = fmaf(k1.x, gv1.x, r.x);
                 r.y = fmaf(k1.y, gv1.y, r.y);
@@ -433,8 +476,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(BnBwdFold f, co
     } else {
         for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
             const int c = (int)(i % C);
-            float r = fmaf(tab[2][c], g0[i], fmaf(-tab[0][c], x[i], -tab[1][c]));
-            if constexpr (NB == 2) r = fmaf(tab[3][c], g1[i], r);
+            float r = fmaf(tab[2 * Cpad + c], g0[i], fmaf(-tab[c], x[i], -tab[Cpad + c]));
+            if constexpr (NB == 2) r = fmaf(tab[3 * Cpad + c], g1[i], r);
             dx[i] = r;
         }
     }
@@ -464,12 +507,16 @@ extern "C" int otvae_bn_bwd_apply_slots(int nb, const float* const* gv, const fl
     hipStream_t st = (hipStream_t)stream;
     const float* g0 = dx ? gv[0] : nullptr;
     const float* g1 = (dx && nb == 2) ? gv[1] : nullptr;
+    const int Cpad = (C + 3) & ~3;
+    bool any_spread = false;
+    for (int b = 0; b < nb; ++b) any_spread = any_spread || (C <= BN_FOLD_WIDE && nslots[b] > 4);
+    const size_t lds = (any_spread ? (size_t)nb * 4 * C * sizeof(unsigned long long) : 0) + (size_t)(2 + nb) * Cpad * sizeof(float);
     if (nb == 1) {
-        if (vec) bn_bwd_apply_slots_kernel<1, true><<<grid, 256, 0, st>>>(f, g0, g1, x, total, C, dx);
-        else bn_bwd_apply_slots_kernel<1, false><<<grid, 256, 0, st>>>(f, g0, g1, x, total, C, dx);
+        if (vec) bn_bwd_apply_slots_kernel<1, true><<<grid, 256, lds, st>>>(f, g0, g1, x, total, C, Cpad, dx);
+        else bn_bwd_apply_slots_kernel<1, false><<<grid, 256, lds, st>>>(f, g0, g1, x, total, C, Cpad, dx);
     } else {
-        if (vec) bn_bwd_apply_slots_kernel<2, true><<<grid, 256, 0, st>>>(f, g0, g1, x, total, C, dx);
-        else bn_bwd_apply_slots_kernel<2, false><<<grid, 256, 0, st>>>(f, g0, g1, x, total, C, dx);
+        if (vec) bn_bwd_apply_slots_kernel<2, true><<<grid, 256, lds, st>>>(f, g0, g1, x, total, C, Cpad, dx);
+        else bn_bwd_apply_slots_kernel<2, false><<<grid, 256, lds, st>>>(f, g0, g1, x, total, C, Cpad, dx);
     }
     OTVAE_CHECK_LAUNCH("otvae_bn_bwd_apply_slots");
     return OTVAE_OK;

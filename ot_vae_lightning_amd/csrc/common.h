@@ -162,41 +162,56 @@ struct BnFold {
 // coalesced 16-byte loads, at most a handful per thread, all in flight together) and summed with LDS integer atomics (associative:
 // same bits in any order); wider layers have few producer blocks, hence small S, and one thread per channel reads its slots itself.
 #define BN_FOLD_WIDE 64
+
+// limb totals of both statistics of C <= BN_FOLD_WIDE channels over the S slots in use -> acc[(stat * C + c) * 2 + limb] (LDS, 4 C
+// words), the reads spread over the block's threads.  Block-uniform call; ends with a barrier.
+__device__ __forceinline__ void bn_slot_block_totals(const long long* __restrict__ slots, int ld, int S, int C,
+                                                     unsigned long long* __restrict__ acc) {
+    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) acc[i] = 0ULL;
+    __syncthreads();
+    const int W = 2 * C * S;
+    for (int w0 = threadIdx.x; w0 < W; w0 += 4 * blockDim.x) {
+        bn_ll2 v[4];
+        int at[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int w = w0 + u * blockDim.x;
+            at[u] = -1;
+            if (w < W) {
+                const int c = w % C, r = w / C;   // r = s * 2 + stat
+                v[u] = *reinterpret_cast<const bn_ll2*>(slots + (((size_t)r * ld + c) << 1));
+                at[u] = ((r & 1) * C + c) * 2;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (at[u] >= 0) {
+                atomicAdd(&acc[at[u]], (unsigned long long)v[u].x);
+                atomicAdd(&acc[at[u] + 1], (unsigned long long)v[u].y);
+            }
+    }
+    __syncthreads();
+}
+
+// both statistics of channel c from what bn_slot_block_totals left (NaN when the tensor's poison word is set)
+__device__ __forceinline__ void bn_block_totals_read(const unsigned long long* __restrict__ acc, const long long* __restrict__ slots, int ld,
+                                                     int S, int C, int c, double& t0, double& t1) {
+    if (slots[(size_t)S * 2 * ld * 2] != 0) {
+        t0 = t1 = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    t0 = bn_limbs_to_double((long long)acc[c * 2], (long long)acc[c * 2 + 1]);
+    t1 = bn_limbs_to_double((long long)acc[(C + c) * 2], (long long)acc[(C + c) * 2 + 1]);
+}
+
 __device__ __forceinline__ void bn_fold_prologue(const BnFold& f, int C, float* s_sc, float* s_sh, bool first_block) {
     __shared__ unsigned long long bn_acc[2 * BN_FOLD_WIDE * 2];   // [stat][c][limb]
     const bool spread = C <= BN_FOLD_WIDE && f.nslots > 4;
-    if (spread) {
-        for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) bn_acc[i] = 0ULL;
-        __syncthreads();
-        const int W = 2 * C * f.nslots;
-        for (int w0 = threadIdx.x; w0 < W; w0 += 4 * blockDim.x) {
-            bn_ll2 v[4];
-            int at[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int w = w0 + u * blockDim.x;
-                at[u] = -1;
-                if (w < W) {
-                    const int c = w % C, r = w / C;   // r = s * 2 + stat
-                    v[u] = *reinterpret_cast<const bn_ll2*>(f.slots + (((size_t)r * f.ld + c) << 1));
-                    at[u] = ((r & 1) * C + c) * 2;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (at[u] >= 0) {
-                    atomicAdd(&bn_acc[at[u]], (unsigned long long)v[u].x);
-                    atomicAdd(&bn_acc[at[u] + 1], (unsigned long long)v[u].y);
-                }
-        }
-        __syncthreads();
-    }
+    if (spread) bn_slot_block_totals(f.slots, f.ld, f.nslots, C, bn_acc);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         double s, q;
         if (spread) {
-            const bool bad = f.slots[(size_t)f.nslots * 2 * f.ld * 2] != 0;
-            s = bad ? __longlong_as_double(0x7ff8000000000000LL) : bn_limbs_to_double((long long)bn_acc[c * 2], (long long)bn_acc[c * 2 + 1]);
-            q = bad ? s : bn_limbs_to_double((long long)bn_acc[(C + c) * 2], (long long)bn_acc[(C + c) * 2 + 1]);
+            bn_block_totals_read(bn_acc, f.slots, f.ld, f.nslots, C, c, s, q);
         } else {
             bn_slot_totals(f.slots, f.ld, f.nslots, c, s, q);
         }
