@@ -68,6 +68,33 @@ def replay_stats(src, tag, steps=20):
     print("wrote", out, "launches/step", len(seg) // steps, "busy ms/step %.3f wall %.3f" % (tot / 1e6 / steps, wall / 1e6 / steps))
 
 
+def timeline(src, tag):
+    """ONE graph replay (the 10th of the fastest 20-step window) as a timeline: start / end of every launch in us from the step's first
+    kernel, the queue it ran on, the idle gap on that queue in front of it: where the chain waits, what ends the step."""
+    f = max(glob.glob(os.path.join(src, "*", "*_kernel_trace.csv")), key=os.path.getmtime)
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
+    t_end = [int(rows[i]["End_Timestamp"]) for i in ends]
+    steps = 20
+    best = min(range(len(ends) - steps), key=lambda a: t_end[a + steps] - t_end[a])
+    seg = rows[ends[best + 9] + 1: ends[best + 10] + 1]
+    t0 = int(seg[0]["Start_Timestamp"])
+    qkey = "Queue_Id" if "Queue_Id" in seg[0] else ("Stream_Id" if "Stream_Id" in seg[0] else None)
+    last_end = {}
+    out = os.path.join(OUT, f"{tag}_step_timeline.txt")
+    with open(out, "w") as w:
+        w.write("# one graph replay; us from the first kernel's start.  gap = idle time on the same queue in front of the launch\n")
+        w.write("# %5s %9s %9s %8s %7s  kernel\n" % ("queue", "start", "end", "dur", "gap"))
+        for r in seg:
+            q = r[qkey] if qkey else "?"
+            a, b = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
+            gap = a - last_end.get(q, a)
+            last_end[q] = b
+            w.write("  %5s %9.2f %9.2f %8.2f %7.2f  %s\n" % (q, a, b, b - a, gap, r["Kernel_Name"].split("(")[0][:70]))
+    print("wrote", out, len(seg), "launches")
+
+
 def csrc_digest():
     """sha256 over the kernel sources (csrc/*.hip, *.h, *.cpp, sorted by name): the same function as bench.csrc_digest"""
     import hashlib
@@ -183,5 +210,7 @@ if __name__ == "__main__":
         pmc(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "--replay":
         replay_stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "--timeline":
+        timeline(sys.argv[2], sys.argv[3])
     else:
         kernel_stats(sys.argv[1], sys.argv[2])
