@@ -33,6 +33,18 @@ from .dp import FlatGradReducer
 from .lifetime import GraphSet, capture_guard
 from .segments import SEGMENT_CALLS, SegmentedStep
 
+DP_OVERLAP_MIN_BYTES = int(os.environ.get("OTVAE_DP_OVERLAP_MIN_BYTES", str(32 << 20)))
+
+
+def default_dp_overlap(world: int, grad_bytes: int, env: Optional[str] = None) -> bool:
+    """Whether a data-parallel step cuts its backward pass to overlap the decoder's all-reduce (see HipTrainer.__init__): never alone,
+    as the environment says when it says anything, else only for gradient buffers of at least DP_OVERLAP_MIN_BYTES."""
+    if world <= 1:
+        return False
+    if env is not None:
+        return env != "0"
+    return grad_bytes >= DP_OVERLAP_MIN_BYTES
+
 # OTVAE_STATS_SIDE=0 (A/B switch): the loss value and the latent-statistics update of a captured step stay on the launch stream
 STATS_ON_SIDE = os.environ.get("OTVAE_STATS_SIDE", "1") != "0"
 
@@ -155,10 +167,14 @@ class HipTrainer:
         # Data-parallel overlap: backward runs in two phases cut at the encoder's output (loss, decoder and prior side
         # first); the decoder's gradient range is all-reduced on the reducer's stream WHILE the encoder's backward runs,
         # the rest afterwards.
-        # Default: on for world > 1 when the model exposes encoder/decoder and their gradients are contiguous ranges of
-        # the flat buffer; OTVAE_DP_OVERLAP=0 (or dp_overlap=False) keeps the single all-reduce after backward.
+        # The cut costs the step 0.18 ms on its own (three graphs and three collective calls instead of two and one: 2.954 against
+        # 2.775 ms with a 1-rank RCCL group, profiles/r03_dp_host_enqueue.txt) and hides about half of the all-reduce, so it pays only
+        # when the all-reduce is longer than ~0.36 ms -- tens of MB of gradients on xGMI.  Default since round 4: on for world > 1 when
+        # the flat gradient buffer holds at least DP_OVERLAP_MIN_BYTES (the MNIST / CIFAR networks of the BASELINE configs: 6.9 / 27 MB,
+        # below it: ONE all-reduce between the forward-backward graph and the optimizer graph); OTVAE_DP_OVERLAP=1 / 0 or
+        # dp_overlap=True / False decide it outright.  (Which side of the threshold an 8-GPU node really is on is unmeasured here.)
         if dp_overlap is None:
-            dp_overlap = self.world > 1 and os.environ.get("OTVAE_DP_OVERLAP", "1") != "0"
+            dp_overlap = default_dp_overlap(self.world, self.gflat.numel() * self.gflat.element_size(), os.environ.get("OTVAE_DP_OVERLAP"))
         self._dec_range = self._decoder_range() if dp_overlap else None
         self.dp_overlap = self._dec_range is not None
         # static I/O

@@ -103,3 +103,14 @@ def test_a_graphed_model_deep_copies_onto_its_own_copy():
     del model
     gc.collect()
     assert ref() is None and graphed() is None     # nothing but the model kept its GraphedNelbo alive
+
+
+def test_data_parallel_overlap_default_follows_the_gradient_size():
+    """The backward cut that overlaps the decoder's all-reduce costs the step 0.18 ms by itself (profiles/r04_dp_host_enqueue.txt): the
+    default takes it only for gradient buffers of tens of MB; the environment switch decides outright; one rank never cuts."""
+    from ot_vae_lightning_amd.engine import trainer as T
+    mnist, big = 1717319 * 4, 64 << 20
+    assert T.DP_OVERLAP_MIN_BYTES == 32 << 20
+    assert not T.default_dp_overlap(1, big) and not T.default_dp_overlap(1, big, "1")
+    assert not T.default_dp_overlap(8, mnist) and T.default_dp_overlap(8, big)
+    assert T.default_dp_overlap(8, mnist, "1") and not T.default_dp_overlap(8, big, "0")
