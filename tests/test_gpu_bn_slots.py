@@ -246,3 +246,68 @@ def test_training_steps_through_slots_agree_with_the_finalize_launch_route(A, mo
         for u, v, name in zip(got, b, ("params", "losses", "buffers")):
             err = float((u.double() - v.double()).norm() / v.double().norm())
             assert err < 2e-5, (name, err)
+
+
+def test_an_arena_that_runs_out_mid_pass_falls_back_to_partials_and_changes_nothing_else(A, monkeypatch):
+    """The arena is a fixed 8 MiB; a pass that wants more takes the partial + finalize-launch route for the tensors that no longer fit
+    (also between the two branches of one layer).  Same numbers as a pass that fits, to the rounding the two routes differ by."""
+    from ot_vae_lightning_amd import functional as HF
+    B, kw = 64, CONFIGS["mnist"]
+    x = [mnist_like(B, 160 + i).cuda() for i in range(2)]
+    eps = [normal((B, kw["latent"], 1, 1), 170 + i).cuda() for i in range(2)]
+
+    def run(words, mode, graph):
+        monkeypatch.setattr(HF, "BN_SLOTS_MODE", mode)
+        monkeypatch.setattr(HF.SlotArena, "WORDS", words)
+        HF.SlotArena._state.clear()   # a fresh arena of the patched size
+        tr = A.HipTrainer(_model(A, 31, **kw), batch_shape=(B, 1, 32, 32), use_graph=graph, data_parallel=False)
+        losses = [tr.step(x[i], eps[i]).clone() for i in range(2)]
+        torch.cuda.synchronize()
+        st = HF.SlotArena._state.get(tr.device)
+        used = st[3] if st is not None else 0
+        out = tr.pflat.clone(), torch.stack(losses)
+        tr.close()
+        return out, used
+
+    try:
+        full, used_full = run(1 << 20, 2, True)
+        for words in (used_full // 2, used_full // 7, 2048):
+            for graph in (False, True):
+                small, used = run(words, 2, graph)
+                assert 0 < used <= words < used_full, "the arena did run out"
+                for u, v, name in zip(small, full, ("params", "losses")):
+                    err = float((u.double() - v.double()).norm() / v.double().norm())
+                    assert err < 2e-5, (words, graph, name, err)
+    finally:
+        HF.SlotArena._state.clear()
+
+
+def test_two_engines_share_the_arena_without_seeing_each_other(A):
+    """One arena per device, zeroed at the start of every step: two engines (one captured, one issued eagerly, different networks)
+    stepping in turn give the bits each gives alone."""
+    from ot_vae_lightning_amd import functional as HF
+    B = 32
+    xa = [mnist_like(B, 180 + i).cuda() for i in range(3)]
+    ea = [normal((B, 128, 1, 1), 185 + i).cuda() for i in range(3)]
+    xb = [normal((B, 3, 32, 32), 190 + i).cuda() for i in range(3)]
+    eb = [normal((B, 256, 1, 1), 195 + i).cuda() for i in range(3)]
+
+    def make():
+        ta = A.HipTrainer(_model(A, 41, **CONFIGS["mnist"]), batch_shape=(B, 1, 32, 32), use_graph=True, data_parallel=False)
+        tb = A.HipTrainer(_model(A, 42, **CONFIGS["cifar"]), batch_shape=(B, 3, 32, 32), use_graph=False, data_parallel=False)
+        return ta, tb
+
+    ta, tb = make()
+    alone_a = [ta.step(xa[i], ea[i]).clone() for i in range(3)]
+    alone_b = [tb.step(xb[i], eb[i]).clone() for i in range(3)]
+    pa, pb = ta.pflat.clone(), tb.pflat.clone()
+    ta.close(); tb.close()
+    ta, tb = make()
+    turn_a, turn_b = [], []
+    for i in range(3):
+        turn_b.append(tb.step(xb[i], eb[i]).clone())
+        turn_a.append(ta.step(xa[i], ea[i]).clone())
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(alone_a, turn_a)) and torch.equal(pa, ta.pflat)
+    assert all(torch.equal(u, v) for u, v in zip(alone_b, turn_b)) and torch.equal(pb, tb.pflat)
+    ta.close(); tb.close()
